@@ -1,0 +1,90 @@
+"""ctypes binding of the hugs C ABI (include/hugs.h).  Fails loudly if the HIP library is missing."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libhugs_hip.so')
+
+# i = int, f = float, p = device/host pointer, q = long long, s = stream
+_PROTOS = {
+    'hugs_level_sample_fwd': 'ippiifffffppiiippppppps',
+    'hugs_test_explog': 'pipps',
+    'hugs_test_arith': 'ppips',
+    'hugs_cast_ipe_fwd': 'iipppppiiiips',
+    'hugs_dir_enc_fwd': 'iipps',
+    'hugs_gemm_nt': 'iiiii' 'pipipi' 'pp' 'iii' 'pi' 'pp' 'pi' 's',
+    'hugs_gemm_tn': 'iiiiipipippps',
+}
+_CT = {'i': ctypes.c_int, 'f': ctypes.c_float, 'p': ctypes.c_void_p, 'q': ctypes.c_longlong,
+       's': ctypes.c_void_p}
+
+
+class HugsError(RuntimeError):
+  pass
+
+
+class _Lib:
+
+  def __init__(self):
+    if not os.path.exists(LIB_PATH):
+      raise HugsError(
+          f'{LIB_PATH} not found: build it with nerf-hugs_amd/csrc/build.sh (or __graft_entry__.build()). '
+          'There is no CPU fallback.')
+    self.cdll = ctypes.CDLL(LIB_PATH)
+    self.cdll.hugs_last_error.restype = ctypes.c_char_p
+    self.cdll.hugs_gemm_tn_ws_bytes.restype = ctypes.c_longlong
+    for name, sig in _PROTOS.items():
+      fn = getattr(self.cdll, name)
+      fn.argtypes = [_CT[c] for c in sig]
+      fn.restype = ctypes.c_int
+
+  def declare(self, name, sig):
+    _PROTOS[name] = sig
+    fn = getattr(self.cdll, name)
+    fn.argtypes = [_CT[c] for c in sig]
+    fn.restype = ctypes.c_int
+
+  def call(self, name, *args):
+    sig = _PROTOS[name]
+    if len(args) != len(sig) - 1:
+      raise TypeError(f'{name}: expected {len(sig) - 1} args (+stream), got {len(args)}')
+    conv = []
+    for a, c in zip(args, sig):
+      if c == 'p':
+        if a is None:
+          conv.append(None)
+        elif isinstance(a, torch.Tensor):
+          if not a.is_cuda:
+            raise HugsError(f'{name}: tensor argument is not on the GPU (no CPU fallback)')
+          if not a.is_contiguous():
+            raise HugsError(f'{name}: tensor argument must be contiguous')
+          conv.append(a.data_ptr())
+        else:
+          conv.append(int(a))
+      elif c == 'f':
+        conv.append(float(a))
+      else:
+        conv.append(int(a))
+    conv.append(torch.cuda.current_stream().cuda_stream)
+    rc = getattr(self.cdll, name)(*conv)
+    if rc != 0:
+      msg = self.cdll.hugs_last_error().decode()
+      if rc == -2:
+        raise ValueError(msg)       # the reference raises ValueError for these argument errors
+      raise HugsError(f'{name} failed (rc={rc}): {msg}')
+
+
+_LIB = None
+
+
+def lib():
+  global _LIB
+  if _LIB is None:
+    _LIB = _Lib()
+  return _LIB
+
+
+def call(name, *args):
+  return lib().call(name, *args)

@@ -1,0 +1,185 @@
+// Ray sections -> Gaussians -> (optional contraction) -> basis lift -> integrated positional
+// encoding, fused: the [N,S,3,3] covariances and [N,S,21] lifted moments never touch HBM; the
+// only output is the MLP input panel X[N*S, 512] (504 features + 8 zero columns so that rows
+// are 16-byte aligned K-tiles for the MFMA GEMMs), written as whole 1 KiB / 2 KiB rows.
+//
+// Replaces (reference, MipNeRF360/internal): render.py:103-127 cast_rays -> :44-78 / :81-100 ->
+// :21-41 lift_gaussian(diag=False); coord.py:21-27 contract + :39-60 track_linearize (closed-form
+// Jacobian instead of jax.linearize); coord.py:129-133 lift_and_diagonalize; :102-126
+// integrated_pos_enc with math.py:26-38 safe_sin; coord.py:136-147 pos_enc (view directions).
+#include "hugs_common.h"
+
+#define ENC_SAMPLES 32   // samples per workgroup
+#define ENC_NB 21        // basis directions (icosahedron, 2 subdivisions)
+#define ENC_F 504
+#define ENC_KP 512
+
+__device__ __forceinline__ float safe_sinf(float x) {
+  // math.py:26-38: sin(where(|x| < 100pi, x, x mod 100pi)), python-style mod
+  const float t = 314.159265358979323846f;
+  if (!(fabsf(x) < t)) { float r = fmodf(x, t); if (r != 0.0f && (r < 0.0f)) r += t; x = r; }
+  return sinf(x);
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_cast_ipe(int nrays, int S, const float* __restrict__ tdist,
+                                                  const float* __restrict__ origins, const float* __restrict__ dirs,
+                                                  const float* __restrict__ radii, const float* __restrict__ basis,
+                                                  int ray_shape, int warp, int max_deg, void* __restrict__ out) {
+  __shared__ float s_mean[ENC_SAMPLES][3];
+  __shared__ float s_cov[ENC_SAMPLES][6];
+  __shared__ float s_lm[ENC_SAMPLES][ENC_NB + 1];
+  __shared__ float s_lv[ENC_SAMPLES][ENC_NB + 1];
+  __shared__ float s_basis[3 * ENC_NB];
+  const int tid = threadIdx.x;
+  const long long total = (long long)nrays * S;
+  const long long base = (long long)blockIdx.x * ENC_SAMPLES;
+  if (tid < 3 * ENC_NB) s_basis[tid] = basis[tid];
+  if (tid < ENC_SAMPLES && base + tid < total) {
+    const long long m = base + tid;
+    const int ray = (int)(m / S), s = (int)(m % S);
+    const float t0 = tdist[(size_t)ray * (S + 1) + s], t1 = tdist[(size_t)ray * (S + 1) + s + 1];
+    const float dx = dirs[ray * 3], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
+    const float rad = radii[ray];
+    float t_mean, t_var, r_var;
+    if (ray_shape == 0) {  // cone, render.py:62-70
+      const float mu = (t0 + t1) / 2, hw = (t1 - t0) / 2;
+      const float den = fmaxf(HUGS_EPS, 3 * mu * mu + hw * hw);
+      const float hw2 = hw * hw, hw4 = hw2 * hw2;
+      t_mean = mu + (2 * mu * hw2) / den;
+      t_var = hw2 / 3 - (4.0f / 15.0f) * hw4 * (12 * mu * mu - hw2) / (den * den);
+      r_var = (mu * mu) / 4 + (5.0f / 12.0f) * hw2 - (4.0f / 15.0f) * hw4 / den;
+      r_var *= rad * rad;
+    } else {               // cylinder, render.py:96-99
+      t_mean = (t0 + t1) / 2;
+      r_var = rad * rad / 4;
+      t_var = (t1 - t0) * (t1 - t0) / 12;
+    }
+    float mx = dx * t_mean + origins[ray * 3], my = dy * t_mean + origins[ray * 3 + 1],
+          mz = dz * t_mean + origins[ray * 3 + 2];
+    const float dms = fmaxf(1e-10f, dx * dx + dy * dy + dz * dz);
+    const float ex = dx / dms, ey = dy / dms, ez = dz / dms;
+    // cov = t_var d d^T + r_var (I - d (d/|d|^2)^T); symmetric -> 6 entries xx xy xz yy yz zz
+    float c[6];
+    c[0] = t_var * dx * dx + r_var * (1 - dx * ex);
+    c[1] = t_var * dx * dy + r_var * (0 - dx * ey);
+    c[2] = t_var * dx * dz + r_var * (0 - dx * ez);
+    c[3] = t_var * dy * dy + r_var * (1 - dy * ey);
+    c[4] = t_var * dy * dz + r_var * (0 - dy * ez);
+    c[5] = t_var * dz * dz + r_var * (1 - dz * ez);
+    if (warp) {  // coord.py:21-27,39-60 with the closed-form Jacobian of contract
+      const float n2 = fmaxf(HUGS_EPS, mx * mx + my * my + mz * mz);
+      if (n2 > 1.0f) {
+        const float n = sqrtf(n2);
+        const float sc = (2 * n - 1) / n2;
+        const float ds2 = 2 * ((1 / n) / n2 - (2 * n - 1) / (n2 * n2));
+        const float x[3] = {mx, my, mz};
+        float J[3][3], C[3][3] = {{c[0], c[1], c[2]}, {c[1], c[3], c[4]}, {c[2], c[4], c[5]}}, T[3][3];
+        for (int a = 0; a < 3; ++a)
+          for (int b = 0; b < 3; ++b) J[a][b] = (a == b ? sc : 0.0f) + ds2 * x[a] * x[b];
+        for (int a = 0; a < 3; ++a)
+          for (int b = 0; b < 3; ++b) T[a][b] = J[a][0] * C[0][b] + J[a][1] * C[1][b] + J[a][2] * C[2][b];
+        float R[3][3];
+        for (int a = 0; a < 3; ++a)
+          for (int b = 0; b < 3; ++b) R[a][b] = T[a][0] * J[b][0] + T[a][1] * J[b][1] + T[a][2] * J[b][2];
+        c[0] = R[0][0]; c[1] = R[0][1]; c[2] = R[0][2]; c[3] = R[1][1]; c[4] = R[1][2]; c[5] = R[2][2];
+        mx *= sc; my *= sc; mz *= sc;
+      }
+    }
+    s_mean[tid][0] = mx; s_mean[tid][1] = my; s_mean[tid][2] = mz;
+    for (int k = 0; k < 6; ++k) s_cov[tid][k] = c[k];
+  }
+  __syncthreads();
+  for (int e = tid; e < ENC_SAMPLES * ENC_NB; e += 256) {  // coord.py:129-133
+    const int s = e / ENC_NB, j = e % ENC_NB;
+    const float b0 = s_basis[j], b1 = s_basis[ENC_NB + j], b2 = s_basis[2 * ENC_NB + j];
+    const float* c = s_cov[s];
+    s_lm[s][j] = s_mean[s][0] * b0 + s_mean[s][1] * b1 + s_mean[s][2] * b2;
+    const float r0 = c[0] * b0 + c[1] * b1 + c[2] * b2;
+    const float r1 = c[1] * b0 + c[3] * b1 + c[4] * b2;
+    const float r2 = c[2] * b0 + c[4] * b1 + c[5] * b2;
+    s_lv[s][j] = b0 * r0 + b1 * r1 + b2 * r2;
+  }
+  __syncthreads();
+  // one wave writes one whole row: lane owns 8 consecutive features
+  const int lane = tid & 63, wv = tid >> 6;
+  const int nfeat_half = ENC_NB * max_deg;  // 252
+  for (int s = wv; s < ENC_SAMPLES; s += 4) {
+    const long long m = base + s;
+    if (m >= total) break;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int f = lane * 8 + q;
+      float val = 0.0f;
+      if (f < 2 * nfeat_half) {
+        const int half = f >= nfeat_half;
+        const int r = f - half * nfeat_half;
+        const int k = r / ENC_NB, j = r - k * ENC_NB;
+        const float sc = (float)(1 << k);
+        float x = s_lm[s][j] * sc;
+        if (half) x = x + 1.57079632679489661923f;   // sin(x + pi/2), as the reference does
+        const float var = s_lv[s][j] * (sc * sc);
+        val = expf(-0.5f * var) * safe_sinf(x);
+      }
+      v[q] = val;
+    }
+    if (BF16) {
+      uint4 pk;
+      pk.x = f_to_bf16(v[0]) | ((uint32_t)f_to_bf16(v[1]) << 16);
+      pk.y = f_to_bf16(v[2]) | ((uint32_t)f_to_bf16(v[3]) << 16);
+      pk.z = f_to_bf16(v[4]) | ((uint32_t)f_to_bf16(v[5]) << 16);
+      pk.w = f_to_bf16(v[6]) | ((uint32_t)f_to_bf16(v[7]) << 16);
+      ((uint4*)out)[(size_t)m * (ENC_KP / 8) + lane] = pk;
+    } else {
+      float4* o = (float4*)out + (size_t)m * (ENC_KP / 4) + lane * 2;
+      o[0] = make_float4(v[0], v[1], v[2], v[3]);
+      o[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+  }
+}
+
+// coord.py:136-147 pos_enc(viewdirs, 0, deg, append_identity=True) -> [N, 3 + 6*deg]
+__global__ void k_dir_enc(int nrays, int deg, const float* __restrict__ viewdirs, float* __restrict__ out) {
+  const int W = 3 + 6 * deg;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrays * W) return;
+  const int ray = i / W, f = i % W;
+  float val;
+  if (f < 3) {
+    val = viewdirs[ray * 3 + f];
+  } else {
+    const int r = f - 3, half = r >= 3 * deg, q = r - half * 3 * deg;
+    const int k = q / 3, c = q % 3;
+    float x = viewdirs[ray * 3 + c] * (float)(1 << k);
+    if (half) x = x + 1.57079632679489661923f;
+    val = sinf(x);
+  }
+  out[i] = val;
+}
+
+extern "C" int hugs_cast_ipe_fwd(int nrays, int num_samples, const float* tdist, const float* origins,
+                                 const float* directions, const float* radii, const float* basis, int ray_shape,
+                                 int warp_contract, int max_deg, int out_bf16, void* out, void* stream) {
+  HUGS_REQUIRE(ray_shape == 0 || ray_shape == 1, -2, "ray_shape must be 'cone' or 'cylinder'");
+  HUGS_REQUIRE(max_deg >= 1 && 2 * ENC_NB * max_deg <= ENC_F, -3, "hugs_cast_ipe_fwd: max_deg %d unsupported", max_deg);
+  const long long total = (long long)nrays * num_samples;
+  if (total <= 0) return 0;
+  const int grid = (int)((total + ENC_SAMPLES - 1) / ENC_SAMPLES);
+  if (out_bf16)
+    hipLaunchKernelGGL(k_cast_ipe<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, nrays, num_samples, tdist,
+                       origins, directions, radii, basis, ray_shape, warp_contract, max_deg, out);
+  else
+    hipLaunchKernelGGL(k_cast_ipe<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, nrays, num_samples, tdist,
+                       origins, directions, radii, basis, ray_shape, warp_contract, max_deg, out);
+  HUGS_CHECK_LAUNCH("hugs_cast_ipe_fwd");
+  return 0;
+}
+
+extern "C" int hugs_dir_enc_fwd(int nrays, int deg, const float* viewdirs, float* out, void* stream) {
+  const int n = nrays * (3 + 6 * deg);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_dir_enc, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, nrays, deg, viewdirs, out);
+  HUGS_CHECK_LAUNCH("hugs_dir_enc_fwd");
+  return 0;
+}

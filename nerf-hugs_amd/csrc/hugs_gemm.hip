@@ -1,0 +1,487 @@
+// MFMA GEMM family for the PropMLP / NerfMLP trunks (reference: MipNeRF360/internal/models.py:451-456
+// trunk Dense+relu+skip-concat, :475 bottleneck, :508-512 view layer; their backward is what
+// jax.value_and_grad derives in train_utils.py:454).
+//
+//   NT : C[M,N]  = epi( [A1|A2][M,K1+K2] * Bt[N,K1+K2]^T )   forward layers and dX (both operands K-contiguous)
+//   TN : D[Kc,N] = sum_m X[m,Kc]^T * G[m,N]                  weight gradients, split over M into fp32 slabs
+//
+// bf16 path: 128x128x64 tiles, 4 waves (2x2), v_mfma_f32_16x16x32_bf16, operands staged with
+// global_load_lds (16 B/lane DMA, no VGPR round trip) into XOR-swizzled LDS (swizzle applied on the
+// per-lane SOURCE address, LDS image stays lane-linear), double buffered.  The MFMA operands are swapped
+// (weights as A, activations as B) so each lane ends up with 4 consecutive output columns of one row:
+// row-major stores without a cross-lane transpose.  TN reads both operands with ds_read_b64_tr_b16
+// (hardware transpose) from row-major tiles.  Workgroup ids are remapped so each XCD owns a contiguous
+// band of row tiles (activations stream once through that XCD's L2, weights stay L2 resident).
+// fp32 path (parity mode): same tiling on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
+#include "hugs_common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+struct GemmEpi {
+  const float* bias;      // [N] added per column, or null
+  const float* row_bias;  // [M/row_div, ld_rb] added per row group (per-ray bias), or null
+  int row_div, ld_rb;
+  int relu;               // max(0, .)
+  const void* mask;       // activation tensor [M, ld_mask] (same dtype as out): multiply by (mask > 0)
+  int ld_mask;
+  const float* r1_row;    // rank-1 term r1_row[m] * r1_col[n], or null
+  const float* r1_col;
+  void* out;              // [M, ldc]
+  int ldc;
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  // contiguous band of tiles per XCD; bijective for any nwg (cdna guide T1)
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <bool BF16OUT>
+__device__ __forceinline__ void epi_store4(const GemmEpi& E, int m, int n, f32x4_t v) {
+  float x[4] = {v[0], v[1], v[2], v[3]};
+  if (E.bias) { const float4 b = *(const float4*)(E.bias + n); x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w; }
+  if (E.row_bias) {
+    const float4 b = *(const float4*)(E.row_bias + (size_t)(m / E.row_div) * E.ld_rb + n);
+    x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w;
+  }
+  if (E.r1_row) {
+    const float r = E.r1_row[m];
+    const float4 c = *(const float4*)(E.r1_col + n);
+    x[0] += r * c.x; x[1] += r * c.y; x[2] += r * c.z; x[3] += r * c.w;
+  }
+  if (E.relu) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
+  if (BF16OUT) {
+    if (E.mask) {
+      const uint2 mk = *(const uint2*)((const uint16_t*)E.mask + (size_t)m * E.ld_mask + n);
+      // bf16 > 0  <=>  sign clear and not zero
+      if (!((mk.x & 0x7fffu) && !(mk.x & 0x8000u))) x[0] = 0.f;
+      if (!((mk.x >> 16 & 0x7fffu) && !(mk.x >> 31))) x[1] = 0.f;
+      if (!((mk.y & 0x7fffu) && !(mk.y & 0x8000u))) x[2] = 0.f;
+      if (!((mk.y >> 16 & 0x7fffu) && !(mk.y >> 31))) x[3] = 0.f;
+    }
+    uint2 pk;
+    pk.x = f_to_bf16(x[0]) | ((uint32_t)f_to_bf16(x[1]) << 16);
+    pk.y = f_to_bf16(x[2]) | ((uint32_t)f_to_bf16(x[3]) << 16);
+    *(uint2*)((uint16_t*)E.out + (size_t)m * E.ldc + n) = pk;
+  } else {
+    if (E.mask) {
+      const float4 mk = *(const float4*)((const float*)E.mask + (size_t)m * E.ld_mask + n);
+      if (!(mk.x > 0.f)) x[0] = 0.f;
+      if (!(mk.y > 0.f)) x[1] = 0.f;
+      if (!(mk.z > 0.f)) x[2] = 0.f;
+      if (!(mk.w > 0.f)) x[3] = 0.f;
+    }
+    *(float4*)((float*)E.out + (size_t)m * E.ldc + n) = make_float4(x[0], x[1], x[2], x[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 NT
+// ------------------------------------------------------------------------------------------------
+#define GB_BM 128
+#define GB_BN 128
+#define GB_BK 64
+#define GB_TILE_BYTES (128 * 64 * 2)  // 16 KiB per operand tile
+
+__global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(int M, int N, int K1, int K2, const uint16_t* __restrict__ A1,
+                                                          int lda1, const uint16_t* __restrict__ A2, int lda2,
+                                                          const uint16_t* __restrict__ Bt, int ldb, GemmEpi E) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * GB_TILE_BYTES];  // [buf][A|B]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntn = N / GB_BN, ntm = M / GB_BM;
+  const int t = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (t / ntn) * GB_BM, n0 = (t % ntn) * GB_BN;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int nk = (K1 + K2) / GB_BK;
+
+  // staging: tile = 128 rows x 8 chunks(16 B).  chunk id p = it*256 + tid -> row p/8, physical pos p%8,
+  // which holds logical chunk (pos ^ (row&7)).
+  auto stage = [&](int kt, int buf) {
+    const int kglob = kt * GB_BK;
+    const uint16_t* Abase; int lda, kcol;
+    if (kglob < K1) { Abase = A1; lda = lda1; kcol = kglob; } else { Abase = A2; lda = lda2; kcol = kglob - K1; }
+    unsigned char* la = lds + buf * 2 * GB_TILE_BYTES;
+    unsigned char* lb = la + GB_TILE_BYTES;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int p = it * 256 + tid;
+      const int row = p >> 3, pos = p & 7, c = pos ^ (row & 7);
+      glds16(Abase + (size_t)(m0 + row) * lda + kcol + c * 8, la + (it * 256 + wv * 64) * 16);
+      glds16(Bt + (size_t)(n0 + row) * ldb + kglob + c * 8, lb + (it * 256 + wv * 64) * 16);
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  const int r16 = lane & 15, kb = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    __syncthreads();  // drains the outstanding LDS-DMA of tile kt and fences the previous compute
+    if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+    const unsigned char* la = lds + buf * 2 * GB_TILE_BYTES;
+    const unsigned char* lb = la + GB_TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8_t xa[4], wb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wm * 64 + i * 16 + r16;
+        xa[i] = *(const bf16x8_t*)(la + row * 128 + (((kk * 4 + kb) ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wn * 64 + j * 16 + r16;
+        wb[j] = *(const bf16x8_t*)(lb + row * 128 + (((kk * 4 + kb) ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      epi_store4<true>(E, m0 + wm * 64 + i * 16 + r16, n0 + wn * 64 + j * 16 + kb * 4, acc[i][j]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 TN: slab[split][Kc, N] (fp32) = sum over this split's rows of X[m,Kc]^T G[m,N]
+//   tile: 128 (Kc) x 128 (N), reduction step 64 rows; both tiles row-major [64][128] bf16 in LDS,
+//   32-byte granules XOR-swizzled by (row & 7) so the 8 rows a transpose-read pair touches hit 8
+//   distinct bank groups.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(int Mrows, int Kc, int N, int nsplit,
+                                                          const uint16_t* __restrict__ X, int ldx,
+                                                          const uint16_t* __restrict__ G, int ldg,
+                                                          float* __restrict__ slab, int lds_out,
+                                                          float* __restrict__ colsum_slab) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * GB_TILE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntn = N / 128, ntk = Kc / 128;
+  const int tiles = ntn * ntk;
+  const int bid = blockIdx.x;
+  const int split = bid / tiles, tt = bid % tiles;
+  const int c0 = (tt / ntn) * 128, n0 = (tt % ntn) * 128;
+  const int rows_per = Mrows / nsplit;
+  const int mbeg = split * rows_per;
+  const int nk = rows_per / 64;
+  const int wk = wv >> 1, wn = wv & 1;  // wave owns Kc rows [wk*64, +64), N cols [wn*64, +64)
+
+  auto stage = [&](int kt, int buf) {
+    const int mrow0 = mbeg + kt * 64;
+    unsigned char* lx = lds + buf * 2 * GB_TILE_BYTES;
+    unsigned char* lg = lx + GB_TILE_BYTES;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int p = it * 256 + tid;          // 1024 chunks: row p/16, physical pos p%16
+      const int row = p >> 4, pos = p & 15;
+      const int c = ((((pos >> 1) ^ (row & 7)) << 1) | (pos & 1));
+      glds16(X + (size_t)(mrow0 + row) * ldx + c0 + c * 8, lx + (it * 256 + wv * 64) * 16);
+      glds16(G + (size_t)(mrow0 + row) * ldg + n0 + c * 8, lg + (it * 256 + wv * 64) * 16);
+    }
+  };
+
+  f32x4_t acc[4][4];  // [i over N frags][j over Kc frags]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float csum = 0.f;  // column sums of G (bias gradient), tiles with c0 == 0 only
+  const bool do_colsum = colsum_slab && c0 == 0;
+
+  stage(0, 0);
+  const int g = lane >> 4, s = lane & 15;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    __syncthreads();
+    if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+    const unsigned char* lx = lds + buf * 2 * GB_TILE_BYTES;
+    const unsigned char* lg = lx + GB_TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8_t ga[4], xb[4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = kk * 32 + h * 16 + g * 4 + (s >> 2);
+        const int sw = row & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int q = (wn * 64 + i * 16) >> 4;  // 32-byte granule of the fragment's 16 columns
+          bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (bf16x4_t __attribute__((address_space(3)))*)(lg + row * 256 + ((q ^ sw) << 5) + ((s & 3) << 3)));
+          ga[i][h * 4 + 0] = v[0]; ga[i][h * 4 + 1] = v[1]; ga[i][h * 4 + 2] = v[2]; ga[i][h * 4 + 3] = v[3];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int q = (wk * 64 + j * 16) >> 4;
+          bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (bf16x4_t __attribute__((address_space(3)))*)(lx + row * 256 + ((q ^ sw) << 5) + ((s & 3) << 3)));
+          xb[j][h * 4 + 0] = v[0]; xb[j][h * 4 + 1] = v[1]; xb[j][h * 4 + 2] = v[2]; xb[j][h * 4 + 3] = v[3];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[i], xb[j], acc[i][j], 0, 0, 0);
+    }
+    if (do_colsum && tid < 128) {  // column tid of the G tile, 64 rows
+      const int q = tid >> 4, w = (tid & 15) * 2;
+      float a = 0.f;
+#pragma unroll 8
+      for (int row = 0; row < 64; ++row) a += bf16_to_f(*(const uint16_t*)(lg + row * 256 + ((q ^ (row & 7)) << 5) + w));
+      csum += a;
+    }
+  }
+  float* out = slab + (size_t)split * Kc * lds_out;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = c0 + wk * 64 + j * 16 + s;
+      const int n = n0 + wn * 64 + i * 16 + g * 4;
+      *(float4*)(out + (size_t)c * lds_out + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+  if (do_colsum && tid < 128) colsum_slab[(size_t)split * N + n0 + tid] = csum;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 parity path: 128x128x16 tiles on v_mfma_f32_16x16x4_f32, register-staged, padded LDS.
+// ------------------------------------------------------------------------------------------------
+#define GF_BK 16
+#define GF_PITCH 20  // floats per LDS row (16 + 4 pad): keeps float4 alignment, spreads banks
+
+__global__ __launch_bounds__(256, 2) void k_gemm_nt_f32(int M, int N, int K1, int K2, const float* __restrict__ A1, int lda1,
+                                                         const float* __restrict__ A2, int lda2,
+                                                         const float* __restrict__ Bt, int ldb, GemmEpi E) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * 128 * GF_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int ntn = N / 128, ntm = M / 128;
+  const int t = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (t / ntn) * 128, n0 = (t % ntn) * 128;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int nk = (K1 + K2) / GF_BK;
+  float4 ra[2], rb[2];
+  auto gload = [&](int kt) {
+    const int kglob = kt * GF_BK;
+    const float* Abase; int lda, kcol;
+    if (kglob < K1) { Abase = A1; lda = lda1; kcol = kglob; } else { Abase = A2; lda = lda2; kcol = kglob - K1; }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int p = it * 256 + tid, row = p >> 2, c = p & 3;
+      ra[it] = *(const float4*)(Abase + (size_t)(m0 + row) * lda + kcol + c * 4);
+      rb[it] = *(const float4*)(Bt + (size_t)(n0 + row) * ldb + kglob + c * 4);
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* la = lds + buf * 2 * 128 * GF_PITCH;
+    float* lb = la + 128 * GF_PITCH;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int p = it * 256 + tid, row = p >> 2, c = p & 3;
+      *(float4*)(la + row * GF_PITCH + c * 4) = ra[it];
+      *(float4*)(lb + row * GF_PITCH + c * 4) = rb[it];
+    }
+  };
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  gload(0);
+  lstore(0);
+  const int r16 = lane & 15, kb = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    __syncthreads();
+    if (kt + 1 < nk) gload(kt + 1);
+    const float* la = lds + buf * 2 * 128 * GF_PITCH;
+    const float* lb = la + 128 * GF_PITCH;
+    float4 xa[4], wb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xa[i] = *(const float4*)(la + (wm * 64 + i * 16 + r16) * GF_PITCH + kb * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wb[j] = *(const float4*)(lb + (wn * 64 + j * 16 + r16) * GF_PITCH + kb * 4);
+    // lane (r16, kb) holds k = kb*4 + q; MFMA step q consumes the same k set on both operands
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[j].x, xa[i].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[j].y, xa[i].y, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[j].z, xa[i].z, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[j].w, xa[i].w, acc[i][j], 0, 0, 0);
+      }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      epi_store4<false>(E, m0 + wm * 64 + i * 16 + r16, n0 + wn * 64 + j * 16 + kb * 4, acc[i][j]);
+}
+
+#define GF_TPITCH 132  // floats per row of a [16][128] tile
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_f32(int Mrows, int Kc, int N, int nsplit, const float* __restrict__ X,
+                                                         int ldx, const float* __restrict__ G, int ldg,
+                                                         float* __restrict__ slab, int lds_out,
+                                                         float* __restrict__ colsum_slab) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * 16 * GF_TPITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int ntn = N / 128, ntk = Kc / 128, tiles = ntn * ntk;
+  const int split = blockIdx.x / tiles, tt = blockIdx.x % tiles;
+  const int c0 = (tt / ntn) * 128, n0 = (tt % ntn) * 128;
+  const int rows_per = Mrows / nsplit, mbeg = split * rows_per, nk = rows_per / 16;
+  const int wk = wv >> 1, wn = wv & 1;
+  float4 rx[2], rg[2];
+  auto gload = [&](int kt) {
+    const int mrow0 = mbeg + kt * 16;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int p = it * 256 + tid, row = p >> 5, c = p & 31;
+      rx[it] = *(const float4*)(X + (size_t)(mrow0 + row) * ldx + c0 + c * 4);
+      rg[it] = *(const float4*)(G + (size_t)(mrow0 + row) * ldg + n0 + c * 4);
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* lx = lds + buf * 2 * 16 * GF_TPITCH;
+    float* lg = lx + 16 * GF_TPITCH;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int p = it * 256 + tid, row = p >> 5, c = p & 31;
+      *(float4*)(lx + row * GF_TPITCH + c * 4) = rx[it];
+      *(float4*)(lg + row * GF_TPITCH + c * 4) = rg[it];
+    }
+  };
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float csum = 0.f;
+  const bool do_colsum = colsum_slab && c0 == 0;
+  gload(0);
+  lstore(0);
+  const int g = lane >> 4, s = lane & 15;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    __syncthreads();
+    if (kt + 1 < nk) gload(kt + 1);
+    const float* lx = lds + buf * 2 * 16 * GF_TPITCH;
+    const float* lg = lx + 16 * GF_TPITCH;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float ga[4], xb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ga[i] = lg[(kk * 4 + g) * GF_TPITCH + wn * 64 + i * 16 + s];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xb[j] = lx[(kk * 4 + g) * GF_TPITCH + wk * 64 + j * 16 + s];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[i], xb[j], acc[i][j], 0, 0, 0);
+    }
+    if (do_colsum && tid < 128) {
+      float a = 0.f;
+#pragma unroll
+      for (int row = 0; row < 16; ++row) a += lg[row * GF_TPITCH + tid];
+      csum += a;
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+  }
+  float* out = slab + (size_t)split * Kc * lds_out;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = c0 + wk * 64 + j * 16 + s;
+      const int n = n0 + wn * 64 + i * 16 + g * 4;
+      *(float4*)(out + (size_t)c * lds_out + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+  if (do_colsum && tid < 128) colsum_slab[(size_t)split * N + n0 + tid] = csum;
+}
+
+// sum fp32 slabs: out[i] = sum_s slab[s][i]   (deterministic order)
+__global__ void k_slab_reduce(const float* __restrict__ slab, int nsplit, size_t per, float* __restrict__ out) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= per) return;
+  float4 a = *(const float4*)(slab + i);
+  for (int s = 1; s < nsplit; ++s) {
+    const float4 b = *(const float4*)(slab + (size_t)s * per + i);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  *(float4*)(out + i) = a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" int hugs_gemm_nt(int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,
+                            const void* Bt, int ldb, const float* bias, const float* row_bias, int row_div, int ld_rb,
+                            int relu, const void* mask, int ld_mask, const float* r1_row, const float* r1_col,
+                            void* out, int ldc, void* stream) {
+  HUGS_REQUIRE(dtype == 0 || dtype == 1, -2, "hugs_gemm_nt: dtype must be 0 (fp32) or 1 (bf16)");
+  const int bk = dtype ? GB_BK : GF_BK;
+  HUGS_REQUIRE(M % 128 == 0 && N % 128 == 0 && K1 % bk == 0 && K2 % bk == 0 && K1 > 0, -3,
+               "hugs_gemm_nt: shape M=%d N=%d K=%d+%d not tile aligned (128,128,%d)", M, N, K1, K2, bk);
+  HUGS_REQUIRE(!row_bias || row_div > 0, -3, "hugs_gemm_nt: row_div must be > 0");
+  if (M == 0 || N == 0) return 0;
+  GemmEpi E{bias, row_bias, row_div, ld_rb, relu, mask, ld_mask, r1_row, r1_col, out, ldc};
+  const int grid = (M / 128) * (N / 128);
+  if (dtype)
+    hipLaunchKernelGGL(k_gemm_nt_bf16, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, N, K1, K2, (const uint16_t*)A1,
+                       lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E);
+  else
+    hipLaunchKernelGGL(k_gemm_nt_f32, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, N, K1, K2, (const float*)A1, lda1,
+                       (const float*)A2, lda2, (const float*)Bt, ldb, E);
+  HUGS_CHECK_LAUNCH("hugs_gemm_nt");
+  return 0;
+}
+
+extern "C" long long hugs_gemm_tn_ws_bytes(int Kc, int N, int nsplit) {
+  return (long long)nsplit * ((long long)Kc * N + N) * 4;
+}
+
+// dW[Kc, ldw(:N)] = X^T G, dbias[N] = colsum(G) (if dbias != null). ws: hugs_gemm_tn_ws_bytes().
+extern "C" int hugs_gemm_tn(int dtype, int Mrows, int Kc, int N, int nsplit, const void* X, int ldx, const void* G, int ldg,
+                            float* dW, float* dbias, void* ws, void* stream) {
+  HUGS_REQUIRE(dtype == 0 || dtype == 1, -2, "hugs_gemm_tn: dtype must be 0 (fp32) or 1 (bf16)");
+  const int step = dtype ? 64 : 16;
+  HUGS_REQUIRE(Kc % 128 == 0 && N % 128 == 0 && nsplit >= 1 && Mrows % (nsplit * step) == 0, -3,
+               "hugs_gemm_tn: shape rows=%d Kc=%d N=%d split=%d not tile aligned", Mrows, Kc, N, nsplit);
+  float* slab = (float*)ws;
+  float* cs = dbias ? slab + (size_t)nsplit * Kc * N : nullptr;
+  const int grid = (Kc / 128) * (N / 128) * nsplit;
+  if (dtype)
+    hipLaunchKernelGGL(k_gemm_tn_bf16, dim3(grid), dim3(256), 0, (hipStream_t)stream, Mrows, Kc, N, nsplit,
+                       (const uint16_t*)X, ldx, (const uint16_t*)G, ldg, slab, N, cs);
+  else
+    hipLaunchKernelGGL(k_gemm_tn_f32, dim3(grid), dim3(256), 0, (hipStream_t)stream, Mrows, Kc, N, nsplit, (const float*)X,
+                       ldx, (const float*)G, ldg, slab, N, cs);
+  HUGS_CHECK_LAUNCH("hugs_gemm_tn");
+  const size_t per = (size_t)Kc * N;
+  hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((per / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, slab, nsplit,
+                     per, dW);
+  if (dbias)
+    hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((N / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cs, nsplit,
+                       (size_t)N, dbias);
+  HUGS_CHECK_LAUNCH("hugs_gemm_tn(reduce)");
+  return 0;
+}

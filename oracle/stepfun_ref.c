@@ -176,6 +176,9 @@ int orc_invert_cdf(const float* u, int ns, const float* t, const float* logits, 
   for (int i = 0; i < n; ++i) w[i] = w[i] / den;
   cw0[0] = 0.0f;
   if (n > 1) orc_wave_cumsum(w, n - 1, cs);
+  /* canonical CDF = running max of the wave-order prefix sums: the tree-ordered scan is not
+   * monotone to the last ulp, the reference's max/min interval search assumes it is. */
+  for (int i = 1; i < n - 1; ++i) if (cs[i] < cs[i - 1]) cs[i] = cs[i - 1];
   for (int i = 0; i < n - 1; ++i) cw0[i + 1] = cs[i] < 1.0f ? cs[i] : 1.0f;
   cw0[n] = 1.0f;
   for (int j = 0; j < ns; ++j) {
