@@ -12,10 +12,29 @@ _PROTOS = {
     'hugs_level_sample_fwd': 'ippiifffffppiiippppppps',
     'hugs_test_explog': 'pipps',
     'hugs_test_arith': 'ppips',
-    'hugs_cast_ipe_fwd': 'iipppppiiiips',
+    'hugs_cast_ipe_fwd': 'iipppppiiiiiips',
     'hugs_dir_enc_fwd': 'iipps',
     'hugs_gemm_nt': 'iiiii' 'pipipi' 'pp' 'iii' 'pi' 'pp' 'pi' 's',
     'hugs_gemm_tn': 'iiiiipipippps',
+    'hugs_density_fwd': 'iiipippfpps',
+    'hugs_density_bwd': 'iiipippfpppps',
+    'hugs_rank1_mask': 'iiipppipis',
+    'hugs_glo_gather': 'iippips',
+    'hugs_raybias_fwd': 'iiiippppps',
+    'hugs_raybias_bwd': 'iiiiii' 'p' 'i' 'ppppppp' 's',
+    'hugs_rgb_fwd': 'iiipippfps',
+    'hugs_rgb_bwd': 'iiipipppfpippps',
+    'hugs_composite_fwd': 'iippppifpppps',
+    'hugs_composite_bwd': 'iippppifpppps',
+    'hugs_data_loss': 'iipppififppps',
+    'hugs_robust_mask': 'iipppfififpppps',
+    'hugs_interlevel': 'iiippppfpps',
+    'hugs_distortion': 'iippfpps',
+    'hugs_sum': 'ipfps',
+    'hugs_add_inplace': 'qpps',
+    'hugs_opt_stats': 'iiipppfffppps',
+    'hugs_opt_adam': 'iipppppppffffffffpps',
+    'hugs_cast_weights': 'iiippps',
 }
 _CT = {'i': ctypes.c_int, 'f': ctypes.c_float, 'p': ctypes.c_void_p, 'q': ctypes.c_longlong,
        's': ctypes.c_void_p}
@@ -34,7 +53,8 @@ class _Lib:
           'There is no CPU fallback.')
     self.cdll = ctypes.CDLL(LIB_PATH)
     self.cdll.hugs_last_error.restype = ctypes.c_char_p
-    self.cdll.hugs_gemm_tn_ws_bytes.restype = ctypes.c_longlong
+    for n_ in ('hugs_gemm_tn_ws_bytes', 'hugs_density_bwd_ws_bytes', 'hugs_rgb_bwd_ws_bytes'):
+      getattr(self.cdll, n_).restype = ctypes.c_longlong
     for name, sig in _PROTOS.items():
       fn = getattr(self.cdll, name)
       fn.argtypes = [_CT[c] for c in sig]

@@ -10,9 +10,7 @@
 #include "hugs_common.h"
 
 #define ENC_SAMPLES 32   // samples per workgroup
-#define ENC_NB 21        // basis directions (icosahedron, 2 subdivisions)
-#define ENC_F 504
-#define ENC_KP 512
+#define ENC_NB 21        // max basis directions (icosahedron, 2 subdivisions)
 
 __device__ __forceinline__ float safe_sinf(float x) {
   // math.py:26-38: sin(where(|x| < 100pi, x, x mod 100pi)), python-style mod
@@ -24,8 +22,8 @@ __device__ __forceinline__ float safe_sinf(float x) {
 template <bool BF16>
 __global__ __launch_bounds__(256) void k_cast_ipe(int nrays, int S, const float* __restrict__ tdist,
                                                   const float* __restrict__ origins, const float* __restrict__ dirs,
-                                                  const float* __restrict__ radii, const float* __restrict__ basis,
-                                                  int ray_shape, int warp, int max_deg, void* __restrict__ out) {
+                                                  const float* __restrict__ radii, const float* __restrict__ basis, int nb,
+                                                  int ray_shape, int warp, int max_deg, int kp, void* __restrict__ out) {
   __shared__ float s_mean[ENC_SAMPLES][3];
   __shared__ float s_cov[ENC_SAMPLES][6];
   __shared__ float s_lm[ENC_SAMPLES][ENC_NB + 1];
@@ -34,7 +32,7 @@ __global__ __launch_bounds__(256) void k_cast_ipe(int nrays, int S, const float*
   const int tid = threadIdx.x;
   const long long total = (long long)nrays * S;
   const long long base = (long long)blockIdx.x * ENC_SAMPLES;
-  if (tid < 3 * ENC_NB) s_basis[tid] = basis[tid];
+  if (tid < 3 * nb) s_basis[tid] = basis[tid];
   if (tid < ENC_SAMPLES && base + tid < total) {
     const long long m = base + tid;
     const int ray = (int)(m / S), s = (int)(m % S);
@@ -90,9 +88,9 @@ __global__ __launch_bounds__(256) void k_cast_ipe(int nrays, int S, const float*
     for (int k = 0; k < 6; ++k) s_cov[tid][k] = c[k];
   }
   __syncthreads();
-  for (int e = tid; e < ENC_SAMPLES * ENC_NB; e += 256) {  // coord.py:129-133
-    const int s = e / ENC_NB, j = e % ENC_NB;
-    const float b0 = s_basis[j], b1 = s_basis[ENC_NB + j], b2 = s_basis[2 * ENC_NB + j];
+  for (int e = tid; e < ENC_SAMPLES * nb; e += 256) {  // coord.py:129-133
+    const int s = e / nb, j = e % nb;
+    const float b0 = s_basis[j], b1 = s_basis[nb + j], b2 = s_basis[2 * nb + j];
     const float* c = s_cov[s];
     s_lm[s][j] = s_mean[s][0] * b0 + s_mean[s][1] * b1 + s_mean[s][2] * b2;
     const float r0 = c[0] * b0 + c[1] * b1 + c[2] * b2;
@@ -103,38 +101,40 @@ __global__ __launch_bounds__(256) void k_cast_ipe(int nrays, int S, const float*
   __syncthreads();
   // one wave writes one whole row: lane owns 8 consecutive features
   const int lane = tid & 63, wv = tid >> 6;
-  const int nfeat_half = ENC_NB * max_deg;  // 252
+  const int nfeat_half = nb * max_deg;
   for (int s = wv; s < ENC_SAMPLES; s += 4) {
     const long long m = base + s;
     if (m >= total) break;
-    float v[8];
+    for (int f0 = lane * 8; f0 < kp; f0 += 512) {
+      float v[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int f = lane * 8 + q;
-      float val = 0.0f;
-      if (f < 2 * nfeat_half) {
-        const int half = f >= nfeat_half;
-        const int r = f - half * nfeat_half;
-        const int k = r / ENC_NB, j = r - k * ENC_NB;
-        const float sc = (float)(1 << k);
-        float x = s_lm[s][j] * sc;
-        if (half) x = x + 1.57079632679489661923f;   // sin(x + pi/2), as the reference does
-        const float var = s_lv[s][j] * (sc * sc);
-        val = expf(-0.5f * var) * safe_sinf(x);
+      for (int q = 0; q < 8; ++q) {
+        const int f = f0 + q;
+        float val = 0.0f;
+        if (f < 2 * nfeat_half) {
+          const int half = f >= nfeat_half;
+          const int r = f - half * nfeat_half;
+          const int k = r / nb, j = r - k * nb;
+          const float sc = (float)(1 << k);
+          float x = s_lm[s][j] * sc;
+          if (half) x = x + 1.57079632679489661923f;   // sin(x + pi/2), as the reference does
+          const float var = s_lv[s][j] * (sc * sc);
+          val = expf(-0.5f * var) * safe_sinf(x);
+        }
+        v[q] = val;
       }
-      v[q] = val;
-    }
-    if (BF16) {
-      uint4 pk;
-      pk.x = f_to_bf16(v[0]) | ((uint32_t)f_to_bf16(v[1]) << 16);
-      pk.y = f_to_bf16(v[2]) | ((uint32_t)f_to_bf16(v[3]) << 16);
-      pk.z = f_to_bf16(v[4]) | ((uint32_t)f_to_bf16(v[5]) << 16);
-      pk.w = f_to_bf16(v[6]) | ((uint32_t)f_to_bf16(v[7]) << 16);
-      ((uint4*)out)[(size_t)m * (ENC_KP / 8) + lane] = pk;
-    } else {
-      float4* o = (float4*)out + (size_t)m * (ENC_KP / 4) + lane * 2;
-      o[0] = make_float4(v[0], v[1], v[2], v[3]);
-      o[1] = make_float4(v[4], v[5], v[6], v[7]);
+      if (BF16) {
+        uint4 pk;
+        pk.x = f_to_bf16(v[0]) | ((uint32_t)f_to_bf16(v[1]) << 16);
+        pk.y = f_to_bf16(v[2]) | ((uint32_t)f_to_bf16(v[3]) << 16);
+        pk.z = f_to_bf16(v[4]) | ((uint32_t)f_to_bf16(v[5]) << 16);
+        pk.w = f_to_bf16(v[6]) | ((uint32_t)f_to_bf16(v[7]) << 16);
+        *(uint4*)((uint16_t*)out + (size_t)m * kp + f0) = pk;
+      } else {
+        float4* o = (float4*)((float*)out + (size_t)m * kp + f0);
+        o[0] = make_float4(v[0], v[1], v[2], v[3]);
+        o[1] = make_float4(v[4], v[5], v[6], v[7]);
+      }
     }
   }
 }
@@ -159,19 +159,23 @@ __global__ void k_dir_enc(int nrays, int deg, const float* __restrict__ viewdirs
 }
 
 extern "C" int hugs_cast_ipe_fwd(int nrays, int num_samples, const float* tdist, const float* origins,
-                                 const float* directions, const float* radii, const float* basis, int ray_shape,
-                                 int warp_contract, int max_deg, int out_bf16, void* out, void* stream) {
+                                 const float* directions, const float* radii, const float* basis, int num_basis,
+                                 int ray_shape, int warp_contract, int max_deg, int out_bf16, int row_pitch, void* out,
+                                 void* stream) {
   HUGS_REQUIRE(ray_shape == 0 || ray_shape == 1, -2, "ray_shape must be 'cone' or 'cylinder'");
-  HUGS_REQUIRE(max_deg >= 1 && 2 * ENC_NB * max_deg <= ENC_F, -3, "hugs_cast_ipe_fwd: max_deg %d unsupported", max_deg);
+  HUGS_REQUIRE(num_basis >= 1 && num_basis <= ENC_NB && max_deg >= 1 && max_deg <= 24, -3,
+               "hugs_cast_ipe_fwd: basis size %d / max_deg %d unsupported", num_basis, max_deg);
+  HUGS_REQUIRE(row_pitch % 8 == 0 && row_pitch >= 2 * num_basis * max_deg, -3,
+               "hugs_cast_ipe_fwd: row pitch %d too small / not a multiple of 8", row_pitch);
   const long long total = (long long)nrays * num_samples;
   if (total <= 0) return 0;
   const int grid = (int)((total + ENC_SAMPLES - 1) / ENC_SAMPLES);
   if (out_bf16)
     hipLaunchKernelGGL(k_cast_ipe<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, nrays, num_samples, tdist,
-                       origins, directions, radii, basis, ray_shape, warp_contract, max_deg, out);
+                       origins, directions, radii, basis, num_basis, ray_shape, warp_contract, max_deg, row_pitch, out);
   else
     hipLaunchKernelGGL(k_cast_ipe<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, nrays, num_samples, tdist,
-                       origins, directions, radii, basis, ray_shape, warp_contract, max_deg, out);
+                       origins, directions, radii, basis, num_basis, ray_shape, warp_contract, max_deg, row_pitch, out);
   HUGS_CHECK_LAUNCH("hugs_cast_ipe_fwd");
   return 0;
 }

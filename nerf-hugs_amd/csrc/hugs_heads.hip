@@ -1,0 +1,368 @@
+// MLP heads around the MFMA trunks: density head (N=1 "GEMV"), view-branch per-ray bias, rgb head,
+// and their backward passes.  All are HBM-streaming kernels (one pass over an [M, K] activation).
+//
+// Replaces (reference, MipNeRF360/internal/models.py): :456 raw_density = Dense(1), :467 softplus(raw-1);
+// :488-512 view-direction / GLO concat feeding Dense(128) -- the per-ray constant part of that matmul is
+// hoisted into a per-ray bias; :514-519 rgb = sigmoid(Dense(3)) * (1+2*pad) - pad.
+#include "hugs_common.h"
+
+template <bool BF16>
+__device__ __forceinline__ void load8(const void* base, size_t elem_off, float v[8]) {
+  if (BF16) {
+    const uint4 p = *(const uint4*)((const uint16_t*)base + elem_off);
+    v[0] = __uint_as_float(p.x << 16); v[1] = __uint_as_float(p.x & 0xffff0000u);
+    v[2] = __uint_as_float(p.y << 16); v[3] = __uint_as_float(p.y & 0xffff0000u);
+    v[4] = __uint_as_float(p.z << 16); v[5] = __uint_as_float(p.z & 0xffff0000u);
+    v[6] = __uint_as_float(p.w << 16); v[7] = __uint_as_float(p.w & 0xffff0000u);
+  } else {
+    const float4 a = *(const float4*)((const float*)base + elem_off);
+    const float4 b = *(const float4*)((const float*)base + elem_off + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+}
+template <bool BF16>
+__device__ __forceinline__ void store8(void* base, size_t elem_off, const float v[8]) {
+  if (BF16) {
+    uint4 pk;
+    pk.x = f_to_bf16(v[0]) | ((uint32_t)f_to_bf16(v[1]) << 16);
+    pk.y = f_to_bf16(v[2]) | ((uint32_t)f_to_bf16(v[3]) << 16);
+    pk.z = f_to_bf16(v[4]) | ((uint32_t)f_to_bf16(v[5]) << 16);
+    pk.w = f_to_bf16(v[6]) | ((uint32_t)f_to_bf16(v[7]) << 16);
+    *(uint4*)((uint16_t*)base + elem_off) = pk;
+  } else {
+    *(float4*)((float*)base + elem_off) = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)((float*)base + elem_off + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+
+__device__ __forceinline__ float softplusf(float x) {  // logaddexp(x, 0)
+  return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+}
+
+// ---- density head forward: raw[m] = Y[m,:] . w + b ; density = softplus(raw + density_bias) ----
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_density_fwd(int M, int K, const void* __restrict__ Y, int ldy,
+                                                     const float* __restrict__ w, const float* __restrict__ b,
+                                                     float density_bias, float* __restrict__ raw,
+                                                     float* __restrict__ density) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const float bb = b[0];
+  for (int m = wave; m < M; m += nwaves) {
+    float acc = 0.f;
+    for (int k0 = lane * 8; k0 < K; k0 += 512) {
+      float v[8];
+      load8<BF16>(Y, (size_t)m * ldy + k0, v);
+      const float4 w0 = *(const float4*)(w + k0), w1 = *(const float4*)(w + k0 + 4);
+      acc += v[0] * w0.x + v[1] * w0.y + v[2] * w0.z + v[3] * w0.w + v[4] * w1.x + v[5] * w1.y + v[6] * w1.z + v[7] * w1.w;
+    }
+    acc = wave_sum_f(acc);
+    if (lane == 0) {
+      const float r = acc + bb;
+      raw[m] = r;
+      density[m] = softplusf(r + density_bias);
+    }
+  }
+}
+
+// d_raw[m] = d_density[m] * sigmoid(raw[m] + density_bias)
+__global__ void k_density_bwd_raw(int M, const float* __restrict__ d_density, const float* __restrict__ raw,
+                                  float density_bias, float* __restrict__ d_raw) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < M) d_raw[i] = d_density[i] / (1.f + expf(-(raw[i] + density_bias)));
+}
+
+// weighted column sums: slab[blk][k] = sum_{m in blk} r[m] * Y[m,k]; slab[blk][K] = sum r[m]   (K <= 2048)
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_wcolsum(int M, int K, int rows_per_blk, const void* __restrict__ Y, int ldy,
+                                                 const float* __restrict__ r, float* __restrict__ slab) {
+  // thread t owns columns [8t, 8t+8) (K/8 <= 256 threads active); rows are walked sequentially
+  const int t = threadIdx.x;
+  const int m0 = blockIdx.x * rows_per_blk, m1 = min(M, m0 + rows_per_blk);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float rs = 0.f;
+  if (t * 8 < K) {
+#pragma unroll 4
+    for (int m = m0; m < m1; ++m) {
+      float v[8];
+      load8<BF16>(Y, (size_t)m * ldy + t * 8, v);
+      const float rm = r[m];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] += rm * v[q];
+    }
+    float* o = slab + (size_t)blockIdx.x * (K + 4) + t * 8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = acc[q];
+  }
+  if (t == 255) {
+    for (int m = m0; m < m1; ++m) rs += r[m];
+    slab[(size_t)blockIdx.x * (K + 4) + K] = rs;
+  }
+}
+
+__global__ void k_slab_reduce_small(const float* __restrict__ slab, int nblk, int width, int stride,
+                                    float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= width) return;
+  float a = 0.f;
+  for (int b = 0; b < nblk; ++b) a += slab[(size_t)b * stride + i];
+  out[i] = a;
+}
+
+// out[m,n] = r[m] * c[n] * (Y[m,n] > 0)   (PropMLP: gradient entering the last trunk layer)
+template <bool BF16>
+__global__ void k_rank1_mask(int M, int N, const float* __restrict__ r, const float* __restrict__ c,
+                             const void* __restrict__ Y, int ldy, void* __restrict__ out, int ldo) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_row = N / 8;
+  if (i >= (size_t)M * per_row) return;
+  const int m = (int)(i / per_row), n0 = (int)(i % per_row) * 8;
+  float y[8], o[8];
+  load8<BF16>(Y, (size_t)m * ldy + n0, y);
+  const float rm = r[m];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) o[q] = y[q] > 0.f ? rm * c[n0 + q] : 0.f;
+  store8<BF16>(out, (size_t)m * ldo + n0, o);
+}
+
+// ---- view branch: per-ray bias rb[ray, j] = b[j] + sum_c enc[ray,c] * Wv[c_off + c, j] ----
+// enc = [dir_enc(nd) | glo(ng)] ; Wv is the fp32 master [*, H]
+__global__ void k_raybias_fwd(int nrays, int H, int nd, int ng, const float* __restrict__ dir_enc,
+                              const float* __restrict__ glo, const float* __restrict__ Wv_tail,
+                              const float* __restrict__ bias, float* __restrict__ rb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrays * H) return;
+  const int ray = i / H, j = i % H;
+  float a = bias[j];
+  for (int c = 0; c < nd; ++c) a += dir_enc[ray * nd + c] * Wv_tail[(size_t)c * H + j];
+  for (int c = 0; c < ng; ++c) a += glo[ray * ng + c] * Wv_tail[(size_t)(nd + c) * H + j];
+  rb[i] = a;
+}
+
+// backward of the per-ray part: d_rb[ray,j] = sum_s G[ray*S+s, j];  then
+//   dWv_tail[c,j] = sum_ray enc[ray,c] d_rb[ray,j];  d_glo[ray,g] = sum_j d_rb[ray,j] Wv_tail[nd+g, j]
+template <bool BF16>
+__global__ void k_segsum(int nrays, int S, int H, const void* __restrict__ G, int ldg, float* __restrict__ d_rb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrays * H) return;
+  const int ray = i / H, j = i % H;
+  float a = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const size_t off = (size_t)(ray * S + s) * ldg + j;
+    a += BF16 ? bf16_to_f(((const uint16_t*)G)[off]) : ((const float*)G)[off];
+  }
+  d_rb[i] = a;
+}
+__global__ void k_raybias_bwd_w(int nrays, int H, int nd, int ng, const float* __restrict__ dir_enc,
+                                const float* __restrict__ glo, const float* __restrict__ d_rb,
+                                float* __restrict__ dWv_tail) {
+  // one thread per (c, j); sequential over rays (deterministic).  (nd+ng)*H <= ~10k threads.
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (nd + ng) * H) return;
+  const int c = i / H, j = i % H;
+  float a = 0.f;
+  if (c < nd) for (int r = 0; r < nrays; ++r) a += dir_enc[r * nd + c] * d_rb[(size_t)r * H + j];
+  else for (int r = 0; r < nrays; ++r) a += glo[r * ng + (c - nd)] * d_rb[(size_t)r * H + j];
+  dWv_tail[i] = a;
+}
+__global__ void k_glo_bwd(int nrays, int H, int nd, int ng, const float* __restrict__ d_rb,
+                          const float* __restrict__ Wv_tail, const int* __restrict__ embed_idx,
+                          float* __restrict__ d_embedding) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrays * ng) return;
+  const int ray = i / ng, g = i % ng;
+  float a = 0.f;
+  for (int j = 0; j < H; ++j) a += d_rb[(size_t)ray * H + j] * Wv_tail[(size_t)(nd + g) * H + j];
+  atomicAdd(d_embedding + (size_t)embed_idx[ray] * ng + g, a);
+}
+__global__ void k_glo_gather(int nrays, int ng, const float* __restrict__ embedding, const int* __restrict__ embed_idx,
+                             int zero_glo, float* __restrict__ glo) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrays * ng) return;
+  glo[i] = zero_glo ? 0.f : embedding[(size_t)embed_idx[i / ng] * ng + (i % ng)];
+}
+
+// ---- rgb head: 16 lanes per row (H = 128 -> 8 elements per lane) ----
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_rgb_fwd(int M, int H, const void* __restrict__ Hact, int ldh,
+                                                 const float* __restrict__ W /*[H,3]*/, const float* __restrict__ b,
+                                                 float pad, float* __restrict__ rgb) {
+  const int sub = threadIdx.x & 15;
+  const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  if (row >= M) return;   // whole 16-lane groups exit together
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int k0 = sub * 8; k0 < H; k0 += 128) {
+    float v[8];
+    load8<BF16>(Hact, (size_t)row * ldh + k0, v);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      a0 += v[q] * W[(k0 + q) * 3]; a1 += v[q] * W[(k0 + q) * 3 + 1]; a2 += v[q] * W[(k0 + q) * 3 + 2];
+    }
+  }
+#pragma unroll
+  for (int d = 1; d < 16; d <<= 1) { a0 += __shfl_xor(a0, d); a1 += __shfl_xor(a1, d); a2 += __shfl_xor(a2, d); }
+  if (sub == 0) {
+    const float sc = 1.f + 2.f * pad;
+    rgb[row * 3] = sc / (1.f + expf(-(a0 + b[0]))) - pad;
+    rgb[row * 3 + 1] = sc / (1.f + expf(-(a1 + b[1]))) - pad;
+    rgb[row * 3 + 2] = sc / (1.f + expf(-(a2 + b[2]))) - pad;
+  }
+}
+
+// backward: dz[c] = d_rgb[c] * (1+2pad) * s(1-s), s = (rgb+pad)/(1+2pad)
+//   G[m,j] = (h[m,j] > 0) * sum_c dz[c] W[j,c]     (gradient at the view layer's pre-activation)
+//   slab[blk] accumulates dW[j,c] = sum_m h[m,j] dz[m,c] and db[c] = sum_m dz[m,c]
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_rgb_bwd(int M, int H, int rows_per_blk, const void* __restrict__ Hact, int ldh,
+                                                 const float* __restrict__ W, const float* __restrict__ rgb,
+                                                 const float* __restrict__ d_rgb, float pad, void* __restrict__ G,
+                                                 int ldg, float* __restrict__ slab) {
+  // 16 lanes per row, each lane 8 consecutive j (H == 128); a block walks rows_per_blk rows, 16 at a time
+  const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int m0 = blockIdx.x * rows_per_blk, m1 = min(M, m0 + rows_per_blk);
+  const int j0 = sub * 8;
+  float w[8][3];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { w[q][0] = W[(j0 + q) * 3]; w[q][1] = W[(j0 + q) * 3 + 1]; w[q][2] = W[(j0 + q) * 3 + 2]; }
+  float dW[8][3];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) dW[q][0] = dW[q][1] = dW[q][2] = 0.f;
+  float db[3] = {0.f, 0.f, 0.f};
+  const float sc = 1.f + 2.f * pad;
+  for (int m = m0 + grp; m < m1; m += 16) {
+    float dz[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float s = (rgb[(size_t)m * 3 + c] + pad) / sc;
+      dz[c] = d_rgb[(size_t)m * 3 + c] * sc * s * (1.f - s);
+    }
+    float h[8], g[8];
+    load8<BF16>(Hact, (size_t)m * ldh + j0, h);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      g[q] = h[q] > 0.f ? dz[0] * w[q][0] + dz[1] * w[q][1] + dz[2] * w[q][2] : 0.f;
+      dW[q][0] += h[q] * dz[0]; dW[q][1] += h[q] * dz[1]; dW[q][2] += h[q] * dz[2];
+    }
+    store8<BF16>(G, (size_t)m * ldg + j0, g);
+    if (sub == 0) { db[0] += dz[0]; db[1] += dz[1]; db[2] += dz[2]; }
+  }
+  // reduce the 16 row-groups of the block through LDS in a fixed order
+  __shared__ float red[16][128 * 3 + 4];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { red[grp][(j0 + q) * 3] = dW[q][0]; red[grp][(j0 + q) * 3 + 1] = dW[q][1]; red[grp][(j0 + q) * 3 + 2] = dW[q][2]; }
+  if (sub == 0) { red[grp][384] = db[0]; red[grp][385] = db[1]; red[grp][386] = db[2]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 387; i += 256) {
+    float a = 0.f;
+#pragma unroll
+    for (int gph = 0; gph < 16; ++gph) a += red[gph][i];
+    slab[(size_t)blockIdx.x * 388 + i] = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int hugs_density_fwd(int dtype, int M, int K, const void* Y, int ldy, const float* w, const float* b,
+                                float density_bias, float* raw, float* density, void* stream) {
+  HUGS_REQUIRE(K % 8 == 0, -3, "hugs_density_fwd: K=%d must be a multiple of 8", K);
+  if (M <= 0) return 0;
+  const int grid = min((M + 3) / 4, 2048);
+  if (dtype) hipLaunchKernelGGL(k_density_fwd<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, K, Y, ldy, w, b, density_bias, raw, density);
+  else hipLaunchKernelGGL(k_density_fwd<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, K, Y, ldy, w, b, density_bias, raw, density);
+  HUGS_CHECK_LAUNCH("hugs_density_fwd");
+  return 0;
+}
+
+#define WCS_BLOCKS 2048
+extern "C" long long hugs_density_bwd_ws_bytes(int K) { return (long long)WCS_BLOCKS * (K + 4) * 4; }
+
+// d_raw = d_density * sigmoid(raw + bias); dw[K] = Y^T d_raw; db = sum d_raw
+extern "C" int hugs_density_bwd(int dtype, int M, int K, const void* Y, int ldy, const float* d_density, const float* raw,
+                                float density_bias, float* d_raw, float* dw, float* db, void* ws, void* stream) {
+  HUGS_REQUIRE(K % 8 == 0 && K <= 2048, -3, "hugs_density_bwd: K=%d unsupported", K);
+  if (M <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_density_bwd_raw, dim3((M + 255) / 256), dim3(256), 0, st, M, d_density, raw, density_bias, d_raw);
+  const int rpb = (M + WCS_BLOCKS - 1) / WCS_BLOCKS;
+  const int nblk = (M + rpb - 1) / rpb;
+  float* slab = (float*)ws;
+  if (dtype) hipLaunchKernelGGL(k_wcolsum<true>, dim3(nblk), dim3(256), 0, st, M, K, rpb, Y, ldy, d_raw, slab);
+  else hipLaunchKernelGGL(k_wcolsum<false>, dim3(nblk), dim3(256), 0, st, M, K, rpb, Y, ldy, d_raw, slab);
+  hipLaunchKernelGGL(k_slab_reduce_small, dim3((K + 255) / 256), dim3(256), 0, st, slab, nblk, K, K + 4, dw);
+  hipLaunchKernelGGL(k_slab_reduce_small, dim3(1), dim3(64), 0, st, slab + K, nblk, 1, K + 4, db);
+  HUGS_CHECK_LAUNCH("hugs_density_bwd");
+  return 0;
+}
+
+extern "C" int hugs_rank1_mask(int dtype, int M, int N, const float* r, const float* c, const void* Y, int ldy, void* out,
+                               int ldo, void* stream) {
+  HUGS_REQUIRE(N % 8 == 0, -3, "hugs_rank1_mask: N=%d must be a multiple of 8", N);
+  const size_t n = (size_t)M * (N / 8);
+  if (n == 0) return 0;
+  if (dtype) hipLaunchKernelGGL(k_rank1_mask<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, N, r, c, Y, ldy, out, ldo);
+  else hipLaunchKernelGGL(k_rank1_mask<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, N, r, c, Y, ldy, out, ldo);
+  HUGS_CHECK_LAUNCH("hugs_rank1_mask");
+  return 0;
+}
+
+extern "C" int hugs_glo_gather(int nrays, int ng, const float* embedding, const int* embed_idx, int zero_glo, float* glo,
+                               void* stream) {
+  if (nrays * ng <= 0) return 0;
+  hipLaunchKernelGGL(k_glo_gather, dim3((nrays * ng + 255) / 256), dim3(256), 0, (hipStream_t)stream, nrays, ng, embedding, embed_idx, zero_glo, glo);
+  HUGS_CHECK_LAUNCH("hugs_glo_gather");
+  return 0;
+}
+
+extern "C" int hugs_raybias_fwd(int nrays, int H, int nd, int ng, const float* dir_enc, const float* glo,
+                                const float* Wv_tail, const float* bias, float* rb, void* stream) {
+  if (nrays <= 0) return 0;
+  hipLaunchKernelGGL(k_raybias_fwd, dim3((nrays * H + 255) / 256), dim3(256), 0, (hipStream_t)stream, nrays, H, nd, ng, dir_enc, glo, Wv_tail, bias, rb);
+  HUGS_CHECK_LAUNCH("hugs_raybias_fwd");
+  return 0;
+}
+
+// G: gradient at the view layer pre-activation [nrays*S, H]. Outputs dWv_tail[(nd+ng), H] and scatter-adds into
+// d_embedding (must be zeroed by the caller once per step). d_rb is workspace [nrays, H].
+extern "C" int hugs_raybias_bwd(int dtype, int nrays, int S, int H, int nd, int ng, const void* G, int ldg,
+                                const float* dir_enc, const float* glo, const float* Wv_tail, const int* embed_idx,
+                                float* d_rb, float* dWv_tail, float* d_embedding, void* stream) {
+  if (nrays <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype) hipLaunchKernelGGL(k_segsum<true>, dim3((nrays * H + 255) / 256), dim3(256), 0, st, nrays, S, H, G, ldg, d_rb);
+  else hipLaunchKernelGGL(k_segsum<false>, dim3((nrays * H + 255) / 256), dim3(256), 0, st, nrays, S, H, G, ldg, d_rb);
+  hipLaunchKernelGGL(k_raybias_bwd_w, dim3(((nd + ng) * H + 63) / 64), dim3(64), 0, st, nrays, H, nd, ng, dir_enc, glo, d_rb, dWv_tail);
+  if (ng > 0 && d_embedding)
+    hipLaunchKernelGGL(k_glo_bwd, dim3((nrays * ng + 255) / 256), dim3(256), 0, st, nrays, H, nd, ng, d_rb, Wv_tail, embed_idx, d_embedding);
+  HUGS_CHECK_LAUNCH("hugs_raybias_bwd");
+  return 0;
+}
+
+extern "C" int hugs_rgb_fwd(int dtype, int M, int H, const void* Hact, int ldh, const float* W, const float* b, float pad,
+                            float* rgb, void* stream) {
+  HUGS_REQUIRE(H % 8 == 0, -3, "hugs_rgb_fwd: H=%d must be a multiple of 8", H);
+  if (M <= 0) return 0;
+  const int grid = (int)(((long long)M * 16 + 255) / 256);
+  if (dtype) hipLaunchKernelGGL(k_rgb_fwd<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, H, Hact, ldh, W, b, pad, rgb);
+  else hipLaunchKernelGGL(k_rgb_fwd<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, H, Hact, ldh, W, b, pad, rgb);
+  HUGS_CHECK_LAUNCH("hugs_rgb_fwd");
+  return 0;
+}
+
+#define RGB_BLOCKS 1024
+extern "C" long long hugs_rgb_bwd_ws_bytes(void) { return (long long)RGB_BLOCKS * 388 * 4; }
+
+extern "C" int hugs_rgb_bwd(int dtype, int M, int H, const void* Hact, int ldh, const float* W, const float* rgb,
+                            const float* d_rgb, float pad, void* G, int ldg, float* dW, float* db, void* ws, void* stream) {
+  HUGS_REQUIRE(H == 128, -3, "hugs_rgb_bwd: view width %d unsupported (128)", H);
+  if (M <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  int rpb = (M + RGB_BLOCKS - 1) / RGB_BLOCKS;
+  rpb = (rpb + 15) / 16 * 16;
+  const int nblk = (M + rpb - 1) / rpb;
+  float* slab = (float*)ws;
+  if (dtype) hipLaunchKernelGGL(k_rgb_bwd<true>, dim3(nblk), dim3(256), 0, st, M, H, rpb, Hact, ldh, W, rgb, d_rgb, pad, G, ldg, slab);
+  else hipLaunchKernelGGL(k_rgb_bwd<false>, dim3(nblk), dim3(256), 0, st, M, H, rpb, Hact, ldh, W, rgb, d_rgb, pad, G, ldg, slab);
+  hipLaunchKernelGGL(k_slab_reduce_small, dim3(2), dim3(256), 0, st, slab, nblk, 384, 388, dW);
+  hipLaunchKernelGGL(k_slab_reduce_small, dim3(1), dim3(64), 0, st, slab + 384, nblk, 3, 388, db);
+  HUGS_CHECK_LAUNCH("hugs_rgb_bwd");
+  return 0;
+}

@@ -1,0 +1,187 @@
+// Fused optimizer step on the flat fp32 parameter buffer: gradient statistics, per-module clip
+// (value then norm), nan_to_num, Adam, update statistics -- two streaming passes over the 36 MB
+// buffers instead of the reference's five pytree traversals; plus the compute-dtype weight casts
+// (natural [K,N] and transposed [N,K] copies the MFMA GEMMs read).
+//
+// Replaces (reference, MipNeRF360/internal/train_utils.py): :442 weight_l2s, :461-462 grad norms/maxes,
+// :351-369 clip_gradients, :466 nan_to_num, :468 apply_gradients (optax.adam, :487-512), :470-473
+// opt_update norms/maxes.
+#include "hugs_common.h"
+
+struct OptChunk { int off, len, leaf, module; };
+
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+  v = wave_sum_f(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ float block_max256(float v, float* red) {
+  v = wave_max_f(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// part1[chunk] = {sum g^2, max|g|, sum theta^2, sum clamp(g)^2}  (g already scaled by gscale = 1/world)
+__global__ __launch_bounds__(256) void k_opt_stats(const OptChunk* __restrict__ chunks, const float* __restrict__ theta,
+                                                   const float* __restrict__ grad, float gscale, float max_val,
+                                                   float* __restrict__ part1) {
+  __shared__ float red[4];
+  const OptChunk c = chunks[blockIdx.x];
+  float sg = 0.f, mg = 0.f, st = 0.f, sc = 0.f;
+  for (int i = threadIdx.x; i < c.len; i += 256) {
+    const float g = grad[c.off + i] * gscale, t = theta[c.off + i];
+    sg += g * g;
+    mg = fmaxf(mg, fabsf(g));   // NaN-ignoring like jnp.max? jnp.max propagates NaN; handled via sg
+    st += t * t;
+    const float gc = max_val > 0.f ? fminf(fmaxf(g, -max_val), max_val) : g;
+    sc += gc * gc;
+  }
+  sg = block_sum256(sg, red); mg = block_max256(mg, red); st = block_sum256(st, red); sc = block_sum256(sc, red);
+  if (threadIdx.x == 0) { float* o = part1 + (size_t)blockIdx.x * 4; o[0] = sg; o[1] = mg; o[2] = st; o[3] = sc; }
+}
+
+// single workgroup: leaf_stats[leaf] = {sum g^2, max|g|, sum theta^2}; mod_scale[m] = min(1, max_norm/(eps+|g_m|))
+__global__ void k_opt_finalize1(int nchunks, int nleaf, int nmod, const OptChunk* __restrict__ chunks,
+                                const float* __restrict__ part1, float max_norm, float* __restrict__ leaf_stats,
+                                float* __restrict__ mod_scale) {
+  __shared__ float s_modsq[16];
+  if (threadIdx.x < 16) s_modsq[threadIdx.x] = 0.f;
+  __syncthreads();
+  for (int leaf = threadIdx.x; leaf < nleaf; leaf += blockDim.x) {
+    float sg = 0.f, mg = 0.f, st = 0.f, sc = 0.f;
+    int module = 0;
+    for (int c = 0; c < nchunks; ++c)
+      if (chunks[c].leaf == leaf) {
+        const float* p = part1 + (size_t)c * 4;
+        sg += p[0]; mg = fmaxf(mg, p[1]); st += p[2]; sc += p[3];
+        module = chunks[c].module;
+      }
+    leaf_stats[leaf * 4] = sg; leaf_stats[leaf * 4 + 1] = mg; leaf_stats[leaf * 4 + 2] = st; leaf_stats[leaf * 4 + 3] = sc;
+    (void)module;
+  }
+  __syncthreads();
+  if (threadIdx.x < nmod) {   // fixed leaf order per module
+    float sq = 0.f;
+    for (int leaf = 0; leaf < nleaf; ++leaf) {
+      int module = -1;
+      for (int c = 0; c < nchunks; ++c) if (chunks[c].leaf == leaf) { module = chunks[c].module; break; }
+      if (module == (int)threadIdx.x) sq += leaf_stats[leaf * 4 + 3];
+    }
+    float mult = 1.f;
+    if (max_norm > 0.f) {
+      const float x = max_norm / (HUGS_EPS + sqrtf(sq));
+      mult = (x != x) ? x : fminf(1.f, x);   // jnp.minimum propagates NaN
+    }
+    mod_scale[threadIdx.x] = mult;
+  }
+}
+
+// Adam on one chunk per workgroup.  trainable[leaf] == 0 -> update forced to zero (optax.set_to_zero).
+// part2[chunk] = {sum delta^2, max|delta|}
+__global__ __launch_bounds__(256) void k_opt_adam(const OptChunk* __restrict__ chunks, float* __restrict__ theta,
+                                                  const float* __restrict__ grad, float* __restrict__ m,
+                                                  float* __restrict__ v, const float* __restrict__ mod_scale,
+                                                  const int* __restrict__ trainable, float gscale, float max_val,
+                                                  float lr, float b1, float b2, float eps, float bc1, float bc2,
+                                                  float* __restrict__ part2) {
+  __shared__ float red[4];
+  const OptChunk c = chunks[blockIdx.x];
+  float sd = 0.f, md = 0.f;
+  if (!trainable || trainable[c.leaf]) {
+    const float mult = mod_scale[c.module];
+    for (int i = threadIdx.x; i < c.len; i += 256) {
+      const int ix = c.off + i;
+      float g = grad[ix] * gscale;
+      if (max_val > 0.f) g = fminf(fmaxf(g, -max_val), max_val);
+      g = mult * g;
+      if (g != g) g = 0.f;                               // nan_to_num
+      else if (g == __builtin_inff()) g = 3.4028234664e38f;
+      else if (g == -__builtin_inff()) g = -3.4028234664e38f;
+      const float mi = b1 * m[ix] + (1.f - b1) * g;
+      const float vi = b2 * v[ix] + (1.f - b2) * g * g;
+      m[ix] = mi; v[ix] = vi;
+      const float delta = -lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+      const float t0 = theta[ix];
+      const float t1 = t0 + delta;
+      theta[ix] = t1;
+      const float d = t1 - t0;                           // the reference reports new - old
+      sd += d * d; md = fmaxf(md, fabsf(d));
+    }
+  }
+  sd = block_sum256(sd, red); md = block_max256(md, red);
+  if (threadIdx.x == 0) { part2[(size_t)blockIdx.x * 2] = sd; part2[(size_t)blockIdx.x * 2 + 1] = md; }
+}
+
+__global__ void k_opt_finalize2(int nchunks, int nleaf, const OptChunk* __restrict__ chunks,
+                                const float* __restrict__ part2, float* __restrict__ leaf_upd) {
+  for (int leaf = threadIdx.x; leaf < nleaf; leaf += blockDim.x) {
+    float sd = 0.f, md = 0.f;
+    for (int c = 0; c < nchunks; ++c)
+      if (chunks[c].leaf == leaf) { sd += part2[(size_t)c * 2]; md = fmaxf(md, part2[(size_t)c * 2 + 1]); }
+    leaf_upd[leaf * 2] = sd; leaf_upd[leaf * 2 + 1] = md;
+  }
+}
+
+// W fp32 [K,N] -> Wn (natural, [K,N]) and Wt (transposed, [N,K]) in the compute dtype. 32x32 LDS tiles.
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_cast_weights(int K, int N, const float* __restrict__ W, void* __restrict__ Wn,
+                                                      void* __restrict__ Wt) {
+  __shared__ float tile[32][33];
+  const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r, n = n0 + tx;
+    float x = 0.f;
+    if (k < K && n < N) {
+      x = W[(size_t)k * N + n];
+      if (Wn) { if (BF16) ((uint16_t*)Wn)[(size_t)k * N + n] = f_to_bf16(x); else ((float*)Wn)[(size_t)k * N + n] = x; }
+    }
+    tile[r][tx] = x;
+  }
+  __syncthreads();
+  if (Wt)
+    for (int r = ty; r < 32; r += 8) {
+      const int n = n0 + r, k = k0 + tx;
+      if (k < K && n < N) {
+        const float x = tile[tx][r];
+        if (BF16) ((uint16_t*)Wt)[(size_t)n * K + k] = f_to_bf16(x); else ((float*)Wt)[(size_t)n * K + k] = x;
+      }
+    }
+}
+
+extern "C" int hugs_opt_stats(int nchunks, int nleaf, int nmod, const void* chunks, const float* theta, const float* grad,
+                              float gscale, float max_val, float max_norm, float* part1_ws, float* leaf_stats,
+                              float* mod_scale, void* stream) {
+  HUGS_REQUIRE(nmod <= 16 && nleaf <= 1024, -3, "hugs_opt_stats: too many modules/leaves (%d/%d)", nmod, nleaf);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_opt_stats, dim3(nchunks), dim3(256), 0, st, (const OptChunk*)chunks, theta, grad, gscale, max_val, part1_ws);
+  hipLaunchKernelGGL(k_opt_finalize1, dim3(1), dim3(256), 0, st, nchunks, nleaf, nmod, (const OptChunk*)chunks, part1_ws,
+                     max_norm, leaf_stats, mod_scale);
+  HUGS_CHECK_LAUNCH("hugs_opt_stats");
+  return 0;
+}
+
+extern "C" int hugs_opt_adam(int nchunks, int nleaf, const void* chunks, float* theta, const float* grad, float* m, float* v,
+                             const float* mod_scale, const int* trainable, float gscale, float max_val, float lr, float b1,
+                             float b2, float eps, float bias_corr1, float bias_corr2, float* part2_ws, float* leaf_upd,
+                             void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_opt_adam, dim3(nchunks), dim3(256), 0, st, (const OptChunk*)chunks, theta, grad, m, v, mod_scale,
+                     trainable, gscale, max_val, lr, b1, b2, eps, bias_corr1, bias_corr2, part2_ws);
+  hipLaunchKernelGGL(k_opt_finalize2, dim3(1), dim3(256), 0, st, nchunks, nleaf, (const OptChunk*)chunks, part2_ws, leaf_upd);
+  HUGS_CHECK_LAUNCH("hugs_opt_adam");
+  return 0;
+}
+
+extern "C" int hugs_cast_weights(int dtype, int K, int N, const float* W, void* Wn, void* Wt, void* stream) {
+  if (K <= 0 || N <= 0) return 0;
+  dim3 grid((N + 31) / 32, (K + 31) / 32);
+  if (dtype) hipLaunchKernelGGL(k_cast_weights<true>, grid, dim3(256), 0, (hipStream_t)stream, K, N, W, Wn, Wt);
+  else hipLaunchKernelGGL(k_cast_weights<false>, grid, dim3(256), 0, (hipStream_t)stream, K, N, W, Wn, Wt);
+  HUGS_CHECK_LAUNCH("hugs_cast_weights");
+  return 0;
+}

@@ -1,0 +1,388 @@
+"""Kernel orchestration for one Model: parameter layout on a flat fp32 buffer, compute-dtype weight
+copies, the per-level forward (models.py:155-312 of the reference) and the hand-scheduled backward
+that replaces jax.value_and_grad (train_utils.py:454).  Python only sequences C-ABI launches on the
+current HIP stream; every tensor op on the path is a kernel from csrc/."""
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib
+from . import geopoly
+from . import stepfun
+
+CHUNK = 16384
+
+
+def _round_up(x, m):
+  return (x + m - 1) // m * m
+
+
+class MLPSpec:
+  """Static description of one MLP (models.py:359-391 attributes + gin bindings)."""
+
+  def __init__(self, name, is_prop, num_glo, **kw):
+    self.name = name
+    self.is_prop = is_prop
+    self.net_depth = 8
+    self.net_width = 256
+    self.bottleneck_width = 256
+    self.net_depth_viewdirs = 1
+    self.net_width_viewdirs = 128
+    self.min_deg_point = 0
+    self.max_deg_point = 12
+    self.skip_layer = 4
+    self.num_rgb_channels = 3
+    self.deg_view = 4
+    self.density_bias = -1.
+    self.rgb_premultiplier = 1.
+    self.rgb_bias = 0.
+    self.rgb_padding = 0.001
+    self.disable_rgb = False
+    self.warp_fn = None
+    self.basis_shape = 'icosahedron'
+    self.basis_subdivisions = 2
+    self.weight_init = 'he_uniform'
+    self.bottleneck_noise = 0.0
+    self.density_noise = 0.
+    for k, v in kw.items():
+      if not hasattr(self, k):
+        raise ValueError(f'{name} has no attribute {k!r}')
+      setattr(self, k, v)
+    self.num_glo = 0 if is_prop else num_glo
+    self._check()
+    self.basis = geopoly.generate_basis(self.basis_shape, self.basis_subdivisions).T.astype(np.float32).copy()  # [3,nb]
+    self.nb = self.basis.shape[1]
+    self.F = 2 * self.nb * (self.max_deg_point - self.min_deg_point)
+    self.Fp = _round_up(self.F, 64)
+    self.nd = 3 + 6 * self.deg_view
+    # Dense layers in flax creation order: (name, fan_in, fan_in_padded, fan_out, kind)
+    L, k = [], self.F
+    for i in range(self.net_depth):
+      concat_in = i > 0 and (i - 1) % self.skip_layer == 0 and (i - 1) > 0
+      L.append(dict(fan_in=k, kpad=(self.net_width + self.Fp) if concat_in else (_round_up(k, 64)),
+                    fan_out=self.net_width, kind='trunk', concat=concat_in))
+      k = self.net_width + self.F if (i % self.skip_layer == 0 and i > 0) else self.net_width
+    L.append(dict(fan_in=k, kpad=k, fan_out=1, kind='density'))
+    if not self.disable_rgb:
+      L.append(dict(fan_in=k, kpad=k, fan_out=self.bottleneck_width, kind='bottleneck'))
+      kv = self.bottleneck_width + self.nd + self.num_glo
+      L.append(dict(fan_in=kv, kpad=kv, fan_out=self.net_width_viewdirs, kind='view'))
+      L.append(dict(fan_in=self.net_width_viewdirs, kpad=self.net_width_viewdirs, fan_out=self.num_rgb_channels, kind='rgb'))
+    for i, l in enumerate(L):
+      l['name'] = f'Dense_{i}'
+    self.layers = L
+
+  def _check(self):
+    d = self.net_depth
+    if (d - 1) > 0 and (d - 1) % self.skip_layer == 0:
+      raise NotImplementedError('a skip-concat after the last trunk layer is not built')
+    if self.net_width % 128 or (not self.disable_rgb and (self.bottleneck_width % 128 or self.net_width_viewdirs != 128)):
+      raise NotImplementedError('MLP widths must be multiples of 128 (view width == 128) for the MFMA tiles')
+    if self.min_deg_point != 0 or self.net_depth_viewdirs != 1 or self.num_rgb_channels != 3:
+      raise NotImplementedError('min_deg_point != 0 / net_depth_viewdirs != 1 / num_rgb_channels != 3 are not built')
+    if self.bottleneck_noise > 0 or self.density_noise > 0:
+      raise NotImplementedError('bottleneck/density noise is not built')
+    if self.rgb_premultiplier != 1. or self.rgb_bias != 0.:
+      raise NotImplementedError('rgb_premultiplier / rgb_bias are not built')
+    if self.warp_fn is not None and getattr(self.warp_fn, 'name', self.warp_fn) != 'coord.contract':
+      raise NotImplementedError(f'warp_fn {self.warp_fn!r}: only @coord.contract is built')
+
+
+class ParamLayout:
+  """Flat fp32 parameter buffer: leaves in (module, layer, kernel|bias) order, kernels stored
+  [fan_in_padded, fan_out] row-major (flax [in,out] + zero rows), chunk table for the optimizer."""
+
+  def __init__(self, specs, num_embeddings, num_glo):
+    self.leaves = []   # dict(path, off, shape (logical), pshape (padded), module, leaf)
+    off = 0
+    self.modules = []
+    for spec in specs:
+      mid = len(self.modules)
+      self.modules.append(spec.name)
+      for l in spec.layers:
+        for kind in ('kernel', 'bias'):
+          shape = (l['fan_in'], l['fan_out']) if kind == 'kernel' else (l['fan_out'],)
+          pshape = (l['kpad'], l['fan_out']) if kind == 'kernel' else (l['fan_out'],)
+          n = int(np.prod(pshape))
+          self.leaves.append(dict(path=(spec.name, l['name'], kind), off=off, shape=shape, pshape=pshape,
+                                  module=mid, leaf=len(self.leaves), layer=l, spec=spec))
+          off += _round_up(n, 4)
+    if num_glo > 0:
+      mid = len(self.modules)
+      self.modules.append('GloEmbed_0')
+      n = num_embeddings * num_glo
+      self.leaves.append(dict(path=('GloEmbed_0', 'embedding'), off=off, shape=(num_embeddings, num_glo),
+                              pshape=(num_embeddings, num_glo), module=mid, leaf=len(self.leaves), layer=None, spec=None))
+      off += _round_up(n, 4)
+    self.size = off
+    chunks = []
+    for lf in self.leaves:
+      n = int(np.prod(lf['pshape']))
+      for s in range(0, n, CHUNK):
+        chunks.append((lf['off'] + s, min(CHUNK, n - s), lf['leaf'], lf['module']))
+    self.chunks = np.array(chunks, dtype=np.int32)
+    self.by_path = {lf['path']: lf for lf in self.leaves}
+
+  def view(self, flat, path, padded=False):
+    lf = self.by_path[path]
+    shp = lf['pshape'] if padded else lf['shape']
+    n = int(np.prod(shp))
+    return flat[lf['off']:lf['off'] + n].view(*shp)
+
+  def tree(self, flat):
+    """flax-style nested dict of views: {'params': {'NerfMLP_0': {'Dense_0': {'kernel','bias'}}, ...}}."""
+    out = {}
+    for lf in self.leaves:
+      d = out
+      for k in lf['path'][:-1]:
+        d = d.setdefault(k, {})
+      d[lf['path'][-1]] = self.view(flat, lf['path'])
+    return {'params': out}
+
+  def num_params(self):
+    return sum(int(np.prod(lf['shape'])) for lf in self.leaves)
+
+
+class Workspace:
+  """Named device buffers reused across steps (no allocation inside the timed loop)."""
+
+  def __init__(self, device):
+    self.device = device
+    self.bufs = {}
+
+  def get(self, name, shape, dtype=torch.float32, zero=False):
+    key = (name, tuple(shape), dtype)
+    b = self.bufs.get(key)
+    if b is None:
+      b = torch.empty(shape, dtype=dtype, device=self.device)
+      self.bufs[key] = b
+    if zero:
+      b.zero_()
+    return b
+
+
+class Engine:
+
+  def __init__(self, model, device, compute_dtype='bf16'):
+    if compute_dtype not in ('bf16', 'fp32'):
+      raise ValueError("compute_dtype must be 'bf16' or 'fp32'")
+    if not torch.cuda.is_available():
+      raise _lib.HugsError('no GPU visible: the hugs path has no CPU fallback')
+    _lib.lib()
+    self.model = model
+    self.device = torch.device(device)
+    self.dt = 1 if compute_dtype == 'bf16' else 0
+    self.tdt = torch.bfloat16 if self.dt else torch.float32
+    self.layout = model.layout
+    self.ws = Workspace(self.device)
+    self.wn, self.wt = {}, {}     # compute-dtype weight copies keyed by leaf path
+    self.basis = {s.name: torch.from_numpy(s.basis).to(self.device) for s in model.specs}
+    self.chunks = torch.from_numpy(self.layout.chunks).to(self.device)
+
+  # ---- weights ------------------------------------------------------------------------------------
+  def refresh_weights(self, theta):
+    """Cast the fp32 masters to the GEMM operand copies: Wn [Kp,N] (dX) and Wt [N,Kp] (forward)."""
+    for lf in self.layout.leaves:
+      if lf['path'][-1] != 'kernel' or lf['layer']['kind'] not in ('trunk', 'bottleneck', 'view'):
+        continue
+      l = lf['layer']
+      W = self.layout.view(theta, lf['path'], padded=True)
+      K = l['kpad'] if l['kind'] != 'view' else lf['spec'].bottleneck_width   # GEMM part of the view layer
+      N = l['fan_out']
+      key = lf['path']
+      if key not in self.wt:
+        self.wt[key] = torch.empty(N, K, dtype=self.tdt, device=self.device)
+        self.wn[key] = torch.empty(K, N, dtype=self.tdt, device=self.device) if self.dt else None
+      _lib.call('hugs_cast_weights', self.dt, K, N, W, self.wn[key], self.wt[key])
+      if not self.dt:
+        self.wn[key] = W[:K]      # fp32: the master itself is the natural-layout operand
+
+  # ---- forward ------------------------------------------------------------------------------------
+  def _mlp_forward(self, spec, theta, lvl, N, S, tdist, rays, glo, keep):
+    M = N * S
+    lay, ws, dt = self.layout, self.ws, self.dt
+    tag = f'{spec.name}/L{lvl}'
+    X0 = ws.get(tag + '/X0', (M, spec.Fp), self.tdt)
+    _lib.call('hugs_cast_ipe_fwd', N, S, tdist, rays['origins'], rays['directions'], rays['radii'], self.basis[spec.name],
+              spec.nb, 0 if self.model.ray_shape == 'cone' else 1, int(spec.warp_fn is not None), spec.max_deg_point,
+              dt, spec.Fp, X0)
+    acts = [X0]
+    x = X0
+    W = spec.net_width
+    for i in range(spec.net_depth):
+      l = spec.layers[i]
+      path = (spec.name, l['name'], 'kernel')
+      bias = lay.view(theta, (spec.name, l['name'], 'bias'))
+      Y = ws.get(f'{tag}/Y{i}', (M, W), self.tdt)
+      if l['concat']:
+        _lib.call('hugs_gemm_nt', dt, M, W, W, spec.Fp, x, W, X0, spec.Fp, self.wt[path], l['kpad'], bias, None, 1, 0, 1,
+                  None, 0, None, None, Y, W)
+      else:
+        K = l['kpad']
+        _lib.call('hugs_gemm_nt', dt, M, W, K, 0, x, K, None, 0, self.wt[path], K, bias, None, 1, 0, 1, None, 0, None,
+                  None, Y, W)
+      acts.append(Y)
+      x = Y
+    ld = spec.layers[spec.net_depth]
+    raw = ws.get(tag + '/raw', (M,))
+    density = ws.get(tag + '/density', (M,))
+    wd = lay.view(theta, (spec.name, ld['name'], 'kernel')).reshape(-1)
+    bd = lay.view(theta, (spec.name, ld['name'], 'bias'))
+    _lib.call('hugs_density_fwd', dt, M, W, x, W, wd, bd, spec.density_bias, raw, density)
+    out = dict(X0=X0, acts=acts, raw=raw, density=density, rgb=None)
+    if not spec.disable_rgb:
+      lb, lv, lr = spec.layers[spec.net_depth + 1:spec.net_depth + 4]
+      Bw, H = spec.bottleneck_width, spec.net_width_viewdirs
+      bott = ws.get(tag + '/bott', (M, Bw), self.tdt)
+      _lib.call('hugs_gemm_nt', dt, M, Bw, W, 0, x, W, None, 0, self.wt[(spec.name, lb['name'], 'kernel')], W,
+                lay.view(theta, (spec.name, lb['name'], 'bias')), None, 1, 0, 0, None, 0, None, None, bott, Bw)
+      Wv = lay.view(theta, (spec.name, lv['name'], 'kernel'))
+      rb = ws.get(tag + '/raybias', (N, H))
+      _lib.call('hugs_raybias_fwd', N, H, spec.nd, spec.num_glo, rays['dir_enc'], glo, Wv[Bw:],
+                lay.view(theta, (spec.name, lv['name'], 'bias')), rb)
+      hact = ws.get(tag + '/hview', (M, H), self.tdt)
+      _lib.call('hugs_gemm_nt', dt, M, H, Bw, 0, bott, Bw, None, 0, self.wt[(spec.name, lv['name'], 'kernel')], Bw, None, rb,
+                S, H, 1, None, 0, None, None, hact, H)
+      rgb = ws.get(tag + '/rgb', (M, 3))
+      _lib.call('hugs_rgb_fwd', dt, M, H, hact, H, lay.view(theta, (spec.name, lr['name'], 'kernel')),
+                lay.view(theta, (spec.name, lr['name'], 'bias')), spec.rgb_padding, rgb)
+      out.update(bott=bott, hview=hact, rgb=rgb)
+    return out
+
+  def forward(self, theta, rays, train_frac, u01, compute_extras, zero_glo=False):
+    """Model.__call__ (models.py:74-330).  rays: dict of contiguous [N,c] cuda tensors (+ 'dir_enc').
+    u01: None or list[num_levels] of U[0,1) draws.  Returns per-level dicts (device tensors; buffers are
+    reused by the next call)."""
+    mdl = self.model
+    N = rays['origins'].shape[0]
+    ws = self.ws
+    glo = None
+    if mdl.num_glo_features > 0:
+      glo = ws.get('glo', (N, mdl.num_glo_features))
+      emb = self.layout.view(theta, ('GloEmbed_0', 'embedding'))
+      _lib.call('hugs_glo_gather', N, mdl.num_glo_features, emb, rays['embed_idx'], int(zero_glo), glo)
+    if 'dir_enc' not in rays:
+      nd = mdl.nerf_spec.nd
+      rays['dir_enc'] = ws.get('dir_enc', (N, nd))
+      _lib.call('hugs_dir_enc_fwd', N, mdl.nerf_spec.deg_view, rays['viewdirs'], rays['dir_enc'])
+    if mdl.near_anneal_rate is None:
+      init_s_near = 0.
+    else:
+      init_s_near = float(np.clip(1 - train_frac / mdl.near_anneal_rate, 0, mdl.near_anneal_init))
+    init_s_far = 1.
+    sdist = ws.get('sdist_init', (N, 2))
+    sdist[:, 0] = init_s_near
+    sdist[:, 1] = init_s_far
+    weights = ws.get('w_init', (N, 1))
+    weights.fill_(1.0)
+    prod = 1
+    levels = []
+    for lvl in range(mdl.num_levels):
+      is_prop = lvl < mdl.num_levels - 1
+      S = mdl.num_prop_samples if is_prop else mdl.num_nerf_samples
+      dilation = mdl.dilation_bias + mdl.dilation_multiplier * (init_s_far - init_s_near) / prod
+      prod *= S
+      use_dilation = mdl.dilation_bias > 0 or mdl.dilation_multiplier > 0
+      if mdl.anneal_slope > 0:
+        anneal = (mdl.anneal_slope * train_frac) / ((mdl.anneal_slope - 1) * train_frac + 1)
+      else:
+        anneal = 1.
+      sd, td = stepfun.level_sample(sdist, weights, lvl > 0 and use_dilation, dilation, (init_s_near, init_s_far), anneal,
+                                    mdl.resample_padding, S, None if u01 is None else u01[lvl], mdl.raydist, rays['near'],
+                                    rays['far'])
+      spec = mdl.prop_spec if is_prop else mdl.nerf_spec
+      out = self._mlp_forward(spec, theta, lvl, N, S, td, rays, glo, True)
+      w = ws.get(f'L{lvl}/weights', (N, S))
+      rgb_all = ws.get('rgb_out_all', (mdl.num_levels, N, 3))
+      rgb_out = rgb_all[lvl]
+      extras = ws.get(f'L{lvl}/extras', (N, 5)) if compute_extras else None
+      _lib.call('hugs_composite_fwd', N, S, out['density'], out['rgb'], td, rays['directions'],
+                int(mdl.opaque_background), mdl.bg_intensity, rays['far'].reshape(-1), w, rgb_out, extras)
+      out.update(sdist=sd, tdist=td, weights=w, rgb_out=rgb_out, rgb_all=rgb_all, extras=extras, S=S, spec=spec, glo=glo)
+      levels.append(out)
+      sdist, weights = sd, w
+    return levels
+
+  # ---- backward -----------------------------------------------------------------------------------
+  def _nsplit(self, M, tiles):
+    step = 64 if self.dt else 16
+    units = M // step
+    want = max(1, min(units, (768 + tiles - 1) // tiles))
+    while units % want:
+      want -= 1
+    return want
+
+  def _tn(self, M, Kc, Nn, X, ldx, G, ldg, dW, db):
+    ns = self._nsplit(M, (Kc // 128) * (Nn // 128))
+    nbytes = _lib.lib().cdll.hugs_gemm_tn_ws_bytes(Kc, Nn, ns)
+    slab = self.ws.get('tn_slab', (max(nbytes // 4, 1),))
+    _lib.call('hugs_gemm_tn', self.dt, M, Kc, Nn, ns, X, ldx, G, ldg, dW, db, slab)
+
+  def backward_level(self, theta, grad, lv, rays, N, d_rgb_out, d_w_extra):
+    """Backward of one level: compositing -> heads -> trunk.  Writes (=, not +=) the level's MLP gradients
+    into `grad` (flat, same layout as theta); GLO embedding rows are scatter-added (caller zeroes them)."""
+    spec, S, lay, ws, dt = lv['spec'], lv['S'], self.layout, self.ws, self.dt
+    M = N * S
+    tag = f'{spec.name}/bwd'
+    W = spec.net_width
+    gview = lambda p, padded=False: lay.view(grad, p, padded)
+    d_density = ws.get(tag + '/d_density', (M,))
+    d_rgb_s = ws.get(tag + '/d_rgb_s', (M, 3)) if lv['rgb'] is not None else None
+    _lib.call('hugs_composite_bwd', N, S, lv['density'], lv['rgb'], lv['tdist'], rays['directions'],
+              int(self.model.opaque_background), self.model.bg_intensity, d_rgb_out, d_w_extra, d_density, d_rgb_s)
+    acts = lv['acts']
+    Ylast = acts[-1]
+    ld = spec.layers[spec.net_depth]
+    d_raw = ws.get(tag + '/d_raw', (M,))
+    dws = ws.get('dens_ws', (max(_lib.lib().cdll.hugs_density_bwd_ws_bytes(W) // 4, 1),))
+    _lib.call('hugs_density_bwd', dt, M, W, Ylast, W, d_density, lv['raw'], spec.density_bias, d_raw,
+              gview((spec.name, ld['name'], 'kernel')).reshape(-1), gview((spec.name, ld['name'], 'bias')), dws)
+    wd = lay.view(theta, (spec.name, ld['name'], 'kernel')).reshape(-1)
+    Ga = ws.get(tag + '/Ga', (M, W), self.tdt)
+    Gb = ws.get(tag + '/Gb', (M, W), self.tdt)
+    if spec.disable_rgb:
+      _lib.call('hugs_rank1_mask', dt, M, W, d_raw, wd, Ylast, W, Ga, W)
+    else:
+      lb, lvw, lr = spec.layers[spec.net_depth + 1:spec.net_depth + 4]
+      Bw, H = spec.bottleneck_width, spec.net_width_viewdirs
+      Gv = ws.get(tag + '/Gview', (M, H), self.tdt)
+      rws = ws.get('rgb_ws', (max(_lib.lib().cdll.hugs_rgb_bwd_ws_bytes() // 4, 1),))
+      _lib.call('hugs_rgb_bwd', dt, M, H, lv['hview'], H, lay.view(theta, (spec.name, lr['name'], 'kernel')), lv['rgb'],
+                d_rgb_s, spec.rgb_padding, Gv, H, gview((spec.name, lr['name'], 'kernel')),
+                gview((spec.name, lr['name'], 'bias')), rws)
+      gWv = gview((spec.name, lvw['name'], 'kernel'))
+      Wv = lay.view(theta, (spec.name, lvw['name'], 'kernel'))
+      d_rb = ws.get(tag + '/d_rb', (N, H))
+      demb = gview(('GloEmbed_0', 'embedding')) if spec.num_glo > 0 else None
+      _lib.call('hugs_raybias_bwd', dt, N, S, H, spec.nd, spec.num_glo, Gv, H, rays['dir_enc'], lv['glo'], Wv[Bw:],
+                rays.get('embed_idx'), d_rb, gWv[Bw:], demb)
+      # dWv[:Bw] = bott^T Gv ; db_v = colsum(Gv)
+      self._tn(M, Bw, H, lv['bott'], Bw, Gv, H, gWv[:Bw], gview((spec.name, lvw['name'], 'bias')))
+      # dBott = Gv Wv[:Bw]^T
+      dB = ws.get(tag + '/dBott', (M, Bw), self.tdt)
+      _lib.call('hugs_gemm_nt', dt, M, Bw, H, 0, Gv, H, None, 0, self.wn[(spec.name, lvw['name'], 'kernel')], H, None, None,
+                1, 0, 0, None, 0, None, None, dB, Bw)
+      self._tn(M, W, Bw, Ylast, W, dB, Bw, gview((spec.name, lb['name'], 'kernel')), gview((spec.name, lb['name'], 'bias')))
+      # G_last = (dBott Wb^T + d_raw (x) w_d) * (Ylast > 0)
+      _lib.call('hugs_gemm_nt', dt, M, W, Bw, 0, dB, Bw, None, 0, self.wn[(spec.name, lb['name'], 'kernel')], Bw, None, None,
+                1, 0, 0, Ylast, W, d_raw, wd, Ga, W)
+    G = Ga
+    other = Gb
+    X0 = lv['X0']
+    for i in range(spec.net_depth - 1, -1, -1):
+      l = spec.layers[i]
+      path = (spec.name, l['name'], 'kernel')
+      gW = gview(path, padded=True)
+      gb = gview((spec.name, l['name'], 'bias'))
+      xin = acts[i]          # acts[0] = X0, acts[i] = Y_{i-1}
+      if l['concat']:
+        self._tn(M, W, W, xin, W, G, W, gW[:W], gb)
+        self._tn(M, spec.Fp, W, X0, spec.Fp, G, W, gW[W:], None)
+      else:
+        self._tn(M, l['kpad'], W, xin, l['kpad'], G, W, gW, gb)
+      if i > 0:
+        # G_{i-1} = (G_i W_i[:W]^T) * (Y_{i-1} > 0)
+        _lib.call('hugs_gemm_nt', dt, M, W, W, 0, G, W, None, 0, self.wn[path][:W] if l['concat'] else self.wn[path], W, None,
+                  None, 1, 0, 0, acts[i], W, None, None, other, W)
+        G, other = other, G

@@ -1,0 +1,211 @@
+"""Model surface of the hot path (reference MipNeRF360/internal/models.py): `Model`, `construct_model`,
+`render_image`, with the reference's call signatures and result dictionaries.  Arithmetic lives in
+csrc/*.hip (see engine.py for the launch sequence)."""
+import math
+
+import numpy as np
+import torch
+
+from . import configs
+from . import engine as _engine
+from . import utils
+
+_MODEL_DEFAULTS = dict(
+    num_prop_samples=64, num_nerf_samples=32, num_levels=3, bg_intensity_range=(1., 1.), anneal_slope=10,
+    stop_level_grad=True, use_viewdirs=True, raydist_fn=None, ray_shape='cone', disable_integration=False,
+    single_jitter=True, dilation_multiplier=0.5, dilation_bias=0.0025, num_glo_features=0, num_transient_features=0,
+    num_embeddings=3500, near_anneal_rate=None, near_anneal_init=0.95, resample_padding=0.0, use_gpu_resampling=False,
+    opaque_background=False, beta_min=0.03)
+
+
+class Model:
+  """A mip-NeRF 360 model containing all MLPs (models.py:46-330).  Attributes are the gin-configurable
+  fields of the reference; `Model.*`, `NerfMLP.*`, `PropMLP.*` gin bindings are applied at construction."""
+
+  def __init__(self, config=None, compute_dtype=None, **overrides):
+    self.config = config
+    attrs = dict(_MODEL_DEFAULTS)
+    for k, v in {**configs.bindings('Model'), **overrides}.items():
+      if k not in attrs:
+        raise ValueError(f'Model has no attribute {k!r}')
+      attrs[k] = v
+    for k, v in attrs.items():
+      setattr(self, k, v)
+    tt = None if config is None else config.transient_type
+    if tt in [None, 'withmask', 'robustnerf']:
+      assert self.num_transient_features == 0
+    elif tt in ['nerfw', 'hanerf']:
+      raise NotImplementedError(f"transient_type {tt!r}: NeRF-W / HA-NeRF branches are not built (SURVEY 8a.28)")
+    else:
+      raise ValueError()
+    if self.ray_shape not in ('cone', 'cylinder'):
+      raise ValueError('ray_shape must be \'cone\' or \'cylinder\'')
+    if self.bg_intensity_range[0] != self.bg_intensity_range[1]:
+      raise NotImplementedError('randomised background intensity is not built (all HuGS gins use (1, 1))')
+    if not self.stop_level_grad or not self.use_viewdirs or self.disable_integration or self.use_gpu_resampling:
+      raise NotImplementedError('stop_level_grad=False / use_viewdirs=False / disable_integration / use_gpu_resampling')
+    self.bg_intensity = float(self.bg_intensity_range[0])
+    rd = self.raydist_fn
+    self.raydist = None if rd is None else {'jnp.reciprocal': 'reciprocal'}.get(getattr(rd, 'name', rd), getattr(rd, 'name', rd))
+    if self.raydist not in (None, 'reciprocal'):
+      raise NotImplementedError(f'raydist_fn {rd!r}: only None and @jnp.reciprocal are built')
+    self.nerf_spec = _engine.MLPSpec('NerfMLP_0', False, self.num_glo_features, **configs.bindings('NerfMLP'))
+    self.prop_spec = _engine.MLPSpec('PropMLP_0', True, self.num_glo_features, **configs.bindings('PropMLP'))
+    self.specs = [self.nerf_spec, self.prop_spec]
+    self.layout = _engine.ParamLayout(self.specs, self.num_embeddings, self.num_glo_features)
+    self.compute_dtype = compute_dtype or 'bf16'
+    self._engine = None
+
+  # -- engine / params ---------------------------------------------------------------------------------
+  def engine(self, device='cuda'):
+    if self._engine is None:
+      self._engine = _engine.Engine(self, device, self.compute_dtype)
+    return self._engine
+
+  def init(self, seed, device='cuda'):
+    """Random-init parameters: he_uniform kernels, zero biases (models.py:372,432-433), N(0,1/G) GLO rows
+    (flax nn.Embed default).  Returns the flat fp32 buffer."""
+    g = torch.Generator().manual_seed(int(seed))
+    flat = torch.zeros(self.layout.size, dtype=torch.float32)
+    for lf in self.layout.leaves:
+      v = self.layout.view(flat, lf['path'])
+      if lf['path'][-1] == 'kernel':
+        lim = math.sqrt(6.0 / lf['shape'][0])
+        v.copy_(((torch.rand(lf['shape'], generator=g, dtype=torch.float64) * 2 - 1) * lim).float())
+      elif lf['path'][-1] == 'embedding':
+        v.copy_((torch.randn(lf['shape'], generator=g, dtype=torch.float64) / math.sqrt(lf['shape'][1])).float())
+    return flat.to(device)
+
+  def variables(self, flat):
+    """flax-style view tree {'params': {...}} sharing memory with `flat` (reference TrainState.params)."""
+    return Variables(self.layout.tree(flat), flat)
+
+  def load_variables(self, flat, variables):
+    """Copy a flax-style nested dict (reference TrainState.params layout) into the flat buffer."""
+    for lf in self.layout.leaves:
+      d = variables['params'] if 'params' in variables else variables
+      for k in lf['path']:
+        d = d[k]
+      self.layout.view(flat, lf['path']).copy_(torch.as_tensor(np.asarray(d) if not torch.is_tensor(d) else d).to(flat.device))
+    return flat
+
+  # -- forward -----------------------------------------------------------------------------------------
+  def apply(self, variables, rng, rays, train_frac, compute_extras, zero_glo=False, zero_tra=False,
+            refresh_weights=True):
+    """Model.__call__ (models.py:74-330).  `variables`: flat buffer or the tree from variables().
+    `rng`: None (deterministic) or a torch.Generator on the GPU.  rays: utils.Rays with any leading
+    shape.  Returns (renderings, ray_history) as lists of dicts, one per level."""
+    flat = variables if torch.is_tensor(variables) else variables.flat
+    eng = self.engine(flat.device)
+    lead = rays.origins.shape[:-1]
+    r = rays_to_dict(rays, flat.device)
+    N = r['origins'].shape[0]
+    u01 = None
+    if rng is not None:
+      shape = (N,) if self.single_jitter else None
+      u01 = [torch.rand(shape if shape else (N, (self.num_prop_samples if l < self.num_levels - 1 else self.num_nerf_samples)),
+                        generator=rng, device=flat.device) for l in range(self.num_levels)]
+    if refresh_weights:
+      eng.refresh_weights(flat)
+    levels = eng.forward(flat, r, float(train_frac), u01, compute_extras, zero_glo)
+    renderings, history = [], []
+    n = 0 if self.config is None else self.config.vis_num_rays
+    for lv in levels:
+      S = lv['S']
+      rend = {'rgb': lv['rgb_out'].clone().reshape(lead + (3,))}
+      rgb_s = lv['rgb'].reshape(N, S, 3) if lv['rgb'] is not None else torch.zeros(N, S, 3, device=flat.device)
+      if compute_extras:
+        e = lv['extras']
+        rend['acc'] = e[:, 0].clone().reshape(lead)
+        rend['distance_mean'] = e[:, 1].clone().reshape(lead)
+        rend['distance_median'] = e[:, 2].clone().reshape(lead)
+        rend['distance_percentile_5'] = e[:, 3].clone().reshape(lead)
+        rend['distance_percentile_95'] = e[:, 4].clone().reshape(lead)
+        rend['ray_sdist'] = lv['sdist'][:n].clone()
+        rend['ray_weights'] = lv['weights'][:n].clone()
+        rend['ray_rgbs'] = rgb_s[:n].clone()
+      renderings.append(rend)
+      history.append(dict(density=lv['density'].clone().reshape(lead + (S,)), rgb=rgb_s.clone().reshape(lead + (S, 3)),
+                          sdist=lv['sdist'].clone().reshape(lead + (S + 1,)), weights=lv['weights'].clone().reshape(lead + (S,))))
+    if compute_extras:
+      # proposal levels show the final average colour (models.py:314-325)
+      final_rgb = (renderings[-1]['ray_rgbs'] * renderings[-1]['ray_weights'][..., None]).sum(-2)
+      for rr in renderings[:-1]:
+        rr['ray_rgbs'] = final_rgb[:, None, :].expand(rr['ray_rgbs'].shape).clone()
+    return renderings, history
+
+  __call__ = apply
+
+
+class Variables(dict):
+  """Nested parameter dict that remembers the flat buffer it views."""
+
+  def __init__(self, tree, flat):
+    super().__init__(tree)
+    self.flat = flat
+
+
+def rays_to_dict(rays, device):
+  f = lambda x, dt=torch.float32: x.reshape(-1, x.shape[-1]).to(device=device, dtype=dt).contiguous()
+  return dict(origins=f(rays.origins), directions=f(rays.directions), viewdirs=f(rays.viewdirs),
+              radii=f(rays.radii).reshape(-1), lossmult=f(rays.lossmult).reshape(-1),
+              static_mask=f(rays.static_mask).reshape(-1), near=f(rays.near).reshape(-1), far=f(rays.far).reshape(-1),
+              embed_idx=f(rays.embed_idx, torch.int32).reshape(-1))
+
+
+def construct_model(rng, rays, config, compute_dtype=None, device='cuda'):
+  """Construct a mip-NeRF 360 model (models.py:333-357).  `rng`: int seed.  Returns (model, variables) with
+  variables = the flat fp32 parameter buffer on `device` (use model.variables(flat) for the flax-style tree)."""
+  model = Model(config=config, compute_dtype=compute_dtype)
+  return model, model.init(rng if rng is not None else 0, device)
+
+
+def render_image(render_fn, rays, rng, config, verbose=True):
+  """Render all the pixels of an image in test mode (models.py:568-649).
+
+  render_fn(rng, chunk_rays) -> (renderings, ray_history) with a leading device axis of size 1 per process
+  (world_size > 1: each rank renders its slice of every chunk and the slices are all-gathered)."""
+  import torch.distributed as dist
+  height, width = rays.origins.shape[:2]
+  num_rays = height * width
+  rays = rays.map(lambda r: r.reshape((num_rays, -1)))
+  world = dist.get_world_size() if dist.is_initialized() else 1
+  rank = dist.get_rank() if dist.is_initialized() else 0
+  chunks = []
+  idx0s = range(0, num_rays, config.render_chunk_size)
+  for i_chunk, idx0 in enumerate(idx0s):
+    if verbose and i_chunk % max(1, len(idx0s) // 10) == 0:
+      print(f'Rendering chunk {i_chunk}/{len(idx0s)-1}')
+    chunk_rays = rays.map(lambda r: r[idx0:idx0 + config.render_chunk_size])
+    actual = chunk_rays.origins.shape[0]
+    rem = actual % world
+    padding = (world - rem) if rem != 0 else 0
+    if padding:
+      chunk_rays = chunk_rays.map(lambda r: torch.cat([r, r[-1:].expand(padding, -1)], 0))   # mode='edge'
+    per = chunk_rays.origins.shape[0] // world
+    local = chunk_rays.map(lambda r: r[rank * per:(rank + 1) * per])
+    chunk_renderings, _ = render_fn(rng, utils.shard(local))
+    # v[0] of the reference's all-gathered [ndev, n/ndev, ...] leaves == the full chunk
+    chunk_renderings = [{k: utils.unshard(v, padding) if not k.startswith('ray_') else v for k, v in r.items()}
+                        for r in chunk_renderings]
+    chunk_rendering = dict(chunk_renderings[-1])
+    for k in chunk_renderings[0]:
+      if k.startswith('ray_'):
+        chunk_rendering[k] = [r[k] for r in chunk_renderings]
+    chunks.append(chunk_rendering)
+  rendering = {}
+  for k in chunks[0]:
+    if k.startswith('ray_'):
+      rendering[k] = [torch.cat([c[k][l] for c in chunks]) for l in range(len(chunks[0][k]))]
+    else:
+      z = torch.cat([c[k] for c in chunks])
+      rendering[k] = z.reshape((height, width) + tuple(z.shape[1:]))
+  keys = [k for k in rendering if k.startswith('ray_')]
+  if keys:
+    n = rendering[keys[0]][0].shape[0]
+    # reference: random.permutation(PRNGKey(0), n)[:vis_num_rays]; JAX's threefry stream is not reproduced
+    #  -- a fixed torch permutation with seed 0 keeps the call deterministic.
+    ray_idx = torch.randperm(n, generator=torch.Generator().manual_seed(0))[:config.vis_num_rays]
+    for k in keys:
+      rendering[k] = [r[ray_idx.to(r.device)] for r in rendering[k]]
+  return rendering

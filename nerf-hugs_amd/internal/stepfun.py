@@ -1,0 +1,70 @@
+"""Step-function sampling entry points (reference MipNeRF360/internal/stepfun.py), HIP underneath.
+
+`sample_intervals` / `max_dilate_weights` keep the reference's argument meaning; the PRNG stays
+outside the kernels: callers pass the uniform draws (`u01`) the reference would have taken from
+`jax.random.uniform` (stepfun.py:203-209)."""
+import numpy as np
+import torch
+
+from .. import _lib
+
+EPS = float(np.finfo(np.float32).eps)
+
+
+def sample_u(num_samples, randomized, deterministic_center=True):
+  """Fixed part of the inverse-CDF abscissae (stepfun.py:191-209) and the jitter scale.
+  float64 host linspace rounded to float32 (jnp.linspace's own rounding is unpinned)."""
+  if not randomized:
+    if deterministic_center:
+      pad = 1 / (2 * num_samples)
+      u = np.linspace(pad, 1. - pad - EPS, num_samples)
+    else:
+      u = np.linspace(0, 1. - EPS, num_samples)
+    return u.astype(np.float32), 0.0
+  u_max = EPS + (1 - EPS) / num_samples
+  max_jitter = (1 - u_max) / (num_samples - 1) - EPS
+  return np.linspace(0, 1 - u_max, num_samples).astype(np.float32), max_jitter
+
+
+def level_sample(t_prev, w_prev, do_dilate, dilation, domain, anneal, resample_padding, num_samples, u01,
+                 raydist, near, far, return_debug=False):
+  """One hierarchical-sampling level (models.py:155-212): [dilate] -> logits -> sample_intervals -> s_to_t.
+
+  t_prev [N, n+1], w_prev [N, n] float32 cuda; u01: None (rng=None) or [N] / [N, num_samples] U[0,1) draws.
+  Returns sdist, tdist ([N, num_samples+1]) (+ idx, t_in, w_in when return_debug)."""
+  if num_samples <= 1:
+    raise ValueError(f'num_samples must be > 1, is {num_samples}.')
+  N, n_prev = w_prev.shape
+  dev = t_prev.device
+  ub, mj = sample_u(num_samples, u01 is not None)
+  ub = torch.from_numpy(ub).to(dev)
+  jitter, stride = None, 1
+  if u01 is not None:
+    jitter = (u01.to(torch.float32) * np.float32(mj)).contiguous()
+    stride = 1 if jitter.dim() == 1 or jitter.shape[-1] == 1 else num_samples
+  sdist = torch.empty(N, num_samples + 1, device=dev)
+  tdist = torch.empty_like(sdist)
+  idx = t_in = w_in = None
+  if return_debug:
+    n_in = 3 * n_prev - 2 if do_dilate else n_prev
+    idx = torch.empty(N, num_samples, dtype=torch.int32, device=dev)
+    t_in = torch.empty(N, n_in + 1, device=dev)
+    w_in = torch.empty(N, n_in, device=dev)
+  rd = {None: 0, 'reciprocal': 1}.get(raydist)
+  if rd is None:
+    raise NotImplementedError(f'raydist_fn {raydist!r}: only None and jnp.reciprocal are built (HuGS/360 gins)')
+  _lib.call('hugs_level_sample_fwd', N, t_prev.contiguous(), w_prev.contiguous(), n_prev, int(do_dilate), dilation,
+            domain[0], domain[1], anneal, resample_padding, ub, jitter, stride, num_samples, rd,
+            near.reshape(-1).contiguous(), far.reshape(-1).contiguous(), sdist, tdist, idx, t_in, w_in)
+  if return_debug:
+    return sdist, tdist, idx, t_in, w_in
+  return sdist, tdist
+
+
+def sample_intervals(u01, t, w_logits_weights, num_samples, single_jitter=False, domain=(-float('inf'), float('inf'))):
+  """stepfun.py:214-263 on weights (logits = log w; anneal 1, no dilation); returns sdist only."""
+  near = torch.zeros(t.shape[0], device=t.device)
+  far = torch.ones(t.shape[0], device=t.device)
+  lo = max(domain[0], -3.0e38)
+  hi = min(domain[1], 3.0e38)
+  return level_sample(t, w_logits_weights, False, 0., (lo, hi), 1.0, 0.0, num_samples, u01, None, near, far)[0]

@@ -1,0 +1,319 @@
+"""Training step and model creation (reference MipNeRF360/internal/train_utils.py): the same entry points
+(`setup_model`, `create_train_step`, `create_optimizer`, `create_render_fn`, `setup_finetune_model`) and the
+same `train_pstep(rngs, state, batch, train_frac, inlier_thresholds) -> (state, stats, rngs)` contract.
+
+One process drives one GPU; data parallelism = one process per GPU with a single RCCL all-reduce of the flat
+gradient buffer (+ the step's scalar stats in its tail) per step, replacing jax.lax.pmean
+(train_utils.py:457-459).  Loss normalisers stay per device, as in the reference (they run before pmean)."""
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .. import _lib
+from . import image
+from . import math as hmath
+from . import models
+from . import utils
+
+STAT_TAIL = 64  # floats appended to the gradient buffer for the per-step scalars that get pmean'ed
+
+
+class TrainState:
+  """Counterpart of flax TrainState (train_utils.py:509-512): .step, .params plus Adam moments, all views of
+  flat fp32 device buffers that the step updates in place (the reference donates its state too)."""
+
+  def __init__(self, model, flat, hyper):
+    self.model = model
+    self.flat = flat
+    self.m = torch.zeros_like(flat)
+    self.v = torch.zeros_like(flat)
+    self.step = 0
+    self.hyper = hyper           # dict(lr_fn, b1, b2, eps, trainable (device int32 per leaf) or None)
+    self.params = model.variables(flat)
+
+  def state_dict(self):
+    return {'step': self.step, 'params': self.flat, 'mu': self.m, 'nu': self.v}
+
+
+class LazyStats(dict):
+  """stats dict whose values materialise from one packed device->host copy on first access, so the step
+  stays asynchronous (the reference returns device arrays that the host reads every print_every)."""
+
+  def __init__(self, packed_dev, build):
+    super().__init__()
+    self._host = torch.empty(packed_dev.shape, dtype=packed_dev.dtype, pin_memory=True)
+    self._host.copy_(packed_dev, non_blocking=True)
+    self._ev = torch.cuda.Event()
+    self._ev.record()
+    self._build = build
+    self._done = False
+
+  def _mat(self):
+    if not self._done:
+      self._ev.synchronize()
+      super().update(self._build(self._host.numpy().copy()))
+      self._done = True
+
+  def __getitem__(self, k):
+    self._mat()
+    return super().__getitem__(k)
+
+  def __contains__(self, k):
+    self._mat()
+    return super().__contains__(k)
+
+  def keys(self):
+    self._mat()
+    return super().keys()
+
+  def items(self):
+    self._mat()
+    return super().items()
+
+  def __iter__(self):
+    self._mat()
+    return super().__iter__()
+
+  def get(self, k, d=None):
+    self._mat()
+    return super().get(k, d)
+
+
+def _world():
+  return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def create_optimizer(config, variables, model=None):
+  """Adam(lr schedule) state (train_utils.py:487-512).  variables: flat buffer."""
+  lr_fn = lambda step: hmath.learning_rate_decay(step, config.lr_init, config.lr_final, config.max_steps,
+                                                 config.lr_delay_steps, config.lr_delay_mult)
+  hyper = dict(lr_fn=lr_fn, b1=config.adam_beta1, b2=config.adam_beta2, eps=config.adam_eps, trainable=None)
+  return TrainState(model, variables, hyper), lr_fn
+
+
+def create_finetune_optimizer(config, variables, model=None):
+  """Adam on leaves whose path contains 'embedding', everything else frozen (train_utils.py:515-552)."""
+  lr_fn = lambda step: hmath.learning_rate_decay(step, config.finetune_lr_init, config.finetune_lr_final,
+                                                 config.finetune_max_steps, config.finetune_lr_delay_steps,
+                                                 config.finetune_lr_delay_mult)
+  tr = torch.tensor([1 if 'embedding' in lf['path'] else 0 for lf in model.layout.leaves], dtype=torch.int32,
+                    device=variables.device)
+  hyper = dict(lr_fn=lr_fn, b1=config.finetune_adam_beta1, b2=config.finetune_adam_beta2, eps=config.finetune_adam_eps,
+               trainable=tr)
+  return TrainState(model, variables, hyper), lr_fn
+
+
+def _summarize(layout, per_leaf, reduce, post=lambda x: x):
+  """summarize_tree (train_utils.py:61-69) to depth 3 from per-leaf values."""
+  groups = {}
+  for lf, val in zip(layout.leaves, per_leaf):
+    for d in range(1, len(lf['path']) + 1):
+      groups.setdefault('/'.join(lf['path'][:d]), []).append(val)
+  return {k: post(reduce(v)) for k, v in groups.items()}
+
+
+def create_train_step(model, config, is_finetune=False):
+  """Creates the training function (train_utils.py:372-484).  Returned callable:
+  train_pstep(rng, state, batch, train_frac, inlier_thresholds) -> (state, stats, rng)."""
+  layout = model.layout
+  L = model.num_levels
+  tt = None if is_finetune else config.transient_type
+  if tt not in (None, 'withmask', 'robustnerf'):
+    raise ValueError()
+  if tt == 'robustnerf':
+    assert config.robustnerf_inner_patch_size <= config.patch_size, \
+        'patch_size must be larger than robustnerf_inner_patch_size.'
+  if config.data_loss_type not in ('mse', 'charb'):
+    assert False
+  if not is_finetune and config.weight_decay_mults:
+    raise NotImplementedError('weight_decay_mults is not built (no shipped gin sets it)')
+  cache = {}
+
+  def train_step(rng, state, batch, train_frac, inlier_thresholds):
+    eng = model.engine(state.flat.device)
+    dev = state.flat.device
+    ws = eng.ws
+    world = _world()
+    rays = models.rays_to_dict(batch.rays, dev)
+    gt = batch.rgb[..., :3].reshape(-1, 3).to(device=dev, dtype=torch.float32).contiguous()
+    N = gt.shape[0]
+    if state.step == 0 and not eng.wt or cache.get('stale', True):
+      eng.refresh_weights(state.flat)
+      cache['stale'] = False
+    u01 = None
+    if config.randomized and rng is not None:
+      u01 = []
+      for l in range(L):
+        S = model.num_prop_samples if l < L - 1 else model.num_nerf_samples
+        u01.append(torch.rand((N,) if model.single_jitter else (N, S), generator=rng, device=dev))
+    levels = eng.forward(state.flat, rays, float(train_frac), u01, False, False)
+
+    grad = ws.get('grad', (layout.size + STAT_TAIL,))
+    tail = grad[layout.size:]
+    tail.zero_()
+    # ---- losses -------------------------------------------------------------------------------------
+    if 'coef' not in cache:
+      cache['coef'] = torch.tensor([config.data_coarse_loss_mult] * (L - 1) + [config.data_loss_mult],
+                                   dtype=torch.float32, device=dev)
+    pred = levels[0]['rgb_all']
+    d_pred = ws.get('d_pred', (L, N, 3))
+    mode, lm = 0, (None if config.disable_multiscale_loss else rays['lossmult'])
+    if tt == 'withmask':
+      mode, lm = 1, rays['static_mask']
+    elif tt == 'robustnerf':
+      P = config.patch_size
+      if N % (P * P):
+        raise ValueError('robustnerf needs whole patches per device')
+      thr = torch.as_tensor(np.asarray(inlier_thresholds, dtype=np.float32) if not torch.is_tensor(inlier_thresholds)
+                            else inlier_thresholds).to(device=dev, dtype=torch.float32).reshape(L, -1)[:, :1].contiguous()
+      mask = ws.get('robust_mask', (L, N))
+      err = ws.get('robust_err', (N,))
+      part = ws.get('robust_part', (N // (P * P) * 4,))
+      for l in range(L):
+        _lib.call('hugs_robust_mask', N // (P * P), P, pred[l], gt, thr[l], config.robustnerf_inlier_quantile,
+                  config.robustnerf_smoothed_filter_size, config.robustnerf_smoothed_inlier_quantile,
+                  config.robustnerf_inner_patch_size, config.robustnerf_inner_patch_inlier_quantile, mask[l], err, part,
+                  tail[16 + 5 * l:16 + 5 * l + 5])
+      mode, lm = 2, mask
+    _lib.call('hugs_data_loss', N, L, pred, gt, lm, mode, config.withmask_transient_weight,
+              int(config.data_loss_type == 'charb'), config.charb_padding, cache['coef'], d_pred, tail[0:2 * L])
+    fin = levels[-1]
+    Sf = fin['S']
+    d_w = [None] * L
+    loss_ray = ws.get('loss_ray', (N,))
+    if not is_finetune and config.interlevel_loss_mult > 0:
+      for l in range(L - 1):
+        d_w[l] = ws.get(f'd_w{l}', (N, levels[l]['S']))
+        _lib.call('hugs_interlevel', N, Sf, levels[l]['S'], fin['sdist'], fin['weights'], levels[l]['sdist'],
+                  levels[l]['weights'], config.interlevel_loss_mult / (N * Sf), loss_ray, d_w[l])
+        _lib.call('hugs_sum', N, loss_ray, 1.0 / (N * Sf), tail[8 + l:9 + l])
+    if not is_finetune and config.distortion_loss_mult > 0:
+      d_w[L - 1] = ws.get(f'd_w{L-1}', (N, Sf))
+      _lib.call('hugs_distortion', N, Sf, fin['sdist'], fin['weights'], config.distortion_loss_mult / N, loss_ray, d_w[L - 1])
+      _lib.call('hugs_sum', N, loss_ray, 1.0 / N, tail[12:13])
+    # ---- backward -----------------------------------------------------------------------------------
+    if model.num_glo_features > 0:
+      layout.view(grad, ('GloEmbed_0', 'embedding')).zero_()
+    prop_done = False
+    prop_lo = layout.by_path[('PropMLP_0', 'Dense_0', 'kernel')]['off']
+    last_prop = [lf for lf in layout.leaves if lf['path'][0] == 'PropMLP_0'][-1]
+    prop_hi = last_prop['off'] + int(np.prod(last_prop['pshape']))
+    for l in range(L - 1, -1, -1):
+      coef = config.data_loss_mult if l == L - 1 else config.data_coarse_loss_mult
+      is_prop = l < L - 1
+      if is_finetune and is_prop:
+        continue                       # proposal MLP gets no gradient in the finetune stage
+      if is_prop and d_w[l] is None and coef == 0:
+        continue
+      tgt = grad
+      if is_prop and prop_done:
+        tgt = ws.get('grad_tmp', (layout.size + STAT_TAIL,))
+      eng.backward_level(state.flat, tgt, levels[l], rays, N, d_pred[l] if coef != 0 else None, d_w[l])
+      if is_prop and prop_done:
+        _lib.call('hugs_add_inplace', prop_hi - prop_lo, tgt[prop_lo:prop_hi], grad[prop_lo:prop_hi])
+      if is_prop:
+        prop_done = True
+    if not prop_done:
+      grad[prop_lo:prop_hi].zero_()
+    # ---- pmean(grad), pmean(stats) ------------------------------------------------------------------
+    if world > 1:
+      dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+    gscale = 1.0 / world
+    # ---- clip + Adam --------------------------------------------------------------------------------
+    nch, nleaf, nmod = layout.chunks.shape[0], len(layout.leaves), len(layout.modules)
+    part1 = ws.get('opt_part1', (nch * 4,))
+    leaf_stats = ws.get('leaf_stats', (nleaf * 4 + nleaf * 2 + 16,))
+    mod_scale = leaf_stats[nleaf * 6:nleaf * 6 + 16]
+    _lib.call('hugs_opt_stats', nch, nleaf, nmod, eng.chunks, state.flat, grad, gscale, config.grad_max_val,
+              config.grad_max_norm, part1, leaf_stats[:nleaf * 4], mod_scale)
+    h = state.hyper
+    count = state.step                      # optax's 0-based update count
+    lr = h['lr_fn'](count)
+    t = count + 1
+    part2 = ws.get('opt_part2', (nch * 2,))
+    _lib.call('hugs_opt_adam', nch, nleaf, eng.chunks, state.flat, grad, state.m, state.v, mod_scale, h['trainable'], gscale,
+              config.grad_max_val, lr, h['b1'], h['b2'], h['eps'], 1.0 - h['b1']**t, 1.0 - h['b2']**t, part2,
+              leaf_stats[nleaf * 4:nleaf * 6])
+    eng.refresh_weights(state.flat)
+    state.step += 1
+    # ---- stats (lazy) -------------------------------------------------------------------------------
+    packed = ws.get('stats_packed', (STAT_TAIL + nleaf * 6 + 16,))
+    packed[:STAT_TAIL].copy_(tail)
+    if world > 1:
+      packed[:STAT_TAIL].mul_(gscale)
+    packed[STAT_TAIL:].copy_(leaf_stats)
+
+    def build(hst):
+      tl = hst[:STAT_TAIL]
+      ls = hst[STAT_TAIL:STAT_TAIL + nleaf * 4].reshape(nleaf, 4)
+      lu = hst[STAT_TAIL + nleaf * 4:STAT_TAIL + nleaf * 6].reshape(nleaf, 2)
+      T = lambda x: torch.tensor(np.asarray(x, dtype=np.float32))
+      stats = {}
+      mses = tl[0:2 * L:2]
+      dls = tl[1:2 * L:2]
+      losses = {'data': float(config.data_coarse_loss_mult * dls[:-1].sum() + config.data_loss_mult * dls[-1])}
+      if not is_finetune and config.interlevel_loss_mult > 0:
+        losses['interlevel'] = float(config.interlevel_loss_mult * tl[8:8 + L - 1].sum())
+      if not is_finetune and config.distortion_loss_mult > 0:
+        losses['distortion'] = float(config.distortion_loss_mult * tl[12])
+      stats['losses'] = {k: T(v) for k, v in losses.items()}
+      stats['loss'] = T(sum(losses.values()))
+      stats['mses'] = T(mses)
+      stats['psnrs'] = image.mse_to_psnr(stats['mses'])
+      stats['psnr'] = stats['psnrs'][-1]
+      if tt == 'robustnerf':
+        r = tl[16:16 + 5 * L].reshape(L, 5)
+        for i, k in enumerate(['inlier_threshold', 'is_inlier_loss', 'has_inlier_neighbors', 'is_inlier_patch', 'mask']):
+          stats['robust_' + k] = T(r[:, i])
+      stats['weight_l2s'] = {k: T(v) for k, v in _summarize(layout, ls[:, 2], sum).items()}
+      stats['grad_norms'] = {k: T(v) for k, v in _summarize(layout, ls[:, 0], sum, math.sqrt).items()}
+      stats['grad_maxes'] = {k: T(v) for k, v in _summarize(layout, ls[:, 1], max).items()}
+      stats['opt_update_norms'] = {k: T(v) for k, v in _summarize(layout, lu[:, 0], sum, math.sqrt).items()}
+      stats['opt_update_maxes'] = {k: T(v) for k, v in _summarize(layout, lu[:, 1], max).items()}
+      return stats
+
+    return state, LazyStats(packed, build), rng
+
+  return train_step
+
+
+def create_render_fn(model, config):
+  """Creates the full-image render function (train_utils.py:555-576):
+  render_eval_pfn(variables, train_frac, _, rays) -> (renderings, ray_history) with the reference's leading
+  device axis (size = world size after the all-gather)."""
+
+  def render_eval_fn(variables, train_frac, _, rays):
+    lead = rays.origins.shape[:2]
+    flat_rays = rays.map(lambda r: r.reshape((-1, r.shape[-1])))
+    rend, hist = model.apply(variables, None, flat_rays, train_frac=train_frac, compute_extras=True,
+                             zero_glo=config.enable_render_zero_glo, zero_tra=config.enable_render_zero_tra)
+    world = _world()
+
+    def gather(v):
+      if world == 1:
+        return v[None]
+      out = [torch.empty_like(v) for _ in range(world)]
+      dist.all_gather(out, v.contiguous())
+      return torch.stack(out)
+
+    return [{k: gather(v) for k, v in r.items()} for r in rend], [{k: gather(v) for k, v in h.items()} for h in hist]
+
+  return render_eval_fn
+
+
+def setup_model(config, rng, compute_dtype=None, device='cuda'):
+  """Creates NeRF model, optimizer, and train/render functions (train_utils.py:579-596)."""
+  model, variables = models.construct_model(rng, utils.dummy_rays(), config, compute_dtype=compute_dtype, device=device)
+  state, lr_fn = create_optimizer(config, variables, model)
+  render_eval_pfn = create_render_fn(model, config)
+  train_pstep = create_train_step(model, config, False)
+  return model, state, render_eval_pfn, train_pstep, lr_fn
+
+
+def setup_finetune_model(config, model, state):
+  """train_utils.py:599-608."""
+  new_state, lr_fn = create_finetune_optimizer(config, state.flat, model)
+  train_pstep = create_train_step(model, config, True)
+  return new_state, train_pstep, lr_fn

@@ -403,13 +403,17 @@ def init_params(cfg, seed=20200823, dtype=torch.float32):
   return {'params': params}
 
 
-def mlp_forward(cfg, mod, which, feats, viewdirs, glo_vec):
-  """models.py:406-550 (no transient branch). feats [...,S,504]."""
+def mlp_forward(cfg, mod, which, feats, viewdirs, glo_vec, taps=None):
+  """models.py:406-550 (no transient branch). feats [...,S,504].  taps: optional list that receives the
+  relu pre-activations (tests use it to find samples sitting on a ReLU kink)."""
   depth = cfg.nerf_depth if which == 'nerf' else cfg.prop_depth
   x, inputs = feats, feats
   for i in range(depth):
     L = mod[f'Dense_{i}']
-    x = torch.relu(x @ L['kernel'] + L['bias'])
+    pre = x @ L['kernel'] + L['bias']
+    if taps is not None:
+      taps.append(pre.detach())
+    x = torch.relu(pre)
     if i % cfg.skip_layer == 0 and i > 0:
       x = torch.cat([x, inputs], -1)
   L = mod[f'Dense_{depth}']
@@ -424,7 +428,10 @@ def mlp_forward(cfg, mod, which, feats, viewdirs, glo_vec):
     parts.append(glo_vec[..., None, :].expand(bott.shape[:-1] + (-1,)))
   x = torch.cat(parts, -1)
   L = mod[f'Dense_{depth + 2}']
-  x = torch.relu(x @ L['kernel'] + L['bias'])
+  pre = x @ L['kernel'] + L['bias']
+  if taps is not None:
+    taps.append(pre.detach())
+  x = torch.relu(pre)
   L = mod[f'Dense_{depth + 3}']
   rgb = torch.sigmoid(x @ L['kernel'] + L['bias'])
   return density, rgb * (1 + 2 * cfg.rgb_padding) - cfg.rgb_padding
@@ -442,7 +449,7 @@ def sample_u_base(num_samples, randomized):
   return np.linspace(0, 1 - u_max, num_samples).astype(np.float32), max_jitter
 
 
-def model_forward(cfg, variables, rays, train_frac, u01, compute_extras, zero_glo=False):
+def model_forward(cfg, variables, rays, train_frac, u01, compute_extras, zero_glo=False, taps=None):
   """Model.__call__ (models.py:74-330).  rays: dict of [N,c] tensors.  u01: None
   (rng=None) or list[num_levels] of [N] float32 uniform draws (single_jitter)."""
   P = variables['params']
@@ -479,8 +486,11 @@ def model_forward(cfg, variables, rays, train_frac, u01, compute_extras, zero_gl
     lm, lv = lift_and_diagonalize(means, covs, basis)
     feats = integrated_pos_enc(lm, lv, 0, cfg.max_deg_point)
     which = 'prop' if is_prop else 'nerf'
+    lvl_taps = None if taps is None else []
     density, rgb = mlp_forward(cfg, P['PropMLP_0' if is_prop else 'NerfMLP_0'], which, feats,
-                               rays['viewdirs'], None if is_prop else glo)
+                               rays['viewdirs'], None if is_prop else glo, lvl_taps)
+    if taps is not None:
+      taps.append(lvl_taps)
     weights = compute_alpha_weights(density, tdist, rays['directions'], cfg.opaque_background)[0]
     rend = volumetric_rendering(rgb, weights, tdist, cfg.bg_intensity, far, compute_extras)
     renderings.append(rend)

@@ -1,0 +1,75 @@
+"""GPU parity of the hand-written backward chain (compositing -> heads -> MFMA trunk) against torch.autograd
+of the oracle, level by level, with random upstream gradients.
+
+Two float32 implementations disagree on which side of a ReLU kink a pre-activation of magnitude ~1e-7 lies; one
+such flip changes a weight gradient by one sample's contribution (~1e-3 of the leaf's max).  The test removes
+that ambiguity instead of loosening the tolerance: rays that own a sample whose oracle pre-activation is within
+5e-6 of zero get zero upstream gradient on both sides, and the rest must agree to 2e-4 of each leaf's max."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('variant', ['base2', 'default3_warp_glo'])
+def test_backward_chain_vs_autograd(variant):
+  from tests import hugs_testlib as H
+  from tests.test_gpu_train_step import SMALL
+  from oracle import torch_ref as R
+  from nerf_hugs_amd.internal import models as M
+  gin = list(SMALL)
+  near, far = 0.1, 1.2
+  if variant == 'default3_warp_glo':
+    gin = [g for g in SMALL if not g.startswith('Model.num_')] + [
+        "Model.num_levels = 3", "Model.num_prop_samples = 64", "Model.num_nerf_samples = 32",
+        "Model.raydist_fn = @jnp.reciprocal", "NerfMLP.warp_fn = @coord.contract", "PropMLP.warp_fn = @coord.contract",
+        "Model.num_glo_features = 4"]
+    near, far = (0.05, 0.3), 1e6
+  config, model, state, _, _, cfg, oparams = H.make_pair(gin)
+  batch = H.synth_rays(1, 8, 5, near=near, far=far)
+  N, L = 64, model.num_levels
+  gen = torch.Generator(device='cuda').manual_seed(11)
+  u01 = [torch.rand(N, generator=gen, device='cuda') for _ in range(L)]
+  orays = H.oracle_rays(batch)
+  eng = model.engine('cuda')
+  eng.refresh_weights(state.flat)
+  rays = M.rays_to_dict(batch.rays, 'cuda')
+  levels = eng.forward(state.flat, rays, 0.37, u01, False)
+  leaves = R.flat_leaves(oparams['params'])
+  req = [v.clone().requires_grad_(True) for _, v in leaves]
+  P = {}
+  for (name, _), v in zip(leaves, req):
+    d = P
+    ks = name.split('/')
+    for k in ks[:-1]:
+      d = d.setdefault(k, {})
+    d[ks[-1]] = v
+  taps = []
+  rend, hist = R.model_forward(cfg, {'params': P}, orays, 0.37, [u.cpu() for u in u01], False, taps=taps)
+  torch.manual_seed(0)
+  for l in range(L):
+    S = levels[l]['S']
+    safe = torch.ones(N, dtype=torch.bool)
+    for pre in taps[l]:
+      safe &= ~(pre.abs() < 5e-6).reshape(N, -1).any(-1)
+    assert safe.float().mean() > 0.15, 'too few kink-free rays for a meaningful check'
+    dw = torch.randn(N, S) * safe[:, None]
+    drgb = torch.randn(N, 3) * safe[:, None]
+    obj = (hist[l]['weights'] * dw).sum() + (rend[l]['rgb'] * drgb).sum()
+    og = torch.autograd.grad(obj, req, allow_unused=True, retain_graph=True)
+    grad = torch.zeros(model.layout.size + 64, device='cuda')
+    eng.backward_level(state.flat, grad, levels[l], rays, N, drgb.cuda().contiguous(), dw.cuda().contiguous())
+    torch.cuda.synchronize()
+    checked = 0
+    for (name, _), g_o in zip(leaves, og):
+      if g_o is None:
+        continue
+      g = model.layout.view(grad, tuple(name.split('/'))).cpu().double()
+      sc = float(g_o.double().abs().max())
+      if sc == 0:
+        continue
+      err = float((g - g_o.double()).abs().max()) / sc
+      assert err < 2e-4, f'level {l} {name}: rel err {err:.2e}'
+      checked += 1
+    assert checked >= 10
