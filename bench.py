@@ -1,0 +1,179 @@
+"""Headline benchmark: training rays/sec of the Mip-NeRF 360 hot path (BASELINE.json: 1024-ray batch,
+64 proposal + 128 fine samples, NerfMLP 8x1024 + PropMLP 4x256, Kubric base gin) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A step = forward + losses + backward + RCCL all-reduce + clip/Adam + weight re-cast on one batch of
+synthetic rays already resident in HBM (data: synthetic).  Weak scaling: 1024 rays per GPU.
+Prints ONE JSON line (rank 0) with `roofline` for the dominant kernel (bf16 NT GEMM of the NerfMLP trunk,
+timed live with HIP events around back-to-back launches on the compute stream) and `cpu_baseline`
+(the oracle = CPU restatement of the reference, timed on a bounded sample at N=1)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GIN = ["Config.patch_size = 16", "Config.data_loss_type = 'mse'", "Config.distortion_loss_mult = 0.",
+       "Config.near = 0.1", "Config.far = 1.2", "Model.opaque_background = True", "Model.num_levels = 2",
+       "Model.num_prop_samples = 64", "Model.num_nerf_samples = 128", "PropMLP.net_depth = 4",
+       "PropMLP.net_width = 256", "PropMLP.disable_rgb = True", "NerfMLP.net_depth = 8", "NerfMLP.net_width = 1024"]
+FLOP_TRAIN_PER_RAY = 6.5036e9   # SURVEY 8d / BASELINE.md work model, cfg2
+PEAK_BF16 = 2.5e15              # dense MFMA peak (MI355X_MICROARCH.md)
+
+
+def synth_batch(n_patch, P, seed, device):
+  from nerf_hugs_amd.internal import utils
+  rng = np.random.default_rng(seed)
+  shp = (n_patch, P, P)
+  d = rng.normal(size=shp + (3,))
+  d = d / np.linalg.norm(d, axis=-1, keepdims=True) * rng.uniform(0.8, 1.2, shp + (1,))
+  f = lambda a, dt=np.float32: torch.from_numpy(np.ascontiguousarray(a.astype(dt))).to(device)
+  rays = utils.Rays(pix_coords=f(rng.uniform(size=shp + (2,))), origins=f(rng.normal(size=shp + (3,)) * 0.5),
+                    directions=f(d), viewdirs=f(d / np.linalg.norm(d, axis=-1, keepdims=True)),
+                    radii=f(rng.uniform(5e-4, 2e-3, shp + (1,))), lossmult=f(np.ones(shp + (1,))),
+                    static_mask=f(np.ones(shp + (1,))), near=f(np.full(shp + (1,), 0.1)), far=f(np.full(shp + (1,), 1.2)),
+                    embed_idx=f(np.zeros(shp + (1,)), np.int32), cam_idx=f(np.zeros(shp + (1,)), np.int32))
+  return utils.Batch(rays=rays, rgb=f(rng.uniform(size=shp + (3,))))
+
+
+def gemm_roofline(device):
+  """Dominant kernel: k_gemm_nt_bf16 at the NerfMLP trunk shape [131072,1024]x[1024,1024]; HIP events on the
+  launch stream around 20 back-to-back launches."""
+  from nerf_hugs_amd import _lib
+  M, N, K = 131072, 1024, 1024
+  A = torch.randn(M, K, device=device).bfloat16()
+  Bt = (torch.randn(N, K, device=device) / 32).bfloat16()
+  bias = torch.zeros(N, device=device)
+  out = torch.empty(M, N, device=device, dtype=torch.bfloat16)
+  call = lambda: _lib.call('hugs_gemm_nt', 1, M, N, K, 0, A, K, None, 0, Bt, K, bias, None, 1, 0, 1, None, 0, None, None, out, N)
+  for _ in range(3):
+    call()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  reps = 20
+  e0.record()
+  for _ in range(reps):
+    call()
+  e1.record()
+  torch.cuda.synchronize()
+  dt = e0.elapsed_time(e1) / reps * 1e-3
+  tf = 2.0 * M * N * K / dt / 1e12
+  return {"bound": "mfma", "kernel": "k_gemm_nt_bf16 [131072x1024]x[1024x1024] bias+relu", "achieved": round(tf, 1),
+          "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(tf * 1e12 / PEAK_BF16, 4), "traffic": None,
+          "avg_us": round(dt * 1e6, 1)}
+
+
+def cpu_baseline(seed):
+  """Oracle (CPU restatement of the reference) full training step on a bounded sample: 64 rays of the same
+  workload (same nets, 64+128 samples), all host cores."""
+  from oracle import torch_ref as R
+  ncores = int(os.environ.get('HUGS_CPU_THREADS', min(os.cpu_count(), 16)))
+  torch.set_num_threads(ncores)
+  cfg = R.kubric_cfg(num_levels=2, num_prop_samples=64, num_nerf_samples=128)
+  params = R.init_params(cfg, seed)
+  n = 64
+  rng = np.random.default_rng(seed)
+  d = rng.normal(size=(n, 3)); d = d / np.linalg.norm(d, axis=-1, keepdims=True) * rng.uniform(0.8, 1.2, (n, 1))
+  T = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.float32)))
+  rays = dict(origins=T(rng.normal(size=(n, 3)) * 0.5), directions=T(d), viewdirs=T(d / np.linalg.norm(d, axis=-1, keepdims=True)),
+              radii=T(rng.uniform(5e-4, 2e-3, (n, 1))), lossmult=T(np.ones((n, 1))), static_mask=T(np.ones((n, 1))),
+              near=T(np.full((n, 1), 0.1)), far=T(np.full((n, 1), 1.2)), embed_idx=torch.zeros(n, 1, dtype=torch.int32))
+  gt = T(rng.uniform(size=(n, 3)))
+  leaves = {nme: v for nme, v in R.flat_leaves(params['params'])}
+  m = {k: torch.zeros_like(v) for k, v in leaves.items()}
+  v_ = {k: torch.zeros_like(v) for k, v in leaves.items()}
+
+  def step(i):
+    u01 = [torch.rand(n) for _ in range(2)]
+    stats, grads, _, _ = R.loss_and_grad(cfg, params, rays, gt, 0.5, u01)
+    g = R.clip_gradients(cfg, grads)
+    R.adam_update(cfg, leaves, g, m, v_, i)
+
+  step(0)
+  t0 = time.time()
+  k = 0
+  while time.time() - t0 < 12.0 or k < 2:
+    step(k + 1)
+    k += 1
+  dt = (time.time() - t0) / k
+  return {"value": round(n / dt, 2), "unit": "rays/s", "cores": ncores, "kind": "port",
+          "sample": f"{k} full train steps of 64 rays x (64+128) samples, oracle/torch_ref.py fp32"}
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=20)
+  ap.add_argument('--warmup', type=int, default=5)
+  ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  args = ap.parse_args()
+  import torch.distributed as dist
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local = int(os.environ.get('LOCAL_RANK', '0'))
+  if args.gpus > 1 and world == 1:
+    raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
+  torch.cuda.set_device(local)
+  device = torch.device('cuda', local)
+  if world > 1:
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', device_id=device)
+  from nerf_hugs_amd.internal import configs, train_utils
+  configs.clear_config()
+  configs.parse_config_files_and_bindings(None, GIN)
+  config = configs.make_config(batch_size=1024 * world)
+  model, state, _, train_step, _ = train_utils.setup_model(config, 20200823, compute_dtype=args.dtype, device=device)
+  rays_per_gpu = 1024
+  batch = synth_batch(rays_per_gpu // 256, 16, 1000 + rank, device)
+  gen = torch.Generator(device=device).manual_seed(7 + rank)
+  thr = np.ones((model.num_levels, 1), np.float32)
+  for _ in range(args.warmup):
+    state, stats, gen = train_step(gen, state, batch, 0.5, thr)
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    state, stats, gen = train_step(gen, state, batch, 0.5, thr)
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  if world > 1:
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+  loss = float(stats['loss'])
+  psnr = float(stats['psnr'])
+  if rank == 0:
+    rps = rays_per_gpu * world * args.steps / dt
+    line = {
+        "metric": "train rays/sec (1024-ray batch per GPU, 64+128 samples)", "value": round(rps, 1), "unit": "rays/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "configs[1]: MipNeRF360 base (kubric_1024_base.gin nets), 1024 rays x (64 prop + 128 fine) per GPU, "
+                               "full train step", "rays_per_gpu": rays_per_gpu, "global_batch": rays_per_gpu * world,
+                   "parallelism": f"dp{world}", "params": model.layout.num_params()},
+        "train_psnr_last": round(psnr, 3), "loss_last": round(loss, 6),
+        "step_mfma_frac": round(rps / world * FLOP_TRAIN_PER_RAY / (PEAK_BF16 if args.dtype == 'bf16' else 157.3e12), 4),
+    }
+    if args.dtype == 'bf16':
+      line["roofline"] = gemm_roofline(device)
+    if world == 1 and not args.no_cpu_baseline:
+      line["cpu_baseline"] = cpu_baseline(20200823)
+    print(json.dumps(line))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -32,8 +32,8 @@ _PROTOS = {
     'hugs_distortion': 'iippfpps',
     'hugs_sum': 'ipfps',
     'hugs_add_inplace': 'qpps',
-    'hugs_opt_stats': 'iiipppfffppps',
-    'hugs_opt_adam': 'iipppppppffffffffpps',
+    'hugs_opt_stats': 'iiippppfffppps',
+    'hugs_opt_adam': 'iippppppppffffffffpps',
     'hugs_cast_weights': 'iiippps',
 }
 _CT = {'i': ctypes.c_int, 'f': ctypes.c_float, 'p': ctypes.c_void_p, 'q': ctypes.c_longlong,

@@ -100,13 +100,23 @@ __global__ __launch_bounds__(256) void k_wcolsum(int M, int K, int rows_per_blk,
   }
 }
 
-__global__ void k_slab_reduce_small(const float* __restrict__ slab, int nblk, int width, int stride,
-                                    float* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= width) return;
+// out[i] = sum_b slab[b*stride + i], i < width.  1024 threads = 64 columns x 16 row groups, fixed order.
+__global__ __launch_bounds__(1024) void k_slab_reduce_small(const float* __restrict__ slab, int nblk, int width, int stride,
+                                                            float* __restrict__ out) {
+  __shared__ float red[16][65];
+  const int cx = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + cx;
   float a = 0.f;
-  for (int b = 0; b < nblk; ++b) a += slab[(size_t)b * stride + i];
-  out[i] = a;
+  if (i < width)
+    for (int b = rg; b < nblk; b += 16) a += slab[(size_t)b * stride + i];
+  red[rg][cx] = a;
+  __syncthreads();
+  if (rg == 0 && i < width) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][cx];
+    out[i] = t;
+  }
 }
 
 // out[m,n] = r[m] * c[n] * (Y[m,n] > 0)   (PropMLP: gradient entering the last trunk layer)
@@ -153,17 +163,23 @@ __global__ void k_segsum(int nrays, int S, int H, const void* __restrict__ G, in
   }
   d_rb[i] = a;
 }
-__global__ void k_raybias_bwd_w(int nrays, int H, int nd, int ng, const float* __restrict__ dir_enc,
-                                const float* __restrict__ glo, const float* __restrict__ d_rb,
-                                float* __restrict__ dWv_tail) {
-  // one thread per (c, j); sequential over rays (deterministic).  (nd+ng)*H <= ~10k threads.
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (nd + ng) * H) return;
-  const int c = i / H, j = i % H;
+__global__ __launch_bounds__(1024) void k_raybias_bwd_w(int nrays, int H, int nd, int ng, const float* __restrict__ dir_enc,
+                                                        const float* __restrict__ glo, const float* __restrict__ d_rb,
+                                                        float* __restrict__ dWv_tail) {
+  // one workgroup per encoding column c: 128 j-lanes x 8 ray groups, LDS reduce in fixed order (H == 128)
+  __shared__ float red[8][129];
+  const int c = blockIdx.x, j = threadIdx.x & 127, rg = threadIdx.x >> 7;
   float a = 0.f;
-  if (c < nd) for (int r = 0; r < nrays; ++r) a += dir_enc[r * nd + c] * d_rb[(size_t)r * H + j];
-  else for (int r = 0; r < nrays; ++r) a += glo[r * ng + (c - nd)] * d_rb[(size_t)r * H + j];
-  dWv_tail[i] = a;
+  if (c < nd) for (int r = rg; r < nrays; r += 8) a += dir_enc[r * nd + c] * d_rb[(size_t)r * H + j];
+  else for (int r = rg; r < nrays; r += 8) a += glo[r * ng + (c - nd)] * d_rb[(size_t)r * H + j];
+  red[rg][j] = a;
+  __syncthreads();
+  if (rg == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += red[g][j];
+    dWv_tail[c * H + j] = t;
+  }
 }
 __global__ void k_glo_bwd(int nrays, int H, int nd, int ng, const float* __restrict__ d_rb,
                           const float* __restrict__ Wv_tail, const int* __restrict__ embed_idx,
@@ -272,7 +288,7 @@ extern "C" int hugs_density_fwd(int dtype, int M, int K, const void* Y, int ldy,
   return 0;
 }
 
-#define WCS_BLOCKS 2048
+#define WCS_BLOCKS 512
 extern "C" long long hugs_density_bwd_ws_bytes(int K) { return (long long)WCS_BLOCKS * (K + 4) * 4; }
 
 // d_raw = d_density * sigmoid(raw + bias); dw[K] = Y^T d_raw; db = sum d_raw
@@ -287,8 +303,8 @@ extern "C" int hugs_density_bwd(int dtype, int M, int K, const void* Y, int ldy,
   float* slab = (float*)ws;
   if (dtype) hipLaunchKernelGGL(k_wcolsum<true>, dim3(nblk), dim3(256), 0, st, M, K, rpb, Y, ldy, d_raw, slab);
   else hipLaunchKernelGGL(k_wcolsum<false>, dim3(nblk), dim3(256), 0, st, M, K, rpb, Y, ldy, d_raw, slab);
-  hipLaunchKernelGGL(k_slab_reduce_small, dim3((K + 255) / 256), dim3(256), 0, st, slab, nblk, K, K + 4, dw);
-  hipLaunchKernelGGL(k_slab_reduce_small, dim3(1), dim3(64), 0, st, slab + K, nblk, 1, K + 4, db);
+  hipLaunchKernelGGL(k_slab_reduce_small, dim3((K + 63) / 64), dim3(1024), 0, st, slab, nblk, K, K + 4, dw);
+  hipLaunchKernelGGL(k_slab_reduce_small, dim3(1), dim3(1024), 0, st, slab + K, nblk, 1, K + 4, db);
   HUGS_CHECK_LAUNCH("hugs_density_bwd");
   return 0;
 }
@@ -325,11 +341,12 @@ extern "C" int hugs_raybias_fwd(int nrays, int H, int nd, int ng, const float* d
 extern "C" int hugs_raybias_bwd(int dtype, int nrays, int S, int H, int nd, int ng, const void* G, int ldg,
                                 const float* dir_enc, const float* glo, const float* Wv_tail, const int* embed_idx,
                                 float* d_rb, float* dWv_tail, float* d_embedding, void* stream) {
+  HUGS_REQUIRE(H == 128, -3, "hugs_raybias_bwd: view width %d unsupported (128)", H);
   if (nrays <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (dtype) hipLaunchKernelGGL(k_segsum<true>, dim3((nrays * H + 255) / 256), dim3(256), 0, st, nrays, S, H, G, ldg, d_rb);
   else hipLaunchKernelGGL(k_segsum<false>, dim3((nrays * H + 255) / 256), dim3(256), 0, st, nrays, S, H, G, ldg, d_rb);
-  hipLaunchKernelGGL(k_raybias_bwd_w, dim3(((nd + ng) * H + 63) / 64), dim3(64), 0, st, nrays, H, nd, ng, dir_enc, glo, d_rb, dWv_tail);
+  hipLaunchKernelGGL(k_raybias_bwd_w, dim3(nd + ng), dim3(1024), 0, st, nrays, H, nd, ng, dir_enc, glo, d_rb, dWv_tail);
   if (ng > 0 && d_embedding)
     hipLaunchKernelGGL(k_glo_bwd, dim3((nrays * ng + 255) / 256), dim3(256), 0, st, nrays, H, nd, ng, d_rb, Wv_tail, embed_idx, d_embedding);
   HUGS_CHECK_LAUNCH("hugs_raybias_bwd");
@@ -361,8 +378,8 @@ extern "C" int hugs_rgb_bwd(int dtype, int M, int H, const void* Hact, int ldh, 
   float* slab = (float*)ws;
   if (dtype) hipLaunchKernelGGL(k_rgb_bwd<true>, dim3(nblk), dim3(256), 0, st, M, H, rpb, Hact, ldh, W, rgb, d_rgb, pad, G, ldg, slab);
   else hipLaunchKernelGGL(k_rgb_bwd<false>, dim3(nblk), dim3(256), 0, st, M, H, rpb, Hact, ldh, W, rgb, d_rgb, pad, G, ldg, slab);
-  hipLaunchKernelGGL(k_slab_reduce_small, dim3(2), dim3(256), 0, st, slab, nblk, 384, 388, dW);
-  hipLaunchKernelGGL(k_slab_reduce_small, dim3(1), dim3(64), 0, st, slab + 384, nblk, 3, 388, db);
+  hipLaunchKernelGGL(k_slab_reduce_small, dim3(6), dim3(1024), 0, st, slab, nblk, 384, 388, dW);
+  hipLaunchKernelGGL(k_slab_reduce_small, dim3(1), dim3(1024), 0, st, slab + 384, nblk, 3, 388, db);
   HUGS_CHECK_LAUNCH("hugs_rgb_bwd");
   return 0;
 }

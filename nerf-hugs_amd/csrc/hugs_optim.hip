@@ -44,33 +44,25 @@ __global__ __launch_bounds__(256) void k_opt_stats(const OptChunk* __restrict__ 
   if (threadIdx.x == 0) { float* o = part1 + (size_t)blockIdx.x * 4; o[0] = sg; o[1] = mg; o[2] = st; o[3] = sc; }
 }
 
-// single workgroup: leaf_stats[leaf] = {sum g^2, max|g|, sum theta^2}; mod_scale[m] = min(1, max_norm/(eps+|g_m|))
-__global__ void k_opt_finalize1(int nchunks, int nleaf, int nmod, const OptChunk* __restrict__ chunks,
+// single workgroup: leaf_stats[leaf] = {sum g^2, max|g|, sum theta^2, sum clamp(g)^2};
+// mod_scale[m] = min(1, max_norm/(eps+|g_m|)).  leaf_info[leaf] = {chunk_begin, chunk_end, module, 0}.
+__global__ void k_opt_finalize1(int nleaf, int nmod, const int4* __restrict__ leaf_info,
                                 const float* __restrict__ part1, float max_norm, float* __restrict__ leaf_stats,
                                 float* __restrict__ mod_scale) {
-  __shared__ float s_modsq[16];
-  if (threadIdx.x < 16) s_modsq[threadIdx.x] = 0.f;
-  __syncthreads();
   for (int leaf = threadIdx.x; leaf < nleaf; leaf += blockDim.x) {
+    const int4 li = leaf_info[leaf];
     float sg = 0.f, mg = 0.f, st = 0.f, sc = 0.f;
-    int module = 0;
-    for (int c = 0; c < nchunks; ++c)
-      if (chunks[c].leaf == leaf) {
-        const float* p = part1 + (size_t)c * 4;
-        sg += p[0]; mg = fmaxf(mg, p[1]); st += p[2]; sc += p[3];
-        module = chunks[c].module;
-      }
+    for (int c = li.x; c < li.y; ++c) {
+      const float* p = part1 + (size_t)c * 4;
+      sg += p[0]; mg = fmaxf(mg, p[1]); st += p[2]; sc += p[3];
+    }
     leaf_stats[leaf * 4] = sg; leaf_stats[leaf * 4 + 1] = mg; leaf_stats[leaf * 4 + 2] = st; leaf_stats[leaf * 4 + 3] = sc;
-    (void)module;
   }
   __syncthreads();
-  if (threadIdx.x < nmod) {   // fixed leaf order per module
+  if ((int)threadIdx.x < nmod) {   // fixed leaf order per module
     float sq = 0.f;
-    for (int leaf = 0; leaf < nleaf; ++leaf) {
-      int module = -1;
-      for (int c = 0; c < nchunks; ++c) if (chunks[c].leaf == leaf) { module = chunks[c].module; break; }
-      if (module == (int)threadIdx.x) sq += leaf_stats[leaf * 4 + 3];
-    }
+    for (int leaf = 0; leaf < nleaf; ++leaf)
+      if (leaf_info[leaf].z == (int)threadIdx.x) sq += leaf_stats[leaf * 4 + 3];
     float mult = 1.f;
     if (max_norm > 0.f) {
       const float x = max_norm / (HUGS_EPS + sqrtf(sq));
@@ -116,12 +108,12 @@ __global__ __launch_bounds__(256) void k_opt_adam(const OptChunk* __restrict__ c
   if (threadIdx.x == 0) { part2[(size_t)blockIdx.x * 2] = sd; part2[(size_t)blockIdx.x * 2 + 1] = md; }
 }
 
-__global__ void k_opt_finalize2(int nchunks, int nleaf, const OptChunk* __restrict__ chunks,
-                                const float* __restrict__ part2, float* __restrict__ leaf_upd) {
+__global__ void k_opt_finalize2(int nleaf, const int4* __restrict__ leaf_info, const float* __restrict__ part2,
+                                float* __restrict__ leaf_upd) {
   for (int leaf = threadIdx.x; leaf < nleaf; leaf += blockDim.x) {
+    const int4 li = leaf_info[leaf];
     float sd = 0.f, md = 0.f;
-    for (int c = 0; c < nchunks; ++c)
-      if (chunks[c].leaf == leaf) { sd += part2[(size_t)c * 2]; md = fmaxf(md, part2[(size_t)c * 2 + 1]); }
+    for (int c = li.x; c < li.y; ++c) { sd += part2[(size_t)c * 2]; md = fmaxf(md, part2[(size_t)c * 2 + 1]); }
     leaf_upd[leaf * 2] = sd; leaf_upd[leaf * 2 + 1] = md;
   }
 }
@@ -153,26 +145,27 @@ __global__ __launch_bounds__(256) void k_cast_weights(int K, int N, const float*
     }
 }
 
-extern "C" int hugs_opt_stats(int nchunks, int nleaf, int nmod, const void* chunks, const float* theta, const float* grad,
+extern "C" int hugs_opt_stats(int nchunks, int nleaf, int nmod, const void* chunks, const void* leaf_info,
+                              const float* theta, const float* grad,
                               float gscale, float max_val, float max_norm, float* part1_ws, float* leaf_stats,
                               float* mod_scale, void* stream) {
   HUGS_REQUIRE(nmod <= 16 && nleaf <= 1024, -3, "hugs_opt_stats: too many modules/leaves (%d/%d)", nmod, nleaf);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_opt_stats, dim3(nchunks), dim3(256), 0, st, (const OptChunk*)chunks, theta, grad, gscale, max_val, part1_ws);
-  hipLaunchKernelGGL(k_opt_finalize1, dim3(1), dim3(256), 0, st, nchunks, nleaf, nmod, (const OptChunk*)chunks, part1_ws,
-                     max_norm, leaf_stats, mod_scale);
+  hipLaunchKernelGGL(k_opt_finalize1, dim3(1), dim3(256), 0, st, nleaf, nmod, (const int4*)leaf_info, part1_ws, max_norm,
+                     leaf_stats, mod_scale);
   HUGS_CHECK_LAUNCH("hugs_opt_stats");
   return 0;
 }
 
-extern "C" int hugs_opt_adam(int nchunks, int nleaf, const void* chunks, float* theta, const float* grad, float* m, float* v,
+extern "C" int hugs_opt_adam(int nchunks, int nleaf, const void* chunks, const void* leaf_info, float* theta, const float* grad, float* m, float* v,
                              const float* mod_scale, const int* trainable, float gscale, float max_val, float lr, float b1,
                              float b2, float eps, float bias_corr1, float bias_corr2, float* part2_ws, float* leaf_upd,
                              void* stream) {
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_opt_adam, dim3(nchunks), dim3(256), 0, st, (const OptChunk*)chunks, theta, grad, m, v, mod_scale,
                      trainable, gscale, max_val, lr, b1, b2, eps, bias_corr1, bias_corr2, part2_ws);
-  hipLaunchKernelGGL(k_opt_finalize2, dim3(1), dim3(256), 0, st, nchunks, nleaf, (const OptChunk*)chunks, part2_ws, leaf_upd);
+  hipLaunchKernelGGL(k_opt_finalize2, dim3(1), dim3(256), 0, st, nleaf, (const int4*)leaf_info, part2_ws, leaf_upd);
   HUGS_CHECK_LAUNCH("hugs_opt_adam");
   return 0;
 }

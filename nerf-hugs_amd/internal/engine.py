@@ -122,6 +122,11 @@ class ParamLayout:
       for s in range(0, n, CHUNK):
         chunks.append((lf['off'] + s, min(CHUNK, n - s), lf['leaf'], lf['module']))
     self.chunks = np.array(chunks, dtype=np.int32)
+    info = []
+    for lf in self.leaves:
+      idx = np.nonzero(self.chunks[:, 2] == lf['leaf'])[0]
+      info.append((int(idx[0]), int(idx[-1]) + 1, lf['module'], 0))
+    self.leaf_info = np.array(info, dtype=np.int32)
     self.by_path = {lf['path']: lf for lf in self.leaves}
 
   def view(self, flat, path, padded=False):
@@ -179,6 +184,7 @@ class Engine:
     self.wn, self.wt = {}, {}     # compute-dtype weight copies keyed by leaf path
     self.basis = {s.name: torch.from_numpy(s.basis).to(self.device) for s in model.specs}
     self.chunks = torch.from_numpy(self.layout.chunks).to(self.device)
+    self.leaf_info = torch.from_numpy(self.layout.leaf_info).to(self.device)
 
   # ---- weights ------------------------------------------------------------------------------------
   def refresh_weights(self, theta):

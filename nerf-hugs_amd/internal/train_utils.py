@@ -226,14 +226,14 @@ def create_train_step(model, config, is_finetune=False):
     part1 = ws.get('opt_part1', (nch * 4,))
     leaf_stats = ws.get('leaf_stats', (nleaf * 4 + nleaf * 2 + 16,))
     mod_scale = leaf_stats[nleaf * 6:nleaf * 6 + 16]
-    _lib.call('hugs_opt_stats', nch, nleaf, nmod, eng.chunks, state.flat, grad, gscale, config.grad_max_val,
+    _lib.call('hugs_opt_stats', nch, nleaf, nmod, eng.chunks, eng.leaf_info, state.flat, grad, gscale, config.grad_max_val,
               config.grad_max_norm, part1, leaf_stats[:nleaf * 4], mod_scale)
     h = state.hyper
     count = state.step                      # optax's 0-based update count
     lr = h['lr_fn'](count)
     t = count + 1
     part2 = ws.get('opt_part2', (nch * 2,))
-    _lib.call('hugs_opt_adam', nch, nleaf, eng.chunks, state.flat, grad, state.m, state.v, mod_scale, h['trainable'], gscale,
+    _lib.call('hugs_opt_adam', nch, nleaf, eng.chunks, eng.leaf_info, state.flat, grad, state.m, state.v, mod_scale, h['trainable'], gscale,
               config.grad_max_val, lr, h['b1'], h['b2'], h['eps'], 1.0 - h['b1']**t, 1.0 - h['b2']**t, part2,
               leaf_stats[nleaf * 4:nleaf * 6])
     eng.refresh_weights(state.flat)

@@ -449,7 +449,8 @@ def sample_u_base(num_samples, randomized):
   return np.linspace(0, 1 - u_max, num_samples).astype(np.float32), max_jitter
 
 
-def model_forward(cfg, variables, rays, train_frac, u01, compute_extras, zero_glo=False, taps=None):
+def model_forward(cfg, variables, rays, train_frac, u01, compute_extras, zero_glo=False, taps=None,
+                  override_samples=None, override_feats=None):
   """Model.__call__ (models.py:74-330).  rays: dict of [N,c] tensors.  u01: None
   (rng=None) or list[num_levels] of [N] float32 uniform draws (single_jitter)."""
   P = variables['params']
@@ -480,11 +481,15 @@ def model_forward(cfg, variables, rays, train_frac, u01, compute_extras, zero_gl
         near.numpy(), far.numpy())
     sdist = torch.from_numpy(sd).to(dt)          # stop_gradient (models.py:208-209)
     tdist = torch.from_numpy(td).to(dt)
+    if override_samples is not None:   # tests: feed the sampler output of the implementation under test
+      sdist, tdist = override_samples[lvl][0].to(dt), override_samples[lvl][1].to(dt)
     means, covs = cast_rays(tdist, rays['origins'], rays['directions'], rays['radii'], cfg.ray_shape)
     if cfg.warp:
       means, covs = contract_track_linearize(means, covs)
     lm, lv = lift_and_diagonalize(means, covs, basis)
     feats = integrated_pos_enc(lm, lv, 0, cfg.max_deg_point)
+    if override_feats is not None:     # tests: identical MLP inputs on both sides
+      feats = override_feats[lvl].to(dt)
     which = 'prop' if is_prop else 'nerf'
     lvl_taps = None if taps is None else []
     density, rgb = mlp_forward(cfg, P['PropMLP_0' if is_prop else 'NerfMLP_0'], which, feats,

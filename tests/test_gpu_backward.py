@@ -46,7 +46,13 @@ def test_backward_chain_vs_autograd(variant):
       d = d.setdefault(k, {})
     d[ks[-1]] = v
   taps = []
-  rend, hist = R.model_forward(cfg, {'params': P}, orays, 0.37, [u.cpu() for u in u01], False, taps=taps)
+  # identical sample positions on both sides (level>0 positions are an ill-conditioned function of the
+  # proposal weights; their own parity is covered by test_gpu_train_step / test_gpu_stepfun)
+  ov = [(lv['sdist'].cpu(), lv['tdist'].cpu()) for lv in levels]
+  F = model.nerf_spec.F
+  ofe = [lv['X0'][:, :F].float().cpu().reshape(N, lv['S'], F) for lv in levels]   # the encoder has its own test
+  rend, hist = R.model_forward(cfg, {'params': P}, orays, 0.37, [u.cpu() for u in u01], False, taps=taps,
+                               override_samples=ov, override_feats=ofe)
   torch.manual_seed(0)
   for l in range(L):
     S = levels[l]['S']
@@ -70,6 +76,7 @@ def test_backward_chain_vs_autograd(variant):
       if sc == 0:
         continue
       err = float((g - g_o.double()).abs().max()) / sc
-      assert err < 2e-4, f'level {l} {name}: rel err {err:.2e}'
+      tol = 2e-4
+      assert err < tol, f'level {l} {name}: rel err {err:.2e}'
       checked += 1
     assert checked >= 10

@@ -75,7 +75,8 @@ def _run_case(gin, n_patch=1, P=8, near=0.1, far=1.2, seed=5, inlier=None, tol_g
     name = '/'.join(lf['path'])
     d_prod = (model.layout.view(state.flat, lf['path']) - model.layout.view(theta0, lf['path'])).cpu().double()
     d_orc = (newp[name] - p0[name]).double()
-    assert float((d_prod - d_orc).abs().max()) <= 1e-4 * float(d_orc.abs().max()) + 1e-12, f'update {name}'
+    # new - old is quantised to ulp(theta) (theta ~ 0.1 -> 7.5e-9) on both sides
+    assert float((d_prod - d_orc).abs().max()) <= 1e-4 * float(d_orc.abs().max()) + 3e-8, f'update {name}'
   if inlier is not None:
     for k in ['inlier_threshold', 'is_inlier_loss', 'has_inlier_neighbors', 'is_inlier_patch', 'mask']:
       np.testing.assert_allclose(stats['robust_' + k].numpy(), ostats['robust_' + k].detach().numpy(), rtol=2e-4, atol=1e-6, err_msg=k)
