@@ -1,0 +1,134 @@
+/* hugs.h -- C ABI of the MI355X-native Mip-NeRF 360 per-ray hot path (libhugs_hip.so, gfx950).
+ *
+ * The reference (cnhaox/NeRF-HuGS, MipNeRF360/internal/*.py) has no FFI layer: models.py / train_utils.py
+ * call jax.numpy directly and XLA is the backend.  These entry points are what an FFI for that path would
+ * bind; each cites the reference function it replaces (paths relative to MipNeRF360/internal/).
+ *
+ * Conventions: every pointer is a caller-owned DEVICE pointer (host pointers only where stated); nothing is
+ * allocated, no stream is created, no global state is kept; `stream` is a hipStream_t; kernels are enqueued
+ * and the call returns.  Return 0 = ok, <0 = error (message via hugs_last_error(), thread local):
+ *   -2 invalid argument for which the reference raises ValueError, -3 unsupported shape, -100 launch failure.
+ * dtype: 0 = float32 (parity mode, v_mfma_f32_16x16x4_f32), 1 = bfloat16 operands with fp32 accumulate.
+ * Activations/weights in `dtype`, everything per-ray / per-sample scalar in float32.  Row-major.
+ */
+#ifndef HUGS_H
+#define HUGS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int hugs_version(void);
+const char* hugs_last_error(void);
+int hugs_device_count(void);
+
+/* models.py:155-212 level prologue = stepfun.py:99-128 max_dilate_weights (renormalize) -> [1:-1] trim ->
+ * models.py:191-193 annealed logits -> stepfun.py:131-161 softmax CDF + math.py:108-127 sorted_interp ->
+ * stepfun.py:214-263 sample_intervals -> coord.py:63-99 s_to_t.  One wavefront per ray.
+ * t_prev [nrays, n_prev+1], w_prev [nrays, n_prev]; u = u_base[j] + jitter[ray*jitter_stride (+j)] (jitter may
+ * be NULL = rng None).  raydist 0 linear / 1 reciprocal.  Outputs sdist,tdist [nrays, num_samples+1];
+ * optional test hooks idx_out [nrays,num_samples] (CDF interval index), t_in_out/w_in_out (the dilated,
+ * trimmed step function).  Bit-exact against oracle/stepfun_ref.c.  -2 if num_samples <= 1 (stepfun.py:239). */
+int hugs_level_sample_fwd(int nrays, const float* t_prev, const float* w_prev, int n_prev, int do_dilate,
+                          float dilation, float domain_lo, float domain_hi, float anneal, float resample_padding,
+                          const float* u_base, const float* jitter, int jitter_stride, int num_samples, int raydist,
+                          const float* near, const float* far, float* sdist, float* tdist, int32_t* idx_out,
+                          float* t_in_out, float* w_in_out, void* stream);
+
+/* render.py:103-127 cast_rays (cone :44-78 / cylinder :81-100, lift_gaussian :21-41 diag=False) ->
+ * coord.py:21-27,39-60 contract + track_linearize (closed-form Jacobian) -> coord.py:129-133
+ * lift_and_diagonalize -> coord.py:102-126 integrated_pos_enc.  out [nrays*num_samples, row_pitch] in
+ * bf16/fp32, columns >= 2*num_basis*max_deg zero.  basis [3, num_basis] fp32.  ray_shape 0 cone / 1 cylinder
+ * (-2 otherwise, render.py:124). */
+int hugs_cast_ipe_fwd(int nrays, int num_samples, const float* tdist, const float* origins, const float* directions,
+                      const float* radii, const float* basis, int num_basis, int ray_shape, int warp_contract,
+                      int max_deg, int out_bf16, int row_pitch, void* out, void* stream);
+/* coord.py:136-147 pos_enc(viewdirs, 0, deg, append_identity=True) -> [nrays, 3+6*deg] */
+int hugs_dir_enc_fwd(int nrays, int deg, const float* viewdirs, float* out, void* stream);
+
+/* models.py:451-455 Dense+relu(+skip concat as a second A panel), :475 bottleneck, :508-512 view layer, and the
+ * dX half of their backward:  out[M,N] = epi([A1|A2][M,K1+K2] * Bt[N,K1+K2]^T) with
+ * epi(x) = (x + bias[n] + row_bias[m/row_div][n] + r1_row[m]*r1_col[n]) -> relu? -> * (mask[m][n] > 0)?.
+ * M,N multiples of 128; K1,K2 multiples of 64 (bf16) / 16 (fp32). */
+int hugs_gemm_nt(int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,
+                 const void* Bt, int ldb, const float* bias, const float* row_bias, int row_div, int ld_rb, int relu,
+                 const void* mask, int ld_mask, const float* r1_row, const float* r1_col, void* out, int ldc,
+                 void* stream);
+/* weight gradients of the same layers: dW[Kc,N] = X[Mrows,Kc]^T G[Mrows,N], dbias[N] = colsum(G) (optional);
+ * Mrows split into nsplit fp32 slabs reduced in fixed order (deterministic). */
+long long hugs_gemm_tn_ws_bytes(int Kc, int N, int nsplit);
+int hugs_gemm_tn(int dtype, int Mrows, int Kc, int N, int nsplit, const void* X, int ldx, const void* G, int ldg,
+                 float* dW, float* dbias, void* ws, void* stream);
+
+/* models.py:456 raw_density = Dense(1)(x)[...,0]; :467 density = softplus(raw + density_bias) */
+int hugs_density_fwd(int dtype, int M, int K, const void* Y, int ldy, const float* w, const float* b,
+                     float density_bias, float* raw, float* density, void* stream);
+long long hugs_density_bwd_ws_bytes(int K);
+int hugs_density_bwd(int dtype, int M, int K, const void* Y, int ldy, const float* d_density, const float* raw,
+                     float density_bias, float* d_raw, float* dw, float* db, void* ws, void* stream);
+/* out[m,n] = r[m]*c[n]*(Y[m,n] > 0): gradient entering the last trunk layer when there is no colour branch */
+int hugs_rank1_mask(int dtype, int M, int N, const float* r, const float* c, const void* Y, int ldy, void* out, int ldo,
+                    void* stream);
+/* models.py:109-118 GloEmbed gather (zeros if zero_glo) */
+int hugs_glo_gather(int nrays, int ng, const float* embedding, const int* embed_idx, int zero_glo, float* glo,
+                    void* stream);
+/* models.py:488-512: the per-ray constant part of the view layer, rb[ray] = b + [dir_enc|glo] * Wv[bottleneck:] */
+int hugs_raybias_fwd(int nrays, int H, int nd, int ng, const float* dir_enc, const float* glo, const float* Wv_tail,
+                     const float* bias, float* rb, void* stream);
+int hugs_raybias_bwd(int dtype, int nrays, int S, int H, int nd, int ng, const void* G, int ldg, const float* dir_enc,
+                     const float* glo, const float* Wv_tail, const int* embed_idx, float* d_rb, float* dWv_tail,
+                     float* d_embedding, void* stream);
+/* models.py:514-519 rgb = sigmoid(Dense(3)(h)) * (1 + 2 pad) - pad */
+int hugs_rgb_fwd(int dtype, int M, int H, const void* Hact, int ldh, const float* W, const float* b, float pad,
+                 float* rgb, void* stream);
+long long hugs_rgb_bwd_ws_bytes(void);
+int hugs_rgb_bwd(int dtype, int M, int H, const void* Hact, int ldh, const float* W, const float* rgb,
+                 const float* d_rgb, float pad, void* G, int ldg, float* dW, float* db, void* ws, void* stream);
+
+/* render.py:130-151 compute_alpha_weights + :185-244 volumetric_rendering.  extras (optional, [nrays,5]) =
+ * {acc, distance_mean, distance_median, distance_percentile_5, distance_percentile_95}. */
+int hugs_composite_fwd(int nrays, int S, const float* density, const float* rgb_s, const float* tdist,
+                       const float* dirs, int opaque_background, float bg, const float* t_far, float* weights,
+                       float* rgb_out, float* extras, void* stream);
+int hugs_composite_bwd(int nrays, int S, const float* density, const float* rgb_s, const float* tdist,
+                       const float* dirs, int opaque_background, float bg, const float* d_rgb_out,
+                       const float* d_w_extra, float* d_density, float* d_rgb_s, void* stream);
+
+/* train_utils.py:72-111 compute_data_loss (mode 0 lossmult, 1 static mask, 2 robust mask) value + gradient */
+int hugs_data_loss(int N, int L, const float* pred, const float* gt, const float* lm_src, int mode,
+                   float transient_weight, int charb, float charb_pad, const float* coef, float* d_pred,
+                   float* out_stats, void* stream);
+/* train_utils.py:251-348 robustnerf_mask (patch_size 16; -5 otherwise) */
+int hugs_robust_mask(int npatch, int P, const float* pred, const float* gt, const float* inlier_threshold,
+                     float quantile, int filter_size, float smoothed_q, int inner_patch, float inner_q, float* mask,
+                     float* err_ws, float* stats_part_ws, float* stats, void* stream);
+/* train_utils.py:228-239 interlevel_loss -> stepfun.py:30-86 (per-ray loss + d/d w_env) */
+int hugs_interlevel(int nrays, int S, int Sp, const float* t, const float* w, const float* t_env, const float* w_env,
+                    float scale, float* loss_ray, float* d_w_env, void* stream);
+/* train_utils.py:242-248 distortion_loss -> stepfun.py:266-276 */
+int hugs_distortion(int nrays, int S, const float* t, const float* w, float scale, float* loss_ray, float* d_w,
+                    void* stream);
+int hugs_sum(int n, const float* x, float scale, float* out, void* stream);
+int hugs_add_inplace(long long n, const float* src, float* dst, void* stream);
+
+/* train_utils.py:442 weight_l2s, :461-462 grad norms/maxes, :351-369 clip_gradients, :466 nan_to_num, :468
+ * optax.adam (:487-512), :470-473 update norms/maxes on the flat fp32 parameter buffer.
+ * chunks: int4 {offset, len, leaf, module}[nchunks]; leaf_info: int4 {chunk_begin, chunk_end, module, 0}[nleaf]. */
+int hugs_opt_stats(int nchunks, int nleaf, int nmod, const void* chunks, const void* leaf_info, const float* theta,
+                   const float* grad, float gscale, float max_val, float max_norm, float* part1_ws, float* leaf_stats,
+                   float* mod_scale, void* stream);
+int hugs_opt_adam(int nchunks, int nleaf, const void* chunks, const void* leaf_info, float* theta, const float* grad,
+                  float* m, float* v, const float* mod_scale, const int* trainable, float gscale, float max_val,
+                  float lr, float b1, float b2, float eps, float bias_corr1, float bias_corr2, float* part2_ws,
+                  float* leaf_upd, void* stream);
+/* fp32 master [K,N] -> compute-dtype copies Wn [K,N] and Wt [N,K] (either may be NULL) */
+int hugs_cast_weights(int dtype, int K, int N, const float* W, void* Wn, void* Wt, void* stream);
+
+/* test hooks: the portable exp/log of the sampler and raw IEEE ops as the device executes them */
+int hugs_test_explog(const float* x, int n, float* y_exp, float* y_log, void* stream);
+int hugs_test_arith(const float* a, const float* b, int n, float* out4n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,142 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/hugs.h declares, the
+product refuses to compute without a GPU (no fallback), the gin-subset reader parses every reference gin file
+form, host helpers match the oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+  txt = open(os.path.join(ROOT, 'include', 'hugs.h')).read()
+  return sorted(set(re.findall(r'\b(hugs_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_library_exports_every_declared_symbol():
+  from nerf_hugs_amd import _lib
+  lib = _lib.lib().cdll
+  names = _declared()
+  assert len(names) >= 30
+  for n in names:
+    assert hasattr(lib, n), f'{n} declared in include/hugs.h but not exported'
+  assert lib.hugs_version() >= 10000
+  # every prototype the Python binding uses is declared in the header
+  for n in _lib._PROTOS:
+    assert n in names, n
+
+
+def test_no_cpu_fallback():
+  from nerf_hugs_amd import _lib
+  if torch.cuda.is_available():
+    pytest.skip('GPU present')
+  with pytest.raises(_lib.HugsError):
+    _lib.call('hugs_sum', 4, torch.zeros(4), 1.0, torch.zeros(1))
+  from nerf_hugs_amd.internal import configs, models
+  configs.clear_config()
+  m = models.Model(configs.make_config())
+  with pytest.raises(_lib.HugsError):
+    m.engine('cuda')
+
+
+def test_product_never_imports_oracle():
+  pkg = os.path.join(ROOT, 'nerf-hugs_amd')
+  for dp, _, fs in os.walk(pkg):
+    for f in fs:
+      if f.endswith(('.py', '.hip', '.h', '.sh')):
+        txt = open(os.path.join(dp, f)).read()
+        assert 'import oracle' not in txt and 'from oracle' not in txt and 'liborc_' not in txt, os.path.join(dp, f)
+
+
+GIN_FORMS = """
+Config.dataset_loader = 'distractor'
+Config.near = 0.2
+Config.far = 1e6   # trailing comment
+Config.transient_type = 'robustnerf'
+Config.enable_render_zero_glo = True
+# comment line
+Model.raydist_fn = @jnp.reciprocal
+Model.num_glo_features = 4
+PropMLP.warp_fn = @coord.contract
+NerfMLP.net_width = 1024
+"""
+
+
+def test_gin_subset_reader(tmp_path):
+  from nerf_hugs_amd.internal import configs, models
+  p = tmp_path / 'x.gin'
+  p.write_text(GIN_FORMS)
+  configs.clear_config()
+  cfg = configs.load_config([str(p)], ["Config.data_dir = '/a/b'", "Config.patch_size = 16"], save_config=False)
+  assert cfg.dataset_loader == 'distractor' and cfg.far == 1e6 and cfg.transient_type == 'robustnerf'
+  assert cfg.data_dir == '/a/b' and cfg.patch_size == 16 and cfg.enable_render_zero_glo is True
+  m = models.Model(cfg)
+  assert m.raydist == 'reciprocal' and m.num_glo_features == 4 and m.nerf_spec.net_width == 1024
+  assert m.prop_spec.warp_fn is not None and m.nerf_spec.warp_fn is None
+  with pytest.raises(ValueError):
+    configs.parse_binding('Model.raydist_fn = @jnp.cosh')
+  configs.clear_config()
+  assert configs.make_config().data_loss_type == 'charb'          # configs.py:85 default
+  # attrs mirrored from models.py:46-72
+  m = models.Model(configs.make_config())
+  assert (m.num_levels, m.num_prop_samples, m.num_nerf_samples, m.num_embeddings) == (3, 64, 32, 3500)
+
+
+def test_param_layout_matches_published_counts():
+  # scripts/generate_tables.ipynb:145 (9,007,493 params for NerfMLP 8x1024 + PropMLP 4x256)
+  from nerf_hugs_amd.internal import configs, models
+  configs.clear_config()
+  configs.parse_config_files_and_bindings(None, ["PropMLP.net_depth = 4", "PropMLP.net_width = 256",
+                                                 "PropMLP.disable_rgb = True", "NerfMLP.net_depth = 8",
+                                                 "NerfMLP.net_width = 1024"])
+  m = models.Model(configs.make_config())
+  assert m.layout.num_params() == 9007493
+  names = ['/'.join(l['path']) for l in m.layout.leaves]
+  assert 'NerfMLP_0/Dense_11/kernel' in names and 'PropMLP_0/Dense_4/bias' in names
+  assert m.layout.by_path[('NerfMLP_0', 'Dense_5', 'kernel')]['shape'] == (1528, 1024)   # skip concat
+  flat = m.init(0, 'cpu')
+  tree = m.variables(flat)['params']
+  k = tree['NerfMLP_0']['Dense_0']['kernel']
+  assert k.shape == (504, 1024) and float(k.abs().max()) <= (6 / 504)**0.5 + 1e-6
+  assert float(tree['NerfMLP_0']['Dense_0']['bias'].abs().max()) == 0
+  configs.clear_config()
+
+
+def test_errors_like_reference():
+  from nerf_hugs_amd.internal import configs, models
+  configs.clear_config()
+  with pytest.raises(ValueError):
+    models.Model(configs.make_config(), ray_shape='sphere')           # render.py:124
+  with pytest.raises(ValueError):
+    models.Model(configs.make_config(transient_type='bogus'))         # models.py:96-101
+  with pytest.raises(NotImplementedError):
+    models.Model(configs.make_config(transient_type='nerfw'), num_transient_features=4)
+
+
+def test_host_helpers_match_oracle():
+  from nerf_hugs_amd.internal import geopoly, math as hmath, stepfun
+  from oracle import torch_ref as R
+  for shape, v in [('icosahedron', 2), ('octahedron', 1), ('octahedron', 4)]:
+    np.testing.assert_allclose(geopoly.generate_basis(shape, v), R.generate_basis(shape, v), atol=1e-12)
+  for s in [0, 10, 512, 125000, 250000]:
+    assert abs(hmath.learning_rate_decay(s, 2e-3, 2e-5, 250000, 512, 0.01) /
+               R.learning_rate_decay(s, 2e-3, 2e-5, 250000, 512, 0.01) - 1) < 1e-12
+  for S in (32, 64, 128):
+    for rnd in (False, True):
+      a, ma = stepfun.sample_u(S, rnd)
+      b, mb = R.sample_u_base(S, rnd)
+      assert np.array_equal(a, b) and ma == mb
+
+
+def test_utils_shard_unshard_and_dummy_rays():
+  from nerf_hugs_amd.internal import utils
+  r = utils.dummy_rays()
+  assert r.origins.shape == (1, 3) and r.embed_idx.dtype == torch.int32     # tests/utils_test.py
+  x = torch.arange(24.).reshape(8, 3)
+  s = utils.shard(x)
+  assert s.shape == (1, 8, 3)
+  assert torch.equal(utils.unshard(s, 2), x[:-2])

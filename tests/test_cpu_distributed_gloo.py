@@ -1,0 +1,74 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel host logic: batch sharding by whole patches, the
+gradient/stat all-reduce mean, and render_image's chunk split + pad + gather across ranks."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def _fake_rays(h, w):
+  from nerf_hugs_amd.internal import utils
+  g = torch.Generator().manual_seed(0)
+  f = lambda c: torch.rand(h, w, c, generator=g)
+  return utils.Rays(pix_coords=f(2), origins=f(3), directions=f(3), viewdirs=f(3), radii=f(1), lossmult=f(1),
+                    static_mask=f(1), near=f(1), far=f(1), embed_idx=torch.zeros(h, w, 1, dtype=torch.int32),
+                    cam_idx=torch.zeros(h, w, 1, dtype=torch.int32))
+
+
+def _fake_render_fn(rng, rays):
+  # [ndev=1, n, c] in -> per-level dicts with the leading device axis of the all-gathered result
+  from nerf_hugs_amd.internal import parallel
+  o = rays.origins[0]
+  rgb = parallel.all_gather_cat(o * 2 + 1)[None]
+  acc = parallel.all_gather_cat(o.sum(-1))[None]
+  lvl = {'rgb': rgb, 'acc': acc, 'ray_sdist': torch.zeros(1, 4, 3)}
+  return [dict(lvl), dict(lvl)], None
+
+
+def _worker(rank, world, port, tmp):
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  from nerf_hugs_amd.internal import configs, models, parallel, utils
+  # 1. gradient mean
+  g = torch.full((1000,), float(rank + 1))
+  parallel.allreduce_mean_(g)
+  assert torch.allclose(g, torch.full((1000,), 1.5))
+  # 2. batch sharding keeps whole patches
+  rays = _fake_rays(4, 4)
+  batch = utils.Batch(rays=rays.map(lambda x: x.reshape(4, 2, 2, -1)), rgb=torch.arange(4 * 2 * 2 * 3.).reshape(4, 2, 2, 3))
+  sb = parallel.shard_batch(batch, rank, world)
+  assert sb.rgb.shape == (2, 2, 2, 3) and torch.equal(sb.rgb, batch.rgb[rank * 2:(rank + 1) * 2])
+  try:
+    parallel.shard_batch(utils.Batch(rays=batch.rays.map(lambda x: x[:3]), rgb=batch.rgb[:3]), rank, world)
+    raise AssertionError('expected ValueError')
+  except ValueError:
+    pass
+  # 3. render_image: 7x5 = 35 rays, chunks of 16 -> 16,16,3(+1 pad)
+  configs.clear_config()
+  cfg = configs.make_config(render_chunk_size=16, vis_num_rays=2)
+  rays = _fake_rays(7, 5)
+  out = models.render_image(_fake_render_fn, rays, None, cfg, verbose=False)
+  assert out['rgb'].shape == (7, 5, 3)
+  assert torch.allclose(out['rgb'], rays.origins * 2 + 1)
+  assert torch.allclose(out['acc'], rays.origins.sum(-1))
+  if rank == 0:
+    open(os.path.join(tmp, 'ok'), 'w').write('1')
+  dist.destroy_process_group()
+
+
+def test_two_rank_gloo(tmp_path):
+  port = _free_port()
+  mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+  assert (tmp_path / 'ok').exists()

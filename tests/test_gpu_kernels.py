@@ -1,0 +1,284 @@
+"""Per-kernel GPU parity through the C ABI: bit-exact for the sampler (sample indices, sorted t-bins, sdist,
+tdist), float tolerances stated per test elsewhere.  Includes the committed golden vectors produced by the
+reference's own source and size-independent properties at the BASELINE batch size."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+dev = 'cuda'
+G = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+bits = lambda a: np.ascontiguousarray(a).view(np.uint32)
+
+
+def _L():
+  from nerf_hugs_amd import _lib
+  return _lib
+
+
+def test_portable_explog_and_ieee_ops_bit_exact():
+  from oracle import cstepfun as C
+  L = _L()
+  x = torch.cat([torch.linspace(-104, 89, 200001), torch.rand(100000) * 1e-30, torch.rand(100000), torch.rand(1000) * 1e-42]).float()
+  ye = torch.empty_like(x, device=dev); yl = torch.empty_like(x, device=dev)
+  L.call('hugs_test_explog', x.to(dev), x.numel(), ye, yl)
+  assert np.array_equal(bits(ye.cpu().numpy()), bits(C.expf(x.numpy())))
+  assert np.array_equal(bits(yl.cpu().numpy()), bits(C.logf(x.numpy())))
+  rng = np.random.default_rng(0)
+  n = 1 << 18
+  for lo, hi in [(-5, 5), (-80, 0), (-100, -60)]:
+    a = (np.exp(rng.uniform(lo, hi, n)) * rng.choice([-1, 1], n)).astype(np.float32)
+    b = (np.exp(rng.uniform(-20, 20, n)) * rng.choice([-1, 1], n)).astype(np.float32)
+    o = torch.empty(4 * n, device=dev)
+    L.call('hugs_test_arith', G(a), G(b), n, o)
+    o = o.cpu().numpy().reshape(4, n)
+    with np.errstate(all='ignore'):
+      for k, ref in enumerate([a / b, a * b, a + b, a - b]):
+        assert np.array_equal(bits(o[k]), bits(ref))
+
+
+def _run_level(N, n_prev, ns, dil, raydist, jitter, seed, wpow=1, zeros=False, anneal=0.7):
+  from oracle import cstepfun as C, torch_ref as R
+  from nerf_hugs_amd.internal import stepfun
+  rng = np.random.default_rng(seed)
+  t = np.sort(rng.uniform(0, 1, (N, n_prev + 1)).astype(np.float32), -1) if n_prev > 1 else np.tile(np.array([[0., 1.]], np.float32), (N, 1))
+  w = rng.uniform(0, 1, (N, n_prev)).astype(np.float32)**wpow
+  if zeros:
+    w[rng.uniform(size=w.shape) < 0.1] = 0
+  w /= np.maximum(w.sum(-1, keepdims=True), 1e-9)
+  u01 = rng.random(N, dtype=np.float32) if jitter else None
+  ub, mj = R.sample_u_base(ns, jitter)
+  jit = (u01 * np.float32(mj)).astype(np.float32) if jitter else None
+  near = rng.uniform(0.05, 0.3, N).astype(np.float32)
+  far = np.full(N, 1e6 if raydist else 1.2, np.float32)
+  sd_o, td_o, idx_o = C.level_sample(t, w, dil is not None, dil or 0., 0., 1., anneal, 0., ub, jit, raydist, near, far)
+  sd, td, idx, tin, win = stepfun.level_sample(G(t), G(w), dil is not None, dil or 0., (0., 1.), anneal, 0., ns,
+                                               None if u01 is None else G(u01), 'reciprocal' if raydist else None,
+                                               G(near), G(far), return_debug=True)
+  assert np.array_equal(idx.cpu().numpy(), idx_o), 'interval indices'
+  assert np.array_equal(bits(sd.cpu().numpy()), bits(sd_o)), 'sdist'
+  assert np.array_equal(bits(td.cpu().numpy()), bits(td_o)), 'tdist'
+  if dil is not None:
+    tdil, wdil = C.max_dilate_weights(t, w, dil, 0., 1.)
+    assert np.array_equal(bits(tin.cpu().numpy()), bits(tdil[:, 1:-1])), 'sorted dilated t-bins'
+    assert np.array_equal(bits(win.cpu().numpy()), bits(wdil[:, 1:-1])), 'dilated weights'
+  s = sd.cpu().numpy()
+  assert np.all(np.diff(s, axis=-1) >= 0) and s.min() >= 0 and s.max() <= 1
+
+
+@pytest.mark.parametrize('case', [
+    dict(N=1000, n_prev=1, ns=64, dil=None, raydist=0, jitter=True),
+    dict(N=1000, n_prev=64, ns=128, dil=0.0103125, raydist=0, jitter=True),
+    dict(N=1000, n_prev=64, ns=64, dil=0.0103125, raydist=1, jitter=False),
+    dict(N=999, n_prev=64, ns=32, dil=0.00262, raydist=1, jitter=True, wpow=4),
+    dict(N=513, n_prev=85, ns=256, dil=0.003, raydist=0, jitter=True, zeros=True),
+    dict(N=3, n_prev=2, ns=2, dil=0.1, raydist=0, jitter=False),
+    dict(N=257, n_prev=190, ns=128, dil=None, raydist=0, jitter=True, wpow=6, zeros=True, anneal=1.0),
+])
+def test_level_sample_bit_exact_vs_oracle(case):
+  _run_level(seed=3, **case)
+
+
+def test_level_sample_errors_and_empty():
+  from nerf_hugs_amd.internal import stepfun
+  t = torch.tensor([[0., 1.]], device=dev); w = torch.ones(1, 1, device=dev); z = torch.zeros(1, device=dev)
+  with pytest.raises(ValueError):                     # stepfun.py:239-240
+    stepfun.level_sample(t, w, False, 0., (0., 1.), 1., 0., 1, None, None, z, z + 1)
+  from nerf_hugs_amd import _lib
+  with pytest.raises(_lib.HugsError):                  # 3*100 bins > capacity
+    stepfun.level_sample(torch.rand(2, 101, device=dev).sort(-1).values, torch.rand(2, 100, device=dev), True, 0.01, (0., 1.), 1., 0.,
+                         8, None, None, torch.zeros(2, device=dev), torch.ones(2, device=dev))
+  sd, td = stepfun.level_sample(t[:0], w[:0], False, 0., (0., 1.), 1., 0., 8, None, None, z[:0], z[:0])
+  assert sd.shape == (0, 9)
+
+
+def test_level_sample_golden_reference_vectors(golden):
+  """The reference's own sample_intervals outputs (tests/golden): level 0 within float rounding; KAT of
+  tests/stepfun_test.py:579-586 (linspace(3,4,11))."""
+  from nerf_hugs_amd.internal import stepfun
+  for tag in ['cfg2_det', 'cfg2_jit', 'def3_nobg']:
+    key = f'{tag}/l0_u01'
+    u01 = G(golden[key][:, 0]) if key in golden.files else None
+    ref = golden[f'{tag}/l0_sdist']
+    sd, td = stepfun.level_sample(G(golden[f'{tag}/l0_in_sdist']), G(golden[f'{tag}/l0_in_weights']), False, 0., (0., 1.), 0.5, 0.,
+                                  ref.shape[1] - 1, u01, None, G(golden[f'{tag}/near'][:, 0]), G(golden[f'{tag}/far'][:, 0]))
+    np.testing.assert_allclose(sd.cpu().numpy(), ref, atol=5e-7)
+    np.testing.assert_allclose(td.cpu().numpy(), golden[f'{tag}/l0_tdist'], rtol=3e-6, atol=1e-7)
+  t = G(golden['kat_linspace/t'][None]); lg = golden['kat_linspace/logits'][None]
+  w = np.exp(lg - lg.max()); w /= w.sum()
+  sd, _ = stepfun.level_sample(t, G(w.astype(np.float32)), False, 0., (1., 6.), 1., 0., 10, None, None,
+                               torch.zeros(1, device=dev), torch.ones(1, device=dev))
+  np.testing.assert_allclose(sd.cpu().numpy()[0], np.linspace(3, 4, 11), atol=1e-4)
+
+
+@pytest.mark.parametrize('warp', [0, 1])
+def test_cast_ipe_vs_oracle_and_golden(golden, warp):
+  from oracle import torch_ref as R
+  L = _L()
+  N, S = 64, 128
+  g = torch.Generator().manual_seed(1)
+  basis = torch.tensor(R.generate_basis('icosahedron', 2).T.copy(), dtype=torch.float32)
+  o = torch.randn(N, 3, generator=g) * 0.5
+  d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1) * (0.8 + 0.4 * torch.rand(N, 1, generator=g))
+  radii = 5e-4 + 1.5e-3 * torch.rand(N, 1, generator=g)
+  td = torch.sort(torch.rand(N, S + 1, generator=g) * 3 + 0.1, -1).values
+  means, covs = R.cast_rays(td, o, d, radii)
+  if warp:
+    means, covs = R.contract_track_linearize(means, covs)
+  lm, lv = R.lift_and_diagonalize(means, covs, basis)
+  ref = R.integrated_pos_enc(lm, lv, 0, 12).reshape(N * S, 504)
+  out = torch.empty(N * S, 512, device=dev)
+  args = (N, S, td.to(dev), o.to(dev), d.to(dev), radii.reshape(-1).to(dev), basis.to(dev), 21, 0, warp, 12)
+  L.call('hugs_cast_ipe_fwd', *args, 0, 512, out)
+  # |feature| <= 1; high degrees multiply the mean by 2^11, so 1e-7 relative on the mean is 2e-4 absolute phase
+  assert float((out.cpu()[:, :504] - ref).abs().max()) < 2e-3
+  assert float((out.cpu()[:, :504] - ref).abs().mean()) < 2e-5
+  assert float(out[:, 504:].abs().max()) == 0
+  outb = torch.empty(N * S, 512, device=dev, dtype=torch.bfloat16)
+  L.call('hugs_cast_ipe_fwd', *args, 1, 512, outb)
+  assert float((outb.float().cpu()[:, :504] - ref).abs().max()) < 6e-3
+  with pytest.raises(ValueError):
+    L.call('hugs_cast_ipe_fwd', *args[:8], 2, *args[9:], 0, 512, out)       # bad ray_shape, render.py:124
+  if not warp:   # the reference's own vectors (cone, no warp), low degrees exactly, all degrees loosely
+    tag = 'cfg2_det'
+    td = G(golden[f'{tag}/l1_tdist']); n, s = td.shape[0], td.shape[1] - 1
+    o2 = torch.empty(n * s, 512, device=dev)
+    L.call('hugs_cast_ipe_fwd', n, s, td, G(golden[f'{tag}/o']), G(golden[f'{tag}/d']), G(golden[f'{tag}/radii'][:, 0]),
+           basis.to(dev), 21, 0, 0, 12, 0, 512, o2)
+    got = o2.cpu().reshape(n, s, 512)[:2, ::3, :504].numpy()
+    np.testing.assert_allclose(got, golden[f'{tag}/l1_ipe_sub'], atol=2e-3)
+    np.testing.assert_allclose(got[..., :63], golden[f'{tag}/l1_ipe_sub'][..., :63], atol=2e-5)
+
+
+def test_dir_enc_vs_golden(golden):
+  L = _L()
+  v = G(golden['cfg2_det/viewdirs'])
+  out = torch.empty(v.shape[0], 27, device=dev)
+  L.call('hugs_dir_enc_fwd', v.shape[0], 4, v, out)
+  np.testing.assert_allclose(out.cpu().numpy(), golden['cfg2_det/dir_enc'], atol=2e-6)
+
+
+@pytest.mark.parametrize('dtype', [0, 1])
+def test_gemm_nt_tn_vs_fp64(dtype):
+  L = _L()
+  tdt = torch.bfloat16 if dtype else torch.float32
+  tol = 2e-2 if dtype else 3e-5
+  g = torch.Generator(device=dev).manual_seed(0)
+  rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+  for (M, N, K1, K2, relu, mask, r1, rb) in [(256, 128, 64, 0, 1, False, False, False), (1024, 1024, 1024, 512, 1, False, False, False),
+                                               (640, 256, 512, 0, 0, True, True, False), (384, 128, 256, 0, 1, False, False, True)]:
+    A1 = rn(M, K1).to(tdt); A2 = rn(M, K2).to(tdt) if K2 else None
+    Bt = (rn(N, K1 + K2) / (K1 + K2)**0.5).to(tdt)
+    bias = rn(N); rbt = rn(M // 64, N) if rb else None
+    mk = rn(M, N).to(tdt) if mask else None
+    rr = rn(M) if r1 else None; rc = rn(N) if r1 else None
+    out = torch.empty(M, N, device=dev, dtype=tdt)
+    L.call('hugs_gemm_nt', dtype, M, N, K1, K2, A1, K1, A2, K2, Bt, K1 + K2, bias, rbt, 64, N, relu, mk, N, rr, rc, out, N)
+    A = torch.cat([A1, A2], 1) if K2 else A1
+    ref = A.double() @ Bt.double().T + bias.double()
+    if rb: ref += rbt.double().repeat_interleave(64, 0)
+    if r1: ref += rr.double()[:, None] * rc.double()[None]
+    if relu: ref = ref.clamp(min=0)
+    if mask: ref = ref * (mk.double() > 0)
+    assert float((out.double() - ref).abs().max()) < tol * max(1.0, float(ref.abs().max()))
+  for (Mr, Kc, N, ns) in [(1024, 128, 128, 1), (4096, 512, 256, 4), (8192, 1024, 1024, 8)]:
+    X = rn(Mr, Kc).to(tdt); Gm = rn(Mr, N).to(tdt)
+    dW = torch.empty(Kc, N, device=dev); db = torch.empty(N, device=dev)
+    ws = torch.empty(L.lib().cdll.hugs_gemm_tn_ws_bytes(Kc, N, ns) // 4, device=dev)
+    L.call('hugs_gemm_tn', dtype, Mr, Kc, N, ns, X, Kc, Gm, N, dW, db, ws)
+    ref = X.double().T @ Gm.double()
+    assert float((dW.double() - ref).abs().max()) < 2e-6 * Mr**0.5 * 16
+    assert float((db.double() - Gm.double().sum(0)).abs().max()) < 1e-3
+  with pytest.raises(L.HugsError):
+    L.call('hugs_gemm_nt', dtype, 100, 128, 64, 0, A1, 64, None, 0, Bt, 64, None, None, 1, 0, 0, None, 0, None, None, out, 128)
+
+
+def test_composite_fwd_extras_and_golden(golden):
+  from oracle import torch_ref as R
+  L = _L()
+  for tag, opaque in [('cfg2_jit', 1), ('def3_nobg', 0)]:
+    lv = 1
+    dens, td, rgb = golden[f'{tag}/l{lv}_density'], golden[f'{tag}/l{lv}_tdist'], golden[f'{tag}/l{lv}_rgb']
+    N, S = dens.shape
+    w = torch.empty(N, S, device=dev); ro = torch.empty(N, 3, device=dev); ex = torch.empty(N, 5, device=dev)
+    L.call('hugs_composite_fwd', N, S, G(dens), G(rgb), G(td), G(golden[f'{tag}/d']), opaque, 1.0, G(golden[f'{tag}/far'][:, 0]), w, ro, ex)
+    np.testing.assert_allclose(w.cpu().numpy(), golden[f'{tag}/l{lv}_weights'], rtol=2e-5, atol=3e-7)
+    np.testing.assert_allclose(ro.cpu().numpy(), golden[f'{tag}/l{lv}_rend_rgb'], rtol=2e-5, atol=2e-6)
+    e = ex.cpu().numpy()
+    for i, k in enumerate(['acc', 'distance_mean', 'distance_median', 'distance_percentile_5', 'distance_percentile_95']):
+      np.testing.assert_allclose(e[:, i], golden[f'{tag}/l{lv}_rend_{k}'], rtol=1e-4, atol=2e-6, err_msg=k)
+  # delta density -> one-hot weights (tests/render_test.py:443-463)
+  td = torch.linspace(0, 1, 33, device=dev)[None].contiguous(); dens = torch.zeros(1, 32, device=dev); dens[0, 10] = 1e10
+  w = torch.empty(1, 32, device=dev); ro = torch.empty(1, 3, device=dev)
+  L.call('hugs_composite_fwd', 1, 32, dens, None, td, torch.tensor([[0., 0., 1.]], device=dev), 0, 1.0, None, w, ro, None)
+  assert float(w[0, 10]) == 1 and float(w.sum()) == 1
+
+
+def test_composite_bwd_finite_and_vs_autograd():
+  from oracle import torch_ref as R
+  L = _L()
+  g = torch.Generator().manual_seed(0)
+  for S, opaque, ls in [(128, 1, 0.), (64, 0, 3.), (32, 1, -10.), (200, 0, 10.), (32, 0, -100.)]:
+    N = 37
+    td = torch.sort(torch.rand(N, S + 1, generator=g) * 2 + 0.1, -1).values
+    dens = (torch.rand(N, S, generator=g) * np.exp(ls)).double().requires_grad_(True)
+    rgb = torch.rand(N, S, 3, generator=g).double().requires_grad_(True)
+    d = torch.randn(N, 3, generator=g)
+    dro = torch.randn(N, 3, generator=g); dwe = torch.randn(N, S, generator=g)
+    w, _, _ = R.compute_alpha_weights(dens, td.double(), d.double(), bool(opaque))
+    rend = R.volumetric_rendering(rgb, w, td.double(), 1.0, None, False)
+    (gd, gr) = torch.autograd.grad((rend['rgb'] * dro.double()).sum() + (w * dwe.double()).sum(), [dens, rgb])
+    dd = torch.empty(N, S, device=dev); dr = torch.empty(N, S, 3, device=dev)
+    L.call('hugs_composite_bwd', N, S, dens.detach().float().to(dev), rgb.detach().float().to(dev), td.to(dev), d.to(dev), opaque, 1.0,
+           dro.to(dev), dwe.to(dev), dd, dr)
+    assert torch.isfinite(dd).all() and torch.isfinite(dr).all()            # tests/render_test.py:408-441
+    sc = max(float(gd.abs().max()), 1e-30)
+    assert float((dd.cpu().double() - gd).abs().max()) < 2e-4 * sc, (S, opaque, ls)
+    assert float((dr.cpu().double() - gr).abs().max()) < 1e-5
+
+
+def test_losses_vs_oracle_autograd(golden):
+  from oracle import torch_ref as R
+  L = _L()
+  tag = 'def3_nobg'
+  c, w = golden[f'{tag}/l2_sdist'], golden[f'{tag}/l2_weights']
+  N, S = w.shape
+  for lv in range(2):
+    cp = golden[f'{tag}/l{lv}_sdist']; wp = torch.tensor(golden[f'{tag}/l{lv}_weights']).double().requires_grad_(True)
+    loss = R.lossfun_outer(torch.tensor(c).double(), torch.tensor(w).double(), torch.tensor(cp).double(), wp)
+    g, = torch.autograd.grad(loss.mean(), wp)
+    lr = torch.empty(N, device=dev); dwe = torch.empty(N, cp.shape[1] - 1, device=dev)
+    L.call('hugs_interlevel', N, S, cp.shape[1] - 1, G(c), G(w), G(cp), G(golden[f'{tag}/l{lv}_weights']), 1.0 / (N * S), lr, dwe)
+    np.testing.assert_allclose(lr.cpu().numpy(), golden[f'{tag}/l{lv}_lossfun_outer'].sum(-1), rtol=2e-3, atol=1e-7)
+    assert float((dwe.cpu().double() - g).abs().max()) < 1e-4 * float(g.abs().max()) + 1e-9
+  wt = torch.tensor(w).double().requires_grad_(True)
+  ld = R.lossfun_distortion(torch.tensor(c).double(), wt)
+  g, = torch.autograd.grad(ld.mean(), wt)
+  lr = torch.empty(N, device=dev); dw = torch.empty(N, S, device=dev)
+  L.call('hugs_distortion', N, S, G(c), G(w), 1.0 / N, lr, dw)
+  np.testing.assert_allclose(lr.cpu().numpy(), golden[f'{tag}/lossfun_distortion'], rtol=2e-5)
+  assert float((dw.cpu().double() - g).abs().max()) < 1e-5 * float(g.abs().max())
+
+
+def test_properties_at_baseline_batch():
+  """BASELINE size (1024 rays, 64 -> 128): sortedness, domain, weights sum to 1 with an opaque background,
+  idempotent determinism (same inputs -> same bits)."""
+  from nerf_hugs_amd.internal import stepfun
+  L = _L()
+  N = 1024
+  g = torch.Generator(device=dev).manual_seed(0)
+  near = torch.full((N,), 0.1, device=dev); far = torch.full((N,), 1.2, device=dev)
+  t0 = torch.tensor([[0., 1.]], device=dev).repeat(N, 1); w0 = torch.ones(N, 1, device=dev)
+  u = torch.rand(N, generator=g, device=dev)
+  sd0, td0 = stepfun.level_sample(t0, w0, False, 0., (0., 1.), 0.9, 0., 64, u, None, near, far)
+  dens = torch.rand(N, 64, generator=g, device=dev) * 30
+  d = torch.randn(N, 3, generator=g, device=dev)
+  w = torch.empty(N, 64, device=dev); ro = torch.empty(N, 3, device=dev)
+  L.call('hugs_composite_fwd', N, 64, dens, None, td0, d, 1, 1.0, None, w, ro, None)
+  assert float((w.sum(-1) - 1).abs().max()) < 1e-5
+  a = stepfun.level_sample(sd0, w, True, 0.0103125, (0., 1.), 0.9, 0., 128, u, None, near, far)
+  b = stepfun.level_sample(sd0, w, True, 0.0103125, (0., 1.), 0.9, 0., 128, u, None, near, far)
+  assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+  s = a[0]
+  assert bool((s[:, 1:] >= s[:, :-1]).all()) and float(s.min()) >= 0 and float(s.max()) <= 1
+  assert bool((a[1][:, 1:] >= a[1][:, :-1]).all()) and float(a[1].min()) >= 0.1 - 1e-6 and float(a[1].max()) <= 1.2 + 1e-6
