@@ -124,6 +124,8 @@ int hugs_opt_adam(int nchunks, int nleaf, const void* chunks, const void* leaf_i
 /* fp32 master [K,N] -> compute-dtype copies Wn [K,N] and Wt [N,K] (either may be NULL) */
 int hugs_cast_weights(int dtype, int K, int N, const float* W, void* Wn, void* Wt, void* stream);
 
+/* test/bench hook: force the 128x128-tile bf16 NT kernel where the 256x256 one would be selected */
+int hugs_test_force_small_tiles(int on);
 /* test hooks: the portable exp/log of the sampler and raw IEEE ops as the device executes them */
 int hugs_test_explog(const float* x, int n, float* y_exp, float* y_log, void* stream);
 int hugs_test_arith(const float* a, const float* b, int n, float* out4n, void* stream);

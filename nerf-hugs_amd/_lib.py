@@ -35,6 +35,7 @@ _PROTOS = {
     'hugs_opt_stats': 'iiippppfffppps',
     'hugs_opt_adam': 'iippppppppffffffffpps',
     'hugs_cast_weights': 'iiippps',
+    'hugs_test_force_small_tiles': 'i',
 }
 _CT = {'i': ctypes.c_int, 'f': ctypes.c_float, 'p': ctypes.c_void_p, 'q': ctypes.c_longlong,
        's': ctypes.c_void_p}
@@ -68,6 +69,8 @@ class _Lib:
 
   def call(self, name, *args):
     sig = _PROTOS[name]
+    if sig and sig[-1] != 's':
+      return getattr(self.cdll, name)(*[int(a) for a in args])
     if len(args) != len(sig) - 1:
       raise TypeError(f'{name}: expected {len(sig) - 1} args (+stream), got {len(args)}')
     conv = []

@@ -161,6 +161,181 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(int M, int N, int K1, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 NT, large tile: 256x256 output tile, 8 waves (2 x 4, each 128 x 64 = 8 x 4 MFMA fragments), K walked
+// in 32-wide stages through a 4-deep LDS ring (4 x 32 KiB).  Three stages stay in flight across the
+// per-stage s_barrier (counted s_waitcnt vmcnt, raw barrier -- a __syncthreads would drain the LDS-DMA
+// queue).  Versus the 128^2 kernel: half the L2->LDS bytes and 3/4 of the LDS-read bytes per flop.
+// Epilogue: bias / rank-1 / relu in registers -> bf16 tile staged in the (now free) ring with a 528-byte
+// row pitch -> whole 512-byte rows stored 16 B per lane, the relu mask of the backward pass applied on
+// the coalesced side.
+// ------------------------------------------------------------------------------------------------
+#define GL_CPAD 16   // bytes added to each row of the staged C tile (bank spread for the 8-byte fragment writes)
+
+// WN = wave columns: 4 -> 256x256 tile, 8 waves, 4-slot ring (128 KiB, 1 workgroup/CU);
+//                    2 -> 256x128 tile, 4 waves, 3-slot ring (72 KiB, 2 workgroups/CU, their epilogues and
+//                         prologues overlap each other's main loops).
+template <int WN>
+__global__ __launch_bounds__(128 * WN, WN == 4 ? 2 : 1) void k_gemm_nt_bf16_big(
+    int M, int N, int K1, int K2, const uint16_t* __restrict__ A1, int lda1, const uint16_t* __restrict__ A2, int lda2,
+    const uint16_t* __restrict__ Bt, int ldb, GemmEpi E) {
+  constexpr int NT = 128 * WN;                 // threads
+  constexpr int TN_ = 64 * WN;                 // tile columns
+  constexpr int NSLOT = WN == 4 ? 4 : 3;
+  constexpr int A_BYTES = 256 * 64, B_BYTES = TN_ * 64, STAGE = A_BYTES + B_BYTES;
+  constexpr int AIT = 1024 / NT, BIT = (TN_ * 4) / NT;   // 16-byte chunks per thread per stage
+  constexpr int CPITCH = TN_ * 2 + GL_CPAD;
+  constexpr int LDS_BYTES = (NSLOT * STAGE) > (256 * CPITCH) ? (NSLOT * STAGE) : (256 * CPITCH);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntn = N / TN_, ntm = M >> 8;
+  const int t = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (t / ntn) << 8, n0 = (t % ntn) * TN_;
+  const int wm = wv / WN, wn = wv % WN;
+  const int ns = (K1 + K2) >> 5;
+
+  // staging: rows of 4 chunks(16 B); chunk id p = it*NT + tid -> row p>>2, physical pos p&3 holding logical
+  // chunk pos ^ (3*((row>>2)&1)) (keeps the fragment ds_read_b128 conflict-free).
+  auto stage = [&](int st) {
+    const int kglob = st << 5;
+    const uint16_t* Abase; int lda, kcol;
+    if (kglob < K1) { Abase = A1; lda = lda1; kcol = kglob; } else { Abase = A2; lda = lda2; kcol = kglob - K1; }
+    unsigned char* la = lds + (st % NSLOT) * STAGE;
+    unsigned char* lb = la + A_BYTES;
+#pragma unroll
+    for (int it = 0; it < AIT; ++it) {
+      const int p = it * NT + tid, row = p >> 2, col = ((p & 3) ^ (3 * ((row >> 2) & 1))) * 8;
+      glds16(Abase + (size_t)(m0 + row) * lda + kcol + col, la + (it * NT + wv * 64) * 16);
+    }
+#pragma unroll
+    for (int it = 0; it < BIT; ++it) {
+      const int p = it * NT + tid, row = p >> 2, col = ((p & 3) ^ (3 * ((row >> 2) & 1))) * 8;
+      glds16(Bt + (size_t)(n0 + row) * ldb + kglob + col, lb + (it * NT + wv * 64) * 16);
+    }
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int r16 = lane & 15, kb = lane >> 4;
+  const int frag_off = r16 * 64 + ((kb ^ (3 * ((r16 >> 2) & 1))) << 4);
+
+  // Fragments are double-buffered in registers: the ds_reads of stage st+1 are issued before the MFMAs of
+  // stage st, so LDS latency/bandwidth hides under the matrix pipe inside each wave (all waves of a
+  // workgroup are barrier-locked to the same phase, so there is no other wave to hide it under).
+  struct Frags { bf16x8_t wb[4], xa[8]; };
+  auto load_frags = [&](Frags& f, int st) {
+    const unsigned char* la = lds + (st % NSLOT) * STAGE + (wm * 128) * 64 + frag_off;
+    const unsigned char* lb = lds + (st % NSLOT) * STAGE + A_BYTES + (wn * 64) * 64 + frag_off;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f.wb[j] = *(const bf16x8_t*)(lb + j * 16 * 64);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f.xa[i] = *(const bf16x8_t*)(la + i * 16 * 64);
+  };
+  auto mfmas = [&](const Frags& f) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wb[j], f.xa[i], acc[i][j], 0, 0, 0);
+  };
+  constexpr int G = AIT + BIT;   // LDS-DMA instructions per thread per stage
+  // iteration st: frags(st) are in `cur`; make stage st+1 visible, refill slot st%NSLOT with stage st+NSLOT,
+  // start reading frags(st+1) into `nxt`, then run the MFMAs of stage st.
+#define GL_ITER(cur, nxt, st, VM)                                                        \
+  {                                                                                       \
+    asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");                     \
+    __builtin_amdgcn_s_barrier();                                                         \
+    asm volatile("" ::: "memory");                                                        \
+    if ((st) + NSLOT < ns) stage((st) + NSLOT);                                           \
+    load_frags(nxt, (st) + 1);                                                            \
+    mfmas(cur);                                                                           \
+  }
+  // Outstanding LDS-DMA groups at the wait of iteration st are stages st+1 .. st+NSLOT-1; stage st+1 must have
+  // landed, so (NSLOT-2)*G loads may stay in flight: 8 for WN=4 (NSLOT 4, G 4), 6 for WN=2 (NSLOT 3, G 6).
+  // The last NSLOT-1 iterations have fewer groups outstanding and are peeled with their own counts.
+  // ns is even (K multiple of 64), so the register sets alternate f0/f1 in lock step with the peel.
+  static_assert((NSLOT - 1) * G == 12, "prologue wait below assumes 12 younger loads");
+  Frags f0, f1;
+#pragma unroll
+  for (int q = 0; q < NSLOT; ++q) stage(q);
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  load_frags(f0, 0);
+  int st = 0;
+  if (WN == 4) {
+    for (; st + 5 < ns; st += 2) { GL_ITER(f0, f1, st, 8) GL_ITER(f1, f0, st + 1, 8) }   // st = 0 .. ns-5
+    GL_ITER(f0, f1, st, 8)                                                                // st = ns-4
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+    load_frags(f0, st + 2); mfmas(f1);                                                    // ns-3
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+    load_frags(f1, st + 3); mfmas(f0);                                                    // ns-2
+    mfmas(f1);                                                                            // ns-1
+  } else {
+    for (; st + 3 < ns; st += 2) { GL_ITER(f0, f1, st, 6) GL_ITER(f1, f0, st + 1, 6) }   // st = 0 .. ns-3
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+    load_frags(f1, st + 1); mfmas(f0);                                                    // ns-2
+    mfmas(f1);                                                                            // ns-1
+  }
+#undef GL_ITER
+  __syncthreads();   // everyone is done reading the ring: reuse it as the C staging tile
+
+  // ---- epilogue: registers -> (bias, rank-1, relu) -> bf16 tile in LDS -> whole rows, 16 B per lane ----
+  float4 bj[4], cj[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wn * 64 + j * 16 + kb * 4;
+    bj[j] = E.bias ? *(const float4*)(E.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    cj[j] = E.r1_row ? *(const float4*)(E.r1_col + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int ml = wm * 128 + i * 16 + r16;
+    const int m = m0 + ml;
+    const float r1 = E.r1_row ? E.r1_row[m] : 0.f;
+    const float* rbp = E.row_bias ? E.row_bias + (size_t)(m / E.row_div) * E.ld_rb + n0 + wn * 64 + kb * 4 : nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nl = wn * 64 + j * 16 + kb * 4;
+      float x[4] = {acc[i][j][0] + bj[j].x + r1 * cj[j].x, acc[i][j][1] + bj[j].y + r1 * cj[j].y,
+                    acc[i][j][2] + bj[j].z + r1 * cj[j].z, acc[i][j][3] + bj[j].w + r1 * cj[j].w};
+      if (rbp) { const float4 b = *(const float4*)(rbp + j * 16); x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w; }
+      if (E.relu) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
+      bf16x4_t pk;   // v_cvt_pk_bf16_f32 (round to nearest even)
+      pk[0] = (__bf16)x[0]; pk[1] = (__bf16)x[1]; pk[2] = (__bf16)x[2]; pk[3] = (__bf16)x[3];
+      *(bf16x4_t*)(lds + ml * CPITCH + nl * 2) = pk;
+    }
+  }
+  __syncthreads();
+  constexpr int CPR = TN_ / 8;                  // 16-byte chunks per row
+  constexpr int EIT = 256 * CPR / NT;           // = 16
+#pragma unroll 4
+  for (int it = 0; it < EIT; ++it) {
+    const int p = it * NT + tid;
+    const int row = p / CPR, c = p % CPR;
+    uint4 v = *(const uint4*)(lds + row * CPITCH + c * 16);
+    if (E.mask) {
+      const uint4 mk = *(const uint4*)((const uint16_t*)E.mask + (size_t)(m0 + row) * E.ld_mask + n0 + c * 8);
+      const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
+      uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // bf16 > 0 <=> sign clear and magnitude non-zero
+        const uint32_t lo = mw[q] & 0xffffu, hi = mw[q] >> 16;
+        const uint32_t keep = (((lo & 0x7fffu) && !(lo & 0x8000u)) ? 0x0000ffffu : 0u) |
+                              (((hi & 0x7fffu) && !(hi & 0x8000u)) ? 0xffff0000u : 0u);
+        vw[q] &= keep;
+      }
+      v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+    }
+    *(uint4*)((uint16_t*)E.out + (size_t)(m0 + row) * E.ldc + n0 + c * 8) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // bf16 TN: slab[split][Kc, N] (fp32) = sum over this split's rows of X[m,Kc]^T G[m,N]
 //   tile: 128 (Kc) x 128 (N), reduction step 64 rows; both tiles row-major [64][128] bf16 in LDS,
 //   32-byte granules XOR-swizzled by (row & 7) so the 8 rows a transpose-read pair touches hit 8
@@ -433,6 +608,9 @@ __global__ void k_slab_reduce(const float* __restrict__ slab, int nsplit, size_t
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
+static int g_force_small_tiles = 0;   // test/bench hook: 0 default (256x256, else 256x128, else 128x128), 1 force 128x128, 3 force 256x128
+extern "C" int hugs_test_force_small_tiles(int on) { g_force_small_tiles = on; return 0; }
+
 extern "C" int hugs_gemm_nt(int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,
                             const void* Bt, int ldb, const float* bias, const float* row_bias, int row_div, int ld_rb,
                             int relu, const void* mask, int ld_mask, const float* r1_row, const float* r1_col,
@@ -445,7 +623,13 @@ extern "C" int hugs_gemm_nt(int dtype, int M, int N, int K1, int K2, const void*
   if (M == 0 || N == 0) return 0;
   GemmEpi E{bias, row_bias, row_div, ld_rb, relu, mask, ld_mask, r1_row, r1_col, out, ldc};
   const int grid = (M / 128) * (N / 128);
-  if (dtype)
+  if (dtype && M % 256 == 0 && N % 256 == 0 && (K1 + K2) % 64 == 0 && K1 + K2 >= 256 && g_force_small_tiles != 1 && g_force_small_tiles != 3)
+    hipLaunchKernelGGL(k_gemm_nt_bf16_big<4>, dim3((M / 256) * (N / 256)), dim3(512), 0, (hipStream_t)stream, M, N, K1, K2,
+                       (const uint16_t*)A1, lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E);
+  else if (dtype && M % 256 == 0 && (K1 + K2) % 64 == 0 && K1 + K2 >= 256 && g_force_small_tiles != 1)
+    hipLaunchKernelGGL(k_gemm_nt_bf16_big<2>, dim3((M / 256) * (N / 128)), dim3(256), 0, (hipStream_t)stream, M, N, K1, K2,
+                       (const uint16_t*)A1, lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E);
+  else if (dtype)
     hipLaunchKernelGGL(k_gemm_nt_bf16, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, N, K1, K2, (const uint16_t*)A1,
                        lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E);
   else
