@@ -438,6 +438,133 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(int Mrows, int Kc, int 
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 TN, large tile: 256 (Kc) x 256 (N) output tile per workgroup, 8 waves (2 over N x 4 over Kc, each
+// 128 x 64), reduction rows walked 32 at a time through the same 4-slot ring / counted-vmcnt / register
+// double-buffer pipeline as the NT kernel.  Both operands are read with ds_read_b64_tr_b16 from row-major
+// [32][256] stages (32-byte granules XOR-swizzled by row&7).  The bias gradient (column sums of G) costs two
+// extra MFMAs per stage against an all-ones fragment instead of a scalar LDS pass.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, int N, int nsplit,
+                                                              const uint16_t* __restrict__ X, int ldx,
+                                                              const uint16_t* __restrict__ G, int ldg,
+                                                              float* __restrict__ slab, int lds_out,
+                                                              float* __restrict__ colsum_slab) {
+  constexpr int NSLOT = 4, STAGE = 32768, XB = 16384;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NSLOT * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntn = N >> 8, ntk = Kc >> 8, tiles = ntn * ntk;
+  const int split = blockIdx.x / tiles, tt = blockIdx.x % tiles;
+  const int c0 = (tt / ntn) << 8, n0 = (tt % ntn) << 8;
+  const int rows_per = Mrows / nsplit, mbeg = split * rows_per;
+  const int ns = rows_per >> 5;
+  const int wn = wv >> 2, wk = wv & 3;
+  const bool do_colsum = colsum_slab && c0 == 0;
+
+  auto stage = [&](int st) {
+    const int mrow0 = mbeg + (st << 5);
+    unsigned char* lx = lds + (st % NSLOT) * STAGE;
+    unsigned char* lg = lx + XB;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int p = it * 512 + tid, row = p >> 5, pos = p & 31;
+      const int c = ((((pos >> 1) ^ (row & 7)) << 1) | (pos & 1)) * 8;
+      glds16(X + (size_t)(mrow0 + row) * ldx + c0 + c, lx + (it * 512 + wv * 64) * 16);
+      glds16(G + (size_t)(mrow0 + row) * ldg + n0 + c, lg + (it * 512 + wv * 64) * 16);
+    }
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  f32x4_t accb[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+  bf16x8_t ones;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) ones[q] = (__bf16)1.0f;
+
+  const int g = lane >> 4, s = lane & 15;
+  struct Frags { bf16x8_t ga[8], xb[4]; };
+  auto load_frags = [&](Frags& f, int st) {
+    const unsigned char* lx = lds + (st % NSLOT) * STAGE;
+    const unsigned char* lg = lx + XB;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = h * 16 + g * 4 + (s >> 2);
+      const int sw = row & 7;
+      const int lo = row * 512 + ((s & 3) << 3);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int q = wn * 8 + i;
+        bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4_t __attribute__((address_space(3)))*)(lg + lo + ((q ^ sw) << 5)));
+        f.ga[i][h * 4 + 0] = v[0]; f.ga[i][h * 4 + 1] = v[1]; f.ga[i][h * 4 + 2] = v[2]; f.ga[i][h * 4 + 3] = v[3];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int q = wk * 4 + j;
+        bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4_t __attribute__((address_space(3)))*)(lx + lo + ((q ^ sw) << 5)));
+        f.xb[j][h * 4 + 0] = v[0]; f.xb[j][h * 4 + 1] = v[1]; f.xb[j][h * 4 + 2] = v[2]; f.xb[j][h * 4 + 3] = v[3];
+      }
+    }
+  };
+  auto mfmas = [&](const Frags& f) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[i], f.xb[j], acc[i][j], 0, 0, 0);
+    if (do_colsum) {   // wave (wn, wk) owns the column sums of its N fragments 2wk, 2wk+1
+      if (wk == 0) { accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[0], ones, accb[0], 0, 0, 0); accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[1], ones, accb[1], 0, 0, 0); }
+      else if (wk == 1) { accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[2], ones, accb[0], 0, 0, 0); accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[3], ones, accb[1], 0, 0, 0); }
+      else if (wk == 2) { accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[4], ones, accb[0], 0, 0, 0); accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[5], ones, accb[1], 0, 0, 0); }
+      else { accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[6], ones, accb[0], 0, 0, 0); accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[7], ones, accb[1], 0, 0, 0); }
+    }
+  };
+#define GT_ITER(cur, nxt, st, VM)                                         \
+  {                                                                       \
+    asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_s_barrier();                                         \
+    asm volatile("" ::: "memory");                                        \
+    if ((st) + NSLOT < ns) stage((st) + NSLOT);                           \
+    load_frags(nxt, (st) + 1);                                            \
+    mfmas(cur);                                                           \
+  }
+  Frags f0, f1;
+#pragma unroll
+  for (int q = 0; q < NSLOT; ++q) stage(q);
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  load_frags(f0, 0);
+  int st = 0;
+  for (; st + 5 < ns; st += 2) { GT_ITER(f0, f1, st, 8) GT_ITER(f1, f0, st + 1, 8) }
+  GT_ITER(f0, f1, st, 8)
+  asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+  load_frags(f0, st + 2); mfmas(f1);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+  load_frags(f1, st + 3); mfmas(f0);
+  mfmas(f1);
+#undef GT_ITER
+
+  float* out = slab + (size_t)split * Kc * lds_out;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = c0 + wk * 64 + j * 16 + s;
+      const int n = n0 + wn * 128 + i * 16 + g * 4;
+      *(float4*)(out + (size_t)c * lds_out + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+  if (do_colsum && s == 0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int n = n0 + wn * 128 + (2 * wk + q) * 16 + g * 4;
+      *(float4*)(colsum_slab + (size_t)split * N + n) = make_float4(accb[q][0], accb[q][1], accb[q][2], accb[q][3]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // fp32 parity path: 128x128x16 tiles on v_mfma_f32_16x16x4_f32, register-staged, padded LDS.
 // ------------------------------------------------------------------------------------------------
 #define GF_BK 16
@@ -653,7 +780,12 @@ extern "C" int hugs_gemm_tn(int dtype, int Mrows, int Kc, int N, int nsplit, con
   float* slab = (float*)ws;
   float* cs = dbias ? slab + (size_t)nsplit * Kc * N : nullptr;
   const int grid = (Kc / 128) * (N / 128) * nsplit;
-  if (dtype)
+  const int rows_per = Mrows / nsplit;
+  if (dtype && Kc % 256 == 0 && N % 256 == 0 && (Kc / 256) * (N / 256) >= 4 && rows_per % 64 == 0 && rows_per >= 256 &&
+      g_force_small_tiles != 1)
+    hipLaunchKernelGGL(k_gemm_tn_bf16_big, dim3((Kc / 256) * (N / 256) * nsplit), dim3(512), 0, (hipStream_t)stream, Mrows, Kc,
+                       N, nsplit, (const uint16_t*)X, ldx, (const uint16_t*)G, ldg, slab, N, cs);
+  else if (dtype)
     hipLaunchKernelGGL(k_gemm_tn_bf16, dim3(grid), dim3(256), 0, (hipStream_t)stream, Mrows, Kc, N, nsplit,
                        (const uint16_t*)X, ldx, (const uint16_t*)G, ldg, slab, N, cs);
   else

@@ -311,16 +311,16 @@ class Engine:
     return levels
 
   # ---- backward -----------------------------------------------------------------------------------
-  def _nsplit(self, M, tiles):
-    step = 64 if self.dt else 16
-    units = M // step
-    want = max(1, min(units, (768 + tiles - 1) // tiles))
-    while units % want:
-      want -= 1
-    return want
-
   def _tn(self, M, Kc, Nn, X, ldx, G, ldg, dW, db):
-    ns = self._nsplit(M, (Kc // 128) * (Nn // 128))
+    """dW[Kc,Nn] = X^T G (+ db = colsum G): split the M reduction so the grid fills the chip once."""
+    if self.dt and Kc % 256 == 0 and Nn % 256 == 0 and (Kc // 256) * (Nn // 256) >= 4:
+      tiles, step, target = (Kc // 256) * (Nn // 256), 64, 256      # 256x256 tiles, one workgroup per CU
+    else:
+      tiles, step, target = (Kc // 128) * (Nn // 128), (64 if self.dt else 16), 768
+    units = M // step
+    ns = max(1, min(units, (target + tiles - 1) // tiles))
+    while units % ns:
+      ns -= 1
     nbytes = _lib.lib().cdll.hugs_gemm_tn_ws_bytes(Kc, Nn, ns)
     slab = self.ws.get('tn_slab', (max(nbytes // 4, 1),))
     _lib.call('hugs_gemm_tn', self.dt, M, Kc, Nn, ns, X, ldx, G, ldg, dW, db, slab)
