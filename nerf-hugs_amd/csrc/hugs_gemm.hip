@@ -454,7 +454,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntn = N >> 8, ntk = Kc >> 8, tiles = ntn * ntk;
-  const int split = blockIdx.x / tiles, tt = blockIdx.x % tiles;
+  // all tiles of one M-split read the same X / G row block: keep them on one XCD so its L2 serves the re-reads
+  const int vb = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = vb / tiles, tt = vb % tiles;
   const int c0 = (tt / ntn) << 8, n0 = (tt % ntn) << 8;
   const int rows_per = Mrows / nsplit, mbeg = split * rows_per;
   const int ns = rows_per >> 5;
