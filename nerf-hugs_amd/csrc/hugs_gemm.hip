@@ -169,6 +169,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(int M, int N, int K1, i
 // row pitch -> whole 512-byte rows stored 16 B per lane, the relu mask of the backward pass applied on
 // the coalesced side.
 // ------------------------------------------------------------------------------------------------
+#ifndef HUGS_NT_VARIANT
+#define HUGS_NT_VARIANT 2   // 8 MFMA : 3 ds_read interleave of next-stage fragment reads (A/B-tested: +5 %)
+#endif
 #define GL_CPAD 16   // bytes added to each row of the staged C tile (bank spread for the 8-byte fragment writes)
 
 // WN = wave columns: 4 -> 256x256 tile, 8 waves, 4-slot ring (128 KiB, 1 workgroup/CU);
@@ -252,12 +255,39 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 2 : 1) void k_gemm_nt_bf16_big(
     if ((st) + NSLOT < ns) stage((st) + NSLOT);                                           \
     load_frags(nxt, (st) + 1);                                                            \
     mfmas(cur);                                                                           \
+    if (HUGS_NT_VARIANT == 2) {                                                           \
+      _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                \
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                                \
+      }                                                                                   \
+    }                                                                                     \
+    if (HUGS_NT_VARIANT == 4) {                                                           \
+      _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) {                                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                \
+      }                                                                                   \
+    }                                                                                     \
+    if (HUGS_NT_VARIANT == 5) {                                                           \
+      _Pragma("unroll") for (int q_ = 0; q_ < 12; ++q_) {                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                \
+      }                                                                                   \
+    }                                                                                     \
+    if (HUGS_NT_VARIANT == 6) {                                                           \
+      _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                \
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                                \
+      }                                                                                   \
+    }                                                                                     \
+    if (HUGS_NT_VARIANT == 7) {                                                           \
+      _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                  \
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                                \
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                \
+      }                                                                                   \
+    }                                                                                     \
   }
-  // Outstanding LDS-DMA groups at the wait of iteration st are stages st+1 .. st+NSLOT-1; stage st+1 must have
-  // landed, so (NSLOT-2)*G loads may stay in flight: 8 for WN=4 (NSLOT 4, G 4), 6 for WN=2 (NSLOT 3, G 6).
-  // The last NSLOT-1 iterations have fewer groups outstanding and are peeled with their own counts.
-  // ns is even (K multiple of 64), so the register sets alternate f0/f1 in lock step with the peel.
-  static_assert((NSLOT - 1) * G == 12, "prologue wait below assumes 12 younger loads");
   Frags f0, f1;
 #pragma unroll
   for (int q = 0; q < NSLOT; ++q) stage(q);

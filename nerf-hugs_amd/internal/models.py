@@ -186,7 +186,7 @@ def render_image(render_fn, rays, rng, config, verbose=True):
     local = chunk_rays.map(lambda r: r[rank * per:(rank + 1) * per])
     chunk_renderings, _ = render_fn(rng, utils.shard(local))
     # v[0] of the reference's all-gathered [ndev, n/ndev, ...] leaves == the full chunk
-    chunk_renderings = [{k: utils.unshard(v, padding) if not k.startswith('ray_') else v for k, v in r.items()}
+    chunk_renderings = [{k: utils.unshard(v, 0 if k.startswith('ray_') else padding) for k, v in r.items()}
                         for r in chunk_renderings]
     chunk_rendering = dict(chunk_renderings[-1])
     for k in chunk_renderings[0]:

@@ -1,0 +1,79 @@
+"""GPU parity of the eval surface (Model.apply with compute_extras, render_image, create_render_fn) and of the
+finetune stage (only GLO embeddings move), against the oracle."""
+import functools
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GIN = ["Config.patch_size = 8", "Config.data_loss_type = 'mse'", "Model.opaque_background = True", "Model.num_levels = 3",
+       "PropMLP.net_depth = 4", "PropMLP.net_width = 128", "PropMLP.disable_rgb = True", "NerfMLP.net_depth = 8",
+       "NerfMLP.net_width = 128", "Model.num_glo_features = 4", "Config.render_chunk_size = 96", "Config.vis_num_rays = 4"]
+
+
+def test_render_image_and_extras_vs_oracle():
+  from tests import hugs_testlib as H
+  from oracle import torch_ref as R
+  from nerf_hugs_amd.internal import models, utils
+  config, model, state, render_fn, _, cfg, oparams = H.make_pair(GIN)
+  batch = H.synth_rays(1, 16, 9)                       # a 16 x 16 "image"
+  rays = batch.rays.map(lambda x: x.reshape(16, 16, -1))
+  out = models.render_image(functools.partial(render_fn, state.params, 1.0), rays, None, config, verbose=False)
+  orend, ohist = R.model_forward(cfg, oparams, H.oracle_rays(batch), 1.0, None, True)
+  ref = orend[-1]
+  assert out['rgb'].shape == (16, 16, 3)
+  for k in ['rgb', 'acc', 'distance_mean', 'distance_median', 'distance_percentile_5', 'distance_percentile_95']:
+    a = out[k].cpu().reshape(-1).double(); b = ref[k].detach().reshape(-1).double()
+    assert float((a - b).abs().max()) < 2e-4 * max(1.0, float(b.abs().max())), k
+  assert len(out['ray_sdist']) == 3 and out['ray_sdist'][0].shape == (4, 65) and out['ray_rgbs'][2].shape == (4, 32, 3)
+  # zero_glo path (Config.enable_render_zero_glo): differs from the embedded one, matches the oracle's
+  rend0, _ = model.apply(state.flat, None, batch.rays, 1.0, True, zero_glo=True)
+  o0, _ = R.model_forward(cfg, oparams, H.oracle_rays(batch), 1.0, None, True, zero_glo=True)
+  assert float((rend0[-1]['rgb'].cpu().reshape(-1, 3) - o0[-1]['rgb'].detach()).abs().max()) < 2e-4
+  # history keys / shapes of Model.__call__
+  rend, hist = model(state.params, None, batch.rays, 1.0, False)
+  assert set(hist[0].keys()) == {'density', 'rgb', 'sdist', 'weights'} and hist[2]['rgb'].shape == (1, 16, 16, 32, 3)
+
+
+def test_finetune_moves_only_embeddings():
+  from tests import hugs_testlib as H
+  from nerf_hugs_amd.internal import train_utils
+  config, model, state, _, train_step, cfg, oparams = H.make_pair(GIN + ["Config.finetune_enable = True"])
+  fstate, ftrain, lr_fn = train_utils.setup_finetune_model(config, model, state)
+  before = fstate.flat.clone()
+  batch = H.synth_rays(1, 8, 3)
+  gen = torch.Generator(device='cuda').manual_seed(0)
+  fstate, stats, gen = ftrain(gen, fstate, batch, 1.0, None)
+  torch.cuda.synchronize()
+  lay = model.layout
+  for lf in lay.leaves:
+    d = (lay.view(fstate.flat, lf['path']) - lay.view(before, lf['path'])).abs().max().item()
+    if 'embedding' in lf['path']:
+      assert d > 0
+    else:
+      assert d == 0, lf['path']
+  assert set(stats['losses'].keys()) == {'data'}        # no interlevel / distortion in the finetune stage
+  assert abs(lr_fn(0) / (config.finetune_lr_init * config.finetune_lr_delay_mult) - 1) < 1e-9
+
+
+def test_leaf_api_wrappers():
+  from oracle import torch_ref as R
+  from nerf_hugs_amd.internal import coord, render
+  g = torch.Generator().manual_seed(0)
+  N, S = 16, 32
+  td = torch.sort(torch.rand(N, S + 1, generator=g) + 0.1, -1).values
+  dens = torch.rand(N, S, generator=g) * 20; rgb = torch.rand(N, S, 3, generator=g); d = torch.randn(N, 3, generator=g)
+  far = td[:, -1:] + 1
+  w = render.compute_alpha_weights(dens.cuda(), td.cuda(), d.cuda(), True)
+  wo = R.compute_alpha_weights(dens, td, d, True)[0]
+  assert float((w.cpu() - wo).abs().max()) < 1e-5
+  out, w2 = render.volumetric_rendering(rgb.cuda(), dens.cuda(), td.cuda(), d.cuda(), 1.0, far.cuda(), True, True)
+  ro = R.volumetric_rendering(rgb, wo, td, 1.0, far, True)
+  for k, v in ro.items():
+    assert float((out[k].cpu() - v).abs().max()) < 2e-4, k
+  v = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
+  assert float((coord.pos_enc(v.cuda(), 0, 4).cpu() - R.pos_enc(v, 0, 4)).abs().max()) < 1e-5
+  with pytest.raises(ValueError):
+    render.cast_rays_ipe(td.cuda(), d.cuda(), d.cuda(), torch.ones(N, 1).cuda(), 'sphere', torch.eye(3).cuda(), 4)
