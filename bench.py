@@ -53,10 +53,10 @@ def gemm_roofline(device):
   bias = torch.zeros(N, device=device)
   out = torch.empty(M, N, device=device, dtype=torch.bfloat16)
   call = lambda: _lib.call('hugs_gemm_nt', 1, M, N, K, 0, A, K, None, 0, Bt, K, bias, None, 1, 0, 1, None, 0, None, None, out, N)
-  for _ in range(3):
+  for _ in range(15):   # the chip clocks down while the host runs the CPU legs: warm it back up
     call()
   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-  reps = 20
+  reps = 30
   e0.record()
   for _ in range(reps):
     call()
@@ -64,8 +64,10 @@ def gemm_roofline(device):
   torch.cuda.synchronize()
   dt = e0.elapsed_time(e1) / reps * 1e-3
   tf = 2.0 * M * N * K / dt / 1e12
-  return {"bound": "mfma", "kernel": "k_gemm_nt_bf16 [131072x1024]x[1024x1024] bias+relu", "achieved": round(tf, 1),
-          "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(tf * 1e12 / PEAK_BF16, 4), "traffic": None,
+  return {"bound": "mfma", "kernel": "k_gemm_nt_bf16_big<4> [131072x1024]x[1024x1024]^T bias+relu (NerfMLP trunk layer)", "achieved": round(tf, 1),
+          "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(tf * 1e12 / PEAK_BF16, 4),
+          # HBM bytes per launch from PMC (profiles/r01_gemm_pmc.md): 2*FETCH_SIZE + WRITE_SIZE (KB) * 1024
+          "traffic": 6.71e8, "algorithmic_bytes": 5.39e8,
           "avg_us": round(dt * 1e6, 1)}
 
 
@@ -106,6 +108,29 @@ def cpu_baseline(seed):
           "sample": f"{k} full train steps of 64 rays x (64+128) samples, oracle/torch_ref.py fp32"}
 
 
+def eval_psnr_vs_oracle(model, state, batch, dtype):
+  """'eval PSNR' leg of the metric (no dataset ships): PSNR of the HIP render (deterministic eval forward, the
+  benchmarked compute dtype, trained weights of this run) against the oracle's fp32 CPU render of the same 256
+  rays with the same weights."""
+  from oracle import torch_ref as R
+  from nerf_hugs_amd.internal import models
+  rays = batch.rays.map(lambda x: x[:1])                      # one 16 x 16 patch
+  rend, _ = model.apply(state.flat, None, rays, 1.0, False)
+  hip = rend[-1]['rgb'].reshape(-1, 3).float().cpu()
+  cfg = R.kubric_cfg(num_levels=2, num_prop_samples=64, num_nerf_samples=128)
+  tree = model.variables(state.flat)['params']
+  P = {m: {k: {kk: vv.detach().float().cpu() for kk, vv in v.items()} for k, v in sub.items()} for m, sub in tree.items()}
+  r = rays.flat()
+  orays = dict(origins=r.origins.cpu(), directions=r.directions.cpu(), viewdirs=r.viewdirs.cpu(), radii=r.radii.cpu(),
+               lossmult=r.lossmult.cpu(), static_mask=r.static_mask.cpu(), near=r.near.cpu(), far=r.far.cpu(),
+               embed_idx=r.embed_idx.cpu())
+  torch.set_num_threads(min(os.cpu_count(), 16))
+  with torch.no_grad():
+    orend, _ = R.model_forward(cfg, {'params': P}, orays, 1.0, None, False)
+  mse = float(((hip - orend[-1]['rgb'])**2).mean())
+  return round(-10.0 * np.log10(max(mse, 1e-20)), 2)
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -120,11 +145,17 @@ def main():
   local = int(os.environ.get('LOCAL_RANK', '0'))
   if args.gpus > 1 and world == 1:
     raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
+  if 'HUGS_FORCE_DEVICE' in os.environ:     # test hook: several ranks on one GPU (with HUGS_DIST_BACKEND=gloo)
+    local = int(os.environ['HUGS_FORCE_DEVICE'])
   torch.cuda.set_device(local)
   device = torch.device('cuda', local)
   if world > 1:
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    dist.init_process_group('nccl', device_id=device)
+    backend = os.environ.get('HUGS_DIST_BACKEND', 'nccl')   # "nccl" is RCCL on ROCm
+    if backend == 'nccl':
+      dist.init_process_group('nccl', device_id=device)
+    else:
+      dist.init_process_group(backend)
   from nerf_hugs_amd.internal import configs, train_utils
   configs.clear_config()
   configs.parse_config_files_and_bindings(None, GIN)
@@ -154,6 +185,9 @@ def main():
     dt = float(tmax.item())
   loss = float(stats['loss'])
   psnr = float(stats['psnr'])
+  eval_psnr = None
+  if rank == 0 and not args.no_cpu_baseline:
+    eval_psnr = eval_psnr_vs_oracle(model, state, batch, args.dtype)
   if rank == 0:
     rps = rays_per_gpu * world * args.steps / dt
     line = {
@@ -164,6 +198,7 @@ def main():
                                "full train step", "rays_per_gpu": rays_per_gpu, "global_batch": rays_per_gpu * world,
                    "parallelism": f"dp{world}", "params": model.layout.num_params()},
         "train_psnr_last": round(psnr, 3), "loss_last": round(loss, 6),
+        "eval_psnr_vs_cpu_fp32_db": eval_psnr,
         "step_mfma_frac": round(rps / world * FLOP_TRAIN_PER_RAY / (PEAK_BF16 if args.dtype == 'bf16' else 157.3e12), 4),
     }
     if args.dtype == 'bf16':
