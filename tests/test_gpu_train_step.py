@@ -105,3 +105,38 @@ def test_train_step_robustnerf():
   gin = [g.replace('patch_size = 8', 'patch_size = 16') for g in SMALL] + [
       "Config.transient_type = 'robustnerf'", "Config.robustnerf_inlier_quantile = 0.8"]
   _run_case(gin, n_patch=2, P=16, inlier=0.3)
+
+
+def test_bf16_full_width_step_vs_oracle():
+  """The benchmarked configuration's kernels (8x1024 / 4x256 nets -> 256x256-tile bf16 GEMMs, ring pipeline,
+  transpose-read TN) on a small ray count against the fp32 oracle.  bf16 operands: loss within 2 %, rendered
+  colour within 2e-2, gradient direction per leaf (cosine) > 0.98 for the large leaves."""
+  from tests import hugs_testlib as H
+  from oracle import torch_ref as R
+  gin = [g for g in SMALL if 'net_width' not in g] + ["PropMLP.net_width = 256", "NerfMLP.net_width = 1024"]
+  config, model, state, _, train_step, cfg, oparams = H.make_pair(gin, compute_dtype='bf16')
+  batch = H.synth_rays(1, 8, 5)
+  N, L = 64, model.num_levels
+  gen = torch.Generator(device='cuda').manual_seed(11)
+  st = gen.get_state()
+  u01 = [torch.rand(N, generator=gen, device='cuda') for _ in range(L)]
+  gen.set_state(st)
+  ostats, ograds, orend, _ = R.loss_and_grad(cfg, oparams, H.oracle_rays(batch), batch.rgb.reshape(-1, 3), 0.37,
+                                             [u.cpu() for u in u01])
+  state, stats, gen = train_step(gen, state, batch, 0.37, None)
+  torch.cuda.synchronize()
+  assert abs(float(stats['loss']) / float(ostats['loss']) - 1) < 2e-2
+  eng = model.engine('cuda')
+  grad = eng.ws.get('grad', (model.layout.size + 64,))
+  checked = 0
+  for lf in model.layout.leaves:
+    name = '/'.join(lf['path'])
+    g = model.layout.view(grad, lf['path']).cpu().double().flatten()
+    og = ograds[name].double().flatten()
+    if og.numel() < 1024:
+      continue
+    cos = float((g * og).sum() / (g.norm() * og.norm()).clamp(min=1e-30))
+    assert cos > 0.98, f'{name}: cosine {cos:.4f}'
+    assert 0.9 < float(g.norm() / og.norm()) < 1.1, name
+    checked += 1
+  assert checked >= 12
