@@ -53,7 +53,7 @@ def gemm_roofline(device):
   bias = torch.zeros(N, device=device)
   out = torch.empty(M, N, device=device, dtype=torch.bfloat16)
   call = lambda: _lib.call('hugs_gemm_nt', 1, M, N, K, 0, A, K, None, 0, Bt, K, bias, None, 1, 0, 1, None, 0, None, None, out, N)
-  for _ in range(15):   # the chip clocks down while the host runs the CPU legs: warm it back up
+  for _ in range(40):   # the chip clocks down while the host runs the CPU legs: warm it back up
     call()
   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
   reps = 30
@@ -186,7 +186,7 @@ def main():
   loss = float(stats['loss'])
   psnr = float(stats['psnr'])
   eval_psnr = None
-  if rank == 0 and not args.no_cpu_baseline:
+  if rank == 0 and world == 1 and not args.no_cpu_baseline:
     eval_psnr = eval_psnr_vs_oracle(model, state, batch, args.dtype)
   if rank == 0:
     rps = rays_per_gpu * world * args.steps / dt
