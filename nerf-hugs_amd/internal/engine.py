@@ -322,7 +322,8 @@ class Engine:
     while units % ns:
       ns -= 1
     nbytes = _lib.lib().cdll.hugs_gemm_tn_ws_bytes(Kc, Nn, ns)
-    slab = self.ws.get('tn_slab', (max(nbytes // 4, 1),))
+    # one slab workspace per stream (calls on a stream are ordered)
+    slab = self.ws.get(f'tn_slab/{torch.cuda.current_stream().cuda_stream}', (max(nbytes // 4, 1),))
     _lib.call('hugs_gemm_tn', self.dt, M, Kc, Nn, ns, X, ldx, G, ldg, dW, db, slab)
 
   def backward_level(self, theta, grad, lv, rays, N, d_rgb_out, d_w_extra):
@@ -374,21 +375,49 @@ class Engine:
       _lib.call('hugs_gemm_nt', dt, M, W, Bw, 0, dB, Bw, None, 0, self.wn[(spec.name, lb['name'], 'kernel')], Bw, None, None,
                 1, 0, 0, Ylast, W, d_raw, wd, Ga, W)
     G = Ga
-    other = Gb
     X0 = lv['X0']
+    # Trunk backward on two HIP streams: the weight-gradient GEMM of layer i (side stream) and the dX GEMM that
+    # produces G_{i-1} (main stream) only share the read of G_i, so they run concurrently and fill each other's
+    # tile-epilogue / launch-boundary bubbles.  Three G buffers rotate so dX never overwrites a buffer a pending
+    # dW still reads; the per-call fp32 slab workspace is double-buffered the same way.
+    main = torch.cuda.current_stream()
+    side = self._side_stream()
+    Gc = ws.get(tag + '/Gc', (M, W), self.tdt)
+    ring = [Ga, Gb, Gc]
+    gi = 0
+    ev_g = torch.cuda.Event()
+    ev_g.record(main)
+    tn_done = {}
     for i in range(spec.net_depth - 1, -1, -1):
       l = spec.layers[i]
       path = (spec.name, l['name'], 'kernel')
       gW = gview(path, padded=True)
       gb = gview((spec.name, l['name'], 'bias'))
       xin = acts[i]          # acts[0] = X0, acts[i] = Y_{i-1}
-      if l['concat']:
-        self._tn(M, W, W, xin, W, G, W, gW[:W], gb)
-        self._tn(M, spec.Fp, W, X0, spec.Fp, G, W, gW[W:], None)
-      else:
-        self._tn(M, l['kpad'], W, xin, l['kpad'], G, W, gW, gb)
+      with torch.cuda.stream(side):
+        side.wait_event(ev_g)                       # G_i is ready
+        if l['concat']:
+          self._tn(M, W, W, xin, W, G, W, gW[:W], gb)
+          self._tn(M, spec.Fp, W, X0, spec.Fp, G, W, gW[W:], None)
+        else:
+          self._tn(M, l['kpad'], W, xin, l['kpad'], G, W, gW, gb)
+        e = torch.cuda.Event()
+        e.record(side)
+        tn_done[gi] = e
       if i > 0:
+        nxt = (gi + 1) % 3
+        if nxt in tn_done:                           # the dW that last read this buffer must be finished
+          main.wait_event(tn_done.pop(nxt))
         # G_{i-1} = (G_i W_i[:W]^T) * (Y_{i-1} > 0)
         _lib.call('hugs_gemm_nt', dt, M, W, W, 0, G, W, None, 0, self.wn[path][:W] if l['concat'] else self.wn[path], W, None,
-                  None, 1, 0, 0, acts[i], W, None, None, other, W)
-        G, other = other, G
+                  None, 1, 0, 0, acts[i], W, None, None, ring[nxt], W)
+        ev_g = torch.cuda.Event()
+        ev_g.record(main)
+        G, gi = ring[nxt], nxt
+    for e in tn_done.values():
+      main.wait_event(e)
+
+  def _side_stream(self):
+    if getattr(self, '_side', None) is None:
+      self._side = torch.cuda.Stream(device=self.device)
+    return self._side
