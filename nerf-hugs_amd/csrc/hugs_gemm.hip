@@ -818,12 +818,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_f32(int Mrows, int Kc, int N
   if (do_colsum && tid < 128) colsum_slab[(size_t)split * N + n0 + tid] = csum;
 }
 
-// sum fp32 slabs: out[i] = sum_s slab[s][i]   (deterministic order)
-__global__ void k_slab_reduce(const float* __restrict__ slab, int nsplit, size_t per, float* __restrict__ out) {
+// sum fp32 slabs: out[i] = sum_s slab[s][i]   (fixed order: deterministic).  Eight slab loads are kept in flight
+// per thread; a 16-slab, 4 MB-per-slab reduction is an HBM stream, not a latency chain.
+__global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ slab, int nsplit, size_t per,
+                                                     float* __restrict__ out) {
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= per) return;
-  float4 a = *(const float4*)(slab + i);
-  for (int s = 1; s < nsplit; ++s) {
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  int s = 0;
+  for (; s + 8 <= nsplit; s += 8) {
+    f32x4_t b[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) b[q] = __builtin_nontemporal_load((const f32x4_t*)(slab + (size_t)(s + q) * per + i));
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { a.x += b[q][0]; a.y += b[q][1]; a.z += b[q][2]; a.w += b[q][3]; }
+  }
+  for (; s < nsplit; ++s) {
     const float4 b = *(const float4*)(slab + (size_t)s * per + i);
     a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
   }

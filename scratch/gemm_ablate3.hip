@@ -9,6 +9,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 struct GemmEpi { const float* bias; const float* row_bias; int row_div, ld_rb; int relu; const void* mask; int ld_mask; const float* r1_row; const float* r1_col; void* out; int ldc; };
 __device__ __forceinline__ void glds16(const void* g, void* l) { __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0); }
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) { const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3; return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k; }
+#ifndef HUGS_NT_DIRECT_EPI
+#define HUGS_NT_DIRECT_EPI 1   // A/B-tested: +10 % over staging the C tile through LDS
+#endif
+typedef unsigned __attribute__((ext_vector_type(2))) u32x2_t;
 #ifndef HUGS_NT_VARIANT
 #define HUGS_NT_VARIANT 2   // 8 MFMA : 3 ds_read interleave of next-stage fragment reads (A/B-tested: +5 %)
 #endif
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 2 : 1) void k_gemm_nt_bf16_big(
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { if (MODE & 1) { asm volatile("" ::"v"(f.xa[i]), "v"(f.wb[j])); } else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wb[j], f.xa[i], acc[i][j], 0, 0, 0); }
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wb[j], f.xa[i], acc[i][j], 0, 0, 0);
   };
   constexpr int G = AIT + BIT;   // LDS-DMA instructions per thread per stage
   // iteration st: frags(st) are in `cur`; make stage st+1 visible, refill slot st%NSLOT with stage st+NSLOT,
@@ -153,16 +157,72 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 2 : 1) void k_gemm_nt_bf16_big(
     mfmas(f1);                                                                            // ns-1
   }
 #undef GL_ITER
-  __syncthreads();   // everyone is done reading the ring: reuse it as the C staging tile
-
-  if (MODE & 8) {
+#if HUGS_NT_DIRECT_EPI
+  if (WN == 4) {
+    // ---- epilogue straight from registers: bias / rank-1 / relu, v_cvt_pk_bf16_f32, one v_permlane16_swap pair
+    // per two neighbouring 16-column fragments turns the 8-byte-per-lane MFMA layout into 16 contiguous bytes per
+    // lane (64-byte runs per row): no LDS round trip, no barriers.
+    float4 bj[4], cj[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + kb * 4;
+      bj[j] = E.bias ? *(const float4*)(E.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      cj[j] = E.r1_row ? *(const float4*)(E.r1_col + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int ccol = n0 + wn * 64 + (kb & 1) * 16 + (kb >> 1) * 8;   // + jp*32: this lane's 8 output columns
+    uint4 mkv[8][2];
+    if (E.mask) {   // all 16 mask chunks in flight before the conversion work starts
 #pragma unroll
-      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp)
+          mkv[i][jp] = *(const uint4*)((const uint16_t*)E.mask + (size_t)(m0 + wm * 128 + i * 16 + r16) * E.ld_mask + ccol + jp * 32);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wm * 128 + i * 16 + r16;
+      const float r1 = E.r1_row ? E.r1_row[m] : 0.f;
+      const float* rbp = E.row_bias ? E.row_bias + (size_t)(m / E.row_div) * E.ld_rb + n0 + wn * 64 + kb * 4 : nullptr;
+      uint32_t pk[4][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x[4] = {acc[i][j][0] + bj[j].x + r1 * cj[j].x, acc[i][j][1] + bj[j].y + r1 * cj[j].y,
+                      acc[i][j][2] + bj[j].z + r1 * cj[j].z, acc[i][j][3] + bj[j].w + r1 * cj[j].w};
+        if (rbp) { const float4 b = *(const float4*)(rbp + j * 16); x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w; }
+        if (E.relu) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
+        bf16x4_t h;
+        h[0] = (__bf16)x[0]; h[1] = (__bf16)x[1]; h[2] = (__bf16)x[2]; h[3] = (__bf16)x[3];
+        const uint2 u = *(const uint2*)&h;
+        pk[j][0] = u.x; pk[j][1] = u.y;
+      }
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(pk[2 * jp][0], pk[2 * jp + 1][0], false, false);
+        const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(pk[2 * jp][1], pk[2 * jp + 1][1], false, false);
+        uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        if (E.mask) {
+          const uint4 mk = mkv[i][jp];
+          const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
+          uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t lo = mw[q] & 0xffffu, hi = mw[q] >> 16;
+            const uint32_t keep = (((lo & 0x7fffu) && !(lo & 0x8000u)) ? 0x0000ffffu : 0u) |
+                                  (((hi & 0x7fffu) && !(hi & 0x8000u)) ? 0xffff0000u : 0u);
+            vw[q] &= keep;
+          }
+          v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+        }
+        if (MODE & 8) *(uint4*)((uint16_t*)E.out + ((size_t)((ccol + jp * 32) >> 5) * M + m) * 32 + ((ccol + jp * 32) & 31)) = v;
+        else *(uint4*)((uint16_t*)E.out + (size_t)m * E.ldc + ccol + jp * 32) = v;
+      }
+    }
     return;
   }
-  // ---- epilogue
+#endif
+  __syncthreads();   // everyone is done reading the ring: reuse it as the C staging tile
+
+  // ---- epilogue: registers -> (bias, rank-1, relu) -> bf16 tile in LDS -> whole rows, 16 B per lane ----
   float4 bj[4], cj[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -234,6 +294,6 @@ int main() {
   hipMemcpy(A, h.data(), (size_t)M * K * 2, hipMemcpyHostToDevice); hipMemcpy(B, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice); hipMemset(bias, 0, N * 4);
   const double fl = 2.0 * M * N * K; float t;
 #define R(MODE, name) t = run<MODE>(M, N, K, A, B, bias, C); printf("%-28s %.3f ms %.0f TF\n", name, t, fl / t / 1e9);
-  R(0, "full") R(2, "full panelB") R(6, "full panelA+B") R(8, "no-epi") R(14, "no-epi panelA+B") R(1, "no-mfma") R(3, "no-mfma panelB") R(7, "no-mfma panelA+B") R(9, "no-mfma no-epi") R(15, "no-mfma no-epi panelA+B") R(0, "full")
+  for (int rep = 0; rep < 3; ++rep) { R(0, "row-major") R(2, "panel B") R(6, "panel A+B") R(14, "panel A+B+out") }
   return 0;
 }
