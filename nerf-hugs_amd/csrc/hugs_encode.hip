@@ -119,7 +119,14 @@ __global__ __launch_bounds__(256) void k_cast_ipe(int nrays, int S, const float*
           float x = s_lm[s][j] * sc;
           if (half) x = x + 1.57079632679489661923f;   // sin(x + pi/2), as the reference does
           const float var = s_lv[s][j] * (sc * sc);
-          val = expf(-0.5f * var) * safe_sinf(x);
+          if (BF16) {
+            // bf16 features carry 8 bits: hardware v_sin_f32 (argument in revolutions, after an exact fract) and
+            // v_exp_f32 are well inside that; the fp32 parity mode keeps the accurate library path.
+            const float rev = x * 0.15915494309189533577f;
+            val = __expf(-0.5f * var) * __builtin_amdgcn_sinf(rev - floorf(rev));
+          } else {
+            val = expf(-0.5f * var) * safe_sinf(x);
+          }
         }
         v[q] = val;
       }
