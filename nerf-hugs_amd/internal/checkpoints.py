@@ -1,0 +1,95 @@
+"""Checkpoint interop with the reference's `flax.training.checkpoints` files (train.py:121,232-236): a flax
+msgpack state dict of `TrainState{step, params, opt_state}`.  flax is not installed here, so this
+follows flax.serialization's documented wire format (msgpack with ExtType 1 = ndarray packed as
+(shape, dtype.name, C-order bytes), ExtType 3 = numpy scalar) and is round-trip tested only -- reading a
+checkpoint written by real flax is "parity unpinned" until one is available.
+
+Layout written / read:
+  {'step': i32, 'params': {'params': {module: {Dense_i: {'kernel','bias'}}, 'GloEmbed_0': {'embedding'}}},
+   'opt_state': {'0': {'count': i32, 'mu': <params tree>, 'nu': <params tree>}, '1': {'count': i32}}}
+(optax.adam = chain(scale_by_adam, scale_by_schedule); tuples serialise as dicts with '0','1',... keys)."""
+import os
+import re
+
+import msgpack
+import numpy as np
+import torch
+
+_EXT_NDARRAY, _EXT_NPSCALAR = 1, 3
+
+
+def _pack_ext(x):
+  if isinstance(x, torch.Tensor):
+    x = x.detach().cpu().numpy()
+  if isinstance(x, np.ndarray):
+    return msgpack.ExtType(_EXT_NDARRAY, msgpack.packb((list(x.shape), x.dtype.name, x.tobytes('C')), use_bin_type=True))
+  if isinstance(x, np.generic):
+    return msgpack.ExtType(_EXT_NPSCALAR, msgpack.packb(((), x.dtype.name, x.tobytes()), use_bin_type=True))
+  raise TypeError(type(x))
+
+
+def _unpack_ext(code, data):
+  if code in (_EXT_NDARRAY, _EXT_NPSCALAR):
+    shape, dtype, buf = msgpack.unpackb(data, raw=False)
+    arr = np.frombuffer(buf, dtype=np.dtype(dtype)).reshape(shape)
+    return arr if code == _EXT_NDARRAY else arr[()]
+  return msgpack.ExtType(code, data)
+
+
+def to_bytes(tree):
+  return msgpack.packb(tree, default=_pack_ext, strict_types=True, use_bin_type=True)
+
+
+def from_bytes(b):
+  return msgpack.unpackb(b, ext_hook=_unpack_ext, raw=False, strict_map_key=False)
+
+
+def _tree_np(model, flat):
+  t = model.variables(flat)
+  conv = lambda d: {k: (conv(v) if isinstance(v, dict) else v.detach().cpu().numpy().copy()) for k, v in d.items()}
+  return conv(dict(t))
+
+
+def state_dict(state):
+  model = state.model
+  return {'step': np.int32(state.step), 'params': _tree_np(model, state.flat),
+          'opt_state': {'0': {'count': np.int32(state.step), 'mu': _tree_np(model, state.m)['params'],
+                              'nu': _tree_np(model, state.v)['params']},
+                        '1': {'count': np.int32(state.step)}}}
+
+
+def save_checkpoint(ckpt_dir, state, step, keep=100):
+  """flax.training.checkpoints.save_checkpoint(dir, state, step, keep) (train.py:232-236)."""
+  os.makedirs(ckpt_dir, exist_ok=True)
+  path = os.path.join(ckpt_dir, f'checkpoint_{int(step)}')
+  with open(path + '.tmp', 'wb') as f:
+    f.write(to_bytes(state_dict(state)))
+  os.replace(path + '.tmp', path)
+  olds = sorted((int(m.group(1)) for m in (re.fullmatch(r'checkpoint_(\d+)', n) for n in os.listdir(ckpt_dir)) if m))
+  for s in olds[:-keep]:
+    os.remove(os.path.join(ckpt_dir, f'checkpoint_{s}'))
+  return path
+
+
+def latest_checkpoint(ckpt_dir):
+  if not ckpt_dir or not os.path.isdir(ckpt_dir):
+    return None
+  steps = [int(m.group(1)) for m in (re.fullmatch(r'checkpoint_(\d+)', n) for n in os.listdir(ckpt_dir)) if m]
+  return os.path.join(ckpt_dir, f'checkpoint_{max(steps)}') if steps else None
+
+
+def restore_checkpoint(ckpt_dir, state):
+  """flax.training.checkpoints.restore_checkpoint(dir, state) (train.py:121): returns `state` unchanged when there
+  is no checkpoint, otherwise loads step / params / Adam moments in place."""
+  path = latest_checkpoint(ckpt_dir) if os.path.isdir(ckpt_dir or '') else ckpt_dir
+  if not path or not os.path.exists(path):
+    return state
+  with open(path, 'rb') as f:
+    d = from_bytes(f.read())
+  model = state.model
+  model.load_variables(state.flat, d['params'])
+  adam = d['opt_state']['0'] if '0' in d['opt_state'] else d['opt_state'][0]
+  model.load_variables(state.m, {'params': adam['mu'].get('params', adam['mu'])})
+  model.load_variables(state.v, {'params': adam['nu'].get('params', adam['nu'])})
+  state.step = int(np.asarray(d['step']))
+  return state

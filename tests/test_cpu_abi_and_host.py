@@ -140,3 +140,32 @@ def test_utils_shard_unshard_and_dummy_rays():
   s = utils.shard(x)
   assert s.shape == (1, 8, 3)
   assert torch.equal(utils.unshard(s, 2), x[:-2])
+
+
+def test_checkpoint_roundtrip(tmp_path):
+  """flax-msgpack state dict round trip (train.py:121,232-236 call pattern) on CPU buffers."""
+  from nerf_hugs_amd.internal import checkpoints, configs, models, train_utils
+  configs.clear_config()
+  configs.parse_config_files_and_bindings(None, ["PropMLP.net_depth = 4", "PropMLP.net_width = 128", "PropMLP.disable_rgb = True",
+                                                 "NerfMLP.net_depth = 8", "NerfMLP.net_width = 128", "Model.num_glo_features = 4"])
+  cfg = configs.make_config()
+  model = models.Model(cfg)
+  flat = model.init(3, 'cpu')
+  state, _ = train_utils.create_optimizer(cfg, flat, model)
+  state.m.normal_(); state.v.uniform_(); state.step = 1234
+  p = checkpoints.save_checkpoint(str(tmp_path), state, state.step)
+  assert os.path.basename(p) == 'checkpoint_1234'
+  d = checkpoints.from_bytes(open(p, 'rb').read())
+  assert set(d.keys()) == {'step', 'params', 'opt_state'}
+  k = d['params']['params']['NerfMLP_0']['Dense_5']['kernel']
+  assert k.shape == (128 + 504, 128) and k.dtype == np.float32        # flax [in,out], skip-concat layer
+  assert d['opt_state']['0']['mu']['GloEmbed_0']['embedding'].shape == (3500, 4)
+  state2, _ = train_utils.create_optimizer(cfg, model.init(9, 'cpu'), model)
+  state2 = checkpoints.restore_checkpoint(str(tmp_path), state2)
+  assert state2.step == 1234
+  lay = model.layout
+  for lf in lay.leaves:        # logical (unpadded) leaves round-trip exactly; padding rows stay zero
+    for a, b in ((state.flat, state2.flat), (state.m, state2.m), (state.v, state2.v)):
+      assert torch.equal(lay.view(a, lf['path']), lay.view(b, lf['path']))
+  assert checkpoints.restore_checkpoint(str(tmp_path / 'none'), state2) is state2
+  configs.clear_config()
