@@ -546,7 +546,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
                                                               float* __restrict__ slab, int lds_out,
                                                               float* __restrict__ colsum_slab) {
   constexpr int NSLOT = 4, STAGE = 32768, XB = 16384;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[NSLOT * STAGE];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[128 * 1040 > NSLOT * STAGE ? 128 * 1040 : NSLOT * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntn = N >> 8, ntk = Kc >> 8, tiles = ntn * ntk;
@@ -644,15 +644,32 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
   mfmas(f1);
 #undef GT_ITER
 
+  // Epilogue: the fp32 tile leaves through LDS (the ring is free now) so that every wave instruction stores one
+  // whole 1 KiB slab row instead of sixteen 64-byte runs.  Two passes of 128 Kc-rows (pitch 1040 B).
   float* out = slab + (size_t)split * Kc * lds_out;
+  constexpr int TP = 1040;
+  __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int h = 0; h < 2; ++h) {
+    if ((wk >> 1) == h) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = c0 + wk * 64 + j * 16 + s;
-      const int n = n0 + wn * 128 + i * 16 + g * 4;
-      *(float4*)(out + (size_t)c * lds_out + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int rl = (wk & 1) * 64 + j * 16 + s;            // row inside this pass
+          const int cl = wn * 128 + i * 16 + g * 4;
+          *(float4*)(lds + rl * TP + cl * 4) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
     }
+    __syncthreads();
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {                            // 128 rows x 64 chunks(16 B) / 512 threads
+      const int p = it * 512 + tid, rl = p >> 6, cq = p & 63;
+      const float4 v = *(const float4*)(lds + rl * TP + cq * 16);
+      *(float4*)(out + (size_t)(c0 + h * 128 + rl) * lds_out + n0 + cq * 4) = v;
+    }
+    __syncthreads();
+  }
   if (do_colsum && s == 0) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {

@@ -86,7 +86,7 @@ class Model:
       d = variables['params'] if 'params' in variables else variables
       for k in lf['path']:
         d = d[k]
-      self.layout.view(flat, lf['path']).copy_(torch.as_tensor(np.asarray(d) if not torch.is_tensor(d) else d).to(flat.device))
+      self.layout.view(flat, lf['path']).copy_((torch.from_numpy(np.array(d)) if not torch.is_tensor(d) else d).to(flat.device))
     return flat
 
   # -- forward -----------------------------------------------------------------------------------------
