@@ -5,7 +5,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libhugs_hip.so')
+LIB_PATH = os.environ.get('HUGS_LIB_PATH', os.path.join(_HERE, 'csrc', 'libhugs_hip.so'))   # env override: A/B builds
 
 # i = int, f = float, p = device/host pointer, q = long long, s = stream
 _PROTOS = {
