@@ -52,14 +52,12 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 2 : 1) void k_gemm_nt_bf16_big(
 #pragma unroll
     for (int it = 0; it < AIT; ++it) {
       const int p = it * NT + tid, row = p >> 2, col = ((p & 3) ^ (3 * ((row >> 2) & 1))) * 8;
-      if (MODE & 4) glds16(Abase + ((size_t)(kcol >> 5) * M + m0 + row) * 32 + col, la + (it * NT + wv * 64) * 16);
-      else glds16(Abase + (size_t)(m0 + row) * lda + kcol + col, la + (it * NT + wv * 64) * 16);
+      glds16(Abase + (size_t)(m0 + row) * lda + kcol + col, la + (it * NT + wv * 64) * 16);
     }
 #pragma unroll
     for (int it = 0; it < BIT; ++it) {
       const int p = it * NT + tid, row = p >> 2, col = ((p & 3) ^ (3 * ((row >> 2) & 1))) * 8;
-      if (MODE & 2) glds16(Bt + ((size_t)(kglob >> 5) * N + n0 + row) * 32 + col, lb + (it * NT + wv * 64) * 16);
-      else glds16(Bt + (size_t)(n0 + row) * ldb + kglob + col, lb + (it * NT + wv * 64) * 16);
+      glds16(Bt + (size_t)(n0 + row) * ldb + kglob + col, lb + (it * NT + wv * 64) * 16);
     }
   };
 
@@ -96,10 +94,10 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 2 : 1) void k_gemm_nt_bf16_big(
 #define GL_ITER(cur, nxt, st, VM)                                                        \
   {                                                                                       \
     asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");                     \
-    __builtin_amdgcn_s_barrier();                                                         \
+    if (!(MODE & 2)) __builtin_amdgcn_s_barrier();                                                         \
     asm volatile("" ::: "memory");                                                        \
-    if ((st) + NSLOT < ns) stage((st) + NSLOT);                                           \
-    load_frags(nxt, (st) + 1);                                                            \
+    if (!(MODE & 1) && (st) + NSLOT < ns) stage((st) + NSLOT);                                           \
+    if (!(MODE & 4)) load_frags(nxt, (st) + 1); else { _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) asm volatile("" : "+v"(nxt.xa[q_])); }                                                            \
     mfmas(cur);                                                                           \
     if (HUGS_NT_VARIANT == 2) {                                                           \
       _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                  \
@@ -157,6 +155,13 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 2 : 1) void k_gemm_nt_bf16_big(
     mfmas(f1);                                                                            // ns-1
   }
 #undef GL_ITER
+  if (MODE & 8) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
 #if HUGS_NT_DIRECT_EPI
   if (WN == 4) {
     // ---- epilogue straight from registers: bias / rank-1 / relu, v_cvt_pk_bf16_f32, one v_permlane16_swap pair
@@ -213,8 +218,7 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 2 : 1) void k_gemm_nt_bf16_big(
           }
           v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
         }
-        if (MODE & 8) *(uint4*)((uint16_t*)E.out + ((size_t)((ccol + jp * 32) >> 5) * M + m) * 32 + ((ccol + jp * 32) & 31)) = v;
-        else *(uint4*)((uint16_t*)E.out + (size_t)m * E.ldc + ccol + jp * 32) = v;
+        *(uint4*)((uint16_t*)E.out + (size_t)m * E.ldc + ccol + jp * 32) = v;
       }
     }
     return;
@@ -279,7 +283,7 @@ template <int MODE> float run(int M, int N, int K, uint16_t* A, uint16_t* B, flo
   GemmEpi E{bias, nullptr, 1, 0, 1, nullptr, 0, nullptr, nullptr, C, N};
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   dim3 g((M / 256) * (N / 256)), b(512);
-  for (int i = 0; i < 3; ++i) k_gemm_nt_bf16_big<4, MODE><<<g, b>>>(M, N, K, 0, A, K, nullptr, 0, B, K, E);
+  for (int i = 0; i < 5; ++i) k_gemm_nt_bf16_big<4, MODE><<<g, b>>>(M, N, K, 0, A, K, nullptr, 0, B, K, E);
   hipEventRecord(e0);
   for (int i = 0; i < 10; ++i) k_gemm_nt_bf16_big<4, MODE><<<g, b>>>(M, N, K, 0, A, K, nullptr, 0, B, K, E);
   hipEventRecord(e1); hipEventSynchronize(e1);
@@ -293,7 +297,7 @@ int main() {
   hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&B, (size_t)N * K * 2); hipMalloc(&C, (size_t)M * N * 2); hipMalloc(&bias, N * 4);
   hipMemcpy(A, h.data(), (size_t)M * K * 2, hipMemcpyHostToDevice); hipMemcpy(B, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice); hipMemset(bias, 0, N * 4);
   const double fl = 2.0 * M * N * K; float t;
-#define R(MODE, name) t = run<MODE>(M, N, K, A, B, bias, C); printf("%-28s %.3f ms %.0f TF\n", name, t, fl / t / 1e9);
-  for (int rep = 0; rep < 3; ++rep) { R(0, "row-major") R(2, "panel B") R(6, "panel A+B") R(14, "panel A+B+out") }
+#define R(MODE, name) t = run<MODE>(M, N, K, A, B, bias, C); printf("%-44s %.3f ms %.0f TF\n", name, t, fl / t / 1e9);
+  R(0, "warm") R(0, "full") R(8, "no-epi") R(9, "no-epi no-glds") R(11, "no-epi no-glds no-barrier") R(15, "no-epi no-glds no-barrier no-dsread (MFMA only)") R(13, "no-epi no-glds no-dsread (MFMA+barrier)") R(0, "full")
   return 0;
 }
