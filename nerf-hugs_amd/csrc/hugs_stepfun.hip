@@ -14,7 +14,7 @@
 // binary searches instead of compare matrices, window max over an index range.
 #include "hugs_common.h"
 
-#define SF_CAP 256  // max bins handled per ray (3*S_prev <= 256)
+#define SF_CAP 512  // max bins handled per ray; a level whose largest array is <= 256 uses 4 elements per lane, else 8
 
 __device__ __forceinline__ float sf_expf(float x) {
   if (x != x) return x;
@@ -70,11 +70,11 @@ __device__ __forceinline__ float sf_logf(float x) {
 }
 
 // canonical wave-order sum over arr[0..n) (n <= 256), arr in LDS, zero padded reads
+template <int C>
 __device__ __forceinline__ float sf_wave_sum(const float* arr, int n, int lane) {
-  float v[4];
+  float p = 0.0f;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { int i = 4 * lane + k; v[k] = i < n ? arr[i] : 0.0f; }
-  float p = ((v[0] + v[1]) + v[2]) + v[3];
+  for (int k = 0; k < C; ++k) { int i = C * lane + k; float v = i < n ? arr[i] : 0.0f; p = k == 0 ? v : p + v; }
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) p = p + __shfl_xor(p, d);
   return p;
@@ -92,26 +92,29 @@ __device__ __forceinline__ int sf_count_lt(const float* base, int len, float off
   return lo;
 }
 
+template <int C>
 struct SfLds {
-  float tp[SF_CAP + 4];   // previous fenceposts
-  float p[SF_CAP];        // pdf of previous bins / softmax weights
-  float td[SF_CAP + 4];   // dilated fenceposts, later cw0
-  float wd[SF_CAP];       // dilated weights
-  float tin[SF_CAP + 4];  // fenceposts fed to the sampler
-  float cen[SF_CAP];      // sampled centers
+  static constexpr int CAP = 64 * C;
+  float tp[CAP + 4];   // previous fenceposts
+  float p[CAP];        // pdf of previous bins / softmax weights
+  float td[CAP + 4];   // dilated fenceposts, later cw0
+  float wd[CAP];       // dilated weights
+  float tin[CAP + 4];  // fenceposts fed to the sampler
+  float cen[CAP];      // sampled centers
 };
 
+template <int C>
 __global__ __launch_bounds__(256) void k_level_sample(
     int nrays, const float* __restrict__ t_prev, const float* __restrict__ w_prev, int n_prev, int do_dilate,
     float dilation, float dlo, float dhi, float anneal, float pad, const float* __restrict__ u_base,
     const float* __restrict__ jitter, int jitter_stride, int ns, int raydist, const float* __restrict__ near,
     const float* __restrict__ far, float* __restrict__ sdist, float* __restrict__ tdist, int32_t* __restrict__ idx_out,
     float* __restrict__ t_in_out, float* __restrict__ w_in_out) {
-  __shared__ SfLds lds[4];
+  __shared__ SfLds<C> lds[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ray = blockIdx.x * 4 + wv;
   const bool live = ray < nrays;
-  SfLds& L = lds[wv];
+  SfLds<C>& L = lds[wv];
   const float eps2 = HUGS_EPS * HUGS_EPS;
   const float ninf = -__builtin_inff();
 
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(256) void k_level_sample(
       }
     }
     __syncthreads();
-    float s = live ? sf_wave_sum(L.wd, m - 1, lane) : 1.0f;
+    float s = live ? sf_wave_sum<C>(L.wd, m - 1, lane) : 1.0f;
     float den = s > eps2 ? s : eps2;
     n_in = 3 * n - 2;
     if (live) {
@@ -192,33 +195,33 @@ __global__ __launch_bounds__(256) void k_level_sample(
   __syncthreads();
   if (live) for (int i = lane; i < n_in; i += 64) L.wd[i] = sf_expf(L.wd[i] - mx);
   __syncthreads();
-  float den = live ? sf_wave_sum(L.wd, n_in, lane) : 1.0f;
+  float den = live ? sf_wave_sum<C>(L.wd, n_in, lane) : 1.0f;
   if (live) for (int i = lane; i < n_in; i += 64) L.p[i] = L.wd[i] / den;
   __syncthreads();
   if (live) {
     // canonical inclusive scan of p[0..n_in-2]
-    float v[4];
+    float v[C];
+    float tot = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { int i = 4 * lane + k; v[k] = i < n_in - 1 ? L.p[i] : 0.0f; }
-    float tot = ((v[0] + v[1]) + v[2]) + v[3];
+    for (int k = 0; k < C; ++k) { int i = C * lane + k; v[k] = i < n_in - 1 ? L.p[i] : 0.0f; tot = k == 0 ? v[k] : tot + v[k]; }
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { float t = __shfl_up(tot, d); if (lane >= d) tot = tot + t; }
     float run = __shfl_up(tot, 1);
     if (lane == 0) run = 0.0f;
-    float cs[4];
+    float cs[C];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { run = run + v[k]; cs[k] = run; }
+    for (int k = 0; k < C; ++k) { run = run + v[k]; cs[k] = run; }
     // The tree-ordered prefix of lane l+1 can round below the sequential tail of lane l when the
     // next weight is tiny; a running max (exact, order independent) restores the monotone CDF the
     // interval search relies on.
-    float pm = cs[3];
+    float pm = cs[C - 1];
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { float t = __shfl_up(pm, d); if (lane >= d) pm = fmaxf(pm, t); }
     float pme = __shfl_up(pm, 1);
     if (lane == 0) pme = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      int i = 4 * lane + k;
+    for (int k = 0; k < C; ++k) {
+      int i = C * lane + k;
       float c = fmaxf(cs[k], pme);
       if (i < n_in - 1) L.td[i + 1] = c < 1.0f ? c : 1.0f;
     }
@@ -283,9 +286,16 @@ extern "C" int hugs_level_sample_fwd(int nrays, const float* t_prev, const float
                n_prev, n_in, SF_CAP);
   HUGS_REQUIRE(raydist == 0 || raydist == 1, -4, "hugs_level_sample_fwd: raydist must be 0 (linear) or 1 (reciprocal)");
   if (nrays <= 0) return 0;
-  hipLaunchKernelGGL(k_level_sample, dim3((nrays + 3) / 4), dim3(256), 0, (hipStream_t)stream, nrays, t_prev, w_prev,
-                     n_prev, do_dilate, dilation, domain_lo, domain_hi, anneal, resample_padding, u_base, jitter,
-                     jitter_stride, num_samples, raydist, near, far, sdist, tdist, idx_out, t_in_out, w_in_out);
+  // one lane-chunk for the whole level, chosen from its largest array (the oracle applies the same rule)
+  const int big = n_in > num_samples ? n_in : num_samples;
+  if (big <= 256)
+    hipLaunchKernelGGL(k_level_sample<4>, dim3((nrays + 3) / 4), dim3(256), 0, (hipStream_t)stream, nrays, t_prev, w_prev,
+                       n_prev, do_dilate, dilation, domain_lo, domain_hi, anneal, resample_padding, u_base, jitter,
+                       jitter_stride, num_samples, raydist, near, far, sdist, tdist, idx_out, t_in_out, w_in_out);
+  else
+    hipLaunchKernelGGL(k_level_sample<8>, dim3((nrays + 3) / 4), dim3(256), 0, (hipStream_t)stream, nrays, t_prev, w_prev,
+                       n_prev, do_dilate, dilation, domain_lo, domain_hi, anneal, resample_padding, u_base, jitter,
+                       jitter_stride, num_samples, raydist, near, far, sdist, tdist, idx_out, t_in_out, w_in_out);
   HUGS_CHECK_LAUNCH("hugs_level_sample_fwd");
   return 0;
 }

@@ -17,7 +17,8 @@
  *   - the three order-sensitive sums (softmax denominator, CDF prefix sum,
  *     dilation renormaliser) use the "wave order": 64 virtual lanes, lane l owns
  *     elements 4l..4l+3 summed left to right, lanes combined by an xor-butterfly
- *     (reduce) or a Kogge-Stone scan (prefix).  Capacity 256 elements.
+ *     (reduce) or a Kogge-Stone scan (prefix).  Capacity 256 elements; a level whose largest array exceeds
+ *     256 (e.g. 128 proposal samples -> 382 dilated bins) uses 8 elements per lane (capacity 512) throughout.
  * XLA's own summation order is unknowable here -- "parity
  * unpinned" at that level; the golden fixtures pin this file against the
  * reference source executed under numpy float32 to ~1e-6.
@@ -27,7 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define ORC_CAP 256
+#define ORC_CAP 512
 #define ORC_EPS 1.1920928955078125e-07f /* finfo(float32).eps */
 
 static float bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -91,11 +92,16 @@ float orc_logf(float x) {
 }
 
 /* ---- canonical "wave order" sums over n <= 256 values ---- */
+static int g_chunk = 4;   /* elements per virtual lane for the current level (4: capacity 256, 8: capacity 512) */
+static int chunk_for(int nmax) { return nmax <= 256 ? 4 : 8; }
 static void lane_partials(const float* x, int n, float lane[64]) {
   for (int l = 0; l < 64; ++l) {
-    float v[4];
-    for (int k = 0; k < 4; ++k) v[k] = (4 * l + k) < n ? x[4 * l + k] : 0.0f;
-    lane[l] = ((v[0] + v[1]) + v[2]) + v[3];
+    float s = 0.0f;
+    for (int k = 0; k < g_chunk; ++k) {
+      float v = (g_chunk * l + k) < n ? x[g_chunk * l + k] : 0.0f;
+      s = k == 0 ? v : s + v;          /* ((v0+v1)+v2)+... left to right */
+    }
+    lane[l] = s;
   }
 }
 float orc_wave_sum(const float* x, int n) {
@@ -117,8 +123,8 @@ void orc_wave_cumsum(const float* x, int n, float* out) {
   }
   for (int l = 0; l < 64; ++l) {
     float run = l ? a[l - 1] : 0.0f;
-    for (int k = 0; k < 4; ++k) {
-      int i = 4 * l + k;
+    for (int k = 0; k < g_chunk; ++k) {
+      int i = g_chunk * l + k;
       if (i >= n) break;
       run = run + x[i];
       out[i] = run;
@@ -133,8 +139,8 @@ static int cmp_float(const void* a, const void* b) {
 
 /* stepfun.py:99-128 max_dilate_weights(renormalize=True): one ray.
  * t[n+1], w[n] -> t_dil[3n+1], w_dil[3n].  Returns 0, or -1 if 3n > capacity. */
-int orc_max_dilate_weights(const float* t, const float* w, int n, float dilation,
-                           float lo, float hi, float* t_dil, float* w_dil) {
+static int max_dilate_weights_(const float* t, const float* w, int n, float dilation,
+                               float lo, float hi, float* t_dil, float* w_dil) {
   const float eps2 = ORC_EPS * ORC_EPS;
   if (3 * n > ORC_CAP) return -1;
   float p[ORC_CAP], t0[ORC_CAP], t1[ORC_CAP];
@@ -161,6 +167,12 @@ int orc_max_dilate_weights(const float* t, const float* w, int n, float dilation
   float den = s > eps2 ? s : eps2;
   for (int i = 0; i < m - 1; ++i) w_dil[i] = w_dil[i] / den;  /* stepfun.py:126-127 */
   return 0;
+}
+
+int orc_max_dilate_weights(const float* t, const float* w, int n, float dilation,
+                           float lo, float hi, float* t_dil, float* w_dil) {
+  g_chunk = chunk_for(3 * n);
+  return max_dilate_weights_(t, w, n, dilation, lo, hi, t_dil, w_dil);
 }
 
 /* stepfun.py:131-161 + math.py:108-127: invert the CDF of softmax(logits) on t at u.
@@ -204,8 +216,8 @@ int orc_invert_cdf(const float* u, int ns, const float* t, const float* logits, 
 }
 
 /* stepfun.py:214-263 sample_intervals given explicit u (= sample()'s u, a7). */
-int orc_sample_intervals(const float* u, int ns, const float* t, const float* logits, int n,
-                         float lo, float hi, float* out /*ns+1*/, int32_t* idx /*ns*/) {
+static int sample_intervals_(const float* u, int ns, const float* t, const float* logits, int n,
+                             float lo, float hi, float* out /*ns+1*/, int32_t* idx /*ns*/) {
   if (ns <= 1 || ns > ORC_CAP) return -2;
   float c[ORC_CAP];
   int rc = orc_invert_cdf(u, ns, t, logits, n, c, idx);
@@ -216,6 +228,12 @@ int orc_sample_intervals(const float* u, int ns, const float* t, const float* lo
   out[0] = first > lo ? first : lo;
   out[ns] = last < hi ? last : hi;
   return 0;
+}
+
+int orc_sample_intervals(const float* u, int ns, const float* t, const float* logits, int n,
+                         float lo, float hi, float* out, int32_t* idx) {
+  g_chunk = chunk_for(n > ns ? n : ns);
+  return sample_intervals_(u, ns, t, logits, n, lo, hi, out, idx);
 }
 
 /* One sampling level for one ray, following models.py:155-212:
@@ -230,9 +248,14 @@ int orc_level_sample(const float* t_prev, const float* w_prev, int n_prev, int d
                      float* t_in_out, float* w_in_out, int* n_in_out) {
   float tb[ORC_CAP + 1], wb[ORC_CAP], lg[ORC_CAP], u[ORC_CAP];
   const float* t_in = t_prev; const float* w_in = w_prev; int n = n_prev;
+  { /* one lane-chunk for the whole level, from its largest array (same rule as the HIP launch) */
+    int big = do_dilate ? 3 * n_prev : n_prev;
+    if (ns > big) big = ns;
+    g_chunk = chunk_for(big);
+  }
   if (do_dilate) {
     float td[ORC_CAP + 1], wd[ORC_CAP];
-    int rc = orc_max_dilate_weights(t_prev, w_prev, n_prev, dilation, lo, hi, td, wd);
+    int rc = max_dilate_weights_(t_prev, w_prev, n_prev, dilation, lo, hi, td, wd);
     if (rc) return rc;
     n = 3 * n_prev - 2;                       /* sdist[1:-1] has 3n-1 posts -> 3n-2 bins */
     memcpy(tb, td + 1, (n + 1) * sizeof(float));
@@ -243,7 +266,7 @@ int orc_level_sample(const float* t_prev, const float* w_prev, int n_prev, int d
   for (int i = 0; i < n; ++i)                 /* models.py:191-193 */
     lg[i] = t_in[i + 1] > t_in[i] ? anneal * orc_logf(w_in[i] + resample_padding) : -INFINITY;
   for (int j = 0; j < ns; ++j) u[j] = u_base[j] + jitter;
-  int rc = orc_sample_intervals(u, ns, t_in, lg, n, lo, hi, sdist, idx);
+  int rc = sample_intervals_(u, ns, t_in, lg, n, lo, hi, sdist, idx);
   if (rc) return rc;
   float s_near = raydist == 1 ? 1.0f / near : near;
   float s_far = raydist == 1 ? 1.0f / far : far;
