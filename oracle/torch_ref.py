@@ -328,6 +328,8 @@ class ModelCfg:
     self.width_viewdirs = 128
     self.skip_layer = 4
     self.max_deg_point = 12
+    self.basis_shape = 'icosahedron'
+    self.basis_subdivisions = 2
     self.deg_view = 4
     self.density_bias = -1.
     self.rgb_padding = 0.001
@@ -370,7 +372,7 @@ def kubric_cfg(**kw):
 def mlp_layer_dims(cfg, which):
   """Dense layer (fan_in, fan_out) list in flax creation order (models.py:432-519)."""
   depth, width = (cfg.nerf_depth, cfg.nerf_width) if which == 'nerf' else (cfg.prop_depth, cfg.prop_width)
-  F = 2 * 21 * cfg.max_deg_point
+  F = 2 * generate_basis(cfg.basis_shape, cfg.basis_subdivisions).shape[0] * cfg.max_deg_point
   dims, k = [], F
   for i in range(depth):
     dims.append((k, width))
@@ -456,7 +458,7 @@ def model_forward(cfg, variables, rays, train_frac, u01, compute_extras, zero_gl
   P = variables['params']
   dt = rays['origins'].dtype
   N = rays['origins'].shape[0]
-  basis = torch.tensor(generate_basis('icosahedron', 2).T.copy(), dtype=dt)  # [3,21]
+  basis = torch.tensor(generate_basis(cfg.basis_shape, cfg.basis_subdivisions).T.copy(), dtype=dt)  # [3,nb]
   glo = None
   if cfg.num_glo_features > 0:
     glo = (torch.zeros(N, cfg.num_glo_features, dtype=dt) if zero_glo else

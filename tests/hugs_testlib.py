@@ -47,7 +47,9 @@ def make_pair(gin_lines, seed=3, compute_dtype='fp32'):
       transient_type=config.transient_type, patch_size=config.patch_size,
       robustnerf_inlier_quantile=config.robustnerf_inlier_quantile, grad_max_norm=config.grad_max_norm,
       lr_init=config.lr_init, lr_final=config.lr_final, max_steps=config.max_steps,
-      lr_delay_steps=config.lr_delay_steps, lr_delay_mult=config.lr_delay_mult, adam_eps=config.adam_eps)
+      lr_delay_steps=config.lr_delay_steps, lr_delay_mult=config.lr_delay_mult, adam_eps=config.adam_eps,
+      basis_shape=model.nerf_spec.basis_shape, basis_subdivisions=model.nerf_spec.basis_subdivisions,
+      max_deg_point=model.nerf_spec.max_deg_point)
   # oracle params = copies of the product's (logical, unpadded) leaves
   tree = model.variables(state.flat)['params']
   P = {m: ({k: {kk: vv.detach().cpu().clone() for kk, vv in v.items()} for k, v in sub.items()} if m != 'GloEmbed_0'

@@ -140,3 +140,16 @@ def test_bf16_full_width_step_vs_oracle():
     assert 0.9 < float(g.norm() / og.norm()) < 1.1, name
     checked += 1
   assert checked >= 12
+
+
+def test_train_step_upstream_blender_llff_shape():
+  """The upstream multinerf gins shipped with the reference (blender_256.gin / llff_256.gin): 128 proposal samples
+  (382 dilated bins -> capacity-512 sampler), octahedron basis with 16 degrees (96 features), cylinder rays,
+  width-256 nets, adam_eps 1e-8.  Bindings restated here because the gin files do not travel to the GPU box."""
+  gin = ["Config.patch_size = 8", "Config.data_loss_type = 'mse'", "Config.adam_eps = 1e-8", "Config.distortion_loss_mult = 0.01",
+         "Model.ray_shape = 'cylinder'", "Model.opaque_background = True", "Model.num_levels = 2",
+         "Model.num_prop_samples = 128", "Model.num_nerf_samples = 32", "PropMLP.net_depth = 4", "PropMLP.net_width = 256",
+         "PropMLP.basis_shape = 'octahedron'", "PropMLP.basis_subdivisions = 1", "PropMLP.disable_rgb = True",
+         "NerfMLP.net_depth = 8", "NerfMLP.net_width = 256", "NerfMLP.basis_shape = 'octahedron'",
+         "NerfMLP.basis_subdivisions = 1", "NerfMLP.max_deg_point = 16", "PropMLP.max_deg_point = 16"]
+  _run_case(gin, near=0.2, far=1.0)
