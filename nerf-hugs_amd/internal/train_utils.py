@@ -200,7 +200,13 @@ def create_train_step(model, config, is_finetune=False):
     prop_lo = layout.by_path[('PropMLP_0', 'Dense_0', 'kernel')]['off']
     last_prop = [lf for lf in layout.leaves if lf['path'][0] == 'PropMLP_0'][-1]
     prop_hi = last_prop['off'] + int(np.prod(last_prop['pshape']))
+    ar_work = None
+    nerf_hi = layout.by_path[('PropMLP_0', 'Dense_0', 'kernel')]['off']      # NerfMLP leaves come first
     for l in range(L - 1, -1, -1):
+      if world > 1 and l == L - 2 and ar_work is None:
+        # the NerfMLP gradient (96 % of the bytes) is complete: start its all-reduce now, it overlaps the
+        # proposal levels' backward (RCCL runs on its own stream; the tail is reduced after the loop)
+        ar_work = dist.all_reduce(grad[:nerf_hi], op=dist.ReduceOp.SUM, async_op=True)
       coef = config.data_loss_mult if l == L - 1 else config.data_coarse_loss_mult
       is_prop = l < L - 1
       if is_finetune and is_prop:
@@ -219,7 +225,11 @@ def create_train_step(model, config, is_finetune=False):
       grad[prop_lo:prop_hi].zero_()
     # ---- pmean(grad), pmean(stats) ------------------------------------------------------------------
     if world > 1:
-      dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+      if ar_work is not None:
+        dist.all_reduce(grad[nerf_hi:], op=dist.ReduceOp.SUM)
+        ar_work.wait()
+      else:
+        dist.all_reduce(grad, op=dist.ReduceOp.SUM)
     gscale = 1.0 / world
     # ---- clip + Adam --------------------------------------------------------------------------------
     nch, nleaf, nmod = layout.chunks.shape[0], len(layout.leaves), len(layout.modules)

@@ -1,0 +1,60 @@
+"""Data-parallel correctness on one GPU: two ranks (gloo backend, both on cuda:0) each take half of a batch;
+with deterministic sampling and the base MSE loss (per-device normalisers are equal-size means) one DP step must
+reproduce the single-process step on the whole batch up to float reassociation of the gradient sum."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+GIN = ["Config.patch_size = 8", "Config.data_loss_type = 'mse'", "Config.distortion_loss_mult = 0.01",
+       "Config.randomized = False", "Model.opaque_background = True", "Model.num_levels = 3", "PropMLP.net_depth = 4",
+       "PropMLP.net_width = 128", "PropMLP.disable_rgb = True", "NerfMLP.net_depth = 8", "NerfMLP.net_width = 128"]
+
+
+def _step(rank, world, port, out_dir):
+  import sys
+  sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+  from tests import hugs_testlib as H
+  from nerf_hugs_amd.internal import configs, train_utils, parallel
+  torch.cuda.set_device(0)
+  if world > 1:
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+  configs.clear_config()
+  configs.parse_config_files_and_bindings(None, GIN)
+  config = configs.make_config()
+  model, state, _, train_step, _ = train_utils.setup_model(config, 3, compute_dtype='fp32')
+  batch = H.synth_rays(4, 8, 5)
+  if world > 1:
+    batch = parallel.shard_batch(batch, rank, world)
+  state, stats, _ = train_step(None, state, batch, 0.4, None)
+  torch.cuda.synchronize()
+  if rank == 0:
+    torch.save({'flat': state.flat.cpu(), 'loss': float(stats['loss']), 'mses': stats['mses']}, os.path.join(out_dir, f'w{world}.pt'))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_process(tmp_path):
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  mp.spawn(_step, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+  mp.spawn(_step, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+  a = torch.load(tmp_path / 'w1.pt'); b = torch.load(tmp_path / 'w2.pt')
+  from tests import hugs_testlib as H
+  from nerf_hugs_amd.internal import configs, models
+  configs.clear_config(); configs.parse_config_files_and_bindings(None, GIN)
+  m = models.Model(configs.make_config())
+  init = m.init(3, 'cpu')
+  da, db = a['flat'] - init, b['flat'] - init
+  assert float(da.abs().max()) > 0
+  # clipped-Adam's first update is ~ lr * g/(|g|+eps): compare the updates leaf by leaf
+  for lf in m.layout.leaves:
+    ua, ub = m.layout.view(da, lf['path']), m.layout.view(db, lf['path'])
+    assert float((ua - ub).abs().max()) <= 2e-3 * float(ua.abs().max()) + 3e-8, lf['path']
+  assert abs(a['loss'] / b['loss'] - 1) < 1e-4      # pmean of per-shard losses == the full-batch loss here
