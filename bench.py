@@ -24,6 +24,12 @@ GIN = ["Config.patch_size = 16", "Config.data_loss_type = 'mse'", "Config.distor
        "Config.near = 0.1", "Config.far = 1.2", "Model.opaque_background = True", "Model.num_levels = 2",
        "Model.num_prop_samples = 64", "Model.num_nerf_samples = 128", "PropMLP.net_depth = 4",
        "PropMLP.net_width = 256", "PropMLP.disable_rgb = True", "NerfMLP.net_depth = 8", "NerfMLP.net_width = 1024"]
+# BASELINE.json configs[2] / configs[3] as synthetic restatements; --config selects them (not bench lines)
+GIN_CFG3 = GIN[:2] + ["Config.distortion_loss_mult = 0.001", "Config.transient_type = 'withmask'", "Config.data_loss_type = 'charb'",
+                      "Model.num_glo_features = 48"] + GIN[5:]
+GIN_CFG4 = GIN[:2] + ["Config.distortion_loss_mult = 0.001", "Config.transient_type = 'robustnerf'",
+                      "Config.robustnerf_inlier_quantile = 0.8", "Model.raydist_fn = @jnp.reciprocal", "Model.num_glo_features = 4",
+                      "NerfMLP.warp_fn = @coord.contract", "PropMLP.warp_fn = @coord.contract"] + GIN[5:]
 FLOP_TRAIN_PER_RAY = 6.5036e9   # SURVEY 8d / BASELINE.md work model, cfg2
 PEAK_BF16 = 2.5e15              # dense MFMA peak (MI355X_MICROARCH.md)
 
@@ -138,6 +144,9 @@ def main():
   ap.add_argument('--warmup', type=int, default=5)
   ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3', 'cfg4'],
+                  help='cfg2 = the headline workload; cfg3 (static masks, 4096 rays, GLO 48, charb) and cfg4 (RobustNeRF 0.8,\n'
+                       'contract + reciprocal, GLO 4, 1024 rays/GPU) are informational')
   args = ap.parse_args()
   import torch.distributed as dist
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -158,11 +167,18 @@ def main():
       dist.init_process_group(backend)
   from nerf_hugs_amd.internal import configs, train_utils
   configs.clear_config()
-  configs.parse_config_files_and_bindings(None, GIN)
-  config = configs.make_config(batch_size=1024 * world)
+  gin = {'cfg2': GIN, 'cfg3': GIN_CFG3, 'cfg4': GIN_CFG4}[args.config]
+  configs.parse_config_files_and_bindings(None, gin)
+  rays_per_gpu = 4096 if args.config == 'cfg3' else 1024
+  config = configs.make_config(batch_size=rays_per_gpu * world)
   model, state, _, train_step, _ = train_utils.setup_model(config, 20200823, compute_dtype=args.dtype, device=device)
-  rays_per_gpu = 1024
   batch = synth_batch(rays_per_gpu // 256, 16, 1000 + rank, device)
+  if args.config == 'cfg4':       # distractor-like geometry: near in [0.05, 0.3], far 1e6
+    batch.rays.near.uniform_(0.05, 0.3)
+    batch.rays.far.fill_(1e6)
+  if args.config != 'cfg2':
+    batch.rays.embed_idx.copy_(torch.randint(0, 3500, (rays_per_gpu // 256, 1, 1, 1), device=device).expand_as(batch.rays.embed_idx))
+    batch.rays.static_mask.copy_((torch.rand(rays_per_gpu // 256, 16, 16, 1, device=device) < 0.8).float())
   gen = torch.Generator(device=device).manual_seed(7 + rank)
   thr = np.ones((model.num_levels, 1), np.float32)
   for _ in range(args.warmup):
@@ -186,16 +202,19 @@ def main():
   loss = float(stats['loss'])
   psnr = float(stats['psnr'])
   eval_psnr = None
-  if rank == 0 and world == 1 and not args.no_cpu_baseline:
+  if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 'cfg2':
     eval_psnr = eval_psnr_vs_oracle(model, state, batch, args.dtype)
   if rank == 0:
     rps = rays_per_gpu * world * args.steps / dt
     line = {
-        "metric": "train rays/sec (1024-ray batch per GPU, 64+128 samples)", "value": round(rps, 1), "unit": "rays/s",
+        "metric": "train rays/sec (%d-ray batch per GPU, 64+128 samples)" % rays_per_gpu, "value": round(rps, 1), "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "configs[1]: MipNeRF360 base (kubric_1024_base.gin nets), 1024 rays x (64 prop + 128 fine) per GPU, "
-                               "full train step", "rays_per_gpu": rays_per_gpu, "global_batch": rays_per_gpu * world,
+        "config": {"workload": {"cfg2": "configs[1]: MipNeRF360 base (kubric_1024_base.gin nets), 1024 rays x (64 prop + 128 fine) per GPU, "
+                                        "full train step",
+                                "cfg3": "configs[2] restatement: + HuGS static masks, GLO 48, charb, 4096 rays x (64+128), full train step",
+                                "cfg4": "configs[3] restatement: RobustNeRF 0.8, contract + reciprocal, GLO 4, 1024 rays/GPU x (64+128)"}[args.config],
+                   "rays_per_gpu": rays_per_gpu, "global_batch": rays_per_gpu * world,
                    "parallelism": f"dp{world}", "params": model.layout.num_params()},
         "train_psnr_last": round(psnr, 3), "loss_last": round(loss, 6),
         "eval_psnr_vs_cpu_fp32_db": eval_psnr,
@@ -203,7 +222,7 @@ def main():
     }
     if args.dtype == 'bf16':
       line["roofline"] = gemm_roofline(device)
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.config == 'cfg2':
       line["cpu_baseline"] = cpu_baseline(20200823)
     print(json.dumps(line))
   if world > 1:
