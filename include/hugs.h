@@ -124,6 +124,27 @@ int hugs_opt_adam(int nchunks, int nleaf, const void* chunks, const void* leaf_i
 /* fp32 master [K,N] -> compute-dtype copies Wn [K,N] and Wt [N,K] (either may be NULL) */
 int hugs_cast_weights(int dtype, int K, int N, const float* W, void* Wn, void* Wt, void* stream);
 
+/* ---- batch assembly on the device (the reference does this in a host numpy thread) ----
+ * camera_utils.py:503-607 pixels_to_rays (+ :462-495 Newton undistort, :561-570 fisheye, :32-100 convert_to_ndc)
+ * and the pix_coords of :649-652 cast_ray_batch.  pixtocams [ncams,3,3], camtoworlds [ncams,3,4] fp32 (ncams == 1:
+ * shared, cam_idx may be NULL); dist NULL or {k1,k2,k3,k4,p1,p2}[1 or ncams] (dist_per_cam); pixtocam_ndc NULL or
+ * [3,3]; camtype 0 perspective / 1 fisheye (-2 otherwise); widths/heights int32 [ncams], needed only for
+ * pix_coords (may be NULL with it).  Outputs [n,3],[n,3],[n,3],[n,1],[n,2] fp32. */
+int hugs_pixels_to_rays(int n, const int32_t* pix_x, const int32_t* pix_y, const int32_t* cam_idx, int ncams,
+                        const float* pixtocams, const float* camtoworlds, const float* dist, int dist_per_cam,
+                        const float* pixtocam_ndc, int camtype, const int32_t* widths, const int32_t* heights,
+                        float* origins, float* directions, float* viewdirs, float* radii, float* pix_coords,
+                        void* stream);
+/* datasets.py:474-491 `arr[cam_idx][pix_y, pix_x]` for images / static masks / near / far kept resident in HBM as
+ * one flat buffer: dst[i,:] = src[(offsets[cam]+y*widths[cam]+x)*channels : +channels]; per_pixel == 0 reads
+ * src[cam,:] (one value per image).  src_u8: bytes, divided by 255 in binary32 as the loaders do. */
+int hugs_gather_pixels(int n, int channels, const int32_t* pix_x, const int32_t* pix_y, const int32_t* cam_idx,
+                       const int64_t* offsets, const int32_t* widths, int per_pixel, int src_u8, const void* src,
+                       float* dst, void* stream);
+/* datasets.py:498-524 patch origins -> pixel coordinates: origin + (dx,dy)*dilation, row-major inside a patch */
+int hugs_expand_patches(int npatch, int patch_size, int dilation, const int32_t* org_x, const int32_t* org_y,
+                        const int32_t* cam_of_patch, int32_t* pix_x, int32_t* pix_y, int32_t* cam_idx, void* stream);
+
 /* test/bench hook: force the 128x128-tile bf16 NT kernel where the 256x256 one would be selected */
 int hugs_test_force_small_tiles(int on);
 /* test hooks: the portable exp/log of the sampler and raw IEEE ops as the device executes them */

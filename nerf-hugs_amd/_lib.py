@@ -35,6 +35,9 @@ _PROTOS = {
     'hugs_opt_stats': 'iiippppfffppps',
     'hugs_opt_adam': 'iippppppppffffffffpps',
     'hugs_cast_weights': 'iiippps',
+    'hugs_pixels_to_rays': 'ipppipppipippppppps',
+    'hugs_gather_pixels': 'iipppppiipps',
+    'hugs_expand_patches': 'iiipppppps',
     'hugs_test_force_small_tiles': 'i',
 }
 _CT = {'i': ctypes.c_int, 'f': ctypes.c_float, 'p': ctypes.c_void_p, 'q': ctypes.c_longlong,

@@ -38,6 +38,19 @@ class Rays:
 
 
 @dataclasses.dataclass
+class Pixels:
+  """Integer pixel coordinates + per-ray metadata, the input of camera_utils.cast_ray_batch (utils.py:31-41)."""
+  pix_x_int: torch.Tensor
+  pix_y_int: torch.Tensor
+  lossmult: torch.Tensor
+  static_mask: torch.Tensor
+  near: torch.Tensor
+  far: torch.Tensor
+  embed_idx: torch.Tensor
+  cam_idx: torch.Tensor
+
+
+@dataclasses.dataclass
 class Batch:
   """Data batch for NeRF training or testing (utils.py:77-81)."""
   rays: Rays
