@@ -179,7 +179,9 @@ def main():
   if args.config != 'cfg2':
     batch.rays.embed_idx.copy_(torch.randint(0, 3500, (rays_per_gpu // 256, 1, 1, 1), device=device).expand_as(batch.rays.embed_idx))
     batch.rays.static_mask.copy_((torch.rand(rays_per_gpu // 256, 16, 16, 1, device=device) < 0.8).float())
-  gen = torch.Generator(device=device).manual_seed(7 + rank)
+  # the reference's stream: PRNGKey(20200823) split over the devices (train.py:46,80), threefry on the GPU
+  from nerf_hugs_amd.internal import random as hrandom
+  gen = hrandom.split(hrandom.PRNGKey(20200823, device), world)[rank].clone()
   thr = np.ones((model.num_levels, 1), np.float32)
   for _ in range(args.warmup):
     state, stats, gen = train_step(gen, state, batch, 0.5, thr)

@@ -145,6 +145,14 @@ int hugs_gather_pixels(int n, int channels, const int32_t* pix_x, const int32_t*
 int hugs_expand_patches(int npatch, int patch_size, int dilation, const int32_t* org_x, const int32_t* org_y,
                         const int32_t* cam_of_patch, int32_t* pix_x, int32_t* pix_y, int32_t* cam_idx, void* stream);
 
+/* ---- JAX-compatible PRNG: Threefry-2x32-20 with jax's counter layout (jax/_src/prng.py
+ * threefry_2x32 on iota(n): first half of the padded counters -> word 0, second half -> word 1).  key: 2 uint32 on
+ * the device.  hugs_prng_bits == jax.random.bits(key, (n,)); split(key, m) is hugs_prng_bits(key, 2m) viewed [m,2]
+ * (train_utils.py:408, models.py:38-43).  hugs_prng_uniform == jax.random.uniform(key, (n,), float32, minval,
+ * maxval) (stepfun.py:207-209).  n < 2^32. */
+int hugs_prng_bits(const uint32_t* key, long long n, uint32_t* out, void* stream);
+int hugs_prng_uniform(const uint32_t* key, long long n, float minval, float maxval, float* out, void* stream);
+
 /* test/bench hook: force the 128x128-tile bf16 NT kernel where the 256x256 one would be selected */
 int hugs_test_force_small_tiles(int on);
 /* test hooks: the portable exp/log of the sampler and raw IEEE ops as the device executes them */

@@ -38,6 +38,8 @@ _PROTOS = {
     'hugs_pixels_to_rays': 'ipppipppipippppppps',
     'hugs_gather_pixels': 'iipppppiipps',
     'hugs_expand_patches': 'iiipppppps',
+    'hugs_prng_bits': 'pqps',
+    'hugs_prng_uniform': 'pqffps',
     'hugs_test_force_small_tiles': 'i',
 }
 _CT = {'i': ctypes.c_int, 'f': ctypes.c_float, 'p': ctypes.c_void_p, 'q': ctypes.c_longlong,

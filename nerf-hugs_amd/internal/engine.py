@@ -258,7 +258,7 @@ class Engine:
 
   def forward(self, theta, rays, train_frac, u01, compute_extras, zero_glo=False):
     """Model.__call__ (models.py:74-330).  rays: dict of contiguous [N,c] cuda tensors (+ 'dir_enc').
-    u01: None or list[num_levels] of U[0,1) draws.  Returns per-level dicts (device tensors; buffers are
+    u01: None, a list[num_levels] of U[0,1) draws, or a stepfun.Jitter list of scaled draws.  Returns per-level dicts (device tensors; buffers are
     reused by the next call)."""
     mdl = self.model
     N = rays['origins'].shape[0]
@@ -294,9 +294,11 @@ class Engine:
         anneal = (mdl.anneal_slope * train_frac) / ((mdl.anneal_slope - 1) * train_frac + 1)
       else:
         anneal = 1.
+      draw = None if u01 is None else u01[lvl]
+      scaled = getattr(u01, 'scaled', False)     # stepfun.Jitter: draws already in [0, max_jitter)
       sd, td = stepfun.level_sample(sdist, weights, lvl > 0 and use_dilation, dilation, (init_s_near, init_s_far), anneal,
-                                    mdl.resample_padding, S, None if u01 is None else u01[lvl], mdl.raydist, rays['near'],
-                                    rays['far'])
+                                    mdl.resample_padding, S, None if scaled else draw, mdl.raydist, rays['near'],
+                                    rays['far'], jitter=draw if scaled else None)
       spec = mdl.prop_spec if is_prop else mdl.nerf_spec
       out = self._mlp_forward(spec, theta, lvl, N, S, td, rays, glo, True)
       w = ws.get(f'L{lvl}/weights', (N, S))

@@ -8,6 +8,8 @@ import torch
 
 from . import configs
 from . import engine as _engine
+from . import random as hrandom
+from . import stepfun
 from . import utils
 
 _MODEL_DEFAULTS = dict(
@@ -89,11 +91,25 @@ class Model:
       self.layout.view(flat, lf['path']).copy_((torch.from_numpy(np.array(d)) if not torch.is_tensor(d) else d).to(flat.device))
     return flat
 
+  def level_jitter(self, rng, N):
+    """The reference's consumption of `rng` inside Model.__call__: per level one split for the sampler key
+    (models.py:196) -- spent by random.uniform(key, [N, d], maxval=max_jitter) (stepfun.py:207-209) -- and one for
+    the MLP key (models.py:230; density / bottleneck noise are 0 in every shipped gin, the split still advances).
+    Returns (stepfun.Jitter, rng after the last level)."""
+    out = stepfun.Jitter()
+    for l in range(self.num_levels):
+      S = self.num_prop_samples if l < self.num_levels - 1 else self.num_nerf_samples
+      key, rng = hrandom.split(rng)
+      out.append(hrandom.uniform(key, (N, 1 if self.single_jitter else S), maxval=stepfun.sample_u(S, True)[1]))
+      _, rng = hrandom.split(rng)
+    return out, rng
+
   # -- forward -----------------------------------------------------------------------------------------
   def apply(self, variables, rng, rays, train_frac, compute_extras, zero_glo=False, zero_tra=False,
             refresh_weights=True):
     """Model.__call__ (models.py:74-330).  `variables`: flat buffer or the tree from variables().
-    `rng`: None (deterministic) or a torch.Generator on the GPU.  rays: utils.Rays with any leading
+    `rng`: None (deterministic), a jax-style key (internal/random.py: the reference's exact split / uniform stream)
+    or a torch.Generator on the GPU (philox draws).  rays: utils.Rays with any leading
     shape.  Returns (renderings, ray_history) as lists of dicts, one per level."""
     flat = variables if torch.is_tensor(variables) else variables.flat
     eng = self.engine(flat.device)
@@ -101,7 +117,9 @@ class Model:
     r = rays_to_dict(rays, flat.device)
     N = r['origins'].shape[0]
     u01 = None
-    if rng is not None:
+    if hrandom.is_key(rng):
+      u01, _ = self.level_jitter(rng, N)
+    elif rng is not None:
       shape = (N,) if self.single_jitter else None
       u01 = [torch.rand(shape if shape else (N, (self.num_prop_samples if l < self.num_levels - 1 else self.num_nerf_samples)),
                         generator=rng, device=flat.device) for l in range(self.num_levels)]
@@ -203,9 +221,9 @@ def render_image(render_fn, rays, rng, config, verbose=True):
   keys = [k for k in rendering if k.startswith('ray_')]
   if keys:
     n = rendering[keys[0]][0].shape[0]
-    # reference: random.permutation(PRNGKey(0), n)[:vis_num_rays]; JAX's threefry stream is not reproduced
-    #  -- a fixed torch permutation with seed 0 keeps the call deterministic.
-    ray_idx = torch.randperm(n, generator=torch.Generator().manual_seed(0))[:config.vis_num_rays]
+    # models.py:644: random.permutation(random.PRNGKey(0), num_rays)[:vis_num_rays], jax's own shuffle
+    dev = rendering[keys[0]][0].device
+    ray_idx = hrandom.permutation(hrandom.PRNGKey(0, dev), n)[:config.vis_num_rays]
     for k in keys:
       rendering[k] = [r[ray_idx.to(r.device)] for r in rendering[k]]
   return rendering

@@ -1,0 +1,65 @@
+"""`jax.random` as the reference uses it, on the device (csrc/hugs_prng.hip).
+
+Keys are int32 CUDA tensors of shape [2] holding jax's two uint32 key words; they never leave the GPU, so splitting
+and drawing cost one small launch each and no synchronisation.  Streams are bit-identical to jax's default
+(non-partitionable) threefry generator -- see oracle/threefry_ref.py for what pins that.
+
+  PRNGKey(seed)            train.py:46            key = (seed >> 32, seed & 0xffffffff)
+  split(key, num=2)        train_utils.py:408     [num, 2] keys
+  uniform(key, shape, ...) stepfun.py:207-209     float32 in [minval, maxval)
+  bits(key, shape)                                raw uint32 draws (as int32 bit patterns)
+  permutation(key, n)      models.py:644          jax's sort-by-random-keys shuffle (ceil(3 ln n / ln 2^32) rounds)
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+
+
+def is_key(x):
+  return torch.is_tensor(x) and x.dtype == torch.int32 and tuple(x.shape) == (2,)
+
+
+def PRNGKey(seed, device='cuda'):
+  seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+  words = np.array([(seed >> 32) & 0xFFFFFFFF, seed & 0xFFFFFFFF], np.uint32).view(np.int32)
+  return torch.from_numpy(words.copy()).to(device)
+
+
+def _check(key):
+  if not is_key(key):
+    raise TypeError('PRNG keys are int32 tensors of shape [2] (random.PRNGKey)')
+  if not key.is_cuda:
+    raise L.HugsError('PRNG key is not on the GPU (no CPU fallback)')
+
+
+def bits(key, shape):
+  _check(key)
+  shape = tuple(shape)
+  out = torch.empty(shape, dtype=torch.int32, device=key.device)
+  L.call('hugs_prng_bits', key, out.numel(), out)
+  return out
+
+
+def split(key, num=2):
+  return bits(key, (num, 2))
+
+
+def uniform(key, shape=(), minval=0., maxval=1.):
+  _check(key)
+  out = torch.empty(tuple(shape), dtype=torch.float32, device=key.device)
+  L.call('hugs_prng_uniform', key, out.numel(), minval, maxval, out)
+  return out
+
+
+def permutation(key, n):
+  """jax.random.permutation(key, n) (jax/_src/random.py _shuffle): repeated stable sort by fresh 32-bit keys."""
+  x = torch.arange(n, device=key.device)
+  rounds = int(math.ceil(3 * math.log(max(1, n)) / math.log(2 ** 32 - 1)))
+  for _ in range(rounds):
+    key, sub = split(key)
+    k = bits(sub, (n,)).long() & 0xFFFFFFFF      # unsigned order
+    x = x[torch.sort(k, stable=True).indices]
+  return x

@@ -11,6 +11,11 @@ from .. import _lib
 EPS = float(np.finfo(np.float32).eps)
 
 
+class Jitter(list):
+  """Per-level jitter draws that are already scaled to [0, max_jitter) (the jax.random path)."""
+  scaled = True
+
+
 def sample_u(num_samples, randomized, deterministic_center=True):
   """Fixed part of the inverse-CDF abscissae (stepfun.py:191-209) and the jitter scale.
   float64 host linspace rounded to float32 (jnp.linspace's own rounding is unpinned)."""
@@ -21,26 +26,31 @@ def sample_u(num_samples, randomized, deterministic_center=True):
     else:
       u = np.linspace(0, 1. - EPS, num_samples)
     return u.astype(np.float32), 0.0
-  u_max = EPS + (1 - EPS) / num_samples
-  max_jitter = (1 - u_max) / (num_samples - 1) - EPS
-  return np.linspace(0, 1 - u_max, num_samples).astype(np.float32), max_jitter
+  # binary32 scalar arithmetic, as `jnp.finfo(jnp.float32).eps` makes it in the reference (stepfun.py:203-205)
+  eps, one = np.float32(EPS), np.float32(1)
+  u_max = eps + (one - eps) / np.float32(num_samples)
+  max_jitter = (one - u_max) / np.float32(num_samples - 1) - eps
+  return np.linspace(0, float(1 - u_max), num_samples).astype(np.float32), float(max_jitter)
 
 
 def level_sample(t_prev, w_prev, do_dilate, dilation, domain, anneal, resample_padding, num_samples, u01,
-                 raydist, near, far, return_debug=False):
+                 raydist, near, far, return_debug=False, jitter=None):
   """One hierarchical-sampling level (models.py:155-212): [dilate] -> logits -> sample_intervals -> s_to_t.
 
-  t_prev [N, n+1], w_prev [N, n] float32 cuda; u01: None (rng=None) or [N] / [N, num_samples] U[0,1) draws.
+  t_prev [N, n+1], w_prev [N, n] float32 cuda; u01: None (rng=None) or [N] / [N, num_samples] U[0,1) draws;
+  jitter: instead of u01, draws already scaled to [0, max_jitter) (random.uniform(key, ..., maxval=max_jitter)).
   Returns sdist, tdist ([N, num_samples+1]) (+ idx, t_in, w_in when return_debug)."""
   if num_samples <= 1:
     raise ValueError(f'num_samples must be > 1, is {num_samples}.')
   N, n_prev = w_prev.shape
   dev = t_prev.device
-  ub, mj = sample_u(num_samples, u01 is not None)
+  ub, mj = sample_u(num_samples, u01 is not None or jitter is not None)
   ub = torch.from_numpy(ub).to(dev)
-  jitter, stride = None, 1
-  if u01 is not None:
-    jitter = (u01.to(torch.float32) * np.float32(mj)).contiguous()
+  stride = 1
+  if jitter is None and u01 is not None:
+    jitter = u01.to(torch.float32) * np.float32(mj)
+  if jitter is not None:
+    jitter = jitter.to(torch.float32).contiguous()
     stride = 1 if jitter.dim() == 1 or jitter.shape[-1] == 1 else num_samples
   sdist = torch.empty(N, num_samples + 1, device=dev)
   tdist = torch.empty_like(sdist)

@@ -15,6 +15,7 @@ from .. import _lib
 from . import image
 from . import math as hmath
 from . import models
+from . import random as hrandom
 from . import utils
 
 STAT_TAIL = 64  # floats appended to the gradient buffer for the per-step scalars that get pmean'ed
@@ -143,7 +144,11 @@ def create_train_step(model, config, is_finetune=False):
       eng.refresh_weights(state.flat)
       cache['stale'] = False
     u01 = None
-    if config.randomized and rng is not None:
+    if hrandom.is_key(rng):                        # jax stream: rng, key = random.split(rng) (train_utils.py:408)
+      rng, key = hrandom.split(rng)
+      if config.randomized:
+        u01, _ = model.level_jitter(key, N)
+    elif config.randomized and rng is not None:
       u01 = []
       for l in range(L):
         S = model.num_prop_samples if l < L - 1 else model.num_nerf_samples

@@ -446,9 +446,11 @@ def sample_u_base(num_samples, randomized):
   if not randomized:
     pad = 1 / (2 * num_samples)
     return np.linspace(pad, 1. - pad - eps, num_samples).astype(np.float32), 0.0
-  u_max = eps + (1 - eps) / num_samples
-  max_jitter = (1 - u_max) / (num_samples - 1) - eps
-  return np.linspace(0, 1 - u_max, num_samples).astype(np.float32), max_jitter
+  # `eps = jnp.finfo(jnp.float32).eps` is a binary32 scalar: u_max / max_jitter are binary32 arithmetic
+  eps, one = np.float32(eps), np.float32(1)
+  u_max = eps + (one - eps) / np.float32(num_samples)
+  max_jitter = (one - u_max) / np.float32(num_samples - 1) - eps
+  return np.linspace(0, float(1 - u_max), num_samples).astype(np.float32), float(max_jitter)
 
 
 def model_forward(cfg, variables, rays, train_frac, u01, compute_extras, zero_glo=False, taps=None,

@@ -59,6 +59,17 @@ def _worker(rank, world, port, tmp):
   configs.clear_config()
   cfg = configs.make_config(render_chunk_size=16, vis_num_rays=2)
   rays = _fake_rays(7, 5)
+  # the ray_* subsample draws jax's permutation on the GPU; this CPU test of the host logic substitutes the oracle's
+  from oracle import threefry_ref as T
+
+  def cpu_permutation(key, n):
+    k, x = T.prng_key(0), np.arange(n)
+    for _ in range(int(np.ceil(3 * np.log(max(1, n)) / np.log(2 ** 32 - 1)))):
+      k, sub = T.split(k)
+      x = x[np.argsort(T.random_bits(sub, (n,)), kind='stable')]
+    return torch.from_numpy(x)
+  models.hrandom.permutation = cpu_permutation
+  models.hrandom.PRNGKey = lambda seed, device=None: None
   out = models.render_image(_fake_render_fn, rays, None, cfg, verbose=False)
   assert out['rgb'].shape == (7, 5, 3)
   assert torch.allclose(out['rgb'], rays.origins * 2 + 1)
