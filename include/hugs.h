@@ -153,6 +153,15 @@ int hugs_expand_patches(int npatch, int patch_size, int dilation, const int32_t*
 int hugs_prng_bits(const uint32_t* key, long long n, uint32_t* out, void* stream);
 int hugs_prng_uniform(const uint32_t* key, long long n, float minval, float maxval, float* out, void* stream);
 
+/* ---- eval metrics: image.py:127-141 MetricHarness.  hugs_ssim == dm_pix.ssim(a, b) for one
+ * [H,W,C] fp32 image pair with dm_pix's defaults passed explicitly (max_val 1, 11 taps fixed, filter_sigma 1.5,
+ * k1 .01, k2 .03): mean of the 'valid' SSIM map.  ws: hugs_ssim_ws_bytes(H,W,C) bytes.  H, W >= 11 (-2 otherwise).
+ * hugs_mse: mean squared error over n floats (image.py:135), ws 1024 floats. */
+long long hugs_ssim_ws_bytes(int H, int W, int C);
+int hugs_ssim(int H, int W, int C, const float* a, const float* b, float max_val, float filter_sigma, float k1, float k2,
+              float* ws, float* out, void* stream);
+int hugs_mse(long long n, const float* a, const float* b, float* ws, float* out, void* stream);
+
 /* test/bench hook: force the 128x128-tile bf16 NT kernel where the 256x256 one would be selected */
 int hugs_test_force_small_tiles(int on);
 /* test hooks: the portable exp/log of the sampler and raw IEEE ops as the device executes them */

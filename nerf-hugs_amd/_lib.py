@@ -40,6 +40,8 @@ _PROTOS = {
     'hugs_expand_patches': 'iiipppppps',
     'hugs_prng_bits': 'pqps',
     'hugs_prng_uniform': 'pqffps',
+    'hugs_ssim': 'iiippffffpps',
+    'hugs_mse': 'qpppps',
     'hugs_test_force_small_tiles': 'i',
 }
 _CT = {'i': ctypes.c_int, 'f': ctypes.c_float, 'p': ctypes.c_void_p, 'q': ctypes.c_longlong,
@@ -59,7 +61,7 @@ class _Lib:
           'There is no CPU fallback.')
     self.cdll = ctypes.CDLL(LIB_PATH)
     self.cdll.hugs_last_error.restype = ctypes.c_char_p
-    for n_ in ('hugs_gemm_tn_ws_bytes', 'hugs_density_bwd_ws_bytes', 'hugs_rgb_bwd_ws_bytes'):
+    for n_ in ('hugs_gemm_tn_ws_bytes', 'hugs_density_bwd_ws_bytes', 'hugs_rgb_bwd_ws_bytes', 'hugs_ssim_ws_bytes'):
       getattr(self.cdll, n_).restype = ctypes.c_longlong
     for name, sig in _PROTOS.items():
       fn = getattr(self.cdll, name)

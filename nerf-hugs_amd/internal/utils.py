@@ -92,3 +92,22 @@ def unshard(x, padding=0):
   if padding > 0:
     y = y[:-padding]
   return y
+
+
+def save_img_u8(img, pth):
+  """Save an image (probably RGB) in [0, 1] to disk as a uint8 PNG (utils.py:157-162)."""
+  import numpy as np
+  from PIL import Image
+  img = img.detach().cpu().numpy() if torch.is_tensor(img) else np.asarray(img)
+  arr = (np.clip(np.nan_to_num(img), 0., 1.) * 255.).astype(np.uint8)
+  with open(pth, 'wb') as f:
+    Image.fromarray(arr).save(f, 'PNG')
+
+
+def save_img_f32(depthmap, pth):
+  """Save an image (probably a depthmap) to disk as a float32 TIFF (utils.py:165-168)."""
+  import numpy as np
+  from PIL import Image
+  img = depthmap.detach().cpu().numpy() if torch.is_tensor(depthmap) else np.asarray(depthmap)
+  with open(pth, 'wb') as f:
+    Image.fromarray(np.nan_to_num(img).astype(np.float32)).save(f, 'TIFF')
