@@ -162,6 +162,24 @@ int hugs_ssim(int H, int W, int C, const float* a, const float* b, float max_val
               float* ws, float* out, void* stream);
 int hugs_mse(long long n, const float* a, const float* b, float* ws, float* out, void* stream);
 
+/* ---- HA-NeRF branch.  models.py:651-674 ImplicitMask: X = [pos_enc(pix_coords,0,deg,identity) |
+ * tra_vec | 0-pad] [N,kpad] in the compute dtype (tra_vec NULL = zero_tra); its Dense+relu layers run on
+ * hugs_gemm_nt / hugs_gemm_tn; head mask = sigmoid(X w + b) and its backward (d_raw [Npad] with zero tail rows,
+ * dW [W], db [1]; G = hugs_rank1_mask(d_raw, w, X)).  hugs_embed_scatter_add: TransientEmbed gradient,
+ * d_embedding[embed_idx[n], :] += dX[n, col0:col0+T] (caller zeroes d_embedding once per step).
+ * hugs_hanerf_loss: train_utils.py:186-225; out_stats [2L+2] = {mean resid^2, mean((1-m) loss)} per level,
+ * mean(m^2), mean(m); d_pred [L,N,3], d_mask [N] include the level multipliers coef[L] and mask_size_mult. */
+int hugs_mask_input_fwd(int N, int T, int deg, const float* pix_coords, const float* tra_vec, int kpad, int dtype, void* X,
+                        void* stream);
+int hugs_mask_head_fwd(int dtype, int N, int W, const void* X, int ldx, const float* w, const float* b, float* mask,
+                       void* stream);
+int hugs_mask_head_bwd(int dtype, int N, int Npad, int W, const void* X, int ldx, const float* mask, const float* d_mask,
+                       float* d_raw, float* dW, float* db, void* stream);
+int hugs_embed_scatter_add(int dtype, int N, int T, const void* dX, int ldx, int col0, const int* embed_idx,
+                           float* d_embedding, void* stream);
+int hugs_hanerf_loss(int N, int L, const float* pred, const float* gt, const float* mask, int charb, float charb_pad,
+                     const float* coef, float mask_size_mult, float* d_pred, float* d_mask, float* out_stats, void* stream);
+
 /* test/bench hook: force the 128x128-tile bf16 NT kernel where the 256x256 one would be selected */
 int hugs_test_force_small_tiles(int on);
 /* test hooks: the portable exp/log of the sampler and raw IEEE ops as the device executes them */

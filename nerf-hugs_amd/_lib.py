@@ -42,6 +42,11 @@ _PROTOS = {
     'hugs_prng_uniform': 'pqffps',
     'hugs_ssim': 'iiippffffpps',
     'hugs_mse': 'qpppps',
+    'hugs_mask_input_fwd': 'iiippiips',
+    'hugs_mask_head_fwd': 'iiipippps',
+    'hugs_mask_head_bwd': 'iiiipippppps',
+    'hugs_embed_scatter_add': 'iiipiipps',
+    'hugs_hanerf_loss': 'iipppifpfppps',
     'hugs_test_force_small_tiles': 'i',
 }
 _CT = {'i': ctypes.c_int, 'f': ctypes.c_float, 'p': ctypes.c_void_p, 'q': ctypes.c_longlong,

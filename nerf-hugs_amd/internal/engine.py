@@ -89,11 +89,40 @@ class MLPSpec:
       raise NotImplementedError(f'warp_fn {self.warp_fn!r}: only @coord.contract is built')
 
 
+class MaskSpec:
+  """HA-NeRF's per-ray ImplicitMask MLP (models.py:651-674): [pos_enc(pix_coords) | tra_vec] -> (Dense+relu) x depth
+  -> sigmoid(Dense(1)).  The input is zero-padded to a multiple of 128 columns so the input-gradient GEMM (for the
+  TransientEmbed rows) has a whole number of output tiles."""
+
+  def __init__(self, num_transient, **kw):
+    self.name = 'ImplicitMask_0'
+    self.net_depth = 4
+    self.net_width = 256
+    self.deg_coord = 10
+    self.weight_init = 'he_uniform'
+    for k, v in kw.items():
+      if not hasattr(self, k):
+        raise ValueError(f'ImplicitMask has no attribute {k!r}')
+      setattr(self, k, v)
+    if self.net_width % 128 or self.net_depth < 1:
+      raise NotImplementedError('ImplicitMask.net_width must be a multiple of 128')
+    self.T = num_transient
+    self.E = 2 + 4 * self.deg_coord
+    self.fan_in = self.E + num_transient
+    self.kpad = _round_up(self.fan_in, 128)
+    L, k, kp = [], self.fan_in, self.kpad
+    for i in range(self.net_depth):
+      L.append(dict(fan_in=k, kpad=kp, fan_out=self.net_width, kind='trunk', concat=False, name=f'Dense_{i}'))
+      k = kp = self.net_width
+    L.append(dict(fan_in=k, kpad=k, fan_out=1, kind='maskhead', name=f'Dense_{self.net_depth}'))
+    self.layers = L
+
+
 class ParamLayout:
   """Flat fp32 parameter buffer: leaves in (module, layer, kernel|bias) order, kernels stored
   [fan_in_padded, fan_out] row-major (flax [in,out] + zero rows), chunk table for the optimizer."""
 
-  def __init__(self, specs, num_embeddings, num_glo):
+  def __init__(self, specs, num_embeddings, num_glo, num_transient=0):
     self.leaves = []   # dict(path, off, shape (logical), pshape (padded), module, leaf)
     off = 0
     self.modules = []
@@ -114,6 +143,14 @@ class ParamLayout:
       n = num_embeddings * num_glo
       self.leaves.append(dict(path=('GloEmbed_0', 'embedding'), off=off, shape=(num_embeddings, num_glo),
                               pshape=(num_embeddings, num_glo), module=mid, leaf=len(self.leaves), layer=None, spec=None))
+      off += _round_up(n, 4)
+    if num_transient > 0:
+      mid = len(self.modules)
+      self.modules.append('TransientEmbed_0')
+      n = num_embeddings * num_transient
+      self.leaves.append(dict(path=('TransientEmbed_0', 'embedding'), off=off, shape=(num_embeddings, num_transient),
+                              pshape=(num_embeddings, num_transient), module=mid, leaf=len(self.leaves), layer=None,
+                              spec=None))
       off += _round_up(n, 4)
     self.size = off
     chunks = []
@@ -418,6 +455,63 @@ class Engine:
         G, gi = ring[nxt], nxt
     for e in tn_done.values():
       main.wait_event(e)
+
+  # ---- HA-NeRF ImplicitMask (per ray) --------------------------------------------------------------
+  def mask_forward(self, theta, rays, N, zero_tra=False):
+    """renderings[-1]['implicit_mask'] (models.py:327-328).  Returns the state mask_backward needs."""
+    spec, lay, ws, dt = self.model.mask_spec, self.layout, self.ws, self.dt
+    Np = _round_up(N, 128)
+    tra = None
+    if not zero_tra:
+      tra = ws.get('tra_vec', (N, spec.T))
+      _lib.call('hugs_glo_gather', N, spec.T, lay.view(theta, ('TransientEmbed_0', 'embedding')), rays['embed_idx'], 0, tra)
+    X0 = ws.get('mask/X0', (Np, spec.kpad), self.tdt)
+    if Np != N:
+      X0[N:].zero_()
+    _lib.call('hugs_mask_input_fwd', N, spec.T, spec.deg_coord, rays['pix_coords'], tra, spec.kpad, dt, X0)
+    acts, x, W = [X0], X0, spec.net_width
+    for i in range(spec.net_depth):
+      l = spec.layers[i]
+      Y = ws.get(f'mask/Y{i}', (Np, W), self.tdt)
+      _lib.call('hugs_gemm_nt', dt, Np, W, l['kpad'], 0, x, l['kpad'], None, 0, self.wt[(spec.name, l['name'], 'kernel')],
+                l['kpad'], lay.view(theta, (spec.name, l['name'], 'bias')), None, 1, 0, 1, None, 0, None, None, Y, W)
+      acts.append(Y)
+      x = Y
+    lh = spec.layers[spec.net_depth]
+    mask = ws.get('mask/out', (N,))
+    _lib.call('hugs_mask_head_fwd', dt, N, W, x, W, lay.view(theta, (spec.name, lh['name'], 'kernel')).reshape(-1),
+              lay.view(theta, (spec.name, lh['name'], 'bias')), mask)
+    return dict(acts=acts, mask=mask, N=N, Np=Np, zero_tra=zero_tra)
+
+  def mask_backward(self, theta, grad, st, rays, d_mask):
+    """Gradients of ImplicitMask_0 (=) and TransientEmbed_0 (+=, caller zeroes) from d loss / d mask [N]."""
+    spec, lay, ws, dt = self.model.mask_spec, self.layout, self.ws, self.dt
+    N, Np, W, acts = st['N'], st['Np'], spec.net_width, st['acts']
+    gview = lambda p, padded=False: lay.view(grad, p, padded)
+    lh = spec.layers[spec.net_depth]
+    d_raw = ws.get('mask/d_raw', (Np,))
+    _lib.call('hugs_mask_head_bwd', dt, N, Np, W, acts[-1], W, st['mask'], d_mask, d_raw,
+              gview((spec.name, lh['name'], 'kernel')).reshape(-1), gview((spec.name, lh['name'], 'bias')))
+    Ga = ws.get('mask/Ga', (Np, W), self.tdt)
+    Gb = ws.get('mask/Gb', (Np, W), self.tdt)
+    _lib.call('hugs_rank1_mask', dt, Np, W, d_raw, lay.view(theta, (spec.name, lh['name'], 'kernel')).reshape(-1), acts[-1], W,
+              Ga, W)
+    G, other = Ga, Gb
+    for i in range(spec.net_depth - 1, -1, -1):
+      l = spec.layers[i]
+      path = (spec.name, l['name'], 'kernel')
+      self._tn(Np, l['kpad'], W, acts[i], l['kpad'], G, W, gview(path, padded=True), gview((spec.name, l['name'], 'bias')))
+      if i > 0:
+        _lib.call('hugs_gemm_nt', dt, Np, W, W, 0, G, W, None, 0, self.wn[path], W, None, None, 1, 0, 0, acts[i], W, None, None,
+                  other, W)
+        G, other = other, G
+      elif not st['zero_tra']:
+        # dX0 = G_0 W_0^T; its tra_vec columns go to the embedding rows of the rays' cameras
+        dX0 = ws.get('mask/dX0', (Np, spec.kpad), self.tdt)
+        _lib.call('hugs_gemm_nt', dt, Np, spec.kpad, W, 0, G, W, None, 0, self.wn[path], W, None, None, 1, 0, 0, None, 0, None,
+                  None, dX0, spec.kpad)
+        _lib.call('hugs_embed_scatter_add', dt, N, spec.T, dX0, spec.kpad, spec.E, rays['embed_idx'],
+                  gview(('TransientEmbed_0', 'embedding')))
 
   def _side_stream(self):
     if getattr(self, '_side', None) is None:

@@ -37,7 +37,9 @@ class Model:
     if tt in [None, 'withmask', 'robustnerf']:
       assert self.num_transient_features == 0
     elif tt in ['nerfw', 'hanerf']:
-      raise NotImplementedError(f"transient_type {tt!r}: NeRF-W / HA-NeRF branches are not built (SURVEY 8a.28)")
+      assert self.num_transient_features > 0
+      if tt == 'nerfw':
+        raise NotImplementedError("transient_type 'nerfw': the NeRF-W branch is not built (SURVEY 8a.28)")
     else:
       raise ValueError()
     if self.ray_shape not in ('cone', 'cylinder'):
@@ -54,7 +56,11 @@ class Model:
     self.nerf_spec = _engine.MLPSpec('NerfMLP_0', False, self.num_glo_features, **configs.bindings('NerfMLP'))
     self.prop_spec = _engine.MLPSpec('PropMLP_0', True, self.num_glo_features, **configs.bindings('PropMLP'))
     self.specs = [self.nerf_spec, self.prop_spec]
-    self.layout = _engine.ParamLayout(self.specs, self.num_embeddings, self.num_glo_features)
+    self.mask_spec = None
+    if tt == 'hanerf':      # models.py:107: ImplicitMask() is constructed after the two MLPs
+      self.mask_spec = _engine.MaskSpec(self.num_transient_features, **configs.bindings('ImplicitMask'))
+    self.layout = _engine.ParamLayout(self.specs + ([self.mask_spec] if self.mask_spec else []), self.num_embeddings,
+                                      self.num_glo_features, self.num_transient_features)
     self.compute_dtype = compute_dtype or 'bf16'
     self._engine = None
 
@@ -126,6 +132,9 @@ class Model:
     if refresh_weights:
       eng.refresh_weights(flat)
     levels = eng.forward(flat, r, float(train_frac), u01, compute_extras, zero_glo)
+    implicit_mask = None
+    if self.mask_spec is not None:
+      implicit_mask = eng.mask_forward(flat, r, N, zero_tra)['mask'].clone().reshape(lead + (1,))
     renderings, history = [], []
     n = 0 if self.config is None else self.config.vis_num_rays
     for lv in levels:
@@ -145,6 +154,8 @@ class Model:
       renderings.append(rend)
       history.append(dict(density=lv['density'].clone().reshape(lead + (S,)), rgb=rgb_s.clone().reshape(lead + (S, 3)),
                           sdist=lv['sdist'].clone().reshape(lead + (S + 1,)), weights=lv['weights'].clone().reshape(lead + (S,))))
+    if implicit_mask is not None:
+      renderings[-1]['implicit_mask'] = implicit_mask        # models.py:327-328
     if compute_extras:
       # proposal levels show the final average colour (models.py:314-325)
       final_rgb = (renderings[-1]['ray_rgbs'] * renderings[-1]['ray_weights'][..., None]).sum(-2)
@@ -165,7 +176,7 @@ class Variables(dict):
 
 def rays_to_dict(rays, device):
   f = lambda x, dt=torch.float32: x.reshape(-1, x.shape[-1]).to(device=device, dtype=dt).contiguous()
-  return dict(origins=f(rays.origins), directions=f(rays.directions), viewdirs=f(rays.viewdirs),
+  return dict(pix_coords=f(rays.pix_coords), origins=f(rays.origins), directions=f(rays.directions), viewdirs=f(rays.viewdirs),
               radii=f(rays.radii).reshape(-1), lossmult=f(rays.lossmult).reshape(-1),
               static_mask=f(rays.static_mask).reshape(-1), near=f(rays.near).reshape(-1), far=f(rays.far).reshape(-1),
               embed_idx=f(rays.embed_idx, torch.int32).reshape(-1))

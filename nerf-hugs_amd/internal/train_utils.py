@@ -121,7 +121,7 @@ def create_train_step(model, config, is_finetune=False):
   layout = model.layout
   L = model.num_levels
   tt = None if is_finetune else config.transient_type
-  if tt not in (None, 'withmask', 'robustnerf'):
+  if tt not in (None, 'withmask', 'robustnerf', 'hanerf'):
     raise ValueError()
   if tt == 'robustnerf':
     assert config.robustnerf_inner_patch_size <= config.patch_size, \
@@ -154,6 +154,7 @@ def create_train_step(model, config, is_finetune=False):
         S = model.num_prop_samples if l < L - 1 else model.num_nerf_samples
         u01.append(torch.rand((N,) if model.single_jitter else (N, S), generator=rng, device=dev))
     levels = eng.forward(state.flat, rays, float(train_frac), u01, False, False)
+    mask_st = eng.mask_forward(state.flat, rays, N) if tt == 'hanerf' else None
 
     grad = ws.get('grad', (layout.size + STAT_TAIL,))
     tail = grad[layout.size:]
@@ -182,8 +183,21 @@ def create_train_step(model, config, is_finetune=False):
                   config.robustnerf_inner_patch_size, config.robustnerf_inner_patch_inlier_quantile, mask[l], err, part,
                   tail[16 + 5 * l:16 + 5 * l + 5])
       mode, lm = 2, mask
-    _lib.call('hugs_data_loss', N, L, pred, gt, lm, mode, config.withmask_transient_weight,
-              int(config.data_loss_type == 'charb'), config.charb_padding, cache['coef'], d_pred, tail[0:2 * L])
+    d_mask = None
+    if tt == 'hanerf':
+      # train_utils.py:190-193: the mask-size weight decays from _max to _min with the step
+      msm = max(config.hanerf_mask_size_loss_mult_min, config.hanerf_mask_size_loss_mult_max *
+                math.exp(-float(train_frac) * config.max_steps * config.hanerf_mask_size_loss_mult_k))
+      cache['mask_size_mult'] = msm
+      d_mask = ws.get('d_mask', (N,))
+      hst = ws.get('hanerf_stats', (2 * L + 2,))
+      _lib.call('hugs_hanerf_loss', N, L, pred, gt, mask_st['mask'], int(config.data_loss_type == 'charb'),
+                config.charb_padding, cache['coef'], msm, d_pred, d_mask, hst)
+      tail[0:2 * L].copy_(hst[:2 * L])
+      tail[40:42].copy_(hst[2 * L:])
+    else:
+      _lib.call('hugs_data_loss', N, L, pred, gt, lm, mode, config.withmask_transient_weight,
+                int(config.data_loss_type == 'charb'), config.charb_padding, cache['coef'], d_pred, tail[0:2 * L])
     fin = levels[-1]
     Sf = fin['S']
     d_w = [None] * L
@@ -201,6 +215,14 @@ def create_train_step(model, config, is_finetune=False):
     # ---- backward -----------------------------------------------------------------------------------
     if model.num_glo_features > 0:
       layout.view(grad, ('GloEmbed_0', 'embedding')).zero_()
+    if model.num_transient_features > 0:
+      layout.view(grad, ('TransientEmbed_0', 'embedding')).zero_()
+    if mask_st is not None:
+      eng.mask_backward(state.flat, grad, mask_st, rays, d_mask)
+    elif model.mask_spec is not None:            # finetune stage of a hanerf model: the mask is not in the loss
+      lo = layout.by_path[('ImplicitMask_0', 'Dense_0', 'kernel')]['off']
+      last = [lf for lf in layout.leaves if lf['path'][0] == 'ImplicitMask_0'][-1]
+      grad[lo:last['off'] + int(np.prod(last['pshape']))].zero_()
     prop_done = False
     prop_lo = layout.by_path[('PropMLP_0', 'Dense_0', 'kernel')]['off']
     last_prop = [lf for lf in layout.leaves if lf['path'][0] == 'PropMLP_0'][-1]
@@ -260,6 +282,8 @@ def create_train_step(model, config, is_finetune=False):
       packed[:STAT_TAIL].mul_(gscale)
     packed[STAT_TAIL:].copy_(leaf_stats)
 
+    msm_now = cache.get('mask_size_mult', 0.0)
+
     def build(hst):
       tl = hst[:STAT_TAIL]
       ls = hst[STAT_TAIL:STAT_TAIL + nleaf * 4].reshape(nleaf, 4)
@@ -273,6 +297,9 @@ def create_train_step(model, config, is_finetune=False):
         losses['interlevel'] = float(config.interlevel_loss_mult * tl[8:8 + L - 1].sum())
       if not is_finetune and config.distortion_loss_mult > 0:
         losses['distortion'] = float(config.distortion_loss_mult * tl[12])
+      if tt == 'hanerf':
+        losses['mask_size'] = float(msm_now * tl[40])
+        stats['implicit_mask'] = T([tl[41]])
       stats['losses'] = {k: T(v) for k, v in losses.items()}
       stats['loss'] = T(sum(losses.values()))
       stats['mses'] = T(mses)

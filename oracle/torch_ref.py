@@ -317,6 +317,8 @@ class ModelCfg:
     self.dilation_multiplier = 0.5
     self.dilation_bias = 0.0025
     self.num_glo_features = 0
+    self.num_transient_features = 0   # HA-NeRF: TransientEmbed width (models.py:64)
+    self.mask_depth, self.mask_width, self.mask_deg_coord = 4, 256, 10   # ImplicitMask (models.py:651-656)
     self.num_embeddings = 3500
     self.resample_padding = 0.0
     self.opaque_background = False
@@ -341,6 +343,9 @@ class ModelCfg:
     self.interlevel_loss_mult = 1.0
     self.distortion_loss_mult = 0.01
     self.transient_type = None
+    self.hanerf_mask_size_loss_mult_min = 6.0e-3
+    self.hanerf_mask_size_loss_mult_max = 5.0e-2
+    self.hanerf_mask_size_loss_mult_k = 1.0e-3
     self.withmask_transient_weight = 0.
     self.disable_multiscale_loss = False
     self.patch_size = 1
@@ -399,10 +404,33 @@ def init_params(cfg, seed=20200823, dtype=torch.float32):
       k = (torch.rand(fi, fo, generator=g, dtype=torch.float64) * 2 - 1) * lim
       mod[f'Dense_{i}'] = {'kernel': k.to(dtype), 'bias': torch.zeros(fo, dtype=dtype)}
     params[name] = mod
+  if cfg.transient_type == 'hanerf':
+    mod, fi = {}, 2 + 4 * cfg.mask_deg_coord + cfg.num_transient_features
+    for i in range(cfg.mask_depth + 1):
+      fo = cfg.mask_width if i < cfg.mask_depth else 1
+      k = (torch.rand(fi, fo, generator=g, dtype=torch.float64) * 2 - 1) * math.sqrt(6.0 / fi)
+      mod[f'Dense_{i}'] = {'kernel': k.to(dtype), 'bias': torch.zeros(fo, dtype=dtype)}
+      fi = fo
+    params['ImplicitMask_0'] = mod
   if cfg.num_glo_features > 0:
     e = torch.randn(cfg.num_embeddings, cfg.num_glo_features, generator=g, dtype=torch.float64)
     params['GloEmbed_0'] = {'embedding': (e / math.sqrt(cfg.num_glo_features)).to(dtype)}
+  if cfg.num_transient_features > 0:
+    e = torch.randn(cfg.num_embeddings, cfg.num_transient_features, generator=g, dtype=torch.float64)
+    params['TransientEmbed_0'] = {'embedding': (e / math.sqrt(cfg.num_transient_features)).to(dtype)}
   return {'params': params}
+
+
+def implicit_mask_forward(cfg, mod, pix_coords, tra_vec, taps=None):
+  """models.py:651-674 ImplicitMask: sigmoid(Dense(1)((Dense+relu)^depth([pos_enc(pix_coords,0,deg,True) | tra_vec])))."""
+  x = torch.cat([pos_enc(pix_coords, 0, cfg.mask_deg_coord, True), tra_vec], -1)
+  for i in range(cfg.mask_depth):
+    pre = x @ mod[f'Dense_{i}']['kernel'] + mod[f'Dense_{i}']['bias']
+    if taps is not None:
+      taps.append(pre.detach())
+    x = torch.relu(pre)
+  L = mod[f'Dense_{cfg.mask_depth}']
+  return torch.sigmoid(x @ L['kernel'] + L['bias'])
 
 
 def mlp_forward(cfg, mod, which, feats, viewdirs, glo_vec, taps=None):
@@ -454,7 +482,7 @@ def sample_u_base(num_samples, randomized):
 
 
 def model_forward(cfg, variables, rays, train_frac, u01, compute_extras, zero_glo=False, taps=None,
-                  override_samples=None, override_feats=None):
+                  override_samples=None, override_feats=None, zero_tra=False, mask_taps=None):
   """Model.__call__ (models.py:74-330).  rays: dict of [N,c] tensors.  u01: None
   (rng=None) or list[num_levels] of [N] float32 uniform draws (single_jitter)."""
   P = variables['params']
@@ -504,6 +532,11 @@ def model_forward(cfg, variables, rays, train_frac, u01, compute_extras, zero_gl
     rend = volumetric_rendering(rgb, weights, tdist, cfg.bg_intensity, far, compute_extras)
     renderings.append(rend)
     history.append(dict(density=density, rgb=rgb, sdist=sdist, tdist=tdist, weights=weights))
+  if cfg.transient_type == 'hanerf':     # models.py:120-129,327-328
+    tra = (torch.zeros(N, cfg.num_transient_features, dtype=dt) if zero_tra else
+           P['TransientEmbed_0']['embedding'][rays['embed_idx'][:, 0].long()])
+    renderings[-1]['implicit_mask'] = implicit_mask_forward(cfg, P['ImplicitMask_0'], rays['pix_coords'].to(dt), tra,
+                                                            mask_taps)
   return renderings, history
 
 
@@ -530,6 +563,27 @@ def compute_data_loss(cfg, gt_rgb, rays, renderings, use_static_mask):
   losses = torch.stack(losses)
   return cfg.data_coarse_loss_mult * losses[:-1].sum() + cfg.data_loss_mult * losses[-1], \
       {'mses': torch.stack(mses)}
+
+
+def compute_hanerf_loss(cfg, gt_rgb, renderings, train_frac):
+  """train_utils.py:186-225."""
+  mult = max(cfg.hanerf_mask_size_loss_mult_min, cfg.hanerf_mask_size_loss_mult_max *
+             math.exp(-train_frac * cfg.max_steps * cfg.hanerf_mask_size_loss_mult_k))
+  m = renderings[-1]['implicit_mask']
+  losses, mses, out = [], [], {}
+  for i, r in enumerate(renderings):
+    resid_sq = (r['rgb'] - gt_rgb)**2
+    dl = resid_sq if cfg.data_loss_type == 'mse' else torch.sqrt(resid_sq + cfg.charb_padding**2)
+    if i == len(renderings) - 1:
+      dl = (1. - m) * dl
+      out['mask_size'] = mult * (m**2).mean()
+    else:
+      dl = (1. - m.detach()) * dl
+    losses.append(dl.mean())
+    mses.append(resid_sq.mean())
+  losses = torch.stack(losses)
+  out['data'] = cfg.data_coarse_loss_mult * losses[:-1].sum() + cfg.data_loss_mult * losses[-1]
+  return out, {'mses': torch.stack(mses), 'implicit_mask': m.mean().detach()[None]}
 
 
 def robustnerf_mask(cfg, errors, thr):
@@ -626,6 +680,9 @@ def loss_and_grad(cfg, variables, rays, gt_rgb, train_frac, u01, inlier_threshol
     ps = cfg.patch_size
     rs = [{'rgb': r['rgb'].reshape(-1, ps, ps, 3)} for r in renderings]
     losses['data'], st = compute_robustnerf_loss(cfg, gt_rgb.reshape(-1, ps, ps, 3), rs, inlier_thresholds)
+  elif cfg.transient_type == 'hanerf':
+    ls, st = compute_hanerf_loss(cfg, gt_rgb, renderings, train_frac)
+    losses.update(ls)
   else:
     raise ValueError()
   stats.update(st)

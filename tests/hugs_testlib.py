@@ -42,24 +42,32 @@ def make_pair(gin_lines, seed=3, compute_dtype='fp32'):
       opaque_background=model.opaque_background, warp=model.nerf_spec.warp_fn is not None,
       nerf_depth=model.nerf_spec.net_depth, nerf_width=model.nerf_spec.net_width, prop_depth=model.prop_spec.net_depth,
       prop_width=model.prop_spec.net_width, prop_disable_rgb=model.prop_spec.disable_rgb,
-      data_loss_type=config.data_loss_type, data_coarse_loss_mult=config.data_coarse_loss_mult,
+      data_loss_type=config.data_loss_type, data_loss_mult=config.data_loss_mult, charb_padding=config.charb_padding,
+      withmask_transient_weight=config.withmask_transient_weight, grad_max_val=config.grad_max_val,
+      disable_multiscale_loss=config.disable_multiscale_loss, data_coarse_loss_mult=config.data_coarse_loss_mult,
       interlevel_loss_mult=config.interlevel_loss_mult, distortion_loss_mult=config.distortion_loss_mult,
       transient_type=config.transient_type, patch_size=config.patch_size,
       robustnerf_inlier_quantile=config.robustnerf_inlier_quantile, grad_max_norm=config.grad_max_norm,
       lr_init=config.lr_init, lr_final=config.lr_final, max_steps=config.max_steps,
       lr_delay_steps=config.lr_delay_steps, lr_delay_mult=config.lr_delay_mult, adam_eps=config.adam_eps,
       basis_shape=model.nerf_spec.basis_shape, basis_subdivisions=model.nerf_spec.basis_subdivisions,
-      max_deg_point=model.nerf_spec.max_deg_point)
+      max_deg_point=model.nerf_spec.max_deg_point, num_transient_features=model.num_transient_features,
+      hanerf_mask_size_loss_mult_min=config.hanerf_mask_size_loss_mult_min,
+      hanerf_mask_size_loss_mult_max=config.hanerf_mask_size_loss_mult_max,
+      hanerf_mask_size_loss_mult_k=config.hanerf_mask_size_loss_mult_k)
+  if model.mask_spec is not None:
+    cfg.mask_depth, cfg.mask_width, cfg.mask_deg_coord = (model.mask_spec.net_depth, model.mask_spec.net_width,
+                                                           model.mask_spec.deg_coord)
   # oracle params = copies of the product's (logical, unpadded) leaves
   tree = model.variables(state.flat)['params']
-  P = {m: ({k: {kk: vv.detach().cpu().clone() for kk, vv in v.items()} for k, v in sub.items()} if m != 'GloEmbed_0'
+  P = {m: ({k: {kk: vv.detach().cpu().clone() for kk, vv in v.items()} for k, v in sub.items()} if 'Embed' not in m
            else {'embedding': sub['embedding'].detach().cpu().clone()}) for m, sub in tree.items()}
   return config, model, state, render_fn, train_step, cfg, {'params': P}
 
 
 def oracle_rays(batch):
   r = batch.rays.flat()
-  return dict(origins=r.origins, directions=r.directions, viewdirs=r.viewdirs, radii=r.radii, lossmult=r.lossmult,
+  return dict(pix_coords=r.pix_coords, origins=r.origins, directions=r.directions, viewdirs=r.viewdirs, radii=r.radii, lossmult=r.lossmult,
               static_mask=r.static_mask, near=r.near, far=r.far, embed_idx=r.embed_idx)
 
 

@@ -153,3 +153,66 @@ def test_train_step_upstream_blender_llff_shape():
          "NerfMLP.net_depth = 8", "NerfMLP.net_width = 256", "NerfMLP.basis_shape = 'octahedron'",
          "NerfMLP.basis_subdivisions = 1", "NerfMLP.max_deg_point = 16", "PropMLP.max_deg_point = 16"]
   _run_case(gin, near=0.2, far=1.0)
+
+
+HANERF = SMALL + ["Config.transient_type = 'hanerf'", "Model.num_transient_features = 16", "Model.num_glo_features = 4",
+                  "Config.data_loss_mult = 0.5", "Config.data_coarse_loss_mult = 0.1", "PropMLP.disable_rgb = False",
+                  "PropMLP.bottleneck_width = 128", "NerfMLP.bottleneck_width = 128"]
+
+
+def test_train_step_hanerf():
+  """SURVEY 8 row a28, HA-NeRF: ImplicitMask MLP + TransientEmbed + compute_hanerf_loss (mask-weighted data loss on
+  every level, stop-gradient on the coarse ones, mask-size penalty) against the oracle, gradients of every leaf."""
+  _run_case(HANERF, n_patch=2)
+
+
+def test_hanerf_implicit_mask_rendering_and_zero_tra():
+  from tests import hugs_testlib as H
+  from oracle import torch_ref as R
+  config, model, state, render_fn, train_step, cfg, oparams = H.make_pair(HANERF)
+  assert model.layout.modules == ['NerfMLP_0', 'PropMLP_0', 'ImplicitMask_0', 'GloEmbed_0', 'TransientEmbed_0']
+  assert model.layout.by_path[('ImplicitMask_0', 'Dense_0', 'kernel')]['shape'] == (42 + 16, 256)
+  batch = H.synth_rays(3, 8, 2)      # 192 rays: the mask MLP pads its batch to 256 rows
+  for zero_tra in (False, True):
+    rend, _ = model.apply(state.flat, None, batch.rays, 0.5, False, zero_tra=zero_tra)
+    orend, _ = R.model_forward(cfg, oparams, H.oracle_rays(batch), 0.5, None, False, zero_tra=zero_tra)
+    a = rend[-1]['implicit_mask']
+    assert a.shape == (3, 8, 8, 1) and 'implicit_mask' not in rend[0]
+    assert float((a.cpu().reshape(-1, 1) - orend[-1]['implicit_mask'].detach()).abs().max()) < 2e-5
+  # the mask-size weight follows the schedule of train_utils.py:190-193
+  gen = torch.Generator(device='cuda').manual_seed(0)
+  for tf, want in ((0., 5e-2), (1., 6e-3)):
+    _, stats, gen = train_step(gen, state, batch, tf, None)
+    m2 = float(stats['losses']['mask_size']) / want
+    assert 0 < m2 < 1 and float(stats['implicit_mask'][0]) ** 2 <= m2 + 1e-6      # mean(m)^2 <= mean(m^2)
+
+
+def test_hanerf_bf16_step_at_the_shipped_transient_width():
+  """distractor_1024_glo4_hanerf.gin's mask input (42 + 128 features -> one 256-column K tile) in bf16 against
+  the fp32 oracle: loss within 2 %, gradient direction of the ImplicitMask / TransientEmbed leaves."""
+  from tests import hugs_testlib as H
+  from oracle import torch_ref as R
+  gin = [g for g in HANERF if 'num_transient_features' not in g] + ["Model.num_transient_features = 128"]
+  config, model, state, _, train_step, cfg, oparams = H.make_pair(gin, compute_dtype='bf16')
+  assert model.mask_spec.kpad == 256
+  batch = H.synth_rays(4, 8, 5)
+  N, L = 256, model.num_levels
+  gen = torch.Generator(device='cuda').manual_seed(11)
+  st = gen.get_state()
+  u01 = [torch.rand(N, generator=gen, device='cuda') for _ in range(L)]
+  gen.set_state(st)
+  ostats, ograds, orend, _ = R.loss_and_grad(cfg, oparams, H.oracle_rays(batch), batch.rgb.reshape(-1, 3), 0.37,
+                                             [u.cpu() for u in u01])
+  state, stats, gen = train_step(gen, state, batch, 0.37, None)
+  torch.cuda.synchronize()
+  assert abs(float(stats['loss']) / float(ostats['loss']) - 1) < 2e-2
+  assert abs(float(stats['losses']['mask_size']) / float(ostats['losses']['mask_size']) - 1) < 2e-2
+  grad = model.engine('cuda').ws.get('grad', (model.layout.size + 64,))
+  for lf in model.layout.leaves:
+    if lf['path'][0] not in ('ImplicitMask_0', 'TransientEmbed_0') or lf['path'][-1] == 'bias':
+      continue
+    name = '/'.join(lf['path'])
+    g = model.layout.view(grad, lf['path']).cpu().double().flatten()
+    og = ograds[name].double().flatten()
+    cos = float((g * og).sum() / (g.norm() * og.norm()).clamp(min=1e-30))
+    assert cos > 0.97 and 0.9 < float(g.norm() / og.norm()) < 1.1, f'{name}: cosine {cos:.4f}'
