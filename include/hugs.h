@@ -180,6 +180,27 @@ int hugs_embed_scatter_add(int dtype, int N, int T, const void* dX, int ldx, int
 int hugs_hanerf_loss(int N, int L, const float* pred, const float* gt, const float* mask, int charb, float charb_pad,
                      const float* coef, float mask_size_mult, float* d_pred, float* d_mask, float* out_stats, void* stream);
 
+/* ---- NeRF-W branch.  render.py:154-182 compute_dual_alpha_weights + :246-273
+ * volumetric_rendering_combined_color + models.py:299-307 uncertainty (beta = sum_i w^t_i u_i + beta_min, w^t from
+ * the transient density alone).  All per-sample arrays [nrays*S(,3)] fp32.  The backward ADDS into d_dens_s (the
+ * static-only hugs_composite_bwd runs first: interlevel / distortion reach sigma_s through `weights`), overwrites
+ * the others; dens_t_const = d(density regulariser)/d sigma_t.  hugs_rank1_add2_mask: G += (r1 c1^T + r2 c2^T) *
+ * (X > 0), the two scalar heads' contribution to the gradient entering the transient trunk.
+ * hugs_nerfw_loss: train_utils.py:150-183 (pred[L-1] = rgb_combined); out_stats [2L+1]. */
+int hugs_dual_composite_fwd(int nrays, int S, const float* dens_s, const float* dens_t, const float* rgb_s,
+                            const float* rgb_t, const float* unc, const float* tdist, const float* dirs,
+                            int opaque_background, float bg, float beta_min, float* rgb_combined, float* rgb_static,
+                            float* rgb_transient, float* beta, void* stream);
+int hugs_dual_composite_bwd(int nrays, int S, const float* dens_s, const float* dens_t, const float* rgb_s,
+                            const float* rgb_t, const float* unc, const float* tdist, const float* dirs,
+                            int opaque_background, float bg, const float* d_rgb_combined, const float* d_beta,
+                            float dens_t_const, float* d_dens_s_accum, float* d_rgb_s, float* d_dens_t, float* d_rgb_t,
+                            float* d_unc, void* stream);
+int hugs_rank1_add2_mask(int dtype, int M, int N, const float* r1, const float* c1, const float* r2, const float* c2,
+                         const void* X, int ldx, void* G, int ldg, void* stream);
+int hugs_nerfw_loss(int N, int L, const float* pred, const float* gt, const float* beta, int charb, float charb_pad,
+                    const float* coef, float beta_mult, float* d_pred, float* d_beta, float* out_stats, void* stream);
+
 /* test/bench hook: force the 128x128-tile bf16 NT kernel where the 256x256 one would be selected */
 int hugs_test_force_small_tiles(int on);
 /* test hooks: the portable exp/log of the sampler and raw IEEE ops as the device executes them */

@@ -47,6 +47,10 @@ _PROTOS = {
     'hugs_mask_head_bwd': 'iiiipippppps',
     'hugs_embed_scatter_add': 'iiipiipps',
     'hugs_hanerf_loss': 'iipppifpfppps',
+    'hugs_dual_composite_fwd': 'iipppppppiffpppps',
+    'hugs_dual_composite_bwd': 'iipppppppifppfppppps',
+    'hugs_rank1_add2_mask': 'iiipppppipis',
+    'hugs_nerfw_loss': 'iipppifpfppps',
     'hugs_test_force_small_tiles': 'i',
 }
 _CT = {'i': ctypes.c_int, 'f': ctypes.c_float, 'p': ctypes.c_void_p, 'q': ctypes.c_longlong,

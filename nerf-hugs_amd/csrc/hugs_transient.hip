@@ -192,3 +192,266 @@ extern "C" int hugs_hanerf_loss(int N, int L, const float* pred, const float* gt
   HUGS_CHECK_LAUNCH("k_hanerf_loss");
   return 0;
 }
+
+// =====================================================================================================
+// NeRF-W branch: static + transient compositing, one WAVEFRONT per ray (<= 256 samples, 4 per
+// lane in registers, wave prefix / suffix scans), and compute_nerfw_loss.
+//   render.py:154-182 compute_dual_alpha_weights, :246-273 volumetric_rendering_combined_color,
+//   models.py:299-307 uncertainty = sum_i w^t_i u_i + beta_min (w^t from the transient density alone),
+//   train_utils.py:150-183 compute_nerfw_loss.
+// =====================================================================================================
+namespace {
+
+#define DC_MAXC 4
+
+struct DualScan {
+  float a[DC_MAXC], b[DC_MAXC];      // sigma_s * delta, sigma_t * delta (+inf on the last sample when opaque)
+  float T[DC_MAXC], Tt[DC_MAXC];     // transmittance of (a+b) and of b alone, before the sample
+  float dl[DC_MAXC];                 // delta
+  bool ok[DC_MAXC], last[DC_MAXC];
+};
+
+__device__ __forceinline__ void dual_scan(int S, int C, int lane, const float* __restrict__ ds, const float* __restrict__ dt_,
+                                          const float* __restrict__ td, float dnorm, int opaque, DualScan& R) {
+  float tg = 0.f, tb = 0.f;
+#pragma unroll
+  for (int k = 0; k < DC_MAXC; ++k) {
+    const int i = lane * C + k;
+    R.ok[k] = k < C && i < S;
+    R.last[k] = R.ok[k] && i == S - 1;
+    float a = 0.f, b = 0.f, d = 0.f;
+    if (R.ok[k]) {
+      d = (td[i + 1] - td[i]) * dnorm;
+      a = ds[i] * d;
+      b = dt_[i] * d;
+    }
+    R.dl[k] = d;
+    if (R.ok[k] && !R.last[k]) { tg += a + b; tb += b; }   // cumsum(...[:-1]): the last interval never enters a prefix
+    if (R.last[k] && opaque) { a = __builtin_inff(); b = __builtin_inff(); }
+    R.a[k] = a; R.b[k] = b;
+  }
+  const float ig = wave_incl_scan_f(tg, lane), ib = wave_incl_scan_f(tb, lane);
+  float rg = __shfl_up(ig, 1), rb = __shfl_up(ib, 1);
+  if (lane == 0) { rg = 0.f; rb = 0.f; }
+#pragma unroll
+  for (int k = 0; k < DC_MAXC; ++k) {
+    R.T[k] = expf(-rg);
+    R.Tt[k] = expf(-rb);
+    if (R.ok[k] && !R.last[k]) { rg += R.a[k] + R.b[k]; rb += R.b[k]; }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_dual_composite_fwd(int nrays, int S, const float* __restrict__ dens_s, const float* __restrict__ dens_t,
+                     const float* __restrict__ rgb_s, const float* __restrict__ rgb_t, const float* __restrict__ unc,
+                     const float* __restrict__ tdist, const float* __restrict__ dirs, int opaque, float bg, float beta_min,
+                     float* __restrict__ rgb_comb, float* __restrict__ rgb_static, float* __restrict__ rgb_trans,
+                     float* __restrict__ beta) {
+  const int lane = threadIdx.x & 63, ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= nrays) return;
+  const int C = (S + 63) >> 6;
+  const float* td = tdist + (size_t)ray * (S + 1);
+  const float dx = dirs[ray * 3], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
+  const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+  DualScan R;
+  dual_scan(S, C, lane, dens_s + (size_t)ray * S, dens_t + (size_t)ray * S, td, dnorm, opaque, R);
+  float acc = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, t0 = 0.f, t1 = 0.f, t2 = 0.f, be = 0.f;
+#pragma unroll
+  for (int k = 0; k < DC_MAXC; ++k) {
+    if (!R.ok[k]) continue;
+    const size_t i = (size_t)ray * S + lane * C + k;
+    const float w1 = (1.f - expf(-R.a[k])) * R.T[k], w2 = (1.f - expf(-R.b[k])) * R.T[k];
+    acc += (1.f - expf(-(R.a[k] + R.b[k]))) * R.T[k];
+    s0 += w1 * rgb_s[i * 3]; s1 += w1 * rgb_s[i * 3 + 1]; s2 += w1 * rgb_s[i * 3 + 2];
+    t0 += w2 * rgb_t[i * 3]; t1 += w2 * rgb_t[i * 3 + 1]; t2 += w2 * rgb_t[i * 3 + 2];
+    be += (1.f - expf(-R.b[k])) * R.Tt[k] * unc[i];
+  }
+  acc = wave_sum_f(acc); be = wave_sum_f(be);
+  s0 = wave_sum_f(s0); s1 = wave_sum_f(s1); s2 = wave_sum_f(s2);
+  t0 = wave_sum_f(t0); t1 = wave_sum_f(t1); t2 = wave_sum_f(t2);
+  if (lane == 0) {
+    const float bgw = fmaxf(0.f, 1.f - acc) * bg;
+    rgb_static[ray * 3] = s0; rgb_static[ray * 3 + 1] = s1; rgb_static[ray * 3 + 2] = s2;
+    rgb_trans[ray * 3] = t0; rgb_trans[ray * 3 + 1] = t1; rgb_trans[ray * 3 + 2] = t2;
+    rgb_comb[ray * 3] = s0 + t0 + bgw; rgb_comb[ray * 3 + 1] = s1 + t1 + bgw; rgb_comb[ray * 3 + 2] = s2 + t2 + bgw;
+    beta[ray] = be + beta_min;
+  }
+}
+
+// d_dens_s += ..., d_rgb_s = ..., d_dens_t = ... (+ dens_t_const: the density regulariser's constant gradient),
+// d_rgb_t = ..., d_unc = ...
+__global__ void __launch_bounds__(256)
+k_dual_composite_bwd(int nrays, int S, const float* __restrict__ dens_s, const float* __restrict__ dens_t,
+                     const float* __restrict__ rgb_s, const float* __restrict__ rgb_t, const float* __restrict__ unc,
+                     const float* __restrict__ tdist, const float* __restrict__ dirs, int opaque, float bg,
+                     const float* __restrict__ d_rgb_comb, const float* __restrict__ d_beta, float dens_t_const,
+                     float* __restrict__ d_dens_s, float* __restrict__ d_rgb_s, float* __restrict__ d_dens_t,
+                     float* __restrict__ d_rgb_t, float* __restrict__ d_unc) {
+  const int lane = threadIdx.x & 63, ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= nrays) return;
+  const int C = (S + 63) >> 6;
+  const float* td = tdist + (size_t)ray * (S + 1);
+  const float dx = dirs[ray * 3], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
+  const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+  DualScan R;
+  dual_scan(S, C, lane, dens_s + (size_t)ray * S, dens_t + (size_t)ray * S, td, dnorm, opaque, R);
+  const float g0 = d_rgb_comb[ray * 3], g1 = d_rgb_comb[ray * 3 + 1], g2 = d_rgb_comb[ray * 3 + 2];
+  const float gbeta = d_beta[ray];
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < DC_MAXC; ++k)
+    if (R.ok[k]) acc += (1.f - expf(-(R.a[k] + R.b[k]))) * R.T[k];
+  acc = wave_sum_f(acc);
+  const float one_m = 1.f - acc;
+  const float gb = one_m > 0.f ? 1.f : (one_m == 0.f ? 0.5f : 0.f);   // jnp.maximum's tie rule
+  const float gbg = gb * bg * (g0 + g1 + g2);
+  float p[DC_MAXC], q[DC_MAXC], u[DC_MAXC], lane_v = 0.f, lane_u = 0.f;
+#pragma unroll
+  for (int k = 0; k < DC_MAXC; ++k) {
+    p[k] = q[k] = u[k] = 0.f;
+    if (!R.ok[k]) continue;
+    const size_t i = (size_t)ray * S + lane * C + k;
+    const float A1 = 1.f - expf(-R.a[k]), A2 = 1.f - expf(-R.b[k]), A = 1.f - expf(-(R.a[k] + R.b[k]));
+    p[k] = g0 * rgb_s[i * 3] + g1 * rgb_s[i * 3 + 1] + g2 * rgb_s[i * 3 + 2];
+    q[k] = g0 * rgb_t[i * 3] + g1 * rgb_t[i * 3 + 1] + g2 * rgb_t[i * 3 + 2];
+    u[k] = unc[i];
+    const float w1 = A1 * R.T[k], w2 = A2 * R.T[k], wt = A2 * R.Tt[k];
+    d_rgb_s[i * 3] = w1 * g0; d_rgb_s[i * 3 + 1] = w1 * g1; d_rgb_s[i * 3 + 2] = w1 * g2;
+    d_rgb_t[i * 3] = w2 * g0; d_rgb_t[i * 3 + 1] = w2 * g1; d_rgb_t[i * 3 + 2] = w2 * g2;
+    d_unc[i] = gbeta * wt;
+    lane_v += R.T[k] * (A1 * p[k] + A2 * q[k] - gbg * A);
+    lane_u += wt * u[k];
+  }
+  const float sv = wave_incl_suffix_scan_f(lane_v, lane), su = wave_incl_suffix_scan_f(lane_u, lane);
+  float sufv = __shfl_down(sv, 1), sufu = __shfl_down(su, 1);      // sums over the lanes after this one
+  if (lane == 63) { sufv = 0.f; sufu = 0.f; }
+#pragma unroll
+  for (int k = DC_MAXC - 1; k >= 0; --k) {
+    if (!R.ok[k]) continue;
+    const size_t i = (size_t)ray * S + lane * C + k;
+    const float ea = expf(-R.a[k]), eb = expf(-R.b[k]), eg = expf(-(R.a[k] + R.b[k]));
+    float da = R.T[k] * (ea * p[k] - gbg * eg) - sufv;
+    float db = R.T[k] * (eb * q[k] - gbg * eg) - sufv + gbeta * (R.Tt[k] * eb * u[k] - sufu);
+    if (R.last[k] && opaque) { da = 0.f; db = 0.f; }              // replaced by +inf: no gradient
+    if (R.last[k] && !opaque) {                                    // the last interval is in no prefix: only its own alpha
+      da = R.T[k] * (ea * p[k] - gbg * eg);
+      db = R.T[k] * (eb * q[k] - gbg * eg) + gbeta * R.Tt[k] * eb * u[k];
+    }
+    d_dens_s[i] += da * R.dl[k];
+    d_dens_t[i] = db * R.dl[k] + dens_t_const;
+    const float A1 = 1.f - ea, A2 = 1.f - eb, A = 1.f - eg;
+    sufv += R.T[k] * (A1 * p[k] + A2 * q[k] - gbg * A);
+    sufu += A2 * R.Tt[k] * u[k];
+  }
+}
+
+// G[m,n] += (r1[m] c1[n] + r2[m] c2[n]) * (X[m,n] > 0)
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+k_rank1_add2_mask(int M, int N, const float* __restrict__ r1, const float* __restrict__ c1, const float* __restrict__ r2,
+                  const float* __restrict__ c2, const void* __restrict__ X, int ldxv, void* __restrict__ G, int ldg) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)M * N) return;
+  const int m = (int)(i / N), n = (int)(i - (size_t)m * N);
+  const float x = ldx<BF16>(X, (size_t)m * ldxv + n);
+  if (x > 0.f) {
+    const float add = r1[m] * c1[n] + r2[m] * c2[n];
+    if (BF16) {
+      uint16_t* g = (uint16_t*)G + (size_t)m * ldg + n;
+      *g = f_to_bf16(bf16_to_f(*g) + add);
+    } else {
+      ((float*)G)[(size_t)m * ldg + n] += add;
+    }
+  }
+}
+
+// train_utils.py:150-183.  pred [L,N,3] (last level = rgb_combined).  stats: [2l] mean resid^2, [2l+1] data loss of
+// level l (the last one divided by 2 beta^2), [2L] mean(log beta).
+__global__ void __launch_bounds__(1024)
+k_nerfw_loss(int N, int L, const float* __restrict__ pred, const float* __restrict__ gt, const float* __restrict__ beta,
+             int charb, float pad, const float* __restrict__ coef, float beta_mult, float* __restrict__ d_pred,
+             float* __restrict__ d_beta, float* __restrict__ stats) {
+  __shared__ float red[16];
+  const float inv = 1.f / (3.f * (float)N);
+  for (int l = 0; l < L; ++l) {
+    const float cf = coef[l];
+    const bool fin = l == L - 1;
+    float s_mse = 0.f, s_loss = 0.f;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+      const float b = fin ? beta[n] : 1.f;
+      const float sc = fin ? 1.f / (2.f * b * b) : 1.f;
+      float row = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const size_t ix = ((size_t)l * N + n) * 3 + c;
+        const float r = pred[ix] - gt[(size_t)n * 3 + c];
+        const float r2 = r * r;
+        float dl, ddl;
+        if (charb) { dl = sqrtf(r2 + pad * pad); ddl = r / dl; } else { dl = r2; ddl = 2.f * r; }
+        s_mse += r2;
+        s_loss += dl * sc;
+        row += dl;
+        d_pred[ix] = cf * sc * ddl * inv;
+      }
+      if (fin) d_beta[n] = -cf * row / (b * b * b) * inv + beta_mult / (b * (float)N);
+    }
+    s_mse = block_sum1024(s_mse, red);
+    s_loss = block_sum1024(s_loss, red);
+    if (threadIdx.x == 0) { stats[2 * l] = s_mse * inv; stats[2 * l + 1] = s_loss * inv; }
+  }
+  float sl = 0.f;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) sl += logf(beta[n]);
+  sl = block_sum1024(sl, red);
+  if (threadIdx.x == 0) stats[2 * L] = sl / (float)N;
+}
+
+}  // namespace
+
+extern "C" int hugs_dual_composite_fwd(int nrays, int S, const float* dens_s, const float* dens_t, const float* rgb_s,
+                                       const float* rgb_t, const float* unc, const float* tdist, const float* dirs,
+                                       int opaque_background, float bg, float beta_min, float* rgb_combined,
+                                       float* rgb_static, float* rgb_transient, float* beta, void* stream) {
+  HUGS_REQUIRE(S >= 1 && S <= 64 * DC_MAXC, -3, "hugs_dual_composite_fwd: %d samples per ray unsupported (<= %d)", S,
+               64 * DC_MAXC);
+  if (nrays <= 0) return 0;
+  k_dual_composite_fwd<<<(nrays + 3) / 4, 256, 0, (hipStream_t)stream>>>(nrays, S, dens_s, dens_t, rgb_s, rgb_t, unc, tdist,
+                                                                       dirs, opaque_background, bg, beta_min, rgb_combined,
+                                                                       rgb_static, rgb_transient, beta);
+  HUGS_CHECK_LAUNCH("k_dual_composite_fwd");
+  return 0;
+}
+
+extern "C" int hugs_dual_composite_bwd(int nrays, int S, const float* dens_s, const float* dens_t, const float* rgb_s,
+                                       const float* rgb_t, const float* unc, const float* tdist, const float* dirs,
+                                       int opaque_background, float bg, const float* d_rgb_combined, const float* d_beta,
+                                       float dens_t_const, float* d_dens_s_accum, float* d_rgb_s, float* d_dens_t,
+                                       float* d_rgb_t, float* d_unc, void* stream) {
+  HUGS_REQUIRE(S >= 1 && S <= 64 * DC_MAXC, -3, "hugs_dual_composite_bwd: %d samples per ray unsupported (<= %d)", S,
+               64 * DC_MAXC);
+  if (nrays <= 0) return 0;
+  k_dual_composite_bwd<<<(nrays + 3) / 4, 256, 0, (hipStream_t)stream>>>(
+      nrays, S, dens_s, dens_t, rgb_s, rgb_t, unc, tdist, dirs, opaque_background, bg, d_rgb_combined, d_beta, dens_t_const,
+      d_dens_s_accum, d_rgb_s, d_dens_t, d_rgb_t, d_unc);
+  HUGS_CHECK_LAUNCH("k_dual_composite_bwd");
+  return 0;
+}
+
+extern "C" int hugs_rank1_add2_mask(int dtype, int M, int N, const float* r1, const float* c1, const float* r2,
+                                    const float* c2, const void* X, int ldx, void* G, int ldg, void* stream) {
+  const size_t n = (size_t)M * N;
+  if (n == 0) return 0;
+  if (dtype) k_rank1_add2_mask<true><<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(M, N, r1, c1, r2, c2, X, ldx, G, ldg);
+  else k_rank1_add2_mask<false><<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(M, N, r1, c1, r2, c2, X, ldx, G, ldg);
+  HUGS_CHECK_LAUNCH("k_rank1_add2_mask");
+  return 0;
+}
+
+extern "C" int hugs_nerfw_loss(int N, int L, const float* pred, const float* gt, const float* beta, int charb,
+                               float charb_pad, const float* coef, float beta_mult, float* d_pred, float* d_beta,
+                               float* out_stats, void* stream) {
+  HUGS_REQUIRE(N > 0 && L >= 1 && L <= 8, -2, "hugs_nerfw_loss: N=%d L=%d", N, L);
+  k_nerfw_loss<<<1, 1024, 0, (hipStream_t)stream>>>(N, L, pred, gt, beta, charb, charb_pad, coef, beta_mult, d_pred, d_beta,
+                                                    out_stats);
+  HUGS_CHECK_LAUNCH("k_nerfw_loss");
+  return 0;
+}

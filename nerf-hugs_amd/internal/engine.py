@@ -21,7 +21,7 @@ def _round_up(x, m):
 class MLPSpec:
   """Static description of one MLP (models.py:359-391 attributes + gin bindings)."""
 
-  def __init__(self, name, is_prop, num_glo, **kw):
+  def __init__(self, name, is_prop, num_glo, num_transient=0, **kw):
     self.name = name
     self.is_prop = is_prop
     self.net_depth = 8
@@ -45,11 +45,15 @@ class MLPSpec:
     self.weight_init = 'he_uniform'
     self.bottleneck_noise = 0.0
     self.density_noise = 0.
+    self.net_depth_transient = 4      # models.py:367-375 (NeRF-W branch of the NerfMLP)
+    self.net_width_transient = 128
+    self.skip_layer_transient = 4
     for k, v in kw.items():
       if not hasattr(self, k):
         raise ValueError(f'{name} has no attribute {k!r}')
       setattr(self, k, v)
     self.num_glo = 0 if is_prop else num_glo
+    self.num_tra = 0 if is_prop else num_transient      # > 0 <=> disable_transient=False (models.py:104)
     self._check()
     self.basis = geopoly.generate_basis(self.basis_shape, self.basis_subdivisions).T.astype(np.float32).copy()  # [3,nb]
     self.nb = self.basis.shape[1]
@@ -69,6 +73,15 @@ class MLPSpec:
       kv = self.bottleneck_width + self.nd + self.num_glo
       L.append(dict(fan_in=kv, kpad=kv, fan_out=self.net_width_viewdirs, kind='view'))
       L.append(dict(fan_in=self.net_width_viewdirs, kpad=self.net_width_viewdirs, fan_out=self.num_rgb_channels, kind='rgb'))
+    self.t0 = len(L)          # index of the first transient layer (flax creates them after the rgb head, models.py:521-539)
+    if self.num_tra > 0:
+      Ht, kt = self.net_width_transient, self.bottleneck_width + self.num_tra
+      L.append(dict(fan_in=kt, kpad=kt, fan_out=Ht, kind='tview'))
+      for _ in range(1, self.net_depth_transient):
+        L.append(dict(fan_in=Ht, kpad=Ht, fan_out=Ht, kind='ttrunk'))
+      L.append(dict(fan_in=Ht, kpad=Ht, fan_out=1, kind='tdensity'))
+      L.append(dict(fan_in=Ht, kpad=Ht, fan_out=self.num_rgb_channels, kind='trgb'))
+      L.append(dict(fan_in=Ht, kpad=Ht, fan_out=1, kind='tuncert'))
     for i, l in enumerate(L):
       l['name'] = f'Dense_{i}'
     self.layers = L
@@ -81,6 +94,9 @@ class MLPSpec:
       raise NotImplementedError('MLP widths must be multiples of 128 (view width == 128) for the MFMA tiles')
     if self.min_deg_point != 0 or self.net_depth_viewdirs != 1 or self.num_rgb_channels != 3:
       raise NotImplementedError('min_deg_point != 0 / net_depth_viewdirs != 1 / num_rgb_channels != 3 are not built')
+    if self.num_tra > 0 and (self.disable_rgb or self.net_width_transient != 128 or self.net_depth_transient < 2 or
+                             self.net_depth_transient > self.skip_layer_transient):
+      raise NotImplementedError('transient MLP: width 128, 2 <= depth <= skip_layer_transient, rgb branch enabled')
     if self.bottleneck_noise > 0 or self.density_noise > 0:
       raise NotImplementedError('bottleneck/density noise is not built')
     if self.rgb_premultiplier != 1. or self.rgb_bias != 0.:
@@ -227,11 +243,11 @@ class Engine:
   def refresh_weights(self, theta):
     """Cast the fp32 masters to the GEMM operand copies: Wn [Kp,N] (dX) and Wt [N,Kp] (forward)."""
     for lf in self.layout.leaves:
-      if lf['path'][-1] != 'kernel' or lf['layer']['kind'] not in ('trunk', 'bottleneck', 'view'):
+      if lf['path'][-1] != 'kernel' or lf['layer']['kind'] not in ('trunk', 'bottleneck', 'view', 'tview', 'ttrunk'):
         continue
       l = lf['layer']
       W = self.layout.view(theta, lf['path'], padded=True)
-      K = l['kpad'] if l['kind'] != 'view' else lf['spec'].bottleneck_width   # GEMM part of the view layer
+      K = l['kpad'] if l['kind'] not in ('view', 'tview') else lf['spec'].bottleneck_width   # GEMM part of the layer
       N = l['fan_out']
       key = lf['path']
       if key not in self.wt:
@@ -240,9 +256,14 @@ class Engine:
       _lib.call('hugs_cast_weights', self.dt, K, N, W, self.wn[key], self.wt[key])
       if not self.dt:
         self.wn[key] = W[:K]      # fp32: the master itself is the natural-layout operand
+    for spec in self.model.specs:
+      if spec.num_tra > 0:      # dBottleneck = [G_view | G_transient0] [Wv[:Bw] | Wt0[:Bw]]^T in one two-segment GEMM
+        lv, lt = spec.layers[spec.net_depth + 2], spec.layers[spec.t0]
+        self.wcat = torch.cat([self.wn[(spec.name, lv['name'], 'kernel')], self.wn[(spec.name, lt['name'], 'kernel')]],
+                              1).contiguous()
 
   # ---- forward ------------------------------------------------------------------------------------
-  def _mlp_forward(self, spec, theta, lvl, N, S, tdist, rays, glo, keep):
+  def _mlp_forward(self, spec, theta, lvl, N, S, tdist, rays, glo, keep, tra=None):
     M = N * S
     lay, ws, dt = self.layout, self.ws, self.dt
     tag = f'{spec.name}/L{lvl}'
@@ -291,9 +312,41 @@ class Engine:
       _lib.call('hugs_rgb_fwd', dt, M, H, hact, H, lay.view(theta, (spec.name, lr['name'], 'kernel')),
                 lay.view(theta, (spec.name, lr['name'], 'bias')), spec.rgb_padding, rgb)
       out.update(bott=bott, hview=hact, rgb=rgb)
+      if spec.num_tra > 0 and tra is not None:
+        # models.py:521-539: x = [bottleneck | tra_vec] -> (Dense+relu) x depth_t -> density_t, rgb_t, uncertainty.
+        # The tra_vec part of the first layer is constant along a ray: a per-ray bias, like the view layer's.
+        Ht, dtn, t0 = spec.net_width_transient, spec.net_depth_transient, spec.t0
+        lt = spec.layers[t0]
+        Wt0 = lay.view(theta, (spec.name, lt['name'], 'kernel'))
+        rbt = ws.get(tag + '/raybias_t', (N, Ht))
+        _lib.call('hugs_raybias_fwd', N, Ht, 0, spec.num_tra, None, tra, Wt0[Bw:],
+                  lay.view(theta, (spec.name, lt['name'], 'bias')), rbt)
+        tacts = []
+        x = ws.get(tag + '/T0', (M, Ht), self.tdt)
+        _lib.call('hugs_gemm_nt', dt, M, Ht, Bw, 0, bott, Bw, None, 0, self.wt[(spec.name, lt['name'], 'kernel')], Bw, None,
+                  rbt, S, Ht, 1, None, 0, None, None, x, Ht)
+        tacts.append(x)
+        for i in range(1, dtn):
+          l = spec.layers[t0 + i]
+          y = ws.get(f'{tag}/T{i}', (M, Ht), self.tdt)
+          _lib.call('hugs_gemm_nt', dt, M, Ht, Ht, 0, x, Ht, None, 0, self.wt[(spec.name, l['name'], 'kernel')], Ht,
+                    lay.view(theta, (spec.name, l['name'], 'bias')), None, 1, 0, 1, None, 0, None, None, y, Ht)
+          tacts.append(y)
+          x = y
+        ld_, lr_, lu_ = spec.layers[t0 + dtn:t0 + dtn + 3]
+        raw_t, dens_t = ws.get(tag + '/raw_t', (M,)), ws.get(tag + '/dens_t', (M,))
+        _lib.call('hugs_density_fwd', dt, M, Ht, x, Ht, lay.view(theta, (spec.name, ld_['name'], 'kernel')).reshape(-1),
+                  lay.view(theta, (spec.name, ld_['name'], 'bias')), spec.density_bias, raw_t, dens_t)
+        rgb_t = ws.get(tag + '/rgb_t', (M, 3))
+        _lib.call('hugs_rgb_fwd', dt, M, Ht, x, Ht, lay.view(theta, (spec.name, lr_['name'], 'kernel')),
+                  lay.view(theta, (spec.name, lr_['name'], 'bias')), spec.rgb_padding, rgb_t)
+        raw_u, unc = ws.get(tag + '/raw_u', (M,)), ws.get(tag + '/unc', (M,))
+        _lib.call('hugs_density_fwd', dt, M, Ht, x, Ht, lay.view(theta, (spec.name, lu_['name'], 'kernel')).reshape(-1),
+                  lay.view(theta, (spec.name, lu_['name'], 'bias')), 0.0, raw_u, unc)      # softplus, no bias shift
+        out.update(tacts=tacts, raw_t=raw_t, dens_t=dens_t, rgb_t=rgb_t, raw_u=raw_u, unc=unc, tra=tra)
     return out
 
-  def forward(self, theta, rays, train_frac, u01, compute_extras, zero_glo=False):
+  def forward(self, theta, rays, train_frac, u01, compute_extras, zero_glo=False, zero_tra=False):
     """Model.__call__ (models.py:74-330).  rays: dict of contiguous [N,c] cuda tensors (+ 'dir_enc').
     u01: None, a list[num_levels] of U[0,1) draws, or a stepfun.Jitter list of scaled draws.  Returns per-level dicts (device tensors; buffers are
     reused by the next call)."""
@@ -305,6 +358,11 @@ class Engine:
       glo = ws.get('glo', (N, mdl.num_glo_features))
       emb = self.layout.view(theta, ('GloEmbed_0', 'embedding'))
       _lib.call('hugs_glo_gather', N, mdl.num_glo_features, emb, rays['embed_idx'], int(zero_glo), glo)
+    tra = None
+    if mdl.nerf_spec.num_tra > 0:          # NeRF-W: TransientEmbed rows of the rays' cameras (models.py:120-129)
+      tra = ws.get('tra_vec', (N, mdl.nerf_spec.num_tra))
+      _lib.call('hugs_glo_gather', N, mdl.nerf_spec.num_tra, self.layout.view(theta, ('TransientEmbed_0', 'embedding')),
+                rays['embed_idx'], int(zero_tra), tra)
     if 'dir_enc' not in rays:
       nd = mdl.nerf_spec.nd
       rays['dir_enc'] = ws.get('dir_enc', (N, nd))
@@ -337,13 +395,20 @@ class Engine:
                                     mdl.resample_padding, S, None if scaled else draw, mdl.raydist, rays['near'],
                                     rays['far'], jitter=draw if scaled else None)
       spec = mdl.prop_spec if is_prop else mdl.nerf_spec
-      out = self._mlp_forward(spec, theta, lvl, N, S, td, rays, glo, True)
+      out = self._mlp_forward(spec, theta, lvl, N, S, td, rays, glo, True, None if is_prop else tra)
       w = ws.get(f'L{lvl}/weights', (N, S))
       rgb_all = ws.get('rgb_out_all', (mdl.num_levels, N, 3))
       rgb_out = rgb_all[lvl]
       extras = ws.get(f'L{lvl}/extras', (N, 5)) if compute_extras else None
       _lib.call('hugs_composite_fwd', N, S, out['density'], out['rgb'], td, rays['directions'],
                 int(mdl.opaque_background), mdl.bg_intensity, rays['far'].reshape(-1), w, rgb_out, extras)
+      if out.get('dens_t') is not None:     # models.py:285-307
+        nw = {k: ws.get(f'L{lvl}/{k}', (N, 3)) for k in ('rgb_combined', 'rgb_static', 'rgb_transient')}
+        nw['uncertainty'] = ws.get(f'L{lvl}/uncertainty', (N,))
+        _lib.call('hugs_dual_composite_fwd', N, S, out['density'], out['dens_t'], out['rgb'], out['rgb_t'], out['unc'], td,
+                  rays['directions'], int(mdl.opaque_background), mdl.bg_intensity, mdl.beta_min, nw['rgb_combined'],
+                  nw['rgb_static'], nw['rgb_transient'], nw['uncertainty'])
+        out.update(nw)
       out.update(sdist=sd, tdist=td, weights=w, rgb_out=rgb_out, rgb_all=rgb_all, extras=extras, S=S, spec=spec, glo=glo)
       levels.append(out)
       sdist, weights = sd, w
@@ -365,7 +430,7 @@ class Engine:
     slab = self.ws.get(f'tn_slab/{torch.cuda.current_stream().cuda_stream}', (max(nbytes // 4, 1),))
     _lib.call('hugs_gemm_tn', self.dt, M, Kc, Nn, ns, X, ldx, G, ldg, dW, db, slab)
 
-  def backward_level(self, theta, grad, lv, rays, N, d_rgb_out, d_w_extra):
+  def backward_level(self, theta, grad, lv, rays, N, d_rgb_out, d_w_extra, nerfw=None):
     """Backward of one level: compositing -> heads -> trunk.  Writes (=, not +=) the level's MLP gradients
     into `grad` (flat, same layout as theta); GLO embedding rows are scatter-added (caller zeroes them)."""
     spec, S, lay, ws, dt = lv['spec'], lv['S'], self.layout, self.ws, self.dt
@@ -377,6 +442,12 @@ class Engine:
     d_rgb_s = ws.get(tag + '/d_rgb_s', (M, 3)) if lv['rgb'] is not None else None
     _lib.call('hugs_composite_bwd', N, S, lv['density'], lv['rgb'], lv['tdist'], rays['directions'],
               int(self.model.opaque_background), self.model.bg_intensity, d_rgb_out, d_w_extra, d_density, d_rgb_s)
+    if nerfw is not None:
+      # the loss saw rgb_combined and beta: their gradients reach sigma_s (added), c_s, sigma_t, c_t, u
+      d_dt, d_ct, d_u = ws.get(tag + '/d_dens_t', (M,)), ws.get(tag + '/d_rgb_t', (M, 3)), ws.get(tag + '/d_unc', (M,))
+      _lib.call('hugs_dual_composite_bwd', N, S, lv['density'], lv['dens_t'], lv['rgb'], lv['rgb_t'], lv['unc'], lv['tdist'],
+                rays['directions'], int(self.model.opaque_background), self.model.bg_intensity, nerfw['d_rgb_combined'],
+                nerfw['d_beta'], nerfw['dens_t_const'], d_density, d_rgb_s, d_dt, d_ct, d_u)
     acts = lv['acts']
     Ylast = acts[-1]
     ld = spec.layers[spec.net_depth]
@@ -405,10 +476,17 @@ class Engine:
                 rays.get('embed_idx'), d_rb, gWv[Bw:], demb)
       # dWv[:Bw] = bott^T Gv ; db_v = colsum(Gv)
       self._tn(M, Bw, H, lv['bott'], Bw, Gv, H, gWv[:Bw], gview((spec.name, lvw['name'], 'bias')))
-      # dBott = Gv Wv[:Bw]^T
       dB = ws.get(tag + '/dBott', (M, Bw), self.tdt)
-      _lib.call('hugs_gemm_nt', dt, M, Bw, H, 0, Gv, H, None, 0, self.wn[(spec.name, lvw['name'], 'kernel')], H, None, None,
-                1, 0, 0, None, 0, None, None, dB, Bw)
+      if nerfw is not None:
+        G0t = self._transient_backward(theta, grad, lv, rays, N, d_dt, d_ct, d_u)
+        Ht = spec.net_width_transient
+        # dBott = Gv Wv[:Bw]^T + G0t Wt0[:Bw]^T: one GEMM over the two K segments
+        _lib.call('hugs_gemm_nt', dt, M, Bw, H, Ht, Gv, H, G0t, Ht, self.wcat, H + Ht, None, None, 1, 0, 0, None, 0, None,
+                  None, dB, Bw)
+      else:
+        # dBott = Gv Wv[:Bw]^T
+        _lib.call('hugs_gemm_nt', dt, M, Bw, H, 0, Gv, H, None, 0, self.wn[(spec.name, lvw['name'], 'kernel')], H, None,
+                  None, 1, 0, 0, None, 0, None, None, dB, Bw)
       self._tn(M, W, Bw, Ylast, W, dB, Bw, gview((spec.name, lb['name'], 'kernel')), gview((spec.name, lb['name'], 'bias')))
       # G_last = (dBott Wb^T + d_raw (x) w_d) * (Ylast > 0)
       _lib.call('hugs_gemm_nt', dt, M, W, Bw, 0, dB, Bw, None, 0, self.wn[(spec.name, lb['name'], 'kernel')], Bw, None, None,
@@ -455,6 +533,45 @@ class Engine:
         G, gi = ring[nxt], nxt
     for e in tn_done.values():
       main.wait_event(e)
+
+  def _transient_backward(self, theta, grad, lv, rays, N, d_dt, d_ct, d_u):
+    """Backward of the NeRF-W transient branch (heads -> trunk -> per-ray tra_vec part).  Returns G at the first
+    transient layer's pre-activation [M, Ht]; writes the branch's weight gradients (=) and scatter-adds into
+    TransientEmbed_0."""
+    spec, S, lay, ws, dt = lv['spec'], lv['S'], self.layout, self.ws, self.dt
+    M, Ht, dtn, t0, Bw = N * S, spec.net_width_transient, spec.net_depth_transient, spec.t0, spec.bottleneck_width
+    gview = lambda p, padded=False: lay.view(grad, p, padded)
+    tacts = lv['tacts']
+    x3 = tacts[-1]
+    ld_, lr_, lu_ = spec.layers[t0 + dtn:t0 + dtn + 3]
+    G = ws.get('tbwd/Ga', (M, Ht), self.tdt)
+    other = ws.get('tbwd/Gb', (M, Ht), self.tdt)
+    rws = ws.get('rgb_ws', (max(_lib.lib().cdll.hugs_rgb_bwd_ws_bytes() // 4, 1),))
+    _lib.call('hugs_rgb_bwd', dt, M, Ht, x3, Ht, lay.view(theta, (spec.name, lr_['name'], 'kernel')), lv['rgb_t'], d_ct,
+              spec.rgb_padding, G, Ht, gview((spec.name, lr_['name'], 'kernel')), gview((spec.name, lr_['name'], 'bias')), rws)
+    dws = ws.get('dens_ws_t', (max(_lib.lib().cdll.hugs_density_bwd_ws_bytes(Ht) // 4, 1),))
+    d_raw_t, d_raw_u = ws.get('tbwd/d_raw_t', (M,)), ws.get('tbwd/d_raw_u', (M,))
+    _lib.call('hugs_density_bwd', dt, M, Ht, x3, Ht, d_dt, lv['raw_t'], spec.density_bias, d_raw_t,
+              gview((spec.name, ld_['name'], 'kernel')).reshape(-1), gview((spec.name, ld_['name'], 'bias')), dws)
+    _lib.call('hugs_density_bwd', dt, M, Ht, x3, Ht, d_u, lv['raw_u'], 0.0, d_raw_u,
+              gview((spec.name, lu_['name'], 'kernel')).reshape(-1), gview((spec.name, lu_['name'], 'bias')), dws)
+    _lib.call('hugs_rank1_add2_mask', dt, M, Ht, d_raw_t, lay.view(theta, (spec.name, ld_['name'], 'kernel')).reshape(-1),
+              d_raw_u, lay.view(theta, (spec.name, lu_['name'], 'kernel')).reshape(-1), x3, Ht, G, Ht)
+    for i in range(dtn - 1, 0, -1):
+      l = spec.layers[t0 + i]
+      path = (spec.name, l['name'], 'kernel')
+      self._tn(M, Ht, Ht, tacts[i - 1], Ht, G, Ht, gview(path), gview((spec.name, l['name'], 'bias')))
+      _lib.call('hugs_gemm_nt', dt, M, Ht, Ht, 0, G, Ht, None, 0, self.wn[path], Ht, None, None, 1, 0, 0, tacts[i - 1], Ht,
+                None, None, other, Ht)
+      G, other = other, G
+    lt = spec.layers[t0]
+    gWt0 = gview((spec.name, lt['name'], 'kernel'))
+    Wt0 = lay.view(theta, (spec.name, lt['name'], 'kernel'))
+    d_rb = ws.get('tbwd/d_rb', (N, Ht))
+    _lib.call('hugs_raybias_bwd', dt, N, S, Ht, 0, spec.num_tra, G, Ht, None, lv['tra'], Wt0[Bw:], rays.get('embed_idx'), d_rb,
+              gWt0[Bw:], gview(('TransientEmbed_0', 'embedding')))
+    self._tn(M, Bw, Ht, lv['bott'], Bw, G, Ht, gWt0[:Bw], gview((spec.name, lt['name'], 'bias')))
+    return G
 
   # ---- HA-NeRF ImplicitMask (per ray) --------------------------------------------------------------
   def mask_forward(self, theta, rays, N, zero_tra=False):

@@ -38,8 +38,6 @@ class Model:
       assert self.num_transient_features == 0
     elif tt in ['nerfw', 'hanerf']:
       assert self.num_transient_features > 0
-      if tt == 'nerfw':
-        raise NotImplementedError("transient_type 'nerfw': the NeRF-W branch is not built (SURVEY 8a.28)")
     else:
       raise ValueError()
     if self.ray_shape not in ('cone', 'cylinder'):
@@ -53,7 +51,9 @@ class Model:
     self.raydist = None if rd is None else {'jnp.reciprocal': 'reciprocal'}.get(getattr(rd, 'name', rd), getattr(rd, 'name', rd))
     if self.raydist not in (None, 'reciprocal'):
       raise NotImplementedError(f'raydist_fn {rd!r}: only None and @jnp.reciprocal are built')
-    self.nerf_spec = _engine.MLPSpec('NerfMLP_0', False, self.num_glo_features, **configs.bindings('NerfMLP'))
+    # models.py:104-105: NerfMLP(disable_transient=(transient_type != 'nerfw')), PropMLP(disable_transient=True)
+    self.nerf_spec = _engine.MLPSpec('NerfMLP_0', False, self.num_glo_features,
+                                     self.num_transient_features if tt == 'nerfw' else 0, **configs.bindings('NerfMLP'))
     self.prop_spec = _engine.MLPSpec('PropMLP_0', True, self.num_glo_features, **configs.bindings('PropMLP'))
     self.specs = [self.nerf_spec, self.prop_spec]
     self.mask_spec = None
@@ -131,7 +131,7 @@ class Model:
                         generator=rng, device=flat.device) for l in range(self.num_levels)]
     if refresh_weights:
       eng.refresh_weights(flat)
-    levels = eng.forward(flat, r, float(train_frac), u01, compute_extras, zero_glo)
+    levels = eng.forward(flat, r, float(train_frac), u01, compute_extras, zero_glo, zero_tra)
     implicit_mask = None
     if self.mask_spec is not None:
       implicit_mask = eng.mask_forward(flat, r, N, zero_tra)['mask'].clone().reshape(lead + (1,))
@@ -151,9 +151,17 @@ class Model:
         rend['ray_sdist'] = lv['sdist'][:n].clone()
         rend['ray_weights'] = lv['weights'][:n].clone()
         rend['ray_rgbs'] = rgb_s[:n].clone()
+      hist = dict(density=lv['density'].clone().reshape(lead + (S,)), rgb=rgb_s.clone().reshape(lead + (S, 3)),
+                  sdist=lv['sdist'].clone().reshape(lead + (S + 1,)), weights=lv['weights'].clone().reshape(lead + (S,)))
+      if lv.get('dens_t') is not None:       # NeRF-W (models.py:285-307, 545-548)
+        for k in ('rgb_combined', 'rgb_static', 'rgb_transient'):
+          rend[k] = lv[k].clone().reshape(lead + (3,))
+        rend['uncertainty'] = lv['uncertainty'].clone().reshape(lead + (1,))
+        hist.update(density_transient=lv['dens_t'].clone().reshape(lead + (S,)),
+                    rgb_transient=lv['rgb_t'].clone().reshape(lead + (S, 3)),
+                    uncertainty=lv['unc'].clone().reshape(lead + (S, 1)))
       renderings.append(rend)
-      history.append(dict(density=lv['density'].clone().reshape(lead + (S,)), rgb=rgb_s.clone().reshape(lead + (S, 3)),
-                          sdist=lv['sdist'].clone().reshape(lead + (S + 1,)), weights=lv['weights'].clone().reshape(lead + (S,))))
+      history.append(hist)
     if implicit_mask is not None:
       renderings[-1]['implicit_mask'] = implicit_mask        # models.py:327-328
     if compute_extras:

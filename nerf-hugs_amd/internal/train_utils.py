@@ -121,7 +121,7 @@ def create_train_step(model, config, is_finetune=False):
   layout = model.layout
   L = model.num_levels
   tt = None if is_finetune else config.transient_type
-  if tt not in (None, 'withmask', 'robustnerf', 'hanerf'):
+  if tt not in (None, 'withmask', 'robustnerf', 'hanerf', 'nerfw'):
     raise ValueError()
   if tt == 'robustnerf':
     assert config.robustnerf_inner_patch_size <= config.patch_size, \
@@ -195,6 +195,20 @@ def create_train_step(model, config, is_finetune=False):
                 config.charb_padding, cache['coef'], msm, d_pred, d_mask, hst)
       tail[0:2 * L].copy_(hst[:2 * L])
       tail[40:42].copy_(hst[2 * L:])
+    elif tt == 'nerfw':
+      fin_ = levels[-1]
+      Mf = N * fin_['S']
+      pred_nw = ws.get('pred_nerfw', (L, N, 3))
+      pred_nw.copy_(pred)
+      pred_nw[L - 1].copy_(fin_['rgb_combined'])       # the final level is scored on rgb_combined (train_utils.py:158-159)
+      nw = dict(d_rgb_combined=d_pred[L - 1], d_beta=ws.get('d_beta', (N,)),
+                dens_t_const=config.nerfw_density_loss_mult / Mf)
+      nst = ws.get('nerfw_stats', (2 * L + 1,))
+      _lib.call('hugs_nerfw_loss', N, L, pred_nw, gt, fin_['uncertainty'], int(config.data_loss_type == 'charb'),
+                config.charb_padding, cache['coef'], config.nerfw_beta_loss_mult, d_pred, nw['d_beta'], nst)
+      tail[0:2 * L].copy_(nst[:2 * L])
+      tail[42:43].copy_(nst[2 * L:])
+      _lib.call('hugs_sum', Mf, fin_['dens_t'], 1.0 / Mf, tail[43:44])
     else:
       _lib.call('hugs_data_loss', N, L, pred, gt, lm, mode, config.withmask_transient_weight,
                 int(config.data_loss_type == 'charb'), config.charb_padding, cache['coef'], d_pred, tail[0:2 * L])
@@ -217,6 +231,11 @@ def create_train_step(model, config, is_finetune=False):
       layout.view(grad, ('GloEmbed_0', 'embedding')).zero_()
     if model.num_transient_features > 0:
       layout.view(grad, ('TransientEmbed_0', 'embedding')).zero_()
+    if model.nerf_spec.num_tra > 0 and tt != 'nerfw':       # finetune stage of a nerfw model: the branch is not in the loss
+      sp = model.nerf_spec
+      lo = layout.by_path[('NerfMLP_0', sp.layers[sp.t0]['name'], 'kernel')]['off']
+      last = layout.by_path[('NerfMLP_0', sp.layers[-1]['name'], 'bias')]
+      grad[lo:last['off'] + int(np.prod(last['pshape']))].zero_()
     if mask_st is not None:
       eng.mask_backward(state.flat, grad, mask_st, rays, d_mask)
     elif model.mask_spec is not None:            # finetune stage of a hanerf model: the mask is not in the loss
@@ -243,7 +262,10 @@ def create_train_step(model, config, is_finetune=False):
       tgt = grad
       if is_prop and prop_done:
         tgt = ws.get('grad_tmp', (layout.size + STAT_TAIL,))
-      eng.backward_level(state.flat, tgt, levels[l], rays, N, d_pred[l] if coef != 0 else None, d_w[l])
+      if tt == 'nerfw' and not is_prop:
+        eng.backward_level(state.flat, tgt, levels[l], rays, N, None, d_w[l], nerfw=nw)
+      else:
+        eng.backward_level(state.flat, tgt, levels[l], rays, N, d_pred[l] if coef != 0 else None, d_w[l])
       if is_prop and prop_done:
         _lib.call('hugs_add_inplace', prop_hi - prop_lo, tgt[prop_lo:prop_hi], grad[prop_lo:prop_hi])
       if is_prop:
@@ -297,6 +319,9 @@ def create_train_step(model, config, is_finetune=False):
         losses['interlevel'] = float(config.interlevel_loss_mult * tl[8:8 + L - 1].sum())
       if not is_finetune and config.distortion_loss_mult > 0:
         losses['distortion'] = float(config.distortion_loss_mult * tl[12])
+      if tt == 'nerfw':
+        losses['beta'] = float(config.nerfw_beta_loss_mult * tl[42] + config.nerfw_beta_loss_bias)
+        losses['density'] = float(config.nerfw_density_loss_mult * tl[43])
       if tt == 'hanerf':
         losses['mask_size'] = float(msm_now * tl[40])
         stats['implicit_mask'] = T([tl[41]])

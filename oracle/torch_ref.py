@@ -343,6 +343,8 @@ class ModelCfg:
     self.interlevel_loss_mult = 1.0
     self.distortion_loss_mult = 0.01
     self.transient_type = None
+    self.transient_depth, self.transient_width, self.beta_min = 4, 128, 0.03   # NeRF-W (models.py:71,367-368)
+    self.nerfw_beta_loss_mult, self.nerfw_beta_loss_bias, self.nerfw_density_loss_mult = 1.0, 3.0, 0.01
     self.hanerf_mask_size_loss_mult_min = 6.0e-3
     self.hanerf_mask_size_loss_mult_max = 5.0e-2
     self.hanerf_mask_size_loss_mult_k = 1.0e-3
@@ -389,6 +391,12 @@ def mlp_layer_dims(cfg, which):
     kv = cfg.bottleneck_width + 3 + 3 * 2 * cfg.deg_view + (cfg.num_glo_features if which == 'nerf' else 0)
     dims.append((kv, cfg.width_viewdirs))
     dims.append((cfg.width_viewdirs, 3))
+    if which == 'nerf' and cfg.transient_type == 'nerfw':        # models.py:521-539, created after the rgb head
+      k = cfg.bottleneck_width + cfg.num_transient_features
+      for _ in range(cfg.transient_depth):
+        dims.append((k, cfg.transient_width))
+        k = cfg.transient_width
+      dims += [(k, 1), (k, 3), (k, 1)]                            # density_transient, rgb_transient, uncertainty
   return dims
 
 
@@ -433,7 +441,7 @@ def implicit_mask_forward(cfg, mod, pix_coords, tra_vec, taps=None):
   return torch.sigmoid(x @ L['kernel'] + L['bias'])
 
 
-def mlp_forward(cfg, mod, which, feats, viewdirs, glo_vec, taps=None):
+def mlp_forward(cfg, mod, which, feats, viewdirs, glo_vec, taps=None, tra_vec=None):
   """models.py:406-550 (no transient branch). feats [...,S,504].  taps: optional list that receives the
   relu pre-activations (tests use it to find samples sitting on a ReLU kink)."""
   depth = cfg.nerf_depth if which == 'nerf' else cfg.prop_depth
@@ -464,7 +472,24 @@ def mlp_forward(cfg, mod, which, feats, viewdirs, glo_vec, taps=None):
   x = torch.relu(pre)
   L = mod[f'Dense_{depth + 3}']
   rgb = torch.sigmoid(x @ L['kernel'] + L['bias'])
-  return density, rgb * (1 + 2 * cfg.rgb_padding) - cfg.rgb_padding
+  rgb = rgb * (1 + 2 * cfg.rgb_padding) - cfg.rgb_padding
+  if tra_vec is None or which != 'nerf' or cfg.transient_type != 'nerfw':
+    return density, rgb
+  # models.py:521-539 (skip_layer_transient = 4 never triggers for depth 4)
+  x = torch.cat([bott, tra_vec[..., None, :].expand(bott.shape[:-1] + (-1,))], -1)
+  j = depth + 4
+  for i in range(cfg.transient_depth):
+    pre = x @ mod[f'Dense_{j + i}']['kernel'] + mod[f'Dense_{j + i}']['bias']
+    if taps is not None:
+      taps.append(pre.detach())
+    x = torch.relu(pre)
+  j += cfg.transient_depth
+  sp = lambda z: torch.logaddexp(z, torch.zeros_like(z))
+  dens_t = sp((x @ mod[f'Dense_{j}']['kernel'] + mod[f'Dense_{j}']['bias'])[..., 0] + cfg.density_bias)
+  rgb_t = torch.sigmoid(x @ mod[f'Dense_{j + 1}']['kernel'] + mod[f'Dense_{j + 1}']['bias'])
+  rgb_t = rgb_t * (1 + 2 * cfg.rgb_padding) - cfg.rgb_padding
+  unc = sp(x @ mod[f'Dense_{j + 2}']['kernel'] + mod[f'Dense_{j + 2}']['bias'])
+  return density, rgb, dict(density_transient=dens_t, rgb_transient=rgb_t, uncertainty=unc)
 
 
 def sample_u_base(num_samples, randomized):
@@ -524,14 +549,31 @@ def model_forward(cfg, variables, rays, train_frac, u01, compute_extras, zero_gl
       feats = override_feats[lvl].to(dt)
     which = 'prop' if is_prop else 'nerf'
     lvl_taps = None if taps is None else []
-    density, rgb = mlp_forward(cfg, P['PropMLP_0' if is_prop else 'NerfMLP_0'], which, feats,
-                               rays['viewdirs'], None if is_prop else glo, lvl_taps)
+    tra = None
+    if not is_prop and cfg.transient_type == 'nerfw':
+      tra = (torch.zeros(N, cfg.num_transient_features, dtype=dt) if zero_tra else
+             P['TransientEmbed_0']['embedding'][rays['embed_idx'][:, 0].long()])
+    res = mlp_forward(cfg, P['PropMLP_0' if is_prop else 'NerfMLP_0'], which, feats,
+                      rays['viewdirs'], None if is_prop else glo, lvl_taps, tra)
+    density, rgb = res[0], res[1]
     if taps is not None:
       taps.append(lvl_taps)
     weights = compute_alpha_weights(density, tdist, rays['directions'], cfg.opaque_background)[0]
     rend = volumetric_rendering(rgb, weights, tdist, cfg.bg_intensity, far, compute_extras)
+    hist = dict(density=density, rgb=rgb, sdist=sdist, tdist=tdist, weights=weights)
+    if len(res) == 3:                      # models.py:285-307
+      tr = res[2]
+      w1, w2, wc = compute_dual_alpha_weights(density, tr['density_transient'], tdist, rays['directions'],
+                                              cfg.opaque_background)
+      bgw = _MaxZero.apply(1 - wc.sum(-1))[..., None]
+      rend['rgb_static'] = (w1[..., None] * rgb).sum(-2)
+      rend['rgb_transient'] = (w2[..., None] * tr['rgb_transient']).sum(-2)
+      rend['rgb_combined'] = rend['rgb_static'] + rend['rgb_transient'] + bgw * cfg.bg_intensity
+      wt = compute_alpha_weights(tr['density_transient'], tdist, rays['directions'], cfg.opaque_background)[0]
+      rend['uncertainty'] = (wt[..., None] * tr['uncertainty']).sum(-2) + cfg.beta_min
+      hist.update(tr)
     renderings.append(rend)
-    history.append(dict(density=density, rgb=rgb, sdist=sdist, tdist=tdist, weights=weights))
+    history.append(hist)
   if cfg.transient_type == 'hanerf':     # models.py:120-129,327-328
     tra = (torch.zeros(N, cfg.num_transient_features, dtype=dt) if zero_tra else
            P['TransientEmbed_0']['embedding'][rays['embed_idx'][:, 0].long()])
@@ -563,6 +605,35 @@ def compute_data_loss(cfg, gt_rgb, rays, renderings, use_static_mask):
   losses = torch.stack(losses)
   return cfg.data_coarse_loss_mult * losses[:-1].sum() + cfg.data_loss_mult * losses[-1], \
       {'mses': torch.stack(mses)}
+
+
+def compute_dual_alpha_weights(density1, density2, tdist, dirs, opaque_background=False):
+  """render.py:154-182."""
+  delta = (tdist[..., 1:] - tdist[..., :-1]) * torch.linalg.norm(dirs[..., None, :], dim=-1)
+  d1, d2, dd = density1 * delta, density2 * delta, (density1 + density2) * delta
+  if opaque_background:
+    inf = torch.full_like(dd[..., -1:], float('inf'))
+    d1, d2, dd = [torch.cat([z[..., :-1], inf], -1) for z in (d1, d2, dd)]
+  trans = torch.exp(-torch.cat([torch.zeros_like(dd[..., :1]), torch.cumsum(dd[..., :-1], -1)], -1))
+  return (1 - torch.exp(-d1)) * trans, (1 - torch.exp(-d2)) * trans, (1 - torch.exp(-dd)) * trans
+
+
+def compute_nerfw_loss(cfg, gt_rgb, renderings, history):
+  """train_utils.py:150-183."""
+  beta = renderings[-1]['uncertainty']
+  losses, mses, out = [], [], {}
+  for i, r in enumerate(renderings):
+    resid_sq = (r['rgb_combined' if 'rgb_combined' in r else 'rgb'] - gt_rgb)**2
+    dl = resid_sq if cfg.data_loss_type == 'mse' else torch.sqrt(resid_sq + cfg.charb_padding**2)
+    if i == len(renderings) - 1:
+      out['beta'] = cfg.nerfw_beta_loss_mult * torch.log(beta).mean() + cfg.nerfw_beta_loss_bias
+      dl = dl / (2 * beta**2)
+      out['density'] = cfg.nerfw_density_loss_mult * history[-1]['density_transient'].mean()
+    losses.append(dl.mean())
+    mses.append(resid_sq.mean())
+  losses = torch.stack(losses)
+  out['data'] = cfg.data_coarse_loss_mult * losses[:-1].sum() + cfg.data_loss_mult * losses[-1]
+  return out, {'mses': torch.stack(mses)}
 
 
 def compute_hanerf_loss(cfg, gt_rgb, renderings, train_frac):
@@ -682,6 +753,9 @@ def loss_and_grad(cfg, variables, rays, gt_rgb, train_frac, u01, inlier_threshol
     losses['data'], st = compute_robustnerf_loss(cfg, gt_rgb.reshape(-1, ps, ps, 3), rs, inlier_thresholds)
   elif cfg.transient_type == 'hanerf':
     ls, st = compute_hanerf_loss(cfg, gt_rgb, renderings, train_frac)
+    losses.update(ls)
+  elif cfg.transient_type == 'nerfw':
+    ls, st = compute_nerfw_loss(cfg, gt_rgb, renderings, history)
     losses.update(ls)
   else:
     raise ValueError()

@@ -55,6 +55,10 @@ def make_pair(gin_lines, seed=3, compute_dtype='fp32'):
       hanerf_mask_size_loss_mult_min=config.hanerf_mask_size_loss_mult_min,
       hanerf_mask_size_loss_mult_max=config.hanerf_mask_size_loss_mult_max,
       hanerf_mask_size_loss_mult_k=config.hanerf_mask_size_loss_mult_k)
+  cfg.transient_depth, cfg.transient_width, cfg.beta_min = (model.nerf_spec.net_depth_transient,
+                                                            model.nerf_spec.net_width_transient, model.beta_min)
+  cfg.nerfw_beta_loss_mult, cfg.nerfw_beta_loss_bias, cfg.nerfw_density_loss_mult = (
+      config.nerfw_beta_loss_mult, config.nerfw_beta_loss_bias, config.nerfw_density_loss_mult)
   if model.mask_spec is not None:
     cfg.mask_depth, cfg.mask_width, cfg.mask_deg_coord = (model.mask_spec.net_depth, model.mask_spec.net_width,
                                                            model.mask_spec.deg_coord)

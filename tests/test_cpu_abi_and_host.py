@@ -113,8 +113,13 @@ def test_errors_like_reference():
     models.Model(configs.make_config(), ray_shape='sphere')           # render.py:124
   with pytest.raises(ValueError):
     models.Model(configs.make_config(transient_type='bogus'))         # models.py:96-101
+  with pytest.raises(AssertionError):                                  # models.py:98-99
+    models.Model(configs.make_config(transient_type='nerfw'), num_transient_features=0)
+  m = models.Model(configs.make_config(transient_type='nerfw'), num_transient_features=16)
+  assert [l['kind'] for l in m.nerf_spec.layers[-7:]] == ['tview', 'ttrunk', 'ttrunk', 'ttrunk', 'tdensity', 'trgb', 'tuncert']
+  assert m.prop_spec.num_tra == 0 and 'TransientEmbed_0' in m.layout.modules
   with pytest.raises(NotImplementedError):
-    models.Model(configs.make_config(transient_type='nerfw'), num_transient_features=4)
+    models.Model(configs.make_config(), bg_intensity_range=(0., 1.))
 
 
 def test_host_helpers_match_oracle():
@@ -173,7 +178,7 @@ def test_checkpoint_roundtrip(tmp_path):
 
 def test_every_reference_gin_file_parses():
   """All 19 gin files of the reference load through the gin-subset reader and build a Model (or raise the
-  documented NotImplementedError for the NeRF-W / HA-NeRF variants).  Runs only where the reference checkout
+  documented NotImplementedError).  Runs only where the reference checkout
   exists (build container); the GPU box has no /root/reference."""
   import glob
   from nerf_hugs_amd.internal import configs, models
@@ -192,4 +197,24 @@ def test_every_reference_gin_file_parses():
       refused.append(os.path.basename(f))
   configs.clear_config()
   # debug.gin asks for a 64-wide PropMLP: MLP widths must be multiples of the 128-column MFMA tile
-  assert built >= 16 and all(('nerfw' in r or r == 'debug.gin') for r in refused), refused
+  assert built >= 16 and refused == ['debug.gin'], refused
+
+
+def test_ctypes_prototypes_match_the_header():
+  """Every signature string in _lib._PROTOS has the argument kinds include/hugs.h declares (i/f/q/p + stream)."""
+  import re
+  from nerf_hugs_amd import _lib
+  h = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'hugs.h')).read()
+  h = re.sub(r'/\*.*?\*/', '', h, flags=re.S)
+  checked = 0
+  for name, proto in _lib._PROTOS.items():
+    m = re.search(r'\b(?:int|long long)\s+' + name + r'\s*\((.*?)\)\s*;', h, re.S)
+    assert m, f'{name} is bound but not declared in include/hugs.h'
+    args = [a.strip() for a in m.group(1).split(',') if a.strip() and a.strip() != 'void']
+    sig = ''.join('p' if '*' in a else 'f' if a.startswith('float') else 'q' if a.startswith('long long') else 'i'
+                  for a in args)
+    if proto and proto[-1] == 's':
+      sig = sig[:-1] + 's'
+    assert sig == proto, f'{name}: header says {sig}, _lib says {proto}'
+    checked += 1
+  assert checked >= 40

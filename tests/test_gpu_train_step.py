@@ -216,3 +216,42 @@ def test_hanerf_bf16_step_at_the_shipped_transient_width():
     og = ograds[name].double().flatten()
     cos = float((g * og).sum() / (g.norm() * og.norm()).clamp(min=1e-30))
     assert cos > 0.97 and 0.9 < float(g.norm() / og.norm()) < 1.1, f'{name}: cosine {cos:.4f}'
+
+
+NERFW = SMALL + ["Config.transient_type = 'nerfw'", "Model.num_transient_features = 16", "Model.num_glo_features = 4",
+                 "NerfMLP.bottleneck_width = 128"]
+
+
+def test_train_step_nerfw():
+  """SURVEY 8 row a28, NeRF-W: per-sample transient MLP (bottleneck | tra_vec -> 4 x 128 -> density_t, rgb_t,
+  uncertainty), static + transient compositing, compute_nerfw_loss -- losses and every leaf gradient vs the oracle."""
+  _run_case(NERFW, n_patch=2)
+
+
+def test_train_step_nerfw_charb_contract_no_opaque():
+  _run_case([g for g in NERFW if 'opaque' not in g and 'mse' not in g] +
+            ["Config.data_loss_type = 'charb'", "NerfMLP.warp_fn = @coord.contract", "PropMLP.warp_fn = @coord.contract",
+             "Model.raydist_fn = @jnp.reciprocal"], n_patch=2, near=0.2, far=1e6)
+
+
+def test_nerfw_renderings_and_zero_tra():
+  from tests import hugs_testlib as H
+  from oracle import torch_ref as R
+  config, model, state, render_fn, train_step, cfg, oparams = H.make_pair(NERFW)
+  names = [l['name'] + ':' + l['kind'] for l in model.nerf_spec.layers]
+  assert names[12:] == ['Dense_12:tview', 'Dense_13:ttrunk', 'Dense_14:ttrunk', 'Dense_15:ttrunk', 'Dense_16:tdensity',
+                        'Dense_17:trgb', 'Dense_18:tuncert']
+  assert model.layout.by_path[('NerfMLP_0', 'Dense_12', 'kernel')]['shape'] == (128 + 16, 128)
+  batch = H.synth_rays(2, 8, 2)
+  for zero_tra in (False, True):
+    rend, hist = model.apply(state.flat, None, batch.rays, 0.5, False, zero_tra=zero_tra)
+    orend, ohist = R.model_forward(cfg, oparams, H.oracle_rays(batch), 0.5, None, False, zero_tra=zero_tra)
+    for k in ('rgb', 'rgb_combined', 'rgb_static', 'rgb_transient', 'uncertainty'):
+      a = rend[-1][k].cpu().reshape(128, -1); b = orend[-1][k].detach().reshape(128, -1)
+      assert float((a - b).abs().max()) < 1e-4 * max(1., float(b.abs().max())), (k, zero_tra)
+    assert 'rgb_combined' not in rend[0] and rend[-1]['uncertainty'].shape == (2, 8, 8, 1)
+    assert float(rend[-1]['uncertainty'].min()) >= model.beta_min
+    for k in ('density_transient', 'rgb_transient', 'uncertainty'):
+      a = hist[-1][k].cpu().reshape(128, -1); b = ohist[-1][k].detach().reshape(128, -1)
+      assert float((a - b).abs().max()) < 1e-3 * max(1., float(b.abs().max())), k
+    assert hist[-1]['uncertainty'].shape == (2, 8, 8, 128, 1)
