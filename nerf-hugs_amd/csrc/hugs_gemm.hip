@@ -14,6 +14,7 @@
 // band of row tiles (activations stream once through that XCD's L2, weights stay L2 resident).
 // fp32 path (parity mode): same tiling on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
 #include "hugs_common.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
@@ -537,15 +538,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(int Mrows, int Kc, int 
 // bf16 TN, large tile: 256 (Kc) x 256 (N) output tile per workgroup, 8 waves (2 over N x 4 over Kc, each
 // 128 x 64), reduction rows walked 32 at a time through the same 4-slot ring / counted-vmcnt / register
 // double-buffer pipeline as the NT kernel.  Both operands are read with ds_read_b64_tr_b16 from row-major
-// [32][256] stages (32-byte granules XOR-swizzled by row&7).  The bias gradient (column sums of G) costs two
+// [32][256] stages stored as 1 KiB row pairs at a 1056-byte pitch (bank spread by padding, not by an address
+// swizzle: fragment reads are base + immediate, which frees ~25 VGPRs and the XOR arithmetic).  The bias gradient (column sums of G) costs two
 // extra MFMAs per stage against an all-ones fragment instead of a scalar LDS pass.
 // ------------------------------------------------------------------------------------------------
+#ifndef HUGS_TN_SCHED
+#define HUGS_TN_SCHED 0
+#endif
 __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, int N, int nsplit,
                                                               const uint16_t* __restrict__ X, int ldx,
                                                               const uint16_t* __restrict__ G, int ldg,
                                                               float* __restrict__ slab, int lds_out,
                                                               float* __restrict__ colsum_slab) {
-  constexpr int NSLOT = 4, STAGE = 32768, XB = 16384;
+  // stage layout: per operand 16 row PAIRS of 1 KiB (rows 2p, 2p+1 as the LDS-DMA writes them) at a 1056-byte
+  // pitch: the 8 rows one 32-lane group of a transpose read touches have distinct p, so they land 8 banks apart
+  // (1056 B = 264 dwords = 8 mod 64) with NO address swizzle: every fragment read is base + immediate.
+  constexpr int NSLOT = 4, PAIR = 1056, XB = 16 * PAIR, STAGE = 2 * XB;
   __shared__ __attribute__((aligned(16))) unsigned char lds[128 * 1040 > NSLOT * STAGE ? 128 * 1040 : NSLOT * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -565,10 +573,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
     unsigned char* lg = lx + XB;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      const int p = it * 512 + tid, row = p >> 5, pos = p & 31;
-      const int c = ((((pos >> 1) ^ (row & 7)) << 1) | (pos & 1)) * 8;
-      glds16(X + (size_t)(mrow0 + row) * ldx + c0 + c, lx + (it * 512 + wv * 64) * 16);
-      glds16(G + (size_t)(mrow0 + row) * ldg + n0 + c, lg + (it * 512 + wv * 64) * 16);
+      const int pair = it * 8 + wv, row = 2 * pair + (lane >> 5), c = (lane & 31) * 8;
+      glds16(X + (size_t)(mrow0 + row) * ldx + c0 + c, lx + pair * PAIR);
+      glds16(G + (size_t)(mrow0 + row) * ldg + n0 + c, lg + pair * PAIR);
     }
   };
 
@@ -587,37 +594,38 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
   auto load_frags = [&](Frags& f, int st) {
     const unsigned char* lx = lds + (st % NSLOT) * STAGE;
     const unsigned char* lg = lx + XB;
+    // reduction row of (lane group g, r = s>>2, read h): (g>>1)*16 + 2*((g&1)*4 + r) + h  (a bijection on the 32 rows)
+    const int lo = ((g >> 1) * 8 + (g & 1) * 4 + (s >> 2)) * PAIR + ((s & 3) << 3);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int row = h * 16 + g * 4 + (s >> 2);
-      const int sw = row & 7;
-      const int lo = row * 512 + ((s & 3) << 3);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int q = wn * 8 + i;
-        bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4_t __attribute__((address_space(3)))*)(lg + lo + ((q ^ sw) << 5)));
+        bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4_t __attribute__((address_space(3)))*)(lg + lo + h * 512 + ((wn * 8 + i) << 5)));
         f.ga[i][h * 4 + 0] = v[0]; f.ga[i][h * 4 + 1] = v[1]; f.ga[i][h * 4 + 2] = v[2]; f.ga[i][h * 4 + 3] = v[3];
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int q = wk * 4 + j;
-        bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4_t __attribute__((address_space(3)))*)(lx + lo + ((q ^ sw) << 5)));
+        bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4_t __attribute__((address_space(3)))*)(lx + lo + h * 512 + ((wk * 4 + j) << 5)));
         f.xb[j][h * 4 + 0] = v[0]; f.xb[j][h * 4 + 1] = v[1]; f.xb[j][h * 4 + 2] = v[2]; f.xb[j][h * 4 + 3] = v[3];
       }
     }
   };
-  auto mfmas = [&](const Frags& f) {
+  // The main loop is instantiated per bias-gradient role (WK = -1: none; 0..3: this wave's two G fragments), chosen
+  // by ONE wave-uniform switch outside the loop: a branch inside an iteration splits it into basic blocks and the
+  // scheduler can then no longer overlap the next stage's ds_reads with this stage's MFMAs across iterations.
+  Frags f0, f1;
+  auto run = [&](auto role) {
+    constexpr int WK = decltype(role)::value;
+    auto mfmas = [&](const Frags& f) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[i], f.xb[j], acc[i][j], 0, 0, 0);
-    if (do_colsum) {   // wave (wn, wk) owns the column sums of its N fragments 2wk, 2wk+1
-      if (wk == 0) { accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[0], ones, accb[0], 0, 0, 0); accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[1], ones, accb[1], 0, 0, 0); }
-      else if (wk == 1) { accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[2], ones, accb[0], 0, 0, 0); accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[3], ones, accb[1], 0, 0, 0); }
-      else if (wk == 2) { accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[4], ones, accb[0], 0, 0, 0); accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[5], ones, accb[1], 0, 0, 0); }
-      else { accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[6], ones, accb[0], 0, 0, 0); accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[7], ones, accb[1], 0, 0, 0); }
-    }
-  };
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[i], f.xb[j], acc[i][j], 0, 0, 0);
+      if constexpr (WK >= 0) {   // wave (wn, wk) owns the column sums of its N fragments 2wk, 2wk+1
+        accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[2 * WK], ones, accb[0], 0, 0, 0);
+        accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[2 * WK + 1], ones, accb[1], 0, 0, 0);
+      }
+    };
 #define GT_ITER(cur, nxt, st, VM)                                         \
   {                                                                       \
     asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");     \
@@ -626,23 +634,46 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
     if ((st) + NSLOT < ns) stage((st) + NSLOT);                           \
     load_frags(nxt, (st) + 1);                                            \
     mfmas(cur);                                                           \
+    if (HUGS_TN_SCHED == 1) {                                             \
+      _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                \
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                \
+      }                                                                   \
+    }                                                                     \
+    if (HUGS_TN_SCHED == 2) {                                             \
+      _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                \
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                \
+      }                                                                   \
+    }                                                                     \
+    if (HUGS_TN_SCHED == 3) {                                             \
+      _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                  \
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                \
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                \
+      }                                                                   \
+    }                                                                     \
   }
-  Frags f0, f1;
 #pragma unroll
-  for (int q = 0; q < NSLOT; ++q) stage(q);
-  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  load_frags(f0, 0);
-  int st = 0;
-  for (; st + 5 < ns; st += 2) { GT_ITER(f0, f1, st, 8) GT_ITER(f1, f0, st + 1, 8) }
-  GT_ITER(f0, f1, st, 8)
-  asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
-  load_frags(f0, st + 2); mfmas(f1);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
-  load_frags(f1, st + 3); mfmas(f0);
-  mfmas(f1);
+    for (int q = 0; q < NSLOT; ++q) stage(q);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    load_frags(f0, 0);
+    int st = 0;
+    for (; st + 5 < ns; st += 2) { GT_ITER(f0, f1, st, 8) GT_ITER(f1, f0, st + 1, 8) }
+    GT_ITER(f0, f1, st, 8)
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+    load_frags(f0, st + 2); mfmas(f1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+    load_frags(f1, st + 3); mfmas(f0);
+    mfmas(f1);
 #undef GT_ITER
+  };
+  if (!do_colsum) run(std::integral_constant<int, -1>{});
+  else if (wk == 0) run(std::integral_constant<int, 0>{});
+  else if (wk == 1) run(std::integral_constant<int, 1>{});
+  else if (wk == 2) run(std::integral_constant<int, 2>{});
+  else run(std::integral_constant<int, 3>{});
 
   // Epilogue: the fp32 tile leaves through LDS (the ring is free now) so that every wave instruction stores one
   // whole 1 KiB slab row instead of sixteen 64-byte runs.  Two passes of 128 Kc-rows (pitch 1040 B).

@@ -632,5 +632,8 @@ class Engine:
 
   def _side_stream(self):
     if getattr(self, '_side', None) is None:
-      self._side = torch.cuda.Stream(device=self.device)
+      import os
+      # HUGS_SINGLE_STREAM=1 (measurement hook): weight-gradient GEMMs stay on the compute stream
+      self._side = (torch.cuda.current_stream() if os.environ.get('HUGS_SINGLE_STREAM') == '1'
+                    else torch.cuda.Stream(device=self.device))
     return self._side
