@@ -228,6 +228,7 @@ def main():
       line["cpu_baseline"] = cpu_baseline(20200823)
     print(json.dumps(line))
   if world > 1:
+    dist.barrier()          # rank 0 measures the roofline / prints after the timed region: keep the group alive until then
     dist.destroy_process_group()
 
 
