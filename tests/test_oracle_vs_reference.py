@@ -222,3 +222,20 @@ def test_param_count_matches_published():
 def test_psnr_golden():
   # image.py:28-30
   assert abs(float(R.mse_to_psnr(torch.tensor(0.01))) - 20.0) < 1e-5
+
+
+def test_inner_outer_match_interval_loops():
+  """stepfun_test.py:697-737 restated (own random numbers): inner / outer measures against the O(n^2) definition --
+  outer sums the bins that touch [t0_i, t0_{i+1}], inner the bins that lie inside it -- and lossfun_outer(t,w,t,w)=0."""
+  rng = np.random.default_rng(0)
+  for _ in range(10):
+    d0, d1 = rng.integers(10, 20, 2)
+    t0 = np.sort(rng.uniform(size=d0 + 1))
+    t1 = np.sort(rng.uniform(size=d1 + 1))
+    w0 = np.exp(rng.normal(size=d0))
+    inner, outer = R.inner_outer(torch.tensor(t1), torch.tensor(t0), torch.tensor(w0))
+    ref_in = [sum(w0[j] for j in range(d0) if t0[j] >= t1[i] and t0[j + 1] < t1[i + 1]) for i in range(d1)]
+    ref_out = [sum(w0[j] for j in range(d0) if t0[j + 1] >= t1[i] and t0[j] <= t1[i + 1]) for i in range(d1)]
+    np.testing.assert_allclose(inner.numpy(), ref_in, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(outer.numpy(), ref_out, rtol=1e-5, atol=1e-5)
+    assert float(R.lossfun_outer(torch.tensor(t0), torch.tensor(w0), torch.tensor(t0), torch.tensor(w0)).max()) < 1e-10
