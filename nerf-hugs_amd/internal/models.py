@@ -129,37 +129,50 @@ class Model:
       shape = (N,) if self.single_jitter else None
       u01 = [torch.rand(shape if shape else (N, (self.num_prop_samples if l < self.num_levels - 1 else self.num_nerf_samples)),
                         generator=rng, device=flat.device) for l in range(self.num_levels)]
+    # Ragged chunks (the reference renders any ray count, e.g. the last chunk of an odd-sized image): the GEMM
+    # tiles need rays*samples to be a multiple of 128 on every level, so the batch is padded with copies of its
+    # last ray and the padding is cut off the outputs.
+    align = max(128 // math.gcd(128, S_) for S_ in (self.num_prop_samples, self.num_nerf_samples))
+    Np = max(align, (N + align - 1) // align * align)
+    if Np != N:
+      if N == 0:
+        raise ValueError('Model.apply needs at least one ray')
+      pad = lambda x: torch.cat([x, x[-1:].expand((Np - N,) + tuple(x.shape[1:]))]).contiguous()
+      r = {k: pad(v) for k, v in r.items()}
+      if u01 is not None:
+        padded = [pad(u) for u in u01]
+        u01 = stepfun.Jitter(padded) if isinstance(u01, stepfun.Jitter) else padded
+    take = lambda buf, *tail: buf.reshape((Np,) + tail)[:N].clone().reshape(lead + tail)
     if refresh_weights:
       eng.refresh_weights(flat)
     levels = eng.forward(flat, r, float(train_frac), u01, compute_extras, zero_glo, zero_tra)
     implicit_mask = None
     if self.mask_spec is not None:
-      implicit_mask = eng.mask_forward(flat, r, N, zero_tra)['mask'].clone().reshape(lead + (1,))
+      implicit_mask = eng.mask_forward(flat, r, Np, zero_tra)['mask'][:N].clone().reshape(lead + (1,))
     renderings, history = [], []
-    n = 0 if self.config is None else self.config.vis_num_rays
+    n = 0 if self.config is None else min(self.config.vis_num_rays, N)
     for lv in levels:
       S = lv['S']
-      rend = {'rgb': lv['rgb_out'].clone().reshape(lead + (3,))}
-      rgb_s = lv['rgb'].reshape(N, S, 3) if lv['rgb'] is not None else torch.zeros(N, S, 3, device=flat.device)
+      rend = {'rgb': take(lv['rgb_out'], 3)}
+      rgb_s = lv['rgb'].reshape(Np, S, 3) if lv['rgb'] is not None else torch.zeros(Np, S, 3, device=flat.device)
       if compute_extras:
         e = lv['extras']
-        rend['acc'] = e[:, 0].clone().reshape(lead)
-        rend['distance_mean'] = e[:, 1].clone().reshape(lead)
-        rend['distance_median'] = e[:, 2].clone().reshape(lead)
-        rend['distance_percentile_5'] = e[:, 3].clone().reshape(lead)
-        rend['distance_percentile_95'] = e[:, 4].clone().reshape(lead)
+        rend['acc'] = take(e[:, 0].contiguous())
+        rend['distance_mean'] = take(e[:, 1].contiguous())
+        rend['distance_median'] = take(e[:, 2].contiguous())
+        rend['distance_percentile_5'] = take(e[:, 3].contiguous())
+        rend['distance_percentile_95'] = take(e[:, 4].contiguous())
         rend['ray_sdist'] = lv['sdist'][:n].clone()
         rend['ray_weights'] = lv['weights'][:n].clone()
         rend['ray_rgbs'] = rgb_s[:n].clone()
-      hist = dict(density=lv['density'].clone().reshape(lead + (S,)), rgb=rgb_s.clone().reshape(lead + (S, 3)),
-                  sdist=lv['sdist'].clone().reshape(lead + (S + 1,)), weights=lv['weights'].clone().reshape(lead + (S,)))
+      hist = dict(density=take(lv['density'], S), rgb=take(rgb_s, S, 3), sdist=take(lv['sdist'], S + 1),
+                  weights=take(lv['weights'], S))
       if lv.get('dens_t') is not None:       # NeRF-W (models.py:285-307, 545-548)
         for k in ('rgb_combined', 'rgb_static', 'rgb_transient'):
-          rend[k] = lv[k].clone().reshape(lead + (3,))
-        rend['uncertainty'] = lv['uncertainty'].clone().reshape(lead + (1,))
-        hist.update(density_transient=lv['dens_t'].clone().reshape(lead + (S,)),
-                    rgb_transient=lv['rgb_t'].clone().reshape(lead + (S, 3)),
-                    uncertainty=lv['unc'].clone().reshape(lead + (S, 1)))
+          rend[k] = take(lv[k], 3)
+        rend['uncertainty'] = take(lv['uncertainty'], 1)
+        hist.update(density_transient=take(lv['dens_t'], S), rgb_transient=take(lv['rgb_t'], S, 3),
+                    uncertainty=take(lv['unc'], S, 1))
       renderings.append(rend)
       history.append(hist)
     if implicit_mask is not None:

@@ -140,6 +140,10 @@ def create_train_step(model, config, is_finetune=False):
     rays = models.rays_to_dict(batch.rays, dev)
     gt = batch.rgb[..., :3].reshape(-1, 3).to(device=dev, dtype=torch.float32).contiguous()
     N = gt.shape[0]
+    for S_ in (model.num_prop_samples, model.num_nerf_samples):
+      if (N * S_) % 128:
+        raise ValueError(f'per-device batch of {N} rays x {S_} samples is not a multiple of the 128-row GEMM tile: '
+                         'use a batch size that is a multiple of 4 (eval pads ragged chunks itself)')
     if state.step == 0 and not eng.wt or cache.get('stale', True):
       eng.refresh_weights(state.flat)
       cache['stale'] = False

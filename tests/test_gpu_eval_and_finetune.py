@@ -77,3 +77,36 @@ def test_leaf_api_wrappers():
   assert float((coord.pos_enc(v.cuda(), 0, 4).cpu() - R.pos_enc(v, 0, 4)).abs().max()) < 1e-5
   with pytest.raises(ValueError):
     render.cast_rays_ipe(td.cuda(), d.cuda(), d.cuda(), torch.ones(N, 1).cuda(), 'sphere', torch.eye(3).cuda(), 4)
+
+
+@pytest.mark.parametrize('n_rays', [1, 35, 131])
+def test_ragged_ray_counts_render_like_the_oracle(n_rays):
+  """The reference renders any ray count (the last chunk of an odd-sized image); the GEMM tiles want rays x samples
+  in multiples of 128, so Model.apply pads internally: outputs for 1 / 35 / 131 rays still match the oracle."""
+  from tests import hugs_testlib as H
+  from oracle import torch_ref as R
+  from nerf_hugs_amd.internal import models, utils
+  config, model, state, render_fn, _, cfg, oparams = H.make_pair(GIN)
+  full = H.synth_rays(3, 8, 21)                          # 192 rays
+  rays = full.rays.map(lambda x: x.reshape(-1, x.shape[-1])[:n_rays])
+  rend, hist = model.apply(state.flat, None, rays, 0.7, True)
+  orays = {k: v[:n_rays] for k, v in H.oracle_rays(full).items()}
+  orend, ohist = R.model_forward(cfg, oparams, orays, 0.7, None, True)
+  assert rend[-1]['rgb'].shape == (n_rays, 3) and hist[-1]['weights'].shape == (n_rays, 32)
+  for k in ['rgb', 'acc', 'distance_mean', 'distance_median']:
+    a = rend[-1][k].cpu().reshape(n_rays, -1).double(); b = orend[-1][k].detach().reshape(n_rays, -1).double()
+    assert float((a - b).abs().max()) < 2e-4 * max(1.0, float(b.abs().max())), k
+  assert float((hist[0]['sdist'].cpu() - ohist[0]['sdist']).abs().max()) < 1e-5
+  # an odd-sized image through render_image: 7 x 5 pixels, chunks of 16 -> 16, 16, 3
+  img = full.rays.map(lambda x: x.reshape(-1, x.shape[-1])[:35].reshape(7, 5, -1))
+  configs_chunk = config.render_chunk_size
+  config.render_chunk_size = 16
+  try:
+    out = models.render_image(functools.partial(render_fn, state.params, 0.7), img, None, config, verbose=False)
+  finally:
+    config.render_chunk_size = configs_chunk
+  o35, _ = R.model_forward(cfg, oparams, {k: v[:35] for k, v in H.oracle_rays(full).items()}, 0.7, None, True)
+  assert out['rgb'].shape == (7, 5, 3)
+  assert float((out['rgb'].cpu().reshape(35, 3) - o35[-1]['rgb'].detach()).abs().max()) < 2e-4
+  with pytest.raises(ValueError):
+    model.apply(state.flat, None, rays.map(lambda x: x[:0]), 0.7, False)
