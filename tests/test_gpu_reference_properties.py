@@ -1,0 +1,165 @@
+"""The reference's own property tests (MipNeRF360/tests/render_test.py, coord_test.py), restated against the
+HIP kernels through the C ABI -- parity evidence that does not pass through this repository's oracle.
+
+`hugs_cast_ipe_fwd` fuses rays -> Gaussians -> (contract) -> lift -> IPE, so the Gaussian moments are read back
+out of its degree-1 features: for a basis vector b the kernel emits E[sin(b.x)] = exp(-var_b / 2) sin(mu_b) and
+E[cos(b.x)] = exp(-var_b / 2) cos(mu_b), hence mu_b = atan2(.,.) and var_b = -2 ln |(.,.)|, with mu_b = b.mean and
+var_b = b^T cov b (render.py:21-41,103-127; coord.py:102-133)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _moments(o, d, radii, tdist, basis, ray_shape=0, contract=False):
+  """-> (mu [N,S,nb], var [N,S,nb]) recovered from the kernel's degree-1 features (fp32 output)."""
+  from nerf_hugs_amd import _lib as L
+  f = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+  N, S, nb = o.shape[0], tdist.shape[1] - 1, basis.shape[1]
+  pitch = 64
+  out = torch.empty(N * S, pitch, device='cuda')
+  L.call('hugs_cast_ipe_fwd', N, S, f(tdist), f(o), f(d), f(radii.reshape(-1)), f(basis), nb, ray_shape, int(contract), 1, 0,
+         pitch, out)
+  out = out.cpu().numpy().astype(np.float64).reshape(N, S, pitch)
+  s, c = out[..., :nb], out[..., nb:2 * nb]
+  assert np.all(out[..., 2 * nb:] == 0)
+  return np.arctan2(s, c), -2 * np.log(np.hypot(s, c))
+
+
+def _sample_frustum(rng, n, d, t0, t1, r):
+  """render_test.py:68-99: uniform samples inside a conical frustum with axis d, radius r*t at distance t."""
+  u = rng.uniform(size=n)
+  t = (t0 ** 3 * (1 - u) + t1 ** 3 * u) ** (1 / 3)
+  theta = rng.uniform(0, 2 * np.pi, n)
+  rad = r * t * np.sqrt(rng.uniform(size=n))
+  dn = d / np.linalg.norm(d)
+  b = np.linalg.svd(np.eye(3) - np.outer(dn, dn))[0][:, :2]
+  return (b[:, :1] * rad * np.cos(theta) + b[:, 1:2] * rad * np.sin(theta) + d[:, None] * t).T
+
+
+def _random_frustum(rng, rmin, rmax, smin, smax, nz=4):
+  """render_test.py:101-149 (conical: r in [.01,.05], |d| in [.8,1.2]; cylinder: r in [.1,.2], |d| in [.4,1.2])."""
+  zm, zd = rng.uniform(1.5, 3, nz), rng.uniform(.1, .3, nz)
+  d = rng.normal(size=3)
+  return d / np.linalg.norm(d) * rng.uniform(smin, smax), zm - zd, zm + zd, rng.uniform(rmin, rmax)
+
+
+BASIS = (np.linalg.qr(np.random.default_rng(5).normal(size=(3, 3)))[0] * 0.25)   # |b.x| < pi for |x| < 4 pi
+
+
+def test_conical_frustum_moments_match_samples():
+  """render_test.py:279-302: mean within 1e-3, covariance within 2e-4 of the empirical moments of 1e5 samples."""
+  rng = np.random.default_rng(0)
+  for _ in range(10):
+    d, t0, t1, r = _random_frustum(rng, .01, .05, .8, 1.2)
+    for a, b in zip(t0, t1):
+      # base_radius r is the cone's radius per unit t along d; the kernel takes per-ray `radii` the same way
+      mu, var = _moments(np.zeros((1, 3)), d[None], np.array([r]), np.array([[a, b]]), BASIS)
+      x = _sample_frustum(rng, 100000, d, a, b, r)
+      proj = x @ BASIS
+      np.testing.assert_allclose(mu[0, 0], proj.mean(0), atol=1e-3 * 0.25)
+      np.testing.assert_allclose(var[0, 0], proj.var(0), atol=2e-4 * 0.25 ** 2 + 3e-6)
+
+
+def test_cylinder_moments_match_samples():
+  """render_test.py:333-352 (mean atol 0.1, cov atol 0.01 there; the same bound here on the projected moments)."""
+  rng = np.random.default_rng(1)
+  for _ in range(10):
+    d, t0, t1, r = _random_frustum(rng, .1, .2, .4, 1.2)
+    for a, b in zip(t0, t1):
+      mu, var = _moments(np.zeros((1, 3)), d[None], np.array([r]), np.array([[a, b]]), BASIS, ray_shape=1)
+      n = 200000
+      t = rng.uniform(a, b, n); th = rng.uniform(0, 2 * np.pi, n); rad = r * np.sqrt(rng.uniform(size=n))
+      dn = d / np.linalg.norm(d)
+      e = np.linalg.svd(np.eye(3) - np.outer(dn, dn))[0][:, :2]
+      x = (e[:, :1] * rad * np.cos(th) + e[:, 1:2] * rad * np.sin(th) + d[:, None] * t).T
+      proj = x @ BASIS
+      np.testing.assert_allclose(mu[0, 0], proj.mean(0), atol=0.1 * 0.25)
+      np.testing.assert_allclose(var[0, 0], proj.var(0), atol=0.01 * 0.25 ** 2)
+      np.testing.assert_allclose(var[0, 0], proj.var(0), rtol=0.03, atol=1e-6)       # (much tighter in practice)
+
+
+@pytest.mark.parametrize('ray_shape', [0, 1])
+def test_scaling_the_direction_scales_the_gaussian(ray_shape):
+  """render_test.py:200-258: with d -> 2.7 d the mean scales by 2.7 and the along-ray variance by 2.7^2, while the
+  across-ray variance is unchanged."""
+  basis = np.eye(3) * 0.2
+  o = np.zeros((1, 3)); d = np.array([[0., 0., 1.]]); r = np.array([0.4]); td = np.array([[0.3, 0.7]])
+  mu, var = _moments(o, d, r, td, basis, ray_shape)
+  mu2, var2 = _moments(o, 2.7 * d, r, td, basis, ray_shape)
+  np.testing.assert_allclose(2.7 * mu, mu2, atol=1e-5, rtol=1e-5)
+  np.testing.assert_allclose(2.7 ** 2 * var[..., 2], var2[..., 2], atol=2e-6, rtol=1e-4)
+  np.testing.assert_allclose(var[..., :2], var2[..., :2], atol=2e-6, rtol=1e-4)
+
+
+def test_origins_shift_the_mean_only():
+  rng = np.random.default_rng(2)
+  d, t0, t1, r = _random_frustum(rng, .01, .05, .8, 1.2)
+  td = np.stack([t0, t1], -1)[:1]
+  o = rng.normal(size=(1, 3)) * 0.5
+  mu0, var0 = _moments(np.zeros((1, 3)), d[None], np.array([r]), td, BASIS)
+  mu1, var1 = _moments(o, d[None], np.array([r]), td, BASIS)
+  np.testing.assert_allclose(mu1 - mu0, (o @ BASIS)[:, None, :], atol=2e-6)
+  np.testing.assert_allclose(var1, var0, atol=2e-6)
+
+
+def test_contract_properties():
+  """coord_test.py:71-90: contract is the identity inside the unit ball and bounded by 2 outside;
+  coord.py:21-27: ||x|| > 1 -> (2 - 1/||x||) x/||x||.  Tiny radii make the Gaussians points."""
+  rng = np.random.default_rng(3)
+  n = 512
+  basis = np.eye(3) * 0.5                                   # |b.y| <= 1 < pi for contracted points
+  x = rng.normal(size=(n, 3))
+  x_in = x / np.maximum(1, np.linalg.norm(x, axis=-1, keepdims=True)) * rng.uniform(0.05, 1, (n, 1))
+  x_out = np.where(rng.uniform(size=(n, 3)) < .5, 1, -1) * np.exp(rng.uniform(-3, 6, (n, 3)))
+  for pts in (x_in, x_out):
+    # a ray from the origin through the point: the interval [1 - 1e-4, 1 + 1e-4] along d = pts has its mean at pts
+    td = np.tile(np.array([[1 - 1e-4, 1 + 1e-4]]), (n, 1))
+    mu, var = _moments(np.zeros((n, 3)), pts, np.full(n, 1e-6), td, basis, contract=True)
+    y = mu[:, 0, :] / 0.5
+    nrm = np.linalg.norm(pts, axis=-1, keepdims=True)
+    want = np.where(nrm <= 1, pts, (2 - 1 / np.maximum(nrm, 1e-30)) * pts / np.maximum(nrm, 1e-30))
+    np.testing.assert_allclose(y, want, atol=2e-5, rtol=1e-5)
+    assert np.linalg.norm(y, axis=-1).max() <= 2 + 1e-5
+
+
+def test_contract_equal_steps_in_disparity():
+  """coord_test.py:61-69 (Figure 2 of arXiv:2111.12077): with t = s_to_t(s) for fn = reciprocal, near = 1, the
+  contracted distances advance in equal steps of 1/n -- through the sampler's s_to_t and the encoder's contract."""
+  from nerf_hugs_amd.internal import stepfun
+  n = 10
+  far = 1e9
+  f = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+  # deterministic sampling of a single unit-weight interval [0,1] gives evenly spaced s (stepfun.py:191-200)
+  sd, td = stepfun.level_sample(f([[0., 1.]]), f([[1.]]), False, 0., (0., 1.), 1.0, 0.0, n, None, 'reciprocal', f([1.]), f([far]))
+  s, t = sd.cpu().numpy()[0].astype(np.float64), td.cpu().numpy()[0].astype(np.float64)
+  np.testing.assert_allclose(t, 1 / (s / far + (1 - s) / 1.), rtol=2e-6)          # coord_test.py:199-222 closed form
+  basis = np.array([[0.5], [0.], [0.]])
+  k = n - 1                                                 # drop the last point (t -> far, contract -> 2)
+  pts = np.zeros((k + 1, 3)); pts[:, 0] = t[:k + 1]
+  tdp = np.tile(np.array([[1 - 1e-5, 1 + 1e-5]]), (k + 1, 1))
+  mu, _ = _moments(np.zeros((k + 1, 3)), pts, np.full(k + 1, 1e-7), tdp, basis, contract=True)
+  tc = mu[:, 0, 0] / 0.5
+  np.testing.assert_allclose(np.diff(tc), np.diff(2 - 1 / t[:k + 1]), atol=2e-5)
+  np.testing.assert_allclose(np.diff(tc), np.diff(s[:k + 1]) * (1 - 1 / far), atol=2e-5)   # equal steps in s
+
+
+def test_ray_warp_extents():
+  """coord_test.py:180-197: s = 0 -> near, s = 1 -> far, for both warps built here."""
+  from nerf_hugs_amd.internal import stepfun
+  rng = np.random.default_rng(4)
+  n = 100
+  near = np.exp(rng.normal(size=n)).astype(np.float32)
+  far = (near + np.exp(rng.normal(size=n))).astype(np.float32)
+  f = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+  t = np.tile(np.array([[0., 1.]], np.float32), (n, 1)); w = np.ones((n, 1), np.float32)
+  for rd in (None, 'reciprocal'):
+    sd, td = stepfun.level_sample(f(t), f(w), False, 0., (0., 1.), 1.0, 0.0, 2, None, rd, f(near), f(far))
+    sd, td = sd.cpu().numpy(), td.cpu().numpy()
+    # two centred samples on one interval -> s = [0, 0.5, 1] (stepfun.py:244-263 end points are the domain)
+    np.testing.assert_allclose(sd, np.tile([0., .5, 1.], (n, 1)), atol=1e-6)
+    np.testing.assert_allclose(td[:, 0], near, rtol=1e-5)
+    np.testing.assert_allclose(td[:, -1], far, rtol=1e-5)
+    mid = 0.5 * (near + far) if rd is None else 1 / (0.5 / far + 0.5 / near)
+    np.testing.assert_allclose(td[:, 1], mid, rtol=1e-5)
