@@ -176,8 +176,20 @@ __global__ __launch_bounds__(256) void k_interlevel(int nrays, int S, int Sp, co
     const float incl = wave_incl_scan_f(tot, lane);
     float run = __shfl_up(incl, 1);
     if (lane == 0) { run = 0.f; s_cy[wv][0] = 0.f; }
+    // The lane-blocked scan is monotone inside a lane but its lane-boundary values come from differently associated
+    // sums, so the prefix could step DOWN by an ulp there; on a stretch of zero weights that would make an outer
+    // measure of -1e-7 and, through 1/(w + eps), an O(1) spurious gradient.  A sequential cumsum of non-negative
+    // numbers (the reference's) never decreases: enforce that with a running maximum across lanes.
+    float cyv[4], last = run;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const int i = lane * C + k; run += v[k]; if (k < C && i < Sp) s_cy[wv][i + 1] = run; }
+    for (int k = 0; k < 4; ++k) { last += v[k]; cyv[k] = last; }
+    float pm = last;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) { const float o = __shfl_up(pm, dd); if (lane >= dd) pm = fmaxf(pm, o); }
+    float carry = __shfl_up(pm, 1);
+    if (lane == 0) carry = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int i = lane * C + k; if (k < C && i < Sp) s_cy[wv][i + 1] = fmaxf(cyv[k], carry); }
   }
   __syncthreads();
   float lsum = 0.f;

@@ -247,3 +247,62 @@ def test_sample_one_hot_bin_stays_inside(randomized):
     assert ts[:, 1:-1].min() >= bins[0, i] - 1e-6 and ts[:, 1:-1].max() <= bins[0, i + 1] + 1e-6, (i, ts.min(), ts.max())
     half = 0.5 * (bins[0, i + 1] - bins[0, i]) / 256
     assert ts.min() >= bins[0, i] - half - 1e-6 and ts.max() <= bins[0, i + 1] + half + 1e-6
+
+
+def _interlevel(t, w, te, we):
+  """hugs_interlevel: per-ray sum_i max(0, w_i - outer_i)^2 / (w_i + eps)   (stepfun.py:80-86 lossfun_outer, summed)."""
+  from nerf_hugs_amd import _lib as L
+  n, S, Sp = w.shape[0], w.shape[1], we.shape[1]
+  loss = torch.empty(n, device='cuda'); d = torch.empty(n, Sp, device='cuda')
+  L.call('hugs_interlevel', n, S, Sp, _G(t), _G(w), _G(te), _G(we), 1.0, loss, d)
+  return loss.cpu().numpy().astype(np.float64), d.cpu().numpy()
+
+
+def test_lossfun_outer_properties():
+  """stepfun_test.py:588-622 (two histograms of the same points: zero loss; of different point sets: non-zero),
+  :657-681 (invariance to a monotonic re-parameterisation of t), :683-697 (self loss is zero) -- on hugs_interlevel."""
+  rng = np.random.default_rng(0)
+  any_nonzero = False
+  for trial in range(10):
+    npts, d0, d1 = rng.integers(10, 20, 3)
+    t0 = np.sort(rng.uniform(size=(1, d0 + 1)), -1); t1 = np.sort(rng.uniform(size=(1, d1 + 1)), -1)
+    lo, hi = max(t0.min(), t1.min()) + 0.1, min(t0.max(), t1.max()) - 0.1
+    if hi <= lo:
+      continue
+    pts = rng.uniform(lo, hi, npts)
+    hist = lambda t, p: np.array([[np.mean((p >= t[0, i]) & (p < t[0, i + 1])) for i in range(t.shape[1] - 1)]])
+    same, _ = _interlevel(t0, hist(t0, pts), t1, hist(t1, pts))
+    assert same[0] < 1e-10
+    diff, _ = _interlevel(t0, hist(t0, pts[:-2]), t1, hist(t1, pts))       # histograms of different point sets
+    any_nonzero |= bool(diff[0] > 1e-12)
+    w0 = np.exp(rng.normal(size=(1, d0))); w1 = np.exp(rng.normal(size=(1, d1)))
+    a, ga = _interlevel(t0, w0, t1, w1)
+    curve = lambda x: 1 + x ** 3
+    b, gb = _interlevel(curve(t0), w0, curve(t1), w1)
+    assert a[0] == b[0] and np.array_equal(ga, gb)                          # depends on the ORDER of the edges only
+    z, _ = _interlevel(t0, w0, t0, w0)
+    assert z[0] < 1e-10
+  assert any_nonzero
+
+
+def test_distance_percentiles_match_empirical_samples():
+  """stepfun_test.py:739-763: weighted_percentile == the empirical percentile of samples drawn from the step function
+  -- against the 5 / 50 / 95 % distances that hugs_composite_fwd emits (render.py:228-244)."""
+  from nerf_hugs_amd import _lib as L
+  rng = np.random.default_rng(1)
+  n, S = 8, 16
+  t = np.sort(rng.uniform(1.0, 5.0, (n, S + 1)), -1)
+  dens = np.exp(rng.normal(size=(n, S))) * 2
+  dirs = np.tile([[0., 0., 1.]], (n, 1))
+  far = np.full((n,), 100.0)
+  w = torch.empty(n, S, device='cuda'); rgb = torch.empty(n, 3, device='cuda'); ex = torch.empty(n, 5, device='cuda')
+  L.call('hugs_composite_fwd', n, S, _G(dens.reshape(-1)), None, _G(t), _G(dirs), 1, 1.0, _G(far), w, rgb, ex)
+  w = w.cpu().numpy().astype(np.float64); ex = ex.cpu().numpy()
+  np.testing.assert_allclose(w.sum(-1), 1, atol=1e-6)                       # opaque background: weights sum to 1
+  m = 400000
+  for r in range(n):
+    k = rng.choice(S, size=m, p=w[r] / w[r].sum())
+    x = t[r, k] + rng.uniform(size=m) * (t[r, k + 1] - t[r, k])            # piecewise-uniform samples of the step function
+    p5, p50, p95 = np.percentile(x, [5, 50, 95])
+    np.testing.assert_allclose([ex[r, 3], ex[r, 2], ex[r, 4]], [p5, p50, p95], rtol=3e-3, atol=3e-3)
+    assert abs(ex[r, 0] - 1) < 1e-6 and t[r, 0] <= ex[r, 1] <= t[r, -1]
