@@ -218,3 +218,27 @@ def test_ctypes_prototypes_match_the_header():
     assert sig == proto, f'{name}: header says {sig}, _lib says {proto}'
     checked += 1
   assert checked >= 40
+
+
+def test_geopoly_basis_reference_golden():
+  """tests/geopoly_test.py:76-99: the icosahedron-2 basis the MLPs lift with, as a set of directions (each golden row
+  matches exactly one basis column up to 1e-4)."""
+  from nerf_hugs_amd.internal import geopoly
+  golden = np.array([
+      [0.85065081, 0.00000000, 0.52573111], [0.80901699, 0.50000000, 0.30901699], [0.52573111, 0.85065081, 0.00000000],
+      [1.00000000, 0.00000000, 0.00000000], [0.80901699, 0.50000000, -0.30901699], [0.85065081, 0.00000000, -0.52573111],
+      [0.30901699, 0.80901699, -0.50000000], [0.00000000, 0.52573111, -0.85065081], [0.50000000, 0.30901699, -0.80901699],
+      [0.00000000, 1.00000000, 0.00000000], [-0.52573111, 0.85065081, 0.00000000], [-0.30901699, 0.80901699, -0.50000000],
+      [0.00000000, 0.52573111, 0.85065081], [-0.30901699, 0.80901699, 0.50000000], [0.30901699, 0.80901699, 0.50000000],
+      [0.50000000, 0.30901699, 0.80901699], [0.50000000, -0.30901699, 0.80901699], [0.00000000, 0.00000000, 1.00000000],
+      [-0.50000000, 0.30901699, 0.80901699], [-0.80901699, 0.50000000, 0.30901699], [-0.80901699, 0.50000000, -0.30901699]])
+
+  def same_basis(x, y, tol=1e-4):      # geopoly_test.py:22-31
+    match = np.minimum(((x[:, None, :] - y[None]) ** 2).sum(-1), ((x[:, None, :] + y[None]) ** 2).sum(-1)) <= tol
+    return bool(np.all(match.sum(0) == 1) and np.all(match.sum(1) == 1))
+
+  basis = np.asarray(geopoly.generate_basis('icosahedron', 2))
+  assert basis.shape == (21, 3) and same_basis(basis, golden)
+  np.testing.assert_allclose(np.linalg.norm(basis, axis=-1), 1, atol=1e-12)
+  # symmetric directions were removed: no column is the negation of another (geopoly.py:113-121)
+  assert (np.abs(basis @ basis.T + 1) < 1e-6).sum() == 0
