@@ -306,3 +306,42 @@ def test_distance_percentiles_match_empirical_samples():
     p5, p50, p95 = np.percentile(x, [5, 50, 95])
     np.testing.assert_allclose([ex[r, 3], ex[r, 2], ex[r, 4]], [p5, p50, p95], rtol=3e-3, atol=3e-3)
     assert abs(ex[r, 0] - 1) < 1e-6 and t[r, 0] <= ex[r, 1] <= t[r, -1]
+
+
+@pytest.mark.parametrize('ld,lt', [(-100, -100), (-100, -10), (-100, 0), (-100, 10), (-10, -100), (-10, -10), (-10, 0), (-10, 10),
+                                   (0, -100), (0, -10), (0, 0), (0, 10), (10, -10), (10, 0), (10, 10), (10, -100)])
+def test_alpha_weights_and_gradients_are_finite_at_extreme_scales(ld, lt):
+  """render_test.py:408-441: densities exp(ld + N(0,1)), distances exp(lt) * sorted U(-1,1): the weights, the rendered
+  colour and every gradient stay finite -- hugs_composite_fwd / hugs_composite_bwd, with and without the opaque
+  background."""
+  from nerf_hugs_amd import _lib as L
+  rng = np.random.default_rng(0)
+  n, d = 100, 128
+  dens = np.exp(ld + rng.normal(size=(n, d)))
+  tv = np.exp(lt) * np.sort(2 * rng.uniform(size=(n, d + 1)) - 1, -1)
+  dirs = rng.normal(size=(n, 3))
+  rgb_s = rng.uniform(size=(n * d, 3))
+  for opaque in (0, 1):
+    w = torch.empty(n, d, device='cuda'); rgb = torch.empty(n, 3, device='cuda')
+    L.call('hugs_composite_fwd', n, d, _G(dens.reshape(-1)), _G(rgb_s), _G(tv), _G(dirs), opaque, 1.0, None, w, rgb, None)
+    assert bool(torch.isfinite(w).all()) and bool(torch.isfinite(rgb).all())
+    assert float(w.min()) >= 0 and float(w.sum(-1).max()) <= 1 + 1e-5
+    dd = torch.empty(n * d, device='cuda'); dc = torch.empty(n * d, 3, device='cuda')
+    L.call('hugs_composite_bwd', n, d, _G(dens.reshape(-1)), _G(rgb_s), _G(tv), _G(dirs), opaque, 1.0, _G(np.ones((n, 3))),
+           _G(np.ones((n, d))), dd, dc)
+    assert bool(torch.isfinite(dd).all()) and bool(torch.isfinite(dc).all())
+
+
+def test_alpha_weights_delta_density():
+  """render_test.py:443-463: one interval with density 1e10 takes all the weight."""
+  from nerf_hugs_amd import _lib as L
+  rng = np.random.default_rng(1)
+  n, d = 100, 128
+  r = rng.normal(size=(n, d))
+  mask = (r == r.max(-1, keepdims=True)).astype(np.float32)
+  tv = np.sort(2 * rng.uniform(size=(n, d + 1)) - 1, -1)
+  keep = np.diff(tv, axis=-1)[mask > 0] > 1e-6        # (a zero-width interval cannot absorb anything)
+  dirs = rng.normal(size=(n, 3))
+  w = torch.empty(n, d, device='cuda'); rgb = torch.empty(n, 3, device='cuda')
+  L.call('hugs_composite_fwd', n, d, _G((1e10 * mask).reshape(-1)), None, _G(tv), _G(dirs), 0, 1.0, None, w, rgb, None)
+  np.testing.assert_allclose(w.cpu().numpy()[keep], mask[keep], atol=1e-5, rtol=1e-5)
