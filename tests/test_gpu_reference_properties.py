@@ -345,3 +345,25 @@ def test_alpha_weights_delta_density():
   w = torch.empty(n, d, device='cuda'); rgb = torch.empty(n, 3, device='cuda')
   L.call('hugs_composite_fwd', n, d, _G((1e10 * mask).reshape(-1)), None, _G(tv), _G(dirs), 0, 1.0, None, w, rgb, None)
   np.testing.assert_allclose(w.cpu().numpy()[keep], mask[keep], atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize('lt,lr', [(-100, -100), (-100, 0), (-10, -10), (-10, 10), (0, -100), (0, 0), (0, 10), (10, -10), (10, 10)])
+def test_encoder_outputs_are_finite_at_extreme_scales(lt, lr):
+  """render_test.py:465-505 (conical_frustum_to_gaussian is finite for distances exp(lt) * U(-1,1) and radii
+  exp(lr + N(0,1))), carried through contract + lift + IPE: every feature of hugs_cast_ipe_fwd is finite and bounded
+  by 1, in fp32 and in bf16."""
+  from nerf_hugs_amd import _lib as L
+  from nerf_hugs_amd.internal import geopoly
+  rng = np.random.default_rng(0)
+  n, d = 10, 128
+  tv = np.exp(lt) * np.sort(rng.uniform(-1, 1, (n, d + 1)), -1)
+  rad = np.exp(lr) * np.exp(rng.normal(size=n))
+  dirs = rng.normal(size=(n, 3)); o = rng.normal(size=(n, 3))
+  basis = np.asarray(geopoly.generate_basis('icosahedron', 2)).T.astype(np.float32).copy()
+  for contract in (0, 1):
+    for bf16 in (0, 1):
+      out = torch.empty(n * d, 512, device='cuda', dtype=torch.bfloat16 if bf16 else torch.float32)
+      L.call('hugs_cast_ipe_fwd', n, d, _G(tv), _G(o), _G(dirs), _G(rad), _G(basis), 21, 0, contract, 12, bf16, 512, out)
+      o32 = out.float()
+      assert bool(torch.isfinite(o32).all()), (contract, bf16)
+      assert float(o32.abs().max()) <= 1.0 + 1e-2 and float(o32[:, 504:].abs().max()) == 0
