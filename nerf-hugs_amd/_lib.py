@@ -61,6 +61,16 @@ class HugsError(RuntimeError):
   pass
 
 
+_GET_RAW = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
+def _raw_stream():
+  """hipStream_t of torch's current stream on the current device (the fast path avoids ~8 us of Python per launch)."""
+  if _GET_RAW is not None:
+    return _GET_RAW(torch.cuda.current_device())
+  return torch.cuda.current_stream().cuda_stream
+
+
 class _Lib:
 
   def __init__(self):
@@ -106,7 +116,7 @@ class _Lib:
         conv.append(float(a))
       else:
         conv.append(int(a))
-    conv.append(torch.cuda.current_stream().cuda_stream)
+    conv.append(_raw_stream())
     rc = getattr(self.cdll, name)(*conv)
     if rc != 0:
       msg = self.cdll.hugs_last_error().decode()

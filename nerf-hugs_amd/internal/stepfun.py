@@ -33,6 +33,21 @@ def sample_u(num_samples, randomized, deterministic_center=True):
   return np.linspace(0, float(1 - u_max), num_samples).astype(np.float32), float(max_jitter)
 
 
+_UB_CACHE = {}
+
+
+def _u_base_on_device(num_samples, randomized, dev):
+  """sample_u's abscissae as a device tensor, uploaded once: a pageable host->device copy inside the step is a
+  synchronisation point (the host waits for everything queued before it), which kept the CPU from running ahead."""
+  key = (num_samples, bool(randomized), str(dev))
+  hit = _UB_CACHE.get(key)
+  if hit is None:
+    ub, mj = sample_u(num_samples, randomized)
+    hit = (torch.from_numpy(ub).to(dev), mj)
+    _UB_CACHE[key] = hit
+  return hit
+
+
 def level_sample(t_prev, w_prev, do_dilate, dilation, domain, anneal, resample_padding, num_samples, u01,
                  raydist, near, far, return_debug=False, jitter=None):
   """One hierarchical-sampling level (models.py:155-212): [dilate] -> logits -> sample_intervals -> s_to_t.
@@ -44,8 +59,7 @@ def level_sample(t_prev, w_prev, do_dilate, dilation, domain, anneal, resample_p
     raise ValueError(f'num_samples must be > 1, is {num_samples}.')
   N, n_prev = w_prev.shape
   dev = t_prev.device
-  ub, mj = sample_u(num_samples, u01 is not None or jitter is not None)
-  ub = torch.from_numpy(ub).to(dev)
+  ub, mj = _u_base_on_device(num_samples, u01 is not None or jitter is not None, dev)
   stride = 1
   if jitter is None and u01 is not None:
     jitter = u01.to(torch.float32) * np.float32(mj)
