@@ -170,7 +170,9 @@ class Dataset:
     ps, dil = self._patch_size, self._patch_dilation
     p = (self._batch_size // self._image_num_per_batch) // ps ** 2
     upper = (ps - 1) * dil
-    host = np.empty((3, self._image_num_per_batch * p), np.int32)
+    npatch = self._image_num_per_batch * p
+    pinned, ev = self._staging(npatch)
+    host = pinned.numpy()
     for i in range(self._image_num_per_batch):   # the reference's draw order, datasets.py:507-519
       cam = self._rs.randint(0, self._n_examples)
       h, w = int(self.heights[cam]), int(self.widths[cam])
@@ -179,12 +181,24 @@ class Dataset:
       host[0, i * p:(i + 1) * p] = self._rs.randint(0, w - upper, (p, 1, 1))[:, 0, 0]
       host[1, i * p:(i + 1) * p] = self._rs.randint(0, h - upper, (p, 1, 1))[:, 0, 0]
       host[2, i * p:(i + 1) * p] = cam
-    org = torch.from_numpy(host).to(self.device, non_blocking=True)
-    npatch = host.shape[1]
+    org = pinned.to(self.device, non_blocking=True)     # pinned source: a truly asynchronous copy, no host stall
+    ev.record()
     n = npatch * ps * ps
     pix = torch.empty((3, n), dtype=torch.int32, device=self.device)
     L.call('hugs_expand_patches', npatch, ps, dil, org[0], org[1], org[2], pix[0], pix[1], pix[2])
     return self._make_ray_batch(pix[0], pix[1], pix[2], (npatch, ps, ps))
+
+  def _staging(self, npatch):
+    """A small ring of pinned host buffers for the patch origins; a slot is reused only after the copy that last read
+    it has completed (the event is normally long done: the ring is 8 deep)."""
+    ring = getattr(self, '_pin_ring', None)
+    if ring is None or ring[0][0].shape[1] != npatch:
+      ring = [(torch.empty((3, npatch), dtype=torch.int32).pin_memory(), torch.cuda.Event()) for _ in range(8)]
+      self._pin_ring, self._pin_next = ring, 0
+    buf, ev = ring[self._pin_next]
+    self._pin_next = (self._pin_next + 1) % len(ring)
+    ev.synchronize()
+    return buf, ev
 
   def generate_ray_batch(self, cam_idx):
     """datasets.py:531-541: every pixel of one image, [H, W, C]."""
