@@ -182,7 +182,7 @@ def main():
   # the reference's stream: PRNGKey(20200823) split over the devices (train.py:46,80), threefry on the GPU
   from nerf_hugs_amd.internal import random as hrandom
   gen = hrandom.split(hrandom.PRNGKey(20200823, device), world)[rank].clone()
-  thr = np.ones((model.num_levels, 1), np.float32)
+  thr = None      # RobustNeRF: thresholds are fed back on the device (first step: ones, train.py:130)
   for _ in range(args.warmup):
     state, stats, gen = train_step(gen, state, batch, 0.5, thr)
   torch.cuda.synchronize()

@@ -176,8 +176,15 @@ def create_train_step(model, config, is_finetune=False):
       P = config.patch_size
       if N % (P * P):
         raise ValueError('robustnerf needs whole patches per device')
-      thr = torch.as_tensor(np.asarray(inlier_thresholds, dtype=np.float32) if not torch.is_tensor(inlier_thresholds)
-                            else inlier_thresholds).to(device=dev, dtype=torch.float32).reshape(L, -1)[:, :1].contiguous()
+      if inlier_thresholds is None:
+        # device-side feedback of the previous step's (rank-averaged) thresholds: what train.py:145-148 does through
+        # the host, without the device->host->device round trip (a synchronisation point in every step)
+        thr = cache.get('thr_dev')
+        if thr is None:
+          thr = torch.ones((L, 1), dtype=torch.float32, device=dev)          # train.py:130
+      else:
+        thr = torch.as_tensor(np.asarray(inlier_thresholds, dtype=np.float32) if not torch.is_tensor(inlier_thresholds)
+                              else inlier_thresholds).to(device=dev, dtype=torch.float32).reshape(L, -1)[:, :1].contiguous()
       mask = ws.get('robust_mask', (L, N))
       err = ws.get('robust_err', (N,))
       part = ws.get('robust_part', (N // (P * P) * 4,))
@@ -307,6 +314,8 @@ def create_train_step(model, config, is_finetune=False):
     if world > 1:
       packed[:STAT_TAIL].mul_(gscale)
     packed[STAT_TAIL:].copy_(leaf_stats)
+    if tt == 'robustnerf':
+      cache['thr_dev'] = packed[16:16 + 5 * L].reshape(L, 5)[:, :1].clone()
 
     msm_now = cache.get('mask_size_mult', 0.0)
 

@@ -255,3 +255,24 @@ def test_nerfw_renderings_and_zero_tra():
       a = hist[-1][k].cpu().reshape(128, -1); b = ohist[-1][k].detach().reshape(128, -1)
       assert float((a - b).abs().max()) < 1e-3 * max(1., float(b.abs().max())), k
     assert hist[-1]['uncertainty'].shape == (2, 8, 8, 128, 1)
+
+
+def test_robustnerf_device_side_threshold_feedback():
+  """train.py:130,145-148: thresholds start at 1 and each step uses the previous step's `robust_inlier_threshold`.
+  Passing None keeps that loop on the device; it must equal feeding the stats back through the host."""
+  from tests import hugs_testlib as H
+  gin = SMALL + ["Config.patch_size = 16", "Config.transient_type = 'robustnerf'", "Config.robustnerf_inlier_quantile = 0.8"]
+  batch = H.synth_rays(1, 16, 4)
+  runs = []
+  for mode in ('host', 'device'):
+    config, model, state, _, train_step, _, _ = H.make_pair(gin)
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    thr = np.ones((model.num_levels, 1), np.float32)
+    seen = []
+    for step in range(4):
+      state, stats, gen = train_step(gen, state, batch, 0.1 * step, thr if mode == 'host' else None)
+      seen.append(stats['robust_inlier_threshold'].numpy().copy())
+      thr = seen[-1][:, None]
+    runs.append((np.stack(seen), state.flat.clone()))
+  assert np.array_equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+  assert not np.allclose(runs[0][0][0], 1.0)              # the thresholds did move away from the initial 1
