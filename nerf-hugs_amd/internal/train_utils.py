@@ -157,8 +157,19 @@ def create_train_step(model, config, is_finetune=False):
       for l in range(L):
         S = model.num_prop_samples if l < L - 1 else model.num_nerf_samples
         u01.append(torch.rand((N,) if model.single_jitter else (N, S), generator=rng, device=dev))
+    mask_st, ev_mask_bwd = None, None
+    if tt == 'hanerf':
+      # the per-ray ImplicitMask MLP is independent of the level pipeline until the loss: it runs on the side stream
+      # underneath the NerfMLP forward (and its backward underneath the level backward)
+      main_s, side_s = torch.cuda.current_stream(), eng._side_stream()
+      ev0 = torch.cuda.Event(); ev0.record(main_s)
+      with torch.cuda.stream(side_s):
+        side_s.wait_event(ev0)
+        mask_st = eng.mask_forward(state.flat, rays, N)
+        ev_mask = torch.cuda.Event(); ev_mask.record(side_s)
     levels = eng.forward(state.flat, rays, float(train_frac), u01, False, False)
-    mask_st = eng.mask_forward(state.flat, rays, N) if tt == 'hanerf' else None
+    if mask_st is not None:
+      main_s.wait_event(ev_mask)
 
     grad = ws.get('grad', (layout.size + STAT_TAIL,))
     tail = grad[layout.size:]
@@ -248,7 +259,11 @@ def create_train_step(model, config, is_finetune=False):
       last = layout.by_path[('NerfMLP_0', sp.layers[-1]['name'], 'bias')]
       grad[lo:last['off'] + int(np.prod(last['pshape']))].zero_()
     if mask_st is not None:
-      eng.mask_backward(state.flat, grad, mask_st, rays, d_mask)
+      ev1 = torch.cuda.Event(); ev1.record(main_s)          # loss gradients and the zeroed embedding rows are ready
+      with torch.cuda.stream(side_s):
+        side_s.wait_event(ev1)
+        eng.mask_backward(state.flat, grad, mask_st, rays, d_mask)
+        ev_mask_bwd = torch.cuda.Event(); ev_mask_bwd.record(side_s)
     elif model.mask_spec is not None:            # finetune stage of a hanerf model: the mask is not in the loss
       lo = layout.by_path[('ImplicitMask_0', 'Dense_0', 'kernel')]['off']
       last = [lf for lf in layout.leaves if lf['path'][0] == 'ImplicitMask_0'][-1]
@@ -283,6 +298,8 @@ def create_train_step(model, config, is_finetune=False):
         prop_done = True
     if not prop_done:
       grad[prop_lo:prop_hi].zero_()
+    if ev_mask_bwd is not None:
+      torch.cuda.current_stream().wait_event(ev_mask_bwd)
     # ---- pmean(grad), pmean(stats) ------------------------------------------------------------------
     if world > 1:
       if ar_work is not None:
