@@ -110,3 +110,33 @@ def test_ragged_ray_counts_render_like_the_oracle(n_rays):
   assert float((out['rgb'].cpu().reshape(35, 3) - o35[-1]['rgb'].detach()).abs().max()) < 2e-4
   with pytest.raises(ValueError):
     model.apply(state.flat, None, rays.map(lambda x: x[:0]), 0.7, False)
+
+
+@pytest.mark.parametrize('tt,T', [('hanerf', 16), ('nerfw', 16)])
+def test_finetune_stage_of_transient_models(tt, T):
+  """train.py:97-109 on a HA-NeRF / NeRF-W model: the finetune loss is the plain data loss, so the transient branches get
+  zero gradient, only the embedding tables are trainable, and every statistic stays finite."""
+  from tests import hugs_testlib as H
+  from nerf_hugs_amd.internal import train_utils
+  gin = GIN + [f"Config.transient_type = '{tt}'", f"Model.num_transient_features = {T}", "Config.finetune_enable = True",
+               "NerfMLP.bottleneck_width = 128"]
+  config, model, state, _, train_step, cfg, oparams = H.make_pair(gin)
+  batch = H.synth_rays(2, 8, 3)
+  gen = torch.Generator(device='cuda').manual_seed(0)
+  state, _, gen = train_step(gen, state, batch, 0.5, None)          # one regular step first (fills every gradient slot)
+  fstate, ftrain, _ = train_utils.setup_finetune_model(config, model, state)
+  before = fstate.flat.clone()
+  for _ in range(2):
+    fstate, stats, gen = ftrain(gen, fstate, batch, 1.0, None)
+  torch.cuda.synchronize()
+  lay = model.layout
+  moved = set()
+  for lf in lay.leaves:
+    d = (lay.view(fstate.flat, lf['path']) - lay.view(before, lf['path'])).abs().max().item()
+    if d > 0:
+      moved.add(lf['path'][0])
+      assert 'embedding' in lf['path'], lf['path']
+  assert moved == {'GloEmbed_0'}            # TransientEmbed rows get exactly zero gradient in this stage
+  for k in ('grad_norms', 'weight_l2s', 'opt_update_norms'):
+    assert all(np.isfinite(float(v)) for v in stats[k].values()), k
+  assert np.isfinite(float(stats['loss'])) and set(stats['losses'].keys()) == {'data'}
