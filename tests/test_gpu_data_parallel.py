@@ -17,7 +17,11 @@ GIN = ["Config.patch_size = 8", "Config.data_loss_type = 'mse'", "Config.distort
        "PropMLP.net_width = 128", "PropMLP.disable_rgb = True", "NerfMLP.net_depth = 8", "NerfMLP.net_width = 128"]
 
 
-def _step(rank, world, port, out_dir):
+HANERF = GIN + ["Config.transient_type = 'hanerf'", "Model.num_transient_features = 16", "Model.num_glo_features = 4",
+                "NerfMLP.bottleneck_width = 128"]
+
+
+def _step(rank, world, port, out_dir, gin):
   import sys
   sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
   from tests import hugs_testlib as H
@@ -27,7 +31,7 @@ def _step(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
   configs.clear_config()
-  configs.parse_config_files_and_bindings(None, GIN)
+  configs.parse_config_files_and_bindings(None, gin)
   config = configs.make_config()
   model, state, _, train_step, _ = train_utils.setup_model(config, 3, compute_dtype='fp32')
   batch = H.synth_rays(4, 8, 5)
@@ -41,14 +45,15 @@ def _step(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_single_process(tmp_path):
+@pytest.mark.parametrize('gin', [GIN, HANERF], ids=['base', 'hanerf'])
+def test_two_rank_step_equals_single_process(tmp_path, gin):
   s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-  mp.spawn(_step, args=(1, port, str(tmp_path)), nprocs=1, join=True)
-  mp.spawn(_step, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+  mp.spawn(_step, args=(1, port, str(tmp_path), gin), nprocs=1, join=True)
+  mp.spawn(_step, args=(2, port, str(tmp_path), gin), nprocs=2, join=True)
   a = torch.load(tmp_path / 'w1.pt'); b = torch.load(tmp_path / 'w2.pt')
   from tests import hugs_testlib as H
   from nerf_hugs_amd.internal import configs, models
-  configs.clear_config(); configs.parse_config_files_and_bindings(None, GIN)
+  configs.clear_config(); configs.parse_config_files_and_bindings(None, gin)
   m = models.Model(configs.make_config())
   init = m.init(3, 'cpu')
   da, db = a['flat'] - init, b['flat'] - init
