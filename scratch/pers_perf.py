@@ -9,7 +9,7 @@ def check(M, N, K1, K2, relu=1, mask=False, r1=False, rb=False):
     rbt = torch.randn(M // 64, N, device=dev) if rb else None; mk = torch.randn(M, N, device=dev).bfloat16() if mask else None
     rr = torch.randn(M, device=dev) if r1 else None; rc = torch.randn(N, device=dev) if r1 else None
     outs = []
-    for mode in (0, 5):
+    for mode in (0, 3):
         L.call('hugs_test_force_small_tiles', mode)
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         L.call('hugs_gemm_nt', 1, M, N, K1, K2, A1, K1, A2, K2, Bt, K1 + K2, bias, rbt, 64, N, relu, mk, N, rr, rc, out, N)
@@ -31,5 +31,5 @@ def perf(M, N, K, mode, mask=False):
     dt = e0.elapsed_time(e1) / 30 * 1e-3
     print(f'perf M={M} N={N} K={K} mode={mode} mask={mask}: {dt*1e6:.1f} us {2*M*N*K/dt/1e12:.0f} TF', flush=True)
 for rep in range(2):
-    for mode in (0, 6, 7, 8):
+    for mode in (0, 3):
         perf(131072, 1024, 1024, mode); perf(131072, 1024, 1024, mode, mask=True); perf(131072, 1024, 512, mode); perf(65536, 256, 256, mode)
