@@ -110,6 +110,8 @@ int hugs_distortion(int nrays, int S, const float* t, const float* w, float scal
                     void* stream);
 int hugs_sum(int n, const float* x, float scale, float* out, void* stream);
 int hugs_add_inplace(long long n, const float* src, float* dst, void* stream);
+/* dst += alpha * src: the gradient of the weight-decay term m * ||theta_group||^2 (train_utils.py:444-447) */
+int hugs_axpy(long long n, float alpha, const float* src, float* dst, void* stream);
 
 /* train_utils.py:442 weight_l2s, :461-462 grad norms/maxes, :351-369 clip_gradients, :466 nan_to_num, :468
  * optax.adam (:487-512), :470-473 update norms/maxes on the flat fp32 parameter buffer.

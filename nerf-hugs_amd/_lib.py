@@ -32,6 +32,7 @@ _PROTOS = {
     'hugs_distortion': 'iippfpps',
     'hugs_sum': 'ipfps',
     'hugs_add_inplace': 'qpps',
+    'hugs_axpy': 'qfpps',
     'hugs_opt_stats': 'iiippppfffppps',
     'hugs_opt_adam': 'iippppppppffffffffpps',
     'hugs_cast_weights': 'iiippps',

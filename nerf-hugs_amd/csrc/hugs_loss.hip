@@ -329,6 +329,19 @@ extern "C" int hugs_sum(int n, const float* x, float scale, float* out, void* st
   return 0;
 }
 
+// dst[i] += alpha * src[i]
+__global__ void k_axpy(size_t n, float alpha, const float* __restrict__ src, float* __restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += alpha * src[i];
+}
+
+extern "C" int hugs_axpy(long long n, float alpha, const float* src, float* dst, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_axpy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (size_t)n, alpha, src, dst);
+  HUGS_CHECK_LAUNCH("hugs_axpy");
+  return 0;
+}
+
 extern "C" int hugs_add_inplace(long long n, const float* src, float* dst, void* stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(k_axpy1, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (size_t)n, src, dst);

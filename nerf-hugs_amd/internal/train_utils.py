@@ -128,8 +128,20 @@ def create_train_step(model, config, is_finetune=False):
         'patch_size must be larger than robustnerf_inner_patch_size.'
   if config.data_loss_type not in ('mse', 'charb'):
     assert False
+  # train_utils.py:444-447: loss += sum_k m_k * ||theta_k||^2 over summarize_tree keys (a module, 'module/layer' or a
+  # leaf path); the gradient 2 m_k theta is added to the leaves under each key.
+  decay = []
   if not is_finetune and config.weight_decay_mults:
-    raise NotImplementedError('weight_decay_mults is not built (no shipped gin sets it)')
+    known = set()
+    for lf in layout.leaves:
+      for d in range(1, len(lf['path']) + 1):
+        known.add('/'.join(lf['path'][:d]))
+    for key, mult in dict(config.weight_decay_mults).items():
+      if key not in known:
+        raise KeyError(f'weight_decay_mults: {key!r} is not a parameter group (have e.g. {sorted(known)[:4]})')
+      for lf in layout.leaves:
+        if '/'.join(lf['path'])[:len(key)] == key and ('/'.join(lf['path']) == key or '/'.join(lf['path'])[len(key)] == '/'):
+          decay.append((lf['off'], int(np.prod(lf['pshape'])), float(mult)))
   cache = {}
 
   def train_step(rng, state, batch, train_frac, inlier_thresholds):
@@ -308,6 +320,8 @@ def create_train_step(model, config, is_finetune=False):
       else:
         dist.all_reduce(grad, op=dist.ReduceOp.SUM)
     gscale = 1.0 / world
+    for off, n_, mult in decay:        # after pmean; the kernels below scale the buffer by gscale, hence the 1/gscale
+      _lib.call('hugs_axpy', n_, 2.0 * mult / gscale, state.flat[off:off + n_], grad[off:off + n_])
     # ---- clip + Adam --------------------------------------------------------------------------------
     nch, nleaf, nmod = layout.chunks.shape[0], len(layout.leaves), len(layout.modules)
     part1 = ws.get('opt_part1', (nch * 4,))
@@ -349,6 +363,9 @@ def create_train_step(model, config, is_finetune=False):
         losses['interlevel'] = float(config.interlevel_loss_mult * tl[8:8 + L - 1].sum())
       if not is_finetune and config.distortion_loss_mult > 0:
         losses['distortion'] = float(config.distortion_loss_mult * tl[12])
+      if decay:
+        wl2 = _summarize(layout, ls[:, 2], sum)
+        losses['weight'] = float(sum(float(m) * wl2[k] for k, m in dict(config.weight_decay_mults).items()))
       if tt == 'nerfw':
         losses['beta'] = float(config.nerfw_beta_loss_mult * tl[42] + config.nerfw_beta_loss_bias)
         losses['density'] = float(config.nerfw_density_loss_mult * tl[43])

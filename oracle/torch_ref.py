@@ -356,6 +356,7 @@ class ModelCfg:
     self.robustnerf_smoothed_inlier_quantile = 0.5
     self.robustnerf_inner_patch_size = 8
     self.robustnerf_inner_patch_inlier_quantile = 0.4
+    self.weight_decay_mults = {}      # {summarize_tree key: multiplier} (train_utils.py:444-447)
     self.grad_max_norm = 0.001
     self.grad_max_val = 0.
     self.lr_init, self.lr_final = 0.002, 0.00002
@@ -764,6 +765,10 @@ def loss_and_grad(cfg, variables, rays, gt_rgb, train_frac, u01, inlier_threshol
     losses['interlevel'] = interlevel_loss(cfg, history)
   if cfg.distortion_loss_mult > 0:
     losses['distortion'] = distortion_loss(cfg, history)
+  if cfg.weight_decay_mults:        # train_utils.py:442-447: m * ||theta_group||^2 over summarize_tree groups
+    losses['weight'] = sum(m * sum((v**2).sum() for (name, _), v in zip(leaves, req)
+                                   if name == k or name.startswith(k + '/'))
+                           for k, m in cfg.weight_decay_mults.items())
   loss = sum(losses.values())
   grads = torch.autograd.grad(loss, req, allow_unused=True)
   grads = [torch.zeros_like(p) if g is None else g for g, p in zip(grads, req)]

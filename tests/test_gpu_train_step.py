@@ -276,3 +276,14 @@ def test_robustnerf_device_side_threshold_feedback():
     runs.append((np.stack(seen), state.flat.clone()))
   assert np.array_equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
   assert not np.allclose(runs[0][0][0], 1.0)              # the thresholds did move away from the initial 1
+
+
+def test_train_step_weight_decay():
+  """train_utils.py:444-447: weight_decay_mults over a module, a layer and a single leaf -- loss term and gradients."""
+  gin = SMALL + ["Config.weight_decay_mults = {'NerfMLP_0': 0.01, 'PropMLP_0/Dense_1': 0.1, 'PropMLP_0/Dense_0/bias': 0.5}"]
+  _run_case(gin, n_patch=2)
+  from nerf_hugs_amd.internal import configs, train_utils
+  configs.clear_config()
+  configs.parse_config_files_and_bindings(None, SMALL + ["Config.weight_decay_mults = {'NoSuchMLP': 1.0}"])
+  with pytest.raises(KeyError):
+    train_utils.setup_model(configs.make_config(), 0, compute_dtype='fp32')
