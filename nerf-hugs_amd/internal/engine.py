@@ -61,15 +61,20 @@ class MLPSpec:
     self.Fp = _round_up(self.F, 64)
     self.nd = 3 + 6 * self.deg_view
     # Dense layers in flax creation order: (name, fan_in, fan_in_padded, fan_out, kind)
-    L, k = [], self.F
+    # Trunk widths that are not a multiple of the 128-column MFMA tile (debug.gin's 64-wide PropMLP) are padded with
+    # zero output columns / zero bias: relu(0) = 0 feeds zero rows of the next kernel, and every gradient of the
+    # padding is exactly 0, so it stays 0 under Adam.
+    self.Wp = _round_up(self.net_width, 128)
+    L, k, kp = [], self.F, _round_up(self.F, 64)
     for i in range(self.net_depth):
       concat_in = i > 0 and (i - 1) % self.skip_layer == 0 and (i - 1) > 0
-      L.append(dict(fan_in=k, kpad=(self.net_width + self.Fp) if concat_in else (_round_up(k, 64)),
-                    fan_out=self.net_width, kind='trunk', concat=concat_in))
+      L.append(dict(fan_in=k, kpad=(self.Wp + self.Fp) if concat_in else kp, fan_out=self.net_width, npad=self.Wp,
+                    kind='trunk', concat=concat_in))
       k = self.net_width + self.F if (i % self.skip_layer == 0 and i > 0) else self.net_width
-    L.append(dict(fan_in=k, kpad=k, fan_out=1, kind='density'))
+      kp = self.Wp
+    L.append(dict(fan_in=k, kpad=kp, fan_out=1, kind='density'))
     if not self.disable_rgb:
-      L.append(dict(fan_in=k, kpad=k, fan_out=self.bottleneck_width, kind='bottleneck'))
+      L.append(dict(fan_in=k, kpad=kp, fan_out=self.bottleneck_width, kind='bottleneck'))
       kv = self.bottleneck_width + self.nd + self.num_glo
       L.append(dict(fan_in=kv, kpad=kv, fan_out=self.net_width_viewdirs, kind='view'))
       L.append(dict(fan_in=self.net_width_viewdirs, kpad=self.net_width_viewdirs, fan_out=self.num_rgb_channels, kind='rgb'))
@@ -90,8 +95,10 @@ class MLPSpec:
     d = self.net_depth
     if (d - 1) > 0 and (d - 1) % self.skip_layer == 0:
       raise NotImplementedError('a skip-concat after the last trunk layer is not built')
-    if self.net_width % 128 or (not self.disable_rgb and (self.bottleneck_width % 128 or self.net_width_viewdirs != 128)):
-      raise NotImplementedError('MLP widths must be multiples of 128 (view width == 128) for the MFMA tiles')
+    if not self.disable_rgb and (self.bottleneck_width % 128 or self.net_width_viewdirs != 128):
+      raise NotImplementedError('bottleneck_width must be a multiple of 128 and net_width_viewdirs == 128 (MFMA tiles)')
+    if self.net_width % 128 and self.net_depth > self.skip_layer + 1:
+      raise NotImplementedError('a trunk width that is not a multiple of 128 together with a skip concat is not built')
     if self.min_deg_point != 0 or self.net_depth_viewdirs != 1 or self.num_rgb_channels != 3:
       raise NotImplementedError('min_deg_point != 0 / net_depth_viewdirs != 1 / num_rgb_channels != 3 are not built')
     if self.num_tra > 0 and (self.disable_rgb or self.net_width_transient != 128 or self.net_depth_transient < 2 or
@@ -148,7 +155,8 @@ class ParamLayout:
       for l in spec.layers:
         for kind in ('kernel', 'bias'):
           shape = (l['fan_in'], l['fan_out']) if kind == 'kernel' else (l['fan_out'],)
-          pshape = (l['kpad'], l['fan_out']) if kind == 'kernel' else (l['fan_out'],)
+          npad = l.get('npad', l['fan_out'])
+          pshape = (l['kpad'], npad) if kind == 'kernel' else (npad,)
           n = int(np.prod(pshape))
           self.leaves.append(dict(path=(spec.name, l['name'], kind), off=off, shape=shape, pshape=pshape,
                                   module=mid, leaf=len(self.leaves), layer=l, spec=spec))
@@ -184,6 +192,10 @@ class ParamLayout:
 
   def view(self, flat, path, padded=False):
     lf = self.by_path[path]
+    if not padded and len(lf['shape']) == 2 and lf['pshape'][1] != lf['shape'][1]:
+      # zero-padded output columns: the logical kernel is a strided window of the stored one
+      n = int(np.prod(lf['pshape']))
+      return flat[lf['off']:lf['off'] + n].view(*lf['pshape'])[:lf['shape'][0], :lf['shape'][1]]
     shp = lf['pshape'] if padded else lf['shape']
     n = int(np.prod(shp))
     return flat[lf['off']:lf['off'] + n].view(*shp)
@@ -248,7 +260,7 @@ class Engine:
       l = lf['layer']
       W = self.layout.view(theta, lf['path'], padded=True)
       K = l['kpad'] if l['kind'] not in ('view', 'tview') else lf['spec'].bottleneck_width   # GEMM part of the layer
-      N = l['fan_out']
+      N = l.get('npad', l['fan_out'])
       key = lf['path']
       if key not in self.wt:
         self.wt[key] = torch.empty(N, K, dtype=self.tdt, device=self.device)
@@ -273,11 +285,11 @@ class Engine:
               dt, spec.Fp, X0)
     acts = [X0]
     x = X0
-    W = spec.net_width
+    W = spec.Wp
     for i in range(spec.net_depth):
       l = spec.layers[i]
       path = (spec.name, l['name'], 'kernel')
-      bias = lay.view(theta, (spec.name, l['name'], 'bias'))
+      bias = lay.view(theta, (spec.name, l['name'], 'bias'), padded=True)
       Y = ws.get(f'{tag}/Y{i}', (M, W), self.tdt)
       if l['concat']:
         _lib.call('hugs_gemm_nt', dt, M, W, W, spec.Fp, x, W, X0, spec.Fp, self.wt[path], l['kpad'], bias, None, 1, 0, 1,
@@ -291,7 +303,7 @@ class Engine:
     ld = spec.layers[spec.net_depth]
     raw = ws.get(tag + '/raw', (M,))
     density = ws.get(tag + '/density', (M,))
-    wd = lay.view(theta, (spec.name, ld['name'], 'kernel')).reshape(-1)
+    wd = lay.view(theta, (spec.name, ld['name'], 'kernel'), padded=True).reshape(-1)
     bd = lay.view(theta, (spec.name, ld['name'], 'bias'))
     _lib.call('hugs_density_fwd', dt, M, W, x, W, wd, bd, spec.density_bias, raw, density)
     out = dict(X0=X0, acts=acts, raw=raw, density=density, rgb=None)
@@ -436,7 +448,7 @@ class Engine:
     spec, S, lay, ws, dt = lv['spec'], lv['S'], self.layout, self.ws, self.dt
     M = N * S
     tag = f'{spec.name}/bwd'
-    W = spec.net_width
+    W = spec.Wp
     gview = lambda p, padded=False: lay.view(grad, p, padded)
     d_density = ws.get(tag + '/d_density', (M,))
     d_rgb_s = ws.get(tag + '/d_rgb_s', (M, 3)) if lv['rgb'] is not None else None
@@ -454,8 +466,8 @@ class Engine:
     d_raw = ws.get(tag + '/d_raw', (M,))
     dws = ws.get('dens_ws', (max(_lib.lib().cdll.hugs_density_bwd_ws_bytes(W) // 4, 1),))
     _lib.call('hugs_density_bwd', dt, M, W, Ylast, W, d_density, lv['raw'], spec.density_bias, d_raw,
-              gview((spec.name, ld['name'], 'kernel')).reshape(-1), gview((spec.name, ld['name'], 'bias')), dws)
-    wd = lay.view(theta, (spec.name, ld['name'], 'kernel')).reshape(-1)
+              gview((spec.name, ld['name'], 'kernel'), True).reshape(-1), gview((spec.name, ld['name'], 'bias')), dws)
+    wd = lay.view(theta, (spec.name, ld['name'], 'kernel'), padded=True).reshape(-1)
     Ga = ws.get(tag + '/Ga', (M, W), self.tdt)
     Gb = ws.get(tag + '/Gb', (M, W), self.tdt)
     if spec.disable_rgb:
@@ -487,7 +499,7 @@ class Engine:
         # dBott = Gv Wv[:Bw]^T
         _lib.call('hugs_gemm_nt', dt, M, Bw, H, 0, Gv, H, None, 0, self.wn[(spec.name, lvw['name'], 'kernel')], H, None,
                   None, 1, 0, 0, None, 0, None, None, dB, Bw)
-      self._tn(M, W, Bw, Ylast, W, dB, Bw, gview((spec.name, lb['name'], 'kernel')), gview((spec.name, lb['name'], 'bias')))
+      self._tn(M, W, Bw, Ylast, W, dB, Bw, gview((spec.name, lb['name'], 'kernel'), True), gview((spec.name, lb['name'], 'bias')))
       # G_last = (dBott Wb^T + d_raw (x) w_d) * (Ylast > 0)
       _lib.call('hugs_gemm_nt', dt, M, W, Bw, 0, dB, Bw, None, 0, self.wn[(spec.name, lb['name'], 'kernel')], Bw, None, None,
                 1, 0, 0, Ylast, W, d_raw, wd, Ga, W)
@@ -509,7 +521,7 @@ class Engine:
       l = spec.layers[i]
       path = (spec.name, l['name'], 'kernel')
       gW = gview(path, padded=True)
-      gb = gview((spec.name, l['name'], 'bias'))
+      gb = gview((spec.name, l['name'], 'bias'), True)
       xin = acts[i]          # acts[0] = X0, acts[i] = Y_{i-1}
       with torch.cuda.stream(side):
         side.wait_event(ev_g)                       # G_i is ready

@@ -196,8 +196,7 @@ def test_every_reference_gin_file_parses():
     except NotImplementedError:
       refused.append(os.path.basename(f))
   configs.clear_config()
-  # debug.gin asks for a 64-wide PropMLP: MLP widths must be multiples of the 128-column MFMA tile
-  assert built >= 16 and refused == ['debug.gin'], refused
+  assert built == len(files) and refused == [], refused      # (debug.gin's 64-wide PropMLP is zero-padded to a tile)
 
 
 def test_ctypes_prototypes_match_the_header():

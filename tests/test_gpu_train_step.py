@@ -287,3 +287,24 @@ def test_train_step_weight_decay():
   configs.parse_config_files_and_bindings(None, SMALL + ["Config.weight_decay_mults = {'NoSuchMLP': 1.0}"])
   with pytest.raises(KeyError):
     train_utils.setup_model(configs.make_config(), 0, compute_dtype='fp32')
+
+
+def test_train_step_debug_gin_shape():
+  """configs/debug.gin: PropMLP 2 x 64 (colour branch on), NerfMLP 4 x 128.  A 64-wide trunk is stored zero-padded to
+  the 128-column tile; losses, every LOGICAL gradient and the update match the oracle, and the padding stays zero."""
+  gin = [g for g in SMALL if 'net_' not in g and 'disable_rgb' not in g] + [
+      "PropMLP.net_depth = 2", "PropMLP.net_width = 64", "NerfMLP.net_depth = 4", "NerfMLP.net_width = 128",
+      "Config.data_coarse_loss_mult = 0.1"]
+  _run_case(gin, n_patch=2)
+  from tests import hugs_testlib as H
+  config, model, state, _, train_step, _, _ = H.make_pair(gin)
+  lf = model.layout.by_path[('PropMLP_0', 'Dense_0', 'kernel')]
+  assert lf['shape'] == (504, 64) and lf['pshape'] == (512, 128)
+  assert model.layout.view(state.flat, lf['path']).shape == (504, 64)
+  gen = torch.Generator(device='cuda').manual_seed(0)
+  for _ in range(3):
+    state, _, gen = train_step(gen, state, H.synth_rays(2, 8, 1), 0.3, None)
+  full = model.layout.view(state.flat, lf['path'], padded=True)
+  assert float(full[:, 64:].abs().max()) == 0 and float(full[504:].abs().max()) == 0 and float(full[:504, :64].abs().max()) > 0
+  b = model.layout.view(state.flat, ('PropMLP_0', 'Dense_1', 'bias'), padded=True)
+  assert b.shape == (128,) and float(b[64:].abs().max()) == 0
