@@ -140,8 +140,8 @@ def eval_psnr_vs_oracle(model, state, batch, dtype):
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=20)
-  ap.add_argument('--warmup', type=int, default=5)
+  ap.add_argument('--steps', type=int, default=30)
+  ap.add_argument('--warmup', type=int, default=10)
   ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3', 'cfg4'],
