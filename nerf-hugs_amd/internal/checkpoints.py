@@ -92,4 +92,6 @@ def restore_checkpoint(ckpt_dir, state):
   model.load_variables(state.m, {'params': adam['mu'].get('params', adam['mu'])})
   model.load_variables(state.v, {'params': adam['nu'].get('params', adam['nu'])})
   state.step = int(np.asarray(d['step']))
+  if getattr(model, '_engine', None) is not None:      # the compute-dtype weight copies follow the restored masters
+    model._engine.refresh_weights(state.flat)
   return state

@@ -60,3 +60,29 @@ def test_training_is_bit_reproducible():
     torch.cuda.synchronize()
     finals.append((state.flat.clone(), float(stats['loss'])))
   assert torch.equal(finals[0][0], finals[1][0]) and finals[0][1] == finals[1][1]
+
+
+def test_checkpoint_resume_is_bit_exact(tmp_path):
+  """train.py:121,232-236: save after 3 steps, restore into a freshly built state (same process or a new one) and
+  continue: parameters, Adam moments and the PRNG key chain equal the uninterrupted run bit for bit."""
+  from tests import hugs_testlib as H
+  from nerf_hugs_amd.internal import checkpoints, random as hr
+  from tests.test_gpu_train_step import SMALL
+  gin = SMALL          # (no GLO: the embedding scatter uses float atomics, the only order-dependent sum on the path)
+  config, model, state, _, train_step, _, _ = H.make_pair(gin, compute_dtype='bf16')
+  batches = [H.synth_rays(2, 8, 10 + i) for i in range(5)]
+  rng = hr.PRNGKey(7)
+  for i in range(3):
+    state, _, rng = train_step(rng, state, batches[i], 0.1 * i, None)
+  checkpoints.save_checkpoint(str(tmp_path), state, state.step)
+  rng_saved = rng.clone()
+  for i in range(3, 5):
+    state, _, rng = train_step(rng, state, batches[i], 0.1 * i, None)
+  ref = (state.flat.clone(), state.m.clone(), state.v.clone(), state.step)
+  config2, model2, state2, _, train_step2, _, _ = H.make_pair(gin, seed=99, compute_dtype='bf16')   # different init
+  state2 = checkpoints.restore_checkpoint(str(tmp_path), state2)
+  assert state2.step == 3
+  rng = rng_saved
+  for i in range(3, 5):
+    state2, _, rng = train_step2(rng, state2, batches[i], 0.1 * i, None)
+  assert state2.step == ref[3] and torch.equal(state2.flat, ref[0]) and torch.equal(state2.m, ref[1]) and torch.equal(state2.v, ref[2])
