@@ -180,10 +180,12 @@ typedef unsigned __attribute__((ext_vector_type(2))) u32x2_t;
 #define GL_CPAD 16   // bytes added to each row of the staged C tile (bank spread for the 8-byte fragment writes)
 
 // WN = wave columns: 4 -> 256x256 tile, 8 waves, 4-slot ring (128 KiB, 1 workgroup/CU);
-//                    2 -> 256x128 tile, 4 waves, 3-slot ring (72 KiB, 2 workgroups/CU, their epilogues and
-//                         prologues overlap each other's main loops).
+//                    2 -> 256x128 tile, 4 waves, 3-slot ring (72 KiB, 2 workgroups/CU).  The launch bound must
+//                         ask for 2 waves/SIMD here too: with "1" the compiler spread the kernel over 366
+//                         registers (AGPRs included), only ONE workgroup fitted a CU and it ran at 610 instead
+//                         of 850 TFLOP/s.
 template <int WN>
-__global__ __launch_bounds__(128 * WN, WN == 4 ? 2 : 1) void k_gemm_nt_bf16_big(
+__global__ __launch_bounds__(128 * WN, 2) void k_gemm_nt_bf16_big(
     int M, int N, int K1, int K2, const uint16_t* __restrict__ A1, int lda1, const uint16_t* __restrict__ A2, int lda2,
     const uint16_t* __restrict__ Bt, int ldb, GemmEpi E) {
   constexpr int NT = 128 * WN;                 // threads
