@@ -33,7 +33,6 @@ def _run_case(gin, n_patch=1, P=8, near=0.1, far=1.2, seed=5, inlier=None, tol_g
   ostats, ograds, orend, ohist = R.loss_and_grad(cfg, oparams, H.oracle_rays(batch), batch.rgb.reshape(-1, 3),
                                                  0.37, [u.cpu() for u in u01], othr)
   # product forward (same jitter)
-  rend, hist = model.apply(state.flat, None, batch.rays, 0.37, False) if False else (None, None)
   theta0 = state.flat.clone()
   eng = model.engine('cuda')
   eng.refresh_weights(state.flat)
