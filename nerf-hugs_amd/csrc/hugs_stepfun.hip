@@ -14,7 +14,7 @@
 // binary searches instead of compare matrices, window max over an index range.
 #include "hugs_common.h"
 
-#define SF_CAP 512  // max bins handled per ray; a level whose largest array is <= 256 uses 4 elements per lane, else 8
+#define SF_CAP 1024  // max bins handled per ray; a level whose largest array is <= 256 uses 4 elements per lane, <= 512: 8, else 16
 
 __device__ __forceinline__ float sf_expf(float x) {
   if (x != x) return x;
@@ -292,8 +292,12 @@ extern "C" int hugs_level_sample_fwd(int nrays, const float* t_prev, const float
     hipLaunchKernelGGL(k_level_sample<4>, dim3((nrays + 3) / 4), dim3(256), 0, (hipStream_t)stream, nrays, t_prev, w_prev,
                        n_prev, do_dilate, dilation, domain_lo, domain_hi, anneal, resample_padding, u_base, jitter,
                        jitter_stride, num_samples, raydist, near, far, sdist, tdist, idx_out, t_in_out, w_in_out);
-  else
+  else if (big <= 512)
     hipLaunchKernelGGL(k_level_sample<8>, dim3((nrays + 3) / 4), dim3(256), 0, (hipStream_t)stream, nrays, t_prev, w_prev,
+                       n_prev, do_dilate, dilation, domain_lo, domain_hi, anneal, resample_padding, u_base, jitter,
+                       jitter_stride, num_samples, raydist, near, far, sdist, tdist, idx_out, t_in_out, w_in_out);
+  else   // 256 samples per level (the other per-ray kernels' limit) dilate to 766 bins
+    hipLaunchKernelGGL(k_level_sample<16>, dim3((nrays + 3) / 4), dim3(256), 0, (hipStream_t)stream, nrays, t_prev, w_prev,
                        n_prev, do_dilate, dilation, domain_lo, domain_hi, anneal, resample_padding, u_base, jitter,
                        jitter_stride, num_samples, raydist, near, far, sdist, tdist, idx_out, t_in_out, w_in_out);
   HUGS_CHECK_LAUNCH("hugs_level_sample_fwd");

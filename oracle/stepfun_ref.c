@@ -28,7 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define ORC_CAP 512
+#define ORC_CAP 1024
 #define ORC_EPS 1.1920928955078125e-07f /* finfo(float32).eps */
 
 static float bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -92,8 +92,8 @@ float orc_logf(float x) {
 }
 
 /* ---- canonical "wave order" sums over n <= 256 values ---- */
-static int g_chunk = 4;   /* elements per virtual lane for the current level (4: capacity 256, 8: capacity 512) */
-static int chunk_for(int nmax) { return nmax <= 256 ? 4 : 8; }
+static int g_chunk = 4;   /* elements per virtual lane for the current level (4: capacity 256, 8: 512, 16: 1024) */
+static int chunk_for(int nmax) { return nmax <= 256 ? 4 : (nmax <= 512 ? 8 : 16); }
 static void lane_partials(const float* x, int n, float lane[64]) {
   for (int l = 0; l < 64; ++l) {
     float s = 0.0f;

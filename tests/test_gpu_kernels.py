@@ -78,6 +78,10 @@ def _run_level(N, n_prev, ns, dil, raydist, jitter, seed, wpow=1, zeros=False, a
     dict(N=300, n_prev=128, ns=32, dil=0.0064, raydist=0, jitter=True, wpow=3, zeros=True),
     dict(N=64, n_prev=128, ns=128, dil=0.0064, raydist=1, jitter=False),
     dict(N=33, n_prev=400, ns=300, dil=None, raydist=0, jitter=True, wpow=5),
+    # 256 samples per level (the per-ray kernels' limit) -> 766 dilated bins: 16-per-lane order (capacity 1024)
+    dict(N=40, n_prev=256, ns=256, dil=0.0031, raydist=1, jitter=True, wpow=3, zeros=True),
+    dict(N=17, n_prev=256, ns=64, dil=0.0031, raydist=0, jitter=False),
+    dict(N=9, n_prev=1000, ns=1024, dil=None, raydist=0, jitter=True, wpow=4),
 ])
 def test_level_sample_bit_exact_vs_oracle(case):
   _run_level(seed=3, **case)
@@ -89,8 +93,8 @@ def test_level_sample_errors_and_empty():
   with pytest.raises(ValueError):                     # stepfun.py:239-240
     stepfun.level_sample(t, w, False, 0., (0., 1.), 1., 0., 1, None, None, z, z + 1)
   from nerf_hugs_amd import _lib
-  with pytest.raises(_lib.HugsError):                  # 3*171 bins > capacity 512
-    stepfun.level_sample(torch.rand(2, 172, device=dev).sort(-1).values, torch.rand(2, 171, device=dev), True, 0.01, (0., 1.), 1., 0.,
+  with pytest.raises(_lib.HugsError):                  # 3*342 bins > capacity 1024
+    stepfun.level_sample(torch.rand(2, 343, device=dev).sort(-1).values, torch.rand(2, 342, device=dev), True, 0.01, (0., 1.), 1., 0.,
                          8, None, None, torch.zeros(2, device=dev), torch.ones(2, device=dev))
   sd, td = stepfun.level_sample(t[:0], w[:0], False, 0., (0., 1.), 1., 0., 8, None, None, z[:0], z[:0])
   assert sd.shape == (0, 9)
