@@ -307,3 +307,11 @@ def test_train_step_debug_gin_shape():
   assert float(full[:, 64:].abs().max()) == 0 and float(full[504:].abs().max()) == 0 and float(full[:504, :64].abs().max()) > 0
   b = model.layout.view(state.flat, ('PropMLP_0', 'Dense_1', 'bias'), padded=True)
   assert b.shape == (128,) and float(b[64:].abs().max()) == 0
+
+
+def test_train_step_256_samples_per_level():
+  """The largest sample counts the per-ray kernels take (256 per level; the second level resamples 766 dilated bins
+  through the 16-per-lane sampler order): losses and gradients against the oracle."""
+  gin = [g for g in SMALL if 'num_' not in g] + ["Model.num_levels = 2", "Model.num_prop_samples = 256",
+                                                  "Model.num_nerf_samples = 256"]
+  _run_case(gin, n_patch=1, P=4)
