@@ -44,8 +44,10 @@ class Model:
       raise ValueError('ray_shape must be \'cone\' or \'cylinder\'')
     if self.bg_intensity_range[0] != self.bg_intensity_range[1]:
       raise NotImplementedError('randomised background intensity is not built (all HuGS gins use (1, 1))')
-    if not self.stop_level_grad or not self.use_viewdirs or self.disable_integration or self.use_gpu_resampling:
-      raise NotImplementedError('stop_level_grad=False / use_viewdirs=False / disable_integration / use_gpu_resampling')
+    # use_gpu_resampling only picks between two XLA formulations of the same inverse-CDF lookup (stepfun.py:153-161,
+    # math.py:101-127); there is one HIP formulation, so the flag is accepted and has no effect.
+    if not self.stop_level_grad or not self.use_viewdirs or self.disable_integration:
+      raise NotImplementedError('stop_level_grad=False / use_viewdirs=False / disable_integration')
     self.bg_intensity = float(self.bg_intensity_range[0])
     rd = self.raydist_fn
     self.raydist = None if rd is None else {'jnp.reciprocal': 'reciprocal'}.get(getattr(rd, 'name', rd), getattr(rd, 'name', rd))
