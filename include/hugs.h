@@ -203,6 +203,19 @@ int hugs_rank1_add2_mask(int dtype, int M, int N, const float* r1, const float* 
 int hugs_nerfw_loss(int N, int L, const float* pred, const float* gt, const float* beta, int charb, float charb_pad,
                     const float* coef, float beta_mult, float* d_pred, float* d_beta, float* out_stats, void* stream);
 
+/* ---- nerfacto encodings (groundwork; PARITY UNPINNED: tiny-cuda-nn is not available, the
+ * algorithm is restated in oracle/hashgrid_ref.py).  nerfacto/models/nerfacto.py:714-733,761-770,921-947 HashGrid:
+ * x01 [n,3] in [0,1]; table fp32 [level_offsets[L], features]; level tables are HOST arrays (offsets [L+1] in entries,
+ * resolutions [L], scales [L]); out [n, row_pitch] (first L*features columns written) bf16 or fp32.  The backward
+ * ADDS into d_table (fp32 atomics).  nerfacto.py:693-700 SphericalHarmonics degree 4: 16 columns from col0. */
+int hugs_hashgrid_fwd(int n, int n_levels, int features, const long long* level_offsets, const int* level_resolutions,
+                      const float* level_scales, const float* x01, const float* table, int out_bf16, int row_pitch,
+                      void* out, void* stream);
+int hugs_hashgrid_bwd(int n, int n_levels, int features, const long long* level_offsets, const int* level_resolutions,
+                      const float* level_scales, const float* x01, const void* d_out, int d_out_bf16, int row_pitch,
+                      float* d_table_accum, void* stream);
+int hugs_sh4_fwd(int n, const float* dirs01, int out_bf16, int row_pitch, int col0, void* out, void* stream);
+
 /* test/bench hook: force the 128x128-tile bf16 NT kernel where the 256x256 one would be selected */
 int hugs_test_force_small_tiles(int on);
 /* test hooks: the portable exp/log of the sampler and raw IEEE ops as the device executes them */

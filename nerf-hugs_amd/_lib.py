@@ -52,6 +52,9 @@ _PROTOS = {
     'hugs_dual_composite_bwd': 'iipppppppifppfppppps',
     'hugs_rank1_add2_mask': 'iiipppppipis',
     'hugs_nerfw_loss': 'iipppifpfppps',
+    'hugs_hashgrid_fwd': 'iiippppp' 'iips',
+    'hugs_hashgrid_bwd': 'iiippppp' 'iips',
+    'hugs_sh4_fwd': 'ipiiips',
     'hugs_test_force_small_tiles': 'i',
 }
 _CT = {'i': ctypes.c_int, 'f': ctypes.c_float, 'p': ctypes.c_void_p, 'q': ctypes.c_longlong,

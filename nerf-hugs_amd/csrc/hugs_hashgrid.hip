@@ -1,0 +1,185 @@
+// Multiresolution hash-grid encoding and degree-4 spherical harmonics for the nerfacto path (SURVEY §8f row 3,
+// groundwork): what nerfacto/models/nerfacto.py:693-733,761-770,921-947 obtains from tiny-cuda-nn.  Algorithm as in
+// oracle/hashgrid_ref.py (Instant-NGP / tiny-cuda-nn HashGrid; PARITY UNPINNED: tiny-cuda-nn is not available).
+// One thread per sample walks the levels: 8 trilinear corners x F features per level gathered from the fp32 table
+// (random 8-byte reads: L2 / HBM-latency bound, not a GEMM), the [n_levels*F] row written contiguously.
+// Backward scatters with fp32 atomics (as tiny-cuda-nn does with half2 atomics).
+#include "hugs_common.h"
+
+#define HG_MAXL 32
+
+struct HgLevels {
+  uint32_t off[HG_MAXL + 1];   // first entry of each level (in entries of F floats)
+  uint32_t res[HG_MAXL];
+  float scale[HG_MAXL];
+};
+
+namespace {
+
+template <int F>
+__device__ __forceinline__ uint32_t hg_index(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t res, uint32_t entries, bool dense) {
+  uint32_t idx;
+  if (dense) idx = cx + cy * res + cz * res * res;
+  else idx = (cx * 1u) ^ (cy * 2654435761u) ^ (cz * 805459861u);
+  return idx % entries;
+}
+
+template <int F, bool BF16>
+__global__ void __launch_bounds__(256)
+k_hashgrid_fwd(int n, int L, HgLevels lv, const float* __restrict__ x, const float* __restrict__ table, int row_pitch,
+               void* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float px = x[3 * i], py = x[3 * i + 1], pz = x[3 * i + 2];
+  for (int l = 0; l < L; ++l) {
+    const uint32_t res = lv.res[l], entries = lv.off[l + 1] - lv.off[l];
+    const bool dense = (uint64_t)res * res * res <= entries;
+    const float sc = lv.scale[l];
+    const float fx = fmaf(px, sc, .5f), fy = fmaf(py, sc, .5f), fz = fmaf(pz, sc, .5f);
+    const float gx = floorf(fx), gy = floorf(fy), gz = floorf(fz);
+    const float wx = fx - gx, wy = fy - gy, wz = fz - gz;
+    const uint32_t cx = (uint32_t)(int)gx, cy = (uint32_t)(int)gy, cz = (uint32_t)(int)gz;
+    const float* tb = table + (size_t)lv.off[l] * F;
+    float acc[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float w = ((c & 1) ? wx : 1.f - wx) * ((c & 2) ? wy : 1.f - wy) * ((c & 4) ? wz : 1.f - wz);
+      const uint32_t idx = hg_index<F>(cx + (c & 1), cy + ((c >> 1) & 1), cz + ((c >> 2) & 1), res, entries, dense);
+#pragma unroll
+      for (int f = 0; f < F; ++f) acc[f] += w * tb[(size_t)idx * F + f];
+    }
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      if (BF16) ((uint16_t*)out)[(size_t)i * row_pitch + l * F + f] = f_to_bf16(acc[f]);
+      else ((float*)out)[(size_t)i * row_pitch + l * F + f] = acc[f];
+    }
+  }
+}
+
+template <int F, bool BF16>
+__global__ void __launch_bounds__(256)
+k_hashgrid_bwd(int n, int L, HgLevels lv, const float* __restrict__ x, const void* __restrict__ d_out, int row_pitch,
+               float* __restrict__ d_table) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float px = x[3 * i], py = x[3 * i + 1], pz = x[3 * i + 2];
+  for (int l = 0; l < L; ++l) {
+    const uint32_t res = lv.res[l], entries = lv.off[l + 1] - lv.off[l];
+    const bool dense = (uint64_t)res * res * res <= entries;
+    const float sc = lv.scale[l];
+    const float fx = fmaf(px, sc, .5f), fy = fmaf(py, sc, .5f), fz = fmaf(pz, sc, .5f);
+    const float gx = floorf(fx), gy = floorf(fy), gz = floorf(fz);
+    const float wx = fx - gx, wy = fy - gy, wz = fz - gz;
+    const uint32_t cx = (uint32_t)(int)gx, cy = (uint32_t)(int)gy, cz = (uint32_t)(int)gz;
+    float g[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+      g[f] = BF16 ? bf16_to_f(((const uint16_t*)d_out)[(size_t)i * row_pitch + l * F + f])
+                  : ((const float*)d_out)[(size_t)i * row_pitch + l * F + f];
+    float* tb = d_table + (size_t)lv.off[l] * F;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float w = ((c & 1) ? wx : 1.f - wx) * ((c & 2) ? wy : 1.f - wy) * ((c & 4) ? wz : 1.f - wz);
+      const uint32_t idx = hg_index<F>(cx + (c & 1), cy + ((c >> 1) & 1), cz + ((c >> 2) & 1), res, entries, dense);
+#pragma unroll
+      for (int f = 0; f < F; ++f) atomicAdd(tb + (size_t)idx * F + f, w * g[f]);
+    }
+  }
+}
+
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+k_sh4(int n, const float* __restrict__ d01, int row_pitch, int col0, void* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float x = d01[3 * i] * 2.f - 1.f, y = d01[3 * i + 1] * 2.f - 1.f, z = d01[3 * i + 2] * 2.f - 1.f;
+  const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+  float o[16];
+  o[0] = 0.28209479177387814f;
+  o[1] = -0.48860251190291987f * y;
+  o[2] = 0.48860251190291987f * z;
+  o[3] = -0.48860251190291987f * x;
+  o[4] = 1.0925484305920792f * xy;
+  o[5] = -1.0925484305920792f * yz;
+  o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+  o[7] = -1.0925484305920792f * xz;
+  o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+  o[9] = 0.59004358992664352f * y * (-3.f * x2 + y2);
+  o[10] = 2.8906114426405538f * xy * z;
+  o[11] = 0.45704579946446572f * y * (1.f - 5.f * z2);
+  o[12] = 0.3731763325901154f * z * (5.f * z2 - 3.f);
+  o[13] = 0.45704579946446572f * x * (1.f - 5.f * z2);
+  o[14] = 1.4453057213202769f * z * (x2 - y2);
+  o[15] = 0.59004358992664352f * x * (-x2 + 3.f * y2);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (BF16) ((uint16_t*)out)[(size_t)i * row_pitch + col0 + k] = f_to_bf16(o[k]);
+    else ((float*)out)[(size_t)i * row_pitch + col0 + k] = o[k];
+  }
+}
+
+int fill_levels(HgLevels& lv, int L, const long long* off, const int* res, const float* scale, const char* who) {
+  HUGS_REQUIRE(L >= 1 && L <= HG_MAXL && off && res && scale, -2, "%s: %d levels (1..%d) / null level table", who, L, HG_MAXL);
+  for (int l = 0; l <= L; ++l) {
+    HUGS_REQUIRE(off[l] >= 0 && off[l] < (1ll << 32) && (l == 0 || off[l] > off[l - 1]), -2, "%s: bad level offsets", who);
+    lv.off[l] = (uint32_t)off[l];
+  }
+  for (int l = 0; l < L; ++l) { lv.res[l] = (uint32_t)res[l]; lv.scale[l] = scale[l]; }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int hugs_hashgrid_fwd(int n, int n_levels, int features, const long long* level_offsets,
+                                 const int* level_resolutions, const float* level_scales, const float* x01,
+                                 const float* table, int out_bf16, int row_pitch, void* out, void* stream) {
+  HgLevels lv;
+  int rc = fill_levels(lv, n_levels, level_offsets, level_resolutions, level_scales, "hugs_hashgrid_fwd");
+  if (rc) return rc;
+  HUGS_REQUIRE(features == 2 || features == 4, -2, "hugs_hashgrid_fwd: %d features per level (2 or 4)", features);
+  HUGS_REQUIRE(row_pitch >= n_levels * features, -2, "hugs_hashgrid_fwd: row pitch %d < %d", row_pitch, n_levels * features);
+  if (n <= 0) return 0;
+  const dim3 g((n + 255) / 256), b(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (features == 2) {
+    if (out_bf16) k_hashgrid_fwd<2, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out);
+    else k_hashgrid_fwd<2, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out);
+  } else {
+    if (out_bf16) k_hashgrid_fwd<4, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out);
+    else k_hashgrid_fwd<4, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out);
+  }
+  HUGS_CHECK_LAUNCH("k_hashgrid_fwd");
+  return 0;
+}
+
+extern "C" int hugs_hashgrid_bwd(int n, int n_levels, int features, const long long* level_offsets,
+                                 const int* level_resolutions, const float* level_scales, const float* x01,
+                                 const void* d_out, int d_out_bf16, int row_pitch, float* d_table_accum, void* stream) {
+  HgLevels lv;
+  int rc = fill_levels(lv, n_levels, level_offsets, level_resolutions, level_scales, "hugs_hashgrid_bwd");
+  if (rc) return rc;
+  HUGS_REQUIRE(features == 2 || features == 4, -2, "hugs_hashgrid_bwd: %d features per level (2 or 4)", features);
+  if (n <= 0) return 0;
+  const dim3 g((n + 255) / 256), b(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (features == 2) {
+    if (d_out_bf16) k_hashgrid_bwd<2, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum);
+    else k_hashgrid_bwd<2, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum);
+  } else {
+    if (d_out_bf16) k_hashgrid_bwd<4, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum);
+    else k_hashgrid_bwd<4, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum);
+  }
+  HUGS_CHECK_LAUNCH("k_hashgrid_bwd");
+  return 0;
+}
+
+extern "C" int hugs_sh4_fwd(int n, const float* dirs01, int out_bf16, int row_pitch, int col0, void* out, void* stream) {
+  HUGS_REQUIRE(row_pitch >= col0 + 16 && col0 >= 0, -2, "hugs_sh4_fwd: row pitch %d, first column %d", row_pitch, col0);
+  if (n <= 0) return 0;
+  if (out_bf16) k_sh4<true><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, dirs01, row_pitch, col0, out);
+  else k_sh4<false><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, dirs01, row_pitch, col0, out);
+  HUGS_CHECK_LAUNCH("k_sh4");
+  return 0;
+}

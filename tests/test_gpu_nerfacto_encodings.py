@@ -1,0 +1,86 @@
+"""GPU parity of the nerfacto encodings (hash grid, SH-4) through the C ABI against oracle/hashgrid_ref.py.
+PARITY UNPINNED with respect to tiny-cuda-nn itself (not importable); the oracle restates the published algorithm and
+is cross-checked by properties here (partition of unity, grid-vertex interpolation, SH orthonormality)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _grid(**kw):
+  from nerf_hugs_amd.nerfacto import encodings as E
+  return E.HashGrid(**kw)
+
+
+@pytest.mark.parametrize('kw', [dict(n_levels=16, features_per_level=2, log2_hashmap_size=19, base_resolution=16, max_resolution=2048),
+                                dict(n_levels=5, features_per_level=2, log2_hashmap_size=17, base_resolution=16, max_resolution=128),
+                                dict(n_levels=8, features_per_level=4, log2_hashmap_size=14, base_resolution=16, max_resolution=1024)])
+def test_hashgrid_forward_backward_vs_oracle(kw):
+  from oracle import hashgrid_ref as H
+  g = _grid(**kw)
+  F = kw['features_per_level']
+  offs, ress, scales = H.level_table(kw['n_levels'], kw['base_resolution'],
+                                     np.exp((np.log(kw['max_resolution']) - np.log(kw['base_resolution'])) / (kw['n_levels'] - 1)),
+                                     kw['log2_hashmap_size'])
+  assert np.array_equal(offs, g.offsets) and np.array_equal(ress, g.resolutions) and np.array_equal(scales, g.scales)
+  rng = np.random.default_rng(0)
+  n = 3000
+  x = rng.uniform(size=(n, 3)).astype(np.float32)
+  x[:4] = [[0, 0, 0], [1, 1, 1], [0, 1, 0.5], [0.999999, 0, 1]]            # domain corners / faces
+  g.table.copy_(torch.from_numpy(rng.normal(size=(g.n_entries, F)).astype(np.float32)))
+  table = g.table.cpu().numpy()
+  want = H.hashgrid_forward(x, table, offs, ress, scales, F)
+  xt = torch.from_numpy(x).cuda()
+  got = g.forward(xt, dtype=torch.float32).cpu().numpy()
+  assert np.abs(got - want).max() < 2e-5 * max(1, np.abs(want).max())
+  got16 = g.forward(xt, dtype=torch.bfloat16).float().cpu().numpy()
+  assert np.abs(got16 - want).max() < 1e-2 * max(1, np.abs(want).max())
+  # backward: d table = scatter of trilinear weights * d_out
+  d_out = rng.normal(size=want.shape).astype(np.float32)
+  gw = H.hashgrid_backward(x, d_out, g.n_entries, offs, ress, scales, F)
+  d_table = torch.zeros_like(g.table)
+  g.backward(xt, torch.from_numpy(d_out).cuda(), d_table)
+  err = np.abs(d_table.cpu().numpy() - gw).max()
+  assert err < 1e-4 * max(1, np.abs(gw).max()), err
+  # <forward(table), d_out> is linear in the table: its gradient is exactly the backward
+  t2 = rng.normal(size=table.shape).astype(np.float32)
+  lhs = float((H.hashgrid_forward(x, t2, offs, ress, scales, F) * d_out).sum())
+  assert abs(lhs - float((gw * t2).sum())) < 1e-6 * abs(lhs) + 1e-6
+
+
+def test_hashgrid_properties():
+  g = _grid(n_levels=6, features_per_level=2, log2_hashmap_size=15, base_resolution=8, max_resolution=256)
+  rng = np.random.default_rng(1)
+  x = torch.from_numpy(rng.uniform(size=(2000, 3)).astype(np.float32)).cuda()
+  # partition of unity: a constant table interpolates to that constant on every level
+  g.table.fill_(0.75)
+  out = g.forward(x, dtype=torch.float32)
+  assert float((out - 0.75).abs().max()) < 1e-6
+  # at a vertex of a DENSE level the lookup returns that vertex's entry exactly
+  res0, sc0 = int(g.resolutions[0]), float(g.scales[0])
+  g.table.copy_(torch.randn(g.table.shape, device='cuda', generator=torch.Generator(device='cuda').manual_seed(0)))
+  v = torch.tensor([[2, 3, 1], [0, 0, 0], [res0 - 2, 1, 4]], dtype=torch.float32, device='cuda')
+  xv = (v - 0.5 + 1e-4) / sc0               # pos = x*scale + 0.5 -> cell = v, weight ~ 1e-4
+  out = g.forward(xv, dtype=torch.float32)[:, :2]
+  idx = (v[:, 0] + v[:, 1] * res0 + v[:, 2] * res0 * res0).long()
+  assert float((out - g.table[idx]).abs().max()) < 2e-3
+  # errors
+  from nerf_hugs_amd.nerfacto import encodings as E
+  with pytest.raises(ValueError):
+    E.HashGrid(features_per_level=3)
+
+
+def test_sh4_vs_oracle_and_orthonormal():
+  from nerf_hugs_amd.nerfacto import encodings as E
+  from oracle import hashgrid_ref as H
+  rng = np.random.default_rng(2)
+  v = rng.normal(size=(200000, 3)); v /= np.linalg.norm(v, axis=-1, keepdims=True)
+  d01 = ((v + 1) / 2).astype(np.float32)
+  got = E.spherical_harmonics4(torch.from_numpy(d01).cuda(), dtype=torch.float32).cpu().numpy().astype(np.float64)
+  assert np.abs(got - H.sh4(d01)).max() < 2e-6
+  gram = got.T @ got / len(v) * 4 * np.pi                                   # Monte-Carlo inner products on the sphere
+  assert np.abs(gram - np.eye(16)).max() < 2e-2
+  out = torch.zeros(5, 32, device='cuda', dtype=torch.bfloat16)
+  E.spherical_harmonics4(torch.from_numpy(d01[:5]).cuda(), out=out, col0=16)
+  assert float(out[:, :16].abs().max()) == 0 and float((out[:, 16:].float().cpu() - torch.from_numpy(got[:5]).float()).abs().max()) < 1e-2
