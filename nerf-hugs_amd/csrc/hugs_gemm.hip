@@ -477,53 +477,63 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(int Mrows, int Kc, int 
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float csum = 0.f;  // column sums of G (bias gradient), tiles with c0 == 0 only
+  // Column sums of G (the bias gradient), tiles with c0 == 0 only: four extra MFMAs per 32 rows against an all-ones
+  // fragment in the waves with wk == 0 (both wk waves read the same G fragments).  The role is chosen ONCE outside
+  // the loop so that the loop body stays a single basic block.
   const bool do_colsum = colsum_slab && c0 == 0;
+  f32x4_t accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accb[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t ones;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) ones[q] = (__bf16)1.0f;
 
   stage(0, 0);
   const int g = lane >> 4, s = lane & 15;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    __syncthreads();
-    if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
-    const unsigned char* lx = lds + buf * 2 * GB_TILE_BYTES;
-    const unsigned char* lg = lx + GB_TILE_BYTES;
+  auto run = [&](auto role) {
+    constexpr bool COLSUM = decltype(role)::value;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      __syncthreads();
+      if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+      const unsigned char* lx = lds + buf * 2 * GB_TILE_BYTES;
+      const unsigned char* lg = lx + GB_TILE_BYTES;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8_t ga[4], xb[4];
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8_t ga[4], xb[4];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int row = kk * 32 + h * 16 + g * 4 + (s >> 2);
-        const int sw = row & 7;
+        for (int h = 0; h < 2; ++h) {
+          const int row = kk * 32 + h * 16 + g * 4 + (s >> 2);
+          const int sw = row & 7;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int q = (wn * 64 + i * 16) >> 4;  // 32-byte granule of the fragment's 16 columns
-          bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-              (bf16x4_t __attribute__((address_space(3)))*)(lg + row * 256 + ((q ^ sw) << 5) + ((s & 3) << 3)));
-          ga[i][h * 4 + 0] = v[0]; ga[i][h * 4 + 1] = v[1]; ga[i][h * 4 + 2] = v[2]; ga[i][h * 4 + 3] = v[3];
+          for (int i = 0; i < 4; ++i) {
+            const int q = (wn * 64 + i * 16) >> 4;  // 32-byte granule of the fragment's 16 columns
+            bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (bf16x4_t __attribute__((address_space(3)))*)(lg + row * 256 + ((q ^ sw) << 5) + ((s & 3) << 3)));
+            ga[i][h * 4 + 0] = v[0]; ga[i][h * 4 + 1] = v[1]; ga[i][h * 4 + 2] = v[2]; ga[i][h * 4 + 3] = v[3];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int q = (wk * 64 + j * 16) >> 4;
+            bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (bf16x4_t __attribute__((address_space(3)))*)(lx + row * 256 + ((q ^ sw) << 5) + ((s & 3) << 3)));
+            xb[j][h * 4 + 0] = v[0]; xb[j][h * 4 + 1] = v[1]; xb[j][h * 4 + 2] = v[2]; xb[j][h * 4 + 3] = v[3];
+          }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int q = (wk * 64 + j * 16) >> 4;
-          bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-              (bf16x4_t __attribute__((address_space(3)))*)(lx + row * 256 + ((q ^ sw) << 5) + ((s & 3) << 3)));
-          xb[j][h * 4 + 0] = v[0]; xb[j][h * 4 + 1] = v[1]; xb[j][h * 4 + 2] = v[2]; xb[j][h * 4 + 3] = v[3];
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[i], xb[j], acc[i][j], 0, 0, 0);
+        if constexpr (COLSUM) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[i], ones, accb[i], 0, 0, 0);
         }
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[i], xb[j], acc[i][j], 0, 0, 0);
     }
-    if (do_colsum && tid < 128) {  // column tid of the G tile, 64 rows
-      const int q = tid >> 4, w = (tid & 15) * 2;
-      float a = 0.f;
-#pragma unroll 8
-      for (int row = 0; row < 64; ++row) a += bf16_to_f(*(const uint16_t*)(lg + row * 256 + ((q ^ (row & 7)) << 5) + w));
-      csum += a;
-    }
-  }
+  };
+  if (do_colsum && wk == 0) run(std::true_type{});
+  else run(std::false_type{});
   float* out = slab + (size_t)split * Kc * lds_out;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -533,7 +543,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(int Mrows, int Kc, int 
       const int n = n0 + wn * 64 + i * 16 + g * 4;
       *(float4*)(out + (size_t)c * lds_out + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
     }
-  if (do_colsum && tid < 128) colsum_slab[(size_t)split * N + n0 + tid] = csum;
+  if (do_colsum && wk == 0 && s == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *(float4*)(colsum_slab + (size_t)split * N + n0 + wn * 64 + i * 16 + g * 4) =
+          make_float4(accb[i][0], accb[i][1], accb[i][2], accb[i][3]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
