@@ -514,7 +514,8 @@ def model_forward(cfg, variables, rays, train_frac, u01, compute_extras, zero_gl
   P = variables['params']
   dt = rays['origins'].dtype
   N = rays['origins'].shape[0]
-  basis = torch.tensor(generate_basis(cfg.basis_shape, cfg.basis_subdivisions).T.copy(), dtype=dt)  # [3,nb]
+  # models.py:393-396: jnp.array(generate_basis(...)).T is a float32 constant whatever the compute dtype
+  basis = torch.tensor(generate_basis(cfg.basis_shape, cfg.basis_subdivisions).T.astype(np.float32)).to(dt)  # [3,nb]
   glo = None
   if cfg.num_glo_features > 0:
     glo = (torch.zeros(N, cfg.num_glo_features, dtype=dt) if zero_glo else
@@ -668,7 +669,10 @@ def robustnerf_mask(cfg, errors, thr):
   stats['is_inlier_loss'] = inl.mean()
   f = cfg.robustnerf_smoothed_filter_size
   win = torch.ones(1, 1, f, f, dtype=err.dtype) / (f * f)
-  nb = torch.nn.functional.conv2d(inl.permute(0, 3, 1, 2), win, padding=f // 2).permute(0, 2, 3, 1)
+  # lax.conv 'SAME': f-1 zero rows/cols in total, (f-1)//2 before and the rest after (asymmetric for even f)
+  lo_, hi_ = (f - 1) // 2, f - 1 - (f - 1) // 2
+  nb = torch.nn.functional.conv2d(torch.nn.functional.pad(inl.permute(0, 3, 1, 2), (lo_, hi_, lo_, hi_)),
+                                  win).permute(0, 2, 3, 1)
   nb = (nb > 1 - cfg.robustnerf_smoothed_inlier_quantile).to(err.dtype)
   stats['has_inlier_neighbors'] = nb.mean()
   ip, op = cfg.robustnerf_inner_patch_size, cfg.patch_size

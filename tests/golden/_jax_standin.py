@@ -39,13 +39,16 @@ def _small_int(a):
   return np.asarray(a).astype(np.float32)
 
 
+KEEP64 = [False]  # set while the reference's source is evaluated in float64 (central differences)
+
+
 def build():
   jnp = types.ModuleType('jax.numpy')
   for name in dir(np):
     if not name.startswith('_'):
       setattr(jnp, name, getattr(np, name))
 
-  keep64 = [False]  # set while jax.linearize evaluates fn in float64
+  keep64 = KEEP64
 
   def _f(x):
     x = np.asarray(x)
@@ -66,7 +69,7 @@ def build():
   jnp.nan_to_num = lambda x, nan=0.0, posinf=None, neginf=None: np.nan_to_num(
       x, nan=nan, posinf=posinf, neginf=neginf)
   jnp.take_along_axis = lambda a, i, axis: np.take_along_axis(a, i.astype(np.int64), axis=axis)
-  jnp.interp = lambda x, xp, fp: np.interp(x, xp, fp).astype(f32)
+  jnp.interp = lambda x, xp, fp: _f(np.interp(x, xp, fp))
   jnp.where = lambda c, a, b: _f(np.where(c, a, b))
 
   def vectorize(fn, signature=None):
@@ -125,22 +128,23 @@ def build():
 
   def linearize(fn, x):
     x64 = np.asarray(x, np.float64)
-    y = fn(np.asarray(x, f32))
-    h = 1e-6
+    y = fn(x64 if keep64[0] else np.asarray(x, f32))
+    # step relative to max(1, |x|): contract's Jacobian at |x| = 1e6 has a radial entry ~1/|x|^2 next to
+    # tangential entries ~1/|x|; an absolute 1e-6 step loses the radial one in float64 rounding.
+    h = 1e-4 * np.maximum(1.0, np.linalg.norm(x64, axis=-1, keepdims=True))
 
     def lin(v):
       v64 = np.asarray(v, np.float64)
-      # float64 evaluation of the same source: the reference functions are
-      # dtype-generic, eps clamps (finfo float32) stay as written.  The step is
-      # relative to |v| so that huge covariances (far=1e6) stay in the linear
-      # regime of fn.
+      # float64 evaluation of the same source: the reference functions are dtype-generic, eps clamps
+      # (finfo float32) stay as written.  The tangent is normalised so that huge covariances (far=1e6)
+      # stay in the linear regime of fn.
       scale = np.maximum(np.linalg.norm(v64, axis=-1, keepdims=True), 1e-30)
-      keep64[0] = True
+      prev, keep64[0] = keep64[0], True
       try:
         jv = (fn(x64 + h * v64 / scale) - fn(x64 - h * v64 / scale)) / (2 * h) * scale
       finally:
-        keep64[0] = False
-      return jv.astype(f32)
+        keep64[0] = prev
+      return jv if prev else jv.astype(f32)
 
     return y, lin
 

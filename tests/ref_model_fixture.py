@@ -1,0 +1,107 @@
+"""Reader for tests/golden/ref_model.npz (the reference's own models.py / train_utils.py executed
+under the numpy stand-ins; generator tests/golden/gen_model_fixtures.py).  Shared by the CPU test of the
+oracle and the GPU test of the HIP path.  Data only: nothing here touches /root/reference."""
+import json
+import os
+
+import numpy as np
+import torch
+
+_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_model.npz')
+_NPZ = None
+CASES = ('base', 'withmask', 'robust', 'nerfw', 'hanerf')
+RAY_FIELDS = ('pix_coords', 'origins', 'directions', 'viewdirs', 'radii', 'lossmult', 'static_mask', 'near', 'far',
+              'embed_idx', 'cam_idx')
+
+
+def npz():
+  global _NPZ
+  if _NPZ is None:
+    _NPZ = np.load(_PATH)
+  return _NPZ
+
+
+def spec(case):
+  return json.loads(str(npz()[f'{case}/spec']))
+
+
+def get(case, key):
+  return npz()[f'{case}/{key}']
+
+
+def keys(case, prefix):
+  p = f'{case}/{prefix}'
+  return [k[len(p):] for k in npz().files if k.startswith(p)]
+
+
+def flat_params(case):
+  return {k: npz()[f'{case}/params/{k}'] for k in keys(case, 'params/')}
+
+
+def param_tree(case, dtype=torch.float32):
+  tree = {}
+  for k, v in flat_params(case).items():
+    d = tree
+    parts = k.split('/')
+    for p in parts[:-1]:
+      d = d.setdefault(p, {})
+    d[parts[-1]] = torch.from_numpy(v.copy()).to(dtype)
+  return {'params': tree}
+
+
+def seeded_tree(case, seed, scale=1.0):
+  """The generator's direction / synthetic-gradient convention: leaves in sorted key order, one
+  standard_normal(shape) float64 draw each from default_rng(seed)."""
+  fp = flat_params(case)
+  rng = np.random.default_rng(seed)
+  return {k: rng.standard_normal(fp[k].shape) * scale for k in sorted(fp)}
+
+
+def rays_flat(case, dtype=torch.float32):
+  """dict of [N,c] tensors (oracle.torch_ref convention)."""
+  out = {}
+  for f in RAY_FIELDS:
+    a = get(case, f'rays/{f}')
+    t = torch.from_numpy(a.reshape(-1, a.shape[-1]).copy())
+    out[f] = t if f in ('embed_idx', 'cam_idx') else t.to(dtype)
+  return out
+
+
+def u01(case, L):
+  return [torch.from_numpy(get(case, f'l{l}_u01').copy()) for l in range(L)]
+
+
+def oracle_cfg(case):
+  """spec -> oracle.torch_ref.ModelCfg (same knob names the reference's gin bindings use)."""
+  from oracle import torch_ref as R
+  s = spec(case)
+  c, m, n, p = s['Config'], s['Model'], s['NerfMLP'], s['PropMLP']
+  kw = dict(
+      num_prop_samples=m['num_prop_samples'], num_nerf_samples=m['num_nerf_samples'], num_levels=m['num_levels'],
+      raydist_fn='reciprocal' if m.get('raydist_fn') == '@jnp.reciprocal' else None,
+      num_glo_features=m.get('num_glo_features', 0), num_transient_features=m.get('num_transient_features', 0),
+      num_embeddings=m['num_embeddings'], opaque_background=m['opaque_background'],
+      warp=n.get('warp_fn') == '@coord.contract',
+      nerf_depth=n['net_depth'], nerf_width=n['net_width'], bottleneck_width=n['bottleneck_width'],
+      width_viewdirs=n['net_width_viewdirs'], prop_depth=p['net_depth'], prop_width=p['net_width'],
+      prop_disable_rgb=p['disable_rgb'])
+  for k in ('data_loss_type', 'distortion_loss_mult', 'transient_type', 'patch_size', 'withmask_transient_weight',
+            'grad_max_norm', 'grad_max_val', 'robustnerf_inlier_quantile', 'max_steps'):
+    if k in c:
+      kw[k] = c[k]
+  cfg = R.ModelCfg(**kw)
+  if 'net_width_transient' in n:
+    cfg.transient_width = n['net_width_transient']
+  if 'ImplicitMask' in s:
+    cfg.mask_width = s['ImplicitMask'].get('net_width', 256)
+  return cfg
+
+
+def gin_lines(case):
+  """spec -> gin binding lines for the product's configs.parse_config_files_and_bindings."""
+  s = spec(case)
+  lines = []
+  for scope in ('Config', 'Model', 'NerfMLP', 'PropMLP', 'ImplicitMask'):
+    for k, v in s.get(scope, {}).items():
+      lines.append(f'{scope}.{k} = {v if isinstance(v, str) and v.startswith("@") else repr(v)}')
+  return lines
