@@ -104,6 +104,7 @@ class _Lib:
     if len(args) != len(sig) - 1:
       raise TypeError(f'{name}: expected {len(sig) - 1} args (+stream), got {len(args)}')
     conv = []
+    dev = -1
     for a, c in zip(args, sig):
       if c == 'p':
         if a is None:
@@ -113,6 +114,12 @@ class _Lib:
             raise HugsError(f'{name}: tensor argument is not on the GPU (no CPU fallback)')
           if not a.is_contiguous():
             raise HugsError(f'{name}: tensor argument must be contiguous')
+          if a.dtype == torch.float64:
+            raise HugsError(f'{name}: float64 tensor passed to a float32 / bf16 kernel')
+          if dev < 0:
+            dev = a.get_device()
+          elif a.get_device() != dev:
+            raise HugsError(f'{name}: tensor arguments live on different GPUs')
           conv.append(a.data_ptr())
         else:
           conv.append(int(a))
@@ -120,6 +127,11 @@ class _Lib:
         conv.append(float(a))
       else:
         conv.append(int(a))
+    if dev >= 0 and dev != torch.cuda.current_device():
+      # the kernels launch on torch's current stream of the CURRENT device: pointers of another GPU would be
+      # dereferenced there.  Engine wraps its launches in torch.cuda.device(self.device).
+      raise HugsError(f'{name}: tensors are on cuda:{dev} but the current device is cuda:{torch.cuda.current_device()} '
+                      '(use `with torch.cuda.device(...)`)')
     conv.append(_raw_stream())
     rc = getattr(self.cdll, name)(*conv)
     if rc != 0:

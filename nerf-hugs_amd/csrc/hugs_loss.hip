@@ -84,11 +84,12 @@ __global__ __launch_bounds__(256) void k_robust_mask(int npatch, int P, const fl
   const float inl = e < thr_ptr[0] ? 1.f : 0.f;
   s_inl[y][x] = inl;
   __syncthreads();
-  // f x f box filter, zero padded SAME (lax.conv), then binarise
-  const int h = fsize / 2;
+  // f x f box filter, zero padded SAME (lax.conv: f-1 pad rows in total, (f-1)/2 before, the rest after -- the
+  // window is asymmetric for an even f), then binarise
+  const int hlo = (fsize - 1) / 2, hhi = fsize - 1 - hlo;
   float nb = 0.f;
-  for (int dy = -h; dy <= h; ++dy)
-    for (int dx_ = -h; dx_ <= h; ++dx_) {
+  for (int dy = -hlo; dy <= hhi; ++dy)
+    for (int dx_ = -hlo; dx_ <= hhi; ++dx_) {
       const int yy = y + dy, xx = x + dx_;
       if (yy >= 0 && yy < P && xx >= 0 && xx < P) nb += s_inl[yy][xx];
     }

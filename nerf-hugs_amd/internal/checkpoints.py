@@ -6,8 +6,11 @@ checkpoint written by real flax is "parity unpinned" until one is available.
 
 Layout written / read:
   {'step': i32, 'params': {'params': {module: {Dense_i: {'kernel','bias'}}, 'GloEmbed_0': {'embedding'}}},
-   'opt_state': {'0': {'count': i32, 'mu': <params tree>, 'nu': <params tree>}, '1': {'count': i32}}}
-(optax.adam = chain(scale_by_adam, scale_by_schedule); tuples serialise as dicts with '0','1',... keys)."""
+   'opt_state': {'0': {'count': i32, 'mu': {'params': ...}, 'nu': {'params': ...}}, '1': {'count': i32}}}
+(optax.adam = chain(scale_by_adam, scale_by_schedule); tuples serialise as dicts with '0','1',... keys; mu / nu
+mirror TrainState.params, i.e. they carry the same outer 'params' level -- flax's restore_checkpoint(dir, state)
+matches field names against the target state, so a file without that level does not load in the reference).
+The reader accepts both forms."""
 import os
 import re
 
@@ -53,8 +56,8 @@ def _tree_np(model, flat):
 def state_dict(state):
   model = state.model
   return {'step': np.int32(state.step), 'params': _tree_np(model, state.flat),
-          'opt_state': {'0': {'count': np.int32(state.step), 'mu': _tree_np(model, state.m)['params'],
-                              'nu': _tree_np(model, state.v)['params']},
+          'opt_state': {'0': {'count': np.int32(state.step), 'mu': _tree_np(model, state.m),
+                              'nu': _tree_np(model, state.v)},
                         '1': {'count': np.int32(state.step)}}}
 
 

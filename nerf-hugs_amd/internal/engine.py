@@ -247,6 +247,7 @@ class Engine:
     self.layout = model.layout
     self.ws = Workspace(self.device)
     self.wn, self.wt = {}, {}     # compute-dtype weight copies keyed by leaf path
+    self._cast_src = None         # (data_ptr, torch version counter) of the flat buffer the copies were cast from
     self.basis = {s.name: torch.from_numpy(s.basis).to(self.device) for s in model.specs}
     self.chunks = torch.from_numpy(self.layout.chunks).to(self.device)
     self.leaf_info = torch.from_numpy(self.layout.leaf_info).to(self.device)
@@ -254,6 +255,7 @@ class Engine:
   # ---- weights ------------------------------------------------------------------------------------
   def refresh_weights(self, theta):
     """Cast the fp32 masters to the GEMM operand copies: Wn [Kp,N] (dX) and Wt [N,Kp] (forward)."""
+    self._cast_src = (theta.data_ptr(), theta._version)
     for lf in self.layout.leaves:
       if lf['path'][-1] != 'kernel' or lf['layer']['kind'] not in ('trunk', 'bottleneck', 'view', 'tview', 'ttrunk'):
         continue
@@ -273,6 +275,12 @@ class Engine:
         lv, lt = spec.layers[spec.net_depth + 2], spec.layers[spec.t0]
         self.wcat = torch.cat([self.wn[(spec.name, lv['name'], 'kernel')], self.wn[(spec.name, lt['name'], 'kernel')]],
                               1).contiguous()
+
+  def weights_current(self, theta):
+    """True when the operand copies were cast from this very buffer and torch has not written to it since
+    (Model.apply on other variables, load_variables, restore_checkpoint all change one of the two).  The step's own
+    Adam kernel writes through the raw pointer and refreshes the copies itself."""
+    return self._cast_src == (theta.data_ptr(), theta._version)
 
   # ---- forward ------------------------------------------------------------------------------------
   def _mlp_forward(self, spec, theta, lvl, N, S, tdist, rays, glo, keep, tra=None):

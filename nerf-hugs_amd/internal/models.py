@@ -60,7 +60,9 @@ class Model:
     self.specs = [self.nerf_spec, self.prop_spec]
     self.mask_spec = None
     if tt == 'hanerf':      # models.py:107: ImplicitMask() is constructed after the two MLPs
-      self.mask_spec = _engine.MaskSpec(self.num_transient_features, **configs.bindings('ImplicitMask'))
+      # ImplicitMask is not @gin.configurable in the reference (models.py:651): `ImplicitMask.*` bindings are unknown
+      # names that gin skips, so the mask MLP always has its class defaults (4 x 256, deg_coord 10)
+      self.mask_spec = _engine.MaskSpec(self.num_transient_features)
     self.layout = _engine.ParamLayout(self.specs + ([self.mask_spec] if self.mask_spec else []), self.num_embeddings,
                                       self.num_glo_features, self.num_transient_features)
     self.compute_dtype = compute_dtype or 'bf16'

@@ -128,6 +128,10 @@ def create_train_step(model, config, is_finetune=False):
         'patch_size must be larger than robustnerf_inner_patch_size.'
   if config.data_loss_type not in ('mse', 'charb'):
     assert False
+  if L > 4:
+    # the stat tail has fixed slots: [0:2L] mse / data loss per level, [8:8+L-1] interlevel, [12] distortion,
+    # [16:16+5L] robust stats -- 5 levels would make them overlap
+    raise NotImplementedError('more than 4 sampling levels: the per-step stat slots are laid out for num_levels <= 4')
   # train_utils.py:444-447: loss += sum_k m_k * ||theta_k||^2 over summarize_tree keys (a module, 'module/layer' or a
   # leaf path); the gradient 2 m_k theta is added to the leaves under each key.
   decay = []
@@ -144,6 +148,32 @@ def create_train_step(model, config, is_finetune=False):
           decay.append((lf['off'], int(np.prod(lf['pshape'])), float(mult)))
   cache = {}
 
+  def optimizer_step(state, grad, gscale=1.0):
+    """The second half of the reference's train_step on a gradient buffer in the flat layout
+    (train_utils.py:461-473): grad_norms / grad_maxes, clip_gradients per module (value clip, then norm clip with
+    `eps + norm`), nan_to_num, Adam (optax.adam: bias-corrected moments, eps outside the sqrt, schedule at the
+    0-based count), opt_update_* stats, refresh of the compute-dtype weight copies.  `gscale`: factor the kernels
+    apply to the buffer first (1/world after a SUM all-reduce).  Returns the per-leaf stat buffer."""
+    eng = model.engine(state.flat.device)
+    ws = eng.ws
+    nch, nleaf, nmod = layout.chunks.shape[0], len(layout.leaves), len(layout.modules)
+    part1 = ws.get('opt_part1', (nch * 4,))
+    leaf_stats = ws.get('leaf_stats', (nleaf * 4 + nleaf * 2 + 16,))
+    mod_scale = leaf_stats[nleaf * 6:nleaf * 6 + 16]
+    _lib.call('hugs_opt_stats', nch, nleaf, nmod, eng.chunks, eng.leaf_info, state.flat, grad, gscale, config.grad_max_val,
+              config.grad_max_norm, part1, leaf_stats[:nleaf * 4], mod_scale)
+    h = state.hyper
+    count = state.step                      # optax's 0-based update count
+    lr = h['lr_fn'](count)
+    t = count + 1
+    part2 = ws.get('opt_part2', (nch * 2,))
+    _lib.call('hugs_opt_adam', nch, nleaf, eng.chunks, eng.leaf_info, state.flat, grad, state.m, state.v, mod_scale, h['trainable'], gscale,
+              config.grad_max_val, lr, h['b1'], h['b2'], h['eps'], 1.0 - h['b1']**t, 1.0 - h['b2']**t, part2,
+              leaf_stats[nleaf * 4:nleaf * 6])
+    eng.refresh_weights(state.flat)
+    state.step += 1
+    return leaf_stats
+
   def train_step(rng, state, batch, train_frac, inlier_thresholds):
     eng = model.engine(state.flat.device)
     dev = state.flat.device
@@ -156,11 +186,14 @@ def create_train_step(model, config, is_finetune=False):
       if (N * S_) % 128:
         raise ValueError(f'per-device batch of {N} rays x {S_} samples is not a multiple of the 128-row GEMM tile: '
                          'use a batch size that is a multiple of 4 (eval pads ragged chunks itself)')
-    if state.step == 0 and not eng.wt or cache.get('stale', True):
+    if not eng.weights_current(state.flat):
       eng.refresh_weights(state.flat)
-      cache['stale'] = False
     u01 = None
-    if hrandom.is_key(rng):                        # jax stream: rng, key = random.split(rng) (train_utils.py:408)
+    if isinstance(rng, (list, tuple)):             # explicit U[0,1) draws, one [N] (or [N,S]) tensor per level: the
+      if len(rng) != L:                            # numbers jax.random.uniform handed the reference (fixtures, tests)
+        raise ValueError(f'explicit jitter needs one tensor per level ({L}), got {len(rng)}')
+      u01 = [u.to(device=dev, dtype=torch.float32).contiguous() for u in rng]
+    elif hrandom.is_key(rng):                        # jax stream: rng, key = random.split(rng) (train_utils.py:408)
       rng, key = hrandom.split(rng)
       if config.randomized:
         u01, _ = model.level_jitter(key, N)
@@ -322,23 +355,8 @@ def create_train_step(model, config, is_finetune=False):
     gscale = 1.0 / world
     for off, n_, mult in decay:        # after pmean; the kernels below scale the buffer by gscale, hence the 1/gscale
       _lib.call('hugs_axpy', n_, 2.0 * mult / gscale, state.flat[off:off + n_], grad[off:off + n_])
-    # ---- clip + Adam --------------------------------------------------------------------------------
-    nch, nleaf, nmod = layout.chunks.shape[0], len(layout.leaves), len(layout.modules)
-    part1 = ws.get('opt_part1', (nch * 4,))
-    leaf_stats = ws.get('leaf_stats', (nleaf * 4 + nleaf * 2 + 16,))
-    mod_scale = leaf_stats[nleaf * 6:nleaf * 6 + 16]
-    _lib.call('hugs_opt_stats', nch, nleaf, nmod, eng.chunks, eng.leaf_info, state.flat, grad, gscale, config.grad_max_val,
-              config.grad_max_norm, part1, leaf_stats[:nleaf * 4], mod_scale)
-    h = state.hyper
-    count = state.step                      # optax's 0-based update count
-    lr = h['lr_fn'](count)
-    t = count + 1
-    part2 = ws.get('opt_part2', (nch * 2,))
-    _lib.call('hugs_opt_adam', nch, nleaf, eng.chunks, eng.leaf_info, state.flat, grad, state.m, state.v, mod_scale, h['trainable'], gscale,
-              config.grad_max_val, lr, h['b1'], h['b2'], h['eps'], 1.0 - h['b1']**t, 1.0 - h['b2']**t, part2,
-              leaf_stats[nleaf * 4:nleaf * 6])
-    eng.refresh_weights(state.flat)
-    state.step += 1
+    nleaf = len(layout.leaves)
+    leaf_stats = optimizer_step(state, grad, gscale)
     # ---- stats (lazy) -------------------------------------------------------------------------------
     packed = ws.get('stats_packed', (STAT_TAIL + nleaf * 6 + 16,))
     packed[:STAT_TAIL].copy_(tail)
@@ -390,6 +408,7 @@ def create_train_step(model, config, is_finetune=False):
 
     return state, LazyStats(packed, build), rng
 
+  train_step.optimizer_step = optimizer_step
   return train_step
 
 

@@ -37,7 +37,8 @@ f32 = np.float32
 HIST_KEYS = ('density', 'rgb', 'sdist', 'weights', 'density_transient', 'rgb_transient', 'uncertainty')
 
 BASE_MODEL = {'num_embeddings': 16, 'opaque_background': True}
-SMALL_NERF = {'net_depth': 8, 'net_width': 64, 'bottleneck_width': 64, 'net_width_viewdirs': 64}
+# sizes the HIP path accepts (128-column MFMA tiles; a 64-wide PropMLP exercises the zero-padded layout)
+SMALL_NERF = {'net_depth': 8, 'net_width': 128, 'bottleneck_width': 128, 'net_width_viewdirs': 128}
 SMALL_PROP = {'net_depth': 4, 'net_width': 64, 'disable_rgb': True}
 
 CASES = {
@@ -65,14 +66,14 @@ CASES = {
         Config={'transient_type': 'nerfw', 'randomized': True, 'patch_size': 4, 'distortion_loss_mult': 0.001},
         Model=dict(BASE_MODEL, num_levels=2, num_prop_samples=64, num_nerf_samples=64, num_glo_features=8,
                    num_transient_features=6),
-        NerfMLP=dict(SMALL_NERF, net_width_transient=64), PropMLP=SMALL_PROP,
+        NerfMLP=dict(SMALL_NERF, net_width_transient=128), PropMLP=SMALL_PROP,
         n_patch=2, P=4, near=0.1, far=1.2, hist_step=1),
     'hanerf': dict(
         Config={'transient_type': 'hanerf', 'randomized': True, 'patch_size': 4, 'distortion_loss_mult': 0.001,
                 'max_steps': 1000},
         Model=dict(BASE_MODEL, num_levels=2, num_prop_samples=64, num_nerf_samples=64, num_glo_features=8,
                    num_transient_features=6),
-        NerfMLP=SMALL_NERF, PropMLP=SMALL_PROP, ImplicitMask={'net_width': 64},
+        NerfMLP=SMALL_NERF, PropMLP=SMALL_PROP,      # ImplicitMask is not gin-configurable: always 4 x 256
         n_patch=2, P=4, near=0.1, far=1.2, hist_step=1),
 }
 TRAIN_FRAC = 0.37
@@ -146,13 +147,22 @@ def main():
     # biases are zero-initialised in flax; give them values so that they are pinned too
     flat = flatten(variables['params'])
     for k in flat:
+      if k.endswith('/kernel'):
+        # kernels are stored as bfloat16 bit patterns (half the fixture): make them exactly representable
+        b = flat[k].view(np.uint32).astype(np.uint64)
+        b = ((b + 0x7FFF + ((b >> 16) & 1)) >> 16).astype(np.uint32) << 16
+        flat[k] = b.view(f32).reshape(flat[k].shape)
       if k.endswith('/bias'):
         flat[k] = (rng.normal(size=flat[k].shape) * 0.1).astype(f32)
       if k.endswith('/embedding'):
         flat[k] = (rng.normal(size=flat[k].shape) * 0.5).astype(f32)
     variables = {'params': unflatten(flat)}
     for k, v in flat.items():
-      out[f'{case}/params/{k}'] = v
+      if k.endswith('/kernel'):
+        assert np.all((v.view(np.uint32) & 0xFFFF) == 0)
+        out[f'{case}/params_bf16/{k}'] = (v.view(np.uint32) >> 16).astype(np.uint16)
+      else:
+        out[f'{case}/params/{k}'] = v
 
     n_patch, P = spec['n_patch'], spec['P']
     shp = (n_patch, P, P)

@@ -35,7 +35,12 @@ def keys(case, prefix):
 
 
 def flat_params(case):
-  return {k: npz()[f'{case}/params/{k}'] for k in keys(case, 'params/')}
+  """{'NerfMLP_0/Dense_0/kernel': float32 array, ...}; kernels are stored as bfloat16 bit patterns (they were
+  rounded to bfloat16-representable values before the reference ran on them)."""
+  out = {k: npz()[f'{case}/params/{k}'] for k in keys(case, 'params/')}
+  for k in keys(case, 'params_bf16/'):
+    out[k] = (npz()[f'{case}/params_bf16/{k}'].astype(np.uint32) << 16).view(np.float32)
+  return out
 
 
 def param_tree(case, dtype=torch.float32):
@@ -83,7 +88,7 @@ def oracle_cfg(case):
       num_embeddings=m['num_embeddings'], opaque_background=m['opaque_background'],
       warp=n.get('warp_fn') == '@coord.contract',
       nerf_depth=n['net_depth'], nerf_width=n['net_width'], bottleneck_width=n['bottleneck_width'],
-      width_viewdirs=n['net_width_viewdirs'], prop_depth=p['net_depth'], prop_width=p['net_width'],
+      width_viewdirs=n.get('net_width_viewdirs', 128), prop_depth=p['net_depth'], prop_width=p['net_width'],
       prop_disable_rgb=p['disable_rgb'])
   for k in ('data_loss_type', 'distortion_loss_mult', 'transient_type', 'patch_size', 'withmask_transient_weight',
             'grad_max_norm', 'grad_max_val', 'robustnerf_inlier_quantile', 'max_steps'):
@@ -92,8 +97,6 @@ def oracle_cfg(case):
   cfg = R.ModelCfg(**kw)
   if 'net_width_transient' in n:
     cfg.transient_width = n['net_width_transient']
-  if 'ImplicitMask' in s:
-    cfg.mask_width = s['ImplicitMask'].get('net_width', 256)
   return cfg
 
 

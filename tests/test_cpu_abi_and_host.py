@@ -164,7 +164,8 @@ def test_checkpoint_roundtrip(tmp_path):
   assert set(d.keys()) == {'step', 'params', 'opt_state'}
   k = d['params']['params']['NerfMLP_0']['Dense_5']['kernel']
   assert k.shape == (128 + 504, 128) and k.dtype == np.float32        # flax [in,out], skip-concat layer
-  assert d['opt_state']['0']['mu']['GloEmbed_0']['embedding'].shape == (3500, 4)
+  assert d['opt_state']['0']['mu']['params']['GloEmbed_0']['embedding'].shape == (3500, 4)   # same tree as TrainState.params
+  assert set(d['opt_state']['0'].keys()) == {'count', 'mu', 'nu'} and set(d['opt_state']['1'].keys()) == {'count'}
   state2, _ = train_utils.create_optimizer(cfg, model.init(9, 'cpu'), model)
   state2 = checkpoints.restore_checkpoint(str(tmp_path), state2)
   assert state2.step == 1234

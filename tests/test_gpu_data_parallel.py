@@ -21,19 +21,23 @@ HANERF = GIN + ["Config.transient_type = 'hanerf'", "Model.num_transient_feature
                 "NerfMLP.bottleneck_width = 128"]
 
 
-def _step(rank, world, port, out_dir, gin):
+def _step(rank, world, port, out_dir, gin, backend='gloo'):
   import sys
   sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
   from tests import hugs_testlib as H
   from nerf_hugs_amd.internal import configs, train_utils, parallel
-  torch.cuda.set_device(0)
+  torch.cuda.set_device(rank if backend == 'nccl' else 0)
   if world > 1:
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if backend == 'nccl':           # RCCL: one GPU per rank
+      dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+    else:
+      dist.init_process_group('gloo', rank=rank, world_size=world)
   configs.clear_config()
   configs.parse_config_files_and_bindings(None, gin)
   config = configs.make_config()
-  model, state, _, train_step, _ = train_utils.setup_model(config, 3, compute_dtype='fp32')
+  model, state, _, train_step, _ = train_utils.setup_model(config, 3, compute_dtype='fp32',
+                                                           device=torch.device('cuda', torch.cuda.current_device()))
   batch = H.synth_rays(4, 8, 5)
   if world > 1:
     batch = parallel.shard_batch(batch, rank, world)
@@ -45,11 +49,10 @@ def _step(rank, world, port, out_dir, gin):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('gin', [GIN, HANERF], ids=['base', 'hanerf'])
-def test_two_rank_step_equals_single_process(tmp_path, gin):
+def _compare(tmp_path, gin, backend):
   s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-  mp.spawn(_step, args=(1, port, str(tmp_path), gin), nprocs=1, join=True)
-  mp.spawn(_step, args=(2, port, str(tmp_path), gin), nprocs=2, join=True)
+  mp.spawn(_step, args=(1, port, str(tmp_path), gin, backend), nprocs=1, join=True)
+  mp.spawn(_step, args=(2, port, str(tmp_path), gin, backend), nprocs=2, join=True)
   a = torch.load(tmp_path / 'w1.pt'); b = torch.load(tmp_path / 'w2.pt')
   from tests import hugs_testlib as H
   from nerf_hugs_amd.internal import configs, models
@@ -63,3 +66,15 @@ def test_two_rank_step_equals_single_process(tmp_path, gin):
     ua, ub = m.layout.view(da, lf['path']), m.layout.view(db, lf['path'])
     assert float((ua - ub).abs().max()) <= 2e-3 * float(ua.abs().max()) + 3e-8, lf['path']
   assert abs(a['loss'] / b['loss'] - 1) < 1e-4      # pmean of per-shard losses == the full-batch loss here
+
+
+@pytest.mark.parametrize('gin', [GIN, HANERF], ids=['base', 'hanerf'])
+def test_two_rank_step_equals_single_process(tmp_path, gin):
+  _compare(tmp_path, gin, 'gloo')
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL needs one GPU per rank: runs on multi-GPU nodes only')
+def test_two_rank_step_equals_single_process_rccl(tmp_path):
+  """The same equality through backend 'nccl' (= RCCL over xGMI): the async all-reduce of the NerfMLP gradient
+  segment overlapping the proposal backward, the side-stream dW GEMMs and RCCL's own stream in one step."""
+  _compare(tmp_path, GIN, 'nccl')
