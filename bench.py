@@ -6,7 +6,7 @@
 A step = forward + losses + backward + RCCL all-reduce + clip/Adam + weight re-cast on one batch of
 synthetic rays already resident in HBM (data: synthetic).  Weak scaling: 1024 rays per GPU.
 Prints ONE JSON line (rank 0) with `roofline` for the dominant kernel (bf16 NT GEMM of the NerfMLP trunk,
-timed live with HIP events around back-to-back launches on the compute stream) and `cpu_baseline`
+timed live with HIP events around its launches INSIDE extra train steps, on the stream they run on) and `cpu_baseline`
 (the oracle = CPU restatement of the reference, timed on a bounded sample at N=1)."""
 import argparse
 import json
@@ -49,32 +49,53 @@ def synth_batch(n_patch, P, seed, device):
   return utils.Batch(rays=rays, rgb=f(rng.uniform(size=shp + (3,))))
 
 
-def gemm_roofline(device):
-  """Dominant kernel: k_gemm_nt_bf16 at the NerfMLP trunk shape [131072,1024]x[1024,1024]; HIP events on the
-  launch stream around 20 back-to-back launches."""
+def instep_roofline(train_step, state, batch, gen, thr, steps=5):
+  """Dominant kernel, measured INSIDE the train steps: every GEMM launch of `steps` extra steps is bracketed by HIP
+  events on the stream it is launched on (nerf_hugs_amd/_lib.py PROFILE hook; the side stream for the weight-gradient
+  GEMMs).  `roofline` is the forward NerfMLP trunk layer [131072,1024]x[1024,1024]^T + bias + relu; the masked dX and
+  the dW GEMM of the same shape are reported next to it.  `traffic` = HBM bytes per launch from the rocprofv3 PMC
+  passes committed as profiles/r02_gemm_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section),
+  null when that file is absent."""
   from nerf_hugs_amd import _lib
-  M, N, K = 131072, 1024, 1024
-  A = torch.randn(M, K, device=device).bfloat16()
-  Bt = (torch.randn(N, K, device=device) / 32).bfloat16()
-  bias = torch.zeros(N, device=device)
-  out = torch.empty(M, N, device=device, dtype=torch.bfloat16)
-  call = lambda: _lib.call('hugs_gemm_nt', 1, M, N, K, 0, A, K, None, 0, Bt, K, bias, None, 1, 0, 1, None, 0, None, None, out, N)
-  for _ in range(40):   # the chip clocks down while the host runs the CPU legs: warm it back up
-    call()
-  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-  reps = 30
-  e0.record()
-  for _ in range(reps):
-    call()
-  e1.record()
+  _lib.PROFILE = []
+  for _ in range(steps):
+    state, stats, gen = train_step(gen, state, batch, 0.5, thr)
   torch.cuda.synchronize()
-  dt = e0.elapsed_time(e1) / reps * 1e-3
-  tf = 2.0 * M * N * K / dt / 1e12
-  return {"bound": "mfma", "kernel": "k_gemm_nt_bf16_big<4> [131072x1024]x[1024x1024]^T bias+relu (NerfMLP trunk layer)", "achieved": round(tf, 1),
-          "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(tf * 1e12 / PEAK_BF16, 4),
-          # HBM bytes per launch from PMC (profiles/r01_gemm_pmc.md): 2*FETCH_SIZE + WRITE_SIZE (KB) * 1024
-          "traffic": 6.71e8, "algorithmic_bytes": 5.39e8,
-          "avg_us": round(dt * 1e6, 1)}
+  recs, _lib.PROFILE = _lib.PROFILE, None
+  agg = {}
+  for name, key, e0, e1 in recs:
+    agg.setdefault(key, []).append(e0.elapsed_time(e1) * 1e3)     # us
+  traffic = {}
+  tpath = os.path.join(ROOT, 'profiles', 'r02_gemm_traffic.json')
+  if os.path.exists(tpath):
+    traffic = json.load(open(tpath))
+
+  def entry(key, label, flops, alg_bytes):
+    if key not in agg:
+      return None
+    us = float(np.mean(agg[key]))
+    tf = flops / (us * 1e-6) / 1e12
+    t = traffic.get(label, {})
+    return {"bound": "mfma", "kernel": label, "launches": len(agg[key]), "avg_us": round(us, 1), "achieved": round(tf, 1),
+            "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(tf * 1e12 / PEAK_BF16, 4),
+            "traffic": t.get("hbm_bytes_per_launch"), "algorithmic_bytes": alg_bytes}
+
+  W = 1024
+  # the forward trunk may run in row chunks (engine._mlp_forward): take whatever M the W x W relu layers ran at
+  fwd = [k for k in agg if k[0] == 'nt' and k[2] == W and k[3] == W and k[4] == 'relu']
+  main = None
+  if fwd:
+    k = max(fwd, key=lambda k: len(agg[k]))
+    main = entry(k, f"NT forward trunk [{k[1]}x1024]x[1024x1024]^T +bias +relu (k_gemm_nt_bf16_pers<3>)", 2.0 * k[1] * W * W,
+                 2.0 * k[1] * W * 2 + W * W * 2)
+  M = 131072
+  fl = 2.0 * M * W * W
+  others = [entry(('nt', M, W, W, 'mask'), "NT masked dX [131072x1024]x[1024x1024] *(Y>0) (k_gemm_nt_bf16_pers<4>)", fl,
+                  3.0 * M * W * 2 + W * W * 2),
+            entry(('tn', M, W, W, 'split16'), "TN dW [1024x131072]x[131072x1024] + slab reduce (k_gemm_tn_bf16_big)", fl,
+                  2.0 * M * W * 2 + W * W * 4)]
+  shapes = {f"{k[0]} M={k[1]} {k[2]}x{k[3]} {k[4]}": [len(v), round(float(np.mean(v)), 1)] for k, v in sorted(agg.items(), key=str)}
+  return main, [o for o in others if o], shapes, state, gen
 
 
 def cpu_baseline(seed):
@@ -203,6 +224,11 @@ def main():
     dt = float(tmax.item())
   loss = float(stats['loss'])
   psnr = float(stats['psnr'])
+  roof = None
+  if args.dtype == 'bf16' and args.config == 'cfg2':
+    # after the timed region: a few more steps with the GEMM launches bracketed by HIP events (every rank runs them:
+    # the steps contain the gradient all-reduce; rank 0 reports)
+    roof, roof_others, roof_shapes, state, gen = instep_roofline(train_step, state, batch, gen, thr)
   eval_psnr = None
   if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 'cfg2':
     eval_psnr = eval_psnr_vs_oracle(model, state, batch, args.dtype)
@@ -222,8 +248,10 @@ def main():
         "eval_psnr_vs_cpu_fp32_db": eval_psnr,
         "step_mfma_frac": round(rps / world * FLOP_TRAIN_PER_RAY / (PEAK_BF16 if args.dtype == 'bf16' else 157.3e12), 4),
     }
-    if args.dtype == 'bf16':
-      line["roofline"] = gemm_roofline(device)
+    if roof is not None:
+      line["roofline"] = roof
+      line["instep_kernels"] = roof_others
+      line["instep_gemm_shapes_count_avg_us"] = roof_shapes
     if world == 1 and not args.no_cpu_baseline and args.config == 'cfg2':
       line["cpu_baseline"] = cpu_baseline(20200823)
     print(json.dumps(line))

@@ -75,6 +75,14 @@ def _raw_stream():
   return torch.cuda.current_stream().cuda_stream
 
 
+# In-step kernel timing (bench.py's roofline leg): when PROFILE is a list, every GEMM launch is bracketed by two
+# HIP events recorded on the stream the kernel is launched on (torch's current stream at call time -- the side
+# stream for the weight-gradient GEMMs) and (name, shape key, ev0, ev1) is appended.
+PROFILE = None
+_PROFILED = {'hugs_gemm_nt': lambda a: ('nt', a[1], a[2], a[3] + a[4], 'mask' if a[16] is not None else ('relu' if a[15] else 'plain')),
+             'hugs_gemm_tn': lambda a: ('tn', a[1], a[2], a[3], f'split{a[4]}')}
+
+
 class _Lib:
 
   def __init__(self):
@@ -133,7 +141,14 @@ class _Lib:
       raise HugsError(f'{name}: tensors are on cuda:{dev} but the current device is cuda:{torch.cuda.current_device()} '
                       '(use `with torch.cuda.device(...)`)')
     conv.append(_raw_stream())
-    rc = getattr(self.cdll, name)(*conv)
+    if PROFILE is not None and name in _PROFILED:
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record()
+      rc = getattr(self.cdll, name)(*conv)
+      e1.record()
+      PROFILE.append((name, _PROFILED[name](args), e0, e1))
+    else:
+      rc = getattr(self.cdll, name)(*conv)
     if rc != 0:
       msg = self.cdll.hugs_last_error().decode()
       if rc == -2:

@@ -33,6 +33,29 @@ struct GemmEpi {
   int ldc;
 };
 
+#ifdef HUGS_TRACE   // scratch builds only (scratch/nt_trace.py): per-workgroup timestamps of the NT kernel's phases
+__device__ unsigned long long* g_nt_trace;
+extern "C" int hugs_debug_set_trace(void* p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_nt_trace), &p, sizeof(p));
+}
+__device__ int g_nt_stagger[2];   // [0] = groups (power of two), [1] = s_sleep(127) iterations per group step
+extern "C" int hugs_debug_set_stagger(int groups, int iters) {
+  int v[2] = {groups, iters};
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_nt_stagger), v, sizeof(v));
+}
+#define HUGS_STAGGER() { const int g_ = g_nt_stagger[0]; if (g_ > 1 && blockIdx.x < 256) { \
+    const int n_ = ((blockIdx.x >> 3) & (g_ - 1)) * g_nt_stagger[1]; for (int q_ = 0; q_ < n_; ++q_) __builtin_amdgcn_s_sleep(127); } }
+#define HUGS_TR(i) { if (g_nt_trace && threadIdx.x == 0) g_nt_trace[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); }
+#define HUGS_TRP(i, k) { if (g_nt_trace && threadIdx.x == 0 && (i) < 16) g_nt_trace[((size_t)blockIdx.x * 16 + (i)) * 4 + (k)] = __builtin_readcyclecounter(); }
+#define HUGS_TR_ID() { if (g_nt_trace && threadIdx.x == 0) { g_nt_trace[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg(63492); \
+                                                             g_nt_trace[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg(63508); } }
+#else
+#define HUGS_TR(i)
+#define HUGS_TRP(i, k)
+#define HUGS_TR_ID()
+#define HUGS_STAGGER()
+#endif
+
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   // contiguous band of tiles per XCD; bijective for any nwg (cdna guide T1)
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
@@ -184,7 +207,116 @@ typedef unsigned __attribute__((ext_vector_type(2))) u32x2_t;
 //                         ask for 2 waves/SIMD here too: with "1" the compiler spread the kernel over 366
 //                         registers (AGPRs included), only ONE workgroup fitted a CU and it ran at 610 instead
 //                         of 850 TFLOP/s.
-template <int WN>
+// EPI: -1 = every epilogue term decided at run time (GemmEpi pointers); >= 0 = compile-time set of terms
+// (bit 0 bias, 1 relu, 2 mask, 3 rank-1; never a per-ray row bias): the run-time form compiles to ~60 branches, each
+// with its own global load + s_waitcnt vmcnt(0) -- a chain of serialised L2 latencies (9.6k cycles per tile by
+// s_memtime, scratch/nt_trace.py) -- while the specialised forms issue all their loads in one batch.
+#define EPI_BIAS 1
+#define EPI_RELU 2
+#define EPI_MASK 4
+#define EPI_R1 8
+// Epilogue of the 256x256 NT tile straight from the accumulator registers (wave (wm, wn) owns rows wm*128.. and
+// columns wn*64..; lane (r16, kb) of fragment (i, j) holds row i*16 + r16, columns j*16 + kb*4 .. +3).
+// lds_bias / lds_r1col: optional LDS-resident copies of E.bias / E.r1_col (indexed by absolute column): the persistent
+// kernel keeps them there so that the epilogue issues no global load that would queue behind the prefetched stages.
+template <int EPI>
+__device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const GemmEpi& E, int m0, int n0, int wm, int wn,
+                                                   int r16, int kb, const float* lds_bias, const float* lds_r1col) {
+    // ---- epilogue straight from registers: bias / rank-1 / relu, v_cvt_pk_bf16_f32, one v_permlane16_swap pair
+    // per two neighbouring 16-column fragments turns the 8-byte-per-lane MFMA layout into 16 contiguous bytes per
+    // lane (64-byte runs per row): no LDS round trip, no barriers.
+    constexpr bool GEN = EPI < 0;
+    const bool has_bias = GEN ? E.bias != nullptr : bool(EPI & EPI_BIAS);
+    const bool has_relu = GEN ? E.relu != 0 : bool(EPI & EPI_RELU);
+    const bool has_mask = GEN ? E.mask != nullptr : bool(EPI & EPI_MASK);
+    const bool has_r1 = GEN ? E.r1_row != nullptr : bool(EPI & EPI_R1);
+    const bool has_rowb = GEN ? E.row_bias != nullptr : false;
+    float4 bj[4], cj[4];
+    float r1v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + kb * 4;
+      bj[j] = has_bias ? (lds_bias ? *(const float4*)(lds_bias + n) : *(const float4*)(E.bias + n)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      cj[j] = has_r1 ? (lds_r1col ? *(const float4*)(lds_r1col + n) : *(const float4*)(E.r1_col + n)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r1v[i] = has_r1 ? E.r1_row[m0 + wm * 128 + i * 16 + r16] : 0.f;
+    // Store geometry.  After the permlane16 swaps lane (r16, kb) holds, for each jp, 16 contiguous bytes of row r16:
+    // columns jp*32 + chunk(kb) .. +7.  Storing that directly writes 64-byte runs of 16 rows per instruction --
+    // HALF cache lines, which cost 62 cycles of store issue each (scratch/store_bench.hip: 8.0k cycles per 128 KiB tile
+    // and CU) against 18.5 for whole 128-byte lines (2.4k).  So lanes r16 and r16+8 trade one chunk (DPP row_ror:8):
+    // afterwards lanes r16<8 hold the jp=0 chunks of rows r16 and r16+8, lanes r16>=8 the jp=1 chunks of rows r16-8
+    // and r16, and every store instruction writes 8 rows x 128 B.
+    const bool hi8 = (r16 & 8) != 0;
+    const int srow = r16 & 7;                                            // row (within the 16-row group) of store A; B = +8
+    const int ccol = n0 + wn * 64 + (kb & 1) * 16 + (kb >> 1) * 8 + (hi8 ? 32 : 0);
+    // relu-mask chunks (same whole-line geometry as the stores), fetched two fragment rows ahead of their use: all 16
+    // in flight at once would cost 64 registers on top of the 128 accumulators
+    uint4 mkv[8][2];
+    auto mask_load = [&](int i) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        mkv[i][h] = *(const uint4*)((const uint16_t*)E.mask + (size_t)(m0 + wm * 128 + i * 16 + h * 8 + srow) * E.ld_mask + ccol);
+    };
+    if (has_mask) { mask_load(0); mask_load(1); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (has_mask && i + 2 < 8) mask_load(i + 2);
+      const int m = m0 + wm * 128 + i * 16 + r16;
+      const float r1 = r1v[i];
+      const float* rbp = has_rowb ? E.row_bias + (size_t)(m / E.row_div) * E.ld_rb + n0 + wn * 64 + kb * 4 : nullptr;
+      uint32_t pk[4][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x[4] = {acc[i][j][0] + bj[j].x + r1 * cj[j].x, acc[i][j][1] + bj[j].y + r1 * cj[j].y,
+                      acc[i][j][2] + bj[j].z + r1 * cj[j].z, acc[i][j][3] + bj[j].w + r1 * cj[j].w};
+        if (rbp) { const float4 b = *(const float4*)(rbp + j * 16); x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w; }
+        if (has_relu) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
+        bf16x4_t h;
+        h[0] = (__bf16)x[0]; h[1] = (__bf16)x[1]; h[2] = (__bf16)x[2]; h[3] = (__bf16)x[3];
+        const uint2 u = *(const uint2*)&h;
+        pk[j][0] = u.x; pk[j][1] = u.y;
+      }
+      uint32_t vv[2][4];
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(pk[2 * jp][0], pk[2 * jp + 1][0], false, false);
+        const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(pk[2 * jp][1], pk[2 * jp + 1][1], false, false);
+        vv[jp][0] = s0[0]; vv[jp][1] = s1[0]; vv[jp][2] = s0[1]; vv[jp][3] = s1[1];
+      }
+      // low lanes give away their jp=1 chunk and receive the partner row's jp=0 chunk; high lanes the other way round
+      uint32_t sa[4], sb[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t send = hi8 ? vv[0][q] : vv[1][q];
+        const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, 0x128, 0xf, 0xf, false);   // row_ror:8
+        sa[q] = hi8 ? recv : vv[0][q];      // store A: row srow
+        sb[q] = hi8 ? vv[1][q] : recv;      // store B: row srow + 8
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        uint32_t* vw = h ? sb : sa;
+        if (has_mask) {
+          const uint4 mk = mkv[i][h];
+          const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t lo = mw[q] & 0xffffu, hi = mw[q] >> 16;
+            const uint32_t keep = (((lo & 0x7fffu) && !(lo & 0x8000u)) ? 0x0000ffffu : 0u) |
+                                  (((hi & 0x7fffu) && !(hi & 0x8000u)) ? 0xffff0000u : 0u);
+            vw[q] &= keep;
+          }
+        }
+#ifdef HUGS_EPI_NOSTORE    // scratch experiment: everything but the store instruction
+        asm volatile("" ::"v"(vw[0]), "v"(vw[1]), "v"(vw[2]), "v"(vw[3]));
+#else
+        *(uint4*)((uint16_t*)E.out + (size_t)(m0 + wm * 128 + i * 16 + h * 8 + srow) * E.ldc + ccol) = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+#endif
+      }
+    }
+}
+
+template <int WN, int EPI = -1>
 __global__ __launch_bounds__(128 * WN, 2) void k_gemm_nt_bf16_big(
     int M, int N, int K1, int K2, const uint16_t* __restrict__ A1, int lda1, const uint16_t* __restrict__ A2, int lda2,
     const uint16_t* __restrict__ Bt, int ldb, GemmEpi E) {
@@ -296,11 +428,14 @@ __global__ __launch_bounds__(128 * WN, 2) void k_gemm_nt_bf16_big(
     }                                                                                     \
   }
   Frags f0, f1;
+  HUGS_STAGGER()
+  HUGS_TR(0) HUGS_TR_ID()
 #pragma unroll
   for (int q = 0; q < NSLOT; ++q) stage(q);
   asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  HUGS_TR(1)
   load_frags(f0, 0);
   int st = 0;
   if (WN == 4) {
@@ -318,65 +453,15 @@ __global__ __launch_bounds__(128 * WN, 2) void k_gemm_nt_bf16_big(
     mfmas(f1);                                                                            // ns-1
   }
 #undef GL_ITER
+  HUGS_TR(2)
 #if HUGS_NT_DIRECT_EPI
   if (WN == 4) {
-    // ---- epilogue straight from registers: bias / rank-1 / relu, v_cvt_pk_bf16_f32, one v_permlane16_swap pair
-    // per two neighbouring 16-column fragments turns the 8-byte-per-lane MFMA layout into 16 contiguous bytes per
-    // lane (64-byte runs per row): no LDS round trip, no barriers.
-    float4 bj[4], cj[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + kb * 4;
-      bj[j] = E.bias ? *(const float4*)(E.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-      cj[j] = E.r1_row ? *(const float4*)(E.r1_col + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    const int ccol = n0 + wn * 64 + (kb & 1) * 16 + (kb >> 1) * 8;   // + jp*32: this lane's 8 output columns
-    uint4 mkv[8][2];
-    if (E.mask) {   // all 16 mask chunks in flight before the conversion work starts
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int jp = 0; jp < 2; ++jp)
-          mkv[i][jp] = *(const uint4*)((const uint16_t*)E.mask + (size_t)(m0 + wm * 128 + i * 16 + r16) * E.ld_mask + ccol + jp * 32);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = m0 + wm * 128 + i * 16 + r16;
-      const float r1 = E.r1_row ? E.r1_row[m] : 0.f;
-      const float* rbp = E.row_bias ? E.row_bias + (size_t)(m / E.row_div) * E.ld_rb + n0 + wn * 64 + kb * 4 : nullptr;
-      uint32_t pk[4][2];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float x[4] = {acc[i][j][0] + bj[j].x + r1 * cj[j].x, acc[i][j][1] + bj[j].y + r1 * cj[j].y,
-                      acc[i][j][2] + bj[j].z + r1 * cj[j].z, acc[i][j][3] + bj[j].w + r1 * cj[j].w};
-        if (rbp) { const float4 b = *(const float4*)(rbp + j * 16); x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w; }
-        if (E.relu) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
-        bf16x4_t h;
-        h[0] = (__bf16)x[0]; h[1] = (__bf16)x[1]; h[2] = (__bf16)x[2]; h[3] = (__bf16)x[3];
-        const uint2 u = *(const uint2*)&h;
-        pk[j][0] = u.x; pk[j][1] = u.y;
-      }
-#pragma unroll
-      for (int jp = 0; jp < 2; ++jp) {
-        const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(pk[2 * jp][0], pk[2 * jp + 1][0], false, false);
-        const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(pk[2 * jp][1], pk[2 * jp + 1][1], false, false);
-        uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-        if (E.mask) {
-          const uint4 mk = mkv[i][jp];
-          const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
-          uint32_t vw[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const uint32_t lo = mw[q] & 0xffffu, hi = mw[q] >> 16;
-            const uint32_t keep = (((lo & 0x7fffu) && !(lo & 0x8000u)) ? 0x0000ffffu : 0u) |
-                                  (((hi & 0x7fffu) && !(hi & 0x8000u)) ? 0xffff0000u : 0u);
-            vw[q] &= keep;
-          }
-          v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
-        }
-        *(uint4*)((uint16_t*)E.out + (size_t)m * E.ldc + ccol + jp * 32) = v;
-      }
-    }
+    nt_epilogue_direct<EPI>(acc, E, m0, n0, wm, wn, r16, kb, nullptr, nullptr);
+    HUGS_TR(3)
+#ifdef HUGS_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HUGS_TR(4)
+#endif
     return;
   }
 #endif
@@ -432,6 +517,150 @@ __global__ __launch_bounds__(128 * WN, 2) void k_gemm_nt_bf16_big(
     }
     *(uint4*)((uint16_t*)E.out + (size_t)(m0 + row) * E.ldc + n0 + c * 8) = v;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 NT, PERSISTENT form of the 256x256 kernel: one workgroup per CU walks its tiles (bid = blockIdx.x + i*grid, the
+// same XCD band as the one-tile-per-workgroup launch) and the 4-slot K-stage ring runs straight on from one tile into
+// the next.  s_memtime bracketing of the one-tile kernel (scratch/nt_trace.py, trunk shape) gave per tile: prologue
+// 9.0k cycles (first stage of a cold ring, every CU fetching at once) + main loop 45k + epilogue 6.3k + store
+// acknowledgement 2.9k + relaunch gap 2.2k.  Here the next tile's first four stages are already in flight when the
+// epilogue starts, the stores drain under the next tile's first iterations, and there is no relaunch:
+//   * the epilogue's 16 stores per lane sit in the SAME in-order vmcnt queue as the LDS-DMA stages, so the three
+//     iterations that follow an epilogue wait with vmcnt(8 + 16): stage landed <=> at most the two younger stages AND
+//     the 16 stores are still outstanding.  (Waiting with the steady-state vmcnt(8) there would drain the stores --
+//     what made an earlier persistent attempt no faster.)
+//   * bias / rank-1 column vectors live in LDS (the ring leaves 32 KiB): an epilogue global load would have to wait
+//     for every prefetched stage ahead of it in the queue.
+//   * past the last tile the loader re-issues the final stages (valid addresses, dead ring slots) so that every
+//     iteration issues exactly one stage and the counted waits stay uniform.
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
+    int M, int N, int K1, int K2, const uint16_t* __restrict__ A1, int lda1, const uint16_t* __restrict__ A2, int lda2,
+    const uint16_t* __restrict__ Bt, int ldb, GemmEpi E, int ntiles) {
+  constexpr int NSLOT = 4, A_BYTES = 256 * 64, STAGE = 2 * A_BYTES;
+  constexpr int VEC_OFF = NSLOT * STAGE;                      // bias / r1_col copies: 2 x 16 KiB behind the ring
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NSLOT * STAGE + 2 * 16384];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntn = N >> 8;
+  const int wm = wv >> 2, wn = wv & 3;
+  const int ns = (K1 + K2) >> 5;
+  const int G = gridDim.x;
+  const int nmine = (ntiles - (int)blockIdx.x + G - 1) / G;
+
+  float* lds_bias = (float*)(lds + VEC_OFF);
+  float* lds_r1 = (float*)(lds + VEC_OFF + 16384);
+  {
+    const bool has_bias = EPI < 0 ? E.bias != nullptr : bool(EPI & EPI_BIAS);
+    const bool has_r1 = EPI < 0 ? E.r1_row != nullptr : bool(EPI & EPI_R1);
+    if (has_bias) for (int n = tid * 4; n < N; n += 2048) *(float4*)(lds_bias + n) = *(const float4*)(E.bias + n);
+    if (has_r1) for (int n = tid * 4; n < N; n += 2048) *(float4*)(lds_r1 + n) = *(const float4*)(E.r1_col + n);
+  }
+
+  // ---- loader state (wave-uniform, SGPRs): tile being fetched, stage within it, ring slot ----
+  // Every LDS-DMA takes its global address as (64-bit SGPR base) + (32-bit per-lane byte offset): the per-lane part
+  // is constant for the whole kernel (6 VGPRs), the base is scalar arithmetic -- no VALU and no address VGPR pairs in
+  // the loop (the builtin's 64-bit per-lane addresses cost 3 VALU + a VGPR pair per load and pushed the kernel into
+  // scratch spills, whose reloads are VMEM operations that drain the counted DMA queue).
+  int l_bid = blockIdx.x, l_st = 0, l_slot = 0;
+  int lm0, ln0;
+  { const int t = xcd_remap(l_bid, ntiles); lm0 = (t / ntn) << 8; ln0 = (t % ntn) << 8; }
+  const int prow = tid >> 2, pcol = ((tid & 3) ^ (3 * ((prow >> 2) & 1))) * 8;   // this thread's chunk of rows 0..127
+  // (rows 128..255 of a stage: the same per-lane offset on a base advanced by 128 rows)
+  const unsigned oA1 = (unsigned)(prow * lda1 + pcol) * 2u, oA2 = (unsigned)(prow * lda2 + pcol) * 2u;
+  const unsigned oB = (unsigned)(prow * ldb + pcol) * 2u;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)wv * 1024u;
+  auto dma = [&](const char* sbase, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory", "m0");
+  };
+  auto issue = [&]() {
+    const int kglob = l_st << 5;
+    const unsigned la = lds_base + (unsigned)l_slot * STAGE;
+    const char* bb = (const char*)Bt + ((size_t)ln0 * ldb + kglob) * 2;
+    if (kglob < K1) {
+      const char* ab = (const char*)A1 + ((size_t)lm0 * lda1 + kglob) * 2;
+      dma(ab, oA1, la); dma(ab + (size_t)lda1 * 256, oA1, la + 8192);
+    } else {
+      const char* ab = (const char*)A2 + ((size_t)lm0 * lda2 + (kglob - K1)) * 2;
+      dma(ab, oA2, la); dma(ab + (size_t)lda2 * 256, oA2, la + 8192);
+    }
+    dma(bb, oB, la + A_BYTES); dma(bb + (size_t)ldb * 256, oB, la + A_BYTES + 8192);
+    l_slot = (l_slot + 1) & 3;
+    if (++l_st == ns) {
+      l_st = 0;
+      if (l_bid + G < ntiles) {
+        l_bid += G;
+        const int t = xcd_remap(l_bid, ntiles);
+        lm0 = (t / ntn) << 8; ln0 = (t % ntn) << 8;
+      }   // else: keep re-reading the last tile (dead slots, uniform counts)
+    }
+  };
+
+  f32x4_t acc[8][4];
+  const int r16 = lane & 15, kb = lane >> 4;
+  const int frag_off = r16 * 64 + ((kb ^ (3 * ((r16 >> 2) & 1))) << 4);
+  struct Frags { bf16x8_t wb[4], xa[8]; };
+  int c_slot = 0;       // ring slot of the stage whose fragments are loaded next
+  auto load_frags = [&](Frags& f) {
+    const unsigned char* la = lds + c_slot * STAGE + (wm * 128) * 64 + frag_off;
+    const unsigned char* lb = lds + c_slot * STAGE + A_BYTES + (wn * 64) * 64 + frag_off;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f.wb[j] = *(const bf16x8_t*)(lb + j * 16 * 64);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f.xa[i] = *(const bf16x8_t*)(la + i * 16 * 64);
+    c_slot = (c_slot + 1) & 3;
+  };
+  auto mfmas = [&](const Frags& f) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wb[j], f.xa[i], acc[i][j], 0, 0, 0);
+  };
+  // iteration for stage g: frags(g) are in `cur`; make stage g+1 visible, refill the slot of stage g with stage g+4,
+  // start reading frags(g+1) into `nxt`, run the MFMAs of stage g.
+#define GP_ITER(cur, nxt, VM)                                                            \
+  {                                                                                       \
+    asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");                     \
+    __builtin_amdgcn_s_barrier();                                                         \
+    asm volatile("" ::: "memory");                                                        \
+    issue();                                                                              \
+    load_frags(nxt);                                                                      \
+    mfmas(cur);                                                                           \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                    \
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                  \
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                                  \
+    }                                                                                     \
+  }
+  Frags f0, f1;
+#pragma unroll
+  for (int q = 0; q < NSLOT; ++q) issue();
+  // all four stages of the cold ring land before the first iteration: the first tile can then run the same three
+  // vmcnt(24) iterations as every later tile (which has 16 epilogue stores in the queue at that point) -- one code path
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();                        // also publishes the bias / r1 vectors
+  load_frags(f0);
+  int c_bid = blockIdx.x;
+  for (int i = 0; i < nmine; ++i, c_bid += G) {
+    int m0, n0;
+    { const int t = xcd_remap(c_bid, ntiles); m0 = (t / ntn) << 8; n0 = (t % ntn) << 8; }
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    HUGS_TRP(i, 0)
+    GP_ITER(f0, f1, 24) GP_ITER(f1, f0, 24) GP_ITER(f0, f1, 24)   // the previous tile's 16 stores are in the queue
+    GP_ITER(f1, f0, 8)
+    HUGS_TRP(i, 1)
+#pragma unroll 1
+    for (int st = 4; st < ns; st += 2) { GP_ITER(f0, f1, 8) GP_ITER(f1, f0, 8) }
+    HUGS_TRP(i, 2)
+    nt_epilogue_direct<EPI>(acc, E, m0, n0, wm, wn, r16, kb, lds_bias, lds_r1);
+    HUGS_TRP(i, 3)
+  }
+#undef GP_ITER
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dead stages past the last tile must land before the LDS is released
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -924,8 +1153,47 @@ extern "C" int hugs_gemm_nt(int dtype, int M, int N, int K1, int K2, const void*
   GemmEpi E{bias, row_bias, row_div, ld_rb, relu, mask, ld_mask, r1_row, r1_col, out, ldc};
   const int grid = (M / 128) * (N / 128);
   if (dtype && M % 256 == 0 && N % 256 == 0 && (K1 + K2) % 64 == 0 && K1 + K2 >= 256 && g_force_small_tiles != 1 && g_force_small_tiles != 3)
-    hipLaunchKernelGGL(k_gemm_nt_bf16_big<4>, dim3((M / 256) * (N / 256)), dim3(512), 0, (hipStream_t)stream, M, N, K1, K2,
-                       (const uint16_t*)A1, lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E);
+  {
+    // epilogue specialisations for the combinations the trunks use (bit set = term present); anything else -> generic
+    const int epi = row_bias ? -1 : (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0) | (mask ? EPI_MASK : 0) | (r1_row ? EPI_R1 : 0);
+    const int ntiles = (M / 256) * (N / 256), nstage = (K1 + K2) / 32;
+    static int ncu = 0;
+    if (!ncu) { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); ncu &= ~7; if (ncu < 8) ncu = 8; }
+    // more than one tile per CU: the persistent kernel (ring carried across tiles).  Needs an even number of stages
+    // (fragment double buffer parity) and N <= 4096 (bias / r1 vectors in the 32 KiB the ring leaves).
+#ifdef HUGS_NO_PERSISTENT
+    if (false) {
+#else
+    if (ntiles > ncu && nstage % 2 == 0 && nstage >= 8 && N <= 4096 && g_force_small_tiles != 5) {
+#endif
+      const dim3 gp(ncu), bp(512);
+#define HUGS_NTP_LAUNCH(EPI_) hipLaunchKernelGGL((k_gemm_nt_bf16_pers<EPI_>), gp, bp, 0, (hipStream_t)stream, M, N, K1, K2, \
+                       (const uint16_t*)A1, lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E, ntiles)
+      switch (epi) {
+        case EPI_BIAS | EPI_RELU: HUGS_NTP_LAUNCH(EPI_BIAS | EPI_RELU); break;
+        case EPI_BIAS: HUGS_NTP_LAUNCH(EPI_BIAS); break;
+        case EPI_MASK: HUGS_NTP_LAUNCH(EPI_MASK); break;
+        case EPI_MASK | EPI_R1: HUGS_NTP_LAUNCH(EPI_MASK | EPI_R1); break;
+        case 0: HUGS_NTP_LAUNCH(0); break;
+        default: HUGS_NTP_LAUNCH(-1); break;
+      }
+#undef HUGS_NTP_LAUNCH
+      HUGS_CHECK_LAUNCH("hugs_gemm_nt(persistent)");
+      return 0;
+    }
+    const dim3 g((M / 256) * (N / 256)), b(512);
+#define HUGS_NT_LAUNCH(EPI_) hipLaunchKernelGGL((k_gemm_nt_bf16_big<4, EPI_>), g, b, 0, (hipStream_t)stream, M, N, K1, K2, \
+                       (const uint16_t*)A1, lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E)
+    switch (epi) {
+      case EPI_BIAS | EPI_RELU: HUGS_NT_LAUNCH(EPI_BIAS | EPI_RELU); break;   // forward trunk layer
+      case EPI_BIAS: HUGS_NT_LAUNCH(EPI_BIAS); break;                          // bottleneck
+      case EPI_MASK: HUGS_NT_LAUNCH(EPI_MASK); break;                          // dX through a relu
+      case EPI_MASK | EPI_R1: HUGS_NT_LAUNCH(EPI_MASK | EPI_R1); break;        // G of the last trunk layer
+      case 0: HUGS_NT_LAUNCH(0); break;                                        // dBottleneck
+      default: HUGS_NT_LAUNCH(-1); break;
+    }
+#undef HUGS_NT_LAUNCH
+  }
   else if (dtype && M % 256 == 0 && (K1 + K2) % 64 == 0 && K1 + K2 >= 256 && g_force_small_tiles != 1)
     hipLaunchKernelGGL(k_gemm_nt_bf16_big<2>, dim3((M / 256) * (N / 128)), dim3(256), 0, (hipStream_t)stream, M, N, K1, K2,
                        (const uint16_t*)A1, lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E);

@@ -12,6 +12,7 @@ from . import geopoly
 from . import stepfun
 
 CHUNK = 16384
+_CHUNK_BYTES = int(float(__import__('os').environ.get('HUGS_FWD_CHUNK_MB', '1e9')) * 1e6)   # forward row-chunk size (A/B knob)
 
 
 def _round_up(x, m):
@@ -294,20 +295,33 @@ class Engine:
     acts = [X0]
     x = X0
     W = spec.Wp
-    for i in range(spec.net_depth):
-      l = spec.layers[i]
-      path = (spec.name, l['name'], 'kernel')
-      bias = lay.view(theta, (spec.name, l['name'], 'bias'), padded=True)
-      Y = ws.get(f'{tag}/Y{i}', (M, W), self.tdt)
-      if l['concat']:
-        _lib.call('hugs_gemm_nt', dt, M, W, W, spec.Fp, x, W, X0, spec.Fp, self.wt[path], l['kpad'], bias, None, 1, 0, 1,
-                  None, 0, None, None, Y, W)
-      else:
-        K = l['kpad']
-        _lib.call('hugs_gemm_nt', dt, M, W, K, 0, x, K, None, 0, self.wt[path], K, bias, None, 1, 0, 1, None, 0, None,
-                  None, Y, W)
-      acts.append(Y)
-      x = Y
+    Ys = [ws.get(f'{tag}/Y{i}', (M, W), self.tdt) for i in range(spec.net_depth)]
+    # Row chunks (OFF by default, HUGS_FWD_CHUNK_MB): a [M,W] activation of the NerfMLP (268 MB at cfg2) does not fit
+    # the 256 MiB Infinity Cache; walking the trunk chunk by chunk keeps each chunk's activations cache-resident from
+    # the layer that writes them to the layer that reads them.  Stand-alone the 8-layer chain gains 3-10 %
+    # (scratch/chain_chunk.py); inside the train step it is a wash (8.68 vs 8.67 ms, same box), so it stays off.
+    nchunk = 1
+    while (M // nchunk) * W * (2 if self.dt else 4) > _CHUNK_BYTES and (M // (2 * nchunk)) % 256 == 0 and M // (2 * nchunk) >= 65536:
+      nchunk *= 2
+    mc = M // nchunk
+    for c in range(nchunk):
+      rows = slice(c * mc, (c + 1) * mc)
+      x = X0[rows]
+      for i in range(spec.net_depth):
+        l = spec.layers[i]
+        path = (spec.name, l['name'], 'kernel')
+        bias = lay.view(theta, (spec.name, l['name'], 'bias'), padded=True)
+        Y = Ys[i][rows]
+        if l['concat']:
+          _lib.call('hugs_gemm_nt', dt, mc, W, W, spec.Fp, x, W, X0[rows], spec.Fp, self.wt[path], l['kpad'], bias, None, 1, 0, 1,
+                    None, 0, None, None, Y, W)
+        else:
+          K = l['kpad']
+          _lib.call('hugs_gemm_nt', dt, mc, W, K, 0, x, K, None, 0, self.wt[path], K, bias, None, 1, 0, 1, None, 0, None,
+                    None, Y, W)
+        x = Y
+    acts += Ys
+    x = Ys[-1]
     ld = spec.layers[spec.net_depth]
     raw = ws.get(tag + '/raw', (M,))
     density = ws.get(tag + '/density', (M,))

@@ -5,7 +5,8 @@ clip + update on the reference's synthetic gradient tree.  fp32 MFMA mode (`comp
 
 Tolerances: sample positions 5e-5 (level 0: 5e-7), interval indices equal except at CDF knots (<= 0.2 %, never
 more than one interval off), rendered colours 1e-4 (north_star), per-sample density / colour 1e-3 of the array max
-(1 ulp of a level>0 sample position through the 2^11 IPE frequency), losses 1e-4, directional derivatives 3e-3."""
+(1 ulp of a level>0 sample position through the 2^11 IPE frequency), losses 1e-4, directional derivatives 1.5e-3 against the float32 oracle and 1e-2 against the reference's float64
+finite differences (see the comment in the test)."""
 import numpy as np
 import pytest
 import torch
@@ -137,12 +138,25 @@ def test_train_step_stats_and_derivatives_vs_reference(case):
   # gradient (before clipping: the buffer the backward pass filled)
   grad = model.engine(dev).ws.get('grad', (model.layout.size + 64,))
   g = {'/'.join(lf['path']): model.layout.view(grad, lf['path']).double().cpu().numpy() for lf in model.layout.leaves}
+  # The reference's number is the float64 derivative.  A float32 evaluation of the same network lands a handful of
+  # the ~1e6 ReLU pre-activations (they differ by ~5e-4 through the 2^11 IPE frequency) on the other side of zero,
+  # and with 32 rays one sample can carry percents of a leaf's gradient: the oracle evaluated in float32 shows the
+  # SAME deviation from its own float64 value (tests/test_oracle_vs_reference_model.py pins that one to the
+  # reference at 2e-5).  So: HIP vs the float32 oracle tightly, HIP vs the reference's float64 number loosely.
+  from oracle import torch_ref as R
+  cfg = FX.oracle_cfg(case)
+  othr = None if thr is None else [torch.from_numpy(t.copy()) for t in thr]
+  _, og, _, _ = R.loss_and_grad(cfg, FX.param_tree(case), FX.rays_flat(case),
+                                torch.from_numpy(FX.get(case, 'rgb').reshape(-1, 3).copy()),
+                                float(FX.get(case, 'train_frac')), FX.u01(case, L), othr)
+  scale = max(abs(float(FX.get(case, f'fd/dir{j}'))) for j in range(3))
   for i in range(3):
     v = FX.seeded_tree(case, 1000 + i)
     mine = sum(float((g[k] * v[k]).sum()) for k in v)
-    fd, fd2 = float(FX.get(case, f'fd/dir{i}')), float(FX.get(case, f'fd/dir{i}_h2'))
-    scale = max(abs(float(FX.get(case, f'fd/dir{j}'))) for j in range(3))
-    assert abs(mine - fd) <= 3e-3 * scale + 4 * abs(fd - fd2), (case, i, mine, fd)
+    o32 = sum(float((og[k].double().numpy() * v[k]).sum()) for k in v)
+    fd = float(FX.get(case, f'fd/dir{i}'))
+    assert abs(mine - o32) <= 1.5e-3 * scale, (case, i, mine, o32)
+    assert abs(mine - fd) <= 1e-2 * scale, (case, i, mine, fd)
 
 
 @pytest.mark.parametrize('case', ['base', 'withmask', 'robust'])
