@@ -165,6 +165,9 @@ def main():
   ap.add_argument('--warmup', type=int, default=10)
   ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                  help='weak: 1024 rays per GPU (the default the driver runs); strong: 1024 rays in total, split over the GPUs '
+                       '(BASELINE.md promises both curves)')
   ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3', 'cfg4'],
                   help='cfg2 = the headline workload; cfg3 (static masks, 4096 rays, GLO 48, charb) and cfg4 (RobustNeRF 0.8,\n'
                        'contract + reciprocal, GLO 4, 1024 rays/GPU) are informational')
@@ -191,15 +194,24 @@ def main():
   gin = {'cfg2': GIN, 'cfg3': GIN_CFG3, 'cfg4': GIN_CFG4}[args.config]
   configs.parse_config_files_and_bindings(None, gin)
   rays_per_gpu = 4096 if args.config == 'cfg3' else 1024
+  P = 16
+  if args.scaling == 'strong':
+    if rays_per_gpu % world or (rays_per_gpu // world) % 64:
+      raise SystemExit(f'--scaling strong: {rays_per_gpu} rays do not split into whole 8x8 patches over {world} GPUs')
+    rays_per_gpu //= world
+    if rays_per_gpu % 256:
+      if args.config == 'cfg4':
+        raise SystemExit('RobustNeRF needs whole 16x16 patches per GPU: strong scaling stops at 4 GPUs for 1024 rays')
+      P = 8                      # 128 rays per GPU = two 8x8 patches (the plain / static-mask losses have no patch structure)
   config = configs.make_config(batch_size=rays_per_gpu * world)
   model, state, _, train_step, _ = train_utils.setup_model(config, 20200823, compute_dtype=args.dtype, device=device)
-  batch = synth_batch(rays_per_gpu // 256, 16, 1000 + rank, device)
+  batch = synth_batch(rays_per_gpu // (P * P), P, 1000 + rank, device)
   if args.config == 'cfg4':       # distractor-like geometry: near in [0.05, 0.3], far 1e6
     batch.rays.near.uniform_(0.05, 0.3)
     batch.rays.far.fill_(1e6)
   if args.config != 'cfg2':
-    batch.rays.embed_idx.copy_(torch.randint(0, 3500, (rays_per_gpu // 256, 1, 1, 1), device=device).expand_as(batch.rays.embed_idx))
-    batch.rays.static_mask.copy_((torch.rand(rays_per_gpu // 256, 16, 16, 1, device=device) < 0.8).float())
+    batch.rays.embed_idx.copy_(torch.randint(0, 3500, (rays_per_gpu // (P * P), 1, 1, 1), device=device).expand_as(batch.rays.embed_idx))
+    batch.rays.static_mask.copy_((torch.rand(rays_per_gpu // (P * P), P, P, 1, device=device) < 0.8).float())
   # the reference's stream: PRNGKey(20200823) split over the devices (train.py:46,80), threefry on the GPU
   from nerf_hugs_amd.internal import random as hrandom
   gen = hrandom.split(hrandom.PRNGKey(20200823, device), world)[rank].clone()
@@ -237,7 +249,7 @@ def main():
     line = {
         "metric": "train rays/sec (%d-ray batch per GPU, 64+128 samples)" % rays_per_gpu, "value": round(rps, 1), "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": {"cfg2": "configs[1]: MipNeRF360 base (kubric_1024_base.gin nets), 1024 rays x (64 prop + 128 fine) per GPU, "
                                         "full train step",
                                 "cfg3": "configs[2] restatement: + HuGS static masks, GLO 48, charb, 4096 rays x (64+128), full train step",

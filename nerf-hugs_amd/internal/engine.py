@@ -464,9 +464,12 @@ class Engine:
     slab = self.ws.get(f'tn_slab/{torch.cuda.current_stream().cuda_stream}', (max(nbytes // 4, 1),))
     _lib.call('hugs_gemm_tn', self.dt, M, Kc, Nn, ns, X, ldx, G, ldg, dW, db, slab)
 
-  def backward_level(self, theta, grad, lv, rays, N, d_rgb_out, d_w_extra, nerfw=None):
+  def backward_level(self, theta, grad, lv, rays, N, d_rgb_out, d_w_extra, nerfw=None, leaf_done=None):
     """Backward of one level: compositing -> heads -> trunk.  Writes (=, not +=) the level's MLP gradients
-    into `grad` (flat, same layout as theta); GLO embedding rows are scatter-added (caller zeroes them)."""
+    into `grad` (flat, same layout as theta); GLO embedding rows are scatter-added (caller zeroes them).
+    leaf_done(lo, hi): optional callback, called on the stream that produced them as soon as the gradient
+    range grad[lo:hi] is final (the heads once, then one trunk layer at a time): the data-parallel step starts that
+    bucket's all-reduce there, underneath the rest of the backward pass."""
     spec, S, lay, ws, dt = lv['spec'], lv['S'], self.layout, self.ws, self.dt
     M = N * S
     tag = f'{spec.name}/bwd'
@@ -525,6 +528,10 @@ class Engine:
       # G_last = (dBott Wb^T + d_raw (x) w_d) * (Ylast > 0)
       _lib.call('hugs_gemm_nt', dt, M, W, Bw, 0, dB, Bw, None, 0, self.wn[(spec.name, lb['name'], 'kernel')], Bw, None, None,
                 1, 0, 0, Ylast, W, d_raw, wd, Ga, W)
+    if leaf_done is not None:      # density / bottleneck / view / rgb (/ transient) layers: everything behind the trunk
+      first = lay.by_path[(spec.name, spec.layers[spec.net_depth]['name'], 'kernel')]
+      last = lay.by_path[(spec.name, spec.layers[-1]['name'], 'bias')]
+      leaf_done(first['off'], last['off'] + int(np.prod(last['pshape'])))
     G = Ga
     X0 = lv['X0']
     # Trunk backward on two HIP streams: the weight-gradient GEMM of layer i (side stream) and the dX GEMM that
@@ -555,6 +562,9 @@ class Engine:
         e = torch.cuda.Event()
         e.record(side)
         tn_done[gi] = e
+        if leaf_done is not None:
+          lk, lb_ = lay.by_path[path], lay.by_path[(spec.name, l['name'], 'bias')]
+          leaf_done(lk['off'], lb_['off'] + int(np.prod(lb_['pshape'])))
       if i > 0:
         nxt = (gi + 1) % 3
         if nxt in tn_done:                           # the dW that last read this buffer must be finished

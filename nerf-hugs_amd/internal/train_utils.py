@@ -317,13 +317,18 @@ def create_train_step(model, config, is_finetune=False):
     prop_lo = layout.by_path[('PropMLP_0', 'Dense_0', 'kernel')]['off']
     last_prop = [lf for lf in layout.leaves if lf['path'][0] == 'PropMLP_0'][-1]
     prop_hi = last_prop['off'] + int(np.prod(last_prop['pshape']))
-    ar_work = None
-    nerf_hi = layout.by_path[('PropMLP_0', 'Dense_0', 'kernel')]['off']      # NerfMLP leaves come first
+    # pmean(grad) in buckets (train_utils.py:457-459 is ONE pmean of the whole tree after the backward pass): the
+    # NerfMLP holds 96 % of the bytes, and its gradient becomes final layer by layer -- heads first, then trunk layer
+    # 7 down to 0, each ~4 MB.  Every bucket's all-reduce (SUM; the 1/world is folded into the clip/Adam kernels) is
+    # issued on the stream that produced it the moment it is final, so RCCL runs underneath the remaining dX / dW
+    # GEMMs and only the last bucket + the small rest (PropMLP, embeddings, stat tail) is exposed.
+    ar_works, ar_ranges = [], []
+
+    def bucket_done(lo, hi):
+      ar_ranges.append((lo, hi))
+      ar_works.append(dist.all_reduce(grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+
     for l in range(L - 1, -1, -1):
-      if world > 1 and l == L - 2 and ar_work is None:
-        # the NerfMLP gradient (96 % of the bytes) is complete: start its all-reduce now, it overlaps the
-        # proposal levels' backward (RCCL runs on its own stream; the tail is reduced after the loop)
-        ar_work = dist.all_reduce(grad[:nerf_hi], op=dist.ReduceOp.SUM, async_op=True)
       coef = config.data_loss_mult if l == L - 1 else config.data_coarse_loss_mult
       is_prop = l < L - 1
       if is_finetune and is_prop:
@@ -333,10 +338,11 @@ def create_train_step(model, config, is_finetune=False):
       tgt = grad
       if is_prop and prop_done:
         tgt = ws.get('grad_tmp', (layout.size + STAT_TAIL,))
+      bucketed = bucket_done if (world > 1 and not is_prop and not is_finetune) else None
       if tt == 'nerfw' and not is_prop:
-        eng.backward_level(state.flat, tgt, levels[l], rays, N, None, d_w[l], nerfw=nw)
+        eng.backward_level(state.flat, tgt, levels[l], rays, N, None, d_w[l], nerfw=nw, leaf_done=bucketed)
       else:
-        eng.backward_level(state.flat, tgt, levels[l], rays, N, d_pred[l] if coef != 0 else None, d_w[l])
+        eng.backward_level(state.flat, tgt, levels[l], rays, N, d_pred[l] if coef != 0 else None, d_w[l], leaf_done=bucketed)
       if is_prop and prop_done:
         _lib.call('hugs_add_inplace', prop_hi - prop_lo, tgt[prop_lo:prop_hi], grad[prop_lo:prop_hi])
       if is_prop:
@@ -347,11 +353,18 @@ def create_train_step(model, config, is_finetune=False):
       torch.cuda.current_stream().wait_event(ev_mask_bwd)
     # ---- pmean(grad), pmean(stats) ------------------------------------------------------------------
     if world > 1:
-      if ar_work is not None:
-        dist.all_reduce(grad[nerf_hi:], op=dist.ReduceOp.SUM)
-        ar_work.wait()
-      else:
-        dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+      # whatever no bucket covered (PropMLP, embeddings, ImplicitMask, the stat tail; everything in the finetune stage)
+      todo, pos = [], 0
+      for lo, hi in sorted(ar_ranges):
+        if lo > pos + 16:                 # (leaves are padded to 4 floats: the few zero floats between buckets need no reduce)
+          todo.append((pos, lo))
+        pos = max(pos, hi)
+      if pos < grad.numel():
+        todo.append((pos, grad.numel()))
+      for lo, hi in todo:
+        ar_works.append(dist.all_reduce(grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+      for w in ar_works:
+        w.wait()
     gscale = 1.0 / world
     for off, n_, mult in decay:        # after pmean; the kernels below scale the buffer by gscale, hence the 1/gscale
       _lib.call('hugs_axpy', n_, 2.0 * mult / gscale, state.flat[off:off + n_], grad[off:off + n_])
