@@ -1,8 +1,9 @@
 """Checkpoint interop with the reference's `flax.training.checkpoints` files (train.py:121,232-236): a flax
 msgpack state dict of `TrainState{step, params, opt_state}`.  flax is not installed here, so this
 follows flax.serialization's documented wire format (msgpack with ExtType 1 = ndarray packed as
-(shape, dtype.name, C-order bytes), ExtType 3 = numpy scalar) and is round-trip tested only -- reading a
-checkpoint written by real flax is "parity unpinned" until one is available.
+(shape, dtype.name, C-order bytes), ExtType 3 = numpy scalar).  Tested by a round trip AND against an independent
+msgpack encoder / decoder written from the msgpack spec (tests/test_cpu_checkpoint_bytes.py); a file written by real
+flax has still never been read (none is available offline): "parity unpinned" in that sense.
 
 Layout written / read:
   {'step': i32, 'params': {'params': {module: {Dense_i: {'kernel','bias'}}, 'GloEmbed_0': {'embedding'}}},

@@ -7,8 +7,9 @@ attributes it must fill (datasets.py:319-332), the batch layout ([num_patches, p
 concatenated on axis 0), `generate_ray_batch`, `peek`, `size`, and -- so that a run is reproducible against the
 reference -- the exact `np.random` call sequence of `_next_train` (:507-519: camera, patch x origins, patch y
 origins, per image).  What is gone: the producer thread and `Queue(3)` (:289): kernels are asynchronous, so
-`__next__` just enqueues ~6 launches.  File-format loaders (Blender, LLFF, Kubric, Phototourism, ...) are host IO
-and out of scope: `ArrayDataset` takes arrays a loader has already decoded.
+`__next__` just enqueues ~6 launches.  The HuGS file-format loaders (Kubric, Phototourism, Distractor) live in
+loaders.py; the upstream multinerf ones (Blender, LLFF, T&T, DTU) are not HuGS datasets and are not built --
+`ArrayDataset` takes arrays a loader has already decoded.
 """
 import numpy as np
 import torch

@@ -1,0 +1,146 @@
+"""restore_checkpoint on bytes that the product's writer did NOT produce, and the product's writer decoded by a
+reader that is not the product's: both sides here are a ~60-line msgpack encoder / decoder written from the msgpack
+spec, laid out the way flax.serialization documents it (flax is not installed; train.py:121,232-236 call pattern):
+
+  msgpack map of the state dict; every ndarray = ExtType(1, msgpack((shape list, dtype.name, C-order bytes)));
+  numpy scalars = ExtType(3, same triple with shape ()); `step` as a 0-d int32 ndarray (what a jax scalar becomes);
+  opt_state = optax.adam's (ScaleByAdamState(count, mu, nu), ScaleByScheduleState(count)) tuple serialised as a
+  dict with keys '0', '1'; mu / nu mirror TrainState.params, i.e. carry the outer 'params' level."""
+import os
+import struct
+
+import numpy as np
+import torch
+
+
+# ---- independent msgpack encoder / decoder (spec: https://github.com/msgpack/msgpack/blob/master/spec.md) ----------
+def enc(o):
+  if isinstance(o, dict):
+    n = len(o)
+    head = bytes([0x80 | n]) if n < 16 else b'\xde' + struct.pack('>H', n)
+    return head + b''.join(enc(k) + enc(v) for k, v in o.items())
+  if isinstance(o, str):
+    b = o.encode()
+    return (bytes([0xa0 | len(b)]) if len(b) < 32 else b'\xd9' + bytes([len(b)])) + b
+  if isinstance(o, bool):
+    return b'\xc3' if o else b'\xc2'
+  if isinstance(o, int):
+    return bytes([o]) if 0 <= o < 128 else b'\xd2' + struct.pack('>i', o)
+  if isinstance(o, bytes):
+    return b'\xc6' + struct.pack('>I', len(o)) + o                      # bin 32
+  if isinstance(o, (list, tuple)):
+    return (bytes([0x90 | len(o)]) if len(o) < 16 else b'\xdc' + struct.pack('>H', len(o))) + b''.join(enc(x) for x in o)
+  if isinstance(o, np.ndarray):
+    payload = enc([list(o.shape), o.dtype.name, o.tobytes('C')])
+    return b'\xc9' + struct.pack('>I', len(payload)) + bytes([1]) + payload        # ext 32, type 1 = ndarray
+  raise TypeError(type(o))
+
+
+def dec(b, i=0):
+  t = b[i]
+  if t < 0x80: return t, i + 1
+  if 0x80 <= t < 0x90 or t in (0xde, 0xdf):
+    n, i = (t & 15, i + 1) if t < 0x90 else ((struct.unpack('>H', b[i + 1:i + 3])[0], i + 3) if t == 0xde else (struct.unpack('>I', b[i + 1:i + 5])[0], i + 5))
+    d = {}
+    for _ in range(n):
+      k, i = dec(b, i); v, i = dec(b, i); d[k] = v
+    return d, i
+  if 0x90 <= t < 0xa0 or t in (0xdc, 0xdd):
+    n, i = (t & 15, i + 1) if t < 0xa0 else ((struct.unpack('>H', b[i + 1:i + 3])[0], i + 3) if t == 0xdc else (struct.unpack('>I', b[i + 1:i + 5])[0], i + 5))
+    out = []
+    for _ in range(n):
+      v, i = dec(b, i); out.append(v)
+    return out, i
+  if 0xa0 <= t < 0xc0: return b[i + 1:i + 1 + (t & 31)].decode(), i + 1 + (t & 31)
+  if t == 0xd9: n = b[i + 1]; return b[i + 2:i + 2 + n].decode(), i + 2 + n
+  if t == 0xda: n = struct.unpack('>H', b[i + 1:i + 3])[0]; return b[i + 3:i + 3 + n].decode(), i + 3 + n
+  if t in (0xc4, 0xc5, 0xc6):
+    w = {0xc4: 1, 0xc5: 2, 0xc6: 4}[t]; n = int.from_bytes(b[i + 1:i + 1 + w], 'big'); return bytes(b[i + 1 + w:i + 1 + w + n]), i + 1 + w + n
+  if t in (0xc7, 0xc8, 0xc9):
+    w = {0xc7: 1, 0xc8: 2, 0xc9: 4}[t]; n = int.from_bytes(b[i + 1:i + 1 + w], 'big'); code = b[i + 1 + w]
+    (shape, dtype, buf), _ = dec(b[i + 2 + w:i + 2 + w + n])
+    arr = np.frombuffer(buf, dtype=np.dtype(dtype)).reshape(shape)
+    return (arr if code == 1 else arr[()]), i + 2 + w + n
+  if t in (0xd4, 0xd5, 0xd6, 0xd7, 0xd8):                     # fixext
+    n = {0xd4: 1, 0xd5: 2, 0xd6: 4, 0xd7: 8, 0xd8: 16}[t]; raise AssertionError('fixext is not what flax writes')
+  if t == 0xd2: return struct.unpack('>i', b[i + 1:i + 5])[0], i + 5
+  if t == 0xd0: return struct.unpack('>b', b[i + 1:i + 2])[0], i + 2
+  if t == 0xd1: return struct.unpack('>h', b[i + 1:i + 3])[0], i + 3
+  if t == 0xcc: return b[i + 1], i + 2
+  if t == 0xcd: return struct.unpack('>H', b[i + 1:i + 3])[0], i + 3
+  if t == 0xce: return struct.unpack('>I', b[i + 1:i + 5])[0], i + 5
+  if t >= 0xe0: return t - 256, i + 1
+  raise AssertionError(hex(t))
+
+
+GIN = ["PropMLP.net_depth = 1", "PropMLP.net_width = 128", "PropMLP.disable_rgb = True", "PropMLP.max_deg_point = 1",
+       "NerfMLP.net_depth = 1", "NerfMLP.net_width = 128", "NerfMLP.bottleneck_width = 128", "NerfMLP.max_deg_point = 1",
+       "Model.num_glo_features = 4", "Model.num_embeddings = 8"]
+
+
+def _model():
+  from nerf_hugs_amd.internal import configs, models, train_utils
+  configs.clear_config()
+  configs.parse_config_files_and_bindings(None, GIN)
+  cfg = configs.make_config()
+  model = models.Model(cfg)
+  state, _ = train_utils.create_optimizer(cfg, model.init(3, 'cpu'), model)
+  configs.clear_config()
+  return model, state
+
+
+def _known_tree(model, seed):
+  rng = np.random.default_rng(seed)
+  tree = {}
+  for lf in model.layout.leaves:
+    d = tree
+    for k in lf['path'][:-1]:
+      d = d.setdefault(k, {})
+    d[lf['path'][-1]] = rng.normal(size=lf['shape']).astype(np.float32)
+  return {'params': tree}
+
+
+def test_restore_checkpoint_from_independently_encoded_flax_bytes(tmp_path):
+  from nerf_hugs_amd.internal import checkpoints
+  model, state = _model()
+  params, mu, nu = _known_tree(model, 1), _known_tree(model, 2), _known_tree(model, 3)
+  blob = enc({'step': np.array(4321, np.int32),                       # 0-d ndarray, as a jax scalar serialises
+              'params': params,
+              'opt_state': {'0': {'count': np.array(4321, np.int32), 'mu': mu, 'nu': nu},
+                            '1': {'count': np.array(4321, np.int32)}}})
+  with open(tmp_path / 'checkpoint_4321', 'wb') as f:
+    f.write(blob)
+  with open(tmp_path / 'checkpoint_12', 'wb') as f:               # an older one that must not be picked
+    f.write(b'\x80')
+  state = checkpoints.restore_checkpoint(str(tmp_path), state)
+  assert state.step == 4321
+  for lf in model.layout.leaves:
+    for buf, tree in ((state.flat, params), (state.m, mu), (state.v, nu)):
+      ref = tree['params']
+      for k in lf['path']:
+        ref = ref[k]
+      assert torch.equal(model.layout.view(buf, lf['path']), torch.from_numpy(ref)), lf['path']
+  # zero-padded rows / columns of the flat layout stay zero (504 -> 512 style padding)
+  k0 = model.layout.by_path[('NerfMLP_0', 'Dense_0', 'kernel')]
+  full = state.flat[k0['off']:k0['off'] + int(np.prod(k0['pshape']))].view(*k0['pshape'])
+  assert float(full[k0['shape'][0]:].abs().max()) == 0.0
+
+
+def test_saved_checkpoint_decodes_with_an_independent_reader(tmp_path):
+  from nerf_hugs_amd.internal import checkpoints
+  model, state = _model()
+  state.m.normal_(); state.v.uniform_(); state.step = 77
+  path = checkpoints.save_checkpoint(str(tmp_path), state, state.step)
+  d, end = dec(open(path, 'rb').read())
+  assert end == os.path.getsize(path)
+  assert set(d) == {'step', 'params', 'opt_state'} and int(d['step']) == 77
+  assert set(d['opt_state']) == {'0', '1'} and set(d['opt_state']['0']) == {'count', 'mu', 'nu'}
+  for tree, buf in ((d['params'], state.flat), (d['opt_state']['0']['mu'], state.m), (d['opt_state']['0']['nu'], state.v)):
+    assert set(tree) == {'params'}
+    assert set(tree['params']) == {'NerfMLP_0', 'PropMLP_0', 'GloEmbed_0'}
+    for lf in model.layout.leaves:
+      a = tree['params']
+      for k in lf['path']:
+        a = a[k]
+      assert a.dtype == np.float32 and a.shape == tuple(lf['shape'])
+      assert np.array_equal(a, model.layout.view(buf, lf['path']).numpy())
