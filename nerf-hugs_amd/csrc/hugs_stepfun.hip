@@ -40,6 +40,20 @@ __device__ __forceinline__ float sf_expf(float x) {
   return (p * s1) * s2;
 }
 
+__device__ __forceinline__ float sf_logf(float x);
+__device__ __forceinline__ float sf_expf(float x);
+// fn_fwd (inverse = false) / fn_inv (inverse = true) of Model.raydist_fn (coord.py:84-93)
+__device__ __forceinline__ float sf_raywarp(float x, int raydist, bool inverse) {
+  switch (raydist) {
+    case 1: return 1.0f / x;
+    case 2: return inverse ? sf_expf(x) : sf_logf(x);
+    case 3: return inverse ? sf_logf(x) : sf_expf(x);
+    case 4: return inverse ? x * x : sqrtf(x);
+    case 5: return inverse ? sqrtf(x) : x * x;
+    default: return x;
+  }
+}
+
 __device__ __forceinline__ float sf_logf(float x) {
   if (x != x || x < 0.0f) return __builtin_nanf("");
   if (x == 0.0f) return -__builtin_inff();
@@ -246,8 +260,11 @@ __global__ __launch_bounds__(256) void k_level_sample(
   __syncthreads();
   if (live) {
     const float nr = near[ray], fr = far[ray];
-    const float s_near = raydist == 1 ? 1.0f / nr : nr;
-    const float s_far = raydist == 1 ? 1.0f / fr : fr;
+    // coord.py:63-99: fn_fwd on the bounds, fn_inv on the blend.  raydist: 0 None, 1 reciprocal, 2 log (inverse exp),
+    // 3 exp (inverse log), 4 sqrt (inverse square), 5 square (inverse sqrt); exp / log are the canonical polynomial
+    // versions shared with the C oracle, sqrt is the correctly rounded one.
+    const float s_near = sf_raywarp(nr, raydist, false);
+    const float s_far = sf_raywarp(fr, raydist, false);
     for (int j = lane; j <= ns; j += 64) {
       float s;
       if (j == 0) {
@@ -263,7 +280,7 @@ __global__ __launch_bounds__(256) void k_level_sample(
       }
       sdist[(size_t)ray * (ns + 1) + j] = s;
       float v = s * s_far + (1.0f - s) * s_near;
-      tdist[(size_t)ray * (ns + 1) + j] = raydist == 1 ? 1.0f / v : v;
+      tdist[(size_t)ray * (ns + 1) + j] = sf_raywarp(v, raydist, true);
     }
   }
 }
@@ -284,7 +301,7 @@ extern "C" int hugs_level_sample_fwd(int nrays, const float* t_prev, const float
   int n_in = do_dilate ? 3 * n_prev : n_prev;
   HUGS_REQUIRE(n_prev >= 1 && n_in <= SF_CAP, -3, "hugs_level_sample_fwd: %d input bins (%d after dilation) > capacity %d",
                n_prev, n_in, SF_CAP);
-  HUGS_REQUIRE(raydist == 0 || raydist == 1, -4, "hugs_level_sample_fwd: raydist must be 0 (linear) or 1 (reciprocal)");
+  HUGS_REQUIRE(raydist >= 0 && raydist <= 5, -4, "hugs_level_sample_fwd: raydist must be 0 (None), 1 reciprocal, 2 log, 3 exp, 4 sqrt or 5 square");
   if (nrays <= 0) return 0;
   // one lane-chunk for the whole level, chosen from its largest array (the oracle applies the same rule)
   const int big = n_in > num_samples ? n_in : num_samples;

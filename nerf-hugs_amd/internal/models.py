@@ -50,9 +50,10 @@ class Model:
       raise NotImplementedError('stop_level_grad=False / use_viewdirs=False / disable_integration')
     self.bg_intensity = float(self.bg_intensity_range[0])
     rd = self.raydist_fn
-    self.raydist = None if rd is None else {'jnp.reciprocal': 'reciprocal'}.get(getattr(rd, 'name', rd), getattr(rd, 'name', rd))
-    if self.raydist not in (None, 'reciprocal'):
-      raise NotImplementedError(f'raydist_fn {rd!r}: only None and @jnp.reciprocal are built')
+    name = None if rd is None else getattr(rd, 'name', rd)
+    self.raydist = None if name is None else (name[4:] if str(name).startswith('jnp.') else name)
+    if self.raydist not in stepfun.RAYDIST:        # coord.py:84-90 knows reciprocal / log / exp / sqrt / square (+ 'piecewise')
+      raise NotImplementedError(f"raydist_fn {rd!r}: built are None and @jnp.reciprocal / log / exp / sqrt / square")
     # models.py:104-105: NerfMLP(disable_transient=(transient_type != 'nerfw')), PropMLP(disable_transient=True)
     self.nerf_spec = _engine.MLPSpec('NerfMLP_0', False, self.num_glo_features,
                                      self.num_transient_features if tt == 'nerfw' else 0, **configs.bindings('NerfMLP'))

@@ -236,6 +236,19 @@ int orc_sample_intervals(const float* u, int ns, const float* t, const float* lo
   return sample_intervals_(u, ns, t, logits, n, lo, hi, out, idx);
 }
 
+/* coord.py:84-93: fn_fwd (inverse = 0) / fn_inv (inverse = 1) of Model.raydist_fn.
+ * raydist: 0 None, 1 reciprocal, 2 log <-> exp, 3 exp <-> log, 4 sqrt <-> square, 5 square <-> sqrt. */
+static float orc_raywarp(float x, int raydist, int inverse) {
+  switch (raydist) {
+    case 1: return 1.0f / x;
+    case 2: return inverse ? orc_expf(x) : orc_logf(x);
+    case 3: return inverse ? orc_logf(x) : orc_expf(x);
+    case 4: return inverse ? x * x : sqrtf(x);
+    case 5: return inverse ? sqrtf(x) : x * x;
+    default: return x;
+  }
+}
+
 /* One sampling level for one ray, following models.py:155-212:
  *   [dilate (level>0)] -> trim [1:-1] -> annealed logits -> sample_intervals -> s_to_t.
  * u = u_base[j] + jitter (one float add, as stepfun.py:203-209 does with the
@@ -268,11 +281,11 @@ int orc_level_sample(const float* t_prev, const float* w_prev, int n_prev, int d
   for (int j = 0; j < ns; ++j) u[j] = u_base[j] + jitter;
   int rc = sample_intervals_(u, ns, t_in, lg, n, lo, hi, sdist, idx);
   if (rc) return rc;
-  float s_near = raydist == 1 ? 1.0f / near : near;
-  float s_far = raydist == 1 ? 1.0f / far : far;
+  float s_near = orc_raywarp(near, raydist, 0);
+  float s_far = orc_raywarp(far, raydist, 0);
   for (int j = 0; j <= ns; ++j) {             /* coord.py:98: fn_inv(s*s_far + (1-s)*s_near) */
     float v = sdist[j] * s_far + (1.0f - sdist[j]) * s_near;
-    tdist[j] = raydist == 1 ? 1.0f / v : v;
+    tdist[j] = orc_raywarp(v, raydist, 1);
   }
   if (t_in_out) memcpy(t_in_out, t_in, (n + 1) * sizeof(float));
   if (w_in_out) memcpy(w_in_out, w_in, n * sizeof(float));

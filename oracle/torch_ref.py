@@ -119,13 +119,15 @@ def contract_track_linearize(mean, cov):
   return contract(mean), J @ cov @ J.transpose(-1, -2)
 
 
+RAYDIST = {None: 0, 'reciprocal': 1, 'log': 2, 'exp': 3, 'sqrt': 4, 'square': 5}
+
+
 def s_to_t(s, near, far, raydist):
-  """coord.py:63-99; raydist in {None, 'reciprocal'} (the HuGS/360 gins use only these)."""
-  if raydist is None:
-    return s * far + (1 - s) * near
-  if raydist == 'reciprocal':
-    return 1 / (s * (1 / far) + (1 - s) * (1 / near))
-  raise ValueError(raydist)
+  """coord.py:63-99: fn_inv(s * fn(far) + (1 - s) * fn(near)) with the (fn, fn_inv) pairs of :84-90."""
+  fwd, inv = {None: (lambda x: x, lambda x: x), 'reciprocal': (torch.reciprocal, torch.reciprocal),
+              'log': (torch.log, torch.exp), 'exp': (torch.exp, torch.log), 'sqrt': (torch.sqrt, torch.square),
+              'square': (torch.square, torch.sqrt)}[raydist]
+  return inv(s * fwd(far) + (1 - s) * fwd(near))
 
 
 def lift_and_diagonalize(mean, cov, basis):
@@ -311,7 +313,7 @@ class ModelCfg:
     self.num_levels = 3
     self.bg_intensity = 1.0
     self.anneal_slope = 10.
-    self.raydist_fn = None           # None | 'reciprocal'
+    self.raydist_fn = None           # None | 'reciprocal' | 'log' | 'exp' | 'sqrt' | 'square' (coord.py:84-90)
     self.ray_shape = 'cone'
     self.single_jitter = True
     self.dilation_multiplier = 0.5
@@ -536,7 +538,7 @@ def model_forward(cfg, variables, rays, train_frac, u01, compute_extras, zero_gl
     jit = None if u01 is None else (u01[lvl].detach().numpy().astype(np.float32) * np.float32(mj))
     sd, td, _ = cstepfun.level_sample(
         sdist.detach().numpy(), weights.detach().numpy(), lvl > 0, dilation, 0., 1., anneal,
-        cfg.resample_padding, ub, jit, 1 if cfg.raydist_fn == 'reciprocal' else 0,
+        cfg.resample_padding, ub, jit, RAYDIST[cfg.raydist_fn],
         near.numpy(), far.numpy())
     sdist = torch.from_numpy(sd).to(dt)          # stop_gradient (models.py:208-209)
     tdist = torch.from_numpy(td).to(dt)

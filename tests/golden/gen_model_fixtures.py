@@ -330,6 +330,23 @@ def main():
     out[f'unit/data/{tag}/data'] = np.float64(losses['data'])
     out[f'unit/data/{tag}/mses'] = np.asarray(st['mses'], np.float64)
 
+  # ---- coord.construct_ray_warps for every raydist_fn it knows (coord.py:84-90) ---------------------------------
+  sv = np.linspace(0, 1, 33).astype(f32)[None, :]
+  nearv = np.array([[0.05], [0.3], [1.0]], f32)
+  farv = np.array([[1.2], [40.0], [1e3]], f32)
+  out['unit/raywarp/s'], out['unit/raywarp/near'], out['unit/raywarp/far'] = sv, nearv, farv
+
+  def named(name, fn):
+    fn.__name__ = name
+    return fn
+  for name, fn in (('none', None), ('reciprocal', named('reciprocal', lambda x: np.reciprocal(x))),
+                   ('log', named('log', lambda x: np.log(x))), ('exp', named('exp', lambda x: np.exp(x))),
+                   ('sqrt', named('sqrt', lambda x: np.sqrt(x))), ('square', named('square', lambda x: np.square(x)))):
+    fv = np.minimum(farv, 40.0) if name == 'exp' else farv          # exp(1e3) overflows float32
+    t_to_s, s_to_t = coord.construct_ray_warps(fn, nearv, fv)
+    out[f'unit/raywarp/{name}/t'] = np.asarray(s_to_t(sv), f32)
+    out[f'unit/raywarp/{name}/s_back'] = np.asarray(t_to_s(s_to_t(sv)), f32)
+
   path = os.path.join(HERE, 'ref_model.npz')
   np.savez_compressed(path, **out)
   print(f'wrote {path}: {len(out)} arrays, {sum(np.asarray(v).nbytes for v in out.values())/1e6:.2f} MB raw, '

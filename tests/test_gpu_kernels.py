@@ -50,10 +50,10 @@ def _run_level(N, n_prev, ns, dil, raydist, jitter, seed, wpow=1, zeros=False, a
   ub, mj = R.sample_u_base(ns, jitter)
   jit = (u01 * np.float32(mj)).astype(np.float32) if jitter else None
   near = rng.uniform(0.05, 0.3, N).astype(np.float32)
-  far = np.full(N, 1e6 if raydist else 1.2, np.float32)
+  far = np.full(N, {0: 1.2, 1: 1e6, 3: 5.0}.get(raydist, 300.0), np.float32)
   sd_o, td_o, idx_o = C.level_sample(t, w, dil is not None, dil or 0., 0., 1., anneal, 0., ub, jit, raydist, near, far)
   sd, td, idx, tin, win = stepfun.level_sample(G(t), G(w), dil is not None, dil or 0., (0., 1.), anneal, 0., ns,
-                                               None if u01 is None else G(u01), 'reciprocal' if raydist else None,
+                                               None if u01 is None else G(u01), [None, 'reciprocal', 'log', 'exp', 'sqrt', 'square'][raydist],
                                                G(near), G(far), return_debug=True)
   assert np.array_equal(idx.cpu().numpy(), idx_o), 'interval indices'
   assert np.array_equal(bits(sd.cpu().numpy()), bits(sd_o)), 'sdist'
@@ -82,6 +82,11 @@ def _run_level(N, n_prev, ns, dil, raydist, jitter, seed, wpow=1, zeros=False, a
     dict(N=40, n_prev=256, ns=256, dil=0.0031, raydist=1, jitter=True, wpow=3, zeros=True),
     dict(N=17, n_prev=256, ns=64, dil=0.0031, raydist=0, jitter=False),
     dict(N=9, n_prev=1000, ns=1024, dil=None, raydist=0, jitter=True, wpow=4),
+    # the other raydist_fn curves of coord.py:84-90 (log, exp, sqrt, square)
+    dict(N=200, n_prev=64, ns=64, dil=0.0103125, raydist=2, jitter=True),
+    dict(N=200, n_prev=64, ns=64, dil=0.0103125, raydist=3, jitter=False),
+    dict(N=200, n_prev=64, ns=128, dil=0.0103125, raydist=4, jitter=True),
+    dict(N=200, n_prev=64, ns=32, dil=0.0103125, raydist=5, jitter=True),
 ])
 def test_level_sample_bit_exact_vs_oracle(case):
   _run_level(seed=3, **case)

@@ -75,7 +75,7 @@ def test_sampler_interval_index_vs_reference(case):
     ub, mj = R.sample_u_base(S, True)
     jit = FX.get(case, f'l{l}_u01')[rows] * np.float32(mj)
     sd, td, idx = cstepfun.level_sample(t_prev, w_prev, l > 0, dilation, 0., 1., anneal, 0., ub, jit,
-                                        1 if cfg.raydist_fn == 'reciprocal' else 0, near[rows], far[rows])
+                                        R.RAYDIST[cfg.raydist_fn], near[rows], far[rows])
     ref_idx = FX.get(case, f'l{l}_idx')[rows]
     ref_sd = FX.get(case, f'train/l{l}_sdist')[rows]
     mism = idx != ref_idx
@@ -224,3 +224,21 @@ def test_data_loss_unit_vs_reference():
     loss, st = R.compute_data_loss(cfg, gt, rays, rend, use_mask)
     assert abs(float(loss) - float(z[f'unit/data/{tag}/data'])) <= 2e-6 * abs(float(loss)), tag
     np.testing.assert_allclose(st['mses'].numpy(), z[f'unit/data/{tag}/mses'], rtol=2e-6)
+
+
+def test_ray_warps_vs_reference():
+  """coord.construct_ray_warps (coord.py:63-99) for every curve it knows: the torch oracle against the reference's own
+  s_to_t, and the C oracle's canonical-arithmetic tdist (polynomial exp / log) against the torch oracle."""
+  z = FX.npz()
+  s, near, far = (torch.from_numpy(z[f'unit/raywarp/{k}'].copy()) for k in ('s', 'near', 'far'))
+  for name in ('none', 'reciprocal', 'log', 'exp', 'sqrt', 'square'):
+    rd = None if name == 'none' else name
+    fv = torch.clamp(far, max=40.0) if name == 'exp' else far
+    t = R.s_to_t(s, near, fv, rd)
+    np.testing.assert_allclose(t.numpy(), z[f'unit/raywarp/{name}/t'], rtol=3e-6, err_msg=name)
+    # C oracle: one trivial level (a single unit-weight interval) -> its sdist through the same warp
+    ub, _ = R.sample_u_base(16, False)
+    sd, td, _ = cstepfun.level_sample(np.tile([[0., 1.]], (3, 1)), np.ones((3, 1), np.float32), False, 0., 0., 1., 1., 0.,
+                                      ub, None, R.RAYDIST[rd], near.numpy(), fv.numpy())
+    ref = R.s_to_t(torch.from_numpy(sd).double(), near.double(), fv.double(), rd).numpy()
+    np.testing.assert_allclose(td, ref, rtol=2e-6, err_msg=name)
