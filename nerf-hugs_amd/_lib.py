@@ -55,6 +55,18 @@ _PROTOS = {
     'hugs_hashgrid_fwd': 'iiippppp' 'iips',
     'hugs_hashgrid_bwd': 'iiippppp' 'iips',
     'hugs_sh4_fwd': 'ipiiips',
+    'hugs_nf_sample': 'iiippffppiffipppps',
+    'hugs_nf_positions': 'iipppifpps',
+    'hugs_nf_weights_fwd': 'iipppipppppps',
+    'hugs_nf_weights_bwd': 'iipppippppppps',
+    'hugs_nf_interlevel': 'iiippppfpps',
+    'hugs_nf_density_act': 'qipiipps',
+    'hugs_nf_base_grad': 'qipipppiiipis',
+    'hugs_nf_head_input': 'qiippiipipis',
+    'hugs_nf_app_bwd': 'iiipiiipps',
+    'hugs_nf_rgb_act': 'qipifps',
+    'hugs_nf_rgb_grad': 'qipppis',
+    'hugs_nf_adam': 'qppppffffffs',
     'hugs_test_force_small_tiles': 'i',
 }
 _CT = {'i': ctypes.c_int, 'f': ctypes.c_float, 'p': ctypes.c_void_p, 'q': ctypes.c_longlong,

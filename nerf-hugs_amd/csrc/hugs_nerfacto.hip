@@ -1,0 +1,484 @@
+// Per-ray and per-sample kernels of the NERFACTO path (reference: /root/reference/nerfacto).
+//   hugs_nf_sample        utils/ray_utils.py:112-231 sample / sample_intervals (+ s_to_t of models/nerfacto.py:243-248)
+//   hugs_nf_positions     models/nerfacto.py:326-328 sample positions, :822-829 / :975-982 normalisation + selector,
+//                         models/custom_functions.py:17-24 contraction
+//   hugs_nf_weights_fwd/bwd  utils/ray_utils.py:234-257 density_to_weight (deltas from the FIRST bin edge -- the
+//                         reference's own arithmetic), :300-314 render_features, :340-347 render_depth
+//   hugs_nf_interlevel    utils/loss_utils.py:7-62 (searchsorted-right `outer`, EPS = 1e-7) with the gradient to w_env
+//   hugs_nf_density_act / hugs_nf_base_grad / hugs_nf_head_input / hugs_nf_app_bwd / hugs_nf_rgb_act / hugs_nf_rgb_grad
+//                         the element-wise glue between the padded GEMMs of the fields (models/nerfacto.py:818-876,
+//                         :971-988; custom_functions.py:38-52 trunc_exp)
+//   hugs_nf_adam          torch.optim.Adam step (train.py:183) on the flat parameter buffer
+// One wavefront owns one ray in the per-ray kernels (up to 1024 bins: 16 per lane, staged in LDS).
+#include "hugs_common.h"
+
+#define NF_CAP 1025
+
+__device__ __forceinline__ float nf_load(const void* p, size_t i, int bf16) {
+  return bf16 ? bf16_to_f(((const uint16_t*)p)[i]) : ((const float*)p)[i];
+}
+__device__ __forceinline__ void nf_store(void* p, size_t i, int bf16, float v) {
+  if (bf16) ((uint16_t*)p)[i] = f_to_bf16(v); else ((float*)p)[i] = v;
+}
+
+// spacing functions of models/nerfacto.py:231-241: 0 uniform, 1 piecewise, 2 reciprocal
+__device__ __forceinline__ float nf_spacing(float x, int mode, bool inverse) {
+  if (mode == 1) return inverse ? (x < 0.5f ? 2.f * x : 1.f / (2.f - 2.f * x)) : (x < 1.f ? x / 2.f : 1.f - 1.f / (2.f * x));
+  if (mode == 2) return 1.f / x;
+  return x;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sampler
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_nf_sample(int nrays, int nb, int ns, const float* __restrict__ bins,
+                                                  const float* __restrict__ weights, float anneal, float padding,
+                                                  const float* __restrict__ u_base, const float* __restrict__ jitter,
+                                                  int jitter_stride, float lo, float hi, int spacing,
+                                                  const float* __restrict__ near, const float* __restrict__ far,
+                                                  float* __restrict__ sbins, float* __restrict__ ebins) {
+  __shared__ float s_bin[NF_CAP], s_cdf[NF_CAP], s_cen[NF_CAP];
+  const int ray = blockIdx.x, lane = threadIdx.x;
+  const float* b = bins + (size_t)ray * (nb + 1);
+  const float* w = weights + (size_t)ray * nb;
+  for (int i = lane; i <= nb; i += 64) s_bin[i] = b[i];
+  __syncthreads();
+  // logits (ray_utils.py:146-150), softmax
+  float mx = -__builtin_inff();
+  for (int i = lane; i < nb; i += 64) {
+    const float lg = s_bin[i + 1] > s_bin[i] ? anneal * logf(w[i] + padding) : -__builtin_inff();
+    s_cen[i] = lg;
+    mx = fmaxf(mx, lg);
+  }
+  mx = wave_max_f(mx);
+  const bool dead = !(mx > -__builtin_inff());          // every logit -inf: the reference sets them all to 1
+  float sum = 0.f;
+  for (int i = lane; i < nb; i += 64) {
+    const float e = dead ? 1.f : expf(s_cen[i] - mx);
+    s_cen[i] = e;
+    sum += e;
+  }
+  sum = wave_sum_f(sum);
+  __syncthreads();
+  // cdf = [0, cumsum(pdf[:-1]).clamp_max(1), 1]: lane owns a contiguous chunk, wave scan of the chunk totals
+  const int per = (nb + 63) / 64;
+  float loc = 0.f;
+  for (int k = 0; k < per; ++k) { const int i = lane * per + k; if (i < nb) loc += s_cen[i] / sum; }
+  const float incl = wave_incl_scan_f(loc, lane);
+  float run = incl - loc;
+  for (int k = 0; k < per; ++k) {
+    const int i = lane * per + k;
+    if (i < nb) { run += s_cen[i] / sum; if (i + 1 < nb) s_cdf[i + 1] = fminf(run, 1.f); }
+  }
+  if (lane == 0) { s_cdf[0] = 0.f; s_cdf[nb] = 1.f; }
+  __syncthreads();
+  // inverse cdf: inds = searchsorted(cdf, u, right); below / above clamped (ray_utils.py:188-199)
+  for (int j = lane; j < ns; j += 64) {
+    const float u = u_base[j] + (jitter ? jitter[(size_t)ray * jitter_stride + (jitter_stride > 1 ? j : 0)] : 0.f);
+    int l = 0, r = nb + 1;                              // first index with cdf > u
+    while (l < r) { const int m = (l + r) >> 1; if (s_cdf[m] > u) r = m; else l = m + 1; }
+    const int below = min(max(l - 1, 0), nb), above = min(max(l, 0), nb);
+    const float c0 = s_cdf[below], c1 = s_cdf[above], b0 = s_bin[below], b1 = s_bin[above];
+    float t = (u - c0) / (c1 - c0);
+    if (t != t) t = 0.f;
+    t = fminf(fmaxf(t, 0.f), 1.f);
+    s_cen[j] = b0 + t * (b1 - b0);
+  }
+  __syncthreads();
+  const float nr = near[ray], fr = far[ray];
+  const float s_near = nf_spacing(nr, spacing, false), s_far = nf_spacing(fr, spacing, false);
+  for (int j = lane; j <= ns; j += 64) {
+    float s;
+    if (j == 0) s = fmaxf(2.f * s_cen[0] - (s_cen[1] + s_cen[0]) / 2.f, lo);
+    else if (j == ns) s = fminf(2.f * s_cen[ns - 1] - (s_cen[ns - 1] + s_cen[ns - 2]) / 2.f, hi);
+    else s = (s_cen[j] + s_cen[j - 1]) / 2.f;
+    sbins[(size_t)ray * (ns + 1) + j] = s;
+    ebins[(size_t)ray * (ns + 1) + j] = nf_spacing(s * s_far + (1.f - s) * s_near, spacing, true);
+  }
+}
+
+extern "C" int hugs_nf_sample(int nrays, int nb, int ns, const float* bins, const float* weights, float anneal, float padding,
+                              const float* u_base, const float* jitter, int jitter_stride, float lo, float hi, int spacing,
+                              const float* near, const float* far, float* sbins, float* ebins, void* stream) {
+  if (ns <= 1) { hugs_set_error("num_samples must be > 1, is %d.", ns); return -2; }
+  HUGS_REQUIRE(nb >= 1 && nb < NF_CAP && ns < NF_CAP, -3, "hugs_nf_sample: %d bins / %d samples exceed the capacity %d", nb, ns, NF_CAP - 1);
+  HUGS_REQUIRE(spacing >= 0 && spacing <= 2, -2, "hugs_nf_sample: spacing must be 0 uniform, 1 piecewise or 2 reciprocal");
+  if (nrays <= 0) return 0;
+  hipLaunchKernelGGL(k_nf_sample, dim3(nrays), dim3(64), 0, (hipStream_t)stream, nrays, nb, ns, bins, weights, anneal, padding,
+                     u_base, jitter, jitter_stride, lo, hi, spacing, near, far, sbins, ebins);
+  HUGS_CHECK_LAUNCH("hugs_nf_sample");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// positions
+// ------------------------------------------------------------------------------------------------
+__global__ void k_nf_positions(long long M, int S, const float* __restrict__ ebins, const float* __restrict__ origins,
+                               const float* __restrict__ dirs, int contract, float bound, float* __restrict__ x01,
+                               float* __restrict__ sel) {
+  const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const int ray = (int)(m / S), s = (int)(m % S);
+  const float t = (ebins[(size_t)ray * (S + 1) + s + 1] + ebins[(size_t)ray * (S + 1) + s]) / 2.f;
+  float p[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) p[c] = origins[ray * 3 + c] + dirs[ray * 3 + c] * t;
+  if (contract) {   // custom_functions.py:17-24, then (x + 2) / 4
+    const float m2 = fmaxf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2], HUGS_EPS);
+    if (!(m2 <= 1.f)) { const float k = (2.f * sqrtf(m2) - 1.f) / m2; p[0] *= k; p[1] *= k; p[2] *= k; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[c] = (p[c] + 2.f) / 4.f;
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[c] = (p[c] + bound) / (2.f * bound);
+  }
+  const bool in = p[0] >= 0.f && p[0] <= 1.f && p[1] >= 0.f && p[1] <= 1.f && p[2] >= 0.f && p[2] <= 1.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) x01[m * 3 + c] = in ? p[c] : 0.f;
+  sel[m] = in ? 1.f : 0.f;
+}
+
+extern "C" int hugs_nf_positions(int nrays, int S, const float* ebins, const float* origins, const float* dirs, int contract,
+                                 float bound, float* x01, float* sel, void* stream) {
+  const long long M = (long long)nrays * S;
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(k_nf_positions, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, S, ebins, origins,
+                     dirs, contract, bound, x01, sel);
+  HUGS_CHECK_LAUNCH("hugs_nf_positions");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// density -> weights, rendering (one wave per ray, samples chunked contiguously per lane)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_nf_weights_fwd(int nrays, int S, const float* __restrict__ density,
+                                                       const float* __restrict__ ebins, const float* __restrict__ dirs,
+                                                       int opaque, const float* __restrict__ rgb_s, const float* __restrict__ bg,
+                                                       float* __restrict__ weights, float* __restrict__ rgb_out,
+                                                       float* __restrict__ acc_out, float* __restrict__ depth_out) {
+  const int ray = blockIdx.x, lane = threadIdx.x;
+  const float* eb = ebins + (size_t)ray * (S + 1);
+  const float dn = sqrtf(dirs[ray * 3] * dirs[ray * 3] + dirs[ray * 3 + 1] * dirs[ray * 3 + 1] + dirs[ray * 3 + 2] * dirs[ray * 3 + 2]);
+  const float e0 = eb[0];
+  const int per = (S + 63) / 64;
+  float loc = 0.f;
+  for (int k = 0; k < per; ++k) {
+    const int i = lane * per + k;
+    if (i < S) { const float dd = (opaque && i == S - 1) ? __builtin_inff() : density[(size_t)ray * S + i] * ((eb[i + 1] - e0) * dn); if (i < S - 1) loc += dd; }
+  }
+  float run = wave_incl_scan_f(loc, lane) - loc;        // sum of dd over samples before this lane's chunk
+  float acc = 0.f, dep = 0.f, r = 0.f, g = 0.f, bl = 0.f, smax = 0.f;
+  for (int k = 0; k < per; ++k) {
+    const int i = lane * per + k;
+    if (i < S) {
+      const float dd = (opaque && i == S - 1) ? __builtin_inff() : density[(size_t)ray * S + i] * ((eb[i + 1] - e0) * dn);
+      float wv = (1.f - expf(-dd)) * expf(-run);
+      if (wv != wv) wv = 0.f;                            // nan_to_num (inf * 0)
+      weights[(size_t)ray * S + i] = wv;
+      run += dd;
+      acc += wv;
+      const float step = (eb[i + 1] + eb[i]) / 2.f;
+      dep += wv * step;
+      smax = fmaxf(smax, step);
+      if (rgb_s) { const float* c = rgb_s + ((size_t)ray * S + i) * 3; r += wv * c[0]; g += wv * c[1]; bl += wv * c[2]; }
+    }
+  }
+  acc = wave_sum_f(acc); dep = wave_sum_f(dep); smax = wave_max_f(smax);
+  if (rgb_s) { r = wave_sum_f(r); g = wave_sum_f(g); bl = wave_sum_f(bl); }
+  if (lane == 0) {
+    if (acc_out) acc_out[ray] = acc;
+    if (depth_out) depth_out[ray] = dep / (acc > 0.f ? acc : HUGS_EPS);   // (the reference clips to the BATCH max step: see host)
+    if (rgb_s && rgb_out) {
+      const float ba = fmaxf(1.f - acc, 0.f);
+      rgb_out[ray * 3] = r + (bg ? bg[ray * 3] * ba : 0.f);
+      rgb_out[ray * 3 + 1] = g + (bg ? bg[ray * 3 + 1] * ba : 0.f);
+      rgb_out[ray * 3 + 2] = bl + (bg ? bg[ray * 3 + 2] * ba : 0.f);
+    }
+  }
+}
+
+// dL/d density and dL/d rgb_s from dL/d rgb_out [N,3] and an extra dL/d weights [N,S] (losses on the histogram).
+// w_i = (1 - e^{-dd_i}) T_i, T_i = e^{-sum_{j<i} dd_j}:  dL/d dd_i = g_i T_i e^{-dd_i} - sum_{k>i} g_k w_k.
+__global__ __launch_bounds__(64) void k_nf_weights_bwd(int nrays, int S, const float* __restrict__ density,
+                                                       const float* __restrict__ ebins, const float* __restrict__ dirs,
+                                                       int opaque, const float* __restrict__ rgb_s, const float* __restrict__ bg,
+                                                       const float* __restrict__ weights, const float* __restrict__ d_rgb_out,
+                                                       const float* __restrict__ d_w_extra, float* __restrict__ d_density,
+                                                       float* __restrict__ d_rgb_s) {
+  const int ray = blockIdx.x, lane = threadIdx.x;
+  const float* eb = ebins + (size_t)ray * (S + 1);
+  const float dn = sqrtf(dirs[ray * 3] * dirs[ray * 3] + dirs[ray * 3 + 1] * dirs[ray * 3 + 1] + dirs[ray * 3 + 2] * dirs[ray * 3 + 2]);
+  const float e0 = eb[0];
+  const int per = (S + 63) / 64;
+  float dr[3] = {0.f, 0.f, 0.f};
+  if (d_rgb_out) { dr[0] = d_rgb_out[ray * 3]; dr[1] = d_rgb_out[ray * 3 + 1]; dr[2] = d_rgb_out[ray * 3 + 2]; }
+  // background term: rgb_out += bg * max(1 - acc, 0)  ->  g_i -= <bg, dr> while acc < 1
+  float accp = 0.f;
+  for (int k = 0; k < per; ++k) { const int i = lane * per + k; if (i < S) accp += weights[(size_t)ray * S + i]; }
+  const float acc = wave_sum_f(accp);
+  const float gbg = (bg && d_rgb_out && acc < 1.f) ? -(bg[ray * 3] * dr[0] + bg[ray * 3 + 1] * dr[1] + bg[ray * 3 + 2] * dr[2]) : 0.f;
+  // pass 1: g_i, suffix sums of g_k w_k, prefix sums of dd
+  float loc_gw = 0.f, loc_dd = 0.f;
+  for (int k = 0; k < per; ++k) {
+    const int i = lane * per + k;
+    if (i < S) {
+      const size_t m = (size_t)ray * S + i;
+      float gi = gbg + (d_w_extra ? d_w_extra[m] : 0.f);
+      if (rgb_s && d_rgb_out) gi += dr[0] * rgb_s[m * 3] + dr[1] * rgb_s[m * 3 + 1] + dr[2] * rgb_s[m * 3 + 2];
+      loc_gw += gi * weights[m];
+      if (i < S - 1) loc_dd += (opaque && i == S - 1) ? 0.f : density[m] * ((eb[i + 1] - e0) * dn);
+    }
+  }
+  float suf = wave_incl_suffix_scan_f(loc_gw, lane) - loc_gw;      // sum over later lanes' chunks
+  float run = wave_incl_scan_f(loc_dd, lane) - loc_dd;
+  // walk the chunk backwards for the suffix part, forwards for T: two small loops
+  float Tpre[16], ddv[16], giv[16];
+  for (int k = 0; k < per; ++k) {
+    const int i = lane * per + k;
+    if (i < S) {
+      const size_t m = (size_t)ray * S + i;
+      const float delta = (eb[i + 1] - e0) * dn;
+      ddv[k] = (opaque && i == S - 1) ? __builtin_inff() : density[m] * delta;
+      Tpre[k] = expf(-run);
+      run += ddv[k];
+      float gi = gbg + (d_w_extra ? d_w_extra[m] : 0.f);
+      if (rgb_s && d_rgb_out) gi += dr[0] * rgb_s[m * 3] + dr[1] * rgb_s[m * 3 + 1] + dr[2] * rgb_s[m * 3 + 2];
+      giv[k] = gi;
+      if (d_rgb_s) { const float wv = weights[m]; d_rgb_s[m * 3] = wv * dr[0]; d_rgb_s[m * 3 + 1] = wv * dr[1]; d_rgb_s[m * 3 + 2] = wv * dr[2]; }
+    }
+  }
+  for (int k = per - 1; k >= 0; --k) {
+    const int i = lane * per + k;
+    if (i < S) {
+      const size_t m = (size_t)ray * S + i;
+      const float delta = (eb[i + 1] - e0) * dn;
+      const bool last_opaque = opaque && i == S - 1;
+      // d w_i / d dd_i = T_i e^{-dd_i} (0 for the infinitely wide last interval)
+      const float own = last_opaque ? 0.f : giv[k] * Tpre[k] * expf(-ddv[k]);
+      float dd_grad = own - suf;
+      if (dd_grad != dd_grad) dd_grad = 0.f;
+      d_density[m] = last_opaque ? 0.f : dd_grad * delta;
+      suf += giv[k] * weights[m];
+    }
+  }
+}
+
+extern "C" int hugs_nf_weights_fwd(int nrays, int S, const float* density, const float* ebins, const float* dirs, int opaque,
+                                   const float* rgb_s, const float* bg, float* weights, float* rgb_out, float* acc, float* depth,
+                                   void* stream) {
+  HUGS_REQUIRE(S >= 1 && S < NF_CAP, -3, "hugs_nf_weights_fwd: %d samples per ray unsupported", S);
+  if (nrays <= 0) return 0;
+  hipLaunchKernelGGL(k_nf_weights_fwd, dim3(nrays), dim3(64), 0, (hipStream_t)stream, nrays, S, density, ebins, dirs, opaque, rgb_s,
+                     bg, weights, rgb_out, acc, depth);
+  HUGS_CHECK_LAUNCH("hugs_nf_weights_fwd");
+  return 0;
+}
+
+extern "C" int hugs_nf_weights_bwd(int nrays, int S, const float* density, const float* ebins, const float* dirs, int opaque,
+                                   const float* rgb_s, const float* bg, const float* weights, const float* d_rgb_out,
+                                   const float* d_w_extra, float* d_density, float* d_rgb_s, void* stream) {
+  HUGS_REQUIRE(S >= 1 && S <= 1024, -3, "hugs_nf_weights_bwd: %d samples per ray unsupported (<= 1024)", S);
+  if (nrays <= 0) return 0;
+  hipLaunchKernelGGL(k_nf_weights_bwd, dim3(nrays), dim3(64), 0, (hipStream_t)stream, nrays, S, density, ebins, dirs, opaque, rgb_s,
+                     bg, weights, d_rgb_out, d_w_extra, d_density, d_rgb_s);
+  HUGS_CHECK_LAUNCH("hugs_nf_weights_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// interlevel loss (loss_utils.py:7-62): per ray sum_i max(w_i - w_outer_i, 0)^2 / (w_i + 1e-7), and its gradient to w_env
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_nf_interlevel(int nrays, int S, int Sp, const float* __restrict__ t,
+                                                      const float* __restrict__ w, const float* __restrict__ t_env,
+                                                      const float* __restrict__ w_env, float scale, float* __restrict__ loss_ray,
+                                                      float* __restrict__ d_w_env) {
+  __shared__ float s_te[NF_CAP], s_cy[NF_CAP], s_diff[NF_CAP];
+  const int ray = blockIdx.x, lane = threadIdx.x;
+  const float* te = t_env + (size_t)ray * (Sp + 1);
+  const float* we = w_env + (size_t)ray * Sp;
+  for (int i = lane; i <= Sp; i += 64) { s_te[i] = te[i]; s_diff[i] = 0.f; }
+  // cy1 = [0, cumsum(w_env)]
+  const int per = (Sp + 63) / 64;
+  float loc = 0.f;
+  for (int k = 0; k < per; ++k) { const int i = lane * per + k; if (i < Sp) loc += we[i]; }
+  float run = wave_incl_scan_f(loc, lane) - loc;
+  for (int k = 0; k < per; ++k) { const int i = lane * per + k; if (i < Sp) { run += we[i]; s_cy[i + 1] = run; } }
+  if (lane == 0) s_cy[0] = 0.f;
+  __syncthreads();
+  float ls = 0.f;
+  for (int i = lane; i < S; i += 64) {
+    const float t0 = t[(size_t)ray * (S + 1) + i], t1 = t[(size_t)ray * (S + 1) + i + 1], wi = w[(size_t)ray * S + i];
+    // idx_lo = searchsorted(t_env[:-1], t0, right) - 1 ; idx_hi = searchsorted(t_env[1:], t1, right) ; both clamped to [0, Sp-1]
+    int l = 0, r = Sp;
+    while (l < r) { const int m = (l + r) >> 1; if (s_te[m] > t0) r = m; else l = m + 1; }
+    const int lo = min(max(l - 1, 0), Sp - 1);
+    l = 0; r = Sp;
+    while (l < r) { const int m = (l + r) >> 1; if (s_te[m + 1] > t1) r = m; else l = m + 1; }
+    const int hi = min(max(l, 0), Sp - 1);
+    const float w_outer = s_cy[hi + 1] - s_cy[lo];
+    const float d = fmaxf(wi - w_outer, 0.f);
+    ls += d * d / (wi + 1.0e-7f);
+    if (d > 0.f && d_w_env) {
+      const float c = -2.f * d / (wi + 1.0e-7f) * scale;     // dL/d w_outer, spread over env bins lo..hi
+      if (hi >= lo) { atomicAdd(&s_diff[lo], c); atomicAdd(&s_diff[hi + 1], -c); }
+      // hi < lo: w_outer = cy[hi+1] - cy[lo] = -(sum of w_env[hi+1 .. lo-1]): the same difference form with the sign flipped
+      else { atomicAdd(&s_diff[hi + 1], -c); atomicAdd(&s_diff[lo], c); }
+    }
+  }
+  ls = wave_sum_f(ls);
+  if (lane == 0 && loss_ray) loss_ray[ray] = ls;
+  __syncthreads();
+  if (d_w_env) {
+    float l2 = 0.f;
+    for (int k = 0; k < per; ++k) { const int i = lane * per + k; if (i < Sp) l2 += s_diff[i]; }
+    float r2 = wave_incl_scan_f(l2, lane) - l2;
+    for (int k = 0; k < per; ++k) { const int i = lane * per + k; if (i < Sp) { r2 += s_diff[i]; d_w_env[(size_t)ray * Sp + i] = r2; } }
+  }
+}
+
+extern "C" int hugs_nf_interlevel(int nrays, int S, int Sp, const float* t, const float* w, const float* t_env, const float* w_env,
+                                  float scale, float* loss_ray, float* d_w_env, void* stream) {
+  HUGS_REQUIRE(S >= 1 && Sp >= 1 && S < NF_CAP && Sp < NF_CAP - 1, -3, "hugs_nf_interlevel: S=%d Sp=%d exceed the capacity", S, Sp);
+  if (nrays <= 0) return 0;
+  hipLaunchKernelGGL(k_nf_interlevel, dim3(nrays), dim3(64), 0, (hipStream_t)stream, nrays, S, Sp, t, w, t_env, w_env, scale, loss_ray, d_w_env);
+  HUGS_CHECK_LAUNCH("hugs_nf_interlevel");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// element-wise glue around the fields' GEMMs.  Matrices are row-major [M, ld] in the compute dtype (bf16 or fp32).
+// ------------------------------------------------------------------------------------------------
+// density = trunc_exp(Y[:, col]) * selector  (nerfacto.py:833-836 / 984-987)
+__global__ void k_nf_density_act(long long M, int bf16, const void* __restrict__ Y, int ldy, int col, const float* __restrict__ sel,
+                                 float* __restrict__ density) {
+  const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  density[m] = expf(nf_load(Y, (size_t)m * ldy + col, bf16)) * sel[m];
+}
+
+// G[M, ldg] = gradient at the base MLP's output: column 0 = d_density * exp(clamp(raw, -15, 15)) * selector
+// (custom_functions.py:46-50), columns 1 .. ngeo = dXhead[:, geo_col0 ...] (the head's input gradient), the rest 0.
+__global__ void k_nf_base_grad(long long M, int bf16, const void* __restrict__ Y, int ldy, const float* __restrict__ sel,
+                               const float* __restrict__ d_density, const void* __restrict__ dXh, int ldx, int geo_col0, int ngeo,
+                               void* __restrict__ G, int ldg) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long m = e / ldg;
+  const int c = (int)(e % ldg);
+  if (m >= M) return;
+  float v = 0.f;
+  if (c == 0) {
+    const float raw = nf_load(Y, (size_t)m * ldy, bf16);
+    v = d_density[m] * expf(fminf(fmaxf(raw, -15.f), 15.f)) * sel[m];
+  } else if (c <= ngeo && dXh) {
+    v = nf_load(dXh, (size_t)m * ldx + geo_col0 + c - 1, bf16);
+  }
+  nf_store(G, (size_t)m * ldg + c, bf16, v);
+}
+
+// head input X[M, ldx] = [SH(viewdir) (16, per ray) | geo = Ybase[:, 1 .. ngeo] | appearance embedding (per ray) | 0 ...]
+__global__ void k_nf_head_input(long long M, int S, int bf16, const float* __restrict__ sh, const void* __restrict__ Yb, int ldy,
+                                int ngeo, const float* __restrict__ app, int napp, void* __restrict__ X, int ldx) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long m = e / ldx;
+  const int c = (int)(e % ldx);
+  if (m >= M) return;
+  const long long ray = m / S;
+  float v = 0.f;
+  if (c < 16) v = sh[ray * 16 + c];
+  else if (c < 16 + ngeo) v = nf_load(Yb, (size_t)m * ldy + 1 + (c - 16), bf16);
+  else if (c < 16 + ngeo + napp) v = app[ray * napp + (c - 16 - ngeo)];
+  nf_store(X, (size_t)m * ldx + c, bf16, v);
+}
+
+// d_app[ray, :] = sum over the ray's samples of dX[:, col0 .. col0 + napp); scatter-added into the embedding row
+__global__ void k_nf_app_bwd(int nrays, int S, int bf16, const void* __restrict__ dX, int ldx, int col0, int napp,
+                             const int* __restrict__ embed_idx, float* __restrict__ d_embedding) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nrays * napp) return;
+  const int ray = e / napp, c = e % napp;
+  float s = 0.f;
+  for (int k = 0; k < S; ++k) s += nf_load(dX, ((size_t)ray * S + k) * ldx + col0 + c, bf16);
+  atomicAdd(&d_embedding[(size_t)embed_idx[ray] * napp + c], s);
+}
+
+// rgb = sigmoid(Y[:, 0..2] + rgb_bias)
+__global__ void k_nf_rgb_act(long long M, int bf16, const void* __restrict__ Y, int ldy, float rgb_bias, float* __restrict__ rgb) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= M * 3) return;
+  const long long m = e / 3;
+  const int c = (int)(e % 3);
+  rgb[e] = 1.f / (1.f + expf(-(nf_load(Y, (size_t)m * ldy + c, bf16) + rgb_bias)));
+}
+
+// G[M, ldg] = gradient at the rgb layer's output: columns 0..2 = d_rgb * rgb * (1 - rgb), the rest 0
+__global__ void k_nf_rgb_grad(long long M, int bf16, const float* __restrict__ rgb, const float* __restrict__ d_rgb, void* __restrict__ G, int ldg) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long m = e / ldg;
+  const int c = (int)(e % ldg);
+  if (m >= M) return;
+  float v = 0.f;
+  if (c < 3) { const float r = rgb[m * 3 + c]; v = d_rgb[m * 3 + c] * r * (1.f - r); }
+  nf_store(G, (size_t)m * ldg + c, bf16, v);
+}
+
+#define NF_LAUNCH1D(kern, total, ...)                                                                      \
+  do {                                                                                                     \
+    const long long tot_ = (total);                                                                        \
+    if (tot_ > 0) hipLaunchKernelGGL(kern, dim3((unsigned)((tot_ + 255) / 256)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+  } while (0)
+
+extern "C" int hugs_nf_density_act(long long M, int dtype, const void* Y, int ldy, int col, const float* sel, float* density, void* stream) {
+  NF_LAUNCH1D(k_nf_density_act, M, M, dtype, Y, ldy, col, sel, density);
+  HUGS_CHECK_LAUNCH("hugs_nf_density_act");
+  return 0;
+}
+extern "C" int hugs_nf_base_grad(long long M, int dtype, const void* Y, int ldy, const float* sel, const float* d_density,
+                                 const void* dXh, int ldx, int geo_col0, int ngeo, void* G, int ldg, void* stream) {
+  NF_LAUNCH1D(k_nf_base_grad, M * ldg, M, dtype, Y, ldy, sel, d_density, dXh, ldx, geo_col0, ngeo, G, ldg);
+  HUGS_CHECK_LAUNCH("hugs_nf_base_grad");
+  return 0;
+}
+extern "C" int hugs_nf_head_input(long long M, int S, int dtype, const float* sh, const void* Yb, int ldy, int ngeo, const float* app,
+                                  int napp, void* X, int ldx, void* stream) {
+  HUGS_REQUIRE(16 + ngeo + napp <= ldx, -3, "hugs_nf_head_input: %d columns do not fit the pitch %d", 16 + ngeo + napp, ldx);
+  NF_LAUNCH1D(k_nf_head_input, M * ldx, M, S, dtype, sh, Yb, ldy, ngeo, app, napp, X, ldx);
+  HUGS_CHECK_LAUNCH("hugs_nf_head_input");
+  return 0;
+}
+extern "C" int hugs_nf_app_bwd(int nrays, int S, int dtype, const void* dX, int ldx, int col0, int napp, const int* embed_idx,
+                               float* d_embedding, void* stream) {
+  NF_LAUNCH1D(k_nf_app_bwd, (long long)nrays * napp, nrays, S, dtype, dX, ldx, col0, napp, embed_idx, d_embedding);
+  HUGS_CHECK_LAUNCH("hugs_nf_app_bwd");
+  return 0;
+}
+extern "C" int hugs_nf_rgb_act(long long M, int dtype, const void* Y, int ldy, float rgb_bias, float* rgb, void* stream) {
+  NF_LAUNCH1D(k_nf_rgb_act, M * 3, M, dtype, Y, ldy, rgb_bias, rgb);
+  HUGS_CHECK_LAUNCH("hugs_nf_rgb_act");
+  return 0;
+}
+extern "C" int hugs_nf_rgb_grad(long long M, int dtype, const float* rgb, const float* d_rgb, void* G, int ldg, void* stream) {
+  NF_LAUNCH1D(k_nf_rgb_grad, M * ldg, M, dtype, rgb, d_rgb, G, ldg);
+  HUGS_CHECK_LAUNCH("hugs_nf_rgb_grad");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam, train.py:183: eps outside the sqrt of the bias-corrected second moment)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_nf_adam(long long n, float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m,
+                          float* __restrict__ v, float lr, float b1, float b2, float eps, float bc1, float bc2) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float g = grad[i];
+  if (g != g) g = 0.f;
+  const float mi = b1 * m[i] + (1.f - b1) * g, vi = b2 * v[i] + (1.f - b2) * g * g;
+  m[i] = mi; v[i] = vi;
+  theta[i] -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+}
+
+extern "C" int hugs_nf_adam(long long n, float* theta, const float* grad, float* m, float* v, float lr, float b1, float b2,
+                            float eps, float bc1, float bc2, void* stream) {
+  NF_LAUNCH1D(k_nf_adam, n, n, theta, grad, m, v, lr, b1, b2, eps, bc1, bc2);
+  HUGS_CHECK_LAUNCH("hugs_nf_adam");
+  return 0;
+}

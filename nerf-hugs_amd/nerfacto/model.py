@@ -1,0 +1,430 @@
+"""The reference's NERFACTO training path (nerfacto/models/nerfacto.py `Model` + `Loss`, nerfacto/train.py:183-215) for
+its base / withmask configurations, on HIP kernels: proposal sampling (csrc/hugs_nerfacto.hip), multiresolution hash
+grids + SH-4 (csrc/hugs_hashgrid.hip), the fields' Linear layers on the shared MFMA GEMMs (csrc/hugs_gemm.hip, every
+width zero-padded to the 128-column tile), density -> weights -> colour, interlevel / distortion / rgb losses, a
+hand-scheduled backward pass and Adam.  SURVEY 8f row 3, BASELINE config 5.
+
+Field form: the `enable_tcnn_mlp: False` one (torch Linear layers, what configs/phototourism_nerfacto_base.yml
+selects); the reference runs them under fp16 autocast, here the GEMM operands are bf16 with fp32 accumulation
+(`compute_dtype='bf16'`) or fp32 (`'fp32'`, parity mode).  PARITY UNPINNED for the encodings (tiny-cuda-nn); the
+sampler / weights / losses are pinned through oracle/nerfacto_ref.py (tests/test_gpu_nerfacto.py).
+Not built: NeRF-W / HA-NeRF / RobustNeRF branches of the nerfacto model, eval-mode embedding averaging, DataParallel
+(the multi-GPU form here is one process per GPU with an all-reduce of the flat gradient, as for Mip-NeRF 360)."""
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from ..internal.engine import Workspace
+from .encodings import HashGrid
+
+PAD = 128
+
+
+def _rup(x, m=PAD):
+  return (x + m - 1) // m * m
+
+
+class NerfactoConfig:
+  """models/nerfacto.py:18-114 ModelConfig + Model.__init__'s bound / enable_scene_contraction (dataclass defaults)."""
+
+  def __init__(self, **kw):
+    self.bound, self.enable_scene_contraction = 2.0, False
+    self.num_levels, self.base_res, self.max_res, self.log2_hashmap_size, self.features_per_level = 16, 16, 2048, 19, 2
+    self.hidden_dim, self.geo_feat_dim, self.hidden_dim_color = 64, 15, 64
+    self.use_appearance_embedding, self.appearance_embedding_dim, self.num_embedding = False, 32, 3500
+    self.num_proposal_samples_per_ray, self.num_nerf_samples_per_ray, self.num_proposal_iterations = (256, 96), 48, 2
+    self.proposal_net_args_list = [dict(hidden_dim=16, log2_hashmap_size=17, num_levels=5, max_res=128),
+                                   dict(hidden_dim=16, log2_hashmap_size=17, num_levels=5, max_res=256)]
+    self.proposal_update_every, self.proposal_warmup = 5, 5000
+    self.proposal_initial_sampler, self.proposal_histogram_padding = 'uniform', 0.01
+    self.use_proposal_weight_anneal, self.proposal_weights_anneal_slope = True, 10.0
+    self.proposal_weights_anneal_max_num_iters = 1000
+    self.use_single_jitter, self.opaque_background = True, False
+    self.rgb_loss_type, self.rgb_charb_loss_padding, self.rgb_loss_mult = 'mse', 0.001, 1.0
+    self.interlevel_loss_mult, self.distortion_loss_mult = 1.0, 0.002
+    self.transient_type, self.withmask_transient_weight = None, 0.
+    self.rgb_bias = 0.
+    # train.py / yml optimiser settings
+    self.lr_init, self.lr_final, self.lr_decay_mult, self.warmup_steps, self.num_steps = 1e-2, 1e-3, 1e-8, 500, 25000
+    self.opt_betas, self.opt_eps = (0.9, 0.999), 1e-15
+    for k, v in kw.items():
+      if not hasattr(self, k):
+        raise ValueError(f'ModelConfig has no field {k!r}')
+      setattr(self, k, v)
+    if self.transient_type not in (None, 'withmask'):
+      raise NotImplementedError(f"nerfacto transient_type {self.transient_type!r}: built are None and 'withmask'")
+    if self.proposal_initial_sampler not in ('uniform', 'piecewise', 'reciprocal'):
+      raise ValueError(f'Sampler does not support {self.proposal_initial_sampler}. ')       # nerfacto.py:241
+    if self.enable_scene_contraction and self.bound != 2.0:
+      raise AssertionError(f'When using scene contraction, bound should be set to 2, but got {self.bound}')
+
+  def prop_args(self, i):
+    a = dict(num_levels=8, base_res=16, max_res=1024, log2_hashmap_size=18, features_per_level=2, hidden_dim=64)
+    a.update(self.proposal_net_args_list[min(i, len(self.proposal_net_args_list) - 1)])
+    return a
+
+
+class _Layout:
+  """Flat fp32 parameter buffer: name -> (offset, stored shape, logical shape)."""
+
+  def __init__(self):
+    self.items, self.size = {}, 0
+
+  def add(self, name, pshape, shape=None):
+    n = int(np.prod(pshape))
+    self.items[name] = (self.size, tuple(pshape), tuple(shape or pshape))
+    self.size += _rup(n, 4)
+
+  def view(self, flat, name, padded=True):
+    off, pshape, shape = self.items[name]
+    v = flat[off:off + int(np.prod(pshape))].view(*pshape)
+    return v if padded else v[tuple(slice(0, s) for s in shape)]
+
+
+class NerfactoModel:
+
+  def __init__(self, cfg, device='cuda', compute_dtype='bf16', seed=0):
+    if not torch.cuda.is_available():
+      raise L.HugsError('no GPU visible: the hugs path has no CPU fallback')
+    L.lib()
+    self.cfg, self.device = cfg, torch.device(device)
+    self.dt = 1 if compute_dtype == 'bf16' else 0
+    self.tdt = torch.bfloat16 if self.dt else torch.float32
+    self.ws = Workspace(self.device)
+    self.L = cfg.num_proposal_iterations
+    self.lay = _Layout()
+    self.grids, self.nets = {}, {}
+    for i in range(self.L):
+      a = cfg.prop_args(i)
+      g = HashGrid(a['num_levels'], a['features_per_level'], a['log2_hashmap_size'], a['base_res'], None, a['max_res'], device='cpu')
+      self.grids[f'prop{i}'] = g
+      self._add_net(f'prop{i}', g, [(g.n_output_dims, a['hidden_dim']), (a['hidden_dim'], 1)])
+    g = HashGrid(cfg.num_levels, cfg.features_per_level, cfg.log2_hashmap_size, cfg.base_res, None, cfg.max_res, device='cpu')
+    self.grids['field'] = g
+    self.napp = cfg.appearance_embedding_dim if cfg.use_appearance_embedding else 0
+    self._add_net('field', g, [(g.n_output_dims, cfg.hidden_dim), (cfg.hidden_dim, 1 + cfg.geo_feat_dim)])
+    hin = 16 + cfg.geo_feat_dim + self.napp
+    for j, (fi, fo) in enumerate([(hin, cfg.hidden_dim_color), (cfg.hidden_dim_color, cfg.hidden_dim_color), (cfg.hidden_dim_color, 3)]):
+      self.lay.add(f'field/c{j}', (_rup(fi), _rup(fo)), (fi, fo))
+      self.lay.add(f'field/cb{j}', (_rup(fo),), (fo,))
+    if self.napp:
+      self.lay.add('appearance', (cfg.num_embedding, self.napp))
+    self.flat = torch.zeros(self.lay.size, dtype=torch.float32, device=self.device)
+    self.m = torch.zeros_like(self.flat)
+    self.v = torch.zeros_like(self.flat)
+    self.grad = torch.zeros_like(self.flat)
+    self.step = 0
+    self.wt, self.wn = {}, {}
+    self._init(seed)
+    self.refresh_weights()
+
+  def _add_net(self, name, grid, dims):
+    self.lay.add(f'{name}/table', (grid.n_entries, grid.features))
+    for j, (fi, fo) in enumerate(dims):
+      self.lay.add(f'{name}/w{j}', (_rup(fi), _rup(fo)), (fi, fo))
+      self.lay.add(f'{name}/b{j}', (_rup(fo),), (fo,))
+
+  # ---- parameters ---------------------------------------------------------------------------------------------------
+  def _init(self, seed):
+    """kaiming_uniform_ weights (nerfacto.py:789-791), nn.Linear default biases, U(+-1e-4) tables (tiny-cuda-nn), N(0,1)
+    embedding rows (nn.Embedding)."""
+    g = torch.Generator().manual_seed(int(seed))
+    for name, (off, pshape, shape) in self.lay.items.items():
+      leaf = name.split('/')[-1]
+      v = self.lay.view(self.flat, name, padded=False)
+      if leaf == 'table':
+        v.copy_(((torch.rand(shape, generator=g) * 2 - 1) * 1e-4).to(self.device))
+      elif leaf[0] in 'wc' and not leaf.startswith('cb'):
+        v.copy_(((torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) * math.sqrt(6.0 / shape[0])).float().to(self.device))
+      elif leaf.startswith('b') or leaf.startswith('cb'):
+        fan_in = self.lay.items[name.replace('/cb', '/c').replace('/b', '/w')][2][0]
+        v.copy_(((torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) / math.sqrt(fan_in)).float().to(self.device))
+      elif name == 'appearance':
+        v.copy_(torch.randn(shape, generator=g).to(self.device))
+
+  def params(self):
+    """{'prop0': {'table','w0','b0','w1','b1'}, ..., 'field': {...,'c0','cb0',...}, 'appearance': ...}: logical views."""
+    out = {}
+    for name in self.lay.items:
+      parts = name.split('/')
+      if len(parts) == 1:
+        out[name] = self.lay.view(self.flat, name, False)
+      else:
+        out.setdefault(parts[0], {})[parts[1]] = self.lay.view(self.flat, name, False)
+    return out
+
+  def load_params(self, P):
+    for name in self.lay.items:
+      parts = name.split('/')
+      src = P[name] if len(parts) == 1 else P[parts[0]][parts[1]]
+      self.lay.view(self.flat, name, False).copy_(torch.as_tensor(src).detach().to(self.device, torch.float32))
+    self.refresh_weights()
+
+  def grads(self):
+    out = {}
+    for name in self.lay.items:
+      parts = name.split('/')
+      v = self.lay.view(self.grad, name, False)
+      if len(parts) == 1:
+        out[name] = v
+      else:
+        out.setdefault(parts[0], {})[parts[1]] = v
+    return out
+
+  def refresh_weights(self):
+    for name, (off, pshape, shape) in self.lay.items.items():
+      leaf = name.split('/')[-1]
+      if len(pshape) == 2 and leaf != 'table' and name != 'appearance':
+        K, N = pshape
+        if name not in self.wt:
+          self.wt[name] = torch.empty(N, K, dtype=self.tdt, device=self.device)
+          self.wn[name] = torch.empty(K, N, dtype=self.tdt, device=self.device) if self.dt else None
+        W = self.lay.view(self.flat, name)
+        L.call('hugs_cast_weights', self.dt, K, N, W, self.wn[name], self.wt[name])
+        if not self.dt:
+          self.wn[name] = W
+
+  # ---- GEMM helpers ---------------------------------------------------------------------------------------------------
+  def _nt(self, M, name, X, bias, relu, out, mask=None, transpose=False):
+    """out[M,N] = act(X W + b) (transpose=False) or out[M,K] = (X W^T) (* mask > 0) (transpose=True, the dX form)."""
+    K, N = self.lay.items[name][1]
+    if not transpose:
+      L.call('hugs_gemm_nt', self.dt, M, N, K, 0, X, K, None, 0, self.wt[name], K, bias, None, 1, 0, int(relu), None, 0, None, None, out, N)
+    else:
+      L.call('hugs_gemm_nt', self.dt, M, K, N, 0, X, N, None, 0, self.wn[name], N, None, None, 1, 0, 0, mask, K if mask is not None else 0,
+             None, None, out, K)
+
+  def _tn(self, M, name, X, G, bias_name):
+    """grad[name] = X^T G, grad[bias] = colsum(G)."""
+    K, N = self.lay.items[name][1]
+    tiles, step, target = (K // 128) * (N // 128), (64 if self.dt else 16), 768
+    units = M // step
+    ns = max(1, min(units, (target + tiles - 1) // tiles))
+    while units % ns:
+      ns -= 1
+    nbytes = L.lib().cdll.hugs_gemm_tn_ws_bytes(K, N, ns)
+    slab = self.ws.get('tn_slab', (max(nbytes // 4, 1),))
+    L.call('hugs_gemm_tn', self.dt, M, K, N, ns, X, K, G, N, self.lay.view(self.grad, name), self.lay.view(self.grad, bias_name), slab)
+
+  # ---- forward ----------------------------------------------------------------------------------------------------------
+  def _u_base(self, ns, randomized):
+    from ..internal import stepfun
+    u, mj = stepfun.sample_u(ns, randomized)
+    key = ('ub', ns, randomized)
+    if key not in self.ws.bufs:
+      self.ws.bufs[key] = torch.from_numpy(u).to(self.device)
+    return self.ws.bufs[key], mj
+
+  def anneal(self, curr_step):
+    c = self.cfg
+    if not c.use_proposal_weight_anneal:
+      return 1.0
+    f = float(np.clip(curr_step / c.proposal_weights_anneal_max_num_iters, 0, 1))
+    s = c.proposal_weights_anneal_slope
+    return (s * f) / ((s - 1) * f + 1)
+
+  def _grid_fwd(self, name, x01, X0):
+    g = self.grids[name]
+    o, r, s = g._tables()
+    L.call('hugs_hashgrid_fwd', x01.shape[0], g.n_levels, g.features, o, r, s, x01, self.lay.view(self.flat, f'{name}/table'),
+           self.dt, X0.stride(0), X0)
+
+  def _grid_bwd(self, name, x01, dX0):
+    g = self.grids[name]
+    o, r, s = g._tables()
+    L.call('hugs_hashgrid_bwd', x01.shape[0], g.n_levels, g.features, o, r, s, x01, dX0, self.dt, dX0.stride(0),
+           self.lay.view(self.grad, f'{name}/table'))
+
+  def forward(self, rays, curr_step, u01=None):
+    """Model.forward_rays (nerfacto.py:286-414), training mode.  rays: dict of device tensors origin / direction / viewdir
+    [N,3], near / far [N], embed_idx [N] int32, bg_rgb [N,3] (or None).  u01: None (perturb=False) or one [N] tensor of
+    U[0,1) draws per level (single jitter).  Returns the per-level state the loss / backward use."""
+    c, ws, dt = self.cfg, self.ws, self.dt
+    N = rays['origin'].shape[0]
+    spacing = {'uniform': 0, 'piecewise': 1, 'reciprocal': 2}[c.proposal_initial_sampler]
+    anneal = self.anneal(curr_step)
+    bins = ws.get('bins_init', (N, 2))
+    bins[:, 0] = 0.; bins[:, 1] = 1.
+    weights = ws.get('w_init', (N, 1))
+    weights.fill_(1.)
+    nb, levels = 1, []
+    for lvl in range(self.L + 1):
+      is_prop = lvl < self.L
+      S = c.num_proposal_samples_per_ray[lvl] if is_prop else c.num_nerf_samples_per_ray
+      M = N * S
+      if M % 128:
+        raise ValueError(f'{N} rays x {S} samples is not a multiple of the 128-row GEMM tile')
+      name = f'prop{lvl}' if is_prop else 'field'
+      ub, mj = self._u_base(S, u01 is not None)
+      jit = None
+      if u01 is not None:
+        jit = ws.get(f'jit{lvl}', (N,))
+        torch.mul(u01[lvl].reshape(-1), mj, out=jit)
+      sb, eb = ws.get(f'sb{lvl}', (N, S + 1)), ws.get(f'eb{lvl}', (N, S + 1))
+      L.call('hugs_nf_sample', N, nb, S, bins, weights, anneal, c.proposal_histogram_padding, ub, jit, 1, 0., 1., spacing,
+             rays['near'], rays['far'], sb, eb)
+      x01, sel = ws.get(f'x01_{lvl}', (M, 3)), ws.get(f'sel{lvl}', (M,))
+      L.call('hugs_nf_positions', N, S, eb, rays['origin'], rays['direction'], int(c.enable_scene_contraction), c.bound, x01, sel)
+      K0, N0 = self.lay.items[f'{name}/w0'][1]
+      N1 = self.lay.items[f'{name}/w1'][1][1]
+      X0 = ws.get(f'X0_{lvl}', (M, K0), self.tdt)
+      if (f'X0z_{lvl}', M) not in ws.bufs:        # the padding columns are written once and stay zero
+        X0.zero_(); ws.bufs[(f'X0z_{lvl}', M)] = True
+      self._grid_fwd(name, x01, X0)
+      Y0, Y1 = ws.get(f'Y0_{lvl}', (M, N0), self.tdt), ws.get(f'Y1_{lvl}', (M, N1), self.tdt)
+      self._nt(M, f'{name}/w0', X0, self.lay.view(self.flat, f'{name}/b0'), True, Y0)
+      self._nt(M, f'{name}/w1', Y0, self.lay.view(self.flat, f'{name}/b1'), False, Y1)
+      dens = ws.get(f'dens{lvl}', (M,))
+      L.call('hugs_nf_density_act', M, dt, Y1, N1, 0, sel, dens)
+      st = dict(S=S, M=M, name=name, sbins=sb, ebins=eb, x01=x01, sel=sel, X0=X0, Y0=Y0, Y1=Y1, density=dens, rgb=None)
+      rgb_out = None
+      if not is_prop:
+        sh = ws.get('sh', (N, 16))
+        vd01 = ws.get('vd01', (N, 3))
+        torch.add(rays['viewdir'], 1.0, out=vd01); vd01.mul_(0.5)
+        L.call('hugs_sh4_fwd', N, vd01, 0, 16, 0, sh)
+        app = None
+        if self.napp:
+          app = ws.get('app', (N, self.napp))
+          L.call('hugs_glo_gather', N, self.napp, self.lay.view(self.flat, 'appearance'), rays['embed_idx'], 0, app)
+        Kh = self.lay.items['field/c0'][1][0]
+        H = self.lay.items['field/c0'][1][1]
+        Xh = ws.get('Xh', (M, Kh), self.tdt)
+        L.call('hugs_nf_head_input', M, S, dt, sh, Y1, N1, c.geo_feat_dim, app, self.napp, Xh, Kh)
+        H0, H1 = ws.get('H0', (M, H), self.tdt), ws.get('H1', (M, H), self.tdt)
+        Yc = ws.get('Yc', (M, self.lay.items['field/c2'][1][1]), self.tdt)
+        self._nt(M, 'field/c0', Xh, self.lay.view(self.flat, 'field/cb0'), True, H0)
+        self._nt(M, 'field/c1', H0, self.lay.view(self.flat, 'field/cb1'), True, H1)
+        self._nt(M, 'field/c2', H1, self.lay.view(self.flat, 'field/cb2'), False, Yc)
+        rgb = ws.get('rgb_s', (M, 3))
+        L.call('hugs_nf_rgb_act', M, dt, Yc, Yc.shape[1], c.rgb_bias, rgb)
+        st.update(rgb=rgb, Xh=Xh, H0=H0, H1=H1, Yc=Yc, app=app)
+        rgb_out = ws.get('rgb_out', (N, 3))
+      w = ws.get(f'w{lvl}', (N, S))
+      acc, depth = ws.get(f'acc{lvl}', (N,)), ws.get(f'depth{lvl}', (N,))
+      L.call('hugs_nf_weights_fwd', N, S, dens, eb, rays['direction'], int(c.opaque_background), st['rgb'],
+             rays.get('bg_rgb') if st['rgb'] is not None else None, w, rgb_out, acc, depth)
+      st.update(weights=w, rgb_out=rgb_out, acc=acc, depth=depth)
+      levels.append(st)
+      bins, weights, nb = sb, w, S
+    return levels
+
+  # ---- loss + backward + Adam ---------------------------------------------------------------------------------------------
+  def proposal_update_enabled(self, curr_step):
+    """nerfacto.py:299-303."""
+    c = self.cfg
+    iv = int(np.clip(np.interp(curr_step, [0, c.proposal_warmup], [0, c.proposal_update_every]), 1, c.proposal_update_every))
+    return (curr_step % iv) == 0
+
+  def train_step(self, batch, curr_step=None, u01=None, apply_update=True, world=1):
+    """One optimisation step (train.py:196-215 + Loss.forward nerfacto.py:598-640).  batch: rays dict + 'rgb' [N,3]
+    (+ 'static_mask' [N] for transient_type='withmask').  Returns a dict of host-lazy device scalars."""
+    c, ws, dt = self.cfg, self.ws, self.dt
+    self.step += 1
+    step = self.step if curr_step is None else curr_step
+    N = batch['origin'].shape[0]
+    levels = self.forward(batch, step, u01)
+    fin = levels[-1]
+    Sf = fin['S']
+    stats = ws.get('stats', (16,))
+    stats.zero_()
+    # rgb loss (mean, or the static-mask weighted mean of compute_withmask_loss nerfacto.py:467-490)
+    d_pred = ws.get('d_pred', (1, N, 3))
+    mode, lm = (1, batch['static_mask']) if c.transient_type == 'withmask' else (0, None)
+    # hugs_data_loss' static-mask mode normalises by the [N,1] mask sum (Mip-NeRF 360's train_utils.py quirk); nerfacto's
+    # compute_withmask_loss broadcasts the mask to the 3 channels first (nerfacto.py:481-483): a factor 3 in the denominator
+    chan = 3.0 if mode == 1 else 1.0
+    coef = ws.bufs.setdefault(('coef1', chan), torch.full((1,), float(c.rgb_loss_mult) / chan, device=self.device))
+    L.call('hugs_data_loss', N, 1, fin['rgb_out'].reshape(1, N, 3), batch['rgb'], lm, mode, c.withmask_transient_weight,
+           int(c.rgb_loss_type == 'charb'), c.rgb_charb_loss_padding, coef, d_pred, stats[0:2])
+    if chan != 1.0:
+      stats[0:2].mul_(1.0 / chan)
+    loss_ray = ws.get('loss_ray', (N,))
+    d_w = [None] * (self.L + 1)
+    prop_on = self.proposal_update_enabled(step)
+    if c.interlevel_loss_mult > 0:
+      for l in range(self.L):
+        d_w[l] = ws.get(f'd_w{l}', (N, levels[l]['S']))
+        L.call('hugs_nf_interlevel', N, Sf, levels[l]['S'], fin['sbins'], fin['weights'], levels[l]['sbins'], levels[l]['weights'],
+               c.interlevel_loss_mult / (N * Sf), loss_ray, d_w[l])
+        L.call('hugs_sum', N, loss_ray, c.interlevel_loss_mult / (N * Sf), stats[2 + l:3 + l])
+    if c.distortion_loss_mult > 0:
+      d_w[self.L] = ws.get('d_w_fin', (N, Sf))
+      L.call('hugs_distortion', N, Sf, fin['sbins'], fin['weights'], c.distortion_loss_mult / N, loss_ray, d_w[self.L])
+      L.call('hugs_sum', N, loss_ray, c.distortion_loss_mult / N, stats[8:9])
+    # ---- backward ----
+    self.grad.zero_()
+    for l in range(self.L, -1, -1):
+      st = levels[l]
+      is_prop = l < self.L
+      if is_prop and (d_w[l] is None or not prop_on):
+        continue
+      self._backward_level(st, batch, N, d_pred[0] if not is_prop else None, d_w[l])
+    if world > 1:
+      import torch.distributed as dist
+      dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+      self.grad.mul_(1.0 / world)
+    if apply_update:
+      self.apply_gradients()
+    return dict(stats=stats, levels=levels)
+
+  def lr(self, step):
+    c = self.cfg
+    if step < c.warmup_steps:
+      f = c.lr_decay_mult + (1 - c.lr_decay_mult) * math.sin(0.5 * math.pi * min(max(step / c.warmup_steps, 0), 1))
+    else:
+      t = min(max((step - c.warmup_steps) / (c.num_steps - c.warmup_steps), 0), 1)
+      f = math.exp(math.log(c.lr_init) * (1 - t) + math.log(c.lr_final) * t) / c.lr_init
+    return c.lr_init * f
+
+  def apply_gradients(self):
+    """optimizer.step() + scheduler.step() (train.py:213-215): the k-th update uses the scheduler's factor at k-1."""
+    c = self.cfg
+    k = getattr(self, '_updates', 0)
+    b1, b2 = c.opt_betas
+    L.call('hugs_nf_adam', self.flat.numel(), self.flat, self.grad, self.m, self.v, self.lr(k), b1, b2, c.opt_eps,
+           1.0 - b1**(k + 1), 1.0 - b2**(k + 1))
+    self._updates = k + 1
+    self.refresh_weights()
+
+  def _backward_level(self, st, rays, N, d_rgb_out, d_w_extra):
+    c, ws, dt = self.cfg, self.ws, self.dt
+    S, M, name = st['S'], st['M'], st['name']
+    d_dens = ws.get(f'd_dens_{name}', (M,))
+    d_rgb_s = ws.get('d_rgb_s', (M, 3)) if st['rgb'] is not None else None
+    L.call('hugs_nf_weights_bwd', N, S, st['density'], st['ebins'], rays['direction'], int(c.opaque_background), st['rgb'],
+           rays.get('bg_rgb') if st['rgb'] is not None else None, st['weights'], d_rgb_out, d_w_extra, d_dens, d_rgb_s)
+    N1 = st['Y1'].shape[1]
+    dXh = None
+    if st['rgb'] is not None:
+      H = st['H0'].shape[1]
+      Nc = st['Yc'].shape[1]
+      Gc = ws.get('Gc', (M, Nc), self.tdt)
+      L.call('hugs_nf_rgb_grad', M, dt, st['rgb'], d_rgb_s, Gc, Nc)
+      self._tn(M, 'field/c2', st['H1'], Gc, 'field/cb2')
+      G1 = ws.get('G1', (M, H), self.tdt)
+      self._nt(M, 'field/c2', Gc, None, False, G1, mask=st['H1'], transpose=True)
+      self._tn(M, 'field/c1', st['H0'], G1, 'field/cb1')
+      G0 = ws.get('G0', (M, H), self.tdt)
+      self._nt(M, 'field/c1', G1, None, False, G0, mask=st['H0'], transpose=True)
+      self._tn(M, 'field/c0', st['Xh'], G0, 'field/cb0')
+      Kh = st['Xh'].shape[1]
+      dXh = ws.get('dXh', (M, Kh), self.tdt)
+      self._nt(M, 'field/c0', G0, None, False, dXh, transpose=True)
+      if self.napp:
+        L.call('hugs_nf_app_bwd', N, S, dt, dXh, Kh, 16 + c.geo_feat_dim, self.napp, rays['embed_idx'],
+               self.lay.view(self.grad, 'appearance'))
+    Gb = ws.get(f'Gb_{name}', (M, N1), self.tdt)
+    L.call('hugs_nf_base_grad', M, dt, st['Y1'], N1, st['sel'], d_dens, dXh, 0 if dXh is None else dXh.shape[1], 16,
+           c.geo_feat_dim if dXh is not None else 0, Gb, N1)
+    self._tn(M, f'{name}/w1', st['Y0'], Gb, f'{name}/b1')
+    N0 = st['Y0'].shape[1]
+    Gy0 = ws.get(f'Gy0_{name}', (M, N0), self.tdt)
+    self._nt(M, f'{name}/w1', Gb, None, False, Gy0, mask=st['Y0'], transpose=True)
+    self._tn(M, f'{name}/w0', st['X0'], Gy0, f'{name}/b0')
+    K0 = st['X0'].shape[1]
+    dX0 = ws.get(f'dX0_{name}', (M, K0), self.tdt)
+    self._nt(M, f'{name}/w0', Gy0, None, False, dX0, transpose=True)
+    self._grid_bwd(name, st['x01'], dX0)

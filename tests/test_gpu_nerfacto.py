@@ -1,0 +1,181 @@
+"""NERFACTO path (BASELINE config 5) on the GPU: the per-ray kernels directly against vectors recorded
+from the reference's own nerfacto/utils/{ray_utils,loss_utils}.py (tests/golden/ref_nerfacto.npz), and the whole model
+(forward, losses, every parameter gradient, Adam) against oracle/nerfacto_ref.py.  The hash grid / SH encodings are
+parity-unpinned (tiny-cuda-nn); fp32 GEMM mode for the parity checks, bf16 for the training smoke test."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+dev = 'cuda'
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.fixture(scope='module')
+def z():
+  return np.load(os.path.join(HERE, 'golden', 'ref_nerfacto.npz'))
+
+
+@pytest.mark.parametrize('tag', ['l0', 'l1', 'l2'])
+def test_sampler_vs_reference(z, tag):
+  from nerf_hugs_amd import _lib as L
+  from nerf_hugs_amd.internal import stepfun
+  bins, w = G(z[f'samp/{tag}/bins']), G(z[f'samp/{tag}/w'])
+  N, nb = w.shape
+  a, p, ns = float(z[f'samp/{tag}/anneal']), float(z[f'samp/{tag}/pad']), int(z[f'samp/{tag}/ns'])
+  near, far = torch.zeros(N, device=dev), torch.ones(N, device=dev)
+  for mode, key in ((False, 'det'), (True, 'jit')):
+    ub, mj = stepfun.sample_u(ns, mode)
+    jit = (G(z[f'samp/{tag}/u01']).reshape(-1) * mj).contiguous() if mode else None
+    sb, eb = torch.empty(N, ns + 1, device=dev), torch.empty(N, ns + 1, device=dev)
+    L.call('hugs_nf_sample', N, nb, ns, bins, w, a, p, G(ub), jit, 1, 0., 1., 0, near, far, sb, eb)
+    # (a sample within float rounding of a CDF knot moves by one bin's slope difference: the wave-order cumsum is not
+    # torch's sequential one)
+    np.testing.assert_allclose(sb.cpu().numpy(), z[f'samp/{tag}/{key}'], rtol=0, atol=2e-5, err_msg=f'{tag} {key}')
+    assert float(np.mean(np.abs(sb.cpu().numpy() - z[f'samp/{tag}/{key}']) > 3e-6)) < 5e-3
+    assert torch.equal(sb, eb) and bool((sb[:, 1:] >= sb[:, :-1]).all())        # uniform spacing, near 0 / far 1
+
+
+@pytest.mark.parametrize('ob', [0, 1])
+def test_weights_render_and_backward_vs_reference(z, ob):
+  from nerf_hugs_amd import _lib as L
+  from oracle import nerfacto_ref as NF
+  eb, dens, dirs, rgb, bg = (G(z[f'w/{k}']) for k in ('ebins', 'dens', 'dirs', 'rgb', 'bg'))
+  N, S = dens.shape
+  w, out, acc, dep = (torch.empty(s, device=dev) for s in ((N, S), (N, 3), (N,), (N,)))
+  L.call('hugs_nf_weights_fwd', N, S, dens.reshape(-1), eb, dirs, ob, rgb.reshape(-1, 3), bg, w, out, acc, dep)
+  np.testing.assert_allclose(w.cpu().numpy(), z[f'w/ob{ob}/weights'], rtol=2e-5, atol=1e-7)
+  np.testing.assert_allclose(out.cpu().numpy(), z[f'w/ob{ob}/rgb'], rtol=2e-5, atol=1e-6)
+  steps_max = float(((eb[:, 1:] + eb[:, :-1]) / 2).max())
+  np.testing.assert_allclose(np.clip(dep.cpu().numpy(), 0, steps_max), z[f'w/ob{ob}/depth'], rtol=2e-5, atol=1e-6)
+  # backward against autograd of the (reference-pinned) oracle
+  g = torch.Generator().manual_seed(1)
+  d_out, d_w = torch.randn(N, 3, generator=g), torch.randn(N, S, generator=g) * 0.1
+  dc, rc = dens.cpu().double().requires_grad_(True), rgb.cpu().double().requires_grad_(True)
+  wo = NF.density_to_weight(dc, eb.cpu().double(), dirs.cpu().double(), bool(ob))[0]
+  ro = NF.render_features(wo, rc, bg.cpu().double())
+  ((ro * d_out.double()).sum() + (wo * d_w.double()).sum()).backward()
+  d_dens, d_rgb = torch.empty(N * S, device=dev), torch.empty(N * S, 3, device=dev)
+  L.call('hugs_nf_weights_bwd', N, S, dens.reshape(-1), eb, dirs, ob, rgb.reshape(-1, 3), bg, w, d_out.to(dev), d_w.to(dev).contiguous(), d_dens, d_rgb)
+  sc = float(dc.grad.abs().max())
+  np.testing.assert_allclose(d_dens.cpu().numpy().reshape(N, S), dc.grad.numpy(), rtol=0, atol=2e-5 * sc)
+  np.testing.assert_allclose(d_rgb.cpu().numpy().reshape(N, S, 3), rc.grad.numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_interlevel_and_distortion_vs_reference(z):
+  from nerf_hugs_amd import _lib as L
+  c, w, cp, wp, cp2, wp2 = (G(z[f'loss/{k}']) for k in ('c', 'w', 'cp', 'wp', 'cp2', 'wp2'))
+  N, S = w.shape
+  tot = 0.
+  for env_t, env_w, key in ((cp, wp, 'd_wp'), (cp2, wp2, 'd_wp2')):
+    Sp = env_w.shape[1]
+    lr, dw = torch.empty(N, device=dev), torch.empty(N, Sp, device=dev)
+    L.call('hugs_nf_interlevel', N, S, Sp, c, w, env_t, env_w, 1.0 / (N * S), lr, dw)
+    if key == 'd_wp':
+      np.testing.assert_allclose(lr.cpu().numpy(), z['loss/lossfun_outer'].sum(-1), rtol=2e-5, atol=1e-9)
+    # (the gradient is the prefix sum of a +c / -c difference array: exact zeros of the reference come out as ~1e-10)
+    np.testing.assert_allclose(dw.cpu().numpy(), z[f'loss/{key}'], rtol=2e-5, atol=5e-5 * float(np.abs(z[f'loss/{key}']).max()))
+    tot += float(lr.sum()) / (N * S)
+  assert abs(tot - float(z['loss/interlevel'])) <= 2e-5 * tot
+  lr, dw = torch.empty(N, device=dev), torch.empty(N, S, device=dev)
+  L.call('hugs_distortion', N, S, c, w, 1.0 / N, lr, dw)
+  np.testing.assert_allclose(lr.cpu().numpy(), z['loss/distortion'], rtol=2e-5)
+  np.testing.assert_allclose(dw.cpu().numpy(), z['loss/d_w_distortion'], rtol=2e-5, atol=1e-9)
+
+
+SMALL = dict(num_levels=4, max_res=64, log2_hashmap_size=10, hidden_dim=16, geo_feat_dim=7, hidden_dim_color=16,
+             num_proposal_samples_per_ray=(32, 16), num_nerf_samples_per_ray=8, opaque_background=True,
+             use_appearance_embedding=True, appearance_embedding_dim=5, num_embedding=4, distortion_loss_mult=0.01,
+             proposal_net_args_list=[dict(hidden_dim=8, log2_hashmap_size=9, num_levels=3, max_res=32)])
+
+
+def _rays(N, seed):
+  g = torch.Generator().manual_seed(seed)
+  d = torch.randn(N, 3, generator=g); d = d / d.norm(dim=-1, keepdim=True)
+  return dict(origin=torch.randn(N, 3, generator=g) * 0.3, direction=d * (0.8 + 0.4 * torch.rand(N, 1, generator=g)), viewdir=d,
+              near=torch.full((N,), 0.05), far=torch.full((N,), 3.0), embed_idx=torch.randint(0, 4, (N,), generator=g).int(),
+              bg_rgb=torch.ones(N, 3), rgb=torch.rand(N, 3, generator=g)), g
+
+
+@pytest.mark.parametrize('variant', ['base', 'contract_piecewise_charb', 'withmask'])
+def test_model_forward_loss_and_gradients_vs_oracle(variant):
+  from nerf_hugs_amd.nerfacto.model import NerfactoConfig, NerfactoModel
+  from oracle import nerfacto_ref as NF
+  kw = dict(SMALL)
+  if variant == 'contract_piecewise_charb':
+    kw.update(enable_scene_contraction=True, proposal_initial_sampler='piecewise', rgb_loss_type='charb', opaque_background=False)
+  if variant == 'withmask':
+    kw.update(transient_type='withmask', withmask_transient_weight=0.25)
+  ocfg = NF.Cfg(**kw)
+  P = NF.init_params(ocfg, 3)
+  # tables at U(+-1e-4) make every field output ~bias: scale them up so that the grids matter in the comparison
+  for k in P:
+    if isinstance(P[k], dict):
+      P[k]['table'] = P[k]['table'] * 3e3
+  model = NerfactoModel(NerfactoConfig(**kw), compute_dtype='fp32')
+  model.load_params(P)
+  N = 128
+  b, g = _rays(N, 5)
+  if variant == 'withmask':
+    b['static_mask'] = (torch.rand(N, generator=g) < 0.7).float() * torch.rand(N, generator=g)
+  u01 = [torch.rand(N, generator=g) for _ in range(3)]
+  leaves = []
+  for grp in P.values():
+    for v in (grp.values() if isinstance(grp, dict) else [grp]):
+      v.requires_grad_(True); leaves.append(v)
+  orays = {k: (v[:, None] if v.dim() == 1 and k in ('near', 'far', 'embed_idx') else v) for k, v in b.items()}
+  out = NF.forward_rays(ocfg, P, orays, 300, [u[:, None] for u in u01])
+  loss, info = NF.loss_fn(ocfg, out, b['rgb'], b.get('static_mask', torch.zeros(N))[:, None])
+  loss.backward()
+  gb = {k: v.to(dev) for k, v in b.items()}
+  res = model.train_step(gb, curr_step=300, u01=[u.to(dev) for u in u01], apply_update=False)
+  torch.cuda.synchronize()
+  lv = res['levels']
+  for l in range(3):
+    np.testing.assert_allclose(lv[l]['sbins'].cpu().numpy(), out['spacing_bins_list'][l].numpy(), rtol=0, atol=1e-5, err_msg=f'sbins {l}')
+    np.testing.assert_allclose(lv[l]['weights'].cpu().numpy(), out['weights_list'][l].detach().numpy(), rtol=0, atol=2e-4, err_msg=f'weights {l}')
+  np.testing.assert_allclose(lv[-1]['rgb_out'].cpu().numpy(), out['rgb'].detach().numpy(), rtol=0, atol=1e-4)
+  st = res['stats'].cpu().numpy()
+  assert abs(st[1] - float(info['rgb_loss'])) <= 2e-4 * abs(float(info['rgb_loss']))
+  assert abs(st[0] - float(info['mse'])) <= 2e-4 * float(info['mse'])
+  assert abs(st[2] + st[3] - float(info['interlevel_loss'])) <= 1e-3 * float(info['interlevel_loss']) + 1e-9
+  assert abs(st[8] - float(info['distortion_loss'])) <= 1e-3 * float(info['distortion_loss'])
+  mg = model.grads()
+  for name, grp in P.items():
+    for k, v in (grp.items() if isinstance(grp, dict) else [(None, grp)]):
+      mine = (mg[name][k] if k else mg[name]).cpu().double()
+      ref = v.grad.double()
+      sc = float(ref.abs().max())
+      assert sc > 0, (name, k)
+      err = float((mine - ref).abs().max()) / sc
+      assert err < 5e-3, f'{variant} grad {name}/{k}: rel err {err:.2e} (max |g| {sc:.2e})'
+
+
+def test_bf16_training_reduces_the_loss_and_is_reproducible():
+  from nerf_hugs_amd.nerfacto.model import NerfactoConfig, NerfactoModel
+  losses = []
+  for rep in range(2):
+    model = NerfactoModel(NerfactoConfig(**dict(SMALL, lr_init=5e-3, warmup_steps=5)), compute_dtype='bf16', seed=11)
+    b, g = _rays(256, 9)
+    b = {k: v.to(dev) for k, v in b.items()}
+    gen = torch.Generator(device=dev).manual_seed(1)
+    run = []
+    for i in range(40):
+      u01 = [torch.rand(256, generator=gen, device=dev) for _ in range(3)]
+      res = model.train_step(b, u01=u01)
+      run.append(float(res['stats'][1]))
+    assert all(np.isfinite(run))
+    losses.append(run)
+  assert np.mean(losses[0][-5:]) < 0.7 * np.mean(losses[0][:5]), losses[0]
+  # float atomics in the table / embedding gradients make the low bits order-dependent: agree closely, not bit-wise
+  np.testing.assert_allclose(losses[0], losses[1], rtol=2e-2)
+
+
+def test_num_samples_error_and_capacity():
+  from nerf_hugs_amd import _lib as L
+  t = torch.tensor([[0., 1.]], device=dev); w = torch.ones(1, 1, device=dev); zz = torch.zeros(1, device=dev)
+  with pytest.raises(ValueError):
+    L.call('hugs_nf_sample', 1, 1, 1, t, w, 1., 0., zz, None, 1, 0., 1., 0, zz, zz + 1, torch.empty(1, 2, device=dev), torch.empty(1, 2, device=dev))
