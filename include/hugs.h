@@ -5,8 +5,12 @@
  * bind; each cites the reference function it replaces (paths relative to MipNeRF360/internal/).
  *
  * Conventions: every pointer is a caller-owned DEVICE pointer (host pointers only where stated); nothing is
- * allocated, no stream is created, no global state is kept; `stream` is a hipStream_t; kernels are enqueued
- * and the call returns.  Return 0 = ok, <0 = error (message via hugs_last_error(), thread local):
+ * allocated, no stream is created; `stream` is a hipStream_t; kernels are enqueued and the call returns.
+ * Process-global state, all of it: (i) the thread-local last-error string; (ii) hugs_gemm_nt caches the device's CU
+ * count on first use (the persistent kernel's grid); (iii) the TEST hook hugs_test_force_small_tiles below, a
+ * process-wide kernel-selection override that production code never sets.  (The Python layer above keeps per-process
+ * caches of its own -- sampler abscissae uploaded once per (num_samples, mode), RobustNeRF thresholds fed back on
+ * the device between steps: nerf-hugs_amd/internal/stepfun.py `_UB_CACHE`, train_utils.py `cache['thr_dev']`.)  Return 0 = ok, <0 = error (message via hugs_last_error(), thread local):
  *   -2 invalid argument for which the reference raises ValueError, -3 unsupported shape, -100 launch failure.
  * dtype: 0 = float32 (parity mode, v_mfma_f32_16x16x4_f32), 1 = bfloat16 operands with fp32 accumulate.
  * Activations/weights in `dtype`, everything per-ray / per-sample scalar in float32.  Row-major.
@@ -26,7 +30,7 @@ int hugs_device_count(void);
  * models.py:191-193 annealed logits -> stepfun.py:131-161 softmax CDF + math.py:108-127 sorted_interp ->
  * stepfun.py:214-263 sample_intervals -> coord.py:63-99 s_to_t.  One wavefront per ray.
  * t_prev [nrays, n_prev+1], w_prev [nrays, n_prev]; u = u_base[j] + jitter[ray*jitter_stride (+j)] (jitter may
- * be NULL = rng None).  raydist 0 linear / 1 reciprocal.  Outputs sdist,tdist [nrays, num_samples+1];
+ * be NULL = rng None).  raydist (coord.py:84-90): 0 None, 1 reciprocal, 2 log, 3 exp, 4 sqrt, 5 square.  Outputs sdist,tdist [nrays, num_samples+1];
  * optional test hooks idx_out [nrays,num_samples] (CDF interval index), t_in_out/w_in_out (the dilated,
  * trimmed step function).  Bit-exact against oracle/stepfun_ref.c.  -2 if num_samples <= 1 (stepfun.py:239). */
 int hugs_level_sample_fwd(int nrays, const float* t_prev, const float* w_prev, int n_prev, int do_dilate,
@@ -207,7 +211,8 @@ int hugs_nerfw_loss(int N, int L, const float* pred, const float* gt, const floa
  * algorithm is restated in oracle/hashgrid_ref.py).  nerfacto/models/nerfacto.py:714-733,761-770,921-947 HashGrid:
  * x01 [n,3] in [0,1]; table fp32 [level_offsets[L], features]; level tables are HOST arrays (offsets [L+1] in entries,
  * resolutions [L], scales [L]); out [n, row_pitch] (first L*features columns written) bf16 or fp32.  The backward
- * ADDS into d_table (fp32 atomics).  nerfacto.py:693-700 SphericalHarmonics degree 4: 16 columns from col0. */
+ * ADDS into d_table (fp32 atomics; runs of consecutive samples inside one cell are summed in the wavefront first).
+ * nerfacto.py:693-700 SphericalHarmonics degree 4: 16 columns from col0. */
 int hugs_hashgrid_fwd(int n, int n_levels, int features, const long long* level_offsets, const int* level_resolutions,
                       const float* level_scales, const float* x01, const float* table, int out_bf16, int row_pitch,
                       void* out, void* stream);
@@ -216,7 +221,50 @@ int hugs_hashgrid_bwd(int n, int n_levels, int features, const long long* level_
                       float* d_table_accum, void* stream);
 int hugs_sh4_fwd(int n, const float* dirs01, int out_bf16, int row_pitch, int col0, void* out, void* stream);
 
-/* test/bench hook: force the 128x128-tile bf16 NT kernel where the 256x256 one would be selected */
+/* ---- nerfacto path (reference /root/reference/nerfacto).  One wavefront per ray in the per-ray
+ * kernels (<= 1024 bins / samples).  Matrices [M, ld] row-major in `dtype` (0 fp32, 1 bf16).
+ * hugs_nf_sample: utils/ray_utils.py:112-231 sample + sample_intervals (softmax of anneal*log(w+padding) with -inf on
+ *   zero-width bins, all -inf -> uniform; cdf = [0, cumsum(pdf[:-1]).clamp_max(1), 1]; searchsorted right; midpoints,
+ *   clamped end posts) and models/nerfacto.py:231-248 s_to_t (spacing 0 uniform / 1 piecewise / 2 reciprocal).
+ *   u = u_base[j] + jitter[ray*jitter_stride (+j)]; jitter may be NULL (perturb=False).  -2 if ns <= 1.
+ * hugs_nf_positions: nerfacto.py:326-328 o + d * t_mid, :822-829 (x+bound)/(2 bound) or contraction (custom_functions.py
+ *   :17-24) then (x+2)/4; selector; positions outside [0,1]^3 zeroed.
+ * hugs_nf_weights_fwd/bwd: ray_utils.py:234-257 density_to_weight -- deltas are (edge[i+1] - edge[0]) |d|, the
+ *   reference's own arithmetic -- + :300-314 render_features (bg * max(1 - acc, 0)) + :340-347 depth (unclipped: the
+ *   reference clips to the batch's largest step).  bwd: dL/d density [M], dL/d rgb_s [M,3] from dL/d rgb_out [nrays,3]
+ *   and an extra dL/d weights [nrays,S]; any of rgb_s / bg / d_rgb_out / d_w_extra may be NULL.
+ * hugs_nf_interlevel: utils/loss_utils.py:7-62 lossfun_outer (searchsorted-right `outer`, EPS 1e-7): loss_ray[nrays] =
+ *   sum_i max(w - w_outer, 0)^2 / (w + 1e-7), d_w_env = scale * d loss / d w_env.
+ * hugs_nf_density_act / base_grad / head_input / app_bwd / rgb_act / rgb_grad: element-wise glue of the fields around
+ *   the padded GEMMs (nerfacto.py:818-876, :971-988; trunc_exp custom_functions.py:38-52).
+ * hugs_nf_adam: torch.optim.Adam step (nerfacto/train.py:183) on a flat buffer; bc1 = 1 - b1^t, bc2 = 1 - b2^t. */
+int hugs_nf_sample(int nrays, int nb, int ns, const float* bins, const float* weights, float anneal, float padding,
+                   const float* u_base, const float* jitter, int jitter_stride, float lo, float hi, int spacing,
+                   const float* near, const float* far, float* sbins, float* ebins, void* stream);
+int hugs_nf_positions(int nrays, int S, const float* ebins, const float* origins, const float* dirs, int contract,
+                      float bound, float* x01, float* sel, void* stream);
+int hugs_nf_weights_fwd(int nrays, int S, const float* density, const float* ebins, const float* dirs, int opaque,
+                        const float* rgb_s, const float* bg, float* weights, float* rgb_out, float* acc, float* depth,
+                        void* stream);
+int hugs_nf_weights_bwd(int nrays, int S, const float* density, const float* ebins, const float* dirs, int opaque,
+                        const float* rgb_s, const float* bg, const float* weights, const float* d_rgb_out,
+                        const float* d_w_extra, float* d_density, float* d_rgb_s, void* stream);
+int hugs_nf_interlevel(int nrays, int S, int Sp, const float* t, const float* w, const float* t_env, const float* w_env,
+                       float scale, float* loss_ray, float* d_w_env, void* stream);
+int hugs_nf_density_act(long long M, int dtype, const void* Y, int ldy, int col, const float* sel, float* density, void* stream);
+int hugs_nf_base_grad(long long M, int dtype, const void* Y, int ldy, const float* sel, const float* d_density,
+                      const void* dXh, int ldx, int geo_col0, int ngeo, void* G, int ldg, void* stream);
+int hugs_nf_head_input(long long M, int S, int dtype, const float* sh, const void* Yb, int ldy, int ngeo, const float* app,
+                       int napp, void* X, int ldx, void* stream);
+int hugs_nf_app_bwd(int nrays, int S, int dtype, const void* dX, int ldx, int col0, int napp, const int* embed_idx,
+                    float* d_embedding, void* stream);
+int hugs_nf_rgb_act(long long M, int dtype, const void* Y, int ldy, float rgb_bias, float* rgb, void* stream);
+int hugs_nf_rgb_grad(long long M, int dtype, const float* rgb, const float* d_rgb, void* G, int ldg, void* stream);
+int hugs_nf_adam(long long n, float* theta, const float* grad, float* m, float* v, float lr, float b1, float b2, float eps,
+                 float bc1, float bc2, void* stream);
+
+/* test/bench hook (process-global, see the conventions above): 1 / 3 force the 128x128-tile bf16 NT kernel where a
+ * 256-row kernel would be selected, 5 disables the persistent form; 0 restores the default selection */
 int hugs_test_force_small_tiles(int on);
 /* test hooks: the portable exp/log of the sampler and raw IEEE ops as the device executes them */
 int hugs_test_explog(const float* x, int n, float* y_exp, float* y_log, void* stream);
