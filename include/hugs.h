@@ -221,6 +221,15 @@ int hugs_hashgrid_bwd(int n, int n_levels, int features, const long long* level_
                       float* d_table_accum, void* stream);
 int hugs_sh4_fwd(int n, const float* dirs01, int out_bf16, int row_pitch, int col0, void* out, void* stream);
 
+/* hugs_gemm_nt with 1-bit relu masks in the 256x256 kernels' own register layout (bf16; M, N multiples of 256, ldc == N,
+ * K a multiple of 64 and >= 256): a relu epilogue writes bits_out (hugs_gemm_nt_bits_bytes(M, N) = M*N/8 bytes: per
+ * tile, wave and lane one 16-byte word), the backward GEMM that produces the same [M, N] shape multiplies its output by
+ * bits_in instead of re-reading the bf16 activation (models.py:451-456 relu; its autodiff, train_utils.py:454). */
+long long hugs_gemm_nt_bits_bytes(int M, int N);
+int hugs_gemm_nt_bits(int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,
+                      const void* Bt, int ldb, const float* bias, int relu, const float* r1_row, const float* r1_col,
+                      void* out, int ldc, uint32_t* bits_out, const uint32_t* bits_in, void* stream);
+
 /* ---- nerfacto path (reference /root/reference/nerfacto).  One wavefront per ray in the per-ray
  * kernels (<= 1024 bins / samples).  Matrices [M, ld] row-major in `dtype` (0 fp32, 1 bf16).
  * hugs_nf_sample: utils/ray_utils.py:112-231 sample + sample_intervals (softmax of anneal*log(w+padding) with -inf on

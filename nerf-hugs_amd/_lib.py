@@ -15,6 +15,7 @@ _PROTOS = {
     'hugs_cast_ipe_fwd': 'iipppppiiiiiips',
     'hugs_dir_enc_fwd': 'iipps',
     'hugs_gemm_nt': 'iiiii' 'pipipi' 'pp' 'iii' 'pi' 'pp' 'pi' 's',
+    'hugs_gemm_nt_bits': 'iiiii' 'pipipi' 'p' 'i' 'pp' 'pi' 'pp' 's',
     'hugs_gemm_tn': 'iiiiipipippps',
     'hugs_density_fwd': 'iiipippfpps',
     'hugs_density_bwd': 'iiipippfpppps',
@@ -92,6 +93,7 @@ def _raw_stream():
 # stream for the weight-gradient GEMMs) and (name, shape key, ev0, ev1) is appended.
 PROFILE = None
 _PROFILED = {'hugs_gemm_nt': lambda a: ('nt', a[1], a[2], a[3] + a[4], 'mask' if a[16] is not None else ('relu' if a[15] else 'plain')),
+             'hugs_gemm_nt_bits': lambda a: ('nt', a[1], a[2], a[3] + a[4], 'mask' if a[18] is not None else ('relu' if a[12] else 'plain')),
              'hugs_gemm_tn': lambda a: ('tn', a[1], a[2], a[3], f'split{a[4]}')}
 
 
@@ -104,7 +106,7 @@ class _Lib:
           'There is no CPU fallback.')
     self.cdll = ctypes.CDLL(LIB_PATH)
     self.cdll.hugs_last_error.restype = ctypes.c_char_p
-    for n_ in ('hugs_gemm_tn_ws_bytes', 'hugs_density_bwd_ws_bytes', 'hugs_rgb_bwd_ws_bytes', 'hugs_ssim_ws_bytes'):
+    for n_ in ('hugs_gemm_tn_ws_bytes', 'hugs_density_bwd_ws_bytes', 'hugs_rgb_bwd_ws_bytes', 'hugs_ssim_ws_bytes', 'hugs_gemm_nt_bits_bytes'):
       getattr(self.cdll, n_).restype = ctypes.c_longlong
     for name, sig in _PROTOS.items():
       fn = getattr(self.cdll, name)

@@ -31,6 +31,12 @@ struct GemmEpi {
   const float* r1_col;
   void* out;              // [M, ldc]
   int ldc;
+  // 1-bit relu masks in the 256x256 kernels' own register layout: per tile (row-major tile index), wave and lane one
+  // 4 words = 128 bits = (fragment row i 0..7) x (fragment column j 0..3) x (4 values); bit = that output is > 0.
+  // bits_out: written by a relu epilogue; bits_in: multiplies the output by the bit (the backward's relu mask, in
+  // place of re-reading the bf16 activation: 16 B per lane instead of 256 B).
+  uint32_t* bits_out;
+  const uint32_t* bits_in;
 };
 
 #ifdef HUGS_TRACE   // scratch builds only (scratch/nt_trace.py): per-workgroup timestamps of the NT kernel's phases
@@ -215,6 +221,8 @@ typedef unsigned __attribute__((ext_vector_type(2))) u32x2_t;
 #define EPI_RELU 2
 #define EPI_MASK 4
 #define EPI_R1 8
+#define EPI_BIN 16    // 1-bit relu mask read (GemmEpi.bits_in)
+#define EPI_BOUT 32   // 1-bit relu mask written (GemmEpi.bits_out)
 // Epilogue of the 256x256 NT tile straight from the accumulator registers (wave (wm, wn) owns rows wm*128.. and
 // columns wn*64..; lane (r16, kb) of fragment (i, j) holds row i*16 + r16, columns j*16 + kb*4 .. +3).
 // lds_bias / lds_r1col: optional LDS-resident copies of E.bias / E.r1_col (indexed by absolute column): the persistent
@@ -231,6 +239,16 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
     const bool has_mask = GEN ? E.mask != nullptr : bool(EPI & EPI_MASK);
     const bool has_r1 = GEN ? E.r1_row != nullptr : bool(EPI & EPI_R1);
     const bool has_rowb = GEN ? E.row_bias != nullptr : false;
+    // lane-private mask words (see GemmEpi): word = i >> 1, bit = (i & 1) * 16 + j * 4 + c
+    // layout [tile][wave][word 0..3][lane]: every word is one 256-byte wave store / load
+    const size_t bits_at = (((size_t)(m0 >> 8) * (size_t)(E.ldc >> 8) + (size_t)(n0 >> 8)) * 8 + (size_t)(wm * 4 + wn)) * 256 + (size_t)(threadIdx.x & 63);
+    const bool has_bin = GEN ? E.bits_in != nullptr : bool(EPI & EPI_BIN);
+    const bool has_bout = GEN ? E.bits_out != nullptr : bool(EPI & EPI_BOUT);
+    uint32_t bin[4] = {0u, 0u, 0u, 0u}, bw = 0u;
+    if (has_bin) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bin[q] = E.bits_in[bits_at + q * 64];
+    }
     float4 bj[4], cj[4];
     float r1v[8];
 #pragma unroll
@@ -272,11 +290,23 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
                       acc[i][j][2] + bj[j].z + r1 * cj[j].z, acc[i][j][3] + bj[j].w + r1 * cj[j].w};
         if (rbp) { const float4 b = *(const float4*)(rbp + j * 16); x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w; }
         if (has_relu) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
+        if (has_bin) {
+          const uint32_t nib = bin[i >> 1] >> ((i & 1) * 16 + j * 4);
+          if (!(nib & 1u)) x[0] = 0.f;
+          if (!(nib & 2u)) x[1] = 0.f;
+          if (!(nib & 4u)) x[2] = 0.f;
+          if (!(nib & 8u)) x[3] = 0.f;
+        }
         bf16x4_t h;
         h[0] = (__bf16)x[0]; h[1] = (__bf16)x[1]; h[2] = (__bf16)x[2]; h[3] = (__bf16)x[3];
         const uint2 u = *(const uint2*)&h;
         pk[j][0] = u.x; pk[j][1] = u.y;
+        if (has_bout) {     // bf16 value > 0  <=>  magnitude bits non-zero (the relu already cleared the negatives)
+          const uint32_t nib = ((u.x & 0x7fffu) ? 1u : 0u) | ((u.x & 0x7fff0000u) ? 2u : 0u) | ((u.y & 0x7fffu) ? 4u : 0u) | ((u.y & 0x7fff0000u) ? 8u : 0u);
+          bw |= nib << ((i & 1) * 16 + j * 4);
+        }
       }
+      if (has_bout && (i & 1)) { E.bits_out[bits_at + (i >> 1) * 64] = bw; bw = 0u; }
       uint32_t vv[2][4];
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp) {
@@ -650,7 +680,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     HUGS_TRP(i, 0)
-    GP_ITER(f0, f1, 24) GP_ITER(f1, f0, 24) GP_ITER(f0, f1, 24)   // the previous tile's 16 stores are in the queue
+    // the previous tile's 16 stores (+ 4 mask-bit words) are in the queue behind the two younger stages
+    if (EPI >= 0 && (EPI & EPI_BOUT)) { GP_ITER(f0, f1, 28) GP_ITER(f1, f0, 28) GP_ITER(f0, f1, 28) }
+    else { GP_ITER(f0, f1, 24) GP_ITER(f1, f0, 24) GP_ITER(f0, f1, 24) }
     GP_ITER(f1, f0, 8)
     HUGS_TRP(i, 1)
 #pragma unroll 1
@@ -1140,22 +1172,53 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ s
 static int g_force_small_tiles = 0;   // test/bench hook: 0 default (256x256, else 256x128, else 128x128), 1 force 128x128, 3 force 256x128
 extern "C" int hugs_test_force_small_tiles(int on) { g_force_small_tiles = on; return 0; }
 
+static int gemm_nt_impl(int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,
+                        const void* Bt, int ldb, const float* bias, const float* row_bias, int row_div, int ld_rb,
+                        int relu, const void* mask, int ld_mask, const float* r1_row, const float* r1_col,
+                        void* out, int ldc, uint32_t* bits_out, const uint32_t* bits_in, void* stream);
+
 extern "C" int hugs_gemm_nt(int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,
                             const void* Bt, int ldb, const float* bias, const float* row_bias, int row_div, int ld_rb,
                             int relu, const void* mask, int ld_mask, const float* r1_row, const float* r1_col,
                             void* out, int ldc, void* stream) {
+  return gemm_nt_impl(dtype, M, N, K1, K2, A1, lda1, A2, lda2, Bt, ldb, bias, row_bias, row_div, ld_rb, relu, mask, ld_mask,
+                      r1_row, r1_col, out, ldc, nullptr, nullptr, stream);
+}
+
+// hugs_gemm_nt with 1-bit relu masks (bf16, 256x256-tile kernels only: M, N multiples of 256, ldc == N).  bits_out
+// (relu epilogue): M*N/8 bytes written; bits_in: the output is multiplied by the bit (in place of `mask`).
+extern "C" long long hugs_gemm_nt_bits_bytes(int M, int N) { return (long long)M * N / 8; }
+extern "C" int hugs_gemm_nt_bits(int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,
+                                 const void* Bt, int ldb, const float* bias, int relu, const float* r1_row,
+                                 const float* r1_col, void* out, int ldc, uint32_t* bits_out, const uint32_t* bits_in,
+                                 void* stream) {
+  HUGS_REQUIRE(dtype == 1 && M % 256 == 0 && N % 256 == 0 && ldc == N && (K1 + K2) % 64 == 0 && K1 + K2 >= 256, -3,
+               "hugs_gemm_nt_bits: needs bf16, M=%d N=%d multiples of 256, ldc == N, K=%d a multiple of 64 and >= 256", M, N, K1 + K2);
+  HUGS_REQUIRE(!bits_out || relu, -3, "hugs_gemm_nt_bits: bits_out needs a relu epilogue");
+  return gemm_nt_impl(dtype, M, N, K1, K2, A1, lda1, A2, lda2, Bt, ldb, bias, nullptr, 1, 0, relu, bits_in ? (const void*)1 : nullptr, 0,
+                      r1_row, r1_col, out, ldc, bits_out, bits_in, stream);
+}
+
+static int gemm_nt_impl(int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,
+                        const void* Bt, int ldb, const float* bias, const float* row_bias, int row_div, int ld_rb,
+                        int relu, const void* mask, int ld_mask, const float* r1_row, const float* r1_col,
+                        void* out, int ldc, uint32_t* bits_out, const uint32_t* bits_in, void* stream) {
   HUGS_REQUIRE(dtype == 0 || dtype == 1, -2, "hugs_gemm_nt: dtype must be 0 (fp32) or 1 (bf16)");
   const int bk = dtype ? GB_BK : GF_BK;
   HUGS_REQUIRE(M % 128 == 0 && N % 128 == 0 && K1 % bk == 0 && K2 % bk == 0 && K1 > 0, -3,
                "hugs_gemm_nt: shape M=%d N=%d K=%d+%d not tile aligned (128,128,%d)", M, N, K1, K2, bk);
   HUGS_REQUIRE(!row_bias || row_div > 0, -3, "hugs_gemm_nt: row_div must be > 0");
   if (M == 0 || N == 0) return 0;
-  GemmEpi E{bias, row_bias, row_div, ld_rb, relu, mask, ld_mask, r1_row, r1_col, out, ldc};
+  const bool bits = bits_out || bits_in;
+  HUGS_REQUIRE(!bits || (g_force_small_tiles != 1 && g_force_small_tiles != 3), -3, "hugs_gemm_nt_bits: the 256x256 kernels are disabled by the test hook");
+  if (bits_in) mask = nullptr;       // (the EPI_MASK specialisation is selected through `epi_mask` below)
+  GemmEpi E{bias, row_bias, row_div, ld_rb, relu, mask, ld_mask, r1_row, r1_col, out, ldc, bits_out, bits_in};
   const int grid = (M / 128) * (N / 128);
   if (dtype && M % 256 == 0 && N % 256 == 0 && (K1 + K2) % 64 == 0 && K1 + K2 >= 256 && g_force_small_tiles != 1 && g_force_small_tiles != 3)
   {
     // epilogue specialisations for the combinations the trunks use (bit set = term present); anything else -> generic
-    const int epi = row_bias ? -1 : (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0) | (mask ? EPI_MASK : 0) | (r1_row ? EPI_R1 : 0);
+    const int epi = row_bias ? -1 : (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0) | (mask ? EPI_MASK : 0) | (r1_row ? EPI_R1 : 0) |
+                                    (bits_in ? EPI_BIN : 0) | (bits_out ? EPI_BOUT : 0);
     const int ntiles = (M / 256) * (N / 256), nstage = (K1 + K2) / 32;
     static int ncu = 0;
     if (!ncu) { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); ncu &= ~7; if (ncu < 8) ncu = 8; }
@@ -1171,6 +1234,9 @@ extern "C" int hugs_gemm_nt(int dtype, int M, int N, int K1, int K2, const void*
                        (const uint16_t*)A1, lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E, ntiles)
       switch (epi) {
         case EPI_BIAS | EPI_RELU: HUGS_NTP_LAUNCH(EPI_BIAS | EPI_RELU); break;
+        case EPI_BIAS | EPI_RELU | EPI_BOUT: HUGS_NTP_LAUNCH(EPI_BIAS | EPI_RELU | EPI_BOUT); break;   // forward trunk, mask bits out
+        case EPI_BIN: HUGS_NTP_LAUNCH(EPI_BIN); break;                                                 // dX, mask bits in
+        case EPI_BIN | EPI_R1: HUGS_NTP_LAUNCH(EPI_BIN | EPI_R1); break;                               // G of the last trunk layer
         case EPI_BIAS: HUGS_NTP_LAUNCH(EPI_BIAS); break;
         case EPI_MASK: HUGS_NTP_LAUNCH(EPI_MASK); break;
         case EPI_MASK | EPI_R1: HUGS_NTP_LAUNCH(EPI_MASK | EPI_R1); break;
@@ -1186,6 +1252,9 @@ extern "C" int hugs_gemm_nt(int dtype, int M, int N, int K1, int K2, const void*
                        (const uint16_t*)A1, lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E)
     switch (epi) {
       case EPI_BIAS | EPI_RELU: HUGS_NT_LAUNCH(EPI_BIAS | EPI_RELU); break;   // forward trunk layer
+      case EPI_BIAS | EPI_RELU | EPI_BOUT: HUGS_NT_LAUNCH(EPI_BIAS | EPI_RELU | EPI_BOUT); break;
+      case EPI_BIN: HUGS_NT_LAUNCH(EPI_BIN); break;
+      case EPI_BIN | EPI_R1: HUGS_NT_LAUNCH(EPI_BIN | EPI_R1); break;
       case EPI_BIAS: HUGS_NT_LAUNCH(EPI_BIAS); break;                          // bottleneck
       case EPI_MASK: HUGS_NT_LAUNCH(EPI_MASK); break;                          // dX through a relu
       case EPI_MASK | EPI_R1: HUGS_NT_LAUNCH(EPI_MASK | EPI_R1); break;        // G of the last trunk layer

@@ -12,6 +12,7 @@ from . import geopoly
 from . import stepfun
 
 CHUNK = 16384
+_USE_BITS = __import__('os').environ.get('HUGS_RELU_BITS', '1') != '0'        # A/B knob: 1-bit relu masks for the dX GEMMs
 _CHUNK_BYTES = int(float(__import__('os').environ.get('HUGS_FWD_CHUNK_MB', '1e9')) * 1e6)   # forward row-chunk size (A/B knob)
 
 
@@ -300,6 +301,11 @@ class Engine:
     # the 256 MiB Infinity Cache; walking the trunk chunk by chunk keeps each chunk's activations cache-resident from
     # the layer that writes them to the layer that reads them.  Stand-alone the 8-layer chain gains 3-10 %
     # (scratch/chain_chunk.py); inside the train step it is a wash (8.68 vs 8.67 ms, same box), so it stays off.
+    # 1-bit relu masks for the backward dX GEMMs (written by the forward epilogue in the 256x256 kernels' own lane
+    # layout, hugs_gemm_nt_bits): bf16, whole 256-row / 256-column tiles only; otherwise the backward reads Y itself
+    use_bits = bool(self.dt and keep and M % 256 == 0 and W % 256 == 0 and _USE_BITS)
+    bits = [ws.get(f'{tag}/bits{i}', (M * W // 32,), torch.int32) if use_bits and spec.layers[i]['kpad'] >= 256 else None
+            for i in range(spec.net_depth)]
     nchunk = 1
     while (M // nchunk) * W * (2 if self.dt else 4) > _CHUNK_BYTES and (M // (2 * nchunk)) % 256 == 0 and M // (2 * nchunk) >= 65536:
       nchunk *= 2
@@ -312,7 +318,15 @@ class Engine:
         path = (spec.name, l['name'], 'kernel')
         bias = lay.view(theta, (spec.name, l['name'], 'bias'), padded=True)
         Y = Ys[i][rows]
-        if l['concat']:
+        bts = None if bits[i] is None else bits[i][c * (mc * W // 32):(c + 1) * (mc * W // 32)]
+        if bts is not None:
+          if l['concat']:
+            _lib.call('hugs_gemm_nt_bits', dt, mc, W, W, spec.Fp, x, W, X0[rows], spec.Fp, self.wt[path], l['kpad'], bias, 1, None,
+                      None, Y, W, bts, None)
+          else:
+            K = l['kpad']
+            _lib.call('hugs_gemm_nt_bits', dt, mc, W, K, 0, x, K, None, 0, self.wt[path], K, bias, 1, None, None, Y, W, bts, None)
+        elif l['concat']:
           _lib.call('hugs_gemm_nt', dt, mc, W, W, spec.Fp, x, W, X0[rows], spec.Fp, self.wt[path], l['kpad'], bias, None, 1, 0, 1,
                     None, 0, None, None, Y, W)
         else:
@@ -328,7 +342,7 @@ class Engine:
     wd = lay.view(theta, (spec.name, ld['name'], 'kernel'), padded=True).reshape(-1)
     bd = lay.view(theta, (spec.name, ld['name'], 'bias'))
     _lib.call('hugs_density_fwd', dt, M, W, x, W, wd, bd, spec.density_bias, raw, density)
-    out = dict(X0=X0, acts=acts, raw=raw, density=density, rgb=None)
+    out = dict(X0=X0, acts=acts, raw=raw, density=density, rgb=None, bits=bits if nchunk == 1 else [None] * len(bits))
     if not spec.disable_rgb:
       lb, lv, lr = spec.layers[spec.net_depth + 1:spec.net_depth + 4]
       Bw, H = spec.bottleneck_width, spec.net_width_viewdirs
@@ -526,8 +540,13 @@ class Engine:
                   None, 1, 0, 0, None, 0, None, None, dB, Bw)
       self._tn(M, W, Bw, Ylast, W, dB, Bw, gview((spec.name, lb['name'], 'kernel'), True), gview((spec.name, lb['name'], 'bias')))
       # G_last = (dBott Wb^T + d_raw (x) w_d) * (Ylast > 0)
-      _lib.call('hugs_gemm_nt', dt, M, W, Bw, 0, dB, Bw, None, 0, self.wn[(spec.name, lb['name'], 'kernel')], Bw, None, None,
-                1, 0, 0, Ylast, W, d_raw, wd, Ga, W)
+      blast = lv['bits'][spec.net_depth - 1] if lv.get('bits') else None
+      if blast is not None and Bw >= 256:
+        _lib.call('hugs_gemm_nt_bits', dt, M, W, Bw, 0, dB, Bw, None, 0, self.wn[(spec.name, lb['name'], 'kernel')], Bw, None, 0,
+                  d_raw, wd, Ga, W, None, blast)
+      else:
+        _lib.call('hugs_gemm_nt', dt, M, W, Bw, 0, dB, Bw, None, 0, self.wn[(spec.name, lb['name'], 'kernel')], Bw, None, None,
+                  1, 0, 0, Ylast, W, d_raw, wd, Ga, W)
     if leaf_done is not None:      # density / bottleneck / view / rgb (/ transient) layers: everything behind the trunk
       first = lay.by_path[(spec.name, spec.layers[spec.net_depth]['name'], 'kernel')]
       last = lay.by_path[(spec.name, spec.layers[-1]['name'], 'bias')]
@@ -570,8 +589,13 @@ class Engine:
         if nxt in tn_done:                           # the dW that last read this buffer must be finished
           main.wait_event(tn_done.pop(nxt))
         # G_{i-1} = (G_i W_i[:W]^T) * (Y_{i-1} > 0)
-        _lib.call('hugs_gemm_nt', dt, M, W, W, 0, G, W, None, 0, self.wn[path][:W] if l['concat'] else self.wn[path], W, None,
-                  None, 1, 0, 0, acts[i], W, None, None, ring[nxt], W)
+        bprev = lv['bits'][i - 1] if lv.get('bits') else None
+        if bprev is not None:
+          _lib.call('hugs_gemm_nt_bits', dt, M, W, W, 0, G, W, None, 0, self.wn[path][:W] if l['concat'] else self.wn[path], W,
+                    None, 0, None, None, ring[nxt], W, None, bprev)
+        else:
+          _lib.call('hugs_gemm_nt', dt, M, W, W, 0, G, W, None, 0, self.wn[path][:W] if l['concat'] else self.wn[path], W, None,
+                    None, 1, 0, 0, acts[i], W, None, None, ring[nxt], W)
         ev_g = torch.cuda.Event()
         ev_g.record(main)
         G, gi = ring[nxt], nxt
