@@ -295,3 +295,34 @@ def test_properties_at_baseline_batch():
   s = a[0]
   assert bool((s[:, 1:] >= s[:, :-1]).all()) and float(s.min()) >= 0 and float(s.max()) <= 1
   assert bool((a[1][:, 1:] >= a[1][:, :-1]).all()) and float(a[1].min()) >= 0.1 - 1e-6 and float(a[1].max()) <= 1.2 + 1e-6
+
+
+def test_torch_library_custom_ops():
+  """`torch.ops.hugs.*` (nerf_hugs_amd/ops.py): the torch.library registration of the hot-path kernels gives the same
+  numbers as the direct C-ABI calls and refuses CPU tensors (no CPU fallback)."""
+  import nerf_hugs_amd.ops as O
+  from nerf_hugs_amd import _lib as L
+  for name in O.OPS:
+    assert hasattr(torch.ops.hugs, name), name
+  g = torch.Generator(device=dev).manual_seed(0)
+  M, K, N = 512, 256, 256
+  x = torch.randn(M, K, device=dev, generator=g).bfloat16()
+  wt = (torch.randn(N, K, device=dev, generator=g) / 16).bfloat16()
+  bias = torch.randn(N, device=dev, generator=g)
+  out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+  torch.ops.hugs.gemm_nt(x, wt, bias, True, out)
+  ref = torch.relu(x.float() @ wt.float().t() + bias)
+  assert float((out.float() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
+  gm = torch.randn(M, N, device=dev, generator=g).bfloat16()
+  dx = torch.empty(M, K, device=dev, dtype=torch.bfloat16)
+  torch.ops.hugs.gemm_nt_masked(gm, wt.t().contiguous(), x, dx)      # wn [K,N] = wt^T
+  refx = (gm.float() @ wt.float()) * (x.float() > 0)
+  assert float((dx.float() - refx).abs().max()) < 2e-2 * float(refx.abs().max())
+  dw, db = torch.empty(K, N, device=dev), torch.empty(N, device=dev)
+  ws = torch.empty(L.lib().cdll.hugs_gemm_tn_ws_bytes(K, N, 2) // 4, device=dev)
+  torch.ops.hugs.gemm_tn(x, gm, 2, dw, db, ws)
+  refw = x.float().t() @ gm.float()
+  assert float((dw - refw).abs().max()) < 1e-3 * float(refw.abs().max())
+  np.testing.assert_allclose(db.cpu().numpy(), gm.float().sum(0).cpu().numpy(), rtol=1e-4, atol=1e-3)
+  with pytest.raises(Exception):
+    torch.ops.hugs.gemm_nt(x.cpu(), wt.cpu(), bias.cpu(), True, out.cpu())

@@ -179,3 +179,38 @@ def test_num_samples_error_and_capacity():
   t = torch.tensor([[0., 1.]], device=dev); w = torch.ones(1, 1, device=dev); zz = torch.zeros(1, device=dev)
   with pytest.raises(ValueError):
     L.call('hugs_nf_sample', 1, 1, 1, t, w, 1., 0., zz, None, 1, 0., 1., 0, zz, zz + 1, torch.empty(1, 2, device=dev), torch.empty(1, 2, device=dev))
+
+
+def _nf_rank(rank, world, port, out_dir):
+  import sys
+  sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+  import torch.distributed as dist
+  from nerf_hugs_amd.nerfacto.model import NerfactoConfig, NerfactoModel
+  torch.cuda.set_device(0)
+  if world > 1:
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+  model = NerfactoModel(NerfactoConfig(**SMALL), compute_dtype='fp32', seed=4)
+  b, _ = _rays(256, 21)
+  n = 256 // world
+  b = {k: v[rank * n:(rank + 1) * n].to(dev).contiguous() for k, v in b.items()}
+  theta0 = model.flat.clone()
+  res = model.train_step(b, curr_step=10, u01=None, world=world)
+  torch.cuda.synchronize()
+  if rank == 0:
+    torch.save({'delta': (model.flat - theta0).cpu(), 'grad': model.grad.cpu(), 'rgb_loss': float(res['stats'][1])}, os.path.join(out_dir, f'nf{world}.pt'))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+def test_two_rank_nerfacto_step_equals_single_process(tmp_path):
+  """Data parallel nerfacto (one process per GPU, all-reduce of the flat gradient; here 2 ranks on one GPU over gloo):
+  with deterministic sampling the averaged per-shard gradients equal the full-batch gradient."""
+  import socket
+  import torch.multiprocessing as mp
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  mp.spawn(_nf_rank, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+  mp.spawn(_nf_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+  a, b = torch.load(tmp_path / 'nf1.pt'), torch.load(tmp_path / 'nf2.pt')
+  sc = float(a['grad'].abs().max())
+  assert sc > 0 and float((a['grad'] - b['grad']).abs().max()) <= 2e-4 * sc
