@@ -129,6 +129,10 @@ int hugs_opt_adam(int nchunks, int nleaf, const void* chunks, const void* leaf_i
                   float* leaf_upd, void* stream);
 /* fp32 master [K,N] -> compute-dtype copies Wn [K,N] and Wt [N,K] (either may be NULL) */
 int hugs_cast_weights(int dtype, int K, int N, const float* W, void* Wn, void* Wt, void* stream);
+/* The same cast for a device table of matrices in one launch.  items: nitems records of 40 bytes
+ * {const float* W; void* Wn; void* Wt; int32 K, N, blk0, nbx} with nbx = ceil(N/32), blk0 = first 32x32 block of the
+ * item in the launch grid (ascending), total_blocks = sum of ceil(K/32)*nbx. */
+int hugs_cast_weights_batch(int dtype, int nitems, const void* items, int total_blocks, void* stream);
 
 /* ---- batch assembly on the device (the reference does this in a host numpy thread) ----
  * camera_utils.py:503-607 pixels_to_rays (+ :462-495 Newton undistort, :561-570 fisheye, :32-100 convert_to_ndc)

@@ -37,6 +37,7 @@ _PROTOS = {
     'hugs_opt_stats': 'iiippppfffppps',
     'hugs_opt_adam': 'iippppppppffffffffpps',
     'hugs_cast_weights': 'iiippps',
+    'hugs_cast_weights_batch': 'iipis',
     'hugs_pixels_to_rays': 'ipppipppipippppppps',
     'hugs_gather_pixels': 'iipppppiipps',
     'hugs_expand_patches': 'iiipppppps',

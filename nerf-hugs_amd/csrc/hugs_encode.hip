@@ -99,23 +99,34 @@ __global__ __launch_bounds__(256) void k_cast_ipe(int nrays, int S, const float*
     s_lv[s][j] = b0 * r0 + b1 * r1 + b2 * r2;
   }
   __syncthreads();
-  // one wave writes one whole row: lane owns 8 consecutive features
+  // one wave writes one whole row: lane owns 8 consecutive features.  Which (half, degree k, basis j) a feature column
+  // is does not depend on the sample: decoded once per lane (no integer division in the per-sample loop).
   const int lane = tid & 63, wv = tid >> 6;
   const int nfeat_half = nb * max_deg;
-  for (int s = wv; s < ENC_SAMPLES; s += 4) {
-    const long long m = base + s;
-    if (m >= total) break;
-    for (int f0 = lane * 8; f0 < kp; f0 += 512) {
+  for (int f0 = lane * 8; f0 < kp; f0 += 512) {
+    int jj[8];         // j | k << 8 | half << 16; half == 2: padding column
+    float scs[8];
+    {
+      int half = f0 >= nfeat_half ? (f0 >= 2 * nfeat_half ? 2 : 1) : 0;
+      const int r = f0 - (half == 1 ? nfeat_half : 0);
+      int k = half < 2 ? r / nb : 0, j = half < 2 ? r - k * nb : 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        jj[q] = j | (half << 16);
+        scs[q] = (float)(1 << k);
+        if (half < 2 && ++j == nb) { j = 0; if (++k == max_deg) { k = 0; ++half; } }
+      }
+    }
+    for (int s = wv; s < ENC_SAMPLES; s += 4) {
+      const long long m = base + s;
+      if (m >= total) break;
       float v[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int f = f0 + q;
+        const int half = jj[q] >> 16, j = jj[q] & 0xffff;
         float val = 0.0f;
-        if (f < 2 * nfeat_half) {
-          const int half = f >= nfeat_half;
-          const int r = f - half * nfeat_half;
-          const int k = r / nb, j = r - k * nb;
-          const float sc = (float)(1 << k);
+        if (half < 2) {
+          const float sc = scs[q];
           float x = s_lm[s][j] * sc;
           if (half) x = x + 1.57079632679489661923f;   // sin(x + pi/2), as the reference does
           const float var = s_lv[s][j] * (sc * sc);

@@ -145,6 +145,37 @@ __global__ __launch_bounds__(256) void k_cast_weights(int K, int N, const float*
     }
 }
 
+// The same cast for a table of matrices in ONE launch (a train step refreshes 14 operand pairs: 14 launches of ~5 us).
+struct CastItem { const float* W; void* Wn; void* Wt; int K, N, blk0, nbx; };
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_cast_weights_batch(int nitems, const CastItem* __restrict__ items) {
+  __shared__ float tile[32][33];
+  int it = 0;
+  while (it + 1 < nitems && (int)blockIdx.x >= items[it + 1].blk0) ++it;
+  const CastItem I = items[it];
+  const int b = blockIdx.x - I.blk0;
+  const int k0 = (b / I.nbx) * 32, n0 = (b % I.nbx) * 32, K = I.K, N = I.N;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r, n = n0 + tx;
+    float x = 0.f;
+    if (k < K && n < N) {
+      x = I.W[(size_t)k * N + n];
+      if (I.Wn) { if (BF16) ((uint16_t*)I.Wn)[(size_t)k * N + n] = f_to_bf16(x); else ((float*)I.Wn)[(size_t)k * N + n] = x; }
+    }
+    tile[r][tx] = x;
+  }
+  __syncthreads();
+  if (I.Wt)
+    for (int r = ty; r < 32; r += 8) {
+      const int n = n0 + r, k = k0 + tx;
+      if (k < K && n < N) {
+        const float x = tile[tx][r];
+        if (BF16) ((uint16_t*)I.Wt)[(size_t)n * K + k] = f_to_bf16(x); else ((float*)I.Wt)[(size_t)n * K + k] = x;
+      }
+    }
+}
+
 extern "C" int hugs_opt_stats(int nchunks, int nleaf, int nmod, const void* chunks, const void* leaf_info,
                               const float* theta, const float* grad,
                               float gscale, float max_val, float max_norm, float* part1_ws, float* leaf_stats,
@@ -167,6 +198,14 @@ extern "C" int hugs_opt_adam(int nchunks, int nleaf, const void* chunks, const v
                      trainable, gscale, max_val, lr, b1, b2, eps, bias_corr1, bias_corr2, part2_ws);
   hipLaunchKernelGGL(k_opt_finalize2, dim3(1), dim3(256), 0, st, nleaf, (const int4*)leaf_info, part2_ws, leaf_upd);
   HUGS_CHECK_LAUNCH("hugs_opt_adam");
+  return 0;
+}
+
+extern "C" int hugs_cast_weights_batch(int dtype, int nitems, const void* items, int total_blocks, void* stream) {
+  if (nitems <= 0 || total_blocks <= 0) return 0;
+  if (dtype) hipLaunchKernelGGL(k_cast_weights_batch<true>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, nitems, (const CastItem*)items);
+  else hipLaunchKernelGGL(k_cast_weights_batch<false>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, nitems, (const CastItem*)items);
+  HUGS_CHECK_LAUNCH("hugs_cast_weights_batch");
   return 0;
 }
 

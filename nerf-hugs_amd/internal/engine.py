@@ -258,20 +258,34 @@ class Engine:
   def refresh_weights(self, theta):
     """Cast the fp32 masters to the GEMM operand copies: Wn [Kp,N] (dX) and Wt [N,Kp] (forward)."""
     self._cast_src = (theta.data_ptr(), theta._version)
-    for lf in self.layout.leaves:
-      if lf['path'][-1] != 'kernel' or lf['layer']['kind'] not in ('trunk', 'bottleneck', 'view', 'tview', 'ttrunk'):
-        continue
-      l = lf['layer']
-      W = self.layout.view(theta, lf['path'], padded=True)
-      K = l['kpad'] if l['kind'] not in ('view', 'tview') else lf['spec'].bottleneck_width   # GEMM part of the layer
-      N = l.get('npad', l['fan_out'])
-      key = lf['path']
-      if key not in self.wt:
-        self.wt[key] = torch.empty(N, K, dtype=self.tdt, device=self.device)
-        self.wn[key] = torch.empty(K, N, dtype=self.tdt, device=self.device) if self.dt else None
-      _lib.call('hugs_cast_weights', self.dt, K, N, W, self.wn[key], self.wt[key])
-      if not self.dt:
-        self.wn[key] = W[:K]      # fp32: the master itself is the natural-layout operand
+    tab = getattr(self, '_cast_table', None)
+    if tab is None or tab[0] != theta.data_ptr():
+      # one 40-byte record per GEMM operand pair (include/hugs.h hugs_cast_weights_batch); rebuilt only when the
+      # master buffer moves
+      rec, blk = [], 0
+      for lf in self.layout.leaves:
+        if lf['path'][-1] != 'kernel' or lf['layer']['kind'] not in ('trunk', 'bottleneck', 'view', 'tview', 'ttrunk'):
+          continue
+        l = lf['layer']
+        W = self.layout.view(theta, lf['path'], padded=True)
+        K = l['kpad'] if l['kind'] not in ('view', 'tview') else lf['spec'].bottleneck_width   # GEMM part of the layer
+        N = l.get('npad', l['fan_out'])
+        key = lf['path']
+        if key not in self.wt:
+          self.wt[key] = torch.empty(N, K, dtype=self.tdt, device=self.device)
+          self.wn[key] = torch.empty(K, N, dtype=self.tdt, device=self.device) if self.dt else None
+        if not self.dt:
+          self.wn[key] = W[:K]      # fp32: the master itself is the natural-layout operand
+        nbx = (N + 31) // 32
+        rec.append((W.data_ptr(), self.wn[key].data_ptr() if self.dt else 0, self.wt[key].data_ptr(), K, N, blk, nbx))
+        blk += ((K + 31) // 32) * nbx
+      raw = np.zeros((len(rec), 5), np.int64)
+      for i, (pw, pn, pt, K, N, b0, nbx) in enumerate(rec):
+        raw[i, :3] = (pw, pn, pt)
+        raw[i, 3:].view(np.int32)[:4] = (K, N, b0, nbx)
+      tab = (theta.data_ptr(), torch.from_numpy(raw).to(self.device), len(rec), blk)
+      self._cast_table = tab
+    _lib.call('hugs_cast_weights_batch', self.dt, tab[2], tab[1], tab[3])
     for spec in self.model.specs:
       if spec.num_tra > 0:      # dBottleneck = [G_view | G_transient0] [Wv[:Bw] | Wt0[:Bw]]^T in one two-segment GEMM
         lv, lt = spec.layers[spec.net_depth + 2], spec.layers[spec.t0]
@@ -478,7 +492,7 @@ class Engine:
     slab = self.ws.get(f'tn_slab/{torch.cuda.current_stream().cuda_stream}', (max(nbytes // 4, 1),))
     _lib.call('hugs_gemm_tn', self.dt, M, Kc, Nn, ns, X, ldx, G, ldg, dW, db, slab)
 
-  def backward_level(self, theta, grad, lv, rays, N, d_rgb_out, d_w_extra, nerfw=None, leaf_done=None):
+  def backward_level(self, theta, grad, lv, rays, N, d_rgb_out, d_w_extra, nerfw=None, leaf_done=None, lane=0):
     """Backward of one level: compositing -> heads -> trunk.  Writes (=, not +=) the level's MLP gradients
     into `grad` (flat, same layout as theta); GLO embedding rows are scatter-added (caller zeroes them).
     leaf_done(lo, hi): optional callback, called on the stream that produced them as soon as the gradient
@@ -503,7 +517,7 @@ class Engine:
     Ylast = acts[-1]
     ld = spec.layers[spec.net_depth]
     d_raw = ws.get(tag + '/d_raw', (M,))
-    dws = ws.get('dens_ws', (max(_lib.lib().cdll.hugs_density_bwd_ws_bytes(W) // 4, 1),))
+    dws = ws.get(tag + '/dens_ws', (max(_lib.lib().cdll.hugs_density_bwd_ws_bytes(W) // 4, 1),))
     _lib.call('hugs_density_bwd', dt, M, W, Ylast, W, d_density, lv['raw'], spec.density_bias, d_raw,
               gview((spec.name, ld['name'], 'kernel'), True).reshape(-1), gview((spec.name, ld['name'], 'bias')), dws)
     wd = lay.view(theta, (spec.name, ld['name'], 'kernel'), padded=True).reshape(-1)
@@ -515,7 +529,7 @@ class Engine:
       lb, lvw, lr = spec.layers[spec.net_depth + 1:spec.net_depth + 4]
       Bw, H = spec.bottleneck_width, spec.net_width_viewdirs
       Gv = ws.get(tag + '/Gview', (M, H), self.tdt)
-      rws = ws.get('rgb_ws', (max(_lib.lib().cdll.hugs_rgb_bwd_ws_bytes() // 4, 1),))
+      rws = ws.get(tag + '/rgb_ws', (max(_lib.lib().cdll.hugs_rgb_bwd_ws_bytes() // 4, 1),))
       _lib.call('hugs_rgb_bwd', dt, M, H, lv['hview'], H, lay.view(theta, (spec.name, lr['name'], 'kernel')), lv['rgb'],
                 d_rgb_s, spec.rgb_padding, Gv, H, gview((spec.name, lr['name'], 'kernel')),
                 gview((spec.name, lr['name'], 'bias')), rws)
@@ -558,7 +572,7 @@ class Engine:
     # tile-epilogue / launch-boundary bubbles.  Three G buffers rotate so dX never overwrites a buffer a pending
     # dW still reads; the per-call fp32 slab workspace is double-buffered the same way.
     main = torch.cuda.current_stream()
-    side = self._side_stream()
+    side = self._side_stream(lane)
     Gc = ws.get(tag + '/Gc', (M, W), self.tdt)
     ring = [Ga, Gb, Gc]
     gi = 0
@@ -698,10 +712,14 @@ class Engine:
         _lib.call('hugs_embed_scatter_add', dt, N, spec.T, dX0, spec.kpad, spec.E, rays['embed_idx'],
                   gview(('TransientEmbed_0', 'embedding')))
 
-  def _side_stream(self):
-    if getattr(self, '_side', None) is None:
+  def _side_stream(self, lane=0):
+    """HIP streams next to the caller's: lane 0 carries the weight-gradient GEMMs of the NerfMLP backward (and the
+    HA-NeRF mask MLP), lane 1 the whole proposal-level backward, lane 2 its weight-gradient GEMMs."""
+    if not hasattr(self, '_side'):
+      self._side = {}
+    if lane not in self._side:
       import os
-      # HUGS_SINGLE_STREAM=1 (measurement hook): weight-gradient GEMMs stay on the compute stream
-      self._side = (torch.cuda.current_stream() if os.environ.get('HUGS_SINGLE_STREAM') == '1'
-                    else torch.cuda.Stream(device=self.device))
-    return self._side
+      # HUGS_SINGLE_STREAM=1 (measurement hook): everything stays on the compute stream
+      self._side[lane] = (torch.cuda.current_stream() if os.environ.get('HUGS_SINGLE_STREAM') == '1'
+                          else torch.cuda.Stream(device=self.device))
+    return self._side[lane]

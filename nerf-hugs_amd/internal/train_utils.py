@@ -328,27 +328,43 @@ def create_train_step(model, config, is_finetune=False):
       ar_ranges.append((lo, hi))
       ar_works.append(dist.all_reduce(grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
-    for l in range(L - 1, -1, -1):
+    def level_backward(l, lane):
+      nonlocal prop_done
       coef = config.data_loss_mult if l == L - 1 else config.data_coarse_loss_mult
       is_prop = l < L - 1
       if is_finetune and is_prop:
-        continue                       # proposal MLP gets no gradient in the finetune stage
+        return                         # proposal MLP gets no gradient in the finetune stage
       if is_prop and d_w[l] is None and coef == 0:
-        continue
+        return
       tgt = grad
       if is_prop and prop_done:
         tgt = ws.get('grad_tmp', (layout.size + STAT_TAIL,))
       bucketed = bucket_done if (world > 1 and not is_prop and not is_finetune) else None
       if tt == 'nerfw' and not is_prop:
-        eng.backward_level(state.flat, tgt, levels[l], rays, N, None, d_w[l], nerfw=nw, leaf_done=bucketed)
+        eng.backward_level(state.flat, tgt, levels[l], rays, N, None, d_w[l], nerfw=nw, leaf_done=bucketed, lane=lane)
       else:
-        eng.backward_level(state.flat, tgt, levels[l], rays, N, d_pred[l] if coef != 0 else None, d_w[l], leaf_done=bucketed)
+        eng.backward_level(state.flat, tgt, levels[l], rays, N, d_pred[l] if coef != 0 else None, d_w[l], leaf_done=bucketed,
+                           lane=lane)
       if is_prop and prop_done:
         _lib.call('hugs_add_inplace', prop_hi - prop_lo, tgt[prop_lo:prop_hi], grad[prop_lo:prop_hi])
       if is_prop:
         prop_done = True
-    if not prop_done:
-      grad[prop_lo:prop_hi].zero_()
+
+    # With stop_level_grad the proposal levels' backward depends on the losses only (interlevel d_w, coarse data loss),
+    # not on the NerfMLP's: it is ~0.4 ms of small launch-latency-bound kernels, enqueued on its own pair of streams
+    # underneath the NerfMLP trunk backward (whose GEMMs fill the chip; the proposal kernels fit in their tails).
+    bwd_main = torch.cuda.current_stream()
+    prop_stream = eng._side_stream(1)
+    ev_loss = torch.cuda.Event(); ev_loss.record(bwd_main)
+    with torch.cuda.stream(prop_stream):
+      prop_stream.wait_event(ev_loss)
+      for l in range(L - 2, -1, -1):
+        level_backward(l, 2)
+      if not prop_done:
+        grad[prop_lo:prop_hi].zero_()
+      ev_prop = torch.cuda.Event(); ev_prop.record(prop_stream)
+    level_backward(L - 1, 0)
+    bwd_main.wait_event(ev_prop)
     if ev_mask_bwd is not None:
       torch.cuda.current_stream().wait_event(ev_mask_bwd)
     # ---- pmean(grad), pmean(stats) ------------------------------------------------------------------
