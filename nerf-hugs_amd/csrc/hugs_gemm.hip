@@ -648,8 +648,58 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wb[j], f.xa[i], acc[i][j], 0, 0, 0);
   };
+  // The same work in four fenced quarters of {1 LDS-DMA, 3 fragment reads, 8 MFMAs} (HUGS_NT_SCHED == 4): the four DMAs
+  // of a stage are not pushed into the CU's vector-memory path back to back by all 8 waves at once.
+  auto issue_piece = [&](int q) {
+    const int kglob = l_st << 5;
+    const unsigned la = lds_base + (unsigned)l_slot * STAGE;
+    if (q < 2) {
+      if (kglob < K1) dma((const char*)A1 + ((size_t)lm0 * lda1 + kglob) * 2 + (q ? (size_t)lda1 * 256 : 0), oA1, la + q * 8192);
+      else dma((const char*)A2 + ((size_t)lm0 * lda2 + (kglob - K1)) * 2 + (q ? (size_t)lda2 * 256 : 0), oA2, la + q * 8192);
+    } else {
+      dma((const char*)Bt + ((size_t)ln0 * ldb + kglob) * 2 + (q == 3 ? (size_t)ldb * 256 : 0), oB, la + A_BYTES + (q - 2) * 8192);
+    }
+    if (q == 3) {
+      l_slot = (l_slot + 1) & 3;
+      if (++l_st == ns) {
+        l_st = 0;
+        if (l_bid + G < ntiles) {
+          l_bid += G;
+          const int t = xcd_remap(l_bid, ntiles);
+          lm0 = (t / ntn) << 8; ln0 = (t % ntn) << 8;
+        }
+      }
+    }
+  };
+  auto frags_piece = [&](Frags& f, int q) {      // reads 3q .. 3q+2 of {wb[0..3], xa[0..7]}
+    const unsigned char* la = lds + c_slot * STAGE + wm * 128 * 64 + frag_off;
+    const unsigned char* lb = lds + c_slot * STAGE + A_BYTES + wn * 64 * 64 + frag_off;
+#pragma unroll
+    for (int r = 3 * q; r < 3 * q + 3; ++r) {
+      if (r < 4) f.wb[r] = *(const bf16x8_t*)(lb + r * 16 * 64);
+      else f.xa[r - 4] = *(const bf16x8_t*)(la + (r - 4) * 16 * 64);
+    }
+    if (q == 3) c_slot = (c_slot + 1) & 3;
+  };
+  auto mfma_piece = [&](const Frags& f, int q) {
+#pragma unroll
+    for (int i = 2 * q; i < 2 * q + 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wb[j], f.xa[i], acc[i][j], 0, 0, 0);
+  };
+#ifndef HUGS_NT_SCHED
+#define HUGS_NT_SCHED 4
+#endif
+#define GP_Q(cur, nxt, q) issue_piece(q); frags_piece(nxt, q); mfma_piece(cur, q); __builtin_amdgcn_sched_barrier(0);
   // iteration for stage g: frags(g) are in `cur`; make stage g+1 visible, refill the slot of stage g with stage g+4,
   // start reading frags(g+1) into `nxt`, run the MFMAs of stage g.
+#define GP_ITERQ(cur, nxt, VM)                                                           \
+  {                                                                                       \
+    asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");                     \
+    __builtin_amdgcn_s_barrier();                                                         \
+    asm volatile("" ::: "memory");                                                        \
+    GP_Q(cur, nxt, 0) GP_Q(cur, nxt, 1) GP_Q(cur, nxt, 2) GP_Q(cur, nxt, 3)               \
+  }
 #define GP_ITER(cur, nxt, VM)                                                            \
   {                                                                                       \
     asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");                     \
@@ -686,12 +736,18 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
     GP_ITER(f1, f0, 8)
     HUGS_TRP(i, 1)
 #pragma unroll 1
+#if HUGS_NT_SCHED == 4
+    for (int st = 4; st < ns; st += 2) { GP_ITERQ(f0, f1, 8) GP_ITERQ(f1, f0, 8) }
+#else
     for (int st = 4; st < ns; st += 2) { GP_ITER(f0, f1, 8) GP_ITER(f1, f0, 8) }
+#endif
     HUGS_TRP(i, 2)
     nt_epilogue_direct<EPI>(acc, E, m0, n0, wm, wn, r16, kb, lds_bias, lds_r1);
     HUGS_TRP(i, 3)
   }
 #undef GP_ITER
+#undef GP_ITERQ
+#undef GP_Q
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dead stages past the last tile must land before the LDS is released
 }
 
@@ -820,8 +876,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(int Mrows, int Kc, int 
 // swizzle: fragment reads are base + immediate, which frees ~25 VGPRs and the XOR arithmetic).  The bias gradient (column sums of G) costs two
 // extra MFMAs per stage against an all-ones fragment instead of a scalar LDS pass.
 // ------------------------------------------------------------------------------------------------
+#define HUGS_STR_(x) #x
+#define HUGS_STR(x) HUGS_STR_(x)
 #ifndef HUGS_TN_SCHED
-#define HUGS_TN_SCHED 0
+#define HUGS_TN_SCHED 4
+#endif
+// Measurement builds only (scratch/tn_exp.sh; results are garbage): bit 0 = no LDS-DMA in the steady-state loop,
+// bit 1 = no fragment ds_reads in the loop, bit 2 = no MFMAs, bit 3 = loads always hit L2, bit 4 = two (not three) stages in flight.
+#ifndef HUGS_TN_EXP
+#define HUGS_TN_EXP 0
+#endif
+// L2 prefetch distance of the TN kernel in K-stages beyond the LDS-DMA front (0 = off)
+#ifndef HUGS_TN_PF
+#define HUGS_TN_PF 0
 #endif
 __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, int N, int nsplit,
                                                               const uint16_t* __restrict__ X, int ldx,
@@ -832,7 +899,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
   // pitch: the 8 rows one 32-lane group of a transpose read touches have distinct p, so they land 8 banks apart
   // (1056 B = 264 dwords = 8 mod 64) with NO address swizzle: every fragment read is base + immediate.
   constexpr int NSLOT = 4, PAIR = 1056, XB = 16 * PAIR, STAGE = 2 * XB;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[128 * 1040 > NSLOT * STAGE ? 128 * 1040 : NSLOT * STAGE];
+  constexpr int RING = 128 * 1040 > NSLOT * STAGE ? 128 * 1040 : NSLOT * STAGE;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[RING + 2048];      // + 256 B per wave: sink of the L2 prefetches
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntn = N >> 8, ntk = Kc >> 8, tiles = ntn * ntk;
@@ -845,16 +913,44 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
   const int wn = wv >> 2, wk = wv & 3;
   const bool do_colsum = colsum_slab && c0 == 0;
 
+  // LDS-DMA as inline asm: (64-bit SGPR base) + (32-bit per-lane byte offset, constant for the whole kernel), M0 = LDS
+  // destination.  Through the builtin the compiler knows the instruction writes LDS and puts an `s_waitcnt vmcnt(0)` in
+  // front of the first transpose read of EVERY iteration (it cannot prove the ds_read_tr intrinsics do not alias the
+  // DMA destination): the ring drained each stage and the counted waits below never counted anything.  The explicit
+  // vmcnt / barrier protocol is the synchronisation; the "memory" clobber keeps the compiler from moving reads across.
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  const unsigned voX = (unsigned)((lane >> 5) * ldx + (lane & 31) * 8) * 2u, voG = (unsigned)((lane >> 5) * ldg + (lane & 31) * 8) * 2u;
+  auto dma16 = [&](const char* sbase, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory", "m0");
+  };
   auto stage = [&](int st) {
-    const int mrow0 = mbeg + (st << 5);
-    unsigned char* lx = lds + (st % NSLOT) * STAGE;
-    unsigned char* lg = lx + XB;
+    const int mrow0 = mbeg + (((HUGS_TN_EXP & 8) ? (st & 7) : st) << 5);      // bit 3: every stage re-reads 8 L2-resident stages
+    const unsigned l = lds0 + (unsigned)(st % NSLOT) * STAGE;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      const int pair = it * 8 + wv, row = 2 * pair + (lane >> 5), c = (lane & 31) * 8;
-      glds16(X + (size_t)(mrow0 + row) * ldx + c0 + c, lx + pair * PAIR);
-      glds16(G + (size_t)(mrow0 + row) * ldg + n0 + c, lg + pair * PAIR);
+      const int pair = it * 8 + wv;
+      dma16((const char*)(X + (size_t)(mrow0 + 2 * pair) * ldx + c0), voX, l + pair * PAIR);
+      dma16((const char*)(G + (size_t)(mrow0 + 2 * pair) * ldg + n0), voG, l + XB + pair * PAIR);
     }
+  };
+
+  // L2 prefetch.  The LDS-DMA front runs 3 stages (96 KB per CU) ahead -- all the ring holds -- which does not cover an HBM
+  // miss, and every stage has one: the rows are new.  So each workgroup also touches, HUGS_TN_PF stages further ahead,
+  // its share of the lines its XCD siblings will need (the 4 workgroups with the same c0 read the same X rows, the 4 with
+  // the same n0 the same G rows: each takes 8 of a stage's 32 rows): one 4-byte-per-lane LDS-DMA into a sink, 8 lanes per
+  // 128-byte line, waves 0-3 on X and 4-7 on G, no VGPR results and no lane masking.  It rides the same in-order vmcnt
+  // queue as the stage loads (one more entry per iteration).
+  const int pf_line = (wv & 3) * 8 + (lane >> 3);
+  const int pf_ld = wv < 4 ? ldx : ldg;
+  const unsigned pf_voff = (unsigned)((pf_line >> 2) * pf_ld) * 2u + (unsigned)((pf_line & 3) * 128 + (lane & 7) * 16);
+  const char* pf_base = wv < 4 ? (const char*)(X + (size_t)(mbeg + (((tt % ntn) * 8) & 31)) * ldx + c0)
+                               : (const char*)(G + (size_t)(mbeg + (((tt / ntn) * 8) & 31)) * ldg + n0);
+  const size_t pf_step = (size_t)pf_ld * 64;      // 32 rows
+  const unsigned pf_sink = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + RING + (unsigned)wv * 256u;
+  auto prefetch = [&](int pst) {
+    pst = pst < ns ? pst : ns - 1;
+    const char* sb = pf_base + (size_t)pst * pf_step;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" ::"s"(sb), "v"(pf_voff), "s"(pf_sink) : "memory", "m0");
   };
 
   f32x4_t acc[8][4];
@@ -904,14 +1000,71 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
         accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[2 * WK + 1], ones, accb[1], 0, 0, 0);
       }
     };
+    // HUGS_TN_SCHED == 4: an iteration in four fenced quarters of {1 LDS-DMA, 6 transpose reads, 8 MFMAs}.  With the four
+    // DMAs issued back to back behind the barrier, 8 waves push 32 KB into the CU's one vector-memory path at once and
+    // every wave sits in VMEM issue (no MFMA behind it can go: in-order issue) until the queue has drained.
+    auto stage_piece = [&](int st, int q) {
+      const int mrow0 = mbeg + (st << 5);
+      const unsigned l = lds0 + (unsigned)(st % NSLOT) * STAGE;
+      const int pair = (q >> 1) * 8 + wv;
+      if (q & 1) dma16((const char*)(G + (size_t)(mrow0 + 2 * pair) * ldg + n0), voG, l + XB + pair * PAIR);
+      else dma16((const char*)(X + (size_t)(mrow0 + 2 * pair) * ldx + c0), voX, l + pair * PAIR);
+    };
+    auto frags_piece = [&](Frags& f, int st, int q) {
+      const unsigned char* lx = lds + (st % NSLOT) * STAGE;
+      const unsigned char* lg = lx + XB;
+      const int lo = ((g >> 1) * 8 + (g & 1) * 4 + (s >> 2)) * PAIR + ((s & 3) << 3);
+#pragma unroll
+      for (int r = 6 * q; r < 6 * q + 6; ++r) {
+        const int h = r / 12, idx = r % 12;
+        if (idx < 8) {
+          bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4_t __attribute__((address_space(3)))*)(lg + lo + h * 512 + ((wn * 8 + idx) << 5)));
+          f.ga[idx][h * 4 + 0] = v[0]; f.ga[idx][h * 4 + 1] = v[1]; f.ga[idx][h * 4 + 2] = v[2]; f.ga[idx][h * 4 + 3] = v[3];
+        } else {
+          bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4_t __attribute__((address_space(3)))*)(lx + lo + h * 512 + ((wk * 4 + idx - 8) << 5)));
+          f.xb[idx - 8][h * 4 + 0] = v[0]; f.xb[idx - 8][h * 4 + 1] = v[1]; f.xb[idx - 8][h * 4 + 2] = v[2]; f.xb[idx - 8][h * 4 + 3] = v[3];
+        }
+      }
+    };
+    auto mfma_piece = [&](const Frags& f, int q) {
+#pragma unroll
+      for (int i = 2 * q; i < 2 * q + 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[i], f.xb[j], acc[i][j], 0, 0, 0);
+      if constexpr (WK >= 0) {
+        if (q == WK) {
+          accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[2 * WK], ones, accb[0], 0, 0, 0);
+          accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[2 * WK + 1], ones, accb[1], 0, 0, 0);
+        }
+      }
+    };
+#define GT_Q(cur, nxt, st, q, DOST)                                       \
+    if (DOST && !(HUGS_TN_EXP & 1)) stage_piece((st) + NSLOT, q);         \
+    if (!(HUGS_TN_EXP & 2)) frags_piece(nxt, (st) + 1, q);                \
+    else asm volatile("" : "+v"(nxt.ga[2 * q]), "+v"(nxt.ga[2 * q + 1]), "+v"(nxt.xb[q])); \
+    if (!(HUGS_TN_EXP & 4)) mfma_piece(cur, q);                           \
+    else asm volatile("" :: "v"(cur.ga[2 * q]), "v"(cur.ga[2 * q + 1]), "v"(cur.xb[q])); \
+    __builtin_amdgcn_sched_barrier(0);
+#define GT_ITER4(cur, nxt, st, VM, DOST)                                  \
+  {                                                                       \
+    if (HUGS_TN_EXP & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    else asm volatile("s_waitcnt vmcnt(" HUGS_STR(VM) ") lgkmcnt(0)" ::: "memory"); \
+    if (!(HUGS_TN_EXP & 32)) __builtin_amdgcn_s_barrier();                \
+    asm volatile("" ::: "memory");                                        \
+    GT_Q(cur, nxt, st, 0, DOST) GT_Q(cur, nxt, st, 1, DOST) GT_Q(cur, nxt, st, 2, DOST) GT_Q(cur, nxt, st, 3, DOST) \
+  }
 #define GT_ITER(cur, nxt, st, VM)                                         \
   {                                                                       \
-    asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");     \
+    asm volatile("s_waitcnt vmcnt(" HUGS_STR(VM) ") lgkmcnt(0)" ::: "memory"); \
     __builtin_amdgcn_s_barrier();                                         \
     asm volatile("" ::: "memory");                                        \
-    if ((st) + NSLOT < ns) stage((st) + NSLOT);                           \
-    load_frags(nxt, (st) + 1);                                            \
-    mfmas(cur);                                                           \
+    if (!(HUGS_TN_EXP & 1)) { if ((st) + NSLOT < ns) stage((st) + NSLOT); } \
+    if (HUGS_TN_PF) prefetch((st) + NSLOT + HUGS_TN_PF);                  \
+    if (!(HUGS_TN_EXP & 2)) load_frags(nxt, (st) + 1);                    \
+    else asm volatile("" : "+v"(nxt.ga[0]), "+v"(nxt.xb[0]));             \
+    if (!(HUGS_TN_EXP & 4)) mfmas(cur);                                   \
+    else { _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) asm volatile("" :: "v"(cur.ga[i_])); \
+           _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) asm volatile("" :: "v"(cur.xb[j_])); } \
     if (HUGS_TN_SCHED == 1) {                                             \
       _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                  \
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                \
@@ -931,21 +1084,44 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
       }                                                                   \
     }                                                                     \
   }
+    // steady state per wave and iteration: 4 stage loads, then 1 prefetch; the wait for stage st+1 leaves the 2 younger
+    // stages and 3 prefetches outstanding (11).  The prologue issues in the same pattern so that the count holds from st = 0.
+#if HUGS_TN_PF
+#define GT_VM 11
+    stage(0); stage(1); prefetch(NSLOT + HUGS_TN_PF - 3); stage(2); prefetch(NSLOT + HUGS_TN_PF - 2); stage(3);
+    prefetch(NSLOT + HUGS_TN_PF - 1);
+    asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+#else
+#define GT_VM 8
 #pragma unroll
     for (int q = 0; q < NSLOT; ++q) stage(q);
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+#endif
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     load_frags(f0, 0);
     int st = 0;
-    for (; st + 5 < ns; st += 2) { GT_ITER(f0, f1, st, 8) GT_ITER(f1, f0, st + 1, 8) }
-    GT_ITER(f0, f1, st, 8)
+#if HUGS_TN_EXP & 16
+    for (; st + 5 < ns; st += 2) { GT_ITER(f0, f1, st, 4) GT_ITER(f1, f0, st + 1, 4) }
+#elif HUGS_TN_SCHED == 4
+    for (; st + 5 < ns; st += 2) { GT_ITER4(f0, f1, st, 8, 1) GT_ITER4(f1, f0, st + 1, 8, 1) }
+#else
+    for (; st + 5 < ns; st += 2) { GT_ITER(f0, f1, st, GT_VM) GT_ITER(f1, f0, st + 1, GT_VM) }
+#endif
+#if HUGS_TN_SCHED == 4
+    GT_ITER4(f0, f1, st, 8, 0)
+#else
+    GT_ITER(f0, f1, st, GT_VM)
+#endif
     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
     load_frags(f0, st + 2); mfmas(f1);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
     load_frags(f1, st + 3); mfmas(f0);
     mfmas(f1);
 #undef GT_ITER
+#undef GT_ITER4
+#undef GT_Q
+#undef GT_VM
   };
   if (!do_colsum) run(std::integral_constant<int, -1>{});
   else if (wk == 0) run(std::integral_constant<int, 0>{});
