@@ -537,10 +537,18 @@ class Engine:
       Wv = lay.view(theta, (spec.name, lvw['name'], 'kernel'))
       d_rb = ws.get(tag + '/d_rb', (N, H))
       demb = gview(('GloEmbed_0', 'embedding')) if spec.num_glo > 0 else None
-      _lib.call('hugs_raybias_bwd', dt, N, S, H, spec.nd, spec.num_glo, Gv, H, rays['dir_enc'], lv['glo'], Wv[Bw:],
-                rays.get('embed_idx'), d_rb, gWv[Bw:], demb)
-      # dWv[:Bw] = bott^T Gv ; db_v = colsum(Gv)
-      self._tn(M, Bw, H, lv['bott'], Bw, Gv, H, gWv[:Bw], gview((spec.name, lvw['name'], 'bias')))
+      # Only Gv -> dBott -> G_last is on the way to the trunk backward.  The head weight gradients (view-layer ray-bias
+      # part + GLO rows, view dW, bottleneck dW: ~0.3 ms of reductions and skinny GEMMs) go to their own stream and run
+      # underneath the trunk GEMMs.
+      cur = torch.cuda.current_stream()
+      hl = self._side_stream(lane + 3)
+      ev_gv = torch.cuda.Event(); ev_gv.record(cur)
+      with torch.cuda.stream(hl):
+        hl.wait_event(ev_gv)
+        _lib.call('hugs_raybias_bwd', dt, N, S, H, spec.nd, spec.num_glo, Gv, H, rays['dir_enc'], lv['glo'], Wv[Bw:],
+                  rays.get('embed_idx'), d_rb, gWv[Bw:], demb)
+        # dWv[:Bw] = bott^T Gv ; db_v = colsum(Gv)
+        self._tn(M, Bw, H, lv['bott'], Bw, Gv, H, gWv[:Bw], gview((spec.name, lvw['name'], 'bias')))
       dB = ws.get(tag + '/dBott', (M, Bw), self.tdt)
       if nerfw is not None:
         G0t = self._transient_backward(theta, grad, lv, rays, N, d_dt, d_ct, d_u)
@@ -552,7 +560,15 @@ class Engine:
         # dBott = Gv Wv[:Bw]^T
         _lib.call('hugs_gemm_nt', dt, M, Bw, H, 0, Gv, H, None, 0, self.wn[(spec.name, lvw['name'], 'kernel')], H, None,
                   None, 1, 0, 0, None, 0, None, None, dB, Bw)
-      self._tn(M, W, Bw, Ylast, W, dB, Bw, gview((spec.name, lb['name'], 'kernel'), True), gview((spec.name, lb['name'], 'bias')))
+      ev_db = torch.cuda.Event(); ev_db.record(cur)
+      with torch.cuda.stream(hl):
+        hl.wait_event(ev_db)
+        self._tn(M, W, Bw, Ylast, W, dB, Bw, gview((spec.name, lb['name'], 'kernel'), True), gview((spec.name, lb['name'], 'bias')))
+        if leaf_done is not None:      # density / bottleneck / view / rgb (/ transient) layers: everything behind the trunk
+          first = lay.by_path[(spec.name, spec.layers[spec.net_depth]['name'], 'kernel')]
+          last = lay.by_path[(spec.name, spec.layers[-1]['name'], 'bias')]
+          leaf_done(first['off'], last['off'] + int(np.prod(last['pshape'])))
+        heads_done = torch.cuda.Event(); heads_done.record(hl)
       # G_last = (dBott Wb^T + d_raw (x) w_d) * (Ylast > 0)
       blast = lv['bits'][spec.net_depth - 1] if lv.get('bits') else None
       if blast is not None and Bw >= 256:
@@ -561,7 +577,7 @@ class Engine:
       else:
         _lib.call('hugs_gemm_nt', dt, M, W, Bw, 0, dB, Bw, None, 0, self.wn[(spec.name, lb['name'], 'kernel')], Bw, None, None,
                   1, 0, 0, Ylast, W, d_raw, wd, Ga, W)
-    if leaf_done is not None:      # density / bottleneck / view / rgb (/ transient) layers: everything behind the trunk
+    if spec.disable_rgb and leaf_done is not None:
       first = lay.by_path[(spec.name, spec.layers[spec.net_depth]['name'], 'kernel')]
       last = lay.by_path[(spec.name, spec.layers[-1]['name'], 'bias')]
       leaf_done(first['off'], last['off'] + int(np.prod(last['pshape'])))
@@ -569,12 +585,14 @@ class Engine:
     X0 = lv['X0']
     # Trunk backward on two HIP streams: the weight-gradient GEMM of layer i (side stream) and the dX GEMM that
     # produces G_{i-1} (main stream) only share the read of G_i, so they run concurrently and fill each other's
-    # tile-epilogue / launch-boundary bubbles.  Three G buffers rotate so dX never overwrites a buffer a pending
-    # dW still reads; the per-call fp32 slab workspace is double-buffered the same way.
+    # tile-epilogue / launch-boundary bubbles.  Four G buffers rotate so dX never overwrites a buffer a pending
+    # dW still reads AND never has to wait for the dW (+ its slab reduction) of the layer just above: with three, every
+    # layer boundary was a ~40 us bubble (dX_{i-1} waited for dW_i to release the buffer it writes).
     main = torch.cuda.current_stream()
     side = self._side_stream(lane)
     Gc = ws.get(tag + '/Gc', (M, W), self.tdt)
-    ring = [Ga, Gb, Gc]
+    Gd = ws.get(tag + '/Gd', (M, W), self.tdt)
+    ring = [Ga, Gb, Gc, Gd]
     gi = 0
     ev_g = torch.cuda.Event()
     ev_g.record(main)
@@ -599,7 +617,7 @@ class Engine:
           lk, lb_ = lay.by_path[path], lay.by_path[(spec.name, l['name'], 'bias')]
           leaf_done(lk['off'], lb_['off'] + int(np.prod(lb_['pshape'])))
       if i > 0:
-        nxt = (gi + 1) % 3
+        nxt = (gi + 1) % 4
         if nxt in tn_done:                           # the dW that last read this buffer must be finished
           main.wait_event(tn_done.pop(nxt))
         # G_{i-1} = (G_i W_i[:W]^T) * (Y_{i-1} > 0)
@@ -615,6 +633,8 @@ class Engine:
         G, gi = ring[nxt], nxt
     for e in tn_done.values():
       main.wait_event(e)
+    if not spec.disable_rgb:
+      main.wait_event(heads_done)
 
   def _transient_backward(self, theta, grad, lv, rays, N, d_dt, d_ct, d_u):
     """Backward of the NeRF-W transient branch (heads -> trunk -> per-ray tra_vec part).  Returns G at the first
