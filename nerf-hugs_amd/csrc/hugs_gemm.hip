@@ -227,7 +227,25 @@ typedef unsigned __attribute__((ext_vector_type(2))) u32x2_t;
 // columns wn*64..; lane (r16, kb) of fragment (i, j) holds row i*16 + r16, columns j*16 + kb*4 .. +3).
 // lds_bias / lds_r1col: optional LDS-resident copies of E.bias / E.r1_col (indexed by absolute column): the persistent
 // kernel keeps them there so that the epilogue issues no global load that would queue behind the prefetched stages.
-template <int EPI>
+// The epilogue is VALU-bound (two waves per SIMD walk 128 accumulator registers each: ~1300 vector instructions per wave
+// cost ~10k of a tile's ~50k cycles), so it is written for instruction count: the bias arrives inside the accumulators
+// when BIAS_IN_ACC (the persistent kernel initialises them with it), relu is one v_pk_max_i16 per bf16 PAIR after the
+// conversion (sign-magnitude bf16 read as int16: negative <=> sign bit; rounding commutes with the clamp), the 1-bit masks
+// are made / applied on the packed pairs (3-4 instructions per pair), terms that are absent are not added as zeros.
+typedef short __attribute__((ext_vector_type(2))) i16x2_t;
+__device__ __forceinline__ uint32_t pk_relu_bf16(uint32_t u) {
+  const i16x2_t z = {0, 0};
+  const i16x2_t r = __builtin_elementwise_max(*(const i16x2_t*)&u, z);
+  return *(const uint32_t*)&r;
+}
+typedef float __attribute__((ext_vector_type(2))) f32x2_t;
+typedef __bf16 __attribute__((ext_vector_type(2))) bf16x2_t;
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {      // one v_cvt_pk_bf16_f32
+  const f32x2_t f = {a, b};
+  const bf16x2_t h = __builtin_convertvector(f, bf16x2_t);
+  return *(const uint32_t*)&h;
+}
+template <int EPI, bool BIAS_IN_ACC = false>
 __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const GemmEpi& E, int m0, int n0, int wm, int wn,
                                                    int r16, int kb, const float* lds_bias, const float* lds_r1col) {
     // ---- epilogue straight from registers: bias / rank-1 / relu, v_cvt_pk_bf16_f32, one v_permlane16_swap pair
@@ -239,7 +257,8 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
     const bool has_mask = GEN ? E.mask != nullptr : bool(EPI & EPI_MASK);
     const bool has_r1 = GEN ? E.r1_row != nullptr : bool(EPI & EPI_R1);
     const bool has_rowb = GEN ? E.row_bias != nullptr : false;
-    // lane-private mask words (see GemmEpi): word = i >> 1, bit = (i & 1) * 16 + j * 4 + c
+    // lane-private mask words (see GemmEpi): word = i >> 1; packed bf16 pair k = (i & 1) * 8 + j * 2 + (c >> 1) of the word
+    // owns bit k (even c) and bit 16 + k (odd c)
     // layout [tile][wave][word 0..3][lane]: every word is one 256-byte wave store / load
     const size_t bits_at = (((size_t)(m0 >> 8) * (size_t)(E.ldc >> 8) + (size_t)(n0 >> 8)) * 8 + (size_t)(wm * 4 + wn)) * 256 + (size_t)(threadIdx.x & 63);
     const bool has_bin = GEN ? E.bits_in != nullptr : bool(EPI & EPI_BIN);
@@ -286,24 +305,24 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
       uint32_t pk[4][2];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float x[4] = {acc[i][j][0] + bj[j].x + r1 * cj[j].x, acc[i][j][1] + bj[j].y + r1 * cj[j].y,
-                      acc[i][j][2] + bj[j].z + r1 * cj[j].z, acc[i][j][3] + bj[j].w + r1 * cj[j].w};
+        float x[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        if (has_bias && !BIAS_IN_ACC) { x[0] += bj[j].x; x[1] += bj[j].y; x[2] += bj[j].z; x[3] += bj[j].w; }
+        if (has_r1) { x[0] += r1 * cj[j].x; x[1] += r1 * cj[j].y; x[2] += r1 * cj[j].z; x[3] += r1 * cj[j].w; }
         if (rbp) { const float4 b = *(const float4*)(rbp + j * 16); x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w; }
-        if (has_relu) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
-        if (has_bin) {
-          const uint32_t nib = bin[i >> 1] >> ((i & 1) * 16 + j * 4);
-          if (!(nib & 1u)) x[0] = 0.f;
-          if (!(nib & 2u)) x[1] = 0.f;
-          if (!(nib & 4u)) x[2] = 0.f;
-          if (!(nib & 8u)) x[3] = 0.f;
+        uint2 u;
+        u.x = cvt_pk_bf16(x[0], x[1]); u.y = cvt_pk_bf16(x[2], x[3]);
+        if (has_relu) { u.x = pk_relu_bf16(u.x); u.y = pk_relu_bf16(u.y); }
+        const int k = (i & 1) * 8 + j * 2;
+        if (has_bin) {      // 0x00010001 * 0xffff = 0xffffffff, 0x1 * 0xffff = low half, 0x10000 * 0xffff = high half
+          const uint32_t t = bin[i >> 1] >> k;
+          u.x &= (t & 0x00010001u) * 0xffffu;
+          u.y &= ((t >> 1) & 0x00010001u) * 0xffffu;
         }
-        bf16x4_t h;
-        h[0] = (__bf16)x[0]; h[1] = (__bf16)x[1]; h[2] = (__bf16)x[2]; h[3] = (__bf16)x[3];
-        const uint2 u = *(const uint2*)&h;
         pk[j][0] = u.x; pk[j][1] = u.y;
-        if (has_bout) {     // bf16 value > 0  <=>  magnitude bits non-zero (the relu already cleared the negatives)
-          const uint32_t nib = ((u.x & 0x7fffu) ? 1u : 0u) | ((u.x & 0x7fff0000u) ? 2u : 0u) | ((u.y & 0x7fffu) ? 4u : 0u) | ((u.y & 0x7fff0000u) ? 8u : 0u);
-          bw |= nib << ((i & 1) * 16 + j * 4);
+        if (has_bout) {     // value > 0 <=> half != 0 once the relu cleared the negatives: half + 0x7fff carries into bit 15
+          const uint32_t ax = has_relu ? u.x : (u.x & 0x7fff7fffu), ay = has_relu ? u.y : (u.y & 0x7fff7fffu);
+          bw |= ((ax + 0x7fff7fffu) >> (15 - k)) & (0x00010001u << k);
+          bw |= ((ay + 0x7fff7fffu) >> (14 - k)) & (0x00010001u << (k + 1));
         }
       }
       if (has_bout && (i & 1)) { E.bits_out[bits_at + (i >> 1) * 64] = bw; bw = 0u; }
@@ -314,14 +333,13 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
         const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(pk[2 * jp][1], pk[2 * jp + 1][1], false, false);
         vv[jp][0] = s0[0]; vv[jp][1] = s1[0]; vv[jp][2] = s0[1]; vv[jp][3] = s1[1];
       }
-      // low lanes give away their jp=1 chunk and receive the partner row's jp=0 chunk; high lanes the other way round
+      // low lanes give away their jp=1 chunk and receive the partner row's jp=0 chunk; high lanes the other way round:
+      // two bank-masked DPP moves (row_ror:8 reads lane (l + 8) % 16; bank_mask 0xc / 0x3 writes lanes 8-15 / 0-7 only)
       uint32_t sa[4], sb[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const uint32_t send = hi8 ? vv[0][q] : vv[1][q];
-        const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, 0x128, 0xf, 0xf, false);   // row_ror:8
-        sa[q] = hi8 ? recv : vv[0][q];      // store A: row srow
-        sb[q] = hi8 ? vv[1][q] : recv;      // store B: row srow + 8
+        sa[q] = (uint32_t)__builtin_amdgcn_update_dpp((int)vv[0][q], (int)vv[1][q], 0x128, 0xf, 0xc, false);   // store A: row srow
+        sb[q] = (uint32_t)__builtin_amdgcn_update_dpp((int)vv[1][q], (int)vv[0][q], 0x128, 0xf, 0x3, false);   // store B: row srow + 8
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -725,10 +743,19 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
   for (int i = 0; i < nmine; ++i, c_bid += G) {
     int m0, n0;
     { const int t = xcd_remap(c_bid, ntiles); m0 = (t / ntn) << 8; n0 = (t % ntn) << 8; }
+    if constexpr (EPI >= 0 && (EPI & EPI_BIAS) != 0) {      // the accumulators start from the bias (same for all 8 row blocks)
 #pragma unroll
-    for (int a = 0; a < 8; ++a)
+      for (int b = 0; b < 4; ++b) {
+        const float4 bb = *(const float4*)(lds_bias + n0 + wn * 64 + b * 16 + kb * 4);
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < 8; ++a) acc[a][b] = f32x4_t{bb.x, bb.y, bb.z, bb.w};
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
     HUGS_TRP(i, 0)
     // the previous tile's 16 stores (+ 4 mask-bit words) are in the queue behind the two younger stages
     if (EPI >= 0 && (EPI & EPI_BOUT)) { GP_ITER(f0, f1, 28) GP_ITER(f1, f0, 28) GP_ITER(f0, f1, 28) }
@@ -742,7 +769,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
     for (int st = 4; st < ns; st += 2) { GP_ITER(f0, f1, 8) GP_ITER(f1, f0, 8) }
 #endif
     HUGS_TRP(i, 2)
-    nt_epilogue_direct<EPI>(acc, E, m0, n0, wm, wn, r16, kb, lds_bias, lds_r1);
+    nt_epilogue_direct<EPI, (EPI >= 0 && (EPI & EPI_BIAS) != 0)>(acc, E, m0, n0, wm, wn, r16, kb, lds_bias, lds_r1);
     HUGS_TRP(i, 3)
   }
 #undef GP_ITER
