@@ -8,7 +8,15 @@ M, N, K = int(os.environ.get('M', 131072)), 1024, int(os.environ.get('K', 1024))
 A = torch.randn(M, K, device=dev).bfloat16(); Bt = (torch.randn(N, K, device=dev) / 32).bfloat16()
 bias = torch.zeros(N, device=dev); out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
 call = lambda: _lib.call('hugs_gemm_nt', 1, M, N, K, 0, A, K, None, 0, Bt, K, bias, None, 1, 0, 1, None, 0, None, None, out, N)
+cd = _lib.lib().cdll
+g, it = int(os.environ.get('SG', 0)), int(os.environ.get('SI', 0))
+if g: cd.hugs_debug_set_stagger(g, it)
 for _ in range(20): call()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize(); e0.record()
+for _ in range(20): call()
+e1.record(); torch.cuda.synchronize()
+print(f'SG={g} SI={it}: {e0.elapsed_time(e1)/20*1e3:.1f} us per launch')
 tr = torch.zeros(256 * 16 * 4, dtype=torch.int64, device=dev)
 cd = _lib.lib().cdll
 cd.hugs_debug_set_trace.argtypes = [ctypes.c_void_p]
