@@ -70,12 +70,12 @@ def instep_roofline(train_step, state, batch, gen, thr, steps=5):
   if os.path.exists(tpath):
     traffic = json.load(open(tpath))
 
-  def entry(key, label, flops, alg_bytes):
+  def entry(key, tkey, label, flops, alg_bytes):
     if key not in agg:
       return None
     us = float(np.mean(agg[key]))
     tf = flops / (us * 1e-6) / 1e12
-    t = traffic.get(label, {})
+    t = traffic.get(tkey, {})
     return {"bound": "mfma", "kernel": label, "launches": len(agg[key]), "avg_us": round(us, 1), "achieved": round(tf, 1),
             "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(tf * 1e12 / PEAK_BF16, 4),
             "traffic": t.get("hbm_bytes_per_launch"), "algorithmic_bytes": alg_bytes}
@@ -86,13 +86,13 @@ def instep_roofline(train_step, state, batch, gen, thr, steps=5):
   main = None
   if fwd:
     k = max(fwd, key=lambda k: len(agg[k]))
-    main = entry(k, f"NT forward trunk [{k[1]}x1024]x[1024x1024]^T +bias +relu (k_gemm_nt_bf16_pers<3>)", 2.0 * k[1] * W * W,
-                 2.0 * k[1] * W * 2 + W * W * 2)
+    main = entry(k, 'nt_fwd', f"NT forward trunk [{k[1]}x1024]x[1024x1024]^T +bias +relu, writes 1-bit relu masks "
+                 "(k_gemm_nt_bf16_pers<35>)", 2.0 * k[1] * W * W, 2.0 * k[1] * W * 2 + W * W * 2 + k[1] * W / 8)
   M = 131072
   fl = 2.0 * M * W * W
-  others = [entry(('nt', M, W, W, 'mask'), "NT masked dX [131072x1024]x[1024x1024] *(Y>0) (k_gemm_nt_bf16_pers<4>)", fl,
-                  3.0 * M * W * 2 + W * W * 2),
-            entry(('tn', M, W, W, 'split16'), "TN dW [1024x131072]x[131072x1024] + slab reduce (k_gemm_tn_bf16_big)", fl,
+  others = [entry(('nt', M, W, W, 'mask'), 'nt_dx', "NT dX [131072x1024]x[1024x1024] *relu-mask bits (k_gemm_nt_bf16_pers<16>)", fl,
+                  2.0 * M * W * 2 + W * W * 2 + M * W / 8),
+            entry(('tn', M, W, W, 'split16'), 'tn_dw', "TN dW [1024x131072]x[131072x1024] + slab reduce (k_gemm_tn_bf16_big)", fl,
                   2.0 * M * W * 2 + W * W * 4)]
   shapes = {f"{k[0]} M={k[1]} {k[2]}x{k[3]} {k[4]}": [len(v), round(float(np.mean(v)), 1)] for k, v in sorted(agg.items(), key=str)}
   return main, [o for o in others if o], shapes, state, gen

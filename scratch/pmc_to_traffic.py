@@ -1,0 +1,27 @@
+"""scratch: gpurun_out/pmc_<tag>.json (scratch/pmc_run2.sh) -> profiles/r02_gemm_traffic.json (what bench.py's roofline.traffic reads)
+and profiles/r02_gemm_pmc_raw.json."""
+import json, sys, shutil
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+d = json.load(open(f'gpurun_out/pmc_{tag}.json'))
+def find(sub):
+  ks = [k for k in d if sub in k]
+  assert len(ks) == 1, (sub, ks)
+  return d[ks[0]]
+def hbm(e, extra=()):
+  rd = 2 * e['FETCH_SIZE'] * 1024 + sum(2 * x['FETCH_SIZE'] * 1024 * x.get('per', 1) for x in extra)
+  wr = e['WRITE_SIZE'] * 1024 + sum(x['WRITE_SIZE'] * 1024 * x.get('per', 1) for x in extra)
+  return {"hbm_bytes_per_launch": rd + wr, "read": rd, "write": wr}
+red = dict(find('k_slab_reduce'), per=2)      # a TN call = the GEMM + two slab reductions (weights, bias)
+out = {
+  "nt_fwd": dict(hbm(find('pers<35>')), kernel='k_gemm_nt_bf16_pers<35>'),
+  "nt_dx": dict(hbm(find('pers<16>')), kernel='k_gemm_nt_bf16_pers<16>'),
+  "nt_fwd_nobits": dict(hbm(find('pers<3>')), kernel='k_gemm_nt_bf16_pers<3>'),
+  "nt_dx_bf16mask": dict(hbm(find('pers<4>')), kernel='k_gemm_nt_bf16_pers<4>'),
+  "tn_dw": dict(hbm(find('k_gemm_tn_bf16_big'), [red]), kernel='k_gemm_tn_bf16_big + 2 x k_slab_reduce'),
+  "_source": "scratch/pmc_run2.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 4 launches each, trunk shape "
+             "M=131072 N=K=1024); HBM bytes = 2 x FETCH_SIZE(KB) x 1024 (gfx950 64-B request correction, MI355X_MICROARCH.md) "
+             "+ WRITE_SIZE(KB) x 1024",
+}
+json.dump(out, open('profiles/r02_gemm_traffic.json', 'w'), indent=1)
+shutil.copy(f'gpurun_out/pmc_{tag}.json', 'profiles/r02_gemm_pmc_raw.json')
+print(json.dumps(out, indent=1))
