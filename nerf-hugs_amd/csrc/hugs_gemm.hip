@@ -1356,9 +1356,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_f32(int Mrows, int Kc, int N
 
 // sum fp32 slabs: out[i] = sum_s slab[s][i]   (fixed order: deterministic).  Eight slab loads are kept in flight
 // per thread; a 16-slab, 4 MB-per-slab reduction is an HBM stream, not a latency chain.
+// A second (small) range -- the bias-gradient slabs -- rides in the same launch: blocks past the first range's reduce it
+// (one kernel boundary less on the weight-gradient stream per layer).
 __global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ slab, int nsplit, size_t per,
-                                                     float* __restrict__ out) {
-  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+                                                     float* __restrict__ out, unsigned nblk1,
+                                                     const float* __restrict__ slab2, size_t per2, float* __restrict__ out2) {
+  unsigned blk = blockIdx.x;
+  if (blk >= nblk1) { blk -= nblk1; slab = slab2; per = per2; out = out2; }
+  const size_t i = ((size_t)blk * blockDim.x + threadIdx.x) * 4;
   if (i >= per) return;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   int s = 0;
@@ -1513,11 +1518,9 @@ extern "C" int hugs_gemm_tn(int dtype, int Mrows, int Kc, int N, int nsplit, con
                        ldx, (const float*)G, ldg, slab, N, cs);
   HUGS_CHECK_LAUNCH("hugs_gemm_tn");
   const size_t per = (size_t)Kc * N;
-  hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((per / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, slab, nsplit,
-                     per, dW);
-  if (dbias)
-    hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((N / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cs, nsplit,
-                       (size_t)N, dbias);
+  const unsigned nb1 = (unsigned)((per / 4 + 255) / 256), nb2 = dbias ? (unsigned)((N / 4 + 255) / 256) : 0u;
+  hipLaunchKernelGGL(k_slab_reduce, dim3(nb1 + nb2), dim3(256), 0, (hipStream_t)stream, slab, nsplit, per, dW, nb1,
+                     (const float*)cs, (size_t)N, dbias);
   HUGS_CHECK_LAUNCH("hugs_gemm_tn(reduce)");
   return 0;
 }

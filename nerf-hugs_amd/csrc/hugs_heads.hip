@@ -100,22 +100,23 @@ __global__ __launch_bounds__(256) void k_wcolsum(int M, int K, int rows_per_blk,
   }
 }
 
-// out[i] = sum_b slab[b*stride + i], i < width.  1024 threads = 64 columns x 16 row groups, fixed order.
+// out[i] = sum_b slab[b*stride + i], i < width; columns width .. width+width2-1 go to out2 (the bias gradient next to the
+// weight gradient: one launch).  1024 threads = 64 columns x 16 row groups, fixed order.
 __global__ __launch_bounds__(1024) void k_slab_reduce_small(const float* __restrict__ slab, int nblk, int width, int stride,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, int width2 = 0, float* __restrict__ out2 = nullptr) {
   __shared__ float red[16][65];
   const int cx = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + cx;
   float a = 0.f;
-  if (i < width)
+  if (i < width + width2)
     for (int b = rg; b < nblk; b += 16) a += slab[(size_t)b * stride + i];
   red[rg][cx] = a;
   __syncthreads();
-  if (rg == 0 && i < width) {
+  if (rg == 0 && i < width + width2) {
     float t = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) t += red[g][cx];
-    out[i] = t;
+    if (i < width) out[i] = t; else out2[i - width] = t;
   }
 }
 
@@ -303,8 +304,7 @@ extern "C" int hugs_density_bwd(int dtype, int M, int K, const void* Y, int ldy,
   float* slab = (float*)ws;
   if (dtype) hipLaunchKernelGGL(k_wcolsum<true>, dim3(nblk), dim3(256), 0, st, M, K, rpb, Y, ldy, d_raw, slab);
   else hipLaunchKernelGGL(k_wcolsum<false>, dim3(nblk), dim3(256), 0, st, M, K, rpb, Y, ldy, d_raw, slab);
-  hipLaunchKernelGGL(k_slab_reduce_small, dim3((K + 63) / 64), dim3(1024), 0, st, slab, nblk, K, K + 4, dw);
-  hipLaunchKernelGGL(k_slab_reduce_small, dim3(1), dim3(1024), 0, st, slab + K, nblk, 1, K + 4, db);
+  hipLaunchKernelGGL(k_slab_reduce_small, dim3((K + 1 + 63) / 64), dim3(1024), 0, st, slab, nblk, K, K + 4, dw, 1, db);
   HUGS_CHECK_LAUNCH("hugs_density_bwd");
   return 0;
 }
@@ -378,8 +378,7 @@ extern "C" int hugs_rgb_bwd(int dtype, int M, int H, const void* Hact, int ldh, 
   float* slab = (float*)ws;
   if (dtype) hipLaunchKernelGGL(k_rgb_bwd<true>, dim3(nblk), dim3(256), 0, st, M, H, rpb, Hact, ldh, W, rgb, d_rgb, pad, G, ldg, slab);
   else hipLaunchKernelGGL(k_rgb_bwd<false>, dim3(nblk), dim3(256), 0, st, M, H, rpb, Hact, ldh, W, rgb, d_rgb, pad, G, ldg, slab);
-  hipLaunchKernelGGL(k_slab_reduce_small, dim3(6), dim3(1024), 0, st, slab, nblk, 384, 388, dW);
-  hipLaunchKernelGGL(k_slab_reduce_small, dim3(1), dim3(1024), 0, st, slab + 384, nblk, 3, 388, db);
+  hipLaunchKernelGGL(k_slab_reduce_small, dim3(7), dim3(1024), 0, st, slab, nblk, 384, 388, dW, 3, db);
   HUGS_CHECK_LAUNCH("hugs_rgb_bwd");
   return 0;
 }
