@@ -11,7 +11,15 @@ Layout written / read:
 (optax.adam = chain(scale_by_adam, scale_by_schedule); tuples serialise as dicts with '0','1',... keys; mu / nu
 mirror TrainState.params, i.e. they carry the same outer 'params' level -- flax's restore_checkpoint(dir, state)
 matches field names against the target state, so a file without that level does not load in the reference).
-The reader accepts both forms."""
+The reader accepts both forms.
+
+Finetune stage (train.py:97-109 -> `<checkpoint_dir>/finetune`, train_utils.py:515-552: optax.multi_transform over
+{'trainable': adam, 'frozen': set_to_zero}):
+  'opt_state': {'inner_states': {'trainable': {'inner_state': {'0': {'count','mu','nu'}, '1': {'count'}}},
+                                 'frozen': {'inner_state': {}}}}
+where mu / nu hold arrays at the 'embedding' leaves and an EMPTY dict at every other leaf (optax's MaskedNode is a
+field-less NamedTuple; flax.serialization.to_state_dict of a NamedTuple is the dict of its fields).  optax is
+un-vendored and not installed: this restates its documented state classes, parity unpinned."""
 import os
 import re
 
@@ -54,8 +62,22 @@ def _tree_np(model, flat):
   return conv(dict(t))
 
 
+def _mask_tree(tree, keep):
+  """optax.masked over a parameter tree: leaves whose path fails `keep` become MaskedNode() == {} on the wire."""
+  def walk(d, path):
+    return {k: (walk(v, path + (k,)) if isinstance(v, dict) else (v if keep(path + (k,)) else {})) for k, v in d.items()}
+  return walk(tree, ())
+
+
 def state_dict(state):
   model = state.model
+  if getattr(state, 'hyper', {}).get('finetune'):      # finetune stage: optax.multi_transform state
+    keep = lambda path: 'embedding' in path
+    adam = {'0': {'count': np.int32(state.step), 'mu': _mask_tree(_tree_np(model, state.m), keep),
+                  'nu': _mask_tree(_tree_np(model, state.v), keep)},
+            '1': {'count': np.int32(state.step)}}
+    return {'step': np.int32(state.step), 'params': _tree_np(model, state.flat),
+            'opt_state': {'inner_states': {'trainable': {'inner_state': adam}, 'frozen': {'inner_state': {}}}}}
   return {'step': np.int32(state.step), 'params': _tree_np(model, state.flat),
           'opt_state': {'0': {'count': np.int32(state.step), 'mu': _tree_np(model, state.m),
                               'nu': _tree_np(model, state.v)},
@@ -92,9 +114,21 @@ def restore_checkpoint(ckpt_dir, state):
     d = from_bytes(f.read())
   model = state.model
   model.load_variables(state.flat, d['params'])
-  adam = d['opt_state']['0'] if '0' in d['opt_state'] else d['opt_state'][0]
-  model.load_variables(state.m, {'params': adam['mu'].get('params', adam['mu'])})
-  model.load_variables(state.v, {'params': adam['nu'].get('params', adam['nu'])})
+  opt = d['opt_state']
+  if 'inner_states' in opt:        # finetune stage: moments exist at the trainable (embedding) leaves only
+    adam = opt['inner_states']['trainable']['inner_state']['0']
+    for buf, tree in ((state.m, adam['mu']), (state.v, adam['nu'])):
+      tree = tree.get('params', tree)
+      for lf in model.layout.leaves:
+        leaf = tree
+        for k in lf['path']:
+          leaf = leaf[k]
+        if not isinstance(leaf, dict):
+          model.layout.view(buf, lf['path']).copy_(torch.from_numpy(np.array(leaf)).to(buf.device))
+  else:
+    adam = opt['0'] if '0' in opt else opt[0]
+    model.load_variables(state.m, {'params': adam['mu'].get('params', adam['mu'])})
+    model.load_variables(state.v, {'params': adam['nu'].get('params', adam['nu'])})
   state.step = int(np.asarray(d['step']))
   if getattr(model, '_engine', None) is not None:      # the compute-dtype weight copies follow the restored masters
     model._engine.refresh_weights(state.flat)

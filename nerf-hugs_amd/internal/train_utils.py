@@ -102,7 +102,7 @@ def create_finetune_optimizer(config, variables, model=None):
   tr = torch.tensor([1 if 'embedding' in lf['path'] else 0 for lf in model.layout.leaves], dtype=torch.int32,
                     device=variables.device)
   hyper = dict(lr_fn=lr_fn, b1=config.finetune_adam_beta1, b2=config.finetune_adam_beta2, eps=config.finetune_adam_eps,
-               trainable=tr)
+               trainable=tr, finetune=True)
   return TrainState(model, variables, hyper), lr_fn
 
 

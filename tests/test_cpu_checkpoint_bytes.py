@@ -144,3 +144,38 @@ def test_saved_checkpoint_decodes_with_an_independent_reader(tmp_path):
         a = a[k]
       assert a.dtype == np.float32 and a.shape == tuple(lf['shape'])
       assert np.array_equal(a, model.layout.view(buf, lf['path']).numpy())
+
+
+def test_finetune_stage_checkpoint_layout(tmp_path):
+  """train.py:97-109 checkpoints the finetune TrainState (optax.multi_transform: adam on 'embedding' leaves, set_to_zero
+  elsewhere) under <checkpoint_dir>/finetune: Adam moments only at the embedding leaves, MaskedNode() == {} elsewhere."""
+  from nerf_hugs_amd.internal import checkpoints, configs, train_utils
+  model, state = _model()
+  config = configs.make_config()
+  fstate, _ = train_utils.create_finetune_optimizer(config, state.flat, model)
+  fstate.m.normal_(); fstate.v.uniform_(); fstate.step = 9
+  path = checkpoints.save_checkpoint(str(tmp_path / 'finetune'), fstate, fstate.step)
+  d, end = dec(open(path, 'rb').read())
+  assert end == os.path.getsize(path)
+  inner = d['opt_state']['inner_states']
+  assert set(inner) == {'trainable', 'frozen'} and inner['frozen'] == {'inner_state': {}}
+  adam = inner['trainable']['inner_state']
+  assert set(adam) == {'0', '1'} and int(adam['0']['count']) == 9
+  for lf in model.layout.leaves:
+    a = adam['0']['mu']['params']
+    for k in lf['path']:
+      a = a[k]
+    if 'embedding' in lf['path']:
+      assert np.array_equal(a, model.layout.view(fstate.m, lf['path']).numpy())
+    else:
+      assert a == {}
+  # and back: moments of the embedding leaves are restored, frozen leaves keep what the fresh state holds (zeros)
+  fresh, _ = train_utils.create_finetune_optimizer(config, state.flat.clone(), model)
+  fresh = checkpoints.restore_checkpoint(str(tmp_path / 'finetune'), fresh)
+  assert fresh.step == 9
+  for lf in model.layout.leaves:
+    got = model.layout.view(fresh.v, lf['path'])
+    if 'embedding' in lf['path']:
+      assert torch.equal(got, model.layout.view(fstate.v, lf['path']))
+    else:
+      assert float(got.abs().max()) == 0.0
