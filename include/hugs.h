@@ -106,6 +106,11 @@ int hugs_data_loss(int N, int L, const float* pred, const float* gt, const float
 int hugs_robust_mask(int npatch, int P, const float* pred, const float* gt, const float* inlier_threshold,
                      float quantile, int filter_size, float smoothed_q, int inner_patch, float inner_q, float* mask,
                      float* err_ws, float* stats_part_ws, float* stats, void* stream);
+/* nerfacto/utils/loss_utils.py:88-150 get_robustnerf_mask as nerfacto/models/nerfacto.py:492-527 calls it: the same mask on
+ * squared residuals (errors = resid_sq). */
+int hugs_nf_robust_mask(int npatch, int P, const float* pred, const float* gt, const float* inlier_threshold,
+                     float quantile, int filter_size, float smoothed_q, int inner_patch, float inner_q, float* mask,
+                     float* err_ws, float* stats_part_ws, float* stats, void* stream);
 /* train_utils.py:228-239 interlevel_loss -> stepfun.py:30-86 (per-ray loss + d/d w_env) */
 int hugs_interlevel(int nrays, int S, int Sp, const float* t, const float* w, const float* t_env, const float* w_env,
                     float scale, float* loss_ray, float* d_w_env, void* stream);

@@ -29,6 +29,7 @@ _PROTOS = {
     'hugs_composite_bwd': 'iippppifpppps',
     'hugs_data_loss': 'iipppififppps',
     'hugs_robust_mask': 'iipppfififpppps',
+    'hugs_nf_robust_mask': 'iipppfififpppps',
     'hugs_interlevel': 'iiippppfpps',
     'hugs_distortion': 'iippfpps',
     'hugs_sum': 'ipfps',

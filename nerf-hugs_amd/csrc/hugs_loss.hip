@@ -71,14 +71,14 @@ __global__ __launch_bounds__(256) void k_robust_mask(int npatch, int P, const fl
                                                      const float* __restrict__ gt, const float* __restrict__ thr_ptr, int fsize,
                                                      float smoothed_q, int inner, float inner_q,
                                                      float* __restrict__ mask, float* __restrict__ err_out,
-                                                     float* __restrict__ stats_part) {
+                                                     float* __restrict__ stats_part, int squared) {
   __shared__ float s_inl[16][16];
   __shared__ float red[4];
   const int p = blockIdx.x, y = threadIdx.x / 16, x = threadIdx.x % 16;
   const size_t n = (size_t)p * P * P + y * P + x;
   float e = 0.f;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) e += fabsf(pred[n * 3 + c] - gt[n * 3 + c]);
+  for (int c = 0; c < 3; ++c) { const float d = pred[n * 3 + c] - gt[n * 3 + c]; e += squared ? d * d : fabsf(d); }
   e = e / 3.f;
   err_out[n] = e;
   const float inl = e < thr_ptr[0] ? 1.f : 0.f;
@@ -287,22 +287,36 @@ extern "C" int hugs_data_loss(int N, int L, const float* pred, const float* gt, 
 
 // pred/gt: [npatch*P*P, 3]. Outputs mask[n], err[n] (workspace), stats[5] = {next threshold (quantile of err),
 // mean is_inlier_loss, mean has_inlier_neighbors, mean is_inlier_patch, mean mask}; stats_part ws [npatch*4].
-extern "C" int hugs_robust_mask(int npatch, int P, const float* pred, const float* gt, const float* inlier_threshold /*device, [1]*/,
-                                float quantile, int filter_size, float smoothed_q, int inner_patch, float inner_q,
-                                float* mask, float* err_ws, float* stats_part_ws, float* stats, void* stream) {
+static int robust_mask_impl(int squared, int npatch, int P, const float* pred, const float* gt, const float* inlier_threshold,
+                            float quantile, int filter_size, float smoothed_q, int inner_patch, float inner_q,
+                            float* mask, float* err_ws, float* stats_part_ws, float* stats, void* stream) {
   HUGS_REQUIRE(P == 16, -5, "hugs_robust_mask: patch_size must be 16 (got %d)", P);
   const int n = npatch * P * P;
   HUGS_REQUIRE(n <= 32768, -3, "hugs_robust_mask: %d rays per device > 32768", n);
   if (n <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_robust_mask, dim3(npatch), dim3(256), 0, st, npatch, P, pred, gt, inlier_threshold, filter_size,
-                     smoothed_q, inner_patch, inner_q, mask, err_ws, stats_part_ws);
+                     smoothed_q, inner_patch, inner_q, mask, err_ws, stats_part_ws, squared);
   int np2 = 1;
   while (np2 < n) np2 <<= 1;
   hipLaunchKernelGGL(k_quantile_stats, dim3(1), dim3(1024), np2 * sizeof(float), st, n, err_ws, quantile, npatch,
                      stats_part_ws, stats);
   HUGS_CHECK_LAUNCH("hugs_robust_mask");
   return 0;
+}
+extern "C" int hugs_robust_mask(int npatch, int P, const float* pred, const float* gt, const float* inlier_threshold /*device, [1]*/,
+                                float quantile, int filter_size, float smoothed_q, int inner_patch, float inner_q,
+                                float* mask, float* err_ws, float* stats_part_ws, float* stats, void* stream) {
+  return robust_mask_impl(0, npatch, P, pred, gt, inlier_threshold, quantile, filter_size, smoothed_q, inner_patch, inner_q, mask,
+                          err_ws, stats_part_ws, stats, stream);
+}
+// nerfacto's get_robustnerf_mask (nerfacto/utils/loss_utils.py:88-150) is the same mask on SQUARED residuals
+// (models/nerfacto.py:505: errors = resid_sq.detach(); Mip-NeRF 360 passes |resid|).
+extern "C" int hugs_nf_robust_mask(int npatch, int P, const float* pred, const float* gt, const float* inlier_threshold,
+                                   float quantile, int filter_size, float smoothed_q, int inner_patch, float inner_q,
+                                   float* mask, float* err_ws, float* stats_part_ws, float* stats, void* stream) {
+  return robust_mask_impl(1, npatch, P, pred, gt, inlier_threshold, quantile, filter_size, smoothed_q, inner_patch, inner_q, mask,
+                          err_ws, stats_part_ws, stats, stream);
 }
 
 extern "C" int hugs_interlevel(int nrays, int S, int Sp, const float* t, const float* w, const float* t_env,

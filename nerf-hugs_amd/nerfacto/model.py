@@ -45,6 +45,9 @@ class NerfactoConfig:
     self.rgb_loss_type, self.rgb_charb_loss_padding, self.rgb_loss_mult = 'mse', 0.001, 1.0
     self.interlevel_loss_mult, self.distortion_loss_mult = 1.0, 0.002
     self.transient_type, self.withmask_transient_weight = None, 0.
+    self.robustnerf_inlier_quantile, self.robustnerf_smoothed_filter_size = 0.8, 3
+    self.robustnerf_smoothed_inlier_quantile, self.robustnerf_inner_patch_size = 0.5, 8
+    self.robustnerf_inner_patch_inlier_quantile, self.patch_size = 0.4, 16      # patch_size: train.py's config.patch_size
     self.rgb_bias = 0.
     # train.py / yml optimiser settings
     self.lr_init, self.lr_final, self.lr_decay_mult, self.warmup_steps, self.num_steps = 1e-2, 1e-3, 1e-8, 500, 25000
@@ -53,8 +56,10 @@ class NerfactoConfig:
       if not hasattr(self, k):
         raise ValueError(f'ModelConfig has no field {k!r}')
       setattr(self, k, v)
-    if self.transient_type not in (None, 'withmask'):
-      raise NotImplementedError(f"nerfacto transient_type {self.transient_type!r}: built are None and 'withmask'")
+    if self.transient_type not in (None, 'withmask', 'robustnerf'):
+      raise NotImplementedError(f"nerfacto transient_type {self.transient_type!r}: built are None, 'withmask' and 'robustnerf'")
+    if self.transient_type == 'robustnerf':
+      assert self.robustnerf_inner_patch_size <= self.patch_size, 'patch_size must be larger than robustnerf_inner_patch_size.'
     if self.proposal_initial_sampler not in ('uniform', 'piecewise', 'reciprocal'):
       raise ValueError(f'Sampler does not support {self.proposal_initial_sampler}. ')       # nerfacto.py:241
     if self.enable_scene_contraction and self.bound != 2.0:
@@ -318,9 +323,11 @@ class NerfactoModel:
     iv = int(np.clip(np.interp(curr_step, [0, c.proposal_warmup], [0, c.proposal_update_every]), 1, c.proposal_update_every))
     return (curr_step % iv) == 0
 
-  def train_step(self, batch, curr_step=None, u01=None, apply_update=True, world=1):
+  def train_step(self, batch, curr_step=None, u01=None, apply_update=True, world=1, inlier_threshold=None):
     """One optimisation step (train.py:196-215 + Loss.forward nerfacto.py:598-640).  batch: rays dict + 'rgb' [N,3]
-    (+ 'static_mask' [N] for transient_type='withmask').  Returns a dict of host-lazy device scalars."""
+    (+ 'static_mask' [N] for transient_type='withmask'; whole 16x16 patches, patch-major, for 'robustnerf', whose stats
+    slots 10..14 hold next inlier_threshold, is_inlier_loss, has_inlier_neighbors, is_inlier_patch, robust_mask).
+    Returns a dict of host-lazy device scalars."""
     c, ws, dt = self.cfg, self.ws, self.dt
     self.step += 1
     step = self.step if curr_step is None else curr_step
@@ -333,9 +340,26 @@ class NerfactoModel:
     # rgb loss (mean, or the static-mask weighted mean of compute_withmask_loss nerfacto.py:467-490)
     d_pred = ws.get('d_pred', (1, N, 3))
     mode, lm = (1, batch['static_mask']) if c.transient_type == 'withmask' else (0, None)
+    if c.transient_type == 'robustnerf':
+      # compute_robustnerf_loss (nerfacto.py:492-527): rays come in whole patch_size^2 patches (train.py:188-192); the
+      # inlier threshold is last step's quantile (extra_infos, 1.0 before the first step), fed back on the device
+      P = c.patch_size
+      if N % (P * P):
+        raise ValueError('robustnerf needs whole patches per device')
+      thr = inlier_threshold if inlier_threshold is not None else getattr(self, '_robust_thr', None)
+      if thr is None:
+        thr = torch.ones(1, device=self.device)
+      elif not torch.is_tensor(thr):
+        thr = torch.full((1,), float(thr), device=self.device)
+      rmask, rerr, rpart = ws.get('robust_mask', (1, N)), ws.get('robust_err', (N,)), ws.get('robust_part', (N // (P * P) * 4,))
+      L.call('hugs_nf_robust_mask', N // (P * P), P, fin['rgb_out'], batch['rgb'], thr, c.robustnerf_inlier_quantile,
+             c.robustnerf_smoothed_filter_size, c.robustnerf_smoothed_inlier_quantile, c.robustnerf_inner_patch_size,
+             c.robustnerf_inner_patch_inlier_quantile, rmask[0], rerr, rpart, stats[10:15])
+      self._robust_thr = stats[10:11].clone()
+      mode, lm = 2, rmask
     # hugs_data_loss' static-mask mode normalises by the [N,1] mask sum (Mip-NeRF 360's train_utils.py quirk); nerfacto's
     # compute_withmask_loss broadcasts the mask to the 3 channels first (nerfacto.py:481-483): a factor 3 in the denominator
-    chan = 3.0 if mode == 1 else 1.0
+    chan = 3.0 if mode == 1 else 1.0     # (the kernel's other modes already count the 3 channels)
     coef = ws.bufs.setdefault(('coef1', chan), torch.full((1,), float(c.rgb_loss_mult) / chan, device=self.device))
     L.call('hugs_data_loss', N, 1, fin['rgb_out'].reshape(1, N, 3), batch['rgb'], lm, mode, c.withmask_transient_weight,
            int(c.rgb_loss_type == 'charb'), c.rgb_charb_loss_padding, coef, d_pred, stats[0:2])

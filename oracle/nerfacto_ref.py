@@ -45,6 +45,9 @@ class Cfg:
     self.rgb_loss_type, self.rgb_charb_loss_padding, self.rgb_loss_mult = 'mse', 0.001, 1.0
     self.interlevel_loss_mult, self.distortion_loss_mult = 1.0, 0.002
     self.transient_type, self.withmask_transient_weight = None, 0.
+    self.robustnerf_inlier_quantile, self.robustnerf_smoothed_filter_size = 0.8, 3
+    self.robustnerf_smoothed_inlier_quantile, self.robustnerf_inner_patch_size = 0.5, 8
+    self.robustnerf_inner_patch_inlier_quantile, self.patch_size = 0.4, 16
     self.rgb_bias = 0.
     for k, v in kw.items():
       if not hasattr(self, k):
@@ -332,12 +335,49 @@ def forward_rays(cfg, P, rays, curr_step, u01):
   return out
 
 
-def loss_fn(cfg, out, gt_rgb, static_mask=None):
-  """Loss.forward (nerfacto.py:598-640) for transient_type None / 'withmask'."""
+def get_robustnerf_mask(cfg, errors, curr_threshold):
+  """utils/loss_utils.py:88-150.  errors [n, P, P, 3]; curr_threshold: extra_infos['inlier_threshold'] (1.0 before the
+  first step).  Returns (mask [n,P,P,1], info dict incl. the NEXT threshold)."""
+  eps = 1e-3
+  err = errors.mean(-1, keepdim=True)
+  P = err.shape[1]
+  assert cfg.robustnerf_inner_patch_size <= min(err.shape[1:3]), 'patch_size must be larger than robustnerf_inner_patch_size.'
+  info = {'inlier_threshold': torch.quantile(err, cfg.robustnerf_inlier_quantile)}
+  inl = (err < curr_threshold).to(err.dtype)
+  info['is_inlier_loss'] = inl.mean()
+  f = cfg.robustnerf_smoothed_filter_size
+  # F.conv2d(padding='same'): f-1 zeros in total per axis, (f-1)//2 in front, the rest behind
+  lo_, hi_ = (f - 1) // 2, f - 1 - (f - 1) // 2
+  nb = torch.nn.functional.conv2d(torch.nn.functional.pad(inl.permute(0, 3, 1, 2), (lo_, hi_, lo_, hi_)),
+                                  torch.ones(1, 1, f, f, dtype=err.dtype) / (f * f)).permute(0, 2, 3, 1)
+  nb = (nb > 1. - cfg.robustnerf_smoothed_inlier_quantile).to(err.dtype)
+  info['has_inlier_neighbors'] = nb.mean()
+  ip = cfg.robustnerf_inner_patch_size
+  h0, w0 = (err.shape[1] - ip) // 2, (err.shape[2] - ip) // 2
+  inner = torch.zeros_like(err)
+  inner[:, h0:h0 + ip, w0:w0 + ip, :] = 1
+  patch = (inl.mean(dim=(1, 2), keepdim=True) > 1. - cfg.robustnerf_inner_patch_inlier_quantile).to(err.dtype) * inner
+  info['is_inlier_patch'] = patch.mean()
+  mask = (patch + nb + inl > eps).to(err.dtype)
+  info['robust_mask'] = mask.mean()
+  return mask, info
+
+
+def loss_fn(cfg, out, gt_rgb, static_mask=None, inlier_threshold=1.0):
+  """Loss.forward (nerfacto.py:598-640) for transient_type None / 'withmask' / 'robustnerf' (rays in whole
+  cfg.patch_size^2 patches, patch-major, for the latter)."""
   resid_sq = (out['rgb'] - gt_rgb)**2
   dl = resid_sq if cfg.rgb_loss_type == 'mse' else torch.sqrt(resid_sq + cfg.rgb_charb_loss_padding**2)
   info = {}
-  if cfg.transient_type == 'withmask':
+  if cfg.transient_type == 'robustnerf':       # compute_robustnerf_loss nerfacto.py:492-527
+    P = cfg.patch_size
+    mask, rinfo = get_robustnerf_mask(cfg, resid_sq.detach().reshape(-1, P, P, 3), inlier_threshold)
+    info.update(rinfo)
+    lm = mask.reshape(-1, 1).expand_as(resid_sq)
+    den = lm.sum().clamp_min(torch.finfo(lm.dtype).eps)
+    rgb_loss = cfg.rgb_loss_mult * ((lm * dl).sum() / den)
+    info['mse'] = ((lm * resid_sq).sum() / den).detach()
+  elif cfg.transient_type == 'withmask':
     sm = (static_mask >= 0.5).to(gt_rgb.dtype)
     lm = (sm + (1 - sm) * cfg.withmask_transient_weight).expand_as(resid_sq)
     den = lm.sum().clamp_min(torch.finfo(lm.dtype).eps)

@@ -101,6 +101,20 @@ def main():
   steps = [0, 1, 100, 499, 500, 501, 10000, 24999, 25000, 30000]
   out['lr/steps'] = np.array(steps)
   out['lr/factor'] = np.array([sch.lr_lambdas[0](s) for s in steps])
+  # ---- get_robustnerf_mask (utils/loss_utils.py:88-150): default filter 3 and an even one, first step (no threshold in
+  # extra_infos -> 1.0) and a fed-back threshold; errors shaped so that every criterion fires somewhere ------------------------
+  for tag, f, q, thr in (('a', 3, 0.8, None), ('b', 3, 0.6, 0.02), ('c', 4, 0.8, 0.05), ('d', 5, 0.5, 0.004)):
+    errs = torch.rand(6, 16, 16, 3, generator=g)**4 * 0.3
+    errs[1] *= 0.02; errs[2, 4:12, 4:12] *= 0.01; errs[3] += 0.2
+    extra = {} if thr is None else {'inlier_threshold': thr}
+    mask, info, extra2 = loss_utils.get_robustnerf_mask(errors=errs, suffix=None, extra_infos=dict(extra), inlier_quantile=q,
+                                                        smoothed_filter_size=f, smoothed_inlier_quantile=0.5, inner_patch_size=8,
+                                                        inner_patch_inlier_quantile=0.4)
+    out[f'robust/{tag}/errors'], out[f'robust/{tag}/mask'] = T(errs), T(mask)
+    out[f'robust/{tag}/cfg'] = np.array([f, q, -1.0 if thr is None else thr])
+    out[f'robust/{tag}/info'] = np.array([float(info[k]) for k in ('inlier_threshold', 'is_inlier_loss', 'has_inlier_neighbors',
+                                                                    'is_inlier_patch', 'robust_mask')])
+    out[f'robust/{tag}/next_thr'] = np.float64(extra2['inlier_threshold'])
   np.savez_compressed(os.path.join(HERE, 'ref_nerfacto.npz'), **out)
   print('wrote ref_nerfacto.npz', len(out), 'arrays')
 

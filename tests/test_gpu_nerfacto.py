@@ -100,7 +100,7 @@ def _rays(N, seed):
               bg_rgb=torch.ones(N, 3), rgb=torch.rand(N, 3, generator=g)), g
 
 
-@pytest.mark.parametrize('variant', ['base', 'contract_piecewise_charb', 'withmask'])
+@pytest.mark.parametrize('variant', ['base', 'contract_piecewise_charb', 'withmask', 'robustnerf'])
 def test_model_forward_loss_and_gradients_vs_oracle(variant):
   from nerf_hugs_amd.nerfacto.model import NerfactoConfig, NerfactoModel
   from oracle import nerfacto_ref as NF
@@ -109,6 +109,8 @@ def test_model_forward_loss_and_gradients_vs_oracle(variant):
     kw.update(enable_scene_contraction=True, proposal_initial_sampler='piecewise', rgb_loss_type='charb', opaque_background=False)
   if variant == 'withmask':
     kw.update(transient_type='withmask', withmask_transient_weight=0.25)
+  if variant == 'robustnerf':
+    kw.update(transient_type='robustnerf', robustnerf_inlier_quantile=0.7, rgb_loss_type='charb')
   ocfg = NF.Cfg(**kw)
   P = NF.init_params(ocfg, 3)
   # tables at U(+-1e-4) make every field output ~bias: scale them up so that the grids matter in the comparison
@@ -117,8 +119,9 @@ def test_model_forward_loss_and_gradients_vs_oracle(variant):
       P[k]['table'] = P[k]['table'] * 3e3
   model = NerfactoModel(NerfactoConfig(**kw), compute_dtype='fp32')
   model.load_params(P)
-  N = 128
+  N = 256 if variant == 'robustnerf' else 128       # robustnerf: one whole 16x16 patch
   b, g = _rays(N, 5)
+  thr0 = 0.05                                        # current inlier threshold (extra_infos of the previous step)
   if variant == 'withmask':
     b['static_mask'] = (torch.rand(N, generator=g) < 0.7).float() * torch.rand(N, generator=g)
   u01 = [torch.rand(N, generator=g) for _ in range(3)]
@@ -128,10 +131,10 @@ def test_model_forward_loss_and_gradients_vs_oracle(variant):
       v.requires_grad_(True); leaves.append(v)
   orays = {k: (v[:, None] if v.dim() == 1 and k in ('near', 'far', 'embed_idx') else v) for k, v in b.items()}
   out = NF.forward_rays(ocfg, P, orays, 300, [u[:, None] for u in u01])
-  loss, info = NF.loss_fn(ocfg, out, b['rgb'], b.get('static_mask', torch.zeros(N))[:, None])
+  loss, info = NF.loss_fn(ocfg, out, b['rgb'], b.get('static_mask', torch.zeros(N))[:, None], thr0)
   loss.backward()
   gb = {k: v.to(dev) for k, v in b.items()}
-  res = model.train_step(gb, curr_step=300, u01=[u.to(dev) for u in u01], apply_update=False)
+  res = model.train_step(gb, curr_step=300, u01=[u.to(dev) for u in u01], apply_update=False, inlier_threshold=thr0)
   torch.cuda.synchronize()
   lv = res['levels']
   for l in range(3):
@@ -143,6 +146,11 @@ def test_model_forward_loss_and_gradients_vs_oracle(variant):
   assert abs(st[0] - float(info['mse'])) <= 2e-4 * float(info['mse'])
   assert abs(st[2] + st[3] - float(info['interlevel_loss'])) <= 1e-3 * float(info['interlevel_loss']) + 1e-9
   assert abs(st[8] - float(info['distortion_loss'])) <= 1e-3 * float(info['distortion_loss'])
+  if variant == 'robustnerf':
+    want = [float(info[k]) for k in ('inlier_threshold', 'is_inlier_loss', 'has_inlier_neighbors', 'is_inlier_patch', 'robust_mask')]
+    assert 0.05 < want[4] < 0.999, want            # the mask must actually select
+    np.testing.assert_allclose(st[10:15], want, rtol=2e-4, atol=1e-6)
+    assert abs(float(model._robust_thr) - want[0]) <= 2e-4 * want[0]     # fed back to the next step
   mg = model.grads()
   for name, grp in P.items():
     for k, v in (grp.items() if isinstance(grp, dict) else [(None, grp)]):
@@ -152,6 +160,25 @@ def test_model_forward_loss_and_gradients_vs_oracle(variant):
       assert sc > 0, (name, k)
       err = float((mine - ref).abs().max()) / sc
       assert err < 5e-3, f'{variant} grad {name}/{k}: rel err {err:.2e} (max |g| {sc:.2e})'
+
+
+@pytest.mark.parametrize('tag', ['a', 'b', 'c', 'd'])
+def test_robust_mask_kernel_vs_reference(z, tag):
+  """hugs_nf_robust_mask against the reference's get_robustnerf_mask (squared residuals; odd and even box filters)."""
+  from nerf_hugs_amd import _lib as L
+  f, q, thr = z[f'robust/{tag}/cfg']
+  errs = z[f'robust/{tag}/errors']                  # the kernel derives errors from pred - gt: gt = 0, pred = sqrt(errors)
+  n = errs.shape[0]
+  pred = G(np.sqrt(errs).reshape(-1, 3).astype(np.float32)); gt = torch.zeros_like(pred)
+  mask, err, part, st = (torch.empty(n * 256, device=dev), torch.empty(n * 256, device=dev), torch.empty(n * 4, device=dev),
+                         torch.empty(5, device=dev))
+  L.call('hugs_nf_robust_mask', n, 16, pred, gt, torch.full((1,), 1.0 if thr < 0 else float(thr), device=dev), float(q), int(f),
+         0.5, 8, 0.4, mask, err, part, st)
+  want = z[f'robust/{tag}/mask'].reshape(-1)
+  got = mask.cpu().numpy()
+  # sqrt then square moves an error by an ulp: a pixel exactly at the threshold may flip; none is in these vectors
+  assert np.array_equal(got, want), int((got != want).sum())
+  np.testing.assert_allclose(st.cpu().numpy(), z[f'robust/{tag}/info'], rtol=3e-6, atol=0)
 
 
 def test_bf16_training_reduces_the_loss_and_is_reproducible():

@@ -101,3 +101,15 @@ def test_forward_rays_runs_and_has_gradients():
       assert v.grad is not None and torch.isfinite(v.grad).all(), (name, k)
       if k != 'emb':
         assert float(v.grad.abs().max()) > 0, (name, k)
+
+
+@pytest.mark.parametrize('tag', ['a', 'b', 'c', 'd'])
+def test_robustnerf_mask(z, tag):
+  """utils/loss_utils.py:88-150 executed by the reference: odd and even box filters, first-step and fed-back threshold."""
+  f, q, thr = z[f'robust/{tag}/cfg']
+  cfg = NF.Cfg(transient_type='robustnerf', robustnerf_smoothed_filter_size=int(f), robustnerf_inlier_quantile=float(q))
+  mask, info = NF.get_robustnerf_mask(cfg, torch.from_numpy(z[f'robust/{tag}/errors']), 1.0 if thr < 0 else float(thr))
+  assert np.array_equal(mask.numpy(), z[f'robust/{tag}/mask'])
+  got = np.array([float(info[k]) for k in ('inlier_threshold', 'is_inlier_loss', 'has_inlier_neighbors', 'is_inlier_patch', 'robust_mask')])
+  np.testing.assert_allclose(got, z[f'robust/{tag}/info'], rtol=1e-6, atol=0)
+  assert abs(got[0] - float(z[f'robust/{tag}/next_thr'])) <= 1e-6 * got[0]
