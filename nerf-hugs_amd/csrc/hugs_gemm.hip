@@ -16,6 +16,15 @@
 #include "hugs_common.h"
 #include <type_traits>
 
+// (measurement knobs) stage loads a wave may leave outstanding at the top of an iteration: 8 = two stages, 4 = one
+#ifndef HUGS_TN_VM
+#define HUGS_TN_VM 8
+#endif
+#ifndef HUGS_NT_VM
+#define HUGS_NT_VM 8
+#endif
+#define HUGS_STR_(x) #x
+#define HUGS_STR(x) HUGS_STR_(x)
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
@@ -714,12 +723,21 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
 #ifndef HUGS_NT_SCHED
 #define HUGS_NT_SCHED 4
 #endif
-#define GP_Q(cur, nxt, q) issue_piece(q); frags_piece(nxt, q); mfma_piece(cur, q); __builtin_amdgcn_sched_barrier(0);
+#ifndef HUGS_NT_EXP     // measurement builds (results garbage): bit 0 no LDS-DMA, bit 1 no fragment reads, bit 2 no MFMAs in the steady-state loop
+#define HUGS_NT_EXP 0
+#endif
+#define GP_Q(cur, nxt, q)                                                                                   \
+    if (!(HUGS_NT_EXP & 1)) issue_piece(q);                                                                  \
+    if (!(HUGS_NT_EXP & 2)) frags_piece(nxt, q);                                                             \
+    else { asm volatile("" : "+v"(nxt.xa[2 * q]), "+v"(nxt.xa[2 * q + 1]), "+v"(nxt.wb[q])); if (q == 3) c_slot = (c_slot + 1) & 3; } \
+    if (!(HUGS_NT_EXP & 4)) mfma_piece(cur, q);                                                              \
+    else asm volatile("" :: "v"(cur.xa[2 * q]), "v"(cur.xa[2 * q + 1]), "v"(cur.wb[q]));                     \
+    __builtin_amdgcn_sched_barrier(0);
   // iteration for stage g: frags(g) are in `cur`; make stage g+1 visible, refill the slot of stage g with stage g+4,
   // start reading frags(g+1) into `nxt`, run the MFMAs of stage g.
 #define GP_ITERQ(cur, nxt, VM)                                                           \
   {                                                                                       \
-    asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");                     \
+    asm volatile("s_waitcnt vmcnt(" HUGS_STR(VM) ") lgkmcnt(0)" ::: "memory");            \
     __builtin_amdgcn_s_barrier();                                                         \
     asm volatile("" ::: "memory");                                                        \
     GP_Q(cur, nxt, 0) GP_Q(cur, nxt, 1) GP_Q(cur, nxt, 2) GP_Q(cur, nxt, 3)               \
@@ -771,7 +789,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
     HUGS_TRP(i, 1)
 #pragma unroll 1
 #if HUGS_NT_SCHED == 4
-    for (int st = 4; st < ns; st += 2) { GP_ITERQ(f0, f1, 8) GP_ITERQ(f1, f0, 8) }
+    for (int st = 4; st < ns; st += 2) { GP_ITERQ(f0, f1, HUGS_NT_VM) GP_ITERQ(f1, f0, HUGS_NT_VM) }
 #else
     for (int st = 4; st < ns; st += 2) { GP_ITER(f0, f1, 8) GP_ITER(f1, f0, 8) }
 #endif
@@ -910,8 +928,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(int Mrows, int Kc, int 
 // swizzle: fragment reads are base + immediate, which frees ~25 VGPRs and the XOR arithmetic).  The bias gradient (column sums of G) costs two
 // extra MFMAs per stage against an all-ones fragment instead of a scalar LDS pass.
 // ------------------------------------------------------------------------------------------------
-#define HUGS_STR_(x) #x
-#define HUGS_STR(x) HUGS_STR_(x)
 #ifndef HUGS_TN_SCHED
 #define HUGS_TN_SCHED 4
 #endif
@@ -1138,7 +1154,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
 #if HUGS_TN_EXP & 16
     for (; st + 5 < ns; st += 2) { GT_ITER(f0, f1, st, 4) GT_ITER(f1, f0, st + 1, 4) }
 #elif HUGS_TN_SCHED == 4
-    for (; st + 5 < ns; st += 2) { GT_ITER4(f0, f1, st, 8, 1) GT_ITER4(f1, f0, st + 1, 8, 1) }
+    for (; st + 5 < ns; st += 2) { GT_ITER4(f0, f1, st, HUGS_TN_VM, 1) GT_ITER4(f1, f0, st + 1, HUGS_TN_VM, 1) }
 #else
     for (; st + 5 < ns; st += 2) { GT_ITER(f0, f1, st, GT_VM) GT_ITER(f1, f0, st + 1, GT_VM) }
 #endif
