@@ -4,6 +4,7 @@
 // One thread per sample walks the levels: 8 trilinear corners x F features per level gathered from the fp32 table
 // (random 8-byte reads: L2 / HBM-latency bound, not a GEMM), the [n_levels*F] row written contiguously.
 // Backward scatters with fp32 atomics (as tiny-cuda-nn does with half2 atomics).
+#include <type_traits>
 #include "hugs_common.h"
 
 #define HG_MAXL 32
@@ -114,8 +115,35 @@ k_hashgrid_bwd(int n, int L, HgLevels lv, const float* __restrict__ x, const voi
     }
     const int nhead = __shfl_down(head, 1);
     const bool tail = live && (lane == 63 || nhead);      // the last lane of a run carries the run's sums
-    if (tail) {
-      float* tb = d_table + (size_t)lv.off[l] * F;
+    float* tb = d_table + (size_t)lv.off[l] * F;
+    if constexpr (F == 2) {
+      // The chip retires ~21 G atomic TRANSACTIONS per second, not atomics: neighbouring lanes of one instruction that hit
+      // neighbouring floats share a transaction (scratch/atomic_pair.hip: 21 / 42 / 84 / 335 G atomics/s for groups of
+      // 1 / 2 / 4 / 16 adjacent floats).  So a run's 16 adds are not issued by its tail lane alone: the four lanes of a quad
+      // serve the quad's four items one after the other, lane q adding feature (q & 1) of the corner with x-offset (q >> 1) --
+      // 8 adjacent bytes always, 16 when the x-neighbour entry is adjacent (dense levels; hashed levels when cx is even).
+      const int q = lane & 3, fq = q & 1, dxq = q >> 1;
+      auto serve = [&](auto subc) {
+        constexpr int CTL = decltype(subc)::value * 0x55;             // quad_perm: every lane reads lane `sub` of its quad
+        const int t_ = __builtin_amdgcn_mov_dpp(tail ? 1 : 0, CTL, 0xf, 0xf, true);
+        if (__ballot(t_) == 0ull) return;
+        const uint32_t bx = (uint32_t)__builtin_amdgcn_mov_dpp((int)cx, CTL, 0xf, 0xf, true);
+        const uint32_t by = (uint32_t)__builtin_amdgcn_mov_dpp((int)cy, CTL, 0xf, 0xf, true);
+        const uint32_t bz = (uint32_t)__builtin_amdgcn_mov_dpp((int)cz, CTL, 0xf, 0xf, true);
+#pragma unroll
+        for (int cb = 0; cb < 8; cb += 2) {
+          const float a0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[cb][0]), CTL, 0xf, 0xf, true));
+          const float a1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[cb][1]), CTL, 0xf, 0xf, true));
+          const float b0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[cb + 1][0]), CTL, 0xf, 0xf, true));
+          const float b1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[cb + 1][1]), CTL, 0xf, 0xf, true));
+          const float val = dxq ? (fq ? b1 : b0) : (fq ? a1 : a0);
+          const uint32_t idx = hg_index<F>(bx + dxq, by + ((cb >> 1) & 1), bz + ((cb >> 2) & 1), res, entries, dense);
+          if (t_) atomicAdd(tb + (size_t)idx * 2 + fq, val);
+        }
+      };
+      serve(std::integral_constant<int, 0>{}); serve(std::integral_constant<int, 1>{});
+      serve(std::integral_constant<int, 2>{}); serve(std::integral_constant<int, 3>{});
+    } else if (tail) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const uint32_t idx = hg_index<F>(cx + (c & 1), cy + ((c >> 1) & 1), cz + ((c >> 2) & 1), res, entries, dense);
