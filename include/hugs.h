@@ -111,6 +111,20 @@ int hugs_robust_mask(int npatch, int P, const float* pred, const float* gt, cons
 int hugs_nf_robust_mask(int npatch, int P, const float* pred, const float* gt, const float* inlier_threshold,
                      float quantile, int filter_size, float smoothed_q, int inner_patch, float inner_q, float* mask,
                      float* err_ws, float* stats_part_ws, float* stats, void* stream);
+/* Fused proposal network (nerfacto/models/nerfacto.py:927-990 HashMLPDensityField with Linear layers; the reference's
+ * tcnn FullyFusedMLP form): density = trunc_exp(relu(X W0 + b0) w1 + b1) * selector for in_dim <= 32, hidden <= 64, one
+ * thread per sample, fp32 weights read from the masters (W0 [in_dim, ldw0], w1 = column 0 of a [hidden, ldw1] matrix).
+ * X [M, ldx] in `dtype` (ldx >= 16 / 32, multiple of 8; columns >= in_dim ignored).  fwd writes raw [M] and density [M];
+ * bwd takes d_density and writes dX [M, ldx] and (=, deterministic slab reduction) the four weight-gradient leaves; ws:
+ * hugs_nf_prop_ws_bytes(in_dim). */
+long long hugs_nf_prop_ws_bytes(int in_dim);
+int hugs_nf_prop_fwd(long long M, int in_dim, int hidden, int dtype, const void* X, int ldx, const float* W0, int ldw0,
+                     const float* b0, const float* w1, int ldw1, const float* b1, const float* sel, float* raw,
+                     float* density, void* stream);
+int hugs_nf_prop_bwd(long long M, int in_dim, int hidden, int dtype, const void* X, int ldx, const float* W0, int ldw0,
+                     const float* b0, const float* w1, int ldw1, const float* raw, const float* sel,
+                     const float* d_density, void* dX, float* gW0, float* gb0, float* gw1, float* gb1, void* ws,
+                     void* stream);
 /* train_utils.py:228-239 interlevel_loss -> stepfun.py:30-86 (per-ray loss + d/d w_env) */
 int hugs_interlevel(int nrays, int S, int Sp, const float* t, const float* w, const float* t_env, const float* w_env,
                     float scale, float* loss_ray, float* d_w_env, void* stream);

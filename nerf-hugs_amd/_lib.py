@@ -30,6 +30,8 @@ _PROTOS = {
     'hugs_data_loss': 'iipppififppps',
     'hugs_robust_mask': 'iipppfififpppps',
     'hugs_nf_robust_mask': 'iipppfififpppps',
+    'hugs_nf_prop_fwd': 'qiii' 'pipi' 'ppi' 'pppp' 's',
+    'hugs_nf_prop_bwd': 'qiii' 'pipi' 'ppi' 'ppp' 'p' 'pppp' 'p' 's',
     'hugs_interlevel': 'iiippppfpps',
     'hugs_distortion': 'iippfpps',
     'hugs_sum': 'ipfps',
@@ -108,7 +110,7 @@ class _Lib:
           'There is no CPU fallback.')
     self.cdll = ctypes.CDLL(LIB_PATH)
     self.cdll.hugs_last_error.restype = ctypes.c_char_p
-    for n_ in ('hugs_gemm_tn_ws_bytes', 'hugs_density_bwd_ws_bytes', 'hugs_rgb_bwd_ws_bytes', 'hugs_ssim_ws_bytes', 'hugs_gemm_nt_bits_bytes'):
+    for n_ in ('hugs_gemm_tn_ws_bytes', 'hugs_density_bwd_ws_bytes', 'hugs_rgb_bwd_ws_bytes', 'hugs_ssim_ws_bytes', 'hugs_gemm_nt_bits_bytes', 'hugs_nf_prop_ws_bytes'):
       getattr(self.cdll, n_).restype = ctypes.c_longlong
     for name, sig in _PROTOS.items():
       fn = getattr(self.cdll, name)

@@ -463,6 +463,276 @@ extern "C" int hugs_nf_rgb_grad(long long M, int dtype, const float* rgb, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused proposal network (models/nerfacto.py:927-990 HashMLPDensityField: hash-grid features -> Linear -> ReLU -> Linear(1)
+// -> trunc_exp, times the selector).  The reference runs it as a tiny-cuda-nn fully fused MLP; as two 128-padded GEMMs a
+// 10 -> 64 -> 1 net moved ~4 KB per sample through HBM in a training step (8.4 M samples at the first proposal level).
+// Here one thread owns one sample: features in registers (KP = padded input width), the hidden layer in 64 registers, fp32
+// weights broadcast from LDS; nothing but the features, the raw density and the feature gradient touches memory.
+// Weight gradients: a sum over samples per (k, n) -- each wave turns its 64 x 64 block of hidden gradients around through
+// LDS so that lane n owns hidden unit n and walks the 64 samples (features broadcast from LDS), keeping dW0[:, n], db0[n],
+// dw1[n] in registers for the whole kernel; workgroup partials go to a slab and are summed in a fixed order.
+// ------------------------------------------------------------------------------------------------
+#define PM_H 64
+__host__ __device__ __forceinline__ constexpr int pm_slab_width(int KP) { return KP * PM_H + 2 * PM_H + 4; }
+
+template <bool BF16, int KP>
+__device__ __forceinline__ void pm_load_x(const void* X, long long m, int ldx, float (&x)[KP]) {
+  if (BF16) {
+#pragma unroll
+    for (int c = 0; c < KP / 8; ++c) {
+      const uint4 u = *(const uint4*)((const uint16_t*)X + (size_t)m * ldx + c * 8);
+      const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { x[c * 8 + 2 * q] = __uint_as_float(w[q] << 16); x[c * 8 + 2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u); }
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < KP / 4; ++c) {
+      const float4 u = *(const float4*)((const float*)X + (size_t)m * ldx + c * 4);
+      x[c * 4] = u.x; x[c * 4 + 1] = u.y; x[c * 4 + 2] = u.z; x[c * 4 + 3] = u.w;
+    }
+  }
+}
+
+template <int KP>
+__device__ __forceinline__ void pm_hidden(const float (&x)[KP], const float* sW0, const float* sb0, float (&h)[PM_H]) {
+#pragma unroll
+  for (int n = 0; n < PM_H; n += 4) { const float4 b = *(const float4*)(sb0 + n); h[n] = b.x; h[n + 1] = b.y; h[n + 2] = b.z; h[n + 3] = b.w; }
+#pragma unroll
+  for (int k = 0; k < KP; ++k)
+#pragma unroll
+    for (int n = 0; n < PM_H; n += 4) {
+      const float4 w = *(const float4*)(sW0 + k * PM_H + n);
+      h[n] = fmaf(x[k], w.x, h[n]); h[n + 1] = fmaf(x[k], w.y, h[n + 1]); h[n + 2] = fmaf(x[k], w.z, h[n + 2]); h[n + 3] = fmaf(x[k], w.w, h[n + 3]);
+      if ((n & 15) == 12) __builtin_amdgcn_sched_barrier(0);      // keep the scheduler from hoisting all 16 * KP weight reads (spills)
+    }
+}
+
+template <int KP>
+__device__ __forceinline__ void pm_stage_weights(int in_dim, int H, const float* W0, int ldw0, const float* b0, const float* w1, int ldw1,
+                                                 float* sW0, float* sb0, float* sw1) {
+  for (int e = threadIdx.x; e < KP * PM_H; e += blockDim.x) {
+    const int k = e / PM_H, n = e % PM_H;
+    sW0[e] = (k < in_dim && n < H) ? W0[(size_t)k * ldw0 + n] : 0.f;
+  }
+  if (threadIdx.x < PM_H) {
+    const int n = threadIdx.x;
+    sb0[n] = n < H ? b0[n] : 0.f;
+    sw1[n] = n < H ? w1[(size_t)n * ldw1] : 0.f;
+  }
+}
+
+template <bool BF16, int KP>
+__global__ __launch_bounds__(256) void k_nf_prop_fwd(long long M, int in_dim, int H, const void* __restrict__ X, int ldx,
+                                                     const float* __restrict__ W0, int ldw0, const float* __restrict__ b0,
+                                                     const float* __restrict__ w1, int ldw1, const float* __restrict__ b1,
+                                                     const float* __restrict__ sel, float* __restrict__ raw, float* __restrict__ density) {
+  __shared__ __attribute__((aligned(16))) float sW0[KP * PM_H];
+  __shared__ __attribute__((aligned(16))) float sb0[PM_H];
+  __shared__ __attribute__((aligned(16))) float sw1[PM_H];
+  pm_stage_weights<KP>(in_dim, H, W0, ldw0, b0, w1, ldw1, sW0, sb0, sw1);
+  __syncthreads();
+  const float b1v = b1[0];
+  for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long long)gridDim.x * 256) {
+    float x[KP], h[PM_H];
+    pm_load_x<BF16, KP>(X, m, ldx, x);
+    pm_hidden<KP>(x, sW0, sb0, h);
+    float o = b1v;
+#pragma unroll
+    for (int n = 0; n < PM_H; n += 4) {
+      const float4 w = *(const float4*)(sw1 + n);
+      o = fmaf(fmaxf(h[n], 0.f), w.x, o); o = fmaf(fmaxf(h[n + 1], 0.f), w.y, o);
+      o = fmaf(fmaxf(h[n + 2], 0.f), w.z, o); o = fmaf(fmaxf(h[n + 3], 0.f), w.w, o);
+    }
+    raw[m] = o;
+    density[m] = expf(o) * sel[m];               // custom_functions.py:38-44 trunc_exp forward, nerfacto.py:984-988 selector
+  }
+}
+
+template <bool BF16, int KP>
+__global__ __launch_bounds__(256) void k_nf_prop_bwd(long long M, int in_dim, int H, const void* __restrict__ X, int ldx,
+                                                     const float* __restrict__ W0, int ldw0, const float* __restrict__ b0,
+                                                     const float* __restrict__ w1, int ldw1, const float* __restrict__ raw,
+                                                     const float* __restrict__ sel, const float* __restrict__ d_density,
+                                                     void* __restrict__ dX, float* __restrict__ slab) {
+  // Loops over the hidden units run in chunks of four with the per-sample hidden values parked in LDS (T[n][sample], pitch 65:
+  // conflict-free by sample and by unit); only x, dx and the lane-n accumulators live in registers (the fully unrolled
+  // 64-register form of the forward kernel spilled here).
+  constexpr int TP = 65;
+  __shared__ __attribute__((aligned(16))) float sW0[KP * PM_H];
+  __shared__ __attribute__((aligned(16))) float sb0[PM_H];
+  __shared__ __attribute__((aligned(16))) float sw1[PM_H];
+  __shared__ float sT[4][PM_H * TP];
+  __shared__ __attribute__((aligned(16))) float sX[4][64 * KP];
+  __shared__ __attribute__((aligned(16))) float sR[4][64];
+  pm_stage_weights<KP>(in_dim, H, W0, ldw0, b0, w1, ldw1, sW0, sb0, sw1);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* T = sT[wv];
+  float* xs = sX[wv];
+  float* rs = sR[wv];
+  float aW0[KP];                                  // lane n: dW0[k][n]
+#pragma unroll
+  for (int k = 0; k < KP; ++k) aW0[k] = 0.f;
+  float ab0 = 0.f, aw1 = 0.f, ab1 = 0.f;
+  const float w1n = sw1[lane];
+  const long long ntile = (M + 255) / 256;
+#define PM_WAVE_SYNC() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+  for (long long t = blockIdx.x; t < ntile; t += gridDim.x) {
+    const long long m = t * 256 + threadIdx.x;
+    const bool valid = m < M;
+    const long long mm = valid ? m : M - 1;
+    float x[KP];
+    pm_load_x<BF16, KP>(X, mm, ldx, x);
+    // d raw = d density * exp(clamp(raw, -15, 15)) * selector (custom_functions.py:46-50)
+    const float r = valid ? d_density[mm] * expf(fminf(fmaxf(raw[mm], -15.f), 15.f)) * sel[mm] : 0.f;
+    ab1 += r;
+    rs[lane] = r;
+#pragma unroll
+    for (int k = 0; k < KP; k += 4) *(float4*)(xs + lane * KP + k) = make_float4(x[k], x[k + 1], x[k + 2], x[k + 3]);
+    // ---- hidden pre-activations of this lane's sample -> T[n][lane] ----
+#pragma unroll 1
+    for (int n = 0; n < PM_H; n += 4) {
+      float4 h = *(const float4*)(sb0 + n);
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        const float4 w = *(const float4*)(sW0 + k * PM_H + n);
+        h.x = fmaf(x[k], w.x, h.x); h.y = fmaf(x[k], w.y, h.y); h.z = fmaf(x[k], w.z, h.z); h.w = fmaf(x[k], w.w, h.w);
+      }
+      T[n * TP + lane] = h.x; T[(n + 1) * TP + lane] = h.y; T[(n + 2) * TP + lane] = h.z; T[(n + 3) * TP + lane] = h.w;
+    }
+    // ---- feature gradient of this lane's sample: dx[k] = sum_n W0[k][n] dh[n], dh[n] = (h[n] > 0) r w1[n] ----
+    float dx[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) dx[k] = 0.f;
+#pragma unroll 1
+    for (int n = 0; n < PM_H; n += 4) {
+      const float4 wv1 = *(const float4*)(sw1 + n);
+      const float d0 = T[n * TP + lane] > 0.f ? r * wv1.x : 0.f, d1 = T[(n + 1) * TP + lane] > 0.f ? r * wv1.y : 0.f;
+      const float d2 = T[(n + 2) * TP + lane] > 0.f ? r * wv1.z : 0.f, d3 = T[(n + 3) * TP + lane] > 0.f ? r * wv1.w : 0.f;
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        const float4 w = *(const float4*)(sW0 + k * PM_H + n);
+        dx[k] = fmaf(w.x, d0, dx[k]); dx[k] = fmaf(w.y, d1, dx[k]); dx[k] = fmaf(w.z, d2, dx[k]); dx[k] = fmaf(w.w, d3, dx[k]);
+      }
+    }
+    if (valid) {
+      if (BF16) {
+#pragma unroll
+        for (int c = 0; c < KP / 8; ++c) {
+          uint4 u;
+          u.x = f_to_bf16(dx[c * 8]) | ((uint32_t)f_to_bf16(dx[c * 8 + 1]) << 16); u.y = f_to_bf16(dx[c * 8 + 2]) | ((uint32_t)f_to_bf16(dx[c * 8 + 3]) << 16);
+          u.z = f_to_bf16(dx[c * 8 + 4]) | ((uint32_t)f_to_bf16(dx[c * 8 + 5]) << 16); u.w = f_to_bf16(dx[c * 8 + 6]) | ((uint32_t)f_to_bf16(dx[c * 8 + 7]) << 16);
+          *(uint4*)((uint16_t*)dX + (size_t)m * ldx + c * 8) = u;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < KP / 4; ++c) *(float4*)((float*)dX + (size_t)m * ldx + c * 4) = make_float4(dx[c * 4], dx[c * 4 + 1], dx[c * 4 + 2], dx[c * 4 + 3]);
+      }
+    }
+    PM_WAVE_SYNC()
+    // ---- lane n walks the 64 samples: dw1[n] += relu(h) r, db0[n] += dh, dW0[k][n] += x[k] dh ----
+#pragma unroll 2
+    for (int s_ = 0; s_ < 64; ++s_) {
+      const float hv = T[lane * TP + s_], rr = rs[s_];
+      aw1 = fmaf(fmaxf(hv, 0.f), rr, aw1);
+      const float d = hv > 0.f ? rr * w1n : 0.f;
+      ab0 += d;
+#pragma unroll
+      for (int k = 0; k < KP; k += 4) {
+        const float4 xv = *(const float4*)(xs + s_ * KP + k);
+        aW0[k] = fmaf(xv.x, d, aW0[k]); aW0[k + 1] = fmaf(xv.y, d, aW0[k + 1]); aW0[k + 2] = fmaf(xv.z, d, aW0[k + 2]); aW0[k + 3] = fmaf(xv.w, d, aW0[k + 3]);
+      }
+    }
+    PM_WAVE_SYNC()
+  }
+#undef PM_WAVE_SYNC
+  // ---- workgroup partials -> slab row (waves summed in a fixed order) ----
+  __syncthreads();
+  float* red = &sT[0][0];                         // [4][KP + 3][64]
+#pragma unroll
+  for (int k = 0; k < KP; ++k) red[(wv * (KP + 3) + k) * 64 + lane] = aW0[k];
+  red[(wv * (KP + 3) + KP) * 64 + lane] = ab0;
+  red[(wv * (KP + 3) + KP + 1) * 64 + lane] = aw1;
+  red[(wv * (KP + 3) + KP + 2) * 64 + lane] = ab1;
+  __syncthreads();
+  float* row = slab + (size_t)blockIdx.x * pm_slab_width(KP);
+  for (int e = threadIdx.x; e < (KP + 2) * 64; e += 256) {
+    const int k = e >> 6, n = e & 63;
+    row[e] = red[(0 * (KP + 3) + k) * 64 + n] + red[(1 * (KP + 3) + k) * 64 + n] + red[(2 * (KP + 3) + k) * 64 + n] + red[(3 * (KP + 3) + k) * 64 + n];
+  }
+  if (threadIdx.x == 0) {
+    float b = 0.f;
+    for (int w_ = 0; w_ < 4; ++w_)
+      for (int l = 0; l < 64; ++l) b += red[(w_ * (KP + 3) + KP + 2) * 64 + l];
+    row[(KP + 2) * 64] = b;
+  }
+}
+
+// slab [nblk][width] -> the four gradient leaves (fixed summation order over the workgroups)
+__global__ __launch_bounds__(256) void k_nf_prop_reduce(const float* __restrict__ slab, int nblk, int KP, int in_dim, int H,
+                                                        float* __restrict__ gW0, int ldw0, float* __restrict__ gb0,
+                                                        float* __restrict__ gw1, int ldw1, float* __restrict__ gb1) {
+  const int width = pm_slab_width(KP);
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  __shared__ float red[4][64];
+  float a = 0.f;
+  if (e < width)
+    for (int b = part; b < nblk; b += 4) a += slab[(size_t)b * width + e];
+  red[part][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (part != 0 || e >= width) return;
+  a = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  const int k = e >> 6, n = e & 63;
+  if (k < KP) { if (k < in_dim && n < H) gW0[(size_t)k * ldw0 + n] = a; }
+  else if (k == KP) { if (n < H) gb0[n] = a; }
+  else if (k == KP + 1) { if (n < H) gw1[(size_t)n * ldw1] = a; }
+  else if (e == (KP + 2) * 64) gb1[0] = a;
+}
+
+extern "C" long long hugs_nf_prop_ws_bytes(int in_dim) {
+  const int KP = in_dim <= 16 ? 16 : 32;
+  return (long long)1024 * pm_slab_width(KP) * 4;
+}
+extern "C" int hugs_nf_prop_fwd(long long M, int in_dim, int hidden, int dtype, const void* X, int ldx, const float* W0, int ldw0,
+                                const float* b0, const float* w1, int ldw1, const float* b1, const float* sel, float* raw,
+                                float* density, void* stream) {
+  HUGS_REQUIRE(in_dim >= 1 && in_dim <= 32 && hidden >= 1 && hidden <= PM_H, -3, "hugs_nf_prop_fwd: %d -> %d -> 1 unsupported (<= 32, <= 64)", in_dim, hidden);
+  const int KP = in_dim <= 16 ? 16 : 32;
+  HUGS_REQUIRE(ldx >= KP && ldx % 8 == 0, -3, "hugs_nf_prop_fwd: feature pitch %d (needs >= %d, multiple of 8)", ldx, KP);
+  if (M <= 0) return 0;
+  const int grid = (int)((M + 255) / 256 < 2048 ? (M + 255) / 256 : 2048);
+  hipStream_t st = (hipStream_t)stream;
+#define PM_FWD(B, K) hipLaunchKernelGGL((k_nf_prop_fwd<B, K>), dim3(grid), dim3(256), 0, st, M, in_dim, hidden, X, ldx, W0, ldw0, b0, w1, ldw1, b1, sel, raw, density)
+  if (dtype) { if (KP == 16) PM_FWD(true, 16); else PM_FWD(true, 32); }
+  else { if (KP == 16) PM_FWD(false, 16); else PM_FWD(false, 32); }
+#undef PM_FWD
+  HUGS_CHECK_LAUNCH("hugs_nf_prop_fwd");
+  return 0;
+}
+extern "C" int hugs_nf_prop_bwd(long long M, int in_dim, int hidden, int dtype, const void* X, int ldx, const float* W0, int ldw0,
+                                const float* b0, const float* w1, int ldw1, const float* raw, const float* sel,
+                                const float* d_density, void* dX, float* gW0, float* gb0, float* gw1, float* gb1, void* ws,
+                                void* stream) {
+  HUGS_REQUIRE(in_dim >= 1 && in_dim <= 32 && hidden >= 1 && hidden <= PM_H, -3, "hugs_nf_prop_bwd: %d -> %d -> 1 unsupported (<= 32, <= 64)", in_dim, hidden);
+  const int KP = in_dim <= 16 ? 16 : 32;
+  HUGS_REQUIRE(ldx >= KP && ldx % 8 == 0, -3, "hugs_nf_prop_bwd: feature pitch %d (needs >= %d, multiple of 8)", ldx, KP);
+  if (M <= 0) return 0;
+  const long long ntile = (M + 255) / 256;
+  const int grid = (int)(ntile < 1024 ? ntile : 1024);
+  hipStream_t st = (hipStream_t)stream;
+  float* slab = (float*)ws;
+#define PM_BWD(B, K) hipLaunchKernelGGL((k_nf_prop_bwd<B, K>), dim3(grid), dim3(256), 0, st, M, in_dim, hidden, X, ldx, W0, ldw0, b0, w1, ldw1, raw, sel, d_density, dX, slab)
+  if (dtype) { if (KP == 16) PM_BWD(true, 16); else PM_BWD(true, 32); }
+  else { if (KP == 16) PM_BWD(false, 16); else PM_BWD(false, 32); }
+#undef PM_BWD
+  hipLaunchKernelGGL(k_nf_prop_reduce, dim3((pm_slab_width(KP) + 63) / 64), dim3(256), 0, st, slab, grid, KP, in_dim, hidden, gW0, ldw0,
+                     gb0, gw1, ldw1, gb1);
+  HUGS_CHECK_LAUNCH("hugs_nf_prop_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam, train.py:183: eps outside the sqrt of the bias-corrected second moment)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_nf_adam(long long n, float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m,

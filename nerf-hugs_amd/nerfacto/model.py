@@ -11,6 +11,7 @@ sampler / weights / losses are pinned through oracle/nerfacto_ref.py (tests/test
 Not built: NeRF-W / HA-NeRF / RobustNeRF branches of the nerfacto model, eval-mode embedding averaging, DataParallel
 (the multi-GPU form here is one process per GPU with an all-reduce of the flat gradient, as for Mip-NeRF 360)."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -100,12 +101,15 @@ class NerfactoModel:
     self.ws = Workspace(self.device)
     self.L = cfg.num_proposal_iterations
     self.lay = _Layout()
-    self.grids, self.nets = {}, {}
+    self.grids, self.nets, self.fused = {}, {}, {}
     for i in range(self.L):
       a = cfg.prop_args(i)
       g = HashGrid(a['num_levels'], a['features_per_level'], a['log2_hashmap_size'], a['base_res'], None, a['max_res'], device='cpu')
       self.grids[f'prop{i}'] = g
       self._add_net(f'prop{i}', g, [(g.n_output_dims, a['hidden_dim']), (a['hidden_dim'], 1)])
+      # proposal nets up to 32 -> 64 -> 1 run as ONE fused kernel per direction (csrc/hugs_nerfacto.hip k_nf_prop_*: the
+      # reference's tcnn fully fused MLP); wider ones fall back to the padded GEMMs
+      self.fused[f'prop{i}'] = (g.n_output_dims <= 32 and a['hidden_dim'] <= 64 and os.environ.get('HUGS_NF_FUSED_PROP', '1') != '0')
     g = HashGrid(cfg.num_levels, cfg.features_per_level, cfg.log2_hashmap_size, cfg.base_res, None, cfg.max_res, device='cpu')
     self.grids['field'] = g
     self.napp = cfg.appearance_embedding_dim if cfg.use_appearance_embedding else 0
@@ -274,16 +278,29 @@ class NerfactoModel:
       L.call('hugs_nf_positions', N, S, eb, rays['origin'], rays['direction'], int(c.enable_scene_contraction), c.bound, x01, sel)
       K0, N0 = self.lay.items[f'{name}/w0'][1]
       N1 = self.lay.items[f'{name}/w1'][1][1]
-      X0 = ws.get(f'X0_{lvl}', (M, K0), self.tdt)
-      if (f'X0z_{lvl}', M) not in ws.bufs:        # the padding columns are written once and stay zero
-        X0.zero_(); ws.bufs[(f'X0z_{lvl}', M)] = True
-      self._grid_fwd(name, x01, X0)
-      Y0, Y1 = ws.get(f'Y0_{lvl}', (M, N0), self.tdt), ws.get(f'Y1_{lvl}', (M, N1), self.tdt)
-      self._nt(M, f'{name}/w0', X0, self.lay.view(self.flat, f'{name}/b0'), True, Y0)
-      self._nt(M, f'{name}/w1', Y0, self.lay.view(self.flat, f'{name}/b1'), False, Y1)
       dens = ws.get(f'dens{lvl}', (M,))
-      L.call('hugs_nf_density_act', M, dt, Y1, N1, 0, sel, dens)
-      st = dict(S=S, M=M, name=name, sbins=sb, ebins=eb, x01=x01, sel=sel, X0=X0, Y0=Y0, Y1=Y1, density=dens, rgb=None)
+      if self.fused.get(name):
+        in_dim, hid = self.lay.items[f'{name}/w0'][2]
+        KP = 16 if in_dim <= 16 else 32
+        X0 = ws.get(f'X0f_{lvl}', (M, KP), self.tdt)
+        if (f'X0fz_{lvl}', M) not in ws.bufs:        # the padding columns are written once and stay zero
+          X0.zero_(); ws.bufs[(f'X0fz_{lvl}', M)] = True
+        self._grid_fwd(name, x01, X0)
+        raw = ws.get(f'raw{lvl}', (M,))
+        L.call('hugs_nf_prop_fwd', M, in_dim, hid, dt, X0, KP, self.lay.view(self.flat, f'{name}/w0'), N0,
+               self.lay.view(self.flat, f'{name}/b0'), self.lay.view(self.flat, f'{name}/w1'), N1,
+               self.lay.view(self.flat, f'{name}/b1'), sel, raw, dens)
+        st = dict(S=S, M=M, name=name, sbins=sb, ebins=eb, x01=x01, sel=sel, X0=X0, Y0=None, Y1=None, raw=raw, density=dens, rgb=None)
+      else:
+        X0 = ws.get(f'X0_{lvl}', (M, K0), self.tdt)
+        if (f'X0z_{lvl}', M) not in ws.bufs:        # the padding columns are written once and stay zero
+          X0.zero_(); ws.bufs[(f'X0z_{lvl}', M)] = True
+        self._grid_fwd(name, x01, X0)
+        Y0, Y1 = ws.get(f'Y0_{lvl}', (M, N0), self.tdt), ws.get(f'Y1_{lvl}', (M, N1), self.tdt)
+        self._nt(M, f'{name}/w0', X0, self.lay.view(self.flat, f'{name}/b0'), True, Y0)
+        self._nt(M, f'{name}/w1', Y0, self.lay.view(self.flat, f'{name}/b1'), False, Y1)
+        L.call('hugs_nf_density_act', M, dt, Y1, N1, 0, sel, dens)
+        st = dict(S=S, M=M, name=name, sbins=sb, ebins=eb, x01=x01, sel=sel, X0=X0, Y0=Y0, Y1=Y1, density=dens, rgb=None)
       rgb_out = None
       if not is_prop:
         sh = ws.get('sh', (N, 16))
@@ -420,6 +437,19 @@ class NerfactoModel:
     d_rgb_s = ws.get('d_rgb_s', (M, 3)) if st['rgb'] is not None else None
     L.call('hugs_nf_weights_bwd', N, S, st['density'], st['ebins'], rays['direction'], int(c.opaque_background), st['rgb'],
            rays.get('bg_rgb') if st['rgb'] is not None else None, st['weights'], d_rgb_out, d_w_extra, d_dens, d_rgb_s)
+    if st.get('raw') is not None:       # fused proposal net: d density -> (dX0, weight gradients) in one kernel
+      in_dim, hid = self.lay.items[f'{name}/w0'][2]
+      N0 = self.lay.items[f'{name}/w0'][1][1]
+      N1 = self.lay.items[f'{name}/w1'][1][1]
+      KP = st['X0'].shape[1]
+      dX0 = ws.get(f'dX0f_{name}', (M, KP), self.tdt)
+      slab = ws.get('prop_slab', (L.lib().cdll.hugs_nf_prop_ws_bytes(in_dim) // 4,))
+      L.call('hugs_nf_prop_bwd', M, in_dim, hid, dt, st['X0'], KP, self.lay.view(self.flat, f'{name}/w0'), N0,
+             self.lay.view(self.flat, f'{name}/b0'), self.lay.view(self.flat, f'{name}/w1'), N1, st['raw'], st['sel'], d_dens,
+             dX0, self.lay.view(self.grad, f'{name}/w0'), self.lay.view(self.grad, f'{name}/b0'),
+             self.lay.view(self.grad, f'{name}/w1'), self.lay.view(self.grad, f'{name}/b1'), slab)
+      self._grid_bwd(name, st['x01'], dX0)
+      return
     N1 = st['Y1'].shape[1]
     dXh = None
     if st['rgb'] is not None:

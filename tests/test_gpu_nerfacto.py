@@ -100,8 +100,8 @@ def _rays(N, seed):
               bg_rgb=torch.ones(N, 3), rgb=torch.rand(N, 3, generator=g)), g
 
 
-@pytest.mark.parametrize('variant', ['base', 'contract_piecewise_charb', 'withmask', 'robustnerf'])
-def test_model_forward_loss_and_gradients_vs_oracle(variant):
+@pytest.mark.parametrize('variant', ['base', 'contract_piecewise_charb', 'withmask', 'robustnerf', 'wide_prop', 'prop_gemm'])
+def test_model_forward_loss_and_gradients_vs_oracle(variant, monkeypatch):
   from nerf_hugs_amd.nerfacto.model import NerfactoConfig, NerfactoModel
   from oracle import nerfacto_ref as NF
   kw = dict(SMALL)
@@ -111,6 +111,10 @@ def test_model_forward_loss_and_gradients_vs_oracle(variant):
     kw.update(transient_type='withmask', withmask_transient_weight=0.25)
   if variant == 'robustnerf':
     kw.update(transient_type='robustnerf', robustnerf_inlier_quantile=0.7, rgb_loss_type='charb')
+  if variant == 'wide_prop':      # 18 input features, 24 hidden units: the fused proposal kernels' 32-wide instantiation
+    kw.update(proposal_net_args_list=[dict(hidden_dim=24, log2_hashmap_size=9, num_levels=9, max_res=48)])
+  if variant == 'prop_gemm':      # the padded-GEMM fallback of the proposal nets (taken for nets wider than 32 -> 64 -> 1)
+    monkeypatch.setenv('HUGS_NF_FUSED_PROP', '0')
   ocfg = NF.Cfg(**kw)
   P = NF.init_params(ocfg, 3)
   # tables at U(+-1e-4) make every field output ~bias: scale them up so that the grids matter in the comparison
