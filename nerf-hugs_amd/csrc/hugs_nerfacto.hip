@@ -550,39 +550,39 @@ __global__ __launch_bounds__(256) void k_nf_prop_fwd(long long M, int in_dim, in
 }
 
 template <bool BF16, int KP>
-__global__ __launch_bounds__(256) void k_nf_prop_bwd(long long M, int in_dim, int H, const void* __restrict__ X, int ldx,
-                                                     const float* __restrict__ W0, int ldw0, const float* __restrict__ b0,
-                                                     const float* __restrict__ w1, int ldw1, const float* __restrict__ raw,
-                                                     const float* __restrict__ sel, const float* __restrict__ d_density,
-                                                     void* __restrict__ dX, float* __restrict__ slab) {
-  // Loops over the hidden units run in chunks of four with the per-sample hidden values parked in LDS (T[n][sample], pitch 65:
-  // conflict-free by sample and by unit); only x, dx and the lane-n accumulators live in registers (the fully unrolled
-  // 64-register form of the forward kernel spilled here).
-  constexpr int TP = 65;
+__global__ __launch_bounds__(256, 2) void k_nf_prop_bwd(long long M, int in_dim, int H, const void* __restrict__ X, int ldx,
+                                                        const float* __restrict__ W0, int ldw0, const float* __restrict__ b0,
+                                                        const float* __restrict__ w1, int ldw1, const float* __restrict__ raw,
+                                                        const float* __restrict__ sel, const float* __restrict__ d_density,
+                                                        void* __restrict__ dX, float* __restrict__ slab) {
+  // The hidden layer is walked in two halves of 32 units, the per-sample values of a half parked in LDS (T[unit][sample],
+  // pitch 65: conflict-free by sample and by unit); only x, dx and the weight-gradient accumulators live in registers (the
+  // fully unrolled 64-register form of the forward kernel spilled here; a whole-layer T left one workgroup per CU).
+  // Turn-around: lane l owns unit 32*half + (l & 31) for the samples of its lane half (l >> 5); the two lane halves are
+  // added at the end.
+  constexpr int TP = 65, TW = 32 * TP, XW = 64 * KP;
   __shared__ __attribute__((aligned(16))) float sW0[KP * PM_H];
   __shared__ __attribute__((aligned(16))) float sb0[PM_H];
   __shared__ __attribute__((aligned(16))) float sw1[PM_H];
-  __shared__ float sT[4][PM_H * TP];
-  __shared__ __attribute__((aligned(16))) float sX[4][64 * KP];
-  __shared__ __attribute__((aligned(16))) float sR[4][64];
+  __shared__ __attribute__((aligned(16))) float sBuf[4 * (TW + XW + 64)];
   pm_stage_weights<KP>(in_dim, H, W0, ldw0, b0, w1, ldw1, sW0, sb0, sw1);
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float* T = sT[wv];
-  float* xs = sX[wv];
-  float* rs = sR[wv];
-  float aW0[KP];                                  // lane n: dW0[k][n]
+  float* xs = sBuf + wv * (TW + XW + 64);         // [64][KP] (first: 16-byte aligned)
+  float* rs = xs + XW;                            // [64]
+  float* T = rs + 64;                             // [32][TP]
+  float aW0[2][KP], ab0[2] = {0.f, 0.f}, aw1[2] = {0.f, 0.f}, ab1 = 0.f;
 #pragma unroll
-  for (int k = 0; k < KP; ++k) aW0[k] = 0.f;
-  float ab0 = 0.f, aw1 = 0.f, ab1 = 0.f;
-  const float w1n = sw1[lane];
+  for (int k = 0; k < KP; ++k) { aW0[0][k] = 0.f; aW0[1][k] = 0.f; }
+  const int nl = lane & 31, sb = (lane >> 5) * 32;
+  const float w1n[2] = {sw1[nl], sw1[32 + nl]};
   const long long ntile = (M + 255) / 256;
 #define PM_WAVE_SYNC() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
   for (long long t = blockIdx.x; t < ntile; t += gridDim.x) {
     const long long m = t * 256 + threadIdx.x;
     const bool valid = m < M;
     const long long mm = valid ? m : M - 1;
-    float x[KP];
+    float x[KP], dx[KP];
     pm_load_x<BF16, KP>(X, mm, ldx, x);
     // d raw = d density * exp(clamp(raw, -15, 15)) * selector (custom_functions.py:46-50)
     const float r = valid ? d_density[mm] * expf(fminf(fmaxf(raw[mm], -15.f), 15.f)) * sel[mm] : 0.f;
@@ -590,31 +590,46 @@ __global__ __launch_bounds__(256) void k_nf_prop_bwd(long long M, int in_dim, in
     rs[lane] = r;
 #pragma unroll
     for (int k = 0; k < KP; k += 4) *(float4*)(xs + lane * KP + k) = make_float4(x[k], x[k + 1], x[k + 2], x[k + 3]);
-    // ---- hidden pre-activations of this lane's sample -> T[n][lane] ----
-#pragma unroll 1
-    for (int n = 0; n < PM_H; n += 4) {
-      float4 h = *(const float4*)(sb0 + n);
-#pragma unroll
-      for (int k = 0; k < KP; ++k) {
-        const float4 w = *(const float4*)(sW0 + k * PM_H + n);
-        h.x = fmaf(x[k], w.x, h.x); h.y = fmaf(x[k], w.y, h.y); h.z = fmaf(x[k], w.z, h.z); h.w = fmaf(x[k], w.w, h.w);
-      }
-      T[n * TP + lane] = h.x; T[(n + 1) * TP + lane] = h.y; T[(n + 2) * TP + lane] = h.z; T[(n + 3) * TP + lane] = h.w;
-    }
-    // ---- feature gradient of this lane's sample: dx[k] = sum_n W0[k][n] dh[n], dh[n] = (h[n] > 0) r w1[n] ----
-    float dx[KP];
 #pragma unroll
     for (int k = 0; k < KP; ++k) dx[k] = 0.f;
-#pragma unroll 1
-    for (int n = 0; n < PM_H; n += 4) {
-      const float4 wv1 = *(const float4*)(sw1 + n);
-      const float d0 = T[n * TP + lane] > 0.f ? r * wv1.x : 0.f, d1 = T[(n + 1) * TP + lane] > 0.f ? r * wv1.y : 0.f;
-      const float d2 = T[(n + 2) * TP + lane] > 0.f ? r * wv1.z : 0.f, d3 = T[(n + 3) * TP + lane] > 0.f ? r * wv1.w : 0.f;
 #pragma unroll
-      for (int k = 0; k < KP; ++k) {
-        const float4 w = *(const float4*)(sW0 + k * PM_H + n);
-        dx[k] = fmaf(w.x, d0, dx[k]); dx[k] = fmaf(w.y, d1, dx[k]); dx[k] = fmaf(w.z, d2, dx[k]); dx[k] = fmaf(w.w, d3, dx[k]);
+    for (int hh = 0; hh < 2; ++hh) {
+      // ---- hidden pre-activations of this lane's sample (units 32 hh ..) -> T, and their share of dx ----
+#pragma unroll 1
+      for (int n = 0; n < 32; n += 4) {
+        const int ng = hh * 32 + n;
+        float4 h = *(const float4*)(sb0 + ng);
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+          const float4 w = *(const float4*)(sW0 + k * PM_H + ng);
+          h.x = fmaf(x[k], w.x, h.x); h.y = fmaf(x[k], w.y, h.y); h.z = fmaf(x[k], w.z, h.z); h.w = fmaf(x[k], w.w, h.w);
+        }
+        T[n * TP + lane] = h.x; T[(n + 1) * TP + lane] = h.y; T[(n + 2) * TP + lane] = h.z; T[(n + 3) * TP + lane] = h.w;
+        const float4 wv1 = *(const float4*)(sw1 + ng);
+        const float d0 = h.x > 0.f ? r * wv1.x : 0.f, d1 = h.y > 0.f ? r * wv1.y : 0.f;
+        const float d2 = h.z > 0.f ? r * wv1.z : 0.f, d3 = h.w > 0.f ? r * wv1.w : 0.f;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {          // dx[k] = sum_n W0[k][n] dh[n]
+          const float4 w = *(const float4*)(sW0 + k * PM_H + ng);
+          dx[k] = fmaf(w.x, d0, dx[k]); dx[k] = fmaf(w.y, d1, dx[k]); dx[k] = fmaf(w.z, d2, dx[k]); dx[k] = fmaf(w.w, d3, dx[k]);
+        }
       }
+      PM_WAVE_SYNC()
+      // ---- lane (unit nl, sample half sb) walks 32 samples: dw1 += relu(h) r, db0 += dh, dW0[k] += x[k] dh ----
+#pragma unroll 2
+      for (int s_ = 0; s_ < 32; ++s_) {
+        const float hv = T[nl * TP + sb + s_], rr = rs[sb + s_];
+        aw1[hh] = fmaf(fmaxf(hv, 0.f), rr, aw1[hh]);
+        const float d = hv > 0.f ? rr * w1n[hh] : 0.f;
+        ab0[hh] += d;
+#pragma unroll
+        for (int k = 0; k < KP; k += 4) {
+          const float4 xv = *(const float4*)(xs + (sb + s_) * KP + k);
+          aW0[hh][k] = fmaf(xv.x, d, aW0[hh][k]); aW0[hh][k + 1] = fmaf(xv.y, d, aW0[hh][k + 1]);
+          aW0[hh][k + 2] = fmaf(xv.z, d, aW0[hh][k + 2]); aW0[hh][k + 3] = fmaf(xv.w, d, aW0[hh][k + 3]);
+        }
+      }
+      PM_WAVE_SYNC()
     }
     if (valid) {
       if (BF16) {
@@ -630,30 +645,27 @@ __global__ __launch_bounds__(256) void k_nf_prop_bwd(long long M, int in_dim, in
         for (int c = 0; c < KP / 4; ++c) *(float4*)((float*)dX + (size_t)m * ldx + c * 4) = make_float4(dx[c * 4], dx[c * 4 + 1], dx[c * 4 + 2], dx[c * 4 + 3]);
       }
     }
-    PM_WAVE_SYNC()
-    // ---- lane n walks the 64 samples: dw1[n] += relu(h) r, db0[n] += dh, dW0[k][n] += x[k] dh ----
-#pragma unroll 2
-    for (int s_ = 0; s_ < 64; ++s_) {
-      const float hv = T[lane * TP + s_], rr = rs[s_];
-      aw1 = fmaf(fmaxf(hv, 0.f), rr, aw1);
-      const float d = hv > 0.f ? rr * w1n : 0.f;
-      ab0 += d;
-#pragma unroll
-      for (int k = 0; k < KP; k += 4) {
-        const float4 xv = *(const float4*)(xs + s_ * KP + k);
-        aW0[k] = fmaf(xv.x, d, aW0[k]); aW0[k + 1] = fmaf(xv.y, d, aW0[k + 1]); aW0[k + 2] = fmaf(xv.z, d, aW0[k + 2]); aW0[k + 3] = fmaf(xv.w, d, aW0[k + 3]);
-      }
-    }
-    PM_WAVE_SYNC()
   }
 #undef PM_WAVE_SYNC
-  // ---- workgroup partials -> slab row (waves summed in a fixed order) ----
-  __syncthreads();
-  float* red = &sT[0][0];                         // [4][KP + 3][64]
+  // ---- the two lane halves, then the four waves (fixed order), -> slab row ----
 #pragma unroll
-  for (int k = 0; k < KP; ++k) red[(wv * (KP + 3) + k) * 64 + lane] = aW0[k];
-  red[(wv * (KP + 3) + KP) * 64 + lane] = ab0;
-  red[(wv * (KP + 3) + KP + 1) * 64 + lane] = aw1;
+  for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+    for (int k = 0; k < KP; ++k) aW0[hh][k] += __shfl_xor(aW0[hh][k], 32);
+    ab0[hh] += __shfl_xor(ab0[hh], 32);
+    aw1[hh] += __shfl_xor(aw1[hh], 32);
+  }
+  __syncthreads();
+  float* red = sBuf;                              // [4][KP + 3][64]
+  if (lane < 32) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+      for (int k = 0; k < KP; ++k) red[(wv * (KP + 3) + k) * 64 + hh * 32 + lane] = aW0[hh][k];
+      red[(wv * (KP + 3) + KP) * 64 + hh * 32 + lane] = ab0[hh];
+      red[(wv * (KP + 3) + KP + 1) * 64 + hh * 32 + lane] = aw1[hh];
+    }
+  }
   red[(wv * (KP + 3) + KP + 2) * 64 + lane] = ab1;
   __syncthreads();
   float* row = slab + (size_t)blockIdx.x * pm_slab_width(KP);
