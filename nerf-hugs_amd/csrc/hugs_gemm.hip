@@ -1445,7 +1445,8 @@ static int gemm_nt_impl(int dtype, int M, int N, int K1, int K2, const void* A1,
   if (bits_in) mask = nullptr;       // (the EPI_MASK specialisation is selected through `epi_mask` below)
   GemmEpi E{bias, row_bias, row_div, ld_rb, relu, mask, ld_mask, r1_row, r1_col, out, ldc, bits_out, bits_in};
   const int grid = (M / 128) * (N / 128);
-  if (dtype && M % 256 == 0 && N % 256 == 0 && (K1 + K2) % 64 == 0 && K1 + K2 >= 256 && g_force_small_tiles != 1 && g_force_small_tiles != 3)
+  // (four K-stages of 32 are the shortest pipeline the ring kernels run: K >= 128)
+  if (dtype && M % 256 == 0 && N % 256 == 0 && (K1 + K2) % 64 == 0 && K1 + K2 >= 128 && g_force_small_tiles != 1 && g_force_small_tiles != 3)
   {
     // epilogue specialisations for the combinations the trunks use (bit set = term present); anything else -> generic
     const int epi = row_bias ? -1 : (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0) | (mask ? EPI_MASK : 0) | (r1_row ? EPI_R1 : 0) |
@@ -1494,7 +1495,7 @@ static int gemm_nt_impl(int dtype, int M, int N, int K1, int K2, const void* A1,
     }
 #undef HUGS_NT_LAUNCH
   }
-  else if (dtype && M % 256 == 0 && (K1 + K2) % 64 == 0 && K1 + K2 >= 256 && g_force_small_tiles != 1)
+  else if (dtype && M % 256 == 0 && (K1 + K2) % 64 == 0 && K1 + K2 >= 128 && g_force_small_tiles != 1)
     hipLaunchKernelGGL(k_gemm_nt_bf16_big<2>, dim3((M / 256) * (N / 128)), dim3(256), 0, (hipStream_t)stream, M, N, K1, K2,
                        (const uint16_t*)A1, lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E);
   else if (dtype)

@@ -179,7 +179,10 @@ def test_gemm_nt_tn_vs_fp64(dtype):
   g = torch.Generator(device=dev).manual_seed(0)
   rn = lambda *s: torch.randn(*s, device=dev, generator=g)
   for (M, N, K1, K2, relu, mask, r1, rb) in [(256, 128, 64, 0, 1, False, False, False), (1024, 1024, 1024, 512, 1, False, False, False),
-                                               (640, 256, 512, 0, 0, True, True, False), (384, 128, 256, 0, 1, False, False, True)]:
+                                               (640, 256, 512, 0, 0, True, True, False), (384, 128, 256, 0, 1, False, False, True),
+                                               # K = 128: four K-stages, the shortest pipeline of the 256x256 / 256x128 ring kernels
+                                               (512, 256, 128, 0, 1, False, False, False), (768, 512, 64, 64, 0, True, False, False),
+                                               (512, 128, 128, 0, 1, False, False, False), (66048, 256, 128, 0, 1, False, False, False)]:
     A1 = rn(M, K1).to(tdt); A2 = rn(M, K2).to(tdt) if K2 else None
     Bt = (rn(N, K1 + K2) / (K1 + K2)**0.5).to(tdt)
     bias = rn(N); rbt = rn(M // 64, N) if rb else None
