@@ -1523,8 +1523,9 @@ extern "C" int hugs_gemm_tn(int dtype, int Mrows, int Kc, int N, int nsplit, con
   float* cs = dbias ? slab + (size_t)nsplit * Kc * N : nullptr;
   const int grid = (Kc / 128) * (N / 128) * nsplit;
   const int rows_per = Mrows / nsplit;
-  if (dtype && Kc % 256 == 0 && N % 256 == 0 && (Kc / 256) * (N / 256) >= 4 && rows_per % 64 == 0 && rows_per >= 256 &&
-      g_force_small_tiles != 1)
+  // (a single 256x256 tile qualifies too when the caller splits the rows deep enough: nerfacto's 256-wide field layers)
+  if (dtype && Kc % 256 == 0 && N % 256 == 0 && ((Kc / 256) * (N / 256) >= 4 || rows_per >= 2048) && rows_per % 64 == 0 &&
+      rows_per >= 256 && g_force_small_tiles != 1)
     hipLaunchKernelGGL(k_gemm_tn_bf16_big, dim3((Kc / 256) * (N / 256) * nsplit), dim3(512), 0, (hipStream_t)stream, Mrows, Kc,
                        N, nsplit, (const uint16_t*)X, ldx, (const uint16_t*)G, ldg, slab, N, cs);
   else if (dtype)

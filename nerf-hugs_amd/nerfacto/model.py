@@ -209,6 +209,8 @@ class NerfactoModel:
     """grad[name] = X^T G, grad[bias] = colsum(G)."""
     K, N = self.lay.items[name][1]
     tiles, step, target = (K // 128) * (N // 128), (64 if self.dt else 16), 768
+    if self.dt and K % 256 == 0 and N % 256 == 0 and M // (256 // max(1, (K // 256) * (N // 256))) >= 2048:
+      tiles, target = (K // 256) * (N // 256), 256            # the 256x256 ring kernel, one workgroup per CU
     units = M // step
     ns = max(1, min(units, (target + tiles - 1) // tiles))
     while units % ns:

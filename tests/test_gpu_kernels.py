@@ -197,7 +197,8 @@ def test_gemm_nt_tn_vs_fp64(dtype):
     if relu: ref = ref.clamp(min=0)
     if mask: ref = ref * (mk.double() > 0)
     assert float((out.double() - ref).abs().max()) < tol * max(1.0, float(ref.abs().max()))
-  for (Mr, Kc, N, ns) in [(1024, 128, 128, 1), (4096, 512, 256, 4), (8192, 1024, 1024, 8)]:
+  for (Mr, Kc, N, ns) in [(1024, 128, 128, 1), (4096, 512, 256, 4), (8192, 1024, 1024, 8),
+                          (16384, 256, 256, 8)]:      # one 256x256 tile, 2048 rows per split: the ring kernel's single-tile form
     X = rn(Mr, Kc).to(tdt); Gm = rn(Mr, N).to(tdt)
     dW = torch.empty(Kc, N, device=dev); db = torch.empty(N, device=dev)
     ws = torch.empty(L.lib().cdll.hugs_gemm_tn_ws_bytes(Kc, N, ns) // 4, device=dev)
