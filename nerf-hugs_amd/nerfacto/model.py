@@ -35,6 +35,7 @@ class NerfactoConfig:
     self.num_levels, self.base_res, self.max_res, self.log2_hashmap_size, self.features_per_level = 16, 16, 2048, 19, 2
     self.hidden_dim, self.geo_feat_dim, self.hidden_dim_color = 64, 15, 64
     self.use_appearance_embedding, self.appearance_embedding_dim, self.num_embedding = False, 32, 3500
+    self.eval_embedding = 'average'          # 'average' | 'zero' | 'original' (Model.get_embedding, nerfacto.py:266-284)
     self.num_proposal_samples_per_ray, self.num_nerf_samples_per_ray, self.num_proposal_iterations = (256, 96), 48, 2
     self.proposal_net_args_list = [dict(hidden_dim=16, log2_hashmap_size=17, num_levels=5, max_res=128),
                                    dict(hidden_dim=16, log2_hashmap_size=17, num_levels=5, max_res=256)]
@@ -61,6 +62,8 @@ class NerfactoConfig:
       raise NotImplementedError(f"nerfacto transient_type {self.transient_type!r}: built are None, 'withmask' and 'robustnerf'")
     if self.transient_type == 'robustnerf':
       assert self.robustnerf_inner_patch_size <= self.patch_size, 'patch_size must be larger than robustnerf_inner_patch_size.'
+    if self.eval_embedding not in ('average', 'zero', 'original'):
+      raise NotImplementedError(f'{self.eval_embedding} is not supported.')                   # nerfacto.py:283
     if self.proposal_initial_sampler not in ('uniform', 'piecewise', 'reciprocal'):
       raise ValueError(f'Sampler does not support {self.proposal_initial_sampler}. ')       # nerfacto.py:241
     if self.enable_scene_contraction and self.bound != 2.0:
@@ -248,7 +251,7 @@ class NerfactoModel:
     L.call('hugs_hashgrid_bwd', x01.shape[0], g.n_levels, g.features, o, r, s, x01, dX0, self.dt, dX0.stride(0),
            self.lay.view(self.grad, f'{name}/table'))
 
-  def forward(self, rays, curr_step, u01=None):
+  def forward(self, rays, curr_step, u01=None, training=True):
     """Model.forward_rays (nerfacto.py:286-414), training mode.  rays: dict of device tensors origin / direction / viewdir
     [N,3], near / far [N], embed_idx [N] int32, bg_rgb [N,3] (or None).  u01: None (perturb=False) or one [N] tensor of
     U[0,1) draws per level (single jitter).  Returns the per-level state the loss / backward use."""
@@ -312,7 +315,12 @@ class NerfactoModel:
         app = None
         if self.napp:
           app = ws.get('app', (N, self.napp))
-          L.call('hugs_glo_gather', N, self.napp, self.lay.view(self.flat, 'appearance'), rays['embed_idx'], 0, app)
+          if training or c.eval_embedding == 'original':
+            L.call('hugs_glo_gather', N, self.napp, self.lay.view(self.flat, 'appearance'), rays['embed_idx'], 0, app)
+          elif c.eval_embedding == 'average':       # eval: every ray sees the mean embedding row (nerfacto.py:272-276)
+            app.copy_(self.lay.view(self.flat, 'appearance').mean(dim=0, keepdim=True).expand(N, -1))
+          else:
+            app.zero_()
         Kh = self.lay.items['field/c0'][1][0]
         H = self.lay.items['field/c0'][1][1]
         Xh = ws.get('Xh', (M, Kh), self.tdt)
@@ -336,6 +344,32 @@ class NerfactoModel:
     return levels
 
   # ---- loss + backward + Adam ---------------------------------------------------------------------------------------------
+  @torch.no_grad()
+  def render(self, batch, curr_step, chunk_size=None):
+    """Model.forward in eval mode (nerfacto.py:419-428, train.py:244-256): perturb=False, rays in chunks of
+    `chunk_size`, embeddings per cfg.eval_embedding.  Returns {'rgb' [N,3], 'accumulation' [N], 'depth' [N]} (the
+    training-only weights / bins lists are not returned, as in the reference)."""
+    N = batch['origin'].shape[0]
+    cs = N if not chunk_size else int(chunk_size)
+    cs = max(128, (cs + 127) // 128 * 128)          # whole GEMM tiles per chunk; the last chunk is padded with its last ray
+    out = {k: [] for k in ('rgb', 'accumulation', 'depth')}
+    for lo in range(0, N, cs):
+      hi = min(N, lo + cs)
+      n = hi - lo
+      npad = (n + 127) // 128 * 128
+      sub = {}
+      for k, v in batch.items():
+        if not torch.is_tensor(v) or v.shape[0] != N:
+          continue
+        sl = v[lo:hi]
+        if npad != n:
+          sl = torch.cat([sl, sl[-1:].expand(npad - n, *sl.shape[1:])], 0)
+        sub[k] = sl.contiguous()
+      fin = self.forward(sub, curr_step, None, training=False)[-1]
+      out['rgb'].append(fin['rgb_out'][:n].clone()); out['accumulation'].append(fin['acc'][:n].clone())
+      out['depth'].append(fin['depth'][:n].clone())
+    return {k: torch.cat(v, 0) for k, v in out.items()}
+
   def proposal_update_enabled(self, curr_step):
     """nerfacto.py:299-303."""
     c = self.cfg

@@ -33,6 +33,7 @@ class Cfg:
     self.hidden_dim, self.geo_feat_dim, self.hidden_dim_color = 64, 15, 64
     self.num_layers, self.num_layers_color = 2, 3
     self.use_appearance_embedding, self.appearance_embedding_dim, self.num_embedding = False, 32, 3500
+    self.eval_embedding = 'average'
     self.num_proposal_samples_per_ray, self.num_nerf_samples_per_ray = (256, 96), 48
     self.num_proposal_iterations = 2
     self.proposal_net_args_list = [dict(hidden_dim=16, log2_hashmap_size=17, num_levels=5, max_res=128),
@@ -292,7 +293,7 @@ def anneal_of(cfg, curr_step):
   return (s * f) / ((s - 1) * f + 1)
 
 
-def forward_rays(cfg, P, rays, curr_step, u01):
+def forward_rays(cfg, P, rays, curr_step, u01, training=True):
   """Model.forward_rays (nerfacto.py:286-414) in training mode.  rays: origin, direction, viewdir [N,3], near, far [N,1],
   embed_idx [N,1] int, bg_rgb [N,3].  u01: None or one [N,1] draw tensor per level."""
   fwd, inv = spacing_fns(cfg.proposal_initial_sampler)
@@ -320,7 +321,13 @@ def forward_rays(cfg, P, rays, curr_step, u01):
       vd = rays['viewdir'][:, None, :].expand_as(pos).reshape(-1, 3)
       app = None
       if cfg.use_appearance_embedding:
-        app = P['appearance'][rays['embed_idx'][:, 0].long()][:, None, :].expand(N, S, -1).reshape(N * S, -1)
+        if training or cfg.eval_embedding == 'original':       # Model.get_embedding nerfacto.py:266-284
+          emb = P['appearance'][rays['embed_idx'][:, 0].long()]
+        elif cfg.eval_embedding == 'average':
+          emb = torch.ones(N, P['appearance'].shape[-1], dtype=P['appearance'].dtype) * P['appearance'].mean(dim=0)
+        else:
+          emb = torch.zeros(N, P['appearance'].shape[-1], dtype=P['appearance'].dtype)
+        app = emb[:, None, :].expand(N, S, -1).reshape(N * S, -1)
       rgb, dens = field_forward(cfg, P['field'], pos.reshape(-1, 3), vd, app)
       rgb, dens = rgb.reshape(N, S, 3), dens.reshape(N, S)
     weights, _, _ = density_to_weight(dens, ebins, rays['direction'], cfg.opaque_background)

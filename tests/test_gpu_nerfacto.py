@@ -245,3 +245,32 @@ def test_two_rank_nerfacto_step_equals_single_process(tmp_path):
   a, b = torch.load(tmp_path / 'nf1.pt'), torch.load(tmp_path / 'nf2.pt')
   sc = float(a['grad'].abs().max())
   assert sc > 0 and float((a['grad'] - b['grad']).abs().max()) <= 2e-4 * sc
+
+
+@pytest.mark.parametrize('mode', ['average', 'zero', 'original'])
+def test_eval_render_vs_oracle(mode):
+  """Model.forward in eval mode (train.py:244-256): perturb=False, ragged chunks, the three eval_embedding policies."""
+  from nerf_hugs_amd.nerfacto.model import NerfactoConfig, NerfactoModel
+  from oracle import nerfacto_ref as NF
+  kw = dict(SMALL, eval_embedding=mode)
+  ocfg = NF.Cfg(**kw)
+  P = NF.init_params(ocfg, 4)
+  for k in P:
+    if isinstance(P[k], dict):
+      P[k]['table'] = P[k]['table'] * 3e3
+  model = NerfactoModel(NerfactoConfig(**kw), compute_dtype='fp32')
+  model.load_params(P)
+  N = 200                                            # not a multiple of the 128-row tile, two ragged chunks of 96 rays -> 128
+  b, g = _rays(N, 9)
+  orays = {k: (v[:, None] if v.dim() == 1 and k in ('near', 'far', 'embed_idx') else v) for k, v in b.items()}
+  with torch.no_grad():
+    out = NF.forward_rays(ocfg, P, orays, 700, None, training=False)
+  res = model.render({k: v.to(dev) for k, v in b.items()}, 700, chunk_size=96)
+  np.testing.assert_allclose(res['rgb'].cpu().numpy(), out['rgb'].numpy(), rtol=0, atol=1e-4)
+  np.testing.assert_allclose(res['accumulation'].cpu().numpy(), out['accumulation'].reshape(-1).numpy(), rtol=0, atol=1e-4)
+  np.testing.assert_allclose(res['depth'].cpu().numpy(), out['depth'].reshape(-1).numpy(), rtol=2e-4, atol=1e-4)
+  if mode != 'original':      # the embedding policy must matter for this model (otherwise the test proves nothing)
+    res_o = NerfactoModel(NerfactoConfig(**dict(kw, eval_embedding='original')), compute_dtype='fp32')
+    res_o.load_params(P)
+    ro = res_o.render({k: v.to(dev) for k, v in b.items()}, 700, chunk_size=96)
+    assert float((ro['rgb'] - res['rgb']).abs().max()) > 1e-3
