@@ -356,38 +356,71 @@ __global__ void k_nf_density_act(long long M, int bf16, const void* __restrict__
   density[m] = expf(nf_load(Y, (size_t)m * ldy + col, bf16)) * sel[m];
 }
 
+// eight consecutive columns per thread (one 16-byte store in bf16): the per-element form of these glue kernels spent its time
+// in 64-bit index divisions and 2-byte stores (0.6 TB/s); ld must be a multiple of 8
+__device__ __forceinline__ void nf_store8(void* p, size_t i, int bf16, const float (&v)[8]) {
+  if (bf16) {
+    uint4 u;
+    u.x = f_to_bf16(v[0]) | ((uint32_t)f_to_bf16(v[1]) << 16); u.y = f_to_bf16(v[2]) | ((uint32_t)f_to_bf16(v[3]) << 16);
+    u.z = f_to_bf16(v[4]) | ((uint32_t)f_to_bf16(v[5]) << 16); u.w = f_to_bf16(v[6]) | ((uint32_t)f_to_bf16(v[7]) << 16);
+    *(uint4*)((uint16_t*)p + i) = u;
+  } else {
+    *(float4*)((float*)p + i) = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)((float*)p + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+
 // G[M, ldg] = gradient at the base MLP's output: column 0 = d_density * exp(clamp(raw, -15, 15)) * selector
 // (custom_functions.py:46-50), columns 1 .. ngeo = dXhead[:, geo_col0 ...] (the head's input gradient), the rest 0.
 __global__ void k_nf_base_grad(long long M, int bf16, const void* __restrict__ Y, int ldy, const float* __restrict__ sel,
                                const float* __restrict__ d_density, const void* __restrict__ dXh, int ldx, int geo_col0, int ngeo,
                                void* __restrict__ G, int ldg) {
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long m = e / ldg;
-  const int c = (int)(e % ldg);
-  if (m >= M) return;
-  float v = 0.f;
-  if (c == 0) {
-    const float raw = nf_load(Y, (size_t)m * ldy, bf16);
-    v = d_density[m] * expf(fminf(fmaxf(raw, -15.f), 15.f)) * sel[m];
-  } else if (c <= ngeo && dXh) {
-    v = nf_load(dXh, (size_t)m * ldx + geo_col0 + c - 1, bf16);
+  if (ldg & 7) {                                  // narrow / odd pitches (the fused proposal path uses ldg = 1): one element per thread
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long m = e / ldg;
+    const int c = (int)(e % ldg);
+    if (m >= M) return;
+    float v = 0.f;
+    if (c == 0) v = d_density[m] * expf(fminf(fmaxf(nf_load(Y, (size_t)m * ldy, bf16), -15.f), 15.f)) * sel[m];
+    else if (c <= ngeo && dXh) v = nf_load(dXh, (size_t)m * ldx + geo_col0 + c - 1, bf16);
+    nf_store(G, (size_t)m * ldg + c, bf16, v);
+    return;
   }
-  nf_store(G, (size_t)m * ldg + c, bf16, v);
+  const int cpr = ldg >> 3;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long m = e / cpr;
+  const int c0 = (int)(e - m * cpr) * 8;
+  if (m >= M) return;
+  float v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int c = c0 + q;
+    v[q] = 0.f;
+    if (c == 0) v[q] = d_density[m] * expf(fminf(fmaxf(nf_load(Y, (size_t)m * ldy, bf16), -15.f), 15.f)) * sel[m];
+    else if (c <= ngeo && dXh) v[q] = nf_load(dXh, (size_t)m * ldx + geo_col0 + c - 1, bf16);
+  }
+  nf_store8(G, (size_t)m * ldg + c0, bf16, v);
 }
 
 // head input X[M, ldx] = [SH(viewdir) (16, per ray) | geo = Ybase[:, 1 .. ngeo] | appearance embedding (per ray) | 0 ...]
 __global__ void k_nf_head_input(long long M, int S, int bf16, const float* __restrict__ sh, const void* __restrict__ Yb, int ldy,
                                 int ngeo, const float* __restrict__ app, int napp, void* __restrict__ X, int ldx) {
+  const int cpr = ldx >> 3;                       // ldx is a multiple of 8 (checked by the launcher)
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long m = e / ldx;
-  const int c = (int)(e % ldx);
+  const long long m = e / cpr;
+  const int c0 = (int)(e - m * cpr) * 8;
   if (m >= M) return;
   const long long ray = m / S;
-  float v = 0.f;
-  if (c < 16) v = sh[ray * 16 + c];
-  else if (c < 16 + ngeo) v = nf_load(Yb, (size_t)m * ldy + 1 + (c - 16), bf16);
-  else if (c < 16 + ngeo + napp) v = app[ray * napp + (c - 16 - ngeo)];
-  nf_store(X, (size_t)m * ldx + c, bf16, v);
+  float v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int c = c0 + q;
+    v[q] = 0.f;
+    if (c < 16) v[q] = sh[ray * 16 + c];
+    else if (c < 16 + ngeo) v[q] = nf_load(Yb, (size_t)m * ldy + 1 + (c - 16), bf16);
+    else if (c < 16 + ngeo + napp) v[q] = app[ray * napp + (c - 16 - ngeo)];
+  }
+  nf_store8(X, (size_t)m * ldx + c0, bf16, v);
 }
 
 // d_app[ray, :] = sum over the ray's samples of dX[:, col0 .. col0 + napp); scatter-added into the embedding row
@@ -412,13 +445,17 @@ __global__ void k_nf_rgb_act(long long M, int bf16, const void* __restrict__ Y, 
 
 // G[M, ldg] = gradient at the rgb layer's output: columns 0..2 = d_rgb * rgb * (1 - rgb), the rest 0
 __global__ void k_nf_rgb_grad(long long M, int bf16, const float* __restrict__ rgb, const float* __restrict__ d_rgb, void* __restrict__ G, int ldg) {
+  const int cpr = ldg >> 3;                       // ldg is a multiple of 8 (checked by the launcher)
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long m = e / ldg;
-  const int c = (int)(e % ldg);
+  const long long m = e / cpr;
+  const int c0 = (int)(e - m * cpr) * 8;
   if (m >= M) return;
-  float v = 0.f;
-  if (c < 3) { const float r = rgb[m * 3 + c]; v = d_rgb[m * 3 + c] * r * (1.f - r); }
-  nf_store(G, (size_t)m * ldg + c, bf16, v);
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { const float r = rgb[m * 3 + c]; v[c] = d_rgb[m * 3 + c] * r * (1.f - r); }
+  }
+  nf_store8(G, (size_t)m * ldg + c0, bf16, v);
 }
 
 #define NF_LAUNCH1D(kern, total, ...)                                                                      \
@@ -434,14 +471,14 @@ extern "C" int hugs_nf_density_act(long long M, int dtype, const void* Y, int ld
 }
 extern "C" int hugs_nf_base_grad(long long M, int dtype, const void* Y, int ldy, const float* sel, const float* d_density,
                                  const void* dXh, int ldx, int geo_col0, int ngeo, void* G, int ldg, void* stream) {
-  NF_LAUNCH1D(k_nf_base_grad, M * ldg, M, dtype, Y, ldy, sel, d_density, dXh, ldx, geo_col0, ngeo, G, ldg);
+  NF_LAUNCH1D(k_nf_base_grad, (ldg & 7) ? M * ldg : M * (ldg >> 3), M, dtype, Y, ldy, sel, d_density, dXh, ldx, geo_col0, ngeo, G, ldg);
   HUGS_CHECK_LAUNCH("hugs_nf_base_grad");
   return 0;
 }
 extern "C" int hugs_nf_head_input(long long M, int S, int dtype, const float* sh, const void* Yb, int ldy, int ngeo, const float* app,
                                   int napp, void* X, int ldx, void* stream) {
-  HUGS_REQUIRE(16 + ngeo + napp <= ldx, -3, "hugs_nf_head_input: %d columns do not fit the pitch %d", 16 + ngeo + napp, ldx);
-  NF_LAUNCH1D(k_nf_head_input, M * ldx, M, S, dtype, sh, Yb, ldy, ngeo, app, napp, X, ldx);
+  HUGS_REQUIRE(16 + ngeo + napp <= ldx && ldx % 8 == 0, -3, "hugs_nf_head_input: %d columns do not fit the pitch %d (a multiple of 8)", 16 + ngeo + napp, ldx);
+  NF_LAUNCH1D(k_nf_head_input, M * (ldx >> 3), M, S, dtype, sh, Yb, ldy, ngeo, app, napp, X, ldx);
   HUGS_CHECK_LAUNCH("hugs_nf_head_input");
   return 0;
 }
@@ -457,7 +494,8 @@ extern "C" int hugs_nf_rgb_act(long long M, int dtype, const void* Y, int ldy, f
   return 0;
 }
 extern "C" int hugs_nf_rgb_grad(long long M, int dtype, const float* rgb, const float* d_rgb, void* G, int ldg, void* stream) {
-  NF_LAUNCH1D(k_nf_rgb_grad, M * ldg, M, dtype, rgb, d_rgb, G, ldg);
+  HUGS_REQUIRE(ldg % 8 == 0, -3, "hugs_nf_rgb_grad: pitch %d is not a multiple of 8", ldg);
+  NF_LAUNCH1D(k_nf_rgb_grad, M * (ldg >> 3), M, dtype, rgb, d_rgb, G, ldg);
   HUGS_CHECK_LAUNCH("hugs_nf_rgb_grad");
   return 0;
 }
