@@ -330,3 +330,26 @@ def test_torch_library_custom_ops():
   np.testing.assert_allclose(db.cpu().numpy(), gm.float().sum(0).cpu().numpy(), rtol=1e-4, atol=1e-3)
   with pytest.raises(Exception):
     torch.ops.hugs.gemm_nt(x.cpu(), wt.cpu(), bias.cpu(), True, out.cpu())
+
+
+@pytest.mark.parametrize('shape', [(256, 256, 128, 0), (512, 256, 192, 0), (768, 512, 320, 0), (256, 768, 1024, 0), (1280, 256, 128, 512),
+                                   (66560, 256, 192, 0), (67072, 512, 256, 64)])
+def test_gemm_ring_kernels_over_stage_counts(shape):
+  """The 256x256 ring kernels (one tile per workgroup, and the persistent form once there are more tiles than CUs) over
+  stage counts 4, 6, 10, 32, 20 and two-segment K: bias + relu forward against float64, and the masked dX form."""
+  L = _L()
+  M, N, K1, K2 = shape
+  g = torch.Generator(device=dev).manual_seed(M + N + K1)
+  rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+  A1 = rn(M, K1).bfloat16(); A2 = rn(M, K2).bfloat16() if K2 else None
+  Bt = (rn(N, K1 + K2) / (K1 + K2)**0.5).bfloat16()
+  bias = rn(N)
+  out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+  L.call('hugs_gemm_nt', 1, M, N, K1, K2, A1, K1, A2, K2, Bt, K1 + K2, bias, None, 1, 0, 1, None, 0, None, None, out, N)
+  A = torch.cat([A1, A2], 1) if K2 else A1
+  ref = (A.double() @ Bt.double().T + bias.double()).clamp(min=0)
+  assert float((out.double() - ref).abs().max()) < 2e-2 * max(1.0, float(ref.abs().max()))
+  mk = rn(M, N).bfloat16()
+  L.call('hugs_gemm_nt', 1, M, N, K1, K2, A1, K1, A2, K2, Bt, K1 + K2, None, None, 1, 0, 0, mk, N, None, None, out, N)
+  ref = (A.double() @ Bt.double().T) * (mk.double() > 0)
+  assert float((out.double() - ref).abs().max()) < 2e-2 * max(1.0, float(ref.abs().max()))
