@@ -370,7 +370,24 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
 #ifndef HUGS_EPI_PLAIN_STORE   // streaming (nontemporal) stores: the 32 MB all workgroups write at the same time do not
                               // push the operand panels out of the 4 MB L2s (in-step A/B: step -1.8 %, forward layer 264 -> 254 us)
         { typedef unsigned __attribute__((ext_vector_type(4))) u32x4_t; const u32x4_t v_ = {vw[0], vw[1], vw[2], vw[3]};
-          __builtin_nontemporal_store(v_, (u32x4_t*)((uint16_t*)E.out + (size_t)(m0 + wm * 128 + i * 16 + h * 8 + srow) * E.ldc + ccol)); }
+          u32x4_t* p_ = (u32x4_t*)((uint16_t*)E.out + (size_t)(m0 + wm * 128 + i * 16 + h * 8 + srow) * E.ldc + ccol);
+#if defined(HUGS_EPI_STORE_MODE)   // measurement builds: explicit cache-policy bits on the output stores
+#if HUGS_EPI_STORE_MODE == 1
+#define HUGS_EPI_STORE_MOD "sc0 sc1"
+#elif HUGS_EPI_STORE_MODE == 2
+#define HUGS_EPI_STORE_MOD "sc1"
+#elif HUGS_EPI_STORE_MODE == 3
+#define HUGS_EPI_STORE_MOD "sc1 nt"
+#elif HUGS_EPI_STORE_MODE == 4
+#define HUGS_EPI_STORE_MOD "sc0 sc1 nt"
+#else
+#define HUGS_EPI_STORE_MOD "nt"
+#endif
+          asm volatile("global_store_dwordx4 %0, %1, off " HUGS_EPI_STORE_MOD :: "v"(p_), "v"(v_) : "memory");
+#else
+          __builtin_nontemporal_store(v_, p_);
+#endif
+        }
 #else
         *(uint4*)((uint16_t*)E.out + (size_t)(m0 + wm * 128 + i * 16 + h * 8 + srow) * E.ldc + ccol) = make_uint4(vw[0], vw[1], vw[2], vw[3]);
 #endif
