@@ -7,7 +7,10 @@ ev = sorted([(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name
 # find the Adam kernels as step boundaries
 adam = [i for i, e in enumerate(ev) if 'k_opt_adam' in e[2]]
 print('steps seen', len(adam))
-a, b = adam[-4], adam[-3]          # one steady-state step
+import os
+k_ = int(os.environ.get('STEP', -4))
+a, b = adam[k_], adam[k_ + 1]          # one steady-state step (STEP: index of the Adam kernel that precedes it; the last 5 steps
+                                       # of a bench run are the event-bracketed roofline leg: use e.g. STEP=5 for a timed step)
 step = ev[a + 1:b + 1]
 t0, t1 = step[0][0], step[-1][1]
 print(f'step wall {(t1-t0)/1e6:.3f} ms, {len(step)} kernels')
