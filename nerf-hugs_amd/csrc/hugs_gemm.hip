@@ -213,7 +213,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(int M, int N, int K1, i
 #endif
 typedef unsigned __attribute__((ext_vector_type(2))) u32x2_t;
 #ifndef HUGS_NT_VARIANT
-#define HUGS_NT_VARIANT 2   // 8 MFMA : 3 ds_read interleave of next-stage fragment reads (A/B-tested: +5 %)
+#define HUGS_NT_VARIANT 2   // 8 MFMA : 3 ds_read interleave of next-stage fragment reads (A/B-tested: +5 %; the finer / DS-first /
+                            // VMEM-slotted interleaves measured in round 1 were slower and are gone)
 #endif
 #define GL_CPAD 16   // bytes added to each row of the staged C tile (bank spread for the 8-byte fragment writes)
 
@@ -478,32 +479,6 @@ __global__ __launch_bounds__(128 * WN, 2) void k_gemm_nt_bf16_big(
       _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                  \
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                \
         __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                                \
-      }                                                                                   \
-    }                                                                                     \
-    if (HUGS_NT_VARIANT == 4) {                                                           \
-      _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) {                                  \
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                \
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                \
-      }                                                                                   \
-    }                                                                                     \
-    if (HUGS_NT_VARIANT == 5) {                                                           \
-      _Pragma("unroll") for (int q_ = 0; q_ < 12; ++q_) {                                 \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                \
-      }                                                                                   \
-    }                                                                                     \
-    if (HUGS_NT_VARIANT == 6) {                                                           \
-      _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                  \
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                \
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                \
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                \
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                                \
-      }                                                                                   \
-    }                                                                                     \
-    if (HUGS_NT_VARIANT == 7) {                                                           \
-      _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                  \
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                                \
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                \
       }                                                                                   \
     }                                                                                     \
   }
@@ -945,17 +920,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(int Mrows, int Kc, int 
 // swizzle: fragment reads are base + immediate, which frees ~25 VGPRs and the XOR arithmetic).  The bias gradient (column sums of G) costs two
 // extra MFMAs per stage against an all-ones fragment instead of a scalar LDS pass.
 // ------------------------------------------------------------------------------------------------
-#ifndef HUGS_TN_SCHED
-#define HUGS_TN_SCHED 4
-#endif
 // Measurement builds only (scratch/tn_exp.sh; results are garbage): bit 0 = no LDS-DMA in the steady-state loop,
-// bit 1 = no fragment ds_reads in the loop, bit 2 = no MFMAs, bit 3 = loads always hit L2, bit 4 = two (not three) stages in flight.
+// bit 1 = no fragment ds_reads in the loop, bit 2 = no MFMAs, bit 3 = loads always hit L2, bit 5 = no barrier, bit 6 = no
+// counted vmcnt wait.  (Round-2 experiments that are gone from the source: 8:6 / 4:3 / DS-first sched_group_barrier
+// interleaves of an un-fenced iteration, and an L2 prefetch of the XCD siblings' lines 4 / 8 / 16 stages ahead through a
+// 4-byte LDS-DMA into a sink -- DESIGN.md section 4 has their numbers.)
 #ifndef HUGS_TN_EXP
 #define HUGS_TN_EXP 0
-#endif
-// L2 prefetch distance of the TN kernel in K-stages beyond the LDS-DMA front (0 = off)
-#ifndef HUGS_TN_PF
-#define HUGS_TN_PF 0
 #endif
 __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, int N, int nsplit,
                                                               const uint16_t* __restrict__ X, int ldx,
@@ -967,7 +938,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
   // (1056 B = 264 dwords = 8 mod 64) with NO address swizzle: every fragment read is base + immediate.
   constexpr int NSLOT = 4, PAIR = 1056, XB = 16 * PAIR, STAGE = 2 * XB;
   constexpr int RING = 128 * 1040 > NSLOT * STAGE ? 128 * 1040 : NSLOT * STAGE;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[RING + 2048];      // + 256 B per wave: sink of the L2 prefetches
+  __shared__ __attribute__((aligned(16))) unsigned char lds[RING];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntn = N >> 8, ntk = Kc >> 8, tiles = ntn * ntk;
@@ -999,25 +970,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
       dma16((const char*)(X + (size_t)(mrow0 + 2 * pair) * ldx + c0), voX, l + pair * PAIR);
       dma16((const char*)(G + (size_t)(mrow0 + 2 * pair) * ldg + n0), voG, l + XB + pair * PAIR);
     }
-  };
-
-  // L2 prefetch.  The LDS-DMA front runs 3 stages (96 KB per CU) ahead -- all the ring holds -- which does not cover an HBM
-  // miss, and every stage has one: the rows are new.  So each workgroup also touches, HUGS_TN_PF stages further ahead,
-  // its share of the lines its XCD siblings will need (the 4 workgroups with the same c0 read the same X rows, the 4 with
-  // the same n0 the same G rows: each takes 8 of a stage's 32 rows): one 4-byte-per-lane LDS-DMA into a sink, 8 lanes per
-  // 128-byte line, waves 0-3 on X and 4-7 on G, no VGPR results and no lane masking.  It rides the same in-order vmcnt
-  // queue as the stage loads (one more entry per iteration).
-  const int pf_line = (wv & 3) * 8 + (lane >> 3);
-  const int pf_ld = wv < 4 ? ldx : ldg;
-  const unsigned pf_voff = (unsigned)((pf_line >> 2) * pf_ld) * 2u + (unsigned)((pf_line & 3) * 128 + (lane & 7) * 16);
-  const char* pf_base = wv < 4 ? (const char*)(X + (size_t)(mbeg + (((tt % ntn) * 8) & 31)) * ldx + c0)
-                               : (const char*)(G + (size_t)(mbeg + (((tt / ntn) * 8) & 31)) * ldg + n0);
-  const size_t pf_step = (size_t)pf_ld * 64;      // 32 rows
-  const unsigned pf_sink = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + RING + (unsigned)wv * 256u;
-  auto prefetch = [&](int pst) {
-    pst = pst < ns ? pst : ns - 1;
-    const char* sb = pf_base + (size_t)pst * pf_step;
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" ::"s"(sb), "v"(pf_voff), "s"(pf_sink) : "memory", "m0");
   };
 
   f32x4_t acc[8][4];
@@ -1067,7 +1019,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
         accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[2 * WK + 1], ones, accb[1], 0, 0, 0);
       }
     };
-    // HUGS_TN_SCHED == 4: an iteration in four fenced quarters of {1 LDS-DMA, 6 transpose reads, 8 MFMAs}.  With the four
+    // An iteration in four fenced quarters of {1 LDS-DMA, 6 transpose reads, 8 MFMAs}.  With the four
     // DMAs issued back to back behind the barrier, 8 waves push 32 KB into the CU's one vector-memory path at once and
     // every wave sits in VMEM issue (no MFMA behind it can go: in-order issue) until the queue has drained.
     auto stage_piece = [&](int st, int q) {
@@ -1120,75 +1072,22 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
     asm volatile("" ::: "memory");                                        \
     GT_Q(cur, nxt, st, 0, DOST) GT_Q(cur, nxt, st, 1, DOST) GT_Q(cur, nxt, st, 2, DOST) GT_Q(cur, nxt, st, 3, DOST) \
   }
-#define GT_ITER(cur, nxt, st, VM)                                         \
-  {                                                                       \
-    asm volatile("s_waitcnt vmcnt(" HUGS_STR(VM) ") lgkmcnt(0)" ::: "memory"); \
-    __builtin_amdgcn_s_barrier();                                         \
-    asm volatile("" ::: "memory");                                        \
-    if (!(HUGS_TN_EXP & 1)) { if ((st) + NSLOT < ns) stage((st) + NSLOT); } \
-    if (HUGS_TN_PF) prefetch((st) + NSLOT + HUGS_TN_PF);                  \
-    if (!(HUGS_TN_EXP & 2)) load_frags(nxt, (st) + 1);                    \
-    else asm volatile("" : "+v"(nxt.ga[0]), "+v"(nxt.xb[0]));             \
-    if (!(HUGS_TN_EXP & 4)) mfmas(cur);                                   \
-    else { _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) asm volatile("" :: "v"(cur.ga[i_])); \
-           _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) asm volatile("" :: "v"(cur.xb[j_])); } \
-    if (HUGS_TN_SCHED == 1) {                                             \
-      _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                  \
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                \
-        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                \
-      }                                                                   \
-    }                                                                     \
-    if (HUGS_TN_SCHED == 2) {                                             \
-      _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                  \
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                \
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                \
-      }                                                                   \
-    }                                                                     \
-    if (HUGS_TN_SCHED == 3) {                                             \
-      _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                  \
-        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                \
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                \
-      }                                                                   \
-    }                                                                     \
-  }
-    // steady state per wave and iteration: 4 stage loads, then 1 prefetch; the wait for stage st+1 leaves the 2 younger
-    // stages and 3 prefetches outstanding (11).  The prologue issues in the same pattern so that the count holds from st = 0.
-#if HUGS_TN_PF
-#define GT_VM 11
-    stage(0); stage(1); prefetch(NSLOT + HUGS_TN_PF - 3); stage(2); prefetch(NSLOT + HUGS_TN_PF - 2); stage(3);
-    prefetch(NSLOT + HUGS_TN_PF - 1);
-    asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-#else
-#define GT_VM 8
 #pragma unroll
     for (int q = 0; q < NSLOT; ++q) stage(q);
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-#endif
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     load_frags(f0, 0);
     int st = 0;
-#if HUGS_TN_EXP & 16
-    for (; st + 5 < ns; st += 2) { GT_ITER(f0, f1, st, 4) GT_ITER(f1, f0, st + 1, 4) }
-#elif HUGS_TN_SCHED == 4
     for (; st + 5 < ns; st += 2) { GT_ITER4(f0, f1, st, HUGS_TN_VM, 1) GT_ITER4(f1, f0, st + 1, HUGS_TN_VM, 1) }
-#else
-    for (; st + 5 < ns; st += 2) { GT_ITER(f0, f1, st, GT_VM) GT_ITER(f1, f0, st + 1, GT_VM) }
-#endif
-#if HUGS_TN_SCHED == 4
     GT_ITER4(f0, f1, st, 8, 0)
-#else
-    GT_ITER(f0, f1, st, GT_VM)
-#endif
     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
     load_frags(f0, st + 2); mfmas(f1);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
     load_frags(f1, st + 3); mfmas(f0);
     mfmas(f1);
-#undef GT_ITER
 #undef GT_ITER4
 #undef GT_Q
-#undef GT_VM
   };
   if (!do_colsum) run(std::integral_constant<int, -1>{});
   else if (wk == 0) run(std::integral_constant<int, 0>{});

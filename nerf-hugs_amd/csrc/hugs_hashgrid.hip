@@ -19,14 +19,15 @@ namespace {
 
 // tiny-cuda-nn grid_index: dense levels index x + y res + z res^2, hashed ones x ^ y p1 ^ z p2, both modulo the level's
 // entry count.  The modulo is never a division here: a dense level has res^3 <= entries and corner coordinates <= res, so
-// the index is below 2 * entries (one conditional subtraction); a hashed level's count is 2^log2_hashmap_size (a mask) --
+// the index of a point inside the unit cube is below 2 * entries (one conditional subtraction); a hashed level's count is 2^log2_hashmap_size (a mask) --
 // anything else takes the generic remainder.  (Eight 32-bit remainders per sample and level were most of the forward
 // kernel's instructions.)
 template <int F>
 __device__ __forceinline__ uint32_t hg_index(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t res, uint32_t entries, bool dense) {
   if (dense) {
-    const uint32_t idx = cx + cy * res + cz * res * res;
-    return idx >= entries ? idx - entries : idx;
+    uint32_t idx = cx + cy * res + cz * res * res;
+    if (idx >= entries) { idx -= entries; if (idx >= entries) idx %= entries; }      // (second case: points outside [0,1]^3 only)
+    return idx;
   }
   const uint32_t idx = (cx * 1u) ^ (cy * 2654435761u) ^ (cz * 805459861u);
   return (entries & (entries - 1u)) == 0u ? (idx & (entries - 1u)) : idx % entries;
