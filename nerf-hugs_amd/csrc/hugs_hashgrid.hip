@@ -76,13 +76,13 @@ k_hashgrid_fwd(int n, int L, HgLevels lv, const float* __restrict__ x, const flo
 template <int F, bool BF16>
 __global__ void __launch_bounds__(256)
 k_hashgrid_bwd(int n, int L, HgLevels lv, const float* __restrict__ x, const void* __restrict__ d_out, int row_pitch,
-               float* __restrict__ d_table) {
+               float* __restrict__ d_table, int l_begin) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool live = i < n;
   const int ii = live ? i : n - 1;
   const float px = x[3 * ii], py = x[3 * ii + 1], pz = x[3 * ii + 2];
-  for (int l = 0; l < L; ++l) {
+  for (int l = l_begin; l < L; ++l) {
     const uint32_t res = lv.res[l], entries = lv.off[l + 1] - lv.off[l];
     const bool dense = (uint64_t)res * res * res <= entries;
     const float sc = lv.scale[l];
@@ -162,6 +162,80 @@ k_hashgrid_bwd(int n, int L, HgLevels lv, const float* __restrict__ x, const voi
   }
 }
 
+// Level 0 in LDS.  The coarsest level (16^3 cells: 4913 entries) receives every sample's gradient in a few thousand
+// addresses: the most contended -- and, per level, the most expensive -- part of the global scatter.  Here a persistent
+// workgroup accumulates it in a private LDS copy of the level (ds_add_f32; runs of lanes in one cell are summed first, as in
+// the global kernel) and adds the copy to the table once at the end: neighbouring lanes, neighbouring floats, so 16 floats per
+// atomic transaction.  Used when the level is dense and fits HG_L0_MAX_FLOATS.
+#define HG_L0_MAX_FLOATS 12288      // 48 KiB
+template <int F, bool BF16>
+__global__ void __launch_bounds__(256)
+k_hashgrid_bwd_l0(int n, HgLevels lv, const float* __restrict__ x, const void* __restrict__ d_out, int row_pitch,
+                  float* __restrict__ d_table) {
+  __shared__ float acc[HG_L0_MAX_FLOATS];
+  const uint32_t res = lv.res[0], entries = lv.off[1] - lv.off[0];
+  const int nfl = (int)entries * F;
+  for (int e = threadIdx.x; e < nfl; e += 256) acc[e] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const float sc = lv.scale[0];
+  const int ntile = (n + 255) / 256;
+  for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+    const int i = t * 256 + threadIdx.x;
+    const bool live = i < n;
+    const int ii = live ? i : n - 1;
+    const float fx = fmaf(x[3 * ii], sc, .5f), fy = fmaf(x[3 * ii + 1], sc, .5f), fz = fmaf(x[3 * ii + 2], sc, .5f);
+    const float gx = floorf(fx), gy = floorf(fy), gz = floorf(fz);
+    const float wx = fx - gx, wy = fy - gy, wz = fz - gz;
+    const uint32_t cx = (uint32_t)(int)gx, cy = (uint32_t)(int)gy, cz = (uint32_t)(int)gz;
+    float g[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+      g[f] = !live ? 0.f : BF16 ? bf16_to_f(((const uint16_t*)d_out)[(size_t)ii * row_pitch + f])
+                                : ((const float*)d_out)[(size_t)ii * row_pitch + f];
+    float v[8][F];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float w = ((c & 1) ? wx : 1.f - wx) * ((c & 2) ? wy : 1.f - wy) * ((c & 4) ? wz : 1.f - wz);
+#pragma unroll
+      for (int f = 0; f < F; ++f) v[c][f] = w * g[f];
+    }
+    const uint32_t pcx = __shfl_up(cx, 1), pcy = __shfl_up(cy, 1), pcz = __shfl_up(cz, 1);
+    const int plive = __shfl_up((int)live, 1);
+    const int head = (lane == 0) || !plive || pcx != cx || pcy != cy || pcz != cz || !live;
+    if (__ballot(!head) != 0ull) {
+      int fl = head;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int tf = __shfl_up(fl, d);
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+          for (int f = 0; f < F; ++f) {
+            const float tv = __shfl_up(v[c][f], d);
+            if (lane >= d && !fl) v[c][f] += tv;
+          }
+        if (lane >= d) fl |= tf;
+      }
+    }
+    const int nhead = __shfl_down(head, 1);
+    if (live && (lane == 63 || nhead)) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const uint32_t idx = hg_index<F>(cx + (c & 1), cy + ((c >> 1) & 1), cz + ((c >> 2) & 1), res, entries, true);
+#pragma unroll
+        for (int f = 0; f < F; ++f) atomicAdd(&acc[idx * F + f], v[c][f]);
+      }
+    }
+  }
+  __syncthreads();
+  float* tb = d_table + (size_t)lv.off[0] * F;
+  for (int e = threadIdx.x; e < nfl; e += 256) {
+    const float a = acc[e];
+    if (a != 0.f) atomicAdd(tb + e, a);
+  }
+}
+
 template <bool BF16>
 __global__ void __launch_bounds__(256)
 k_sh4(int n, const float* __restrict__ d01, int row_pitch, int col0, void* __restrict__ out) {
@@ -237,12 +311,28 @@ extern "C" int hugs_hashgrid_bwd(int n, int n_levels, int features, const long l
   if (n <= 0) return 0;
   const dim3 g((n + 255) / 256), b(256);
   hipStream_t st = (hipStream_t)stream;
+  // level 0 through LDS when it is dense and small (see k_hashgrid_bwd_l0); the global kernel then starts at level 1
+  const unsigned long long r0 = (unsigned long long)lv.res[0];
+  const unsigned e0 = lv.off[1] - lv.off[0];
+  int l_begin = 0;
+  if (r0 * r0 * r0 <= e0 && (long long)e0 * features <= HG_L0_MAX_FLOATS && n >= 65536) {
+    const int g0 = (int)(((n + 255) / 256) < 768 ? ((n + 255) / 256) : 768);
+    if (features == 2) {
+      if (d_out_bf16) k_hashgrid_bwd_l0<2, true><<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum);
+      else k_hashgrid_bwd_l0<2, false><<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum);
+    } else {
+      if (d_out_bf16) k_hashgrid_bwd_l0<4, true><<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum);
+      else k_hashgrid_bwd_l0<4, false><<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum);
+    }
+    l_begin = 1;
+    if (n_levels == 1) { HUGS_CHECK_LAUNCH("k_hashgrid_bwd_l0"); return 0; }
+  }
   if (features == 2) {
-    if (d_out_bf16) k_hashgrid_bwd<2, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum);
-    else k_hashgrid_bwd<2, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum);
+    if (d_out_bf16) k_hashgrid_bwd<2, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin);
+    else k_hashgrid_bwd<2, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin);
   } else {
-    if (d_out_bf16) k_hashgrid_bwd<4, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum);
-    else k_hashgrid_bwd<4, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum);
+    if (d_out_bf16) k_hashgrid_bwd<4, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin);
+    else k_hashgrid_bwd<4, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin);
   }
   HUGS_CHECK_LAUNCH("k_hashgrid_bwd");
   return 0;

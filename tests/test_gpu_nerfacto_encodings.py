@@ -84,3 +84,26 @@ def test_sh4_vs_oracle_and_orthonormal():
   out = torch.zeros(5, 32, device='cuda', dtype=torch.bfloat16)
   E.spherical_harmonics4(torch.from_numpy(d01[:5]).cuda(), out=out, col0=16)
   assert float(out[:, :16].abs().max()) == 0 and float((out[:, 16:].float().cpu() - torch.from_numpy(got[:5]).float()).abs().max()) < 1e-2
+
+
+@pytest.mark.parametrize('F', [2, 4])
+def test_hashgrid_backward_many_ray_ordered_samples(F):
+  """>= 65536 samples in ray order (runs of samples inside one coarse cell): the size at which level 0 is accumulated in LDS
+  by persistent workgroups and the other levels use the quad-cooperative atomics; against the numpy oracle."""
+  from oracle import hashgrid_ref as H
+  kw = dict(n_levels=4, features_per_level=F, log2_hashmap_size=12, base_resolution=16, max_resolution=96)
+  g = _grid(**kw)
+  offs, ress, scales = H.level_table(4, 16, np.exp((np.log(96) - np.log(16)) / 3), 12)
+  rng = np.random.default_rng(3)
+  nr, S = 560, 128                                  # 71680 samples
+  o = rng.uniform(0.3, 0.7, (nr, 1, 3)); d = rng.normal(size=(nr, 1, 3)); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+  x = np.clip(o + d * np.linspace(0, 0.5, S)[None, :, None], 0, 1).reshape(-1, 3).astype(np.float32)
+  d_out = rng.normal(size=(x.shape[0], 4 * F)).astype(np.float32)
+  gw = H.hashgrid_backward(x, d_out, g.n_entries, offs, ress, scales, F)
+  d_table = torch.zeros_like(g.table)
+  g.backward(torch.from_numpy(x).cuda(), torch.from_numpy(d_out).cuda(), d_table)
+  err = np.abs(d_table.cpu().numpy() - gw).max()
+  assert err < 3e-4 * max(1, np.abs(gw).max()), err
+  # level 0 alone (the LDS path) and the rest separately
+  n0 = int(offs[1])
+  assert np.abs(d_table.cpu().numpy()[:n0] - gw[:n0]).max() < 3e-4 * np.abs(gw[:n0]).max()
