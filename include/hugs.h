@@ -30,7 +30,7 @@ int hugs_device_count(void);
  * models.py:191-193 annealed logits -> stepfun.py:131-161 softmax CDF + math.py:108-127 sorted_interp ->
  * stepfun.py:214-263 sample_intervals -> coord.py:63-99 s_to_t.  One wavefront per ray.
  * t_prev [nrays, n_prev+1], w_prev [nrays, n_prev]; u = u_base[j] + jitter[ray*jitter_stride (+j)] (jitter may
- * be NULL = rng None).  raydist (coord.py:84-90): 0 None, 1 reciprocal, 2 log, 3 exp, 4 sqrt, 5 square.  Outputs sdist,tdist [nrays, num_samples+1];
+ * be NULL = rng None).  raydist (coord.py:78-90): 0 None, 1 reciprocal, 2 log, 3 exp, 4 sqrt, 5 square, 6 piecewise.  Outputs sdist,tdist [nrays, num_samples+1];
  * optional test hooks idx_out [nrays,num_samples] (CDF interval index), t_in_out/w_in_out (the dilated,
  * trimmed step function).  Bit-exact against oracle/stepfun_ref.c.  -2 if num_samples <= 1 (stepfun.py:239). */
 int hugs_level_sample_fwd(int nrays, const float* t_prev, const float* w_prev, int n_prev, int do_dilate,

@@ -50,6 +50,7 @@ __device__ __forceinline__ float sf_raywarp(float x, int raydist, bool inverse) 
     case 3: return inverse ? sf_logf(x) : sf_expf(x);
     case 4: return inverse ? x * x : sqrtf(x);
     case 5: return inverse ? sqrtf(x) : x * x;
+    case 6: return inverse ? (x < 0.5f ? 2.0f * x : 0.5f / (1.0f - x)) : (x < 1.0f ? 0.5f * x : 1.0f - 0.5f / x);   // 'piecewise', coord.py:81-84
     default: return x;
   }
 }
@@ -301,7 +302,7 @@ extern "C" int hugs_level_sample_fwd(int nrays, const float* t_prev, const float
   int n_in = do_dilate ? 3 * n_prev : n_prev;
   HUGS_REQUIRE(n_prev >= 1 && n_in <= SF_CAP, -3, "hugs_level_sample_fwd: %d input bins (%d after dilation) > capacity %d",
                n_prev, n_in, SF_CAP);
-  HUGS_REQUIRE(raydist >= 0 && raydist <= 5, -4, "hugs_level_sample_fwd: raydist must be 0 (None), 1 reciprocal, 2 log, 3 exp, 4 sqrt or 5 square");
+  HUGS_REQUIRE(raydist >= 0 && raydist <= 6, -4, "hugs_level_sample_fwd: raydist must be 0 (None), 1 reciprocal, 2 log, 3 exp, 4 sqrt, 5 square or 6 piecewise");
   if (nrays <= 0) return 0;
   // one lane-chunk for the whole level, chosen from its largest array (the oracle applies the same rule)
   const int big = n_in > num_samples ? n_in : num_samples;

@@ -53,7 +53,7 @@ class Model:
     name = None if rd is None else getattr(rd, 'name', rd)
     self.raydist = None if name is None else (name[4:] if str(name).startswith('jnp.') else name)
     if self.raydist not in stepfun.RAYDIST:        # coord.py:84-90 knows reciprocal / log / exp / sqrt / square (+ 'piecewise')
-      raise NotImplementedError(f"raydist_fn {rd!r}: built are None and @jnp.reciprocal / log / exp / sqrt / square")
+      raise NotImplementedError(f"raydist_fn {rd!r}: coord.py:78-90 knows None, 'piecewise' and @jnp.reciprocal / log / exp / sqrt / square")
     # models.py:104-105: NerfMLP(disable_transient=(transient_type != 'nerfw')), PropMLP(disable_transient=True)
     self.nerf_spec = _engine.MLPSpec('NerfMLP_0', False, self.num_glo_features,
                                      self.num_transient_features if tt == 'nerfw' else 0, **configs.bindings('NerfMLP'))

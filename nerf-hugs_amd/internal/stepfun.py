@@ -48,7 +48,7 @@ def _u_base_on_device(num_samples, randomized, dev):
   return hit
 
 
-RAYDIST = {None: 0, 'reciprocal': 1, 'log': 2, 'exp': 3, 'sqrt': 4, 'square': 5}      # kernel codes (coord.py:84-90)
+RAYDIST = {None: 0, 'reciprocal': 1, 'log': 2, 'exp': 3, 'sqrt': 4, 'square': 5, 'piecewise': 6}      # kernel codes (coord.py:78-90)
 
 
 def level_sample(t_prev, w_prev, do_dilate, dilation, domain, anneal, resample_padding, num_samples, u01,
@@ -79,8 +79,8 @@ def level_sample(t_prev, w_prev, do_dilate, dilation, domain, anneal, resample_p
     w_in = torch.empty(N, n_in, device=dev)
   rd = RAYDIST.get(raydist)
   if rd is None:
-    raise NotImplementedError(f"raydist_fn {raydist!r}: built are None and jnp.reciprocal / log / exp / sqrt / square "
-                              "(coord.py:84-90); 'piecewise' is not")
+    raise NotImplementedError(f"raydist_fn {raydist!r}: coord.py:78-90 knows None, 'piecewise' and jnp.reciprocal / log / exp / "
+                              "sqrt / square")
   _lib.call('hugs_level_sample_fwd', N, t_prev.contiguous(), w_prev.contiguous(), n_prev, int(do_dilate), dilation,
             domain[0], domain[1], anneal, resample_padding, ub, jitter, stride, num_samples, rd,
             near.reshape(-1).contiguous(), far.reshape(-1).contiguous(), sdist, tdist, idx, t_in, w_in)

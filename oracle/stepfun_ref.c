@@ -245,6 +245,7 @@ static float orc_raywarp(float x, int raydist, int inverse) {
     case 3: return inverse ? orc_logf(x) : orc_expf(x);
     case 4: return inverse ? x * x : sqrtf(x);
     case 5: return inverse ? sqrtf(x) : x * x;
+    case 6: return inverse ? (x < 0.5f ? 2.0f * x : 0.5f / (1.0f - x)) : (x < 1.0f ? 0.5f * x : 1.0f - 0.5f / x);   /* 'piecewise', coord.py:81-84 */
     default: return x;
   }
 }

@@ -119,14 +119,15 @@ def contract_track_linearize(mean, cov):
   return contract(mean), J @ cov @ J.transpose(-1, -2)
 
 
-RAYDIST = {None: 0, 'reciprocal': 1, 'log': 2, 'exp': 3, 'sqrt': 4, 'square': 5}
+RAYDIST = {None: 0, 'reciprocal': 1, 'log': 2, 'exp': 3, 'sqrt': 4, 'square': 5, 'piecewise': 6}
 
 
 def s_to_t(s, near, far, raydist):
   """coord.py:63-99: fn_inv(s * fn(far) + (1 - s) * fn(near)) with the (fn, fn_inv) pairs of :84-90."""
   fwd, inv = {None: (lambda x: x, lambda x: x), 'reciprocal': (torch.reciprocal, torch.reciprocal),
               'log': (torch.log, torch.exp), 'exp': (torch.exp, torch.log), 'sqrt': (torch.sqrt, torch.square),
-              'square': (torch.square, torch.sqrt)}[raydist]
+              'square': (torch.square, torch.sqrt),
+              'piecewise': (lambda x: torch.where(x < 1, .5 * x, 1 - .5 / x), lambda x: torch.where(x < .5, 2 * x, .5 / (1 - x)))}[raydist]
   return inv(s * fwd(far) + (1 - s) * fwd(near))
 
 

@@ -341,7 +341,8 @@ def main():
     return fn
   for name, fn in (('none', None), ('reciprocal', named('reciprocal', lambda x: np.reciprocal(x))),
                    ('log', named('log', lambda x: np.log(x))), ('exp', named('exp', lambda x: np.exp(x))),
-                   ('sqrt', named('sqrt', lambda x: np.sqrt(x))), ('square', named('square', lambda x: np.square(x)))):
+                   ('sqrt', named('sqrt', lambda x: np.sqrt(x))), ('square', named('square', lambda x: np.square(x))),
+                   ('piecewise', 'piecewise')):
     fv = np.minimum(farv, 40.0) if name == 'exp' else farv          # exp(1e3) overflows float32
     t_to_s, s_to_t = coord.construct_ray_warps(fn, nearv, fv)
     out[f'unit/raywarp/{name}/t'] = np.asarray(s_to_t(sv), f32)

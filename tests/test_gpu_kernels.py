@@ -53,7 +53,7 @@ def _run_level(N, n_prev, ns, dil, raydist, jitter, seed, wpow=1, zeros=False, a
   far = np.full(N, {0: 1.2, 1: 1e6, 3: 5.0}.get(raydist, 300.0), np.float32)
   sd_o, td_o, idx_o = C.level_sample(t, w, dil is not None, dil or 0., 0., 1., anneal, 0., ub, jit, raydist, near, far)
   sd, td, idx, tin, win = stepfun.level_sample(G(t), G(w), dil is not None, dil or 0., (0., 1.), anneal, 0., ns,
-                                               None if u01 is None else G(u01), [None, 'reciprocal', 'log', 'exp', 'sqrt', 'square'][raydist],
+                                               None if u01 is None else G(u01), [None, 'reciprocal', 'log', 'exp', 'sqrt', 'square', 'piecewise'][raydist],
                                                G(near), G(far), return_debug=True)
   assert np.array_equal(idx.cpu().numpy(), idx_o), 'interval indices'
   assert np.array_equal(bits(sd.cpu().numpy()), bits(sd_o)), 'sdist'
@@ -87,6 +87,7 @@ def _run_level(N, n_prev, ns, dil, raydist, jitter, seed, wpow=1, zeros=False, a
     dict(N=200, n_prev=64, ns=64, dil=0.0103125, raydist=3, jitter=False),
     dict(N=200, n_prev=64, ns=128, dil=0.0103125, raydist=4, jitter=True),
     dict(N=200, n_prev=64, ns=32, dil=0.0103125, raydist=5, jitter=True),
+    dict(N=200, n_prev=64, ns=64, dil=0.0103125, raydist=6, jitter=True),       # 'piecewise' (coord.py:81-84)
 ])
 def test_level_sample_bit_exact_vs_oracle(case):
   _run_level(seed=3, **case)

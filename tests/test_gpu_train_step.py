@@ -94,6 +94,14 @@ def test_train_step_default3_charb_contract_glo():
   _run_case(gin, near=(0.05, 0.3), far=1e6, tol_grad=1e-1)
 
 
+def test_train_step_piecewise_raydist():
+  """Model.raydist_fn = 'piecewise' (coord.py:81-84: identity below 1, 1 - .5 / t beyond: near may be 0) with the contraction."""
+  gin = [g for g in SMALL if not g.startswith('Model.num_')] + [
+      "Model.num_levels = 2", "Model.num_prop_samples = 32", "Model.num_nerf_samples = 32",
+      "Model.raydist_fn = 'piecewise'", "NerfMLP.warp_fn = @coord.contract", "PropMLP.warp_fn = @coord.contract"]
+  _run_case(gin, near=(0.0, 0.2), far=50.0, tol_grad=1e-1)
+
+
 def test_train_step_static_mask():
   gin = [g for g in SMALL if 'data_loss_type' not in g] + ["Config.transient_type = 'withmask'",
                                                            "Model.num_glo_features = 48"]

@@ -231,7 +231,7 @@ def test_ray_warps_vs_reference():
   s_to_t, and the C oracle's canonical-arithmetic tdist (polynomial exp / log) against the torch oracle."""
   z = FX.npz()
   s, near, far = (torch.from_numpy(z[f'unit/raywarp/{k}'].copy()) for k in ('s', 'near', 'far'))
-  for name in ('none', 'reciprocal', 'log', 'exp', 'sqrt', 'square'):
+  for name in ('none', 'reciprocal', 'log', 'exp', 'sqrt', 'square', 'piecewise'):
     rd = None if name == 'none' else name
     fv = torch.clamp(far, max=40.0) if name == 'exp' else far
     t = R.s_to_t(s, near, fv, rd)
@@ -241,4 +241,5 @@ def test_ray_warps_vs_reference():
     sd, td, _ = cstepfun.level_sample(np.tile([[0., 1.]], (3, 1)), np.ones((3, 1), np.float32), False, 0., 0., 1., 1., 0.,
                                       ub, None, R.RAYDIST[rd], near.numpy(), fv.numpy())
     ref = R.s_to_t(torch.from_numpy(sd).double(), near.double(), fv.double(), rd).numpy()
-    np.testing.assert_allclose(td, ref, rtol=2e-6, err_msg=name)
+    # ('piecewise' inverts through .5 / (1 - x): float32 cancellation in 1 - x as t -> far = 1e3 costs ~5e-5 against float64)
+    np.testing.assert_allclose(td, ref, rtol=1e-4 if name == 'piecewise' else 2e-6, err_msg=name)
