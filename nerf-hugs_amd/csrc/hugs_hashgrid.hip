@@ -122,7 +122,14 @@ k_hashgrid_bwd(int n, int L, HgLevels lv, const float* __restrict__ x, const voi
       }
     }
     const int nhead = __shfl_down(head, 1);
-    const bool tail = live && (lane == 63 || nhead);      // the last lane of a run carries the run's sums
+    // the last lane of a run carries the run's sums; a run whose sums are all zero adds nothing (samples outside the
+    // scene box, fully occluded ones: their output gradient is exactly 0 -- a large share of a real batch)
+    bool nz = false;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int f = 0; f < F; ++f) nz |= v[c][f] != 0.f;
+    const bool tail = live && nz && (lane == 63 || nhead);
     float* tb = d_table + (size_t)lv.off[l] * F;
     if constexpr (F == 2) {
       // The chip retires ~21 G atomic TRANSACTIONS per second, not atomics: neighbouring lanes of one instruction that hit
@@ -219,7 +226,12 @@ k_hashgrid_bwd_l0(int n, HgLevels lv, const float* __restrict__ x, const void* _
       }
     }
     const int nhead = __shfl_down(head, 1);
-    if (live && (lane == 63 || nhead)) {
+    bool nz = false;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int f = 0; f < F; ++f) nz |= v[c][f] != 0.f;
+    if (live && nz && (lane == 63 || nhead)) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const uint32_t idx = hg_index<F>(cx + (c & 1), cy + ((c >> 1) & 1), cz + ((c >> 2) & 1), res, entries, true);
