@@ -625,11 +625,23 @@ __global__ __launch_bounds__(256, 2) void k_nf_prop_bwd(long long M, int in_dim,
     // d raw = d density * exp(clamp(raw, -15, 15)) * selector (custom_functions.py:46-50)
     const float r = valid ? d_density[mm] * expf(fminf(fmaxf(raw[mm], -15.f), 15.f)) * sel[mm] : 0.f;
     ab1 += r;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) dx[k] = 0.f;
+    if (__ballot(r != 0.f) == 0ull) {             // a wave of samples without gradient (outside the box, zero weight): dX = 0, done
+      if (valid) {
+        if (BF16) {
+#pragma unroll
+          for (int c = 0; c < KP / 8; ++c) *(uint4*)((uint16_t*)dX + (size_t)m * ldx + c * 8) = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+#pragma unroll
+          for (int c = 0; c < KP / 4; ++c) *(float4*)((float*)dX + (size_t)m * ldx + c * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      continue;
+    }
     rs[lane] = r;
 #pragma unroll
     for (int k = 0; k < KP; k += 4) *(float4*)(xs + lane * KP + k) = make_float4(x[k], x[k + 1], x[k + 2], x[k + 3]);
-#pragma unroll
-    for (int k = 0; k < KP; ++k) dx[k] = 0.f;
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       // ---- hidden pre-activations of this lane's sample (units 32 hh ..) -> T, and their share of dx ----
