@@ -32,14 +32,21 @@ __global__ __launch_bounds__(256) void k_opt_stats(const OptChunk* __restrict__ 
   __shared__ float red[4];
   const OptChunk c = chunks[blockIdx.x];
   float sg = 0.f, mg = 0.f, st = 0.f, sc = 0.f;
-  for (int i = threadIdx.x; i < c.len; i += 256) {
-    const float g = grad[c.off + i] * gscale, t = theta[c.off + i];
+  auto one = [&](float g, float t) {
+    g *= gscale;
     sg += g * g;
     mg = fmaxf(mg, fabsf(g));   // NaN-ignoring like jnp.max? jnp.max propagates NaN; handled via sg
     st += t * t;
     const float gc = max_val > 0.f ? fminf(fmaxf(g, -max_val), max_val) : g;
     sc += gc * gc;
+  };
+  // chunk offsets are multiples of 4 floats (leaves are padded to 4): 16-byte accesses, scalar tail
+  const int nv = (c.off & 3) ? 0 : (c.len >> 2);
+  for (int i = threadIdx.x; i < nv; i += 256) {
+    const float4 g = *(const float4*)(grad + c.off + 4 * i), t = *(const float4*)(theta + c.off + 4 * i);
+    one(g.x, t.x); one(g.y, t.y); one(g.z, t.z); one(g.w, t.w);
   }
+  for (int i = 4 * nv + threadIdx.x; i < c.len; i += 256) one(grad[c.off + i], theta[c.off + i]);
   sg = block_sum256(sg, red); mg = block_max256(mg, red); st = block_sum256(st, red); sc = block_sum256(sc, red);
   if (threadIdx.x == 0) { float* o = part1 + (size_t)blockIdx.x * 4; o[0] = sg; o[1] = mg; o[2] = st; o[3] = sc; }
 }
@@ -85,23 +92,34 @@ __global__ __launch_bounds__(256) void k_opt_adam(const OptChunk* __restrict__ c
   float sd = 0.f, md = 0.f;
   if (!trainable || trainable[c.leaf]) {
     const float mult = mod_scale[c.module];
-    for (int i = threadIdx.x; i < c.len; i += 256) {
-      const int ix = c.off + i;
-      float g = grad[ix] * gscale;
+    auto one = [&](float g, float& mi, float& vi, float& th) {
+      g *= gscale;
       if (max_val > 0.f) g = fminf(fmaxf(g, -max_val), max_val);
       g = mult * g;
       if (g != g) g = 0.f;                               // nan_to_num
       else if (g == __builtin_inff()) g = 3.4028234664e38f;
       else if (g == -__builtin_inff()) g = -3.4028234664e38f;
-      const float mi = b1 * m[ix] + (1.f - b1) * g;
-      const float vi = b2 * v[ix] + (1.f - b2) * g * g;
-      m[ix] = mi; v[ix] = vi;
+      mi = b1 * mi + (1.f - b1) * g;
+      vi = b2 * vi + (1.f - b2) * g * g;
       const float delta = -lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
-      const float t0 = theta[ix];
-      const float t1 = t0 + delta;
-      theta[ix] = t1;
-      const float d = t1 - t0;                           // the reference reports new - old
+      const float t0 = th;
+      th = t0 + delta;
+      const float d = th - t0;                           // the reference reports new - old
       sd += d * d; md = fmaxf(md, fabsf(d));
+    };
+    const int nv = (c.off & 3) ? 0 : (c.len >> 2);       // 16-byte accesses (chunk offsets are multiples of 4 floats), scalar tail
+    for (int i = threadIdx.x; i < nv; i += 256) {
+      const int ix = c.off + 4 * i;
+      const float4 g = *(const float4*)(grad + ix);
+      float4 mi = *(const float4*)(m + ix), vi = *(const float4*)(v + ix), th = *(const float4*)(theta + ix);
+      one(g.x, mi.x, vi.x, th.x); one(g.y, mi.y, vi.y, th.y); one(g.z, mi.z, vi.z, th.z); one(g.w, mi.w, vi.w, th.w);
+      *(float4*)(m + ix) = mi; *(float4*)(v + ix) = vi; *(float4*)(theta + ix) = th;
+    }
+    for (int i = 4 * nv + threadIdx.x; i < c.len; i += 256) {
+      const int ix = c.off + i;
+      float mi = m[ix], vi = v[ix], th = theta[ix];
+      one(grad[ix], mi, vi, th);
+      m[ix] = mi; v[ix] = vi; theta[ix] = th;
     }
   }
   sd = block_sum256(sd, red); md = block_max256(md, red);
