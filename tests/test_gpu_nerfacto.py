@@ -274,3 +274,50 @@ def test_eval_render_vs_oracle(mode):
     res_o.load_params(P)
     ro = res_o.render({k: v.to(dev) for k, v in b.items()}, 700, chunk_size=96)
     assert float((ro['rgb'] - res['rgb']).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize('shape', [(1000, 10, 64, 16), (4099, 32, 40, 32), (65, 1, 1, 16), (70000, 14, 64, 24)])
+@pytest.mark.parametrize('bf16', [0, 1])
+def test_fused_proposal_net_kernels_vs_autograd(shape, bf16):
+  """hugs_nf_prop_fwd / hugs_nf_prop_bwd directly: ragged sample counts, both input widths (16 / 32 padded), narrow hidden
+  layers, padded weight strides, zero-gradient waves; against float64 autograd of the same two-layer net."""
+  from nerf_hugs_amd import _lib as L
+  M, in_dim, H, ldx = shape
+  g = torch.Generator().manual_seed(M + in_dim)
+  ldw0, ldw1 = 128, 128                             # the model's padded master layout
+  W0 = torch.zeros(128, ldw0); W0[:in_dim, :H] = torch.randn(in_dim, H, generator=g) * 0.5
+  b0 = torch.zeros(128); b0[:H] = torch.randn(H, generator=g) * 0.2
+  w1 = torch.zeros(128, ldw1); w1[:H, 0] = torch.randn(H, generator=g) * 0.5
+  b1 = torch.randn(1, generator=g) * 0.1 - 1.0
+  X = torch.zeros(M, ldx); X[:, :in_dim] = torch.randn(M, in_dim, generator=g)
+  X[:, in_dim:] = 7.0                               # padding columns must be ignored
+  Xd = X.bfloat16() if bf16 else X
+  sel = (torch.rand(M, generator=g) < 0.9).float()
+  dd = torch.randn(M, generator=g)
+  dd[M // 3: M // 3 + 200] = 0.                     # a stretch of samples without gradient (whole waves at the larger M)
+  G = lambda a: a.to(dev).contiguous()
+  raw, dens = torch.empty(M, device=dev), torch.empty(M, device=dev)
+  L.call('hugs_nf_prop_fwd', M, in_dim, H, bf16, G(Xd), ldx, G(W0), ldw0, G(b0), G(w1), ldw1, G(b1), G(sel), raw, dens)
+  # float64 reference on the values the kernel saw
+  x64 = Xd.double()[:, :in_dim].requires_grad_(True)
+  P = [W0[:in_dim, :H].double().requires_grad_(True), b0[:H].double().requires_grad_(True),
+       w1[:H, 0].double().requires_grad_(True), b1.double().requires_grad_(True)]
+  r64 = torch.relu(x64 @ P[0] + P[1]) @ P[2] + P[3]
+  d64 = torch.exp(r64) * sel.double()
+  np.testing.assert_allclose(raw.cpu().numpy(), r64.detach().numpy(), rtol=0, atol=2e-5 * max(1, float(r64.detach().abs().max())))
+  np.testing.assert_allclose(dens.cpu().numpy(), d64.detach().numpy(), rtol=3e-5, atol=1e-7)
+  # backward: d raw = d density * exp(clamp(raw, -15, 15)) * selector (trunc_exp's backward)
+  (torch.exp(r64.detach().clamp(-15, 15)) * sel.double() * dd.double() * r64).sum().backward()
+  dX = torch.full((M, ldx), 3.0, device=dev, dtype=torch.bfloat16 if bf16 else torch.float32)
+  gW0, gb0, gw1, gb1 = (torch.full(s_, 5.0, device=dev) for s_ in ((128, ldw0), (128,), (128, ldw1), (1,)))
+  ws = torch.empty(L.lib().cdll.hugs_nf_prop_ws_bytes(in_dim) // 4, device=dev)
+  L.call('hugs_nf_prop_bwd', M, in_dim, H, bf16, G(Xd), ldx, G(W0), ldw0, G(b0), G(w1), ldw1, raw, G(sel), G(dd), dX, gW0, gb0, gw1, gb1, ws)
+  tol = lambda ref, rel: rel * max(1e-6, float(ref.abs().max()))
+  assert float((gW0[:in_dim, :H].cpu().double() - P[0].grad).abs().max()) < tol(P[0].grad, 2e-4)
+  assert float((gb0[:H].cpu().double() - P[1].grad).abs().max()) < tol(P[1].grad, 2e-4)
+  assert float((gw1[:H, 0].cpu().double() - P[2].grad).abs().max()) < tol(P[2].grad, 2e-4)
+  assert abs(float(gb1[0]) - float(P[3].grad)) < tol(P[3].grad, 2e-4) + 1e-6
+  assert float(gW0[in_dim:, :].abs().max() if in_dim < 128 else 0) == 5.0 and float(gw1[:, 1:].min()) == 5.0     # padding untouched
+  dxr = x64.grad
+  got = dX[:, :in_dim].float().cpu().double()
+  assert float((got - dxr).abs().max()) < tol(dxr, 1e-2 if bf16 else 2e-4)
