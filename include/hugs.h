@@ -32,11 +32,14 @@ int hugs_device_count(void);
  * t_prev [nrays, n_prev+1], w_prev [nrays, n_prev]; u = u_base[j] + jitter[ray*jitter_stride (+j)] (jitter may
  * be NULL = rng None).  raydist (coord.py:78-90): 0 None, 1 reciprocal, 2 log, 3 exp, 4 sqrt, 5 square, 6 piecewise.  Outputs sdist,tdist [nrays, num_samples+1];
  * optional test hooks idx_out [nrays,num_samples] (CDF interval index), t_in_out/w_in_out (the dilated,
- * trimmed step function).  Bit-exact against oracle/stepfun_ref.c.  -2 if num_samples <= 1 (stepfun.py:239). */
+ * trimmed step function).  sum_order: order of the three order-sensitive float sums (dilation renormaliser
+ * stepfun.py:126, softmax denominator :142, CDF cumsum :145): 1 = the reference's calls executed with numpy float32
+ * semantics (pairwise jnp.sum, sequential jnp.cumsum -- what the reference-generated fixtures pin), 0 = wave order
+ * (lane-blocked tree).  Bit-exact against oracle/stepfun_ref.c in either order.  -2 if num_samples <= 1 (stepfun.py:239). */
 int hugs_level_sample_fwd(int nrays, const float* t_prev, const float* w_prev, int n_prev, int do_dilate,
                           float dilation, float domain_lo, float domain_hi, float anneal, float resample_padding,
                           const float* u_base, const float* jitter, int jitter_stride, int num_samples, int raydist,
-                          const float* near, const float* far, float* sdist, float* tdist, int32_t* idx_out,
+                          int sum_order, const float* near, const float* far, float* sdist, float* tdist, int32_t* idx_out,
                           float* t_in_out, float* w_in_out, void* stream);
 
 /* render.py:103-127 cast_rays (cone :44-78 / cylinder :81-100, lift_gaussian :21-41 diag=False) ->

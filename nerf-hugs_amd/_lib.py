@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get('HUGS_LIB_PATH', os.path.join(_HERE, 'csrc', 'libhugs_
 
 # i = int, f = float, p = device/host pointer, q = long long, s = stream
 _PROTOS = {
-    'hugs_level_sample_fwd': 'ippiifffffppiiippppppps',
+    'hugs_level_sample_fwd': 'ippiifffffppiiiippppppps',
     'hugs_test_explog': 'pipps',
     'hugs_test_arith': 'ppips',
     'hugs_cast_ipe_fwd': 'iipppppiiiiiips',

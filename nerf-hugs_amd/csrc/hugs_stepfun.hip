@@ -8,8 +8,10 @@
 //
 // Bit-exact contract (DESIGN.md "canonical arithmetic"): every float op here is one IEEE
 // binary32 op (this TU is built with -ffp-contract=off and correctly-rounded div), exp/log
-// are the polynomial versions below, and the three order-sensitive sums use the wave order
-// (lane l owns elements 4l..4l+3; xor-butterfly reduce / Kogge-Stone scan across lanes).
+// are the polynomial versions below, and the three order-sensitive sums (dilation renormaliser, softmax
+// denominator, CDF prefix sum) follow the `sum_order` argument: 1 = reference order (numpy pairwise sums, sequential
+// cumsum: what the reference-executed fixtures pin; the default of the Python layer), 0 = wave order (lane l owns
+// elements 4l..4l+3; xor-butterfly reduce / Kogge-Stone scan across lanes + running max).
 // Algorithms differ from the oracle's on purpose: 3-way rank merge instead of a sort,
 // binary searches instead of compare matrices, window max over an index range.
 #include "hugs_common.h"
@@ -95,6 +97,36 @@ __device__ __forceinline__ float sf_wave_sum(const float* arr, int n, int lane) 
   return p;
 }
 
+// ORDER 1 ("reference order"): the order the reference's own calls have when its source is executed under numpy
+// float32 (what tests/golden pins): jnp.sum and the softmax denominator = numpy's pairwise reduction -- blocks of <= 128
+// elements on 8 interleaved accumulators combined ((0+1)+(2+3))+((4+5)+(6+7)), a sequential tail, halves split at
+// a multiple of 8 above 128 -- and jnp.cumsum (stepfun.py:145) = a sequential left-to-right running sum.
+// Lanes 0..7 hold the 8 accumulators of a block; IEEE addition is commutative, so the xor-butterfly over those 8
+// lanes reproduces the fixed tree bit for bit.
+__device__ __forceinline__ float sf_np_block(const float* a, int n, int lane) {      // n <= 128
+  if (n < 8) { float r = 0.0f; for (int i = 0; i < n; ++i) r = r + a[i]; return r; }
+  const int nb = n - (n & 7);
+  float r = lane < 8 ? a[lane] : 0.0f;
+  for (int i = 8; i < nb; i += 8) { if (lane < 8) r = r + a[i + lane]; }
+  float t = r + __shfl_xor(r, 1);
+  t = t + __shfl_xor(t, 2);
+  t = t + __shfl_xor(t, 4);
+  float res = __shfl(t, 0);
+  for (int i = nb; i < n; ++i) res = res + a[i];
+  return res;
+}
+template <int DEPTH>
+__device__ __forceinline__ float sf_np_sum(const float* a, int n, int lane) {
+  if constexpr (DEPTH == 0) return sf_np_block(a, n, lane);
+  else {
+    if (n <= 128) return sf_np_block(a, n, lane);
+    int n2 = n >> 1; n2 -= n2 & 7;
+    const float lo = sf_np_sum<DEPTH - 1>(a, n2, lane);
+    const float hi = sf_np_sum<DEPTH - 1>(a + n2, n - n2, lane);
+    return lo + hi;
+  }
+}
+
 // # of j in [0,len) with (base[j] + off) <= x   (base ascending)
 __device__ __forceinline__ int sf_count_le(const float* base, int len, float off, float x) {
   int lo = 0, hi = len;
@@ -118,7 +150,7 @@ struct SfLds {
   float cen[CAP];      // sampled centers
 };
 
-template <int C>
+template <int C, int ORDER>
 __global__ __launch_bounds__(256) void k_level_sample(
     int nrays, const float* __restrict__ t_prev, const float* __restrict__ w_prev, int n_prev, int do_dilate,
     float dilation, float dlo, float dhi, float anneal, float pad, const float* __restrict__ u_base,
@@ -177,7 +209,8 @@ __global__ __launch_bounds__(256) void k_level_sample(
       }
     }
     __syncthreads();
-    float s = live ? sf_wave_sum<C>(L.wd, m - 1, lane) : 1.0f;
+    float s = 1.0f;
+    if (live) s = ORDER == 1 ? sf_np_sum<3>(L.wd, m - 1, lane) : sf_wave_sum<C>(L.wd, m - 1, lane);
     float den = s > eps2 ? s : eps2;
     n_in = 3 * n - 2;
     if (live) {
@@ -210,10 +243,19 @@ __global__ __launch_bounds__(256) void k_level_sample(
   __syncthreads();
   if (live) for (int i = lane; i < n_in; i += 64) L.wd[i] = sf_expf(L.wd[i] - mx);
   __syncthreads();
-  float den = live ? sf_wave_sum<C>(L.wd, n_in, lane) : 1.0f;
+  float den = 1.0f;
+  if (live) den = ORDER == 1 ? sf_np_sum<3>(L.wd, n_in, lane) : sf_wave_sum<C>(L.wd, n_in, lane);
   if (live) for (int i = lane; i < n_in; i += 64) L.p[i] = L.wd[i] / den;
   __syncthreads();
-  if (live) {
+  if (live && ORDER == 1) {
+    // jnp.cumsum: one lane walks the <= 1023 weights left to right (a float running sum cannot be re-associated)
+    if (lane == 0) {
+      float run = 0.0f;
+      L.td[0] = 0.0f;
+      for (int i = 0; i < n_in - 1; ++i) { run = run + L.p[i]; L.td[i + 1] = run < 1.0f ? run : 1.0f; }
+      L.td[n_in] = 1.0f;
+    }
+  } else if (live) {
     // canonical inclusive scan of p[0..n_in-2]
     float v[C];
     float tot = 0.0f;
@@ -294,7 +336,7 @@ __global__ void k_explog(const float* x, int n, float* ye, float* yl) {
 extern "C" int hugs_level_sample_fwd(int nrays, const float* t_prev, const float* w_prev, int n_prev, int do_dilate,
                                      float dilation, float domain_lo, float domain_hi, float anneal,
                                      float resample_padding, const float* u_base, const float* jitter,
-                                     int jitter_stride, int num_samples, int raydist, const float* near,
+                                     int jitter_stride, int num_samples, int raydist, int sum_order, const float* near,
                                      const float* far, float* sdist, float* tdist, int32_t* idx_out,
                                      float* t_in_out, float* w_in_out, void* stream) {
   HUGS_REQUIRE(num_samples > 1, -2, "num_samples must be > 1, is %d.", num_samples);
@@ -302,22 +344,18 @@ extern "C" int hugs_level_sample_fwd(int nrays, const float* t_prev, const float
   int n_in = do_dilate ? 3 * n_prev : n_prev;
   HUGS_REQUIRE(n_prev >= 1 && n_in <= SF_CAP, -3, "hugs_level_sample_fwd: %d input bins (%d after dilation) > capacity %d",
                n_prev, n_in, SF_CAP);
+  HUGS_REQUIRE(sum_order == 0 || sum_order == 1, -4, "hugs_level_sample_fwd: sum_order must be 0 (wave order) or 1 (reference order)");
   HUGS_REQUIRE(raydist >= 0 && raydist <= 6, -4, "hugs_level_sample_fwd: raydist must be 0 (None), 1 reciprocal, 2 log, 3 exp, 4 sqrt, 5 square or 6 piecewise");
   if (nrays <= 0) return 0;
   // one lane-chunk for the whole level, chosen from its largest array (the oracle applies the same rule)
   const int big = n_in > num_samples ? n_in : num_samples;
-  if (big <= 256)
-    hipLaunchKernelGGL(k_level_sample<4>, dim3((nrays + 3) / 4), dim3(256), 0, (hipStream_t)stream, nrays, t_prev, w_prev,
-                       n_prev, do_dilate, dilation, domain_lo, domain_hi, anneal, resample_padding, u_base, jitter,
-                       jitter_stride, num_samples, raydist, near, far, sdist, tdist, idx_out, t_in_out, w_in_out);
-  else if (big <= 512)
-    hipLaunchKernelGGL(k_level_sample<8>, dim3((nrays + 3) / 4), dim3(256), 0, (hipStream_t)stream, nrays, t_prev, w_prev,
-                       n_prev, do_dilate, dilation, domain_lo, domain_hi, anneal, resample_padding, u_base, jitter,
-                       jitter_stride, num_samples, raydist, near, far, sdist, tdist, idx_out, t_in_out, w_in_out);
-  else   // 256 samples per level (the other per-ray kernels' limit) dilate to 766 bins
-    hipLaunchKernelGGL(k_level_sample<16>, dim3((nrays + 3) / 4), dim3(256), 0, (hipStream_t)stream, nrays, t_prev, w_prev,
-                       n_prev, do_dilate, dilation, domain_lo, domain_hi, anneal, resample_padding, u_base, jitter,
-                       jitter_stride, num_samples, raydist, near, far, sdist, tdist, idx_out, t_in_out, w_in_out);
+#define HUGS_LS_LAUNCH(C_, O_) hipLaunchKernelGGL((k_level_sample<C_, O_>), dim3((nrays + 3) / 4), dim3(256), 0, (hipStream_t)stream, nrays, \
+    t_prev, w_prev, n_prev, do_dilate, dilation, domain_lo, domain_hi, anneal, resample_padding, u_base, jitter, jitter_stride, \
+    num_samples, raydist, near, far, sdist, tdist, idx_out, t_in_out, w_in_out)
+  if (big <= 256) { if (sum_order) HUGS_LS_LAUNCH(4, 1); else HUGS_LS_LAUNCH(4, 0); }
+  else if (big <= 512) { if (sum_order) HUGS_LS_LAUNCH(8, 1); else HUGS_LS_LAUNCH(8, 0); }
+  else { if (sum_order) HUGS_LS_LAUNCH(16, 1); else HUGS_LS_LAUNCH(16, 0); }      // 256 samples per level dilate to 766 bins
+#undef HUGS_LS_LAUNCH
   HUGS_CHECK_LAUNCH("hugs_level_sample_fwd");
   return 0;
 }

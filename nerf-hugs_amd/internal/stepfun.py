@@ -3,6 +3,8 @@
 `sample_intervals` / `max_dilate_weights` keep the reference's argument meaning; the PRNG stays
 outside the kernels: callers pass the uniform draws (`u01`) the reference would have taken from
 `jax.random.uniform` (stepfun.py:203-209)."""
+import os
+
 import numpy as np
 import torch
 
@@ -51,8 +53,14 @@ def _u_base_on_device(num_samples, randomized, dev):
 RAYDIST = {None: 0, 'reciprocal': 1, 'log': 2, 'exp': 3, 'sqrt': 4, 'square': 5, 'piecewise': 6}      # kernel codes (coord.py:78-90)
 
 
+# Order of the sampler's three order-sensitive float sums (include/hugs.h hugs_level_sample_fwd): 1 = reference order
+# (numpy-pairwise jnp.sum, sequential jnp.cumsum: the order the reference-executed fixtures pin) -- what ships;
+# 0 = wave order (lane-blocked tree), kept as an A/B switch (HUGS_SAMPLER_ORDER=wave).
+SUM_ORDER = 0 if os.environ.get('HUGS_SAMPLER_ORDER', 'reference') == 'wave' else 1
+
+
 def level_sample(t_prev, w_prev, do_dilate, dilation, domain, anneal, resample_padding, num_samples, u01,
-                 raydist, near, far, return_debug=False, jitter=None):
+                 raydist, near, far, return_debug=False, jitter=None, sum_order=None):
   """One hierarchical-sampling level (models.py:155-212): [dilate] -> logits -> sample_intervals -> s_to_t.
 
   t_prev [N, n+1], w_prev [N, n] float32 cuda; u01: None (rng=None) or [N] / [N, num_samples] U[0,1) draws;
@@ -83,7 +91,7 @@ def level_sample(t_prev, w_prev, do_dilate, dilation, domain, anneal, resample_p
                               "sqrt / square")
   _lib.call('hugs_level_sample_fwd', N, t_prev.contiguous(), w_prev.contiguous(), n_prev, int(do_dilate), dilation,
             domain[0], domain[1], anneal, resample_padding, ub, jitter, stride, num_samples, rd,
-            near.reshape(-1).contiguous(), far.reshape(-1).contiguous(), sdist, tdist, idx, t_in, w_in)
+            SUM_ORDER if sum_order is None else int(sum_order), near.reshape(-1).contiguous(), far.reshape(-1).contiguous(), sdist, tdist, idx, t_in, w_in)
   if return_debug:
     return sdist, tdist, idx, t_in, w_in
   return sdist, tdist

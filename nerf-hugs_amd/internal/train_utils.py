@@ -18,7 +18,16 @@ from . import models
 from . import random as hrandom
 from . import utils
 
-STAT_TAIL = 64  # floats appended to the gradient buffer for the per-step scalars that get pmean'ed
+STAT_TAIL = 64  # floats appended to the gradient buffer for the per-step scalars that get pmean'ed (<= 7 levels)
+
+
+def _tail_slots(L):
+  """Offsets of the per-step scalars in the stat tail for L sampling levels: (data [2L: mse, data loss per level],
+  interlevel [L-1], distortion [1], robust [5L], hanerf [2], nerfw [2])."""
+  o = dict(data=0, interlevel=2 * L, distortion=3 * L - 1, robust=3 * L, hanerf=8 * L, nerfw=8 * L + 2)
+  if 8 * L + 4 > STAT_TAIL:
+    raise NotImplementedError(f'{L} sampling levels: the stat tail holds {STAT_TAIL} floats (<= 7 levels)')
+  return o
 
 
 class TrainState:
@@ -115,6 +124,29 @@ def _summarize(layout, per_leaf, reduce, post=lambda x: x):
   return {k: post(reduce(v)) for k, v in groups.items()}
 
 
+_AR_BUCKETS = __import__('os').environ.get('HUGS_AR_BUCKETS', '1') != '0'
+
+
+def uncovered_ranges(layout, covered, total):
+  """[lo, hi) ranges of the flat gradient buffer (+ stat tail) that no bucket all-reduced: every LEAF that is not
+  wholly inside one covered range is reduced in full (adjacent ones merged), plus the tail behind the last leaf.  Only
+  the alignment padding between leaves (never written, always zero) may stay out."""
+  cov = sorted(covered)
+  todo = []
+  for lf in layout.leaves:
+    lo, hi = lf['off'], lf['off'] + int(np.prod(lf['pshape']))
+    if not any(c0 <= lo and hi <= c1 for c0, c1 in cov):
+      if todo and todo[-1][1] >= lo - 4:         # merge neighbours (leaves are padded to 4 floats)
+        todo[-1][1] = hi
+      else:
+        todo.append([lo, hi])
+  if todo and todo[-1][1] >= layout.size - 4:
+    todo[-1][1] = total
+  elif layout.size < total:
+    todo.append([layout.size, total])
+  return [tuple(t) for t in todo]
+
+
 def create_train_step(model, config, is_finetune=False):
   """Creates the training function (train_utils.py:372-484).  Returned callable:
   train_pstep(rng, state, batch, train_frac, inlier_thresholds) -> (state, stats, rng)."""
@@ -128,10 +160,8 @@ def create_train_step(model, config, is_finetune=False):
         'patch_size must be larger than robustnerf_inner_patch_size.'
   if config.data_loss_type not in ('mse', 'charb'):
     assert False
-  if L > 4:
-    # the stat tail has fixed slots: [0:2L] mse / data loss per level, [8:8+L-1] interlevel, [12] distortion,
-    # [16:16+5L] robust stats -- 5 levels would make them overlap
-    raise NotImplementedError('more than 4 sampling levels: the per-step stat slots are laid out for num_levels <= 4')
+  TS = _tail_slots(L)      # stat-tail slots sized by the number of levels (any L the 64-float tail holds: <= 7)
+  o_il, o_dist, o_rob, o_han, o_nw = TS['interlevel'], TS['distortion'], TS['robust'], TS['hanerf'], TS['nerfw']
   # train_utils.py:444-447: loss += sum_k m_k * ||theta_k||^2 over summarize_tree keys (a module, 'module/layer' or a
   # leaf path); the gradient 2 m_k theta is added to the leaves under each key.
   decay = []
@@ -248,7 +278,7 @@ def create_train_step(model, config, is_finetune=False):
         _lib.call('hugs_robust_mask', N // (P * P), P, pred[l], gt, thr[l], config.robustnerf_inlier_quantile,
                   config.robustnerf_smoothed_filter_size, config.robustnerf_smoothed_inlier_quantile,
                   config.robustnerf_inner_patch_size, config.robustnerf_inner_patch_inlier_quantile, mask[l], err, part,
-                  tail[16 + 5 * l:16 + 5 * l + 5])
+                  tail[o_rob + 5 * l:o_rob + 5 * l + 5])
       mode, lm = 2, mask
     d_mask = None
     if tt == 'hanerf':
@@ -261,7 +291,7 @@ def create_train_step(model, config, is_finetune=False):
       _lib.call('hugs_hanerf_loss', N, L, pred, gt, mask_st['mask'], int(config.data_loss_type == 'charb'),
                 config.charb_padding, cache['coef'], msm, d_pred, d_mask, hst)
       tail[0:2 * L].copy_(hst[:2 * L])
-      tail[40:42].copy_(hst[2 * L:])
+      tail[o_han:o_han + 2].copy_(hst[2 * L:])
     elif tt == 'nerfw':
       fin_ = levels[-1]
       Mf = N * fin_['S']
@@ -274,8 +304,8 @@ def create_train_step(model, config, is_finetune=False):
       _lib.call('hugs_nerfw_loss', N, L, pred_nw, gt, fin_['uncertainty'], int(config.data_loss_type == 'charb'),
                 config.charb_padding, cache['coef'], config.nerfw_beta_loss_mult, d_pred, nw['d_beta'], nst)
       tail[0:2 * L].copy_(nst[:2 * L])
-      tail[42:43].copy_(nst[2 * L:])
-      _lib.call('hugs_sum', Mf, fin_['dens_t'], 1.0 / Mf, tail[43:44])
+      tail[o_nw:o_nw + 1].copy_(nst[2 * L:])
+      _lib.call('hugs_sum', Mf, fin_['dens_t'], 1.0 / Mf, tail[o_nw + 1:o_nw + 2])
     else:
       _lib.call('hugs_data_loss', N, L, pred, gt, lm, mode, config.withmask_transient_weight,
                 int(config.data_loss_type == 'charb'), config.charb_padding, cache['coef'], d_pred, tail[0:2 * L])
@@ -288,11 +318,11 @@ def create_train_step(model, config, is_finetune=False):
         d_w[l] = ws.get(f'd_w{l}', (N, levels[l]['S']))
         _lib.call('hugs_interlevel', N, Sf, levels[l]['S'], fin['sdist'], fin['weights'], levels[l]['sdist'],
                   levels[l]['weights'], config.interlevel_loss_mult / (N * Sf), loss_ray, d_w[l])
-        _lib.call('hugs_sum', N, loss_ray, 1.0 / (N * Sf), tail[8 + l:9 + l])
+        _lib.call('hugs_sum', N, loss_ray, 1.0 / (N * Sf), tail[o_il + l:o_il + l + 1])
     if not is_finetune and config.distortion_loss_mult > 0:
       d_w[L - 1] = ws.get(f'd_w{L-1}', (N, Sf))
       _lib.call('hugs_distortion', N, Sf, fin['sdist'], fin['weights'], config.distortion_loss_mult / N, loss_ray, d_w[L - 1])
-      _lib.call('hugs_sum', N, loss_ray, 1.0 / N, tail[12:13])
+      _lib.call('hugs_sum', N, loss_ray, 1.0 / N, tail[o_dist:o_dist + 1])
     # ---- backward -----------------------------------------------------------------------------------
     if model.num_glo_features > 0:
       layout.view(grad, ('GloEmbed_0', 'embedding')).zero_()
@@ -322,6 +352,8 @@ def create_train_step(model, config, is_finetune=False):
     # 7 down to 0, each ~4 MB.  Every bucket's all-reduce (SUM; the 1/world is folded into the clip/Adam kernels) is
     # issued on the stream that produced it the moment it is final, so RCCL runs underneath the remaining dX / dW
     # GEMMs and only the last bucket + the small rest (PropMLP, embeddings, stat tail) is exposed.
+    # HUGS_AR_BUCKETS=0 (A/B switch for the first hardware scaling run): no buckets, ONE all-reduce of the whole buffer
+    # after the backward pass -- the reference's own structure.
     ar_works, ar_ranges = [], []
 
     def bucket_done(lo, hi):
@@ -339,7 +371,7 @@ def create_train_step(model, config, is_finetune=False):
       tgt = grad
       if is_prop and prop_done:
         tgt = ws.get('grad_tmp', (layout.size + STAT_TAIL,))
-      bucketed = bucket_done if (world > 1 and not is_prop and not is_finetune) else None
+      bucketed = bucket_done if (world > 1 and not is_prop and not is_finetune and _AR_BUCKETS) else None
       if tt == 'nerfw' and not is_prop:
         eng.backward_level(state.flat, tgt, levels[l], rays, N, None, d_w[l], nerfw=nw, leaf_done=bucketed, lane=lane)
       else:
@@ -370,14 +402,7 @@ def create_train_step(model, config, is_finetune=False):
     # ---- pmean(grad), pmean(stats) ------------------------------------------------------------------
     if world > 1:
       # whatever no bucket covered (PropMLP, embeddings, ImplicitMask, the stat tail; everything in the finetune stage)
-      todo, pos = [], 0
-      for lo, hi in sorted(ar_ranges):
-        if lo > pos + 16:                 # (leaves are padded to 4 floats: the few zero floats between buckets need no reduce)
-          todo.append((pos, lo))
-        pos = max(pos, hi)
-      if pos < grad.numel():
-        todo.append((pos, grad.numel()))
-      for lo, hi in todo:
+      for lo, hi in uncovered_ranges(layout, ar_ranges, grad.numel()):
         ar_works.append(dist.all_reduce(grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
       for w in ar_works:
         w.wait()
@@ -393,7 +418,7 @@ def create_train_step(model, config, is_finetune=False):
       packed[:STAT_TAIL].mul_(gscale)
     packed[STAT_TAIL:].copy_(leaf_stats)
     if tt == 'robustnerf':
-      cache['thr_dev'] = packed[16:16 + 5 * L].reshape(L, 5)[:, :1].clone()
+      cache['thr_dev'] = packed[o_rob:o_rob + 5 * L].reshape(L, 5)[:, :1].clone()
 
     msm_now = cache.get('mask_size_mult', 0.0)
 
@@ -407,25 +432,25 @@ def create_train_step(model, config, is_finetune=False):
       dls = tl[1:2 * L:2]
       losses = {'data': float(config.data_coarse_loss_mult * dls[:-1].sum() + config.data_loss_mult * dls[-1])}
       if not is_finetune and config.interlevel_loss_mult > 0:
-        losses['interlevel'] = float(config.interlevel_loss_mult * tl[8:8 + L - 1].sum())
+        losses['interlevel'] = float(config.interlevel_loss_mult * tl[o_il:o_il + L - 1].sum())
       if not is_finetune and config.distortion_loss_mult > 0:
-        losses['distortion'] = float(config.distortion_loss_mult * tl[12])
+        losses['distortion'] = float(config.distortion_loss_mult * tl[o_dist])
       if decay:
         wl2 = _summarize(layout, ls[:, 2], sum)
         losses['weight'] = float(sum(float(m) * wl2[k] for k, m in dict(config.weight_decay_mults).items()))
       if tt == 'nerfw':
-        losses['beta'] = float(config.nerfw_beta_loss_mult * tl[42] + config.nerfw_beta_loss_bias)
-        losses['density'] = float(config.nerfw_density_loss_mult * tl[43])
+        losses['beta'] = float(config.nerfw_beta_loss_mult * tl[o_nw] + config.nerfw_beta_loss_bias)
+        losses['density'] = float(config.nerfw_density_loss_mult * tl[o_nw + 1])
       if tt == 'hanerf':
-        losses['mask_size'] = float(msm_now * tl[40])
-        stats['implicit_mask'] = T([tl[41]])
+        losses['mask_size'] = float(msm_now * tl[o_han])
+        stats['implicit_mask'] = T([tl[o_han + 1]])
       stats['losses'] = {k: T(v) for k, v in losses.items()}
       stats['loss'] = T(sum(losses.values()))
       stats['mses'] = T(mses)
       stats['psnrs'] = image.mse_to_psnr(stats['mses'])
       stats['psnr'] = stats['psnrs'][-1]
       if tt == 'robustnerf':
-        r = tl[16:16 + 5 * L].reshape(L, 5)
+        r = tl[o_rob:o_rob + 5 * L].reshape(L, 5)
         for i, k in enumerate(['inlier_threshold', 'is_inlier_loss', 'has_inlier_neighbors', 'is_inlier_patch', 'mask']):
           stats['robust_' + k] = T(r[:, i])
       stats['weight_l2s'] = {k: T(v) for k, v in _summarize(layout, ls[:, 2], sum).items()}

@@ -16,6 +16,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
+from .internal import stepfun as _stepfun
 
 _CU = 'cuda'
 
@@ -35,7 +36,7 @@ def level_sample(t_prev: Tensor, w_prev: Tensor, do_dilate: bool, dilation: floa
   """models.py:155-212 sampling level (hugs_level_sample_fwd)."""
   N, ns = sdist.shape[0], sdist.shape[1] - 1
   _lib.call('hugs_level_sample_fwd', N, t_prev, w_prev, w_prev.shape[1], int(do_dilate), dilation, 0., 1., anneal,
-            resample_padding, u_base, jitter, 1, ns, raydist, near, far, sdist, tdist, None, None, None)
+            resample_padding, u_base, jitter, 1, ns, raydist, _stepfun.SUM_ORDER, near, far, sdist, tdist, None, None, None)
 
 
 @torch.library.custom_op('hugs::cast_ipe', mutates_args=('out',), device_types=_CU)

@@ -34,6 +34,15 @@ def _c(a):
   return np.ascontiguousarray(a, np.float32)
 
 
+# order of the three order-sensitive sums (stepfun_ref.c orc_set_sum_order): 1 = reference order (numpy pairwise sums,
+# sequential cumsum -- the product's default), 0 = wave order
+SUM_ORDER = 0 if os.environ.get('HUGS_SAMPLER_ORDER', 'reference') == 'wave' else 1
+
+
+def set_sum_order(order):
+  lib().orc_set_sum_order(ctypes.c_int(int(order)))
+
+
 def expf(x):
   x = _c(x); y = np.empty_like(x)
   lib().orc_expf_vec(_p(x), ctypes.c_int(x.size), _p(y))
@@ -47,19 +56,20 @@ def logf(x):
 
 
 def wave_sum(x):
-  x = _c(x)
+  x = _c(x); lib().orc_set_sum_order(ctypes.c_int(0))
   return np.float32(lib().orc_wave_sum(_p(x), ctypes.c_int(x.size)))
 
 
 def wave_cumsum(x):
-  x = _c(x); y = np.empty_like(x)
+  x = _c(x); y = np.empty_like(x); lib().orc_set_sum_order(ctypes.c_int(0))
   lib().orc_wave_cumsum(_p(x), ctypes.c_int(x.size), _p(y))
   return y
 
 
-def max_dilate_weights(t, w, dilation, lo, hi):
+def max_dilate_weights(t, w, dilation, lo, hi, sum_order=None):
   """stepfun.py:112-128 with renormalize=True. t[N,n+1], w[N,n] -> [N,3n+1],[N,3n]."""
   t = _c(t); w = _c(w)
+  set_sum_order(SUM_ORDER if sum_order is None else sum_order)
   N, n = w.shape
   td = np.empty((N, 3 * n + 1), np.float32); wd = np.empty((N, 3 * n), np.float32)
   for r in range(N):
@@ -69,9 +79,10 @@ def max_dilate_weights(t, w, dilation, lo, hi):
   return td, wd
 
 
-def sample_intervals(u, t, logits, lo, hi):
+def sample_intervals(u, t, logits, lo, hi, sum_order=None):
   """stepfun.py:214-263 with explicit u[N,ns]. Returns (sdist[N,ns+1], idx[N,ns])."""
   u = _c(u); t = _c(t); logits = _c(logits)
+  set_sum_order(SUM_ORDER if sum_order is None else sum_order)
   N, ns = u.shape
   n = logits.shape[1]
   if ns <= 1:
@@ -85,8 +96,9 @@ def sample_intervals(u, t, logits, lo, hi):
 
 
 def level_sample(t_prev, w_prev, do_dilate, dilation, lo, hi, anneal, pad, u_base, jitter,
-                 raydist, near, far):
+                 raydist, near, far, sum_order=None):
   """One sampling level (models.py:155-212). Returns sdist, tdist, idx."""
+  set_sum_order(SUM_ORDER if sum_order is None else sum_order)
   t_prev = _c(t_prev); w_prev = _c(w_prev); u_base = _c(u_base)
   near = _c(near).reshape(-1); far = _c(far).reshape(-1)
   N, n_prev = w_prev.shape

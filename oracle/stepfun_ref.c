@@ -104,7 +104,28 @@ static void lane_partials(const float* x, int n, float lane[64]) {
     lane[l] = s;
   }
 }
+/* Summation order of the three order-sensitive sums: 0 = wave order (above), 1 = the order the reference's own calls
+ * have when its source runs under numpy float32 (tests/golden fixtures): jnp.cumsum = sequential left to right
+ * (stepfun.py:145), jnp.sum / softmax denominator = numpy's pairwise reduction (8 accumulators over blocks of <= 128,
+ * halves above).  XLA's own order is not knowable here; this is the only pinned one. */
+static int g_order = 0;
+void orc_set_sum_order(int order) { g_order = order; }
+static float np_pairwise(const float* a, int n) {
+  if (n < 8) { float r = 0.0f; for (int i = 0; i < n; ++i) r = r + a[i]; return r; }
+  if (n <= 128) {
+    float r[8];
+    int i;
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    for (i = 8; i < n - (n % 8); i += 8) for (int j = 0; j < 8; ++j) r[j] = r[j] + a[i + j];
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res = res + a[i];
+    return res;
+  }
+  int n2 = n / 2; n2 -= n2 % 8;
+  return np_pairwise(a, n2) + np_pairwise(a + n2, n - n2);
+}
 float orc_wave_sum(const float* x, int n) {
+  if (g_order == 1) return np_pairwise(x, n);
   float a[64], b[64];
   lane_partials(x, n, a);
   for (int d = 1; d < 64; d <<= 1) {
@@ -115,6 +136,7 @@ float orc_wave_sum(const float* x, int n) {
 }
 /* inclusive prefix sum, out[i] = x[0]+..+x[i] in wave order */
 void orc_wave_cumsum(const float* x, int n, float* out) {
+  if (g_order == 1) { float run = 0.0f; for (int i = 0; i < n; ++i) { run = run + x[i]; out[i] = run; } return; }
   float a[64], b[64];
   lane_partials(x, n, a);
   for (int d = 1; d < 64; d <<= 1) { /* Kogge-Stone inclusive scan of lane totals */

@@ -37,7 +37,7 @@ def test_portable_explog_and_ieee_ops_bit_exact():
         assert np.array_equal(bits(o[k]), bits(ref))
 
 
-def _run_level(N, n_prev, ns, dil, raydist, jitter, seed, wpow=1, zeros=False, anneal=0.7):
+def _run_level(N, n_prev, ns, dil, raydist, jitter, seed, wpow=1, zeros=False, anneal=0.7, order=1):
   from oracle import cstepfun as C, torch_ref as R
   from nerf_hugs_amd.internal import stepfun
   rng = np.random.default_rng(seed)
@@ -51,15 +51,15 @@ def _run_level(N, n_prev, ns, dil, raydist, jitter, seed, wpow=1, zeros=False, a
   jit = (u01 * np.float32(mj)).astype(np.float32) if jitter else None
   near = rng.uniform(0.05, 0.3, N).astype(np.float32)
   far = np.full(N, {0: 1.2, 1: 1e6, 3: 5.0}.get(raydist, 300.0), np.float32)
-  sd_o, td_o, idx_o = C.level_sample(t, w, dil is not None, dil or 0., 0., 1., anneal, 0., ub, jit, raydist, near, far)
+  sd_o, td_o, idx_o = C.level_sample(t, w, dil is not None, dil or 0., 0., 1., anneal, 0., ub, jit, raydist, near, far, sum_order=order)
   sd, td, idx, tin, win = stepfun.level_sample(G(t), G(w), dil is not None, dil or 0., (0., 1.), anneal, 0., ns,
                                                None if u01 is None else G(u01), [None, 'reciprocal', 'log', 'exp', 'sqrt', 'square', 'piecewise'][raydist],
-                                               G(near), G(far), return_debug=True)
+                                               G(near), G(far), return_debug=True, sum_order=order)
   assert np.array_equal(idx.cpu().numpy(), idx_o), 'interval indices'
   assert np.array_equal(bits(sd.cpu().numpy()), bits(sd_o)), 'sdist'
   assert np.array_equal(bits(td.cpu().numpy()), bits(td_o)), 'tdist'
   if dil is not None:
-    tdil, wdil = C.max_dilate_weights(t, w, dil, 0., 1.)
+    tdil, wdil = C.max_dilate_weights(t, w, dil, 0., 1., sum_order=order)
     assert np.array_equal(bits(tin.cpu().numpy()), bits(tdil[:, 1:-1])), 'sorted dilated t-bins'
     assert np.array_equal(bits(win.cpu().numpy()), bits(wdil[:, 1:-1])), 'dilated weights'
   s = sd.cpu().numpy()
@@ -89,8 +89,12 @@ def _run_level(N, n_prev, ns, dil, raydist, jitter, seed, wpow=1, zeros=False, a
     dict(N=200, n_prev=64, ns=32, dil=0.0103125, raydist=5, jitter=True),
     dict(N=200, n_prev=64, ns=64, dil=0.0103125, raydist=6, jitter=True),       # 'piecewise' (coord.py:81-84)
 ])
-def test_level_sample_bit_exact_vs_oracle(case):
-  _run_level(seed=3, **case)
+@pytest.mark.parametrize('order', [1, 0], ids=['reference_order', 'wave_order'])
+def test_level_sample_bit_exact_vs_oracle(case, order):
+  """Both summation orders of hugs_level_sample_fwd (1 = reference order: numpy-pairwise sums + sequential cumsum, the
+  one that ships; 0 = wave order) against the C oracle in the same order: sample indices, sorted t-bins, sdist, tdist
+  bit for bit."""
+  _run_level(seed=3, order=order, **case)
 
 
 def test_level_sample_errors_and_empty():
