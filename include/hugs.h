@@ -7,8 +7,7 @@
  * Conventions: every pointer is a caller-owned DEVICE pointer (host pointers only where stated); nothing is
  * allocated, no stream is created; `stream` is a hipStream_t; kernels are enqueued and the call returns.
  * Process-global state, all of it: (i) the thread-local last-error string; (ii) hugs_gemm_nt caches the device's CU
- * count on first use (the persistent kernel's grid); (iii) the TEST hook hugs_test_force_small_tiles below, a
- * process-wide kernel-selection override that production code never sets.  (The Python layer above keeps per-process
+ * count on first use (the persistent kernel's grid).  (The Python layer above keeps per-process
  * caches of its own -- sampler abscissae uploaded once per (num_samples, mode), RobustNeRF thresholds fed back on
  * the device between steps: nerf-hugs_amd/internal/stepfun.py `_UB_CACHE`, train_utils.py `cache['thr_dev']`.)  Return 0 = ok, <0 = error (message via hugs_last_error(), thread local):
  *   -2 invalid argument for which the reference raises ValueError, -3 unsupported shape, -100 launch failure.
@@ -298,9 +297,14 @@ int hugs_nf_rgb_grad(long long M, int dtype, const float* rgb, const float* d_rg
 int hugs_nf_adam(long long n, float* theta, const float* grad, float* m, float* v, float lr, float b1, float b2, float eps,
                  float bc1, float bc2, void* stream);
 
-/* test/bench hook (process-global, see the conventions above): 1 / 3 force the 128x128-tile bf16 NT kernel where a
- * 256-row kernel would be selected, 5 disables the persistent form; 0 restores the default selection */
-int hugs_test_force_small_tiles(int on);
+/* test/bench forms of hugs_gemm_nt / hugs_gemm_tn with an explicit kernel selection (a call argument: no process
+ * state): tile_mode 0 = the default choice (what the plain entry points use), 1 = force the 128x128-tile kernels,
+ * 3 = the 256x128 NT kernel where a 256x256 one would be chosen, 5 = 256x256 without the persistent form */
+int hugs_gemm_nt_tiles(int tile_mode, int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,
+                       const void* Bt, int ldb, const float* bias, const float* row_bias, int row_div, int ld_rb, int relu,
+                       const void* mask, int ld_mask, const float* r1_row, const float* r1_col, void* out, int ldc, void* stream);
+int hugs_gemm_tn_tiles(int tile_mode, int dtype, int Mrows, int Kc, int N, int nsplit, const void* X, int ldx, const void* G, int ldg,
+                       float* dW, float* dbias, void* ws, void* stream);
 /* test hooks: the portable exp/log of the sampler and raw IEEE ops as the device executes them */
 int hugs_test_explog(const float* x, int n, float* y_exp, float* y_log, void* stream);
 int hugs_test_arith(const float* a, const float* b, int n, float* out4n, void* stream);

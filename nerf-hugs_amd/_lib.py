@@ -72,7 +72,8 @@ _PROTOS = {
     'hugs_nf_rgb_act': 'qipifps',
     'hugs_nf_rgb_grad': 'qipppis',
     'hugs_nf_adam': 'qppppffffffs',
-    'hugs_test_force_small_tiles': 'i',
+    'hugs_gemm_nt_tiles': 'i' 'iiiii' 'pipipi' 'pp' 'iii' 'pi' 'pp' 'pi' 's',
+    'hugs_gemm_tn_tiles': 'i' 'iiiiipipippps',
 }
 _CT = {'i': ctypes.c_int, 'f': ctypes.c_float, 'p': ctypes.c_void_p, 'q': ctypes.c_longlong,
        's': ctypes.c_void_p}

@@ -16,15 +16,6 @@
 #include "hugs_common.h"
 #include <type_traits>
 
-// (measurement knobs) stage loads a wave may leave outstanding at the top of an iteration: 8 = two stages, 4 = one
-#ifndef HUGS_TN_VM
-#define HUGS_TN_VM 8
-#endif
-#ifndef HUGS_NT_VM
-#define HUGS_NT_VM 8
-#endif
-#define HUGS_STR_(x) #x
-#define HUGS_STR(x) HUGS_STR_(x)
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
@@ -48,22 +39,10 @@ struct GemmEpi {
   const uint32_t* bits_in;
 };
 
-#ifdef HUGS_TRACE   // scratch builds only (scratch/nt_trace.py): per-workgroup timestamps of the NT kernel's phases
-__device__ unsigned long long* g_nt_trace;
-extern "C" int hugs_debug_set_trace(void* p) {
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_nt_trace), &p, sizeof(p));
-}
-__device__ int g_nt_stagger[2];   // [0] = groups (power of two), [1] = s_sleep(127) iterations per group step
-extern "C" int hugs_debug_set_stagger(int groups, int iters) {
-  int v[2] = {groups, iters};
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_nt_stagger), v, sizeof(v));
-}
-#define HUGS_STAGGER() { const int g_ = g_nt_stagger[0]; if (g_ > 1 && blockIdx.x < 256) { \
-    const int n_ = ((blockIdx.x >> 3) & (g_ - 1)) * g_nt_stagger[1]; for (int q_ = 0; q_ < n_; ++q_) __builtin_amdgcn_s_sleep(127); } }
-#define HUGS_TR(i) { if (g_nt_trace && threadIdx.x == 0) g_nt_trace[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); }
-#define HUGS_TRP(i, k) { if (g_nt_trace && threadIdx.x == 0 && (i) < 16) g_nt_trace[((size_t)blockIdx.x * 16 + (i)) * 4 + (k)] = __builtin_readcyclecounter(); }
-#define HUGS_TR_ID() { if (g_nt_trace && threadIdx.x == 0) { g_nt_trace[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg(63492); \
-                                                             g_nt_trace[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg(63508); } }
+// Per-phase timestamps / staggered starts for the measurement builds live in scratch/hugs_gemm_trace.h (scratch/build_trace.sh
+// compiles with -DHUGS_TRACE -I scratch); the product build sees empty macros.
+#ifdef HUGS_TRACE
+#include "hugs_gemm_trace.h"
 #else
 #define HUGS_TR(i)
 #define HUGS_TRP(i, k)
@@ -208,14 +187,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(int M, int N, int K1, i
 // row pitch -> whole 512-byte rows stored 16 B per lane, the relu mask of the backward pass applied on
 // the coalesced side.
 // ------------------------------------------------------------------------------------------------
-#ifndef HUGS_NT_DIRECT_EPI
-#define HUGS_NT_DIRECT_EPI 1   // A/B-tested: +10 % over staging the C tile through LDS
-#endif
 typedef unsigned __attribute__((ext_vector_type(2))) u32x2_t;
-#ifndef HUGS_NT_VARIANT
-#define HUGS_NT_VARIANT 2   // 8 MFMA : 3 ds_read interleave of next-stage fragment reads (A/B-tested: +5 %; the finer / DS-first /
-                            // VMEM-slotted interleaves measured in round 1 were slower and are gone)
-#endif
 #define GL_CPAD 16   // bytes added to each row of the staged C tile (bank spread for the 8-byte fragment writes)
 
 // WN = wave columns: 4 -> 256x256 tile, 8 waves, 4-slot ring (128 KiB, 1 workgroup/CU);
@@ -365,34 +337,13 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
             vw[q] &= keep;
           }
         }
-#ifdef HUGS_EPI_NOSTORE    // scratch experiment: everything but the store instruction
-        asm volatile("" ::"v"(vw[0]), "v"(vw[1]), "v"(vw[2]), "v"(vw[3]));
-#else
-#ifndef HUGS_EPI_PLAIN_STORE   // streaming (nontemporal) stores: the 32 MB all workgroups write at the same time do not
-                              // push the operand panels out of the 4 MB L2s (in-step A/B: step -1.8 %, forward layer 264 -> 254 us)
+        // streaming (nontemporal) stores: the 32 MB all workgroups write at the same time do not push the operand panels
+        // out of the 4 MB L2s (in-step A/B: step -1.8 %, forward layer 264 -> 254 us; explicit sc0 / sc1 / nt policy
+        // bits measured within noise of it)
         { typedef unsigned __attribute__((ext_vector_type(4))) u32x4_t; const u32x4_t v_ = {vw[0], vw[1], vw[2], vw[3]};
           u32x4_t* p_ = (u32x4_t*)((uint16_t*)E.out + (size_t)(m0 + wm * 128 + i * 16 + h * 8 + srow) * E.ldc + ccol);
-#if defined(HUGS_EPI_STORE_MODE)   // measurement builds: explicit cache-policy bits on the output stores
-#if HUGS_EPI_STORE_MODE == 1
-#define HUGS_EPI_STORE_MOD "sc0 sc1"
-#elif HUGS_EPI_STORE_MODE == 2
-#define HUGS_EPI_STORE_MOD "sc1"
-#elif HUGS_EPI_STORE_MODE == 3
-#define HUGS_EPI_STORE_MOD "sc1 nt"
-#elif HUGS_EPI_STORE_MODE == 4
-#define HUGS_EPI_STORE_MOD "sc0 sc1 nt"
-#else
-#define HUGS_EPI_STORE_MOD "nt"
-#endif
-          asm volatile("global_store_dwordx4 %0, %1, off " HUGS_EPI_STORE_MOD :: "v"(p_), "v"(v_) : "memory");
-#else
           __builtin_nontemporal_store(v_, p_);
-#endif
         }
-#else
-        *(uint4*)((uint16_t*)E.out + (size_t)(m0 + wm * 128 + i * 16 + h * 8 + srow) * E.ldc + ccol) = make_uint4(vw[0], vw[1], vw[2], vw[3]);
-#endif
-#endif
       }
     }
 }
@@ -475,11 +426,9 @@ __global__ __launch_bounds__(128 * WN, 2) void k_gemm_nt_bf16_big(
     if ((st) + NSLOT < ns) stage((st) + NSLOT);                                           \
     load_frags(nxt, (st) + 1);                                                            \
     mfmas(cur);                                                                           \
-    if (HUGS_NT_VARIANT == 2) {                                                           \
-      _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                  \
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                \
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                                \
-      }                                                                                   \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {   /* 8 MFMA : 3 ds_read interleave (A/B: +5 %) */ \
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                  \
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                                  \
     }                                                                                     \
   }
   Frags f0, f1;
@@ -509,17 +458,11 @@ __global__ __launch_bounds__(128 * WN, 2) void k_gemm_nt_bf16_big(
   }
 #undef GL_ITER
   HUGS_TR(2)
-#if HUGS_NT_DIRECT_EPI
-  if (WN == 4) {
+  if (WN == 4) {     // register-direct epilogue (A/B: +10 % over staging the C tile through LDS)
     nt_epilogue_direct<EPI>(acc, E, m0, n0, wm, wn, r16, kb, nullptr, nullptr);
     HUGS_TR(3)
-#ifdef HUGS_TRACE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    HUGS_TR(4)
-#endif
     return;
   }
-#endif
   __syncthreads();   // everyone is done reading the ring: reuse it as the C staging tile
 
   // ---- epilogue: registers -> (bias, rank-1, relu) -> bf16 tile in LDS -> whole rows, 16 B per lane ----
@@ -673,7 +616,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wb[j], f.xa[i], acc[i][j], 0, 0, 0);
   };
-  // The same work in four fenced quarters of {1 LDS-DMA, 3 fragment reads, 8 MFMAs} (HUGS_NT_SCHED == 4): the four DMAs
+  // The same work in four fenced quarters of {1 LDS-DMA, 3 fragment reads, 8 MFMAs}: the four DMAs
   // of a stage are not pushed into the CU's vector-memory path back to back by all 8 waves at once.
   auto issue_piece = [&](int q) {
     const int kglob = l_st << 5;
@@ -712,24 +655,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wb[j], f.xa[i], acc[i][j], 0, 0, 0);
   };
-#ifndef HUGS_NT_SCHED
-#define HUGS_NT_SCHED 4
-#endif
-#ifndef HUGS_NT_EXP     // measurement builds (results garbage): bit 0 no LDS-DMA, bit 1 no fragment reads, bit 2 no MFMAs in the steady-state loop
-#define HUGS_NT_EXP 0
-#endif
 #define GP_Q(cur, nxt, q)                                                                                   \
-    if (!(HUGS_NT_EXP & 1)) issue_piece(q);                                                                  \
-    if (!(HUGS_NT_EXP & 2)) frags_piece(nxt, q);                                                             \
-    else { asm volatile("" : "+v"(nxt.xa[2 * q]), "+v"(nxt.xa[2 * q + 1]), "+v"(nxt.wb[q])); if (q == 3) c_slot = (c_slot + 1) & 3; } \
-    if (!(HUGS_NT_EXP & 4)) mfma_piece(cur, q);                                                              \
-    else asm volatile("" :: "v"(cur.xa[2 * q]), "v"(cur.xa[2 * q + 1]), "v"(cur.wb[q]));                     \
+    issue_piece(q); frags_piece(nxt, q); mfma_piece(cur, q);                                                 \
     __builtin_amdgcn_sched_barrier(0);
   // iteration for stage g: frags(g) are in `cur`; make stage g+1 visible, refill the slot of stage g with stage g+4,
   // start reading frags(g+1) into `nxt`, run the MFMAs of stage g.
 #define GP_ITERQ(cur, nxt, VM)                                                           \
   {                                                                                       \
-    asm volatile("s_waitcnt vmcnt(" HUGS_STR(VM) ") lgkmcnt(0)" ::: "memory");            \
+    asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");                     \
     __builtin_amdgcn_s_barrier();                                                         \
     asm volatile("" ::: "memory");                                                        \
     GP_Q(cur, nxt, 0) GP_Q(cur, nxt, 1) GP_Q(cur, nxt, 2) GP_Q(cur, nxt, 3)               \
@@ -780,11 +713,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
     GP_ITER(f1, f0, 8)
     HUGS_TRP(i, 1)
 #pragma unroll 1
-#if HUGS_NT_SCHED == 4
-    for (int st = 4; st < ns; st += 2) { GP_ITERQ(f0, f1, HUGS_NT_VM) GP_ITERQ(f1, f0, HUGS_NT_VM) }
-#else
-    for (int st = 4; st < ns; st += 2) { GP_ITER(f0, f1, 8) GP_ITER(f1, f0, 8) }
-#endif
+    for (int st = 4; st < ns; st += 2) { GP_ITERQ(f0, f1, 8) GP_ITERQ(f1, f0, 8) }
     HUGS_TRP(i, 2)
     nt_epilogue_direct<EPI, (EPI >= 0 && (EPI & EPI_BIAS) != 0)>(acc, E, m0, n0, wm, wn, r16, kb, lds_bias, lds_r1);
     HUGS_TRP(i, 3)
@@ -920,14 +849,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(int Mrows, int Kc, int 
 // swizzle: fragment reads are base + immediate, which frees ~25 VGPRs and the XOR arithmetic).  The bias gradient (column sums of G) costs two
 // extra MFMAs per stage against an all-ones fragment instead of a scalar LDS pass.
 // ------------------------------------------------------------------------------------------------
-// Measurement builds only (scratch/tn_exp.sh; results are garbage): bit 0 = no LDS-DMA in the steady-state loop,
-// bit 1 = no fragment ds_reads in the loop, bit 2 = no MFMAs, bit 3 = loads always hit L2, bit 5 = no barrier, bit 6 = no
-// counted vmcnt wait.  (Round-2 experiments that are gone from the source: 8:6 / 4:3 / DS-first sched_group_barrier
-// interleaves of an un-fenced iteration, and an L2 prefetch of the XCD siblings' lines 4 / 8 / 16 stages ahead through a
-// 4-byte LDS-DMA into a sink -- DESIGN.md section 4 has their numbers.)
-#ifndef HUGS_TN_EXP
-#define HUGS_TN_EXP 0
-#endif
+// (Round-2 measurement builds -- no DMA / no fragment reads / no MFMA / L2-resident loads / no barrier / uncounted waits,
+// 8:6 / 4:3 / DS-first interleaves, an L2 prefetch of the XCD siblings' lines -- are in the git history; DESIGN.md
+// section 4 has their numbers.)
 __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, int N, int nsplit,
                                                               const uint16_t* __restrict__ X, int ldx,
                                                               const uint16_t* __restrict__ G, int ldg,
@@ -962,7 +886,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory", "m0");
   };
   auto stage = [&](int st) {
-    const int mrow0 = mbeg + (((HUGS_TN_EXP & 8) ? (st & 7) : st) << 5);      // bit 3: every stage re-reads 8 L2-resident stages
+    const int mrow0 = mbeg + (st << 5);
     const unsigned l = lds0 + (unsigned)(st % NSLOT) * STAGE;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -1058,17 +982,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
       }
     };
 #define GT_Q(cur, nxt, st, q, DOST)                                       \
-    if (DOST && !(HUGS_TN_EXP & 1)) stage_piece((st) + NSLOT, q);         \
-    if (!(HUGS_TN_EXP & 2)) frags_piece(nxt, (st) + 1, q);                \
-    else asm volatile("" : "+v"(nxt.ga[2 * q]), "+v"(nxt.ga[2 * q + 1]), "+v"(nxt.xb[q])); \
-    if (!(HUGS_TN_EXP & 4)) mfma_piece(cur, q);                           \
-    else asm volatile("" :: "v"(cur.ga[2 * q]), "v"(cur.ga[2 * q + 1]), "v"(cur.xb[q])); \
+    if (DOST) stage_piece((st) + NSLOT, q);                               \
+    frags_piece(nxt, (st) + 1, q);                                        \
+    mfma_piece(cur, q);                                                   \
     __builtin_amdgcn_sched_barrier(0);
 #define GT_ITER4(cur, nxt, st, VM, DOST)                                  \
   {                                                                       \
-    if (HUGS_TN_EXP & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-    else asm volatile("s_waitcnt vmcnt(" HUGS_STR(VM) ") lgkmcnt(0)" ::: "memory"); \
-    if (!(HUGS_TN_EXP & 32)) __builtin_amdgcn_s_barrier();                \
+    asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_s_barrier();                                         \
     asm volatile("" ::: "memory");                                        \
     GT_Q(cur, nxt, st, 0, DOST) GT_Q(cur, nxt, st, 1, DOST) GT_Q(cur, nxt, st, 2, DOST) GT_Q(cur, nxt, st, 3, DOST) \
   }
@@ -1079,7 +1000,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
     asm volatile("" ::: "memory");
     load_frags(f0, 0);
     int st = 0;
-    for (; st + 5 < ns; st += 2) { GT_ITER4(f0, f1, st, HUGS_TN_VM, 1) GT_ITER4(f1, f0, st + 1, HUGS_TN_VM, 1) }
+    for (; st + 5 < ns; st += 2) { GT_ITER4(f0, f1, st, 8, 1) GT_ITER4(f1, f0, st + 1, 8, 1) }
     GT_ITER4(f0, f1, st, 8, 0)
     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
     load_frags(f0, st + 2); mfmas(f1);
@@ -1316,10 +1237,10 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ s
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
-static int g_force_small_tiles = 0;   // test/bench hook: 0 default (256x256, else 256x128, else 128x128), 1 force 128x128, 3 force 256x128
-extern "C" int hugs_test_force_small_tiles(int on) { g_force_small_tiles = on; return 0; }
-
-static int gemm_nt_impl(int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,
+// tile_mode (hugs_gemm_nt_tiles / hugs_gemm_tn_tiles; the plain entry points pass 0): 0 = default kernel selection
+// (persistent 256x256, else 256x256, else 256x128, else 128x128), 1 = force 128x128, 3 = force 256x128 where 256x256
+// would be chosen, 5 = 256x256 without the persistent form.
+static int gemm_nt_impl(int tile_mode, int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,
                         const void* Bt, int ldb, const float* bias, const float* row_bias, int row_div, int ld_rb,
                         int relu, const void* mask, int ld_mask, const float* r1_row, const float* r1_col,
                         void* out, int ldc, uint32_t* bits_out, const uint32_t* bits_in, void* stream);
@@ -1328,8 +1249,16 @@ extern "C" int hugs_gemm_nt(int dtype, int M, int N, int K1, int K2, const void*
                             const void* Bt, int ldb, const float* bias, const float* row_bias, int row_div, int ld_rb,
                             int relu, const void* mask, int ld_mask, const float* r1_row, const float* r1_col,
                             void* out, int ldc, void* stream) {
-  return gemm_nt_impl(dtype, M, N, K1, K2, A1, lda1, A2, lda2, Bt, ldb, bias, row_bias, row_div, ld_rb, relu, mask, ld_mask,
+  return gemm_nt_impl(0, dtype, M, N, K1, K2, A1, lda1, A2, lda2, Bt, ldb, bias, row_bias, row_div, ld_rb, relu, mask, ld_mask,
                       r1_row, r1_col, out, ldc, nullptr, nullptr, stream);
+}
+extern "C" int hugs_gemm_nt_tiles(int tile_mode, int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2,
+                                  int lda2, const void* Bt, int ldb, const float* bias, const float* row_bias, int row_div, int ld_rb,
+                                  int relu, const void* mask, int ld_mask, const float* r1_row, const float* r1_col,
+                                  void* out, int ldc, void* stream) {
+  HUGS_REQUIRE(tile_mode == 0 || tile_mode == 1 || tile_mode == 3 || tile_mode == 5, -2, "hugs_gemm_nt_tiles: tile_mode %d", tile_mode);
+  return gemm_nt_impl(tile_mode, dtype, M, N, K1, K2, A1, lda1, A2, lda2, Bt, ldb, bias, row_bias, row_div, ld_rb, relu, mask,
+                      ld_mask, r1_row, r1_col, out, ldc, nullptr, nullptr, stream);
 }
 
 // hugs_gemm_nt with 1-bit relu masks (bf16, 256x256-tile kernels only: M, N multiples of 256, ldc == N).  bits_out
@@ -1342,12 +1271,12 @@ extern "C" int hugs_gemm_nt_bits(int dtype, int M, int N, int K1, int K2, const 
   HUGS_REQUIRE(dtype == 1 && M % 256 == 0 && N % 256 == 0 && ldc == N && (K1 + K2) % 64 == 0 && K1 + K2 >= 256, -3,
                "hugs_gemm_nt_bits: needs bf16, M=%d N=%d multiples of 256, ldc == N, K=%d a multiple of 64 and >= 256", M, N, K1 + K2);
   HUGS_REQUIRE(!bits_out || relu, -3, "hugs_gemm_nt_bits: bits_out needs a relu epilogue");
-  return gemm_nt_impl(dtype, M, N, K1, K2, A1, lda1, A2, lda2, Bt, ldb, bias, nullptr, 1, 0, relu, bits_in ? (const void*)1 : nullptr, 0,
+  return gemm_nt_impl(0, dtype, M, N, K1, K2, A1, lda1, A2, lda2, Bt, ldb, bias, nullptr, 1, 0, relu, bits_in ? (const void*)1 : nullptr, 0,
                       r1_row, r1_col, out, ldc, bits_out, bits_in, stream);
 }
 
-static int gemm_nt_impl(int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,
-                        const void* Bt, int ldb, const float* bias, const float* row_bias, int row_div, int ld_rb,
+static int gemm_nt_impl(int tile_mode, int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2,
+                        int lda2, const void* Bt, int ldb, const float* bias, const float* row_bias, int row_div, int ld_rb,
                         int relu, const void* mask, int ld_mask, const float* r1_row, const float* r1_col,
                         void* out, int ldc, uint32_t* bits_out, const uint32_t* bits_in, void* stream) {
   HUGS_REQUIRE(dtype == 0 || dtype == 1, -2, "hugs_gemm_nt: dtype must be 0 (fp32) or 1 (bf16)");
@@ -1357,26 +1286,28 @@ static int gemm_nt_impl(int dtype, int M, int N, int K1, int K2, const void* A1,
   HUGS_REQUIRE(!row_bias || row_div > 0, -3, "hugs_gemm_nt: row_div must be > 0");
   if (M == 0 || N == 0) return 0;
   const bool bits = bits_out || bits_in;
-  HUGS_REQUIRE(!bits || (g_force_small_tiles != 1 && g_force_small_tiles != 3), -3, "hugs_gemm_nt_bits: the 256x256 kernels are disabled by the test hook");
+  HUGS_REQUIRE(!bits || (tile_mode != 1 && tile_mode != 3), -3, "hugs_gemm_nt_bits: needs the 256x256 kernels (tile_mode 0 or 5)");
   if (bits_in) mask = nullptr;       // (the EPI_MASK specialisation is selected through `epi_mask` below)
   GemmEpi E{bias, row_bias, row_div, ld_rb, relu, mask, ld_mask, r1_row, r1_col, out, ldc, bits_out, bits_in};
   const int grid = (M / 128) * (N / 128);
   // (four K-stages of 32 are the shortest pipeline the ring kernels run: K >= 128)
-  if (dtype && M % 256 == 0 && N % 256 == 0 && (K1 + K2) % 64 == 0 && K1 + K2 >= 128 && g_force_small_tiles != 1 && g_force_small_tiles != 3)
+  if (dtype && M % 256 == 0 && N % 256 == 0 && (K1 + K2) % 64 == 0 && K1 + K2 >= 128 && tile_mode != 1 && tile_mode != 3)
   {
     // epilogue specialisations for the combinations the trunks use (bit set = term present); anything else -> generic
     const int epi = row_bias ? -1 : (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0) | (mask ? EPI_MASK : 0) | (r1_row ? EPI_R1 : 0) |
                                     (bits_in ? EPI_BIN : 0) | (bits_out ? EPI_BOUT : 0);
     const int ntiles = (M / 256) * (N / 256), nstage = (K1 + K2) / 32;
     static int ncu = 0;
-    if (!ncu) { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); ncu &= ~7; if (ncu < 8) ncu = 8; }
+    if (!ncu) {
+      int dev = 0, n = 0;
+      HUGS_REQUIRE(hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess,
+                   -100, "hugs_gemm_nt: cannot query the device's CU count");
+      n &= ~7;
+      ncu = n < 8 ? 8 : n;
+    }
     // more than one tile per CU: the persistent kernel (ring carried across tiles).  Needs an even number of stages
     // (fragment double buffer parity) and N <= 4096 (bias / r1 vectors in the 32 KiB the ring leaves).
-#ifdef HUGS_NO_PERSISTENT
-    if (false) {
-#else
-    if (ntiles > ncu && nstage % 2 == 0 && nstage >= 8 && N <= 4096 && g_force_small_tiles != 5) {
-#endif
+    if (ntiles > ncu && nstage % 2 == 0 && nstage >= 8 && N <= 4096 && tile_mode != 5) {
       const dim3 gp(ncu), bp(512);
 #define HUGS_NTP_LAUNCH(EPI_) hipLaunchKernelGGL((k_gemm_nt_bf16_pers<EPI_>), gp, bp, 0, (hipStream_t)stream, M, N, K1, K2, \
                        (const uint16_t*)A1, lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E, ntiles)
@@ -1411,7 +1342,7 @@ static int gemm_nt_impl(int dtype, int M, int N, int K1, int K2, const void* A1,
     }
 #undef HUGS_NT_LAUNCH
   }
-  else if (dtype && M % 256 == 0 && (K1 + K2) % 64 == 0 && K1 + K2 >= 128 && g_force_small_tiles != 1)
+  else if (dtype && M % 256 == 0 && (K1 + K2) % 64 == 0 && K1 + K2 >= 128 && tile_mode != 1)
     hipLaunchKernelGGL(k_gemm_nt_bf16_big<2>, dim3((M / 256) * (N / 128)), dim3(256), 0, (hipStream_t)stream, M, N, K1, K2,
                        (const uint16_t*)A1, lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E);
   else if (dtype)
@@ -1429,8 +1360,19 @@ extern "C" long long hugs_gemm_tn_ws_bytes(int Kc, int N, int nsplit) {
 }
 
 // dW[Kc, ldw(:N)] = X^T G, dbias[N] = colsum(G) (if dbias != null). ws: hugs_gemm_tn_ws_bytes().
+static int gemm_tn_impl(int tile_mode, int dtype, int Mrows, int Kc, int N, int nsplit, const void* X, int ldx, const void* G, int ldg,
+                        float* dW, float* dbias, void* ws, void* stream);
 extern "C" int hugs_gemm_tn(int dtype, int Mrows, int Kc, int N, int nsplit, const void* X, int ldx, const void* G, int ldg,
                             float* dW, float* dbias, void* ws, void* stream) {
+  return gemm_tn_impl(0, dtype, Mrows, Kc, N, nsplit, X, ldx, G, ldg, dW, dbias, ws, stream);
+}
+extern "C" int hugs_gemm_tn_tiles(int tile_mode, int dtype, int Mrows, int Kc, int N, int nsplit, const void* X, int ldx, const void* G,
+                                  int ldg, float* dW, float* dbias, void* ws, void* stream) {
+  HUGS_REQUIRE(tile_mode == 0 || tile_mode == 1, -2, "hugs_gemm_tn_tiles: tile_mode %d (0 default, 1 force 128x128)", tile_mode);
+  return gemm_tn_impl(tile_mode, dtype, Mrows, Kc, N, nsplit, X, ldx, G, ldg, dW, dbias, ws, stream);
+}
+static int gemm_tn_impl(int tile_mode, int dtype, int Mrows, int Kc, int N, int nsplit, const void* X, int ldx, const void* G, int ldg,
+                        float* dW, float* dbias, void* ws, void* stream) {
   HUGS_REQUIRE(dtype == 0 || dtype == 1, -2, "hugs_gemm_tn: dtype must be 0 (fp32) or 1 (bf16)");
   const int step = dtype ? 64 : 16;
   HUGS_REQUIRE(Kc % 128 == 0 && N % 128 == 0 && nsplit >= 1 && Mrows % (nsplit * step) == 0, -3,
@@ -1441,7 +1383,7 @@ extern "C" int hugs_gemm_tn(int dtype, int Mrows, int Kc, int N, int nsplit, con
   const int rows_per = Mrows / nsplit;
   // (a single 256x256 tile qualifies too when the caller splits the rows deep enough: nerfacto's 256-wide field layers)
   if (dtype && Kc % 256 == 0 && N % 256 == 0 && ((Kc / 256) * (N / 256) >= 4 || rows_per >= 2048) && rows_per % 64 == 0 &&
-      rows_per >= 256 && g_force_small_tiles != 1)
+      rows_per >= 256 && tile_mode != 1)
     hipLaunchKernelGGL(k_gemm_tn_bf16_big, dim3((Kc / 256) * (N / 256) * nsplit), dim3(512), 0, (hipStream_t)stream, Mrows, Kc,
                        N, nsplit, (const uint16_t*)X, ldx, (const uint16_t*)G, ldg, slab, N, cs);
   else if (dtype)

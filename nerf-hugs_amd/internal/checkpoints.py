@@ -119,17 +119,23 @@ def restore_checkpoint(ckpt_dir, state):
     adam = opt['inner_states']['trainable']['inner_state']['0']
     for buf, tree in ((state.m, adam['mu']), (state.v, adam['nu'])):
       tree = tree.get('params', tree)
+      buf.zero_()                  # frozen leaves carry no moments (MaskedNode): a reused state must not keep stale ones
       for lf in model.layout.leaves:
         leaf = tree
         for k in lf['path']:
+          if not isinstance(leaf, dict) or k not in leaf:
+            raise ValueError(f'checkpoint {path}: optimizer state has no entry {"/".join(lf["path"])}')
           leaf = leaf[k]
         if not isinstance(leaf, dict):
-          model.layout.view(buf, lf['path']).copy_(torch.from_numpy(np.array(leaf)).to(buf.device))
+          arr = np.array(leaf)
+          if tuple(arr.shape) != tuple(lf['shape']):
+            raise ValueError(f'checkpoint {path}: moment {"/".join(lf["path"])} has shape {arr.shape}, the model wants {lf["shape"]}')
+          model.layout.view(buf, lf['path']).copy_(torch.from_numpy(arr).to(buf.device))
   else:
     adam = opt['0'] if '0' in opt else opt[0]
     model.load_variables(state.m, {'params': adam['mu'].get('params', adam['mu'])})
     model.load_variables(state.v, {'params': adam['nu'].get('params', adam['nu'])})
   state.step = int(np.asarray(d['step']))
   if getattr(model, '_engine', None) is not None:      # the compute-dtype weight copies follow the restored masters
-    model._engine.refresh_weights(state.flat)
+    model._engine.refresh_weights(state.flat, owner=state)
   return state

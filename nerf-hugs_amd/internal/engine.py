@@ -249,19 +249,20 @@ class Engine:
     self.layout = model.layout
     self.ws = Workspace(self.device)
     self.wn, self.wt = {}, {}     # compute-dtype weight copies keyed by leaf path
-    self._cast_src = None         # (data_ptr, torch version counter) of the flat buffer the copies were cast from
+    self._cast_src = None         # (TrainState.gen, data_ptr, torch version) the operand copies were last cast for, or None
     self.basis = {s.name: torch.from_numpy(s.basis).to(self.device) for s in model.specs}
     self.chunks = torch.from_numpy(self.layout.chunks).to(self.device)
     self.leaf_info = torch.from_numpy(self.layout.leaf_info).to(self.device)
 
   # ---- weights ------------------------------------------------------------------------------------
-  def refresh_weights(self, theta):
-    """Cast the fp32 masters to the GEMM operand copies: Wn [Kp,N] (dX) and Wt [N,Kp] (forward)."""
-    self._cast_src = (theta.data_ptr(), theta._version)
+  def refresh_weights(self, theta, owner=None):
+    """Cast the fp32 masters to the GEMM operand copies: Wn [Kp,N] (dX) and Wt [N,Kp] (forward).  owner: the
+    TrainState whose buffer `theta` is (the train step's own refresh), None for any other caller."""
+    self._cast_src = None if owner is None else (owner.gen, theta.data_ptr(), theta._version)
     tab = getattr(self, '_cast_table', None)
     if tab is None or tab[0] != theta.data_ptr():
-      # one 40-byte record per GEMM operand pair (include/hugs.h hugs_cast_weights_batch); rebuilt only when the
-      # master buffer moves
+      # one 40-byte record per GEMM operand pair (include/hugs.h hugs_cast_weights_batch): device ADDRESSES only, a pure
+      # function of (buffer address, layout) -- rebuilt when the master buffer moves
       rec, blk = [], 0
       for lf in self.layout.leaves:
         if lf['path'][-1] != 'kernel' or lf['layer']['kind'] not in ('trunk', 'bottleneck', 'view', 'tview', 'ttrunk'):
@@ -292,11 +293,12 @@ class Engine:
         self.wcat = torch.cat([self.wn[(spec.name, lv['name'], 'kernel')], self.wn[(spec.name, lt['name'], 'kernel')]],
                               1).contiguous()
 
-  def weights_current(self, theta):
-    """True when the operand copies were cast from this very buffer and torch has not written to it since
-    (Model.apply on other variables, load_variables, restore_checkpoint all change one of the two).  The step's own
-    Adam kernel writes through the raw pointer and refreshes the copies itself."""
-    return self._cast_src == (theta.data_ptr(), theta._version)
+  def weights_current(self, state):
+    """True when the operand copies were cast for this very TrainState (its process-unique generation number: a new
+    state that inherits a freed buffer's address and version count is NOT current) and torch has not written to its
+    buffer since (load_variables / restore_checkpoint bump the tensor version; Model.apply on any variables resets the
+    record).  The step's own Adam kernel writes through the raw pointer and refreshes the copies itself."""
+    return self._cast_src is not None and self._cast_src == (state.gen, state.flat.data_ptr(), state.flat._version)
 
   # ---- forward ------------------------------------------------------------------------------------
   def _mlp_forward(self, spec, theta, lvl, N, S, tdist, rays, glo, keep, tra=None):

@@ -18,6 +18,7 @@ from . import models
 from . import random as hrandom
 from . import utils
 
+_STATE_GEN = __import__('itertools').count(1)
 STAT_TAIL = 64  # floats appended to the gradient buffer for the per-step scalars that get pmean'ed (<= 7 levels)
 
 
@@ -40,6 +41,7 @@ class TrainState:
     self.m = torch.zeros_like(flat)
     self.v = torch.zeros_like(flat)
     self.step = 0
+    self.gen = next(_STATE_GEN)  # process-unique id of this state (Engine.weights_current: allocator addresses get reused)
     self.hyper = hyper           # dict(lr_fn, b1, b2, eps, trainable (device int32 per leaf) or None)
     self.params = model.variables(flat)
 
@@ -200,7 +202,7 @@ def create_train_step(model, config, is_finetune=False):
     _lib.call('hugs_opt_adam', nch, nleaf, eng.chunks, eng.leaf_info, state.flat, grad, state.m, state.v, mod_scale, h['trainable'], gscale,
               config.grad_max_val, lr, h['b1'], h['b2'], h['eps'], 1.0 - h['b1']**t, 1.0 - h['b2']**t, part2,
               leaf_stats[nleaf * 4:nleaf * 6])
-    eng.refresh_weights(state.flat)
+    eng.refresh_weights(state.flat, owner=state)
     state.step += 1
     return leaf_stats
 
@@ -216,8 +218,8 @@ def create_train_step(model, config, is_finetune=False):
       if (N * S_) % 128:
         raise ValueError(f'per-device batch of {N} rays x {S_} samples is not a multiple of the 128-row GEMM tile: '
                          'use a batch size that is a multiple of 4 (eval pads ragged chunks itself)')
-    if not eng.weights_current(state.flat):
-      eng.refresh_weights(state.flat)
+    if not eng.weights_current(state):
+      eng.refresh_weights(state.flat, owner=state)
     u01 = None
     if isinstance(rng, (list, tuple)):             # explicit U[0,1) draws, one [N] (or [N,S]) tensor per level: the
       if len(rng) != L:                            # numbers jax.random.uniform handed the reference (fixtures, tests)

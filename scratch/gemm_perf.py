@@ -10,9 +10,8 @@ def check(M,N,K1,K2,relu=1,mask=False,r1=False,rb=False):
     rr=torch.randn(M,device=dev) if r1 else None; rc=torch.randn(N,device=dev) if r1 else None
     outs=[]
     for small in (0,1,2):
-        L.call('hugs_test_force_small_tiles', small)
         out=torch.empty(M,N,device=dev,dtype=torch.bfloat16)
-        L.call('hugs_gemm_nt',1,M,N,K1,K2,A1,K1,A2,K2,Bt,K1+K2,bias,rbt,64,N,relu,mk,N,rr,rc,out,N)
+        L.call('hugs_gemm_nt_tiles', small, 1,M,N,K1,K2,A1,K1,A2,K2,Bt,K1+K2,bias,rbt,64,N,relu,mk,N,rr,rc,out,N)
         outs.append(out)
     A=torch.cat([A1,A2],1) if K2 else A1
     ref=A.double()@Bt.double().T+bias.double()
@@ -23,10 +22,9 @@ def check(M,N,K1,K2,relu=1,mask=False,r1=False,rb=False):
     print(f'M={M} N={N} K={K1}+{K2} relu={relu} mask={mask} r1={r1} rb={rb}: err256 {(outs[0].double()-ref).abs().max().item():.3e} err128 {(outs[1].double()-ref).abs().max().item():.3e} equal {torch.equal(outs[0],outs[1])} {torch.equal(outs[0],outs[2])}')
 check(256,256,128,0); check(1024,1024,1024,512); check(512,256,512,0,relu=0,mask=True,r1=True); check(768,256,256,0,rb=True); check(2048,1024,256,0); check(512,128,1024,512)
 def perf(M,N,K,small,mask=False):
-    L.call('hugs_test_force_small_tiles', small)
     A=torch.randn(M,K,device=dev).bfloat16(); Bt=(torch.randn(N,K,device=dev)/32).bfloat16(); bias=torch.zeros(N,device=dev)
     out=torch.empty(M,N,device=dev,dtype=torch.bfloat16); mk=torch.randn(M,N,device=dev).bfloat16() if mask else None
-    f=lambda: L.call('hugs_gemm_nt',1,M,N,K,0,A,K,None,0,Bt,K,bias,None,1,0,0 if mask else 1,mk,N,None,None,out,N)
+    f=lambda: L.call('hugs_gemm_nt_tiles', small, 1,M,N,K,0,A,K,None,0,Bt,K,bias,None,1,0,0 if mask else 1,mk,N,None,None,out,N)
     for _ in range(3): f()
     e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -1,4 +1,4 @@
-"""scratch: K = 128 NT GEMM, 256x256 ring kernel vs the 128x128 kernel (hugs_test_force_small_tiles), two M."""
+"""scratch: K = 128 NT GEMM, 256x256 ring kernel vs the 128x128 kernel (hugs_gemm_nt_tiles tile_mode 1), two M."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,10 +14,8 @@ def t(fn, n=30):
 for M in (131072, 2097152):
   for (N, K) in ((256, 128), (128, 256), (256, 256)):
     A = torch.randn(M, K, device=dev).bfloat16(); Bt = (torch.randn(N, K, device=dev) / 16).bfloat16(); out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-    call = lambda: L.call('hugs_gemm_nt', 1, M, N, K, 0, A, K, None, 0, Bt, K, None, None, 1, 0, 0, None, 0, None, None, out, N)
+    call = lambda force=0: L.call('hugs_gemm_nt_tiles', force, 1, M, N, K, 0, A, K, None, 0, Bt, K, None, None, 1, 0, 0, None, 0, None, None, out, N)
     res = []
     for force in (0, 1):
-      L.lib().cdll.hugs_test_force_small_tiles(force)
-      res.append(t(call))
-    L.lib().cdll.hugs_test_force_small_tiles(0)
+      res.append(t(lambda: call(force)))
     print(f'M={M} N={N} K={K}: ring {res[0]:.1f} us, 128x128 {res[1]:.1f} us')

@@ -4,11 +4,10 @@ import torch
 from nerf_hugs_amd import _lib as L
 dev='cuda'
 def run(Mr,Kc,N,ns,small,check=True,bias=True):
-    L.call('hugs_test_force_small_tiles', small)
     X=torch.randn(Mr,Kc,device=dev).bfloat16(); G=torch.randn(Mr,N,device=dev).bfloat16()
     dW=torch.empty(Kc,N,device=dev); db=torch.empty(N,device=dev) if bias else None
     ws=torch.empty(L.lib().cdll.hugs_gemm_tn_ws_bytes(Kc,N,ns)//4,device=dev)
-    f=lambda: L.call('hugs_gemm_tn',1,Mr,Kc,N,ns,X,Kc,G,N,dW,db,ws)
+    f=lambda: L.call('hugs_gemm_tn_tiles', small, 1,Mr,Kc,N,ns,X,Kc,G,N,dW,db,ws)
     f(); msg=''
     if check:
         ref=X.double().T@G.double()

@@ -8,9 +8,8 @@ A=torch.randn(M,K,device=dev).bfloat16(); Bt=(torch.randn(N,K,device=dev)/32).bf
 for v in sys.argv[1:]:
     L._LIB=None; L.LIB_PATH=os.path.join(os.path.dirname(L.LIB_PATH), f'libhugs_v{v}.so')
     for mode in (0, 3):
-        L.call('hugs_test_force_small_tiles', mode)
         out=torch.empty(M,N,device=dev,dtype=torch.bfloat16)
-        f=lambda: L.call('hugs_gemm_nt',1,M,N,K,0,A,K,None,0,Bt,K,bias,None,1,0,1,None,0,None,None,out,N)
+        f=lambda: L.call('hugs_gemm_nt_tiles', mode, 1,M,N,K,0,A,K,None,0,Bt,K,bias,None,1,0,1,None,0,None,None,out,N)
         res=[]
         for rep in range(3):
             for _ in range(10): f()

@@ -242,3 +242,56 @@ def test_geopoly_basis_reference_golden():
   np.testing.assert_allclose(np.linalg.norm(basis, axis=-1), 1, atol=1e-12)
   # symmetric directions were removed: no column is the negation of another (geopoly.py:113-121)
   assert (np.abs(basis @ basis.T + 1) < 1e-6).sum() == 0
+
+
+def test_allreduce_leftover_ranges_cover_every_leaf():
+  """The bucketed gradient all-reduce (train_utils.py:457-459 is ONE pmean): whatever the buckets leave out is found
+  leaf by leaf -- a tiny leaf (1-float density bias, 3-float rgb bias) sitting between two bucketed ranges must be
+  reduced, only alignment padding may stay out."""
+  from nerf_hugs_amd.internal import configs, models, train_utils
+  configs.clear_config()
+  configs.parse_config_files_and_bindings(None, ["Model.num_glo_features = 4"])
+  m = models.Model(configs.make_config())
+  lay = m.layout
+  total = lay.size + train_utils.STAT_TAIL
+  span = lambda lf: (lf['off'], lf['off'] + int(np.prod(lf['pshape'])))
+
+  def check(covered):
+    todo = train_utils.uncovered_ranges(lay, covered, total)
+    flags = np.zeros(total, bool)
+    for lo, hi in covered + todo:
+      flags[lo:hi] = True
+    for lf in lay.leaves:
+      lo, hi = span(lf)
+      assert flags[lo:hi].all(), f'{"/".join(lf["path"])} is never all-reduced'
+    assert flags[lay.size:].all(), 'the stat tail is never all-reduced'
+    for (a, b), (c, d) in zip(todo, todo[1:]):
+      assert b <= c
+    return todo
+
+  assert check([]) == [(0, total)]
+  # buckets = every NerfMLP kernel; all the (small) biases between them, the PropMLP, the GLO table and the tail are left over
+  kernels = [span(lf) for lf in lay.leaves if lf['path'][0] == 'NerfMLP_0' and lf['path'][-1] == 'kernel']
+  todo = check(kernels)
+  dens_bias = lay.by_path[('NerfMLP_0', f'Dense_{m.nerf_spec.net_depth}', 'bias')]
+  assert int(np.prod(dens_bias['pshape'])) == 1
+  assert any(lo <= dens_bias['off'] < hi for lo, hi in todo)
+  # a bucket that cuts a leaf in half does not count as covering it
+  k0 = kernels[0]
+  check([(k0[0], (k0[0] + k0[1]) // 2)] + kernels[1:])
+  configs.clear_config()
+
+
+def test_stat_tail_slots_do_not_overlap_for_any_level_count():
+  from nerf_hugs_amd.internal import train_utils
+  for L in range(1, 8):
+    o = train_utils._tail_slots(L)
+    spans = sorted([(o['data'], 2 * L), (o['interlevel'], L - 1), (o['distortion'], 1), (o['robust'], 5 * L), (o['hanerf'], 2),
+                    (o['nerfw'], 2)])
+    end = 0
+    for lo, n in spans:
+      assert lo >= end
+      end = lo + n
+    assert end <= train_utils.STAT_TAIL
+  with pytest.raises(NotImplementedError):
+    train_utils._tail_slots(8)
