@@ -49,6 +49,9 @@ struct GemmEpi {
 #define HUGS_TR_ID()
 #define HUGS_STAGGER()
 #endif
+#ifndef HUGS_EPI_STORE
+#define HUGS_EPI_STORE(v_, p_) __builtin_nontemporal_store(v_, p_)
+#endif
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   // contiguous band of tiles per XCD; bijective for any nwg (cdna guide T1)
@@ -342,7 +345,7 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
         // bits measured within noise of it)
         { typedef unsigned __attribute__((ext_vector_type(4))) u32x4_t; const u32x4_t v_ = {vw[0], vw[1], vw[2], vw[3]};
           u32x4_t* p_ = (u32x4_t*)((uint16_t*)E.out + (size_t)(m0 + wm * 128 + i * 16 + h * 8 + srow) * E.ldc + ccol);
-          __builtin_nontemporal_store(v_, p_);
+          HUGS_EPI_STORE(v_, p_);
         }
       }
     }

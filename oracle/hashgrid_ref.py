@@ -8,7 +8,8 @@ published algorithm (Mueller et al., "Instant Neural Graphics Primitives", SIGGR
 
   level l:  scale_l = 2^(l * log2(per_level_scale)) * base_resolution - 1,  resolution_l = ceil(scale_l) + 1
             entries_l = min(round_up(resolution_l^3, 8), 2^log2_hashmap_size);  levels are concatenated
-  lookup :  pos = fma(x, scale_l, 0.5);  cell = floor(pos);  w = pos - cell;  trilinear weights over the 8 corners;
+  lookup :  pos = fma(x, scale_l, 0.5);  cell = floor(pos);  w = pos - cell;  trilinear weights over the 8 corners
+            (bilinear over 4 for the 2-D grid: resolution_l^2 dense entries, hash over the first two primes);
             corner index = dense (x + y*res + z*res^2) while res^d stays within the level's entries, otherwise
             the coherent prime hash (x*1) ^ (y*2654435761) ^ (z*805459861), both modulo entries_l (uint32 arithmetic)
   output :  [N, n_levels * features_per_level], level-major
@@ -23,14 +24,15 @@ import numpy as np
 PRIMES = (np.uint32(1), np.uint32(2654435761), np.uint32(805459861))
 
 
-def level_table(n_levels, base_resolution, per_level_scale, log2_hashmap_size):
-  """-> (offsets [L+1] in entries, resolutions [L], scales [L] float32)."""
+def level_table(n_levels, base_resolution, per_level_scale, log2_hashmap_size, dims=3):
+  """-> (offsets [L+1] in entries, resolutions [L], scales [L] float32).  dims: 3 (fields) or 2 (the nerfacto HA-NeRF
+  ImplicitMask's image-plane grid, nerfacto.py:1036-1047)."""
   offs, ress, scales, off = [0], [], [], 0
   l2 = np.float32(np.log2(np.float32(per_level_scale)))
   for l in range(n_levels):
     scale = np.float32(np.exp2(np.float32(l) * l2) * np.float32(base_resolution) - np.float32(1.0))
     res = int(np.ceil(scale)) + 1
-    n = min(res ** 3, 2 ** 31 - 1)
+    n = min(res ** dims, 2 ** 31 - 1)
     n = (n + 7) // 8 * 8
     n = min(n, 1 << log2_hashmap_size)
     off += n
@@ -38,13 +40,20 @@ def level_table(n_levels, base_resolution, per_level_scale, log2_hashmap_size):
   return np.array(offs, np.int64), np.array(ress, np.int64), np.array(scales, np.float32)
 
 
-def _index(cx, cy, cz, res, entries):
+def _index(cs, res, entries):
+  """cs: list of D integer coordinate arrays."""
+  D = len(cs)
   res = np.uint64(res)
-  if int(res) ** 3 <= entries:       # dense: the stride never exceeds the level's size
-    idx = cx.astype(np.uint64) + cy.astype(np.uint64) * res + cz.astype(np.uint64) * res * res
+  if int(res) ** D <= entries:       # dense: the stride never exceeds the level's size
+    idx, stride = np.zeros(cs[0].shape, np.uint64), np.uint64(1)
+    for c in cs:
+      idx = idx + c.astype(np.uint64) * stride
+      stride = stride * res
   else:
     with np.errstate(over='ignore'):
-      idx = ((cx.astype(np.uint32) * PRIMES[0]) ^ (cy.astype(np.uint32) * PRIMES[1]) ^ (cz.astype(np.uint32) * PRIMES[2]))
+      idx = cs[0].astype(np.uint32) * PRIMES[0]
+      for k in range(1, D):
+        idx = idx ^ (cs[k].astype(np.uint32) * PRIMES[k])
   return (idx.astype(np.uint64) % np.uint64(entries)).astype(np.int64)
 
 
@@ -54,8 +63,9 @@ def _fma(x, sc):
 
 
 def hashgrid_forward(x, table, offsets, resolutions, scales, F):
-  """x [N,3] float32 in [0,1]; table [sum entries, F] -> [N, L*F] (float64 accumulation of float32 operands)."""
+  """x [N,D] float32 in [0,1] (D = 3 or 2); table [sum entries, F] -> [N, L*F] (float64 accumulation of float32 operands)."""
   x = np.asarray(x, np.float32)
+  D = x.shape[1]
   out = np.zeros((x.shape[0], len(resolutions) * F), np.float64)
   for l, (res, sc) in enumerate(zip(resolutions, scales)):
     pos = _fma(x, sc)
@@ -63,12 +73,12 @@ def hashgrid_forward(x, table, offsets, resolutions, scales, F):
     w = (pos - cell).astype(np.float64)
     c = cell.astype(np.int64)
     entries = int(offsets[l + 1] - offsets[l])
-    for corner in range(8):
-      d = [(corner >> k) & 1 for k in range(3)]
+    for corner in range(1 << D):
+      d = [(corner >> k) & 1 for k in range(D)]
       wt = np.ones(x.shape[0])
-      for k in range(3):
+      for k in range(D):
         wt = wt * (w[:, k] if d[k] else 1 - w[:, k])
-      idx = _index(c[:, 0] + d[0], c[:, 1] + d[1], c[:, 2] + d[2], res, entries) + int(offsets[l])
+      idx = _index([c[:, k] + d[k] for k in range(D)], res, entries) + int(offsets[l])
       out[:, l * F:(l + 1) * F] += wt[:, None] * table[idx].astype(np.float64)
   return out
 
@@ -76,6 +86,7 @@ def hashgrid_forward(x, table, offsets, resolutions, scales, F):
 def hashgrid_backward(x, d_out, n_entries, offsets, resolutions, scales, F):
   """d loss / d table [n_entries, F] (float64)."""
   x = np.asarray(x, np.float32)
+  D = x.shape[1]
   g = np.zeros((n_entries, F), np.float64)
   for l, (res, sc) in enumerate(zip(resolutions, scales)):
     pos = _fma(x, sc)
@@ -83,12 +94,12 @@ def hashgrid_backward(x, d_out, n_entries, offsets, resolutions, scales, F):
     w = (pos - cell).astype(np.float64)
     c = cell.astype(np.int64)
     entries = int(offsets[l + 1] - offsets[l])
-    for corner in range(8):
-      d = [(corner >> k) & 1 for k in range(3)]
+    for corner in range(1 << D):
+      d = [(corner >> k) & 1 for k in range(D)]
       wt = np.ones(x.shape[0])
-      for k in range(3):
+      for k in range(D):
         wt = wt * (w[:, k] if d[k] else 1 - w[:, k])
-      idx = _index(c[:, 0] + d[0], c[:, 1] + d[1], c[:, 2] + d[2], res, entries) + int(offsets[l])
+      idx = _index([c[:, k] + d[k] for k in range(D)], res, entries) + int(offsets[l])
       np.add.at(g, idx, wt[:, None] * np.asarray(d_out, np.float64)[:, l * F:(l + 1) * F])
   return g
 

@@ -58,7 +58,9 @@ def _run_case(gin, n_patch=1, P=8, near=0.1, far=1.2, seed=5, inlier=None, tol_g
     sc = og.double().abs().max().clamp(min=1e-20)
     e = ((g.double() - og.double()).abs() / sc).flatten()
     worst = max(worst, float(e.max()))
-    assert float(e.median()) < 3e-3 and float(e.max()) < tol_grad, \
+    # (the median is a statement about a population: one- and three-element leaves -- head biases -- are held to the
+    # max bound only; one flipped relu moves such a leaf by a sample's whole contribution)
+    assert (e.numel() <= 8 or float(e.median()) < 3e-3) and float(e.max()) < tol_grad, \
         f'grad {name}: rel err median {float(e.median()):.2e} max {float(e.max()):.2e} (max |g| {float(sc):.2e})'
   assert abs(float(stats['loss']) / float(ostats['loss']) - 1) < 1e-4
   np.testing.assert_allclose(stats['mses'].numpy(), ostats['mses'].detach().numpy(), rtol=2e-4)
