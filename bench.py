@@ -159,20 +159,11 @@ def eval_psnr_vs_oracle(model, state, batch, dtype):
   return round(-10.0 * np.log10(max(mse, 1e-20)), 2)
 
 
-# BASELINE.json configs[4]: nerfacto/configs/phototourism_nerfacto_base.yml model section
-CFG5 = dict(hidden_dim=256, geo_feat_dim=64, hidden_dim_color=256, base_res=16, max_res=8192, log2_hashmap_size=21, features_per_level=2,
-            use_appearance_embedding=True, appearance_embedding_dim=48, opaque_background=True, num_nerf_samples_per_ray=128,
-            num_proposal_samples_per_ray=(512, 256), num_proposal_iterations=2,
-            proposal_net_args_list=[dict(base_res=16, hidden_dim=64, log2_hashmap_size=17, features_per_level=2, num_levels=5, max_res=512),
-                                    dict(base_res=16, hidden_dim=64, log2_hashmap_size=17, features_per_level=2, num_levels=7, max_res=2048)],
-            proposal_initial_sampler='uniform', proposal_histogram_padding=0.005, proposal_weights_anneal_max_num_iters=10000,
-            rgb_loss_type='mse', distortion_loss_mult=0.001, bound=2.0)
-
-
 def bench_nerfacto(args, device, world, rank):
   """Informational line for BASELINE configs[4] (nerfacto hash-grid path): 16384 rays per GPU, full train step."""
   import torch.distributed as dist
   from nerf_hugs_amd.nerfacto.model import NerfactoConfig, NerfactoModel
+  from nerf_hugs_amd.nerfacto.configs import PHOTOTOURISM_NERFACTO_BASE as CFG5     # BASELINE.json configs[4]: the yml's sizes
   model = NerfactoModel(NerfactoConfig(**CFG5), device=device, compute_dtype=args.dtype, seed=20200823)
   N = 16384
   g = torch.Generator(device=device).manual_seed(100 + rank)

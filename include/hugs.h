@@ -245,6 +245,16 @@ int hugs_hashgrid_bwd(int n, int n_levels, int features, const long long* level_
                       const float* level_scales, const float* x01, const void* d_out, int d_out_bf16, int row_pitch,
                       float* d_table_accum, void* stream);
 int hugs_sh4_fwd(int n, const float* dirs01, int out_bf16, int row_pitch, int col0, void* out, void* stream);
+/* nerfacto.py:1036-1047,1080-1091 (HA-NeRF ImplicitMask of the nerfacto model): 2-D hash grid of per-RAY image coordinates
+ * x01 [n,2] (resolution^2 dense entries / two-prime hash, bilinear).  The forward writes the mask MLP's whole input row
+ * out[n, :row_pitch] = [grid (n_levels*features) | extra[n, :T] (the ray's transient embedding row) | zeros]; the backward
+ * ADDS the table gradient (fp32 atomics) from the first n_levels*features columns of d_out. */
+int hugs_hashgrid2d_fwd(int n, int n_levels, int features, const long long* level_offsets, const int* level_resolutions,
+                        const float* level_scales, const float* x01, const float* table, const float* extra, int T,
+                        int out_bf16, int row_pitch, void* out, void* stream);
+int hugs_hashgrid2d_bwd(int n, int n_levels, int features, const long long* level_offsets, const int* level_resolutions,
+                        const float* level_scales, const float* x01, const void* d_out, int d_out_bf16, int row_pitch,
+                        float* d_table_accum, void* stream);
 
 /* hugs_gemm_nt with 1-bit relu masks in the 256x256 kernels' own register layout (bf16; M, N multiples of 256, ldc == N,
  * K a multiple of 64 and >= 256): a relu epilogue writes bits_out (hugs_gemm_nt_bits_bytes(M, N) = M*N/8 bytes: per

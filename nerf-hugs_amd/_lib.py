@@ -60,6 +60,8 @@ _PROTOS = {
     'hugs_hashgrid_fwd': 'iiippppp' 'iips',
     'hugs_hashgrid_bwd': 'iiippppp' 'iips',
     'hugs_sh4_fwd': 'ipiiips',
+    'hugs_hashgrid2d_fwd': 'iiippppp' 'piiips',
+    'hugs_hashgrid2d_bwd': 'iiippppp' 'iips',
     'hugs_nf_sample': 'iiippffppiffipppps',
     'hugs_nf_positions': 'iipppifpps',
     'hugs_nf_weights_fwd': 'iipppipppppps',

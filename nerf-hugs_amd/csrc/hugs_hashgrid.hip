@@ -279,6 +279,78 @@ k_sh4(int n, const float* __restrict__ d01, int row_pitch, int col0, void* __res
   }
 }
 
+// ---- 2-D grid: HA-NeRF's ImplicitMask in the nerfacto model (nerfacto.py:1036-1047, 1080-1091) encodes the pixel coordinate
+// of a RAY (not a sample): resolution^2 dense entries or the two-prime hash, bilinear over 4 corners.  One thread per ray
+// writes the whole input row of the mask MLP: [grid features | per-ray transient embedding | zero padding].
+template <int F, bool BF16>
+__global__ void __launch_bounds__(256)
+k_hashgrid2d_fwd(int n, int L, HgLevels lv, const float* __restrict__ x, const float* __restrict__ table,
+                 const float* __restrict__ extra, int T, int row_pitch, void* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float px = x[2 * i], py = x[2 * i + 1];
+  auto put = [&](int col, float v) {
+    if (BF16) ((uint16_t*)out)[(size_t)i * row_pitch + col] = f_to_bf16(v);
+    else ((float*)out)[(size_t)i * row_pitch + col] = v;
+  };
+  for (int l = 0; l < L; ++l) {
+    const uint32_t res = lv.res[l], entries = lv.off[l + 1] - lv.off[l];
+    const bool dense = (uint64_t)res * res <= entries;
+    const float sc = lv.scale[l];
+    const float fx = fmaf(px, sc, .5f), fy = fmaf(py, sc, .5f);
+    const float gx = floorf(fx), gy = floorf(fy);
+    const float wx = fx - gx, wy = fy - gy;
+    const uint32_t cx = (uint32_t)(int)gx, cy = (uint32_t)(int)gy;
+    const float* tb = table + (size_t)lv.off[l] * F;
+    float acc[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float w = ((c & 1) ? wx : 1.f - wx) * ((c & 2) ? wy : 1.f - wy);
+      const uint32_t ux = cx + (c & 1), uy = cy + (c >> 1);
+      const uint32_t idx = (dense ? ux + uy * res : (ux * 1u) ^ (uy * 2654435761u)) % entries;
+#pragma unroll
+      for (int f = 0; f < F; ++f) acc[f] += w * tb[(size_t)idx * F + f];
+    }
+#pragma unroll
+    for (int f = 0; f < F; ++f) put(l * F + f, acc[f]);
+  }
+  for (int t = 0; t < T; ++t) put(L * F + t, extra[(size_t)i * T + t]);
+  for (int c = L * F + T; c < row_pitch; ++c) put(c, 0.f);
+}
+
+template <int F, bool BF16>
+__global__ void __launch_bounds__(256)
+k_hashgrid2d_bwd(int n, int L, HgLevels lv, const float* __restrict__ x, const void* __restrict__ d_out, int row_pitch,
+                 float* __restrict__ d_table) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float px = x[2 * i], py = x[2 * i + 1];
+  for (int l = 0; l < L; ++l) {
+    const uint32_t res = lv.res[l], entries = lv.off[l + 1] - lv.off[l];
+    const bool dense = (uint64_t)res * res <= entries;
+    const float sc = lv.scale[l];
+    const float fx = fmaf(px, sc, .5f), fy = fmaf(py, sc, .5f);
+    const float gx = floorf(fx), gy = floorf(fy);
+    const float wx = fx - gx, wy = fy - gy;
+    const uint32_t cx = (uint32_t)(int)gx, cy = (uint32_t)(int)gy;
+    float* tb = d_table + (size_t)lv.off[l] * F;
+    float g[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+      g[f] = BF16 ? bf16_to_f(((const uint16_t*)d_out)[(size_t)i * row_pitch + l * F + f]) : ((const float*)d_out)[(size_t)i * row_pitch + l * F + f];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float w = ((c & 1) ? wx : 1.f - wx) * ((c & 2) ? wy : 1.f - wy);
+      const uint32_t ux = cx + (c & 1), uy = cy + (c >> 1);
+      const uint32_t idx = (dense ? ux + uy * res : (ux * 1u) ^ (uy * 2654435761u)) % entries;
+#pragma unroll
+      for (int f = 0; f < F; ++f) atomicAdd(tb + (size_t)idx * F + f, w * g[f]);
+    }
+  }
+}
+
 int fill_levels(HgLevels& lv, int L, const long long* off, const int* res, const float* scale, const char* who) {
   HUGS_REQUIRE(L >= 1 && L <= HG_MAXL && off && res && scale, -2, "%s: %d levels (1..%d) / null level table", who, L, HG_MAXL);
   for (int l = 0; l <= L; ++l) {
@@ -356,5 +428,52 @@ extern "C" int hugs_sh4_fwd(int n, const float* dirs01, int out_bf16, int row_pi
   if (out_bf16) k_sh4<true><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, dirs01, row_pitch, col0, out);
   else k_sh4<false><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, dirs01, row_pitch, col0, out);
   HUGS_CHECK_LAUNCH("k_sh4");
+  return 0;
+}
+
+/* 2-D hash grid of per-RAY image coordinates (nerfacto HA-NeRF ImplicitMask, nerfacto.py:1036-1047,1080-1091): writes the
+ * mask MLP's whole input row out[n, :] = [grid(x01[n]) (n_levels*features) | extra[n, :T] | 0 ... (row_pitch)]. */
+extern "C" int hugs_hashgrid2d_fwd(int n, int n_levels, int features, const long long* level_offsets,
+                                   const int* level_resolutions, const float* level_scales, const float* x01,
+                                   const float* table, const float* extra, int T, int out_bf16, int row_pitch, void* out,
+                                   void* stream) {
+  HgLevels lv;
+  int rc = fill_levels(lv, n_levels, level_offsets, level_resolutions, level_scales, "hugs_hashgrid2d_fwd");
+  if (rc) return rc;
+  HUGS_REQUIRE(features == 2 || features == 4, -2, "hugs_hashgrid2d_fwd: %d features per level (2 or 4)", features);
+  HUGS_REQUIRE(T >= 0 && (T == 0 || extra) && row_pitch >= n_levels * features + T, -2, "hugs_hashgrid2d_fwd: row pitch %d < %d + %d",
+               row_pitch, n_levels * features, T);
+  if (n <= 0) return 0;
+  const dim3 g((n + 255) / 256), b(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (features == 2) {
+    if (out_bf16) k_hashgrid2d_fwd<2, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, extra, T, row_pitch, out);
+    else k_hashgrid2d_fwd<2, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, extra, T, row_pitch, out);
+  } else {
+    if (out_bf16) k_hashgrid2d_fwd<4, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, extra, T, row_pitch, out);
+    else k_hashgrid2d_fwd<4, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, extra, T, row_pitch, out);
+  }
+  HUGS_CHECK_LAUNCH("k_hashgrid2d_fwd");
+  return 0;
+}
+
+extern "C" int hugs_hashgrid2d_bwd(int n, int n_levels, int features, const long long* level_offsets,
+                                   const int* level_resolutions, const float* level_scales, const float* x01,
+                                   const void* d_out, int d_out_bf16, int row_pitch, float* d_table_accum, void* stream) {
+  HgLevels lv;
+  int rc = fill_levels(lv, n_levels, level_offsets, level_resolutions, level_scales, "hugs_hashgrid2d_bwd");
+  if (rc) return rc;
+  HUGS_REQUIRE(features == 2 || features == 4, -2, "hugs_hashgrid2d_bwd: %d features per level (2 or 4)", features);
+  if (n <= 0) return 0;
+  const dim3 g((n + 255) / 256), b(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (features == 2) {
+    if (d_out_bf16) k_hashgrid2d_bwd<2, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum);
+    else k_hashgrid2d_bwd<2, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum);
+  } else {
+    if (d_out_bf16) k_hashgrid2d_bwd<4, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum);
+    else k_hashgrid2d_bwd<4, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum);
+  }
+  HUGS_CHECK_LAUNCH("k_hashgrid2d_bwd");
   return 0;
 }

@@ -10,25 +10,28 @@ from .. import _lib as L
 
 
 class HashGrid:
-  """n_levels x features_per_level multiresolution hash encoding of points in [0,1]^3.
+  """n_levels x features_per_level multiresolution hash encoding of points in [0,1]^3 (dims=2: of image-plane
+  coordinates in [0,1]^2, the nerfacto HA-NeRF ImplicitMask's grid -- level table only, the model calls the 2-D kernels).
 
   `table` is the fp32 parameter tensor [total entries, features] (tiny-cuda-nn initialises U(-1e-4, 1e-4));
   `forward(x01)` returns [N, n_levels*features] in bf16 or fp32, `backward(x01, d_out, d_table)` accumulates
   d loss / d table into `d_table` (the positions get no gradient: nerfacto does not optimise cameras here)."""
 
   def __init__(self, n_levels=16, features_per_level=2, log2_hashmap_size=19, base_resolution=16, per_level_scale=None,
-               max_resolution=2048, device='cuda', seed=0):
+               max_resolution=2048, device='cuda', seed=0, dims=3):
     if per_level_scale is None:       # nerfacto.py:713 growth_factor
       per_level_scale = float(np.exp((np.log(max_resolution) - np.log(base_resolution)) / (n_levels - 1))) if n_levels > 1 else 1.0
     if features_per_level not in (2, 4):
       raise ValueError('features_per_level must be 2 or 4')
-    self.n_levels, self.features = n_levels, features_per_level
+    if dims not in (2, 3):
+      raise ValueError('hash grid of 2-D (image plane) or 3-D points')
+    self.n_levels, self.features, self.dims = n_levels, features_per_level, dims
     offs, ress, scales, off = [0], [], [], 0
     l2 = np.float32(np.log2(np.float32(per_level_scale)))
     for l in range(n_levels):
       scale = np.float32(np.exp2(np.float32(l) * l2) * np.float32(base_resolution) - np.float32(1.0))
       res = int(np.ceil(scale)) + 1
-      n = min(res ** 3, 2 ** 31 - 1)
+      n = min(res ** dims, 2 ** 31 - 1)
       n = min((n + 7) // 8 * 8, 1 << log2_hashmap_size)
       off += n
       offs.append(off); ress.append(res); scales.append(scale)

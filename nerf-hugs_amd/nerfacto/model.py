@@ -1,15 +1,25 @@
-"""The reference's NERFACTO training path (nerfacto/models/nerfacto.py `Model` + `Loss`, nerfacto/train.py:183-215) for
-its base / withmask configurations, on HIP kernels: proposal sampling (csrc/hugs_nerfacto.hip), multiresolution hash
+"""The reference's NERFACTO training path (nerfacto/models/nerfacto.py `Model` + `Loss`, nerfacto/train.py:183-215) on HIP
+kernels: proposal sampling (csrc/hugs_nerfacto.hip), multiresolution hash
 grids + SH-4 (csrc/hugs_hashgrid.hip), the fields' Linear layers on the shared MFMA GEMMs (csrc/hugs_gemm.hip, every
 width zero-padded to the 128-column tile), density -> weights -> colour, interlevel / distortion / rgb losses, a
 hand-scheduled backward pass and Adam.  SURVEY 8f row 3, BASELINE config 5.
 
 Field form: the `enable_tcnn_mlp: False` one (torch Linear layers, what configs/phototourism_nerfacto_base.yml
 selects); the reference runs them under fp16 autocast, here the GEMM operands are bf16 with fp32 accumulation
-(`compute_dtype='bf16'`) or fp32 (`'fp32'`, parity mode).  PARITY UNPINNED for the encodings (tiny-cuda-nn); the
-sampler / weights / losses are pinned through oracle/nerfacto_ref.py (tests/test_gpu_nerfacto.py).
-Not built: NeRF-W / HA-NeRF / RobustNeRF branches of the nerfacto model, eval-mode embedding averaging, DataParallel
-(the multi-GPU form here is one process per GPU with an all-reduce of the flat gradient, as for Mip-NeRF 360)."""
+(`compute_dtype='bf16'`) or fp32 (`'fp32'`, parity mode).  PARITY UNPINNED for the encodings themselves (tiny-cuda-nn);
+the sampler / weights / losses are pinned by vectors from the reference's pure-torch utils, and the field / model / loss
+WIRING by vectors recorded from executing the reference's own `Model` / `Loss` classes over a stand-in `tinycudann`
+(tests/golden/gen_nerfacto_model_fixtures.py -> tests/test_gpu_nerfacto_reference.py).
+Built: transient_type None / 'withmask' / 'robustnerf' / 'hanerf' (ImplicitMask: 2-D hash grid of the ray's image
+coordinate | transient embedding -> Linear+relu x 2 -> sigmoid, compute_hanerf_loss), eval-mode rendering with
+eval_embedding average / zero / original, the finetune stage (plain data loss, listed parameter groups only), the
+reference's proposal-update gating INCLUDING what it does to the optimizer (parameters whose .grad stays None are
+skipped by torch.optim.Adam: no moment decay, no step count).
+'nerfw' raises: the reference's own nerfacto NeRF-W branch cannot execute (nerfacto.py:394-401 format an undefined name
+`output_type`: NameError on the first forward; recorded in ref_nerfacto_model.npz).
+Multi-GPU: one process per GPU with an all-reduce of the flat gradient (the reference wraps the model in
+nn.DataParallel: ONE loss over the gathered batch).  Per-rank normalisers therefore differ from the reference's for
+'withmask' (mask sum) and 'robustnerf' (the inlier quantile is taken per rank, and each rank feeds back its own)."""
 import math
 import os
 
@@ -51,6 +61,11 @@ class NerfactoConfig:
     self.robustnerf_smoothed_inlier_quantile, self.robustnerf_inner_patch_size = 0.5, 8
     self.robustnerf_inner_patch_inlier_quantile, self.patch_size = 0.4, 16      # patch_size: train.py's config.patch_size
     self.rgb_bias = 0.
+    # HA-NeRF (nerfacto.py:42-53, 94-102): transient embedding + ImplicitMask
+    self.use_transient_embedding, self.transient_embedding_dim = False, 16
+    self.num_levels_implicit, self.base_res_implicit, self.max_res_implicit = 8, 16, 1024
+    self.log2_hashmap_size_implicit, self.features_per_level_implicit, self.hidden_dim_implicit = 17, 2, 128
+    self.hanerf_mask_size_loss_mult_min, self.hanerf_mask_size_loss_mult_max, self.hanerf_mask_size_loss_mult_k = 6e-3, 5e-2, 1e-3
     # train.py / yml optimiser settings
     self.lr_init, self.lr_final, self.lr_decay_mult, self.warmup_steps, self.num_steps = 1e-2, 1e-3, 1e-8, 500, 25000
     self.opt_betas, self.opt_eps = (0.9, 0.999), 1e-15
@@ -58,8 +73,17 @@ class NerfactoConfig:
       if not hasattr(self, k):
         raise ValueError(f'ModelConfig has no field {k!r}')
       setattr(self, k, v)
-    if self.transient_type not in (None, 'withmask', 'robustnerf'):
-      raise NotImplementedError(f"nerfacto transient_type {self.transient_type!r}: built are None, 'withmask' and 'robustnerf'")
+    if self.transient_type == 'nerfw':
+      # the reference constructs this model and dies on its first forward: nerfacto.py:394-401 format `output_type`,
+      # a name that is never bound anywhere in the file
+      raise NameError("name 'output_type' is not defined (the reference's nerfacto NeRF-W branch, models/nerfacto.py:394, "
+                      "cannot execute; nothing to reproduce)")
+    if self.transient_type not in (None, 'withmask', 'robustnerf', 'hanerf'):
+      raise NotImplementedError(f"nerfacto transient_type {self.transient_type!r}")
+    if self.transient_type == 'hanerf':       # nerfacto.py:139-143
+      assert self.transient_embedding_dim > 0 and self.use_transient_embedding
+    else:
+      assert not self.use_transient_embedding
     if self.transient_type == 'robustnerf':
       assert self.robustnerf_inner_patch_size <= self.patch_size, 'patch_size must be larger than robustnerf_inner_patch_size.'
     if self.eval_embedding not in ('average', 'zero', 'original'):
@@ -123,6 +147,32 @@ class NerfactoModel:
       self.lay.add(f'field/cb{j}', (_rup(fo),), (fo,))
     if self.napp:
       self.lay.add('appearance', (cfg.num_embedding, self.napp))
+    self.ntra, self.mask_grid = 0, None
+    if cfg.transient_type == 'hanerf':
+      # TransientEmbed + ImplicitMask (nerfacto.py:159-166, 218-231, 1010-1091): 2-D grid | embedding -> (Linear+relu) x 2 ->
+      # Linear(1) -> sigmoid; the head is a vector (dot product per ray)
+      self.ntra = cfg.transient_embedding_dim
+      self.lay.add('transient', (cfg.num_embedding, self.ntra))
+      g2 = HashGrid(cfg.num_levels_implicit, cfg.features_per_level_implicit, cfg.log2_hashmap_size_implicit, cfg.base_res_implicit,
+                    None, cfg.max_res_implicit, device='cpu', dims=2)
+      self.mask_grid = g2
+      self.lay.add('mask/table', (g2.n_entries, g2.features))
+      Hm, kin = cfg.hidden_dim_implicit, g2.n_output_dims + self.ntra
+      self.lay.add('mask/m0', (_rup(kin), _rup(Hm)), (kin, Hm)); self.lay.add('mask/mb0', (_rup(Hm),), (Hm,))
+      self.lay.add('mask/m1', (_rup(Hm), _rup(Hm)), (Hm, Hm)); self.lay.add('mask/mb1', (_rup(Hm),), (Hm,))
+      self.lay.add('mask/m2', (_rup(Hm), 1), (Hm, 1)); self.lay.add('mask/mb2', (1,), (1,))
+    # optimizer groups (Model.get_params_dict nerfacto.py:250-264): name -> [lo, hi) of the flat buffer; the proposal
+    # networks come first in the layout, so 'proposal' is one contiguous range
+    self.groups = {'proposal': (0, self.lay.items['field/table'][0])}
+    ends = {'field': 'appearance' if self.napp else ('transient' if self.ntra else None)}
+    self.groups['field'] = (self.lay.items['field/table'][0], self.lay.items[ends['field']][0] if ends['field'] else self.lay.size)
+    if self.napp:
+      self.groups['appearance_embedding'] = (self.lay.items['appearance'][0], self.lay.items['transient'][0] if self.ntra else self.lay.size)
+    if self.ntra:
+      self.groups['transient_embedding'] = (self.lay.items['transient'][0], self.lay.items['mask/table'][0])
+      self.groups['implicit_mask'] = (self.lay.items['mask/table'][0], self.lay.size)
+    self.trainable = None         # None: every group (train stage); else the finetune stage's list (train.py:136)
+    self.counts = {}              # per-group number of Adam updates (torch keeps `step` per parameter)
     self.flat = torch.zeros(self.lay.size, dtype=torch.float32, device=self.device)
     self.m = torch.zeros_like(self.flat)
     self.v = torch.zeros_like(self.flat)
@@ -148,13 +198,13 @@ class NerfactoModel:
       v = self.lay.view(self.flat, name, padded=False)
       if leaf == 'table':
         v.copy_(((torch.rand(shape, generator=g) * 2 - 1) * 1e-4).to(self.device))
-      elif leaf[0] in 'wc' and not leaf.startswith('cb'):
-        v.copy_(((torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) * math.sqrt(6.0 / shape[0])).float().to(self.device))
-      elif leaf.startswith('b') or leaf.startswith('cb'):
-        fan_in = self.lay.items[name.replace('/cb', '/c').replace('/b', '/w')][2][0]
-        v.copy_(((torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) / math.sqrt(fan_in)).float().to(self.device))
-      elif name == 'appearance':
+      elif name in ('appearance', 'transient'):
         v.copy_(torch.randn(shape, generator=g).to(self.device))
+      elif (leaf[0] in 'wc' and not leaf.startswith('cb')) or (leaf[0] == 'm' and not leaf.startswith('mb')):
+        v.copy_(((torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) * math.sqrt(6.0 / shape[0])).float().to(self.device))
+      elif leaf.startswith('b') or leaf.startswith('cb') or leaf.startswith('mb'):
+        fan_in = self.lay.items[name.replace('/cb', '/c').replace('/mb', '/m').replace('/b', '/w')][2][0]
+        v.copy_(((torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) / math.sqrt(fan_in)).float().to(self.device))
 
   def params(self):
     """{'prop0': {'table','w0','b0','w1','b1'}, ..., 'field': {...,'c0','cb0',...}, 'appearance': ...}: logical views."""
@@ -188,7 +238,7 @@ class NerfactoModel:
   def refresh_weights(self):
     for name, (off, pshape, shape) in self.lay.items.items():
       leaf = name.split('/')[-1]
-      if len(pshape) == 2 and leaf != 'table' and name != 'appearance':
+      if len(pshape) == 2 and leaf != 'table' and name not in ('appearance', 'transient', 'mask/m2'):
         K, N = pshape
         if name not in self.wt:
           self.wt[name] = torch.empty(N, K, dtype=self.tdt, device=self.device)
@@ -343,6 +393,52 @@ class NerfactoModel:
       bins, weights, nb = sb, w, S
     return levels
 
+  # ---- HA-NeRF ImplicitMask (per ray; nerfacto.py:403-408, 1080-1091) -------------------------------------------------
+  def _mask_forward(self, rays, N, training):
+    c, ws, dt, g, T = self.cfg, self.ws, self.dt, self.mask_grid, self.ntra
+    Np = _rup(N)
+    tra = ws.get('tra', (N, T))
+    if training or c.eval_embedding == 'original':          # Model.get_embedding nerfacto.py:266-284
+      L.call('hugs_glo_gather', N, T, self.lay.view(self.flat, 'transient'), rays['embed_idx'], 0, tra)
+    elif c.eval_embedding == 'average':
+      tra.copy_(self.lay.view(self.flat, 'transient').mean(dim=0, keepdim=True).expand(N, -1))
+    else:
+      tra.zero_()
+    K0, H = self.lay.items['mask/m0'][1]
+    X0 = ws.get('mask/X0', (Np, K0), self.tdt)
+    if Np != N:
+      X0[N:].zero_()
+    o, r, sc = g._tables()
+    L.call('hugs_hashgrid2d_fwd', N, g.n_levels, g.features, o, r, sc, rays['coord'], self.lay.view(self.flat, 'mask/table'), tra, T,
+           dt, K0, X0)
+    Y0, Y1 = ws.get('mask/Y0', (Np, H), self.tdt), ws.get('mask/Y1', (Np, H), self.tdt)
+    self._nt(Np, 'mask/m0', X0, self.lay.view(self.flat, 'mask/mb0'), True, Y0)
+    self._nt(Np, 'mask/m1', Y0, self.lay.view(self.flat, 'mask/mb1'), True, Y1)
+    mask = ws.get('mask/out', (N,))
+    L.call('hugs_mask_head_fwd', dt, N, H, Y1, H, self.lay.view(self.flat, 'mask/m2').reshape(-1), self.lay.view(self.flat, 'mask/mb2'),
+           mask)
+    return dict(X0=X0, Y0=Y0, Y1=Y1, mask=mask, Np=Np)
+
+  def _mask_backward(self, st, rays, N, d_mask):
+    """Gradients of the ImplicitMask parameters (=) and of the transient embedding rows (+=) from d loss / d mask [N]."""
+    ws, dt, g, T = self.ws, self.dt, self.mask_grid, self.ntra
+    Np = st['Np']
+    K0, H = self.lay.items['mask/m0'][1]
+    d_raw = ws.get('mask/d_raw', (Np,))
+    L.call('hugs_mask_head_bwd', dt, N, Np, H, st['Y1'], H, st['mask'], d_mask, d_raw, self.lay.view(self.grad, 'mask/m2').reshape(-1),
+           self.lay.view(self.grad, 'mask/mb2'))
+    G1 = ws.get('mask/G1', (Np, H), self.tdt)
+    L.call('hugs_rank1_mask', dt, Np, H, d_raw, self.lay.view(self.flat, 'mask/m2').reshape(-1), st['Y1'], H, G1, H)
+    self._tn(Np, 'mask/m1', st['Y0'], G1, 'mask/mb1')
+    G0 = ws.get('mask/G0', (Np, H), self.tdt)
+    self._nt(Np, 'mask/m1', G1, None, False, G0, mask=st['Y0'], transpose=True)
+    self._tn(Np, 'mask/m0', st['X0'], G0, 'mask/mb0')
+    dX0 = ws.get('mask/dX0', (Np, K0), self.tdt)
+    self._nt(Np, 'mask/m0', G0, None, False, dX0, transpose=True)
+    o, r, sc = g._tables()
+    L.call('hugs_hashgrid2d_bwd', N, g.n_levels, g.features, o, r, sc, rays['coord'], dX0, dt, K0, self.lay.view(self.grad, 'mask/table'))
+    L.call('hugs_embed_scatter_add', dt, N, T, dX0, K0, g.n_output_dims, rays['embed_idx'], self.lay.view(self.grad, 'transient'))
+
   # ---- loss + backward + Adam ---------------------------------------------------------------------------------------------
   @torch.no_grad()
   def render(self, batch, curr_step, chunk_size=None):
@@ -352,7 +448,7 @@ class NerfactoModel:
     N = batch['origin'].shape[0]
     cs = N if not chunk_size else int(chunk_size)
     cs = max(128, (cs + 127) // 128 * 128)          # whole GEMM tiles per chunk; the last chunk is padded with its last ray
-    out = {k: [] for k in ('rgb', 'accumulation', 'depth')}
+    out = {k: [] for k in ('rgb', 'accumulation', 'depth') + (('implicit_mask',) if self.ntra else ())}
     for lo in range(0, N, cs):
       hi = min(N, lo + cs)
       n = hi - lo
@@ -368,6 +464,8 @@ class NerfactoModel:
       fin = self.forward(sub, curr_step, None, training=False)[-1]
       out['rgb'].append(fin['rgb_out'][:n].clone()); out['accumulation'].append(fin['acc'][:n].clone())
       out['depth'].append(fin['depth'][:n].clone())
+      if self.ntra:
+        out['implicit_mask'].append(self._mask_forward(sub, npad, False)['mask'][:n].clone())
     return {k: torch.cat(v, 0) for k, v in out.items()}
 
   def proposal_update_enabled(self, curr_step):
@@ -376,10 +474,13 @@ class NerfactoModel:
     iv = int(np.clip(np.interp(curr_step, [0, c.proposal_warmup], [0, c.proposal_update_every]), 1, c.proposal_update_every))
     return (curr_step % iv) == 0
 
-  def train_step(self, batch, curr_step=None, u01=None, apply_update=True, world=1, inlier_threshold=None):
+  def train_step(self, batch, curr_step=None, u01=None, apply_update=True, world=1, inlier_threshold=None, is_finetune=False):
     """One optimisation step (train.py:196-215 + Loss.forward nerfacto.py:598-640).  batch: rays dict + 'rgb' [N,3]
     (+ 'static_mask' [N] for transient_type='withmask'; whole 16x16 patches, patch-major, for 'robustnerf', whose stats
     slots 10..14 hold next inlier_threshold, is_inlier_loss, has_inlier_neighbors, is_inlier_patch, robust_mask).
+    'hanerf': batch also holds 'coord' [N,2] (the ray's image coordinate in [0,1]^2, nerfacto.py:404); stats slots 12 / 13 =
+    mask_size_loss / mean mask.  is_finetune: Loss.forward's finetune branch (plain data loss whatever the transient
+    type, nerfacto.py:606-609); which parameters move is begin_finetune()'s list.
     Returns a dict of host-lazy device scalars."""
     c, ws, dt = self.cfg, self.ws, self.dt
     self.step += 1
@@ -392,8 +493,12 @@ class NerfactoModel:
     stats.zero_()
     # rgb loss (mean, or the static-mask weighted mean of compute_withmask_loss nerfacto.py:467-490)
     d_pred = ws.get('d_pred', (1, N, 3))
-    mode, lm = (1, batch['static_mask']) if c.transient_type == 'withmask' else (0, None)
-    if c.transient_type == 'robustnerf':
+    tt = None if is_finetune else c.transient_type
+    mode, lm = (1, batch['static_mask']) if tt == 'withmask' else (0, None)
+    mask_st, d_mask = None, None
+    if tt == 'hanerf':
+      mask_st = self._mask_forward(batch, N, True)
+    if tt == 'robustnerf':
       # compute_robustnerf_loss (nerfacto.py:492-527): rays come in whole patch_size^2 patches (train.py:188-192); the
       # inlier threshold is last step's quantile (extra_infos, 1.0 before the first step), fed back on the device
       P = c.patch_size
@@ -414,10 +519,20 @@ class NerfactoModel:
     # compute_withmask_loss broadcasts the mask to the 3 channels first (nerfacto.py:481-483): a factor 3 in the denominator
     chan = 3.0 if mode == 1 else 1.0     # (the kernel's other modes already count the 3 channels)
     coef = ws.bufs.setdefault(('coef1', chan), torch.full((1,), float(c.rgb_loss_mult) / chan, device=self.device))
-    L.call('hugs_data_loss', N, 1, fin['rgb_out'].reshape(1, N, 3), batch['rgb'], lm, mode, c.withmask_transient_weight,
-           int(c.rgb_loss_type == 'charb'), c.rgb_charb_loss_padding, coef, d_pred, stats[0:2])
-    if chan != 1.0:
-      stats[0:2].mul_(1.0 / chan)
+    if tt == 'hanerf':
+      # compute_hanerf_loss (nerfacto.py:560-596): mean((1 - mask) * loss) + mult(curr_step) * mean(mask^2)
+      msm = max(c.hanerf_mask_size_loss_mult_min, c.hanerf_mask_size_loss_mult_max * math.exp(-step * c.hanerf_mask_size_loss_mult_k))
+      d_mask, hst = ws.get('d_mask', (N,)), ws.get('hanerf_stats', (4,))
+      L.call('hugs_hanerf_loss', N, 1, fin['rgb_out'].reshape(1, N, 3), batch['rgb'], mask_st['mask'], int(c.rgb_loss_type == 'charb'),
+             c.rgb_charb_loss_padding, coef, msm, d_pred, d_mask, hst)
+      stats[0:2].copy_(hst[0:2])
+      torch.mul(hst[2:3], msm, out=stats[12:13])
+      stats[13:14].copy_(hst[3:4])
+    else:
+      L.call('hugs_data_loss', N, 1, fin['rgb_out'].reshape(1, N, 3), batch['rgb'], lm, mode, c.withmask_transient_weight,
+             int(c.rgb_loss_type == 'charb'), c.rgb_charb_loss_padding, coef, d_pred, stats[0:2])
+      if chan != 1.0:
+        stats[0:2].mul_(1.0 / chan)
     loss_ray = ws.get('loss_ray', (N,))
     d_w = [None] * (self.L + 1)
     prop_on = self.proposal_update_enabled(step)
@@ -433,37 +548,79 @@ class NerfactoModel:
       L.call('hugs_sum', N, loss_ray, c.distortion_loss_mult / N, stats[8:9])
     # ---- backward ----
     self.grad.zero_()
+    want = lambda group: self.trainable is None or group in self.trainable
     for l in range(self.L, -1, -1):
       st = levels[l]
       is_prop = l < self.L
-      if is_prop and (d_w[l] is None or not prop_on):
+      if is_prop and (d_w[l] is None or not prop_on or not want('proposal')):
+        continue
+      if not is_prop and not (want('field') or want('appearance_embedding')):
         continue
       self._backward_level(st, batch, N, d_pred[0] if not is_prop else None, d_w[l])
+    if mask_st is not None:
+      self._mask_backward(mask_st, batch, N, d_mask)
     if world > 1:
       import torch.distributed as dist
       dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
       self.grad.mul_(1.0 / world)
+    self._prop_updated = bool(prop_on and any(d is not None for d in d_w[:self.L]))
     if apply_update:
-      self.apply_gradients()
-    return dict(stats=stats, levels=levels)
+      self.apply_gradients(self._prop_updated)
+    return dict(stats=stats, levels=levels, mask=None if mask_st is None else mask_st['mask'])
+
+  def _opt(self):
+    if not hasattr(self, 'opt'):
+      c = self.cfg
+      self.opt = dict(lr_init=c.lr_init, lr_final=c.lr_final, lr_decay_mult=c.lr_decay_mult, warmup_steps=c.warmup_steps,
+                      num_steps=c.num_steps, betas=tuple(c.opt_betas), eps=c.opt_eps)
+    return self.opt
 
   def lr(self, step):
-    c = self.cfg
-    if step < c.warmup_steps:
-      f = c.lr_decay_mult + (1 - c.lr_decay_mult) * math.sin(0.5 * math.pi * min(max(step / c.warmup_steps, 0), 1))
+    """utils/lr_scheduler_utils.py:6-27 get_warmup_decay_scheduler: lr_init x the LambdaLR factor at `step`."""
+    o = self._opt()
+    if step < o['warmup_steps']:
+      f = o['lr_decay_mult'] + (1 - o['lr_decay_mult']) * math.sin(0.5 * math.pi * min(max(step / o['warmup_steps'], 0), 1))
     else:
-      t = min(max((step - c.warmup_steps) / (c.num_steps - c.warmup_steps), 0), 1)
-      f = math.exp(math.log(c.lr_init) * (1 - t) + math.log(c.lr_final) * t) / c.lr_init
-    return c.lr_init * f
+      t = min(max((step - o['warmup_steps']) / (o['num_steps'] - o['warmup_steps']), 0), 1)
+      f = math.exp(math.log(o['lr_init']) * (1 - t) + math.log(o['lr_final']) * t) / o['lr_init']
+    return o['lr_init'] * f
 
-  def apply_gradients(self):
-    """optimizer.step() + scheduler.step() (train.py:213-215): the k-th update uses the scheduler's factor at k-1."""
-    c = self.cfg
-    k = getattr(self, '_updates', 0)
-    b1, b2 = c.opt_betas
-    L.call('hugs_nf_adam', self.flat.numel(), self.flat, self.grad, self.m, self.v, self.lr(k), b1, b2, c.opt_eps,
-           1.0 - b1**(k + 1), 1.0 - b2**(k + 1))
-    self._updates = k + 1
+  def begin_finetune(self, params=('appearance_embedding',), lr_init=5e-3, lr_final=5e-4, lr_decay_mult=0.01, warmup_steps=500,
+                     num_steps=5000, betas=(0.9, 0.999), eps=1e-8):
+    """The reference's second training stage (train.py:126-165): a NEW Adam + scheduler over the listed parameter groups
+    only (`finetune_params`, the yml default is [appearance_embedding]); everything else keeps its value."""
+    for p in params:
+      if p not in self.groups:
+        raise KeyError(f'finetune_params: {p!r} is not a parameter group (have {sorted(self.groups)})')      # train.py:160 params_dict[key]
+    self.trainable = tuple(params)
+    self.opt = dict(lr_init=lr_init, lr_final=lr_final, lr_decay_mult=lr_decay_mult, warmup_steps=warmup_steps, num_steps=num_steps,
+                    betas=tuple(betas), eps=eps)
+    self.m.zero_(); self.v.zero_()
+    self.counts, self._updates = {}, 0
+
+  def apply_gradients(self, prop_updated=True):
+    """optimizer.step() + scheduler.step() (train.py:213-215): the k-th scheduler step's factor applies to update k.
+    torch.optim.Adam skips a parameter whose .grad is None completely -- no update, no moment decay, no increment of its
+    own `step` -- and that is what the proposal networks are on steps without a proposal update (their forward runs
+    under set_grad_enabled(False), nerfacto.py:338, and zero_grad() resets to None): the 'proposal' range is left out
+    and keeps its own update count for the bias corrections."""
+    o = self._opt()
+    k_sched = getattr(self, '_updates', 0)
+    lr, (b1, b2) = self.lr(k_sched), o['betas']
+    todo = []
+    for gname, (lo, hi) in sorted(self.groups.items(), key=lambda kv: kv[1][0]):
+      if hi <= lo or (self.trainable is not None and gname not in self.trainable) or (gname == 'proposal' and not prop_updated):
+        continue
+      k = self.counts.get(gname, 0)
+      self.counts[gname] = k + 1
+      if todo and todo[-1][1] == lo and todo[-1][2] == k:
+        todo[-1][1] = hi                      # neighbouring groups with the same update count: one launch
+      else:
+        todo.append([lo, hi, k])
+    for lo, hi, k in todo:
+      L.call('hugs_nf_adam', hi - lo, self.flat[lo:hi], self.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], lr, b1, b2, o['eps'],
+             1.0 - b1**(k + 1), 1.0 - b2**(k + 1))
+    self._updates = k_sched + 1
     self.refresh_weights()
 
   def _backward_level(self, st, rays, N, d_rgb_out, d_w_extra):

@@ -50,6 +50,10 @@ class Cfg:
     self.robustnerf_smoothed_inlier_quantile, self.robustnerf_inner_patch_size = 0.5, 8
     self.robustnerf_inner_patch_inlier_quantile, self.patch_size = 0.4, 16
     self.rgb_bias = 0.
+    self.use_transient_embedding, self.transient_embedding_dim = False, 16
+    self.num_levels_implicit, self.base_res_implicit, self.max_res_implicit = 8, 16, 1024
+    self.log2_hashmap_size_implicit, self.features_per_level_implicit, self.hidden_dim_implicit = 17, 2, 128
+    self.hanerf_mask_size_loss_mult_min, self.hanerf_mask_size_loss_mult_max, self.hanerf_mask_size_loss_mult_k = 6e-3, 5e-2, 1e-3
     for k, v in kw.items():
       if not hasattr(self, k):
         raise AttributeError(k)
@@ -195,6 +199,24 @@ def lossfun_distortion(t, w):
 
 
 # ---- fields (nerfacto.py:643-1008, enable_tcnn_mlp=False form) ----------------------------------------------------------
+def mask_grid_spec(cfg):
+  """ImplicitMask's 2-D grid (nerfacto.py:1036-1047)."""
+  growth = np.exp((np.log(cfg.max_res_implicit) - np.log(cfg.base_res_implicit)) / (cfg.num_levels_implicit - 1))
+  offs, ress, scales = HG.level_table(cfg.num_levels_implicit, cfg.base_res_implicit, growth, cfg.log2_hashmap_size_implicit, dims=2)
+  return dict(offsets=offs, resolutions=ress, scales=scales, F=cfg.features_per_level_implicit, n_entries=int(offs[-1]),
+              out_dim=cfg.num_levels_implicit * cfg.features_per_level_implicit)
+
+
+def implicit_mask(cfg, P, coords, tra):
+  """ImplicitMask.forward (nerfacto.py:1080-1091, the nn.Linear form :1062-1075): grid(coords) | embedding -> (Linear+relu) x 2
+  -> Linear(1) -> sigmoid."""
+  x = _HashGridFn.apply(P['table'], coords, mask_grid_spec(cfg))
+  h = torch.cat([x, tra], dim=-1)
+  h = torch.relu(h @ P['m0'] + P['mb0'])
+  h = torch.relu(h @ P['m1'] + P['mb1'])
+  return torch.sigmoid(h @ P['m2'] + P['mb2'])
+
+
 def grid_spec(num_levels, base_res, max_res, log2_hashmap_size, features_per_level):
   growth = float(np.exp((np.log(max_res) - np.log(base_res)) / (num_levels - 1))) if num_levels > 1 else 1.0
   offs, ress, scales = HG.level_table(num_levels, base_res, growth, log2_hashmap_size)
@@ -281,6 +303,11 @@ def init_params(cfg, seed=0, dtype=torch.float32):
   P['field'] = dict(table=table(spec), w0=w0, b0=b0, w1=w1, b1=b1, c0=c0, cb0=cb0, c1=c1, cb1=cb1, c2=c2, cb2=cb2)
   if app:
     P['appearance'] = torch.randn(cfg.num_embedding, app, generator=g, dtype=torch.float64).to(dtype)
+  if cfg.transient_type == 'hanerf':
+    T, H, ms = cfg.transient_embedding_dim, cfg.hidden_dim_implicit, mask_grid_spec(cfg)
+    P['transient'] = torch.randn(cfg.num_embedding, T, generator=g, dtype=torch.float64).to(dtype)
+    m0, mb0 = lin(ms['out_dim'] + T, H); m1, mb1 = lin(H, H); m2, mb2 = lin(H, 1)
+    P['mask'] = dict(table=table(ms), m0=m0, mb0=mb0, m1=m1, mb1=mb1, m2=m2, mb2=mb2)
   return P
 
 
@@ -338,6 +365,15 @@ def forward_rays(cfg, P, rays, curr_step, u01, training=True):
     out[f'depth{sfx}'] = render_depth(weights, ebins)
     out[f'accumulation{sfx}'] = torch.sum(weights, dim=-1)
     out[f'density{sfx}'], out[f'ebins{sfx}'] = dens, ebins
+  if cfg.transient_type == 'hanerf':          # nerfacto.py:403-408
+    T = P['transient']
+    if training or cfg.eval_embedding == 'original':
+      tra = T[rays['embed_idx'][:, 0].long()]
+    elif cfg.eval_embedding == 'average':
+      tra = torch.ones(rays['embed_idx'].shape[0], T.shape[-1], dtype=T.dtype) * T.mean(dim=0)
+    else:
+      tra = torch.zeros(rays['embed_idx'].shape[0], T.shape[-1], dtype=T.dtype)
+    out['implicit_mask'] = implicit_mask(cfg, P['mask'], rays['coord'], tra)
   out['weights_list'], out['spacing_bins_list'] = wl, bl
   return out
 
@@ -370,13 +406,23 @@ def get_robustnerf_mask(cfg, errors, curr_threshold):
   return mask, info
 
 
-def loss_fn(cfg, out, gt_rgb, static_mask=None, inlier_threshold=1.0):
+def loss_fn(cfg, out, gt_rgb, static_mask=None, inlier_threshold=1.0, curr_step=0, is_finetune=False):
   """Loss.forward (nerfacto.py:598-640) for transient_type None / 'withmask' / 'robustnerf' (rays in whole
-  cfg.patch_size^2 patches, patch-major, for the latter)."""
+  cfg.patch_size^2 patches, patch-major) / 'hanerf'; is_finetune selects compute_data_loss whatever the type (:606)."""
   resid_sq = (out['rgb'] - gt_rgb)**2
   dl = resid_sq if cfg.rgb_loss_type == 'mse' else torch.sqrt(resid_sq + cfg.rgb_charb_loss_padding**2)
   info = {}
-  if cfg.transient_type == 'robustnerf':       # compute_robustnerf_loss nerfacto.py:492-527
+  tt = None if is_finetune else cfg.transient_type
+  extra = 0.
+  if tt == 'hanerf':                             # compute_hanerf_loss nerfacto.py:560-596
+    msm = max(cfg.hanerf_mask_size_loss_mult_min, cfg.hanerf_mask_size_loss_mult_max * np.exp(-curr_step * cfg.hanerf_mask_size_loss_mult_k))
+    m = out['implicit_mask']
+    info['implicit_mask'] = m.mean().detach()
+    extra = msm * (m**2).mean()
+    info['mask_size_loss'] = extra.detach()
+    rgb_loss = cfg.rgb_loss_mult * ((1 - m) * dl).mean()
+    info['mse'] = resid_sq.mean().detach()
+  elif tt == 'robustnerf':       # compute_robustnerf_loss nerfacto.py:492-527
     P = cfg.patch_size
     mask, rinfo = get_robustnerf_mask(cfg, resid_sq.detach().reshape(-1, P, P, 3), inlier_threshold)
     info.update(rinfo)
@@ -384,7 +430,7 @@ def loss_fn(cfg, out, gt_rgb, static_mask=None, inlier_threshold=1.0):
     den = lm.sum().clamp_min(torch.finfo(lm.dtype).eps)
     rgb_loss = cfg.rgb_loss_mult * ((lm * dl).sum() / den)
     info['mse'] = ((lm * resid_sq).sum() / den).detach()
-  elif cfg.transient_type == 'withmask':
+  elif tt == 'withmask':
     sm = (static_mask >= 0.5).to(gt_rgb.dtype)
     lm = (sm + (1 - sm) * cfg.withmask_transient_weight).expand_as(resid_sq)
     den = lm.sum().clamp_min(torch.finfo(lm.dtype).eps)
@@ -393,7 +439,7 @@ def loss_fn(cfg, out, gt_rgb, static_mask=None, inlier_threshold=1.0):
   else:
     rgb_loss = cfg.rgb_loss_mult * dl.mean()
     info['mse'] = resid_sq.mean().detach()
-  loss = rgb_loss
+  loss = rgb_loss + extra
   info['rgb_loss'] = rgb_loss.detach()
   if cfg.interlevel_loss_mult > 0:
     il = cfg.interlevel_loss_mult * interlevel_loss(out['weights_list'], out['spacing_bins_list'])

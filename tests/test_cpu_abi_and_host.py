@@ -295,3 +295,30 @@ def test_stat_tail_slots_do_not_overlap_for_any_level_count():
     assert end <= train_utils.STAT_TAIL
   with pytest.raises(NotImplementedError):
     train_utils._tail_slots(8)
+
+
+def test_nerfacto_yml_configs():
+  """nerfacto/configs/*.yml -> NerfactoConfig: every shipped nerfacto yml parses (the NeRF-W ones raise the NameError the
+  reference's own model dies with), and the restated BASELINE config-5 dictionary equals the yml.  Needs the reference
+  checkout (build container only)."""
+  import glob
+  import yaml
+  ref = '/root/reference/nerfacto/configs'
+  if not os.path.isdir(ref):
+    pytest.skip('reference checkout not present')
+  from nerf_hugs_amd.nerfacto import configs as C
+  seen = 0
+  for p in sorted(glob.glob(os.path.join(ref, '*nerfacto*.yml'))):
+    if 'nerfw' in p:
+      with pytest.raises(NameError):
+        C.load_yml(p)
+      continue
+    c = C.load_yml(p)
+    seen += 1
+    assert c.num_proposal_iterations == len(c.num_proposal_samples_per_ray)
+    if 'hanerf' in p:
+      assert c.transient_type == 'hanerf' and c.use_transient_embedding
+  assert seen >= 10
+  kw = C.yml_to_kwargs(yaml.safe_load(open(os.path.join(ref, 'phototourism_nerfacto_base.yml'))))
+  kw.pop('use_transient_embedding')
+  assert kw == C.PHOTOTOURISM_NERFACTO_BASE
