@@ -159,6 +159,56 @@ def eval_psnr_vs_oracle(model, state, batch, dtype):
   return round(-10.0 * np.log10(max(mse, 1e-20)), 2)
 
 
+def nerfacto_roofline(model, step_fn, N, steps=3):
+  """Per-kernel figures of the nerfacto step, measured INSIDE extra train steps (HIP events around every launch of the
+  hash-grid, fused-proposal and GEMM entry points on the stream they run on).  Bounds: hash-grid forward = gathered table
+  bytes (8 corners x features x 4 B per sample and level) + the row written, against HBM 8 TB/s; hash-grid backward = the
+  table updates the algorithm must apply, counted as atomic TRANSACTIONS (adjacent floats of one instruction share one:
+  4 per sample and level where the x-neighbour entry is adjacent, i.e. dense levels, 8 on hashed ones -- before the
+  kernel's run merging, which is why `frac` can exceed 1) against the 21 G transactions/s this chip retires
+  (scratch/atomic_pair.hip); GEMMs = 2 M K N against the dense bf16 MFMA peak."""
+  from nerf_hugs_amd import _lib
+  _lib.PROFILE = []
+  for _ in range(steps):
+    step_fn()
+  torch.cuda.synchronize()
+  recs, _lib.PROFILE = _lib.PROFILE, None
+  agg = {}
+  for name, key, e0, e1 in recs:
+    agg.setdefault(key, []).append(e0.elapsed_time(e1) * 1e3)
+  grids = {(g.n_levels, g.features): g for g in model.grids.values()}
+  out = []
+  for key, v in agg.items():
+    us = float(np.mean(v))
+    per_step = len(v) / steps
+    ent = {"kernel": None, "launches_per_step": per_step, "avg_us": round(us, 1), "ms_per_step": round(us * per_step * 1e-3, 3)}
+    if key[0] in ('hg_fwd', 'hg_bwd'):
+      n, L_, F = key[1:]
+      g = grids.get((L_, F))
+      dense = sum(1 for l in range(L_) if g is not None and int(g.resolutions[l]) ** 3 <= int(g.offsets[l + 1] - g.offsets[l]))
+      if key[0] == 'hg_fwd':
+        by = n * L_ * 8 * F * 4 + n * L_ * F * 2 + n * 12
+        ent.update(kernel=f"k_hashgrid_fwd {n} samples x {L_} levels", bound="hbm", achieved=round(by / (us * 1e-6) / 1e9, 1), peak=8000.0,
+                   unit="GB/s", frac=round(by / (us * 1e-6) / 8e12, 4), algorithmic_bytes=by)
+      else:
+        tx = n * (4 * dense + 8 * (L_ - dense))
+        ent.update(kernel=f"k_hashgrid_bwd(+_l0) {n} samples x {L_} levels ({dense} dense)", bound="atomic",
+                   achieved=round(tx / (us * 1e-6) / 1e9, 2), peak=21.0, unit="Gtransactions/s", frac=round(tx / (us * 1e-6) / 21e9, 4),
+                   algorithmic_transactions=tx)
+    elif key[0] in ('prop_fwd', 'prop_bwd'):
+      n, i_, h_ = key[1:]
+      fl = 2.0 * n * (i_ * h_ + h_) * (1 if key[0] == 'prop_fwd' else 3)
+      ent.update(kernel=f"k_nf_{key[0]} {n} samples {i_}->{h_}->1 (fp32 VALU)", bound="valu", achieved=round(fl / (us * 1e-6) / 1e12, 2),
+                 peak=157.3, unit="TFLOP/s", frac=round(fl / (us * 1e-6) / 157.3e12, 4))
+    else:
+      fl = 2.0 * key[1] * key[2] * key[3]
+      ent.update(kernel=f"gemm_{key[0]} M={key[1]} {key[2]}x{key[3]} {key[4]} (padded shape)", bound="mfma",
+                 achieved=round(fl / (us * 1e-6) / 1e12, 1), peak=PEAK_BF16 / 1e12, unit="TFLOP/s", frac=round(fl / (us * 1e-6) / PEAK_BF16, 4))
+    out.append(ent)
+  out.sort(key=lambda e: -e["ms_per_step"])
+  return out
+
+
 def bench_nerfacto(args, device, world, rank):
   """Informational line for BASELINE configs[4] (nerfacto hash-grid path): 16384 rays per GPU, full train step."""
   import torch.distributed as dist
@@ -173,30 +223,51 @@ def bench_nerfacto(args, device, world, rank):
                embed_idx=torch.randint(0, 3500, (N,), generator=g, device=device).int(), bg_rgb=torch.ones(N, 3, device=device),
                rgb=torch.rand(N, 3, generator=g, device=device))
   draws = lambda: [torch.rand(N, generator=g, device=device) for _ in range(3)]
-  for _ in range(args.warmup):
-    model.train_step(batch, u01=draws(), world=world)
-  torch.cuda.synchronize()
-  if world > 1:
-    dist.barrier()
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
+  res = None
+
+  def step():
+    nonlocal res
     res = model.train_step(batch, u01=draws(), world=world)
-  torch.cuda.synchronize()
-  if world > 1:
-    dist.barrier()
-  dt = time.perf_counter() - t0
-  if world > 1:
-    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+  for _ in range(args.warmup):
+    step()
+
+  def window():
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+      step()
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+    w = time.perf_counter() - t0
+    if world > 1:
+      tmax = torch.tensor([w], device=device, dtype=torch.float64)
+      dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+      w = float(tmax.item())
+    return w
+  wins = [window()]
+  for _ in range(int(min(max(1, math.ceil(args.min_time / wins[0])), args.max_windows)) - 1):
+    wins.append(window())
+  dt = float(np.median(wins))
+  kernels = nerfacto_roofline(model, step, N) if world == 1 else None
   if rank == 0:
     st = res['stats'].cpu().numpy()
-    print(json.dumps({"metric": "train rays/sec (nerfacto, 16384-ray batch per GPU, 512+256+128 samples)", "value": round(N * world * args.steps / dt, 1),
-                      "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-                      "config": {"workload": "configs[4] restatement: nerfacto hash-grid fields (phototourism_nerfacto_base.yml sizes), "
-                                             "16384 rays/GPU, full train step", "params": int(model.flat.numel()), "parallelism": f"dp{world}"},
-                      "loss_rgb_last": round(float(st[1]), 6)}))
+    line = {"metric": "train rays/sec (nerfacto, 16384-ray batch per GPU, 512+256+128 samples)", "value": round(N * world * args.steps / dt, 1),
+            "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "windows": len(wins), "value_min": round(N * world * args.steps / max(wins), 1), "value_max": round(N * world * args.steps / min(wins), 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "configs[4] restatement: nerfacto hash-grid fields (phototourism_nerfacto_base.yml sizes), "
+                                   "16384 rays/GPU, full train step", "params": int(model.flat.numel()), "parallelism": f"dp{world}"},
+            "loss_rgb_last": round(float(st[1]), 6)}
+    if kernels:
+      line["roofline"] = kernels[0]
+      line["instep_kernels"] = kernels[1:12]
+      line["instep_profiled_ms_per_step"] = round(sum(k["ms_per_step"] for k in kernels), 3)
+    print(json.dumps(line))
   if world > 1:
     dist.barrier()
     dist.destroy_process_group()

@@ -101,7 +101,12 @@ def _raw_stream():
 PROFILE = None
 _PROFILED = {'hugs_gemm_nt': lambda a: ('nt', a[1], a[2], a[3] + a[4], 'mask' if a[16] is not None else ('relu' if a[15] else 'plain')),
              'hugs_gemm_nt_bits': lambda a: ('nt', a[1], a[2], a[3] + a[4], 'mask' if a[18] is not None else ('relu' if a[12] else 'plain')),
-             'hugs_gemm_tn': lambda a: ('tn', a[1], a[2], a[3], f'split{a[4]}')}
+             'hugs_gemm_tn': lambda a: ('tn', a[1], a[2], a[3], f'split{a[4]}'),
+             # nerfacto (bench.py --config cfg5): (kind, samples, levels, features) / (kind, samples, in_dim, hidden)
+             'hugs_hashgrid_fwd': lambda a: ('hg_fwd', a[0], a[1], a[2]),
+             'hugs_hashgrid_bwd': lambda a: ('hg_bwd', a[0], a[1], a[2]),
+             'hugs_nf_prop_fwd': lambda a: ('prop_fwd', a[0], a[1], a[2]),
+             'hugs_nf_prop_bwd': lambda a: ('prop_bwd', a[0], a[1], a[2])}
 
 
 class _Lib:
