@@ -183,6 +183,12 @@ int hugs_expand_patches(int npatch, int patch_size, int dilation, const int32_t*
  * maxval) (stepfun.py:207-209).  n < 2^32. */
 int hugs_prng_bits(const uint32_t* key, long long n, uint32_t* out, void* stream);
 int hugs_prng_uniform(const uint32_t* key, long long n, float minval, float maxval, float* out, void* stream);
+/* One training step's consumption of the jax.random stream in ONE launch: key_out = first key of split(key_in)
+ * (train_utils.py:408 `rng, key = random.split(rng)`); with the second key, per level l < L (<= 8): models.py:196 split ->
+ * stepfun.py:207-209 random.uniform(key, [n[l]], maxval = maxval[l]) into out[l], models.py:230 split.  n, maxval and out
+ * are HOST arrays (out[l] device pointers).  Bit-identical to the chain of hugs_prng_bits / hugs_prng_uniform calls. */
+int hugs_prng_step_jitter(const uint32_t* key_in, int L, const long long* n, const float* maxval, float* const* out,
+                          uint32_t* key_out, void* stream);
 
 /* ---- eval metrics: image.py:127-141 MetricHarness.  hugs_ssim == dm_pix.ssim(a, b) for one
  * [H,W,C] fp32 image pair with dm_pix's defaults passed explicitly (max_val 1, 11 taps fixed, filter_sigma 1.5,

@@ -48,7 +48,68 @@ k_threefry(const uint32_t* __restrict__ key, long long n, float lo, float hi, vo
   }
 }
 
+// The whole key chain one training step consumes, in ONE launch (train_utils.py:408 `rng, key = random.split(rng)`, then per
+// level models.py:196 `key, rng = random.split(rng)` -> stepfun.py:207-209 random.uniform(key, [n_l], maxval_l) and
+// models.py:230 `key, rng = random.split(rng)` for the MLP key): every thread re-derives the (1 + 2 L) splits -- two
+// threefry evaluations each, a few hundred integer ops -- and writes its pair of uniform draws of every level.
+struct StepJitter {
+  int L;
+  long long n[8];
+  float maxval[8];
+  float* out[8];
+};
+
+__device__ __forceinline__ void split2(uint32_t k0, uint32_t k1, uint32_t (&a)[2], uint32_t (&b)[2]) {
+  // bits(key, 4): thread pairs (0, 2) and (1, 3); first key = (out0, out1), second = (out2, out3)
+  uint32_t x0 = 0u, x1 = 2u, y0 = 1u, y1 = 3u;
+  threefry2x32(k0, k1, x0, x1);
+  threefry2x32(k0, k1, y0, y1);
+  a[0] = x0; a[1] = y0; b[0] = x1; b[1] = y1;
+}
+
+__global__ void __launch_bounds__(256)
+k_step_jitter(const uint32_t* __restrict__ key_in, StepJitter J, uint32_t* __restrict__ key_out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  uint32_t rng[2], r[2], k[2], t_[2];
+  split2(key_in[0], key_in[1], rng, r);             // rng, key = split(rng): `rng` goes back to the caller, `key` feeds the levels
+  if (i == 0) { key_out[0] = rng[0]; key_out[1] = rng[1]; }
+  for (int l = 0; l < J.L; ++l) {
+    split2(r[0], r[1], k, t_);                       // key, rng = split(rng)
+    const long long n = J.n[l], h = (n + 1) >> 1;
+    if (i < h) {
+      uint32_t x0 = (uint32_t)i, x1 = (h + i < n) ? (uint32_t)(h + i) : 0u;
+      threefry2x32(k[0], k[1], x0, x1);
+      const float hi = J.maxval[l];
+      const float f0 = __fsub_rn(__uint_as_float((x0 >> 9) | 0x3F800000u), 1.f);
+      const float f1 = __fsub_rn(__uint_as_float((x1 >> 9) | 0x3F800000u), 1.f);
+      J.out[l][i] = fmaxf(0.f, __fadd_rn(__fmul_rn(f0, hi), 0.f));
+      if (h + i < n) J.out[l][h + i] = fmaxf(0.f, __fadd_rn(__fmul_rn(f1, hi), 0.f));
+    }
+    split2(t_[0], t_[1], k, r);                      // _, rng = split(rng)
+  }
+}
+
 }  // namespace
+
+/* One training step's draws from the reference's jax.random stream in one launch: key_out = first half of split(key_in)
+ * (train_utils.py:408), and for every level l < L (<= 8) out[l][0..n[l]) = random.uniform(k_l, [n[l]], maxval = maxval[l]) with
+ * the keys of models.py:196,230.  n / maxval / out are HOST arrays.  Bit-identical to the split / uniform entry points. */
+extern "C" int hugs_prng_step_jitter(const uint32_t* key_in, int L, const long long* n, const float* maxval, float* const* out,
+                                     uint32_t* key_out, void* stream) {
+  HUGS_REQUIRE(key_in && key_out && n && maxval && out && L >= 0 && L <= 8, -2, "hugs_prng_step_jitter: null pointer or L=%d outside 0..8", L);
+  StepJitter J;
+  J.L = L;
+  long long hmax = 1;
+  for (int l = 0; l < L; ++l) {
+    HUGS_REQUIRE(n[l] >= 0 && n[l] < (1ll << 32) && (out[l] || n[l] == 0), -2, "hugs_prng_step_jitter: level %d", l);
+    J.n[l] = n[l]; J.maxval[l] = maxval[l]; J.out[l] = out[l];
+    const long long h = (n[l] + 1) >> 1;
+    if (h > hmax) hmax = h;
+  }
+  k_step_jitter<<<(unsigned)((hmax + 255) / 256), 256, 0, (hipStream_t)stream>>>(key_in, J, key_out);
+  HUGS_CHECK_LAUNCH("k_step_jitter");
+  return 0;
+}
 
 extern "C" int hugs_prng_bits(const uint32_t* key, long long n, uint32_t* out, void* stream) {
   HUGS_REQUIRE(key && (out || n == 0), -2, "hugs_prng_bits: null pointer");

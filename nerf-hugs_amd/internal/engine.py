@@ -436,11 +436,15 @@ class Engine:
     else:
       init_s_near = float(np.clip(1 - train_frac / mdl.near_anneal_rate, 0, mdl.near_anneal_init))
     init_s_far = 1.
+    # level-0 input histogram: one bin [init_s_near, init_s_far] of weight 1 per ray -- constant between steps unless
+    # near_anneal moves it: written when the values change (three launches less per step)
     sdist = ws.get('sdist_init', (N, 2))
-    sdist[:, 0] = init_s_near
-    sdist[:, 1] = init_s_far
     weights = ws.get('w_init', (N, 1))
-    weights.fill_(1.0)
+    if ws.bufs.get(('init_hist', N)) != (init_s_near, init_s_far):
+      sdist[:, 0] = init_s_near
+      sdist[:, 1] = init_s_far
+      weights.fill_(1.0)
+      ws.bufs[('init_hist', N)] = (init_s_near, init_s_far)
     prod = 1
     levels = []
     for lvl in range(mdl.num_levels):

@@ -115,6 +115,14 @@ class Model:
       _, rng = hrandom.split(rng)
     return out, rng
 
+  def step_jitter(self, rng, N):
+    """train_step's `rng, key = random.split(rng)` (train_utils.py:408) followed by level_jitter(key, N), as one launch.
+    Returns (stepfun.Jitter, the advanced rng)."""
+    Ss = [self.num_prop_samples if l < self.num_levels - 1 else self.num_nerf_samples for l in range(self.num_levels)]
+    d = [1 if self.single_jitter else S for S in Ss]
+    outs, rng = hrandom.step_jitter(rng, [N * dl for dl in d], [stepfun.sample_u(S, True)[1] for S in Ss])
+    return stepfun.Jitter([o.view(N, dl) for o, dl in zip(outs, d)]), rng
+
   # -- forward -----------------------------------------------------------------------------------------
   def apply(self, variables, rng, rays, train_frac, compute_extras, zero_glo=False, zero_tra=False,
             refresh_weights=True):

@@ -54,6 +54,23 @@ def uniform(key, shape=(), minval=0., maxval=1.):
   return out
 
 
+def step_jitter(key, sizes, maxvals):
+  """One training step's whole consumption of the stream in ONE launch (csrc/hugs_prng.hip k_step_jitter), bit-identical to
+
+      rng, k = split(key)                                    # train_utils.py:408
+      for each level l:  kl, k = split(k); u_l = uniform(kl, (sizes[l],), maxval=maxvals[l]); _, k = split(k)     # models.py:196,230
+
+  Returns ([u_0, u_1, ...], rng)."""
+  _check(key)
+  outs = [torch.empty(int(n), dtype=torch.float32, device=key.device) for n in sizes]
+  new_key = torch.empty(2, dtype=torch.int32, device=key.device)
+  n_arr = np.ascontiguousarray(sizes, np.int64)
+  m_arr = np.ascontiguousarray(maxvals, np.float32)
+  p_arr = np.ascontiguousarray([o.data_ptr() for o in outs], np.uint64)
+  L.call('hugs_prng_step_jitter', key, len(outs), n_arr.ctypes.data, m_arr.ctypes.data, p_arr.ctypes.data, new_key)
+  return outs, new_key
+
+
 def permutation(key, n):
   """jax.random.permutation(key, n) (jax/_src/random.py _shuffle): repeated stable sort by fresh 32-bit keys."""
   x = torch.arange(n, device=key.device)

@@ -190,7 +190,8 @@ def create_train_step(model, config, is_finetune=False):
     ws = eng.ws
     nch, nleaf, nmod = layout.chunks.shape[0], len(layout.leaves), len(layout.modules)
     part1 = ws.get('opt_part1', (nch * 4,))
-    leaf_stats = ws.get('leaf_stats', (nleaf * 4 + nleaf * 2 + 16,))
+    # (the per-leaf stats land directly behind the stat tail in the buffer the host reads: one copy less per step)
+    leaf_stats = ws.get('stats_packed', (STAT_TAIL + nleaf * 6 + 16,))[STAT_TAIL:]
     mod_scale = leaf_stats[nleaf * 6:nleaf * 6 + 16]
     _lib.call('hugs_opt_stats', nch, nleaf, nmod, eng.chunks, eng.leaf_info, state.flat, grad, gscale, config.grad_max_val,
               config.grad_max_norm, part1, leaf_stats[:nleaf * 4], mod_scale)
@@ -226,9 +227,12 @@ def create_train_step(model, config, is_finetune=False):
         raise ValueError(f'explicit jitter needs one tensor per level ({L}), got {len(rng)}')
       u01 = [u.to(device=dev, dtype=torch.float32).contiguous() for u in rng]
     elif hrandom.is_key(rng):                        # jax stream: rng, key = random.split(rng) (train_utils.py:408)
-      rng, key = hrandom.split(rng)
-      if config.randomized:
-        u01, _ = model.level_jitter(key, N)
+      if config.randomized and L <= 8:
+        u01, rng = model.step_jitter(rng, N)         # that split + every level's split / uniform / split in one launch
+      else:
+        rng, key = hrandom.split(rng)
+        if config.randomized:
+          u01, _ = model.level_jitter(key, N)
     elif config.randomized and rng is not None:
       u01 = []
       for l in range(L):
@@ -418,7 +422,7 @@ def create_train_step(model, config, is_finetune=False):
     packed[:STAT_TAIL].copy_(tail)
     if world > 1:
       packed[:STAT_TAIL].mul_(gscale)
-    packed[STAT_TAIL:].copy_(leaf_stats)
+    assert leaf_stats.data_ptr() == packed[STAT_TAIL:].data_ptr()
     if tt == 'robustnerf':
       cache['thr_dev'] = packed[o_rob:o_rob + 5 * L].reshape(L, 5)[:, :1].clone()
 

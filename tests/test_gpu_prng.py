@@ -126,3 +126,36 @@ def test_train_step_consumes_keys_like_the_reference(single_jitter):
   assert torch.equal(hist[0]['sdist'], hist2[0]['sdist'])
   rend3, hist3 = model.apply(s1.flat, None, batch.rays, 0.5, False)
   assert not torch.equal(hist[0]['sdist'].clone(), hist3[0]['sdist'])
+
+
+def test_step_jitter_is_the_chain_of_splits_and_uniforms():
+  """hugs_prng_step_jitter (one launch per training step) == train_utils.py:408 split + per level models.py:196 split ->
+  stepfun.py:207-209 uniform -> models.py:230 split, bit for bit (odd and even sizes, up to 8 levels)."""
+  from nerf_hugs_amd.internal import random as hr
+  for seed, sizes, maxvals in ((0, [1024, 1024], [0.0154, 0.0077]), (20200823, [1, 7, 131072 * 3 + 1], [1.0, 0.5, 0.003]),
+                               (5, [64] * 8, [0.1 * (i + 1) for i in range(8)]), (9, [], [])):
+    key = hr.PRNGKey(seed, 'cuda')
+    outs, rng = hr.step_jitter(key, sizes, maxvals)
+    want_rng, k = hr.split(key)
+    for n, mv, o in zip(sizes, maxvals, outs):
+      kl, k = hr.split(k)
+      assert torch.equal(o, hr.uniform(kl, (n,), maxval=mv)), (seed, n)
+      _, k = hr.split(k)
+    assert torch.equal(rng, want_rng)
+
+
+def test_train_step_consumes_the_stream_as_before():
+  """Model.step_jitter (fused) hands the sampler the same draws and returns the same advanced key as split + level_jitter."""
+  from nerf_hugs_amd.internal import configs, models
+  from nerf_hugs_amd.internal import random as hr
+  configs.clear_config()
+  configs.parse_config_files_and_bindings(None, ["Model.num_levels = 3", "Model.single_jitter = False"])
+  m = models.Model(configs.make_config())
+  key = hr.PRNGKey(11, 'cuda')
+  fused, rng = m.step_jitter(key, 96)
+  want_rng, k = hr.split(key)
+  chain, _ = m.level_jitter(k, 96)
+  assert torch.equal(rng, want_rng) and len(fused) == 3 and fused.scaled
+  for a, b in zip(fused, chain):
+    assert a.shape == b.shape and torch.equal(a, b)
+  configs.clear_config()
