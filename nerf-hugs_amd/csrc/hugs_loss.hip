@@ -158,11 +158,13 @@ __global__ __launch_bounds__(1024) void k_quantile_stats(int n, const float* __r
 // ---- interlevel loss, one wave per ray -----------------------------------------------------------
 // t[S+1], w[S]: final level (constants);  te[Sp+1], we[Sp]: proposal level (gradient flows to we).
 // loss_ray = sum_i max(0, w_i - wo_i)^2 / (w_i + eps);  d_we = scale * d loss_ray / d we
-#define IL_CAP 260
+// MAXC = samples per lane of the blocked scan: 4 -> <= 256 samples per level, 8 -> 512, 16 -> 1024 (LDS 5 x 4 x (64 MAXC + 4) floats)
+template <int MAXC>
 __global__ __launch_bounds__(256) void k_interlevel(int nrays, int S, int Sp, const float* __restrict__ t,
                                                     const float* __restrict__ w, const float* __restrict__ te,
                                                     const float* __restrict__ we, float scale,
                                                     float* __restrict__ loss_ray, float* __restrict__ d_we) {
+  constexpr int IL_CAP = 64 * MAXC + 4;
   __shared__ float s_te[4][IL_CAP], s_cy[4][IL_CAP], s_g[4][IL_CAP];
   __shared__ int s_a[4][IL_CAP], s_b[4][IL_CAP];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, ray = blockIdx.x * 4 + wv;
@@ -171,9 +173,9 @@ __global__ __launch_bounds__(256) void k_interlevel(int nrays, int S, int Sp, co
     for (int i = lane; i <= Sp; i += 64) s_te[wv][i] = te[(size_t)ray * (Sp + 1) + i];
     // cy[0] = 0, cy[j+1] = cumsum(we)[j]: blocked scan, C elements per lane
     const int C = (Sp + 63) >> 6;
-    float v[4], tot = 0.f;
+    float v[MAXC], tot = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const int i = lane * C + k; v[k] = (k < C && i < Sp) ? we[(size_t)ray * Sp + i] : 0.f; tot += v[k]; }
+    for (int k = 0; k < MAXC; ++k) { const int i = lane * C + k; v[k] = (k < C && i < Sp) ? we[(size_t)ray * Sp + i] : 0.f; tot += v[k]; }
     const float incl = wave_incl_scan_f(tot, lane);
     float run = __shfl_up(incl, 1);
     if (lane == 0) { run = 0.f; s_cy[wv][0] = 0.f; }
@@ -181,16 +183,16 @@ __global__ __launch_bounds__(256) void k_interlevel(int nrays, int S, int Sp, co
     // sums, so the prefix could step DOWN by an ulp there; on a stretch of zero weights that would make an outer
     // measure of -1e-7 and, through 1/(w + eps), an O(1) spurious gradient.  A sequential cumsum of non-negative
     // numbers (the reference's) never decreases: enforce that with a running maximum across lanes.
-    float cyv[4], last = run;
+    float cyv[MAXC], last = run;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { last += v[k]; cyv[k] = last; }
+    for (int k = 0; k < MAXC; ++k) { last += v[k]; cyv[k] = last; }
     float pm = last;
 #pragma unroll
     for (int dd = 1; dd < 64; dd <<= 1) { const float o = __shfl_up(pm, dd); if (lane >= dd) pm = fmaxf(pm, o); }
     float carry = __shfl_up(pm, 1);
     if (lane == 0) carry = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const int i = lane * C + k; if (k < C && i < Sp) s_cy[wv][i + 1] = fmaxf(cyv[k], carry); }
+    for (int k = 0; k < MAXC; ++k) { const int i = lane * C + k; if (k < C && i < Sp) s_cy[wv][i + 1] = fmaxf(cyv[k], carry); }
   }
   __syncthreads();
   float lsum = 0.f;
@@ -232,9 +234,11 @@ __global__ __launch_bounds__(256) void k_interlevel(int nrays, int S, int Sp, co
 }
 
 // ---- distortion loss, one wave per ray (O(S^2) in LDS) -------------------------------------------
+template <int MAXC>
 __global__ __launch_bounds__(256) void k_distortion(int nrays, int S, const float* __restrict__ t,
                                                     const float* __restrict__ w, float scale,
                                                     float* __restrict__ loss_ray, float* __restrict__ d_w) {
+  constexpr int IL_CAP = 64 * MAXC + 4;
   __shared__ float s_u[4][IL_CAP], s_w[4][IL_CAP];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, ray = blockIdx.x * 4 + wv;
   const bool live = ray < nrays;
@@ -321,19 +325,24 @@ extern "C" int hugs_nf_robust_mask(int npatch, int P, const float* pred, const f
 
 extern "C" int hugs_interlevel(int nrays, int S, int Sp, const float* t, const float* w, const float* t_env,
                                const float* w_env, float scale, float* loss_ray, float* d_w_env, void* stream) {
-  HUGS_REQUIRE(S < IL_CAP - 1 && Sp < IL_CAP - 1 && Sp <= 256, -3, "hugs_interlevel: S=%d Sp=%d exceed capacity", S, Sp);
+  HUGS_REQUIRE(S >= 1 && Sp >= 1 && S <= 1024 && Sp <= 1024, -3, "hugs_interlevel: S=%d Sp=%d exceed capacity (1024 samples per level)", S, Sp);
   if (nrays <= 0) return 0;
-  hipLaunchKernelGGL(k_interlevel, dim3((nrays + 3) / 4), dim3(256), 0, (hipStream_t)stream, nrays, S, Sp, t, w, t_env,
-                     w_env, scale, loss_ray, d_w_env);
+  const int big = S > Sp ? S : Sp;
+#define HUGS_IL_LAUNCH(C_) hipLaunchKernelGGL(k_interlevel<C_>, dim3((nrays + 3) / 4), dim3(256), 0, (hipStream_t)stream, nrays, S, Sp, t, w, \
+    t_env, w_env, scale, loss_ray, d_w_env)
+  if (big <= 256) HUGS_IL_LAUNCH(4); else if (big <= 512) HUGS_IL_LAUNCH(8); else HUGS_IL_LAUNCH(16);
+#undef HUGS_IL_LAUNCH
   HUGS_CHECK_LAUNCH("hugs_interlevel");
   return 0;
 }
 
 extern "C" int hugs_distortion(int nrays, int S, const float* t, const float* w, float scale, float* loss_ray, float* d_w,
                                void* stream) {
-  HUGS_REQUIRE(S < IL_CAP, -3, "hugs_distortion: S=%d exceeds capacity", S);
+  HUGS_REQUIRE(S >= 1 && S <= 1024, -3, "hugs_distortion: S=%d exceeds capacity (1024 samples per level)", S);
   if (nrays <= 0) return 0;
-  hipLaunchKernelGGL(k_distortion, dim3((nrays + 3) / 4), dim3(256), 0, (hipStream_t)stream, nrays, S, t, w, scale, loss_ray, d_w);
+#define HUGS_DL_LAUNCH(C_) hipLaunchKernelGGL(k_distortion<C_>, dim3((nrays + 3) / 4), dim3(256), 0, (hipStream_t)stream, nrays, S, t, w, scale, loss_ray, d_w)
+  if (S <= 256) HUGS_DL_LAUNCH(4); else if (S <= 512) HUGS_DL_LAUNCH(8); else HUGS_DL_LAUNCH(16);
+#undef HUGS_DL_LAUNCH
   HUGS_CHECK_LAUNCH("hugs_distortion");
   return 0;
 }

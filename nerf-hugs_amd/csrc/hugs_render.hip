@@ -1,5 +1,5 @@
 // Volumetric compositing, one WAVEFRONT per ray: density -> alpha / transmittance (wave prefix scan
-// over the ray's <= 256 samples held 4-per-lane in registers) -> weights -> colour, and the backward
+// over the ray's samples held 4 / 8 / 16 per lane in registers: <= 256 / 512 / 1024 samples per level) -> weights -> colour, and the backward
 // pass (wave suffix scan).  Nothing but the per-sample weights round-trips through HBM.
 //
 // Replaces (reference, MipNeRF360/internal): render.py:130-151 compute_alpha_weights, :185-244
@@ -7,16 +7,18 @@
 // stepfun.py:298-308 weighted_percentile), and their autodiff (train_utils.py:454).
 #include "hugs_common.h"
 
-#define RC_MAXC 4  // samples per lane -> S <= 256
+// RC_MAXC = samples per lane (template parameter): 4 -> S <= 256, 8 -> 512, 16 -> 1024, chosen per launch from S
 
+template <int RC_MAXC>
 struct RayScan {
   float sd[RC_MAXC];   // density * delta
   float pre[RC_MAXC];  // exclusive prefix of sd
   float w[RC_MAXC];
 };
 
+template <int RC_MAXC>
 __device__ __forceinline__ void ray_weights(int S, int C, int lane, const float* __restrict__ dens,
-                                            const float* __restrict__ td, float dnorm, int opaque, RayScan& R) {
+                                            const float* __restrict__ td, float dnorm, int opaque, RayScan<RC_MAXC>& R) {
   float tot = 0.f;
 #pragma unroll
   for (int k = 0; k < RC_MAXC; ++k) {
@@ -46,6 +48,7 @@ __device__ __forceinline__ void ray_weights(int S, int C, int lane, const float*
 }
 
 // forward.  rgb_s may be null (proposal levels: rgb == 0).  extras may be null.
+template <int RC_MAXC>
 __global__ __launch_bounds__(256) void k_composite_fwd(int nrays, int S, const float* __restrict__ density,
                                                        const float* __restrict__ rgb_s, const float* __restrict__ tdist,
                                                        const float* __restrict__ dirs, int opaque, float bg,
@@ -57,8 +60,8 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int nrays, int S, const f
   const float* td = tdist + (size_t)ray * (S + 1);
   const float dx = dirs[ray * 3], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
   const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
-  RayScan R;
-  ray_weights(S, C, lane, density + (size_t)ray * S, td, dnorm, opaque, R);
+  RayScan<RC_MAXC> R;
+  ray_weights<RC_MAXC>(S, C, lane, density + (size_t)ray * S, td, dnorm, opaque, R);
   float acc = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, elog = 0.f;
 #pragma unroll
   for (int k = 0; k < RC_MAXC; ++k) {
@@ -143,6 +146,7 @@ __global__ __launch_bounds__(256) void k_composite_fwd(int nrays, int S, const f
 }
 
 // backward: d_density, d_rgb_s from d_rgb_out [N,3] and d_w_extra [N,S] (nullable)
+template <int RC_MAXC>
 __global__ __launch_bounds__(256) void k_composite_bwd(int nrays, int S, const float* __restrict__ density,
                                                        const float* __restrict__ rgb_s, const float* __restrict__ tdist,
                                                        const float* __restrict__ dirs, int opaque, float bg,
@@ -155,8 +159,8 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int nrays, int S, const f
   const float* td = tdist + (size_t)ray * (S + 1);
   const float dx = dirs[ray * 3], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
   const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
-  RayScan R;
-  ray_weights(S, C, lane, density + (size_t)ray * S, td, dnorm, opaque, R);
+  RayScan<RC_MAXC> R;
+  ray_weights<RC_MAXC>(S, C, lane, density + (size_t)ray * S, td, dnorm, opaque, R);
   float lane_w = 0.f;
 #pragma unroll
   for (int k = 0; k < RC_MAXC; ++k) lane_w += R.w[k];
@@ -207,11 +211,13 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int nrays, int S, const f
 extern "C" int hugs_composite_fwd(int nrays, int S, const float* density, const float* rgb_s, const float* tdist,
                                   const float* dirs, int opaque_background, float bg, const float* t_far, float* weights,
                                   float* rgb_out, float* extras, void* stream) {
-  HUGS_REQUIRE(S >= 1 && S <= 64 * RC_MAXC, -3, "hugs_composite_fwd: %d samples per ray unsupported (<= %d)", S, 64 * RC_MAXC);
+  HUGS_REQUIRE(S >= 1 && S <= 1024, -3, "hugs_composite_fwd: %d samples per ray unsupported (<= 1024)", S);
   HUGS_REQUIRE(!extras || t_far, -3, "hugs_composite_fwd: extras need t_far");
   if (nrays <= 0) return 0;
-  hipLaunchKernelGGL(k_composite_fwd, dim3((nrays + 3) / 4), dim3(256), 0, (hipStream_t)stream, nrays, S, density, rgb_s,
-                     tdist, dirs, opaque_background, bg, t_far, weights, rgb_out, extras);
+#define HUGS_CF_LAUNCH(C_) hipLaunchKernelGGL(k_composite_fwd<C_>, dim3((nrays + 3) / 4), dim3(256), 0, (hipStream_t)stream, nrays, S, \
+    density, rgb_s, tdist, dirs, opaque_background, bg, t_far, weights, rgb_out, extras)
+  if (S <= 256) HUGS_CF_LAUNCH(4); else if (S <= 512) HUGS_CF_LAUNCH(8); else HUGS_CF_LAUNCH(16);
+#undef HUGS_CF_LAUNCH
   HUGS_CHECK_LAUNCH("hugs_composite_fwd");
   return 0;
 }
@@ -219,10 +225,12 @@ extern "C" int hugs_composite_fwd(int nrays, int S, const float* density, const 
 extern "C" int hugs_composite_bwd(int nrays, int S, const float* density, const float* rgb_s, const float* tdist,
                                   const float* dirs, int opaque_background, float bg, const float* d_rgb_out,
                                   const float* d_w_extra, float* d_density, float* d_rgb_s, void* stream) {
-  HUGS_REQUIRE(S >= 1 && S <= 64 * RC_MAXC, -3, "hugs_composite_bwd: %d samples per ray unsupported (<= %d)", S, 64 * RC_MAXC);
+  HUGS_REQUIRE(S >= 1 && S <= 1024, -3, "hugs_composite_bwd: %d samples per ray unsupported (<= 1024)", S);
   if (nrays <= 0) return 0;
-  hipLaunchKernelGGL(k_composite_bwd, dim3((nrays + 3) / 4), dim3(256), 0, (hipStream_t)stream, nrays, S, density, rgb_s,
-                     tdist, dirs, opaque_background, bg, d_rgb_out, d_w_extra, d_density, d_rgb_s);
+#define HUGS_CB_LAUNCH(C_) hipLaunchKernelGGL(k_composite_bwd<C_>, dim3((nrays + 3) / 4), dim3(256), 0, (hipStream_t)stream, nrays, S, \
+    density, rgb_s, tdist, dirs, opaque_background, bg, d_rgb_out, d_w_extra, d_density, d_rgb_s)
+  if (S <= 256) HUGS_CB_LAUNCH(4); else if (S <= 512) HUGS_CB_LAUNCH(8); else HUGS_CB_LAUNCH(16);
+#undef HUGS_CB_LAUNCH
   HUGS_CHECK_LAUNCH("hugs_composite_bwd");
   return 0;
 }

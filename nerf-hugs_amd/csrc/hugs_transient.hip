@@ -202,8 +202,8 @@ extern "C" int hugs_hanerf_loss(int N, int L, const float* pred, const float* gt
 // =====================================================================================================
 namespace {
 
-#define DC_MAXC 4
-
+// DC_MAXC = samples per lane (template parameter): 4 -> <= 256 samples per level, 8 -> 512, 16 -> 1024
+template <int DC_MAXC>
 struct DualScan {
   float a[DC_MAXC], b[DC_MAXC];      // sigma_s * delta, sigma_t * delta (+inf on the last sample when opaque)
   float T[DC_MAXC], Tt[DC_MAXC];     // transmittance of (a+b) and of b alone, before the sample
@@ -211,8 +211,9 @@ struct DualScan {
   bool ok[DC_MAXC], last[DC_MAXC];
 };
 
+template <int DC_MAXC>
 __device__ __forceinline__ void dual_scan(int S, int C, int lane, const float* __restrict__ ds, const float* __restrict__ dt_,
-                                          const float* __restrict__ td, float dnorm, int opaque, DualScan& R) {
+                                          const float* __restrict__ td, float dnorm, int opaque, DualScan<DC_MAXC>& R) {
   float tg = 0.f, tb = 0.f;
 #pragma unroll
   for (int k = 0; k < DC_MAXC; ++k) {
@@ -241,6 +242,7 @@ __device__ __forceinline__ void dual_scan(int S, int C, int lane, const float* _
   }
 }
 
+template <int DC_MAXC>
 __global__ void __launch_bounds__(256)
 k_dual_composite_fwd(int nrays, int S, const float* __restrict__ dens_s, const float* __restrict__ dens_t,
                      const float* __restrict__ rgb_s, const float* __restrict__ rgb_t, const float* __restrict__ unc,
@@ -253,8 +255,8 @@ k_dual_composite_fwd(int nrays, int S, const float* __restrict__ dens_s, const f
   const float* td = tdist + (size_t)ray * (S + 1);
   const float dx = dirs[ray * 3], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
   const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
-  DualScan R;
-  dual_scan(S, C, lane, dens_s + (size_t)ray * S, dens_t + (size_t)ray * S, td, dnorm, opaque, R);
+  DualScan<DC_MAXC> R;
+  dual_scan<DC_MAXC>(S, C, lane, dens_s + (size_t)ray * S, dens_t + (size_t)ray * S, td, dnorm, opaque, R);
   float acc = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, t0 = 0.f, t1 = 0.f, t2 = 0.f, be = 0.f;
 #pragma unroll
   for (int k = 0; k < DC_MAXC; ++k) {
@@ -280,6 +282,7 @@ k_dual_composite_fwd(int nrays, int S, const float* __restrict__ dens_s, const f
 
 // d_dens_s += ..., d_rgb_s = ..., d_dens_t = ... (+ dens_t_const: the density regulariser's constant gradient),
 // d_rgb_t = ..., d_unc = ...
+template <int DC_MAXC>
 __global__ void __launch_bounds__(256)
 k_dual_composite_bwd(int nrays, int S, const float* __restrict__ dens_s, const float* __restrict__ dens_t,
                      const float* __restrict__ rgb_s, const float* __restrict__ rgb_t, const float* __restrict__ unc,
@@ -293,8 +296,8 @@ k_dual_composite_bwd(int nrays, int S, const float* __restrict__ dens_s, const f
   const float* td = tdist + (size_t)ray * (S + 1);
   const float dx = dirs[ray * 3], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
   const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
-  DualScan R;
-  dual_scan(S, C, lane, dens_s + (size_t)ray * S, dens_t + (size_t)ray * S, td, dnorm, opaque, R);
+  DualScan<DC_MAXC> R;
+  dual_scan<DC_MAXC>(S, C, lane, dens_s + (size_t)ray * S, dens_t + (size_t)ray * S, td, dnorm, opaque, R);
   const float g0 = d_rgb_comb[ray * 3], g1 = d_rgb_comb[ray * 3 + 1], g2 = d_rgb_comb[ray * 3 + 2];
   const float gbeta = d_beta[ray];
   float acc = 0.f;
@@ -411,12 +414,12 @@ extern "C" int hugs_dual_composite_fwd(int nrays, int S, const float* dens_s, co
                                        const float* rgb_t, const float* unc, const float* tdist, const float* dirs,
                                        int opaque_background, float bg, float beta_min, float* rgb_combined,
                                        float* rgb_static, float* rgb_transient, float* beta, void* stream) {
-  HUGS_REQUIRE(S >= 1 && S <= 64 * DC_MAXC, -3, "hugs_dual_composite_fwd: %d samples per ray unsupported (<= %d)", S,
-               64 * DC_MAXC);
+  HUGS_REQUIRE(S >= 1 && S <= 1024, -3, "hugs_dual_composite_fwd: %d samples per ray unsupported (<= 1024)", S);
   if (nrays <= 0) return 0;
-  k_dual_composite_fwd<<<(nrays + 3) / 4, 256, 0, (hipStream_t)stream>>>(nrays, S, dens_s, dens_t, rgb_s, rgb_t, unc, tdist,
-                                                                       dirs, opaque_background, bg, beta_min, rgb_combined,
-                                                                       rgb_static, rgb_transient, beta);
+#define HUGS_DCF(C_) k_dual_composite_fwd<C_><<<(nrays + 3) / 4, 256, 0, (hipStream_t)stream>>>(nrays, S, dens_s, dens_t, rgb_s, rgb_t, unc, \
+    tdist, dirs, opaque_background, bg, beta_min, rgb_combined, rgb_static, rgb_transient, beta)
+  if (S <= 256) HUGS_DCF(4); else if (S <= 512) HUGS_DCF(8); else HUGS_DCF(16);
+#undef HUGS_DCF
   HUGS_CHECK_LAUNCH("k_dual_composite_fwd");
   return 0;
 }
@@ -426,12 +429,13 @@ extern "C" int hugs_dual_composite_bwd(int nrays, int S, const float* dens_s, co
                                        int opaque_background, float bg, const float* d_rgb_combined, const float* d_beta,
                                        float dens_t_const, float* d_dens_s_accum, float* d_rgb_s, float* d_dens_t,
                                        float* d_rgb_t, float* d_unc, void* stream) {
-  HUGS_REQUIRE(S >= 1 && S <= 64 * DC_MAXC, -3, "hugs_dual_composite_bwd: %d samples per ray unsupported (<= %d)", S,
-               64 * DC_MAXC);
+  HUGS_REQUIRE(S >= 1 && S <= 1024, -3, "hugs_dual_composite_bwd: %d samples per ray unsupported (<= 1024)", S);
   if (nrays <= 0) return 0;
-  k_dual_composite_bwd<<<(nrays + 3) / 4, 256, 0, (hipStream_t)stream>>>(
-      nrays, S, dens_s, dens_t, rgb_s, rgb_t, unc, tdist, dirs, opaque_background, bg, d_rgb_combined, d_beta, dens_t_const,
-      d_dens_s_accum, d_rgb_s, d_dens_t, d_rgb_t, d_unc);
+#define HUGS_DCB(C_) k_dual_composite_bwd<C_><<<(nrays + 3) / 4, 256, 0, (hipStream_t)stream>>>( \
+      nrays, S, dens_s, dens_t, rgb_s, rgb_t, unc, tdist, dirs, opaque_background, bg, d_rgb_combined, d_beta, dens_t_const, \
+      d_dens_s_accum, d_rgb_s, d_dens_t, d_rgb_t, d_unc)
+  if (S <= 256) HUGS_DCB(4); else if (S <= 512) HUGS_DCB(8); else HUGS_DCB(16);
+#undef HUGS_DCB
   HUGS_CHECK_LAUNCH("k_dual_composite_bwd");
   return 0;
 }

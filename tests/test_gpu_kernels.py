@@ -240,7 +240,8 @@ def test_composite_bwd_finite_and_vs_autograd():
   from oracle import torch_ref as R
   L = _L()
   g = torch.Generator().manual_seed(0)
-  for S, opaque, ls in [(128, 1, 0.), (64, 0, 3.), (32, 1, -10.), (200, 0, 10.), (32, 0, -100.)]:
+  # (more than 256 samples per level run 8 / 16 samples per lane: 320, 700, 1024)
+  for S, opaque, ls in [(128, 1, 0.), (64, 0, 3.), (32, 1, -10.), (200, 0, 10.), (32, 0, -100.), (320, 1, 1.), (700, 0, 2.), (1024, 1, 0.)]:
     N = 37
     td = torch.sort(torch.rand(N, S + 1, generator=g) * 2 + 0.1, -1).values
     dens = (torch.rand(N, S, generator=g) * np.exp(ls)).double().requires_grad_(True)
@@ -280,6 +281,49 @@ def test_losses_vs_oracle_autograd(golden):
   L.call('hugs_distortion', N, S, G(c), G(w), 1.0 / N, lr, dw)
   np.testing.assert_allclose(lr.cpu().numpy(), golden[f'{tag}/lossfun_distortion'], rtol=2e-5)
   assert float((dw.cpu().double() - g).abs().max()) < 1e-5 * float(g.abs().max())
+
+
+def test_more_than_256_samples_per_level():
+  """The per-ray kernels of the Mip-NeRF 360 path beyond 256 samples per level (8 / 16 samples per lane: capacity 512 /
+  1024): compositing forward incl. extras, interlevel and distortion losses with gradients, against the float64 oracle."""
+  from oracle import torch_ref as R
+  L = _L()
+  g = torch.Generator().manual_seed(3)
+  N = 19
+  for S, Sp in ((384, 300), (1000, 512), (128, 700)):
+    td = torch.sort(torch.rand(N, S + 1, generator=g) * 2 + 0.1, -1).values
+    dens = torch.rand(N, S, generator=g) * 20
+    rgb = torch.rand(N, S, 3, generator=g)
+    d = torch.randn(N, 3, generator=g)
+    far = td[:, -1] + 1.0
+    w = torch.empty(N, S, device=dev); ro = torch.empty(N, 3, device=dev); ex = torch.empty(N, 5, device=dev)
+    L.call('hugs_composite_fwd', N, S, dens.to(dev), rgb.to(dev), td.to(dev), d.to(dev), 0, 1.0, far.to(dev), w, ro, ex)
+    wo, _, _ = R.compute_alpha_weights(dens.double(), td.double(), d.double(), False)
+    rend = R.volumetric_rendering(rgb.double(), wo, td.double(), 1.0, far.double()[:, None], True)
+    np.testing.assert_allclose(w.cpu().numpy(), wo.numpy(), rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(ro.cpu().numpy(), rend['rgb'].numpy(), rtol=0, atol=2e-5)
+    for i, k in enumerate(['acc', 'distance_mean', 'distance_median', 'distance_percentile_5', 'distance_percentile_95']):
+      np.testing.assert_allclose(ex.cpu().numpy()[:, i], rend[k].numpy().reshape(-1), rtol=2e-4, atol=2e-5, err_msg=f'{S} {k}')
+    # losses: final level (S) against a proposal level (Sp)
+    c = torch.sort(torch.rand(N, S + 1, generator=g), -1).values; c[:, 0], c[:, -1] = 0., 1.
+    wf = torch.rand(N, S, generator=g); wf = wf / wf.sum(-1, keepdim=True)
+    cp = torch.sort(torch.rand(N, Sp + 1, generator=g), -1).values; cp[:, 0], cp[:, -1] = 0., 1.
+    wp = (torch.rand(N, Sp, generator=g) * (1.5 / Sp)).double().requires_grad_(True)
+    lo = R.lossfun_outer(c.double(), wf.double(), cp.double(), wp)
+    gp, = torch.autograd.grad(lo.mean(), wp)
+    lr = torch.empty(N, device=dev); dwe = torch.empty(N, Sp, device=dev)
+    L.call('hugs_interlevel', N, S, Sp, c.to(dev), wf.to(dev), cp.to(dev), wp.detach().float().to(dev), 1.0 / (N * S), lr, dwe)
+    np.testing.assert_allclose(lr.cpu().numpy(), lo.detach().sum(-1).numpy(), rtol=5e-3, atol=1e-7)
+    assert float((dwe.cpu().double() - gp).abs().max()) < 2e-3 * float(gp.abs().max()) + 1e-9
+    wt = wf.double().requires_grad_(True)
+    ld = R.lossfun_distortion(c.double(), wt)
+    gd, = torch.autograd.grad(ld.mean(), wt)
+    dw = torch.empty(N, S, device=dev)
+    L.call('hugs_distortion', N, S, c.to(dev), wf.to(dev), 1.0 / N, lr, dw)
+    np.testing.assert_allclose(lr.cpu().numpy(), ld.detach().numpy(), rtol=5e-5)
+    assert float((dw.cpu().double() - gd).abs().max()) < 2e-5 * float(gd.abs().max())
+  with pytest.raises(L.HugsError):
+    L.call('hugs_composite_fwd', 1, 1025, dens.to(dev), None, td.to(dev), d.to(dev), 0, 1.0, None, w, ro, None)
 
 
 def test_properties_at_baseline_batch():

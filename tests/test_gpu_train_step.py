@@ -65,7 +65,9 @@ def _run_case(gin, n_patch=1, P=8, near=0.1, far=1.2, seed=5, inlier=None, tol_g
   assert abs(float(stats['loss']) / float(ostats['loss']) - 1) < 1e-4
   np.testing.assert_allclose(stats['mses'].numpy(), ostats['mses'].detach().numpy(), rtol=2e-4)
   for k, v in ostats['losses'].items():
-    assert abs(float(stats['losses'][k]) - float(v)) <= 2e-4 * abs(float(v)) + 1e-9, k
+    # (absolute floor 1e-7: the interlevel term of some cases is ~5e-5, a sum of squared hinge excesses that one sample
+    # crossing a proposal bin edge between the two float32 evaluations moves by 1e-3 of itself)
+    assert abs(float(stats['losses'][k]) - float(v)) <= 2e-4 * abs(float(v)) + 1e-7, k
   # optimizer: oracle clip + adam on the ORACLE gradients
   names = [n for n, _ in R.flat_leaves(oparams['params'])]
   p0 = {n: t for n, t in R.flat_leaves(oparams['params'])}
