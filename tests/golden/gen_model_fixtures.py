@@ -77,7 +77,7 @@ CASES = {
         n_patch=2, P=4, near=0.1, far=1.2, hist_step=1),
 }
 TRAIN_FRAC = 0.37
-N_DIRS = 3
+N_DIRS = 10
 SYN_GRAD_SEED = 4242
 
 

@@ -54,6 +54,9 @@ def param_tree(case, dtype=torch.float32):
   return {'params': tree}
 
 
+N_DIRS = 10      # seeded parameter directions with a float64 finite-difference derivative of the reference's loss_fn per case
+
+
 def seeded_tree(case, seed, scale=1.0):
   """The generator's direction / synthetic-gradient convention: leaves in sorted key order, one
   standard_normal(shape) float64 draw each from default_rng(seed)."""

@@ -145,8 +145,8 @@ def test_train_step_stats_and_derivatives_vs_reference(case):
   _, og, _, _ = R.loss_and_grad(cfg, FX.param_tree(case), FX.rays_flat(case),
                                 torch.from_numpy(FX.get(case, 'rgb').reshape(-1, 3).copy()),
                                 float(FX.get(case, 'train_frac')), FX.u01(case, L), othr)
-  scale = max(abs(float(FX.get(case, f'fd/dir{j}'))) for j in range(3))
-  for i in range(3):
+  scale = max(abs(float(FX.get(case, f'fd/dir{j}'))) for j in range(FX.N_DIRS))
+  for i in range(FX.N_DIRS):
     v = FX.seeded_tree(case, 1000 + i)
     mine = sum(float((g[k] * v[k]).sum()) for k in v)
     o32 = sum(float((og[k].double().numpy() * v[k]).sum()) for k in v)

@@ -143,11 +143,13 @@ def test_directional_derivatives_vs_reference(case):
     R.model_forward = orig
   l64 = float(FX.get(case, 'loss64'))
   assert abs(float(stats['loss']) - l64) <= 1e-6 * abs(l64), (float(stats['loss']), l64)
-  for i in range(3):
+  scale = max(abs(float(FX.get(case, f'fd/dir{j}'))) for j in range(FX.N_DIRS))
+  for i in range(FX.N_DIRS):
     v = FX.seeded_tree(case, 1000 + i)
     mine = sum(float((grads[k].numpy() * v[k]).sum()) for k in v)
     fd, fd2 = float(FX.get(case, f'fd/dir{i}')), float(FX.get(case, f'fd/dir{i}_h2'))
-    assert abs(mine - fd) <= 2e-5 * abs(fd) + 4 * abs(fd - fd2) + 1e-9, (case, i, mine, fd, fd2)
+    # relative to the largest of the case's projections: a single direction's value can be small by cancellation
+    assert abs(mine - fd) <= 2e-5 * scale + 4 * abs(fd - fd2) + 1e-9, (case, i, mine, fd, fd2)
 
 
 @pytest.mark.parametrize('case', FX.CASES)
