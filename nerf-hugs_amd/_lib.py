@@ -17,7 +17,7 @@ _PROTOS = {
     'hugs_gemm_nt': 'iiiii' 'pipipi' 'pp' 'iii' 'pi' 'pp' 'pi' 's',
     'hugs_gemm_nt_bits': 'iiiii' 'pipipi' 'p' 'i' 'pp' 'pi' 'pp' 's',
     'hugs_gemm_tn': 'iiiiipipippps',
-    'hugs_gemm_nt_bits_dot': 'iiiii' 'pipipi' 'ppp' 'pi' 'p' 's',
+    'hugs_gemm_nt_bits_dot': 'iiiii' 'pipipi' 'pppi' 'pi' 'p' 's',
     'hugs_density_from_partials': 'iippfpps',
     'hugs_density_fwd': 'iiipippfpps',
     'hugs_density_bwd': 'iiipippfpppps',

@@ -37,11 +37,12 @@ struct GemmEpi {
   // place of re-reading the bf16 activation: 16 B per lane instead of 256 B).
   uint32_t* bits_out;
   const uint32_t* bits_in;
-  // fused "N = 1" head (the density head behind the last trunk layer, models.py:456): dot_out[m, n / 64] = sum over the 64
-  // columns n .. n+63 of out[m, n'] * dot_w[n'] (out AFTER bias / relu / bf16 rounding: what a separate pass over the stored
-  // activation would read); the caller sums the N / 64 partials per row (hugs_density_from_partials).  256x256 kernels only.
+  // fused "N = 1" head (the density head behind the last trunk layer, models.py:456): dot_out[n / 64][m] (slice-major) = sum
+  // over the 64 columns n .. n+63 of out[m, n'] * dot_w[n'] (out AFTER bias / relu / bf16 rounding: what a separate pass over
+  // the stored activation would read); the caller sums the N / 64 partials per row (hugs_density_from_partials).  256x256 kernels only.
   const float* dot_w;
   float* dot_out;
+  int dot_ld;             // rows between two slices of dot_out (>= M; the caller's whole-batch row count when M is a row chunk)
 };
 
 // Per-phase timestamps / staggered starts for the measurement builds live in scratch/hugs_gemm_trace.h (scratch/build_trace.sh
@@ -297,6 +298,7 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
         mkv[i][h] = *(const uint4*)((const uint16_t*)E.mask + (size_t)(m0 + wm * 128 + i * 16 + h * 8 + srow) * E.ld_mask + ccol);
     };
     if (has_mask) { mask_load(0); mask_load(1); }
+    float dacc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       if (has_mask && i + 2 < 8) mask_load(i + 2);
@@ -335,7 +337,7 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
       if (has_dot) {        // the four kb lane groups hold the row's four 16-column quarters of this wave's 64 columns
         dsum += __shfl_xor(dsum, 16);
         dsum += __shfl_xor(dsum, 32);
-        if (kb == 0) E.dot_out[(size_t)(m0 + wm * 128 + i * 16 + r16) * (size_t)(E.ldc >> 6) + (size_t)((n0 >> 6) + wn)] = dsum;
+        dacc[i] = dsum;     // (every lane of a row now holds the row's sum)
       }
       uint32_t vv[2][4];
 #pragma unroll
@@ -374,6 +376,19 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
           HUGS_EPI_STORE(v_, p_);
         }
       }
+    }
+    if (has_dot) {
+      // dot_out is slice-major, [N / 64][M]: this wave's 128 rows of its slice are 512 contiguous bytes.  Lane group kb writes
+      // the row blocks i = 2 kb and 2 kb + 1 (16 rows = 64 contiguous bytes each): two store instructions per wave and tile
+      // instead of eight quarter-empty ones (4-byte pieces of different cache lines made the fused head no faster than the
+      // separate pass it replaces).
+      float v0 = dacc[0], v1 = dacc[1];
+      if (kb == 1) { v0 = dacc[2]; v1 = dacc[3]; }
+      if (kb == 2) { v0 = dacc[4]; v1 = dacc[5]; }
+      if (kb == 3) { v0 = dacc[6]; v1 = dacc[7]; }
+      float* dp = E.dot_out + (size_t)((n0 >> 6) + wn) * (size_t)E.dot_ld + (size_t)(m0 + wm * 128 + kb * 32 + r16);
+      dp[0] = v0;
+      dp[16] = v1;
     }
 }
 
@@ -738,8 +753,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
     HUGS_TRP(i, 0)
-    // the previous tile's 16 stores (+ 4 mask-bit words, + 8 head partials) are in the queue behind the two younger stages
-    if (EPI >= 0 && (EPI & EPI_BOUT) && (EPI & EPI_DOT)) { GP_ITER(f0, f1, 36) GP_ITER(f1, f0, 36) GP_ITER(f0, f1, 36) }
+    // the previous tile's 16 stores (+ 4 mask-bit words, + 2 head-partial stores) are in the queue behind the two younger stages
+    if (EPI >= 0 && (EPI & EPI_BOUT) && (EPI & EPI_DOT)) { GP_ITER(f0, f1, 30) GP_ITER(f1, f0, 30) GP_ITER(f0, f1, 30) }
     else if (EPI >= 0 && (EPI & EPI_BOUT)) { GP_ITER(f0, f1, 28) GP_ITER(f1, f0, 28) GP_ITER(f0, f1, 28) }
     else { GP_ITER(f0, f1, 24) GP_ITER(f1, f0, 24) GP_ITER(f0, f1, 24) }
     GP_ITER(f1, f0, 8)
@@ -1277,7 +1292,7 @@ static int gemm_nt_impl(int tile_mode, int dtype, int M, int N, int K1, int K2, 
                         const void* Bt, int ldb, const float* bias, const float* row_bias, int row_div, int ld_rb,
                         int relu, const void* mask, int ld_mask, const float* r1_row, const float* r1_col,
                         void* out, int ldc, uint32_t* bits_out, const uint32_t* bits_in, void* stream,
-                        const float* dot_w = nullptr, float* dot_out = nullptr);
+                        const float* dot_w = nullptr, float* dot_out = nullptr, int dot_ld = 0);
 
 extern "C" int hugs_gemm_nt(int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,
                             const void* Bt, int ldb, const float* bias, const float* row_bias, int row_div, int ld_rb,
@@ -1310,24 +1325,25 @@ extern "C" int hugs_gemm_nt_bits(int dtype, int M, int N, int K1, int K2, const 
 }
 
 // hugs_gemm_nt_bits with the density head fused into the epilogue (models.py:456 raw_density = Dense(1)(x) on the last trunk
-// layer's output): dot_out[M, N/64] receives, per row and per 64-column slice, sum_n out[m, n] * dot_w[n] over the slice (out
-// as stored: after bias, relu and bf16 rounding); hugs_density_from_partials adds the N/64 partials in a fixed order.
+// layer's output): dot_out[N/64][dot_ld >= M] (slice-major) receives, per 64-column slice and row, sum_n out[m, n] * dot_w[n] over
+// the slice (out as stored: after bias, relu and bf16 rounding); hugs_density_from_partials adds the N/64 partials in a fixed order.
 // Needs the relu + bits_out form (the forward trunk layer) -- -3 otherwise.
 extern "C" int hugs_gemm_nt_bits_dot(int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,
-                                     const void* Bt, int ldb, const float* bias, const float* dot_w, float* dot_out, void* out, int ldc,
-                                     uint32_t* bits_out, void* stream) {
+                                     const void* Bt, int ldb, const float* bias, const float* dot_w, float* dot_out, int dot_ld, void* out,
+                                     int ldc, uint32_t* bits_out, void* stream) {
   HUGS_REQUIRE(dtype == 1 && M % 256 == 0 && N % 256 == 0 && ldc == N && (K1 + K2) % 64 == 0 && K1 + K2 >= 256, -3,
                "hugs_gemm_nt_bits_dot: needs bf16, M=%d N=%d multiples of 256, ldc == N, K=%d a multiple of 64 and >= 256", M, N, K1 + K2);
-  HUGS_REQUIRE(bias && dot_w && dot_out && bits_out, -3, "hugs_gemm_nt_bits_dot: bias, dot_w, dot_out and bits_out are all required");
+  HUGS_REQUIRE(bias && dot_w && dot_out && bits_out && dot_ld >= M, -3,
+               "hugs_gemm_nt_bits_dot: bias, dot_w, dot_out and bits_out are all required, dot_ld (%d) >= M (%d)", dot_ld, M);
   return gemm_nt_impl(0, dtype, M, N, K1, K2, A1, lda1, A2, lda2, Bt, ldb, bias, nullptr, 1, 0, 1, nullptr, 0, nullptr, nullptr, out, ldc,
-                      bits_out, nullptr, stream, dot_w, dot_out);
+                      bits_out, nullptr, stream, dot_w, dot_out, dot_ld);
 }
 
 static int gemm_nt_impl(int tile_mode, int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2,
                         int lda2, const void* Bt, int ldb, const float* bias, const float* row_bias, int row_div, int ld_rb,
                         int relu, const void* mask, int ld_mask, const float* r1_row, const float* r1_col,
                         void* out, int ldc, uint32_t* bits_out, const uint32_t* bits_in, void* stream,
-                        const float* dot_w, float* dot_out) {
+                        const float* dot_w, float* dot_out, int dot_ld) {
   HUGS_REQUIRE(dtype == 0 || dtype == 1, -2, "hugs_gemm_nt: dtype must be 0 (fp32) or 1 (bf16)");
   const int bk = dtype ? GB_BK : GF_BK;
   HUGS_REQUIRE(M % 128 == 0 && N % 128 == 0 && K1 % bk == 0 && K2 % bk == 0 && K1 > 0, -3,
@@ -1337,7 +1353,7 @@ static int gemm_nt_impl(int tile_mode, int dtype, int M, int N, int K1, int K2, 
   const bool bits = bits_out || bits_in;
   HUGS_REQUIRE(!bits || (tile_mode != 1 && tile_mode != 3), -3, "hugs_gemm_nt_bits: needs the 256x256 kernels (tile_mode 0 or 5)");
   if (bits_in) mask = nullptr;       // (the EPI_MASK specialisation is selected through `epi_mask` below)
-  GemmEpi E{bias, row_bias, row_div, ld_rb, relu, mask, ld_mask, r1_row, r1_col, out, ldc, bits_out, bits_in, dot_w, dot_out};
+  GemmEpi E{bias, row_bias, row_div, ld_rb, relu, mask, ld_mask, r1_row, r1_col, out, ldc, bits_out, bits_in, dot_w, dot_out, dot_ld};
   const int grid = (M / 128) * (N / 128);
   // (four K-stages of 32 are the shortest pipeline the ring kernels run: K >= 128)
   if (dtype && M % 256 == 0 && N % 256 == 0 && (K1 + K2) % 64 == 0 && K1 + K2 >= 128 && tile_mode != 1 && tile_mode != 3)

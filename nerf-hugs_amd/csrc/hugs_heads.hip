@@ -65,17 +65,15 @@ __global__ __launch_bounds__(256) void k_density_fwd(int M, int K, const void* _
   }
 }
 
-// density head from the partial dot products the last trunk layer's GEMM epilogue left (hugs_gemm_nt_bits_dot): raw[m] = b +
-// sum_p part[m, p] in index order (deterministic), density = softplus(raw + density_bias).  P = N / 64 (16 at width 1024).
+// density head from the partial dot products the last trunk layer's GEMM epilogue left (hugs_gemm_nt_bits_dot, slice-major
+// part[p][m]): raw[m] = b + sum_p part[p][m] in index order (deterministic), density = softplus(raw + density_bias).
+// P = N / 64 (16 at width 1024).
 __global__ __launch_bounds__(256) void k_density_from_partials(int M, int P, const float* __restrict__ part, const float* __restrict__ b,
                                                                float density_bias, float* __restrict__ raw, float* __restrict__ density) {
   const int m = blockIdx.x * 256 + threadIdx.x;
   if (m >= M) return;
   float acc = 0.f;
-  for (int p = 0; p < P; p += 4) {
-    const float4 v = *(const float4*)(part + (size_t)m * P + p);
-    acc += v.x; acc += v.y; acc += v.z; acc += v.w;
-  }
+  for (int p = 0; p < P; ++p) acc += part[(size_t)p * M + m];
   const float r = acc + b[0];
   raw[m] = r;
   density[m] = softplusf(r + density_bias);
@@ -307,7 +305,7 @@ extern "C" int hugs_density_fwd(int dtype, int M, int K, const void* Y, int ldy,
 
 extern "C" int hugs_density_from_partials(int M, int P, const float* partials, const float* b, float density_bias, float* raw,
                                           float* density, void* stream) {
-  HUGS_REQUIRE(P >= 4 && P % 4 == 0, -3, "hugs_density_from_partials: P=%d must be a positive multiple of 4", P);
+  HUGS_REQUIRE(P >= 1, -3, "hugs_density_from_partials: P=%d", P);
   if (M <= 0) return 0;
   hipLaunchKernelGGL(k_density_from_partials, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, M, P, partials, b, density_bias, raw, density);
   HUGS_CHECK_LAUNCH("hugs_density_from_partials");

@@ -334,7 +334,7 @@ class Engine:
     # [M, W] activation (268 MB at cfg2) for a 1-column output.
     last = spec.net_depth - 1
     fuse_density = bool(_FUSED_DENSITY and bits[last] is not None and not spec.layers[last]['concat'])
-    dparts = ws.get(f'{tag}/dens_parts', (M, W // 64)) if fuse_density else None
+    dparts = ws.get(f'{tag}/dens_parts', (W // 64, M)) if fuse_density else None      # slice-major partials
     for c in range(nchunk):
       rows = slice(c * mc, (c + 1) * mc)
       x = X0[rows]
@@ -346,7 +346,7 @@ class Engine:
         bts = None if bits[i] is None else bits[i][c * (mc * W // 32):(c + 1) * (mc * W // 32)]
         if bts is not None and fuse_density and i == last:
           K = l['kpad']
-          _lib.call('hugs_gemm_nt_bits_dot', dt, mc, W, K, 0, x, K, None, 0, self.wt[path], K, bias, wd, dparts[rows], Y, W, bts)
+          _lib.call('hugs_gemm_nt_bits_dot', dt, mc, W, K, 0, x, K, None, 0, self.wt[path], K, bias, wd, dparts[0, c * mc:], M, Y, W, bts)
         elif bts is not None:
           if l['concat']:
             _lib.call('hugs_gemm_nt_bits', dt, mc, W, W, spec.Fp, x, W, X0[rows], spec.Fp, self.wt[path], l['kpad'], bias, 1, None,

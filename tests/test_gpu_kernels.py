@@ -422,8 +422,8 @@ def test_density_head_fused_into_the_trunk_epilogue(shape):
   L.call('hugs_gemm_nt_bits', 1, M, N, K, 0, A, K, None, 0, Bt, K, bias, 1, None, None, out0, N, bits0, None)
   raw0, den0 = torch.empty(M, device=dev), torch.empty(M, device=dev)
   L.call('hugs_density_fwd', 1, M, N, out0, N, wd, bd, -1.0, raw0, den0)
-  parts = torch.empty(M, N // 64, device=dev)
-  L.call('hugs_gemm_nt_bits_dot', 1, M, N, K, 0, A, K, None, 0, Bt, K, bias, wd, parts, out1, N, bits1)
+  parts = torch.empty(N // 64, M, device=dev)
+  L.call('hugs_gemm_nt_bits_dot', 1, M, N, K, 0, A, K, None, 0, Bt, K, bias, wd, parts, M, out1, N, bits1)
   raw1, den1 = torch.empty(M, device=dev), torch.empty(M, device=dev)
   L.call('hugs_density_from_partials', M, N // 64, parts, bd, -1.0, raw1, den1)
   torch.cuda.synchronize()
@@ -433,4 +433,4 @@ def test_density_head_fused_into_the_trunk_epilogue(shape):
   ref = (out0.double() @ wd.double() + 0.3)
   assert float((raw1.double() - ref).abs().max()) <= 1e-5 * sc
   with pytest.raises(L.HugsError):
-    L.call('hugs_gemm_nt_bits_dot', 1, M, N, K, 0, A, K, None, 0, Bt, K, None, wd, parts, out1, N, bits1)
+    L.call('hugs_gemm_nt_bits_dot', 1, M, N, K, 0, A, K, None, 0, Bt, K, None, wd, parts, M, out1, N, bits1)
