@@ -70,6 +70,9 @@ int hugs_gemm_tn(int dtype, int Mrows, int Kc, int N, int nsplit, const void* X,
 int hugs_density_fwd(int dtype, int M, int K, const void* Y, int ldy, const float* w, const float* b,
                      float density_bias, float* raw, float* density, void* stream);
 long long hugs_density_bwd_ws_bytes(int K);
+/* backward of the two lines above: d_raw = d_density * sigmoid(raw + density_bias); dw = Y^T d_raw, db = sum d_raw.
+ * d_density == NULL: d_raw is an input (an earlier call made it) and only the weight gradient is computed; dw == NULL: only
+ * d_raw -- the two halves may run on different streams. */
 int hugs_density_bwd(int dtype, int M, int K, const void* Y, int ldy, const float* d_density, const float* raw,
                      float density_bias, float* d_raw, float* dw, float* db, void* ws, void* stream);
 /* out[m,n] = r[m]*c[n]*(Y[m,n] > 0): gradient entering the last trunk layer when there is no colour branch */

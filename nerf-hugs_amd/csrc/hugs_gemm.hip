@@ -334,11 +334,7 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
         }
       }
       if (has_bout && (i & 1)) { E.bits_out[bits_at + (i >> 1) * 64] = bw; bw = 0u; }
-      if (has_dot) {        // the four kb lane groups hold the row's four 16-column quarters of this wave's 64 columns
-        dsum += __shfl_xor(dsum, 16);
-        dsum += __shfl_xor(dsum, 32);
-        dacc[i] = dsum;     // (every lane of a row now holds the row's sum)
-      }
+      if (has_dot) dacc[i] = dsum;     // this lane's 16 columns of row i*16 + r16; the four kb lane groups are summed below
       uint32_t vv[2][4];
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp) {
@@ -382,6 +378,16 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
       // the row blocks i = 2 kb and 2 kb + 1 (16 rows = 64 contiguous bytes each): two store instructions per wave and tile
       // instead of eight quarter-empty ones (4-byte pieces of different cache lines made the fused head no faster than the
       // separate pass it replaces).
+      // row sums over the four kb lane groups (lanes l, l^16, l^32, l^48) with the swap instructions -- VALU, no LDS round trip:
+      // permlane16_swap(x, x) = {[r0 r0 r2 r2], [r1 r1 r3 r3]} (16-lane rows), permlane32_swap(t, t) = {[lo lo], [hi hi]}
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t xi = __float_as_uint(dacc[i]);
+        const u32x2_t a = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
+        const uint32_t ti = __float_as_uint(__uint_as_float(a[0]) + __uint_as_float(a[1]));
+        const u32x2_t b = __builtin_amdgcn_permlane32_swap(ti, ti, false, false);
+        dacc[i] = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+      }
       float v0 = dacc[0], v1 = dacc[1];
       if (kb == 1) { v0 = dacc[2]; v1 = dacc[3]; }
       if (kb == 2) { v0 = dacc[4]; v1 = dacc[5]; }

@@ -319,9 +319,15 @@ extern "C" long long hugs_density_bwd_ws_bytes(int K) { return (long long)WCS_BL
 extern "C" int hugs_density_bwd(int dtype, int M, int K, const void* Y, int ldy, const float* d_density, const float* raw,
                                 float density_bias, float* d_raw, float* dw, float* db, void* ws, void* stream) {
   HUGS_REQUIRE(K % 8 == 0 && K <= 2048, -3, "hugs_density_bwd: K=%d unsupported", K);
+  HUGS_REQUIRE(d_raw && (d_density || dw), -2, "hugs_density_bwd: d_raw and at least one of d_density / dw are required");
   if (M <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_density_bwd_raw, dim3((M + 255) / 256), dim3(256), 0, st, M, d_density, raw, density_bias, d_raw);
+  // d_density == null: d_raw is an INPUT (computed by an earlier call); dw == null: only d_raw is wanted.  The two halves can
+  // then run on different streams: d_raw feeds the trunk's input gradient (critical path), the weight gradient is a 268 MB
+  // pass over Y that nothing downstream waits for.
+  if (d_density) hipLaunchKernelGGL(k_density_bwd_raw, dim3((M + 255) / 256), dim3(256), 0, st, M, d_density, raw, density_bias, d_raw);
+  if (!dw) { HUGS_CHECK_LAUNCH("hugs_density_bwd"); return 0; }
+  HUGS_REQUIRE(db && ws, -2, "hugs_density_bwd: db and ws are required with dw");
   const int rpb = (M + WCS_BLOCKS - 1) / WCS_BLOCKS;
   const int nblk = (M + rpb - 1) / rpb;
   float* slab = (float*)ws;

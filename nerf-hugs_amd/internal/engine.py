@@ -537,8 +537,13 @@ class Engine:
     ld = spec.layers[spec.net_depth]
     d_raw = ws.get(tag + '/d_raw', (M,))
     dws = ws.get(tag + '/dens_ws', (max(_lib.lib().cdll.hugs_density_bwd_ws_bytes(W) // 4, 1),))
-    _lib.call('hugs_density_bwd', dt, M, W, Ylast, W, d_density, lv['raw'], spec.density_bias, d_raw,
-              gview((spec.name, ld['name'], 'kernel'), True).reshape(-1), gview((spec.name, ld['name'], 'bias')), dws)
+    if spec.disable_rgb:
+      _lib.call('hugs_density_bwd', dt, M, W, Ylast, W, d_density, lv['raw'], spec.density_bias, d_raw,
+                gview((spec.name, ld['name'], 'kernel'), True).reshape(-1), gview((spec.name, ld['name'], 'bias')), dws)
+    else:
+      # only d_raw here: the density head's weight gradient (a pass over the whole [M, W] activation) goes to the head
+      # weight-gradient stream below instead of sitting in front of rgb_bwd -> dBott -> G_last
+      _lib.call('hugs_density_bwd', dt, M, W, Ylast, W, d_density, lv['raw'], spec.density_bias, d_raw, None, None, None)
     wd = lay.view(theta, (spec.name, ld['name'], 'kernel'), padded=True).reshape(-1)
     Ga = ws.get(tag + '/Ga', (M, W), self.tdt)
     Gb = ws.get(tag + '/Gb', (M, W), self.tdt)
@@ -564,6 +569,8 @@ class Engine:
       ev_gv = torch.cuda.Event(); ev_gv.record(cur)
       with torch.cuda.stream(hl):
         hl.wait_event(ev_gv)
+        _lib.call('hugs_density_bwd', dt, M, W, Ylast, W, None, lv['raw'], spec.density_bias, d_raw,
+                  gview((spec.name, ld['name'], 'kernel'), True).reshape(-1), gview((spec.name, ld['name'], 'bias')), dws)
         _lib.call('hugs_raybias_bwd', dt, N, S, H, spec.nd, spec.num_glo, Gv, H, rays['dir_enc'], lv['glo'], Wv[Bw:],
                   rays.get('embed_idx'), d_rb, gWv[Bw:], demb)
         # dWv[:Bw] = bott^T Gv ; db_v = colsum(Gv)
