@@ -273,16 +273,6 @@ long long hugs_gemm_nt_bits_bytes(int M, int N);
 int hugs_gemm_nt_bits(int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,
                       const void* Bt, int ldb, const float* bias, int relu, const float* r1_row, const float* r1_col,
                       void* out, int ldc, uint32_t* bits_out, const uint32_t* bits_in, void* stream);
-/* hugs_gemm_nt_bits in its forward-trunk form (bias + relu + bits_out) with the density head (models.py:456 raw_density =
- * Dense(1)(x)) fused into the epilogue: dot_out [N/64][dot_ld] (slice-major, dot_ld >= M: the row count of the whole batch
- * when M is a row chunk of it) = per 64-column slice and row sum_n out[m,n] * dot_w[n] (out as stored: after bias, relu, bf16
- * rounding); hugs_density_from_partials (models.py:456,467; partials [P][M]) adds the P = N/64 partials per row in index order
- * + bias and applies softplus(raw + density_bias).  Saves the separate pass over the [M, N] activation. */
-int hugs_gemm_nt_bits_dot(int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,
-                          const void* Bt, int ldb, const float* bias, const float* dot_w, float* dot_out, int dot_ld, void* out,
-                          int ldc, uint32_t* bits_out, void* stream);
-int hugs_density_from_partials(int M, int P, const float* partials, const float* b, float density_bias, float* raw,
-                               float* density, void* stream);
 
 /* ---- nerfacto path (reference /root/reference/nerfacto).  One wavefront per ray in the per-ray
  * kernels (<= 1024 bins / samples).  Matrices [M, ld] row-major in `dtype` (0 fp32, 1 bf16).

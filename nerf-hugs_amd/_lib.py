@@ -17,8 +17,6 @@ _PROTOS = {
     'hugs_gemm_nt': 'iiiii' 'pipipi' 'pp' 'iii' 'pi' 'pp' 'pi' 's',
     'hugs_gemm_nt_bits': 'iiiii' 'pipipi' 'p' 'i' 'pp' 'pi' 'pp' 's',
     'hugs_gemm_tn': 'iiiiipipippps',
-    'hugs_gemm_nt_bits_dot': 'iiiii' 'pipipi' 'pppi' 'pi' 'p' 's',
-    'hugs_density_from_partials': 'iippfpps',
     'hugs_density_fwd': 'iiipippfpps',
     'hugs_density_bwd': 'iiipippfpppps',
     'hugs_rank1_mask': 'iiipppipis',
@@ -104,7 +102,6 @@ def _raw_stream():
 PROFILE = None
 _PROFILED = {'hugs_gemm_nt': lambda a: ('nt', a[1], a[2], a[3] + a[4], 'mask' if a[16] is not None else ('relu' if a[15] else 'plain')),
              'hugs_gemm_nt_bits': lambda a: ('nt', a[1], a[2], a[3] + a[4], 'mask' if a[18] is not None else ('relu' if a[12] else 'plain')),
-             'hugs_gemm_nt_bits_dot': lambda a: ('nt', a[1], a[2], a[3] + a[4], 'relu+dot'),
              'hugs_gemm_tn': lambda a: ('tn', a[1], a[2], a[3], f'split{a[4]}'),
              # nerfacto (bench.py --config cfg5): (kind, samples, levels, features) / (kind, samples, in_dim, hidden)
              'hugs_hashgrid_fwd': lambda a: ('hg_fwd', a[0], a[1], a[2]),

@@ -37,12 +37,6 @@ struct GemmEpi {
   // place of re-reading the bf16 activation: 16 B per lane instead of 256 B).
   uint32_t* bits_out;
   const uint32_t* bits_in;
-  // fused "N = 1" head (the density head behind the last trunk layer, models.py:456): dot_out[n / 64][m] (slice-major) = sum
-  // over the 64 columns n .. n+63 of out[m, n'] * dot_w[n'] (out AFTER bias / relu / bf16 rounding: what a separate pass over
-  // the stored activation would read); the caller sums the N / 64 partials per row (hugs_density_from_partials).  256x256 kernels only.
-  const float* dot_w;
-  float* dot_out;
-  int dot_ld;             // rows between two slices of dot_out (>= M; the caller's whole-batch row count when M is a row chunk)
 };
 
 // Per-phase timestamps / staggered starts for the measurement builds live in scratch/hugs_gemm_trace.h (scratch/build_trace.sh
@@ -214,7 +208,6 @@ typedef unsigned __attribute__((ext_vector_type(2))) u32x2_t;
 #define EPI_R1 8
 #define EPI_BIN 16    // 1-bit relu mask read (GemmEpi.bits_in)
 #define EPI_BOUT 32   // 1-bit relu mask written (GemmEpi.bits_out)
-#define EPI_DOT 64    // per-row partial dot products with GemmEpi.dot_w written to GemmEpi.dot_out
 // Epilogue of the 256x256 NT tile straight from the accumulator registers (wave (wm, wn) owns rows wm*128.. and
 // columns wn*64..; lane (r16, kb) of fragment (i, j) holds row i*16 + r16, columns j*16 + kb*4 .. +3).
 // lds_bias / lds_r1col: optional LDS-resident copies of E.bias / E.r1_col (indexed by absolute column): the persistent
@@ -239,8 +232,7 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {      // one 
 }
 template <int EPI, bool BIAS_IN_ACC = false>
 __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const GemmEpi& E, int m0, int n0, int wm, int wn,
-                                                   int r16, int kb, const float* lds_bias, const float* lds_r1col,
-                                                   const float* lds_dot = nullptr) {
+                                                   int r16, int kb, const float* lds_bias, const float* lds_r1col) {
     // ---- epilogue straight from registers: bias / rank-1 / relu, v_cvt_pk_bf16_f32, one v_permlane16_swap pair
     // per two neighbouring 16-column fragments turns the 8-byte-per-lane MFMA layout into 16 contiguous bytes per
     // lane (64-byte runs per row): no LDS round trip, no barriers.
@@ -256,7 +248,6 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
     const size_t bits_at = (((size_t)(m0 >> 8) * (size_t)(E.ldc >> 8) + (size_t)(n0 >> 8)) * 8 + (size_t)(wm * 4 + wn)) * 256 + (size_t)(threadIdx.x & 63);
     const bool has_bin = GEN ? E.bits_in != nullptr : bool(EPI & EPI_BIN);
     const bool has_bout = GEN ? E.bits_out != nullptr : bool(EPI & EPI_BOUT);
-    const bool has_dot = GEN ? E.dot_w != nullptr : bool(EPI & EPI_DOT);
     uint32_t bin[4] = {0u, 0u, 0u, 0u}, bw = 0u;
     if (has_bin) {
 #pragma unroll
@@ -269,14 +260,6 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
       const int n = n0 + wn * 64 + j * 16 + kb * 4;
       bj[j] = has_bias ? (lds_bias ? *(const float4*)(lds_bias + n) : *(const float4*)(E.bias + n)) : make_float4(0.f, 0.f, 0.f, 0.f);
       cj[j] = has_r1 ? (lds_r1col ? *(const float4*)(lds_r1col + n) : *(const float4*)(E.r1_col + n)) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    float4 dwj[4];
-    if (has_dot) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + kb * 4;
-        dwj[j] = lds_dot ? *(const float4*)(lds_dot + n) : *(const float4*)(E.dot_w + n);
-      }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) r1v[i] = has_r1 ? E.r1_row[m0 + wm * 128 + i * 16 + r16] : 0.f;
@@ -298,7 +281,6 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
         mkv[i][h] = *(const uint4*)((const uint16_t*)E.mask + (size_t)(m0 + wm * 128 + i * 16 + h * 8 + srow) * E.ld_mask + ccol);
     };
     if (has_mask) { mask_load(0); mask_load(1); }
-    float dacc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       if (has_mask && i + 2 < 8) mask_load(i + 2);
@@ -306,7 +288,6 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
       const float r1 = r1v[i];
       const float* rbp = has_rowb ? E.row_bias + (size_t)(m / E.row_div) * E.ld_rb + n0 + wn * 64 + kb * 4 : nullptr;
       uint32_t pk[4][2];
-      float dsum = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float x[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
@@ -323,10 +304,6 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
           u.y &= ((t >> 1) & 0x00010001u) * 0xffffu;
         }
         pk[j][0] = u.x; pk[j][1] = u.y;
-        if (has_dot) {      // the values as stored (bf16, after relu / mask): high halves are the odd columns
-          dsum += __uint_as_float(u.x << 16) * dwj[j].x + __uint_as_float(u.x & 0xffff0000u) * dwj[j].y +
-                  __uint_as_float(u.y << 16) * dwj[j].z + __uint_as_float(u.y & 0xffff0000u) * dwj[j].w;
-        }
         if (has_bout) {     // value > 0 <=> half != 0 once the relu cleared the negatives: half + 0x7fff carries into bit 15
           const uint32_t ax = has_relu ? u.x : (u.x & 0x7fff7fffu), ay = has_relu ? u.y : (u.y & 0x7fff7fffu);
           bw |= ((ax + 0x7fff7fffu) >> (15 - k)) & (0x00010001u << k);
@@ -334,7 +311,6 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
         }
       }
       if (has_bout && (i & 1)) { E.bits_out[bits_at + (i >> 1) * 64] = bw; bw = 0u; }
-      if (has_dot) dacc[i] = dsum;     // this lane's 16 columns of row i*16 + r16; the four kb lane groups are summed below
       uint32_t vv[2][4];
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp) {
@@ -372,29 +348,6 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
           HUGS_EPI_STORE(v_, p_);
         }
       }
-    }
-    if (has_dot) {
-      // dot_out is slice-major, [N / 64][M]: this wave's 128 rows of its slice are 512 contiguous bytes.  Lane group kb writes
-      // the row blocks i = 2 kb and 2 kb + 1 (16 rows = 64 contiguous bytes each): two store instructions per wave and tile
-      // instead of eight quarter-empty ones (4-byte pieces of different cache lines made the fused head no faster than the
-      // separate pass it replaces).
-      // row sums over the four kb lane groups (lanes l, l^16, l^32, l^48) with the swap instructions -- VALU, no LDS round trip:
-      // permlane16_swap(x, x) = {[r0 r0 r2 r2], [r1 r1 r3 r3]} (16-lane rows), permlane32_swap(t, t) = {[lo lo], [hi hi]}
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const uint32_t xi = __float_as_uint(dacc[i]);
-        const u32x2_t a = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
-        const uint32_t ti = __float_as_uint(__uint_as_float(a[0]) + __uint_as_float(a[1]));
-        const u32x2_t b = __builtin_amdgcn_permlane32_swap(ti, ti, false, false);
-        dacc[i] = __uint_as_float(b[0]) + __uint_as_float(b[1]);
-      }
-      float v0 = dacc[0], v1 = dacc[1];
-      if (kb == 1) { v0 = dacc[2]; v1 = dacc[3]; }
-      if (kb == 2) { v0 = dacc[4]; v1 = dacc[5]; }
-      if (kb == 3) { v0 = dacc[6]; v1 = dacc[7]; }
-      float* dp = E.dot_out + (size_t)((n0 >> 6) + wn) * (size_t)E.dot_ld + (size_t)(m0 + wm * 128 + kb * 32 + r16);
-      dp[0] = v0;
-      dp[16] = v1;
     }
 }
 
@@ -605,8 +558,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
     const bool has_r1 = EPI < 0 ? E.r1_row != nullptr : bool(EPI & EPI_R1);
     if (has_bias) for (int n = tid * 4; n < N; n += 2048) *(float4*)(lds_bias + n) = *(const float4*)(E.bias + n);
     if (has_r1) for (int n = tid * 4; n < N; n += 2048) *(float4*)(lds_r1 + n) = *(const float4*)(E.r1_col + n);
-    // (the rank-1 column and the fused head's weight vector are never asked for together: they share the slot)
-    if (EPI >= 0 && (EPI & EPI_DOT)) for (int n = tid * 4; n < N; n += 2048) *(float4*)(lds_r1 + n) = *(const float4*)(E.dot_w + n);
   }
 
   // ---- loader state (wave-uniform, SGPRs): tile being fetched, stage within it, ring slot ----
@@ -759,17 +710,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
     HUGS_TRP(i, 0)
-    // the previous tile's 16 stores (+ 4 mask-bit words, + 2 head-partial stores) are in the queue behind the two younger stages
-    if (EPI >= 0 && (EPI & EPI_BOUT) && (EPI & EPI_DOT)) { GP_ITER(f0, f1, 30) GP_ITER(f1, f0, 30) GP_ITER(f0, f1, 30) }
-    else if (EPI >= 0 && (EPI & EPI_BOUT)) { GP_ITER(f0, f1, 28) GP_ITER(f1, f0, 28) GP_ITER(f0, f1, 28) }
+    // the previous tile's 16 stores (+ 4 mask-bit words) are in the queue behind the two younger stages
+    if (EPI >= 0 && (EPI & EPI_BOUT)) { GP_ITER(f0, f1, 28) GP_ITER(f1, f0, 28) GP_ITER(f0, f1, 28) }
     else { GP_ITER(f0, f1, 24) GP_ITER(f1, f0, 24) GP_ITER(f0, f1, 24) }
     GP_ITER(f1, f0, 8)
     HUGS_TRP(i, 1)
 #pragma unroll 1
     for (int st = 4; st < ns; st += 2) { GP_ITERQ(f0, f1, 8) GP_ITERQ(f1, f0, 8) }
     HUGS_TRP(i, 2)
-    nt_epilogue_direct<EPI, (EPI >= 0 && (EPI & EPI_BIAS) != 0)>(acc, E, m0, n0, wm, wn, r16, kb, lds_bias, lds_r1,
-                                                                 (EPI >= 0 && (EPI & EPI_DOT)) ? lds_r1 : nullptr);
+    nt_epilogue_direct<EPI, (EPI >= 0 && (EPI & EPI_BIAS) != 0)>(acc, E, m0, n0, wm, wn, r16, kb, lds_bias, lds_r1);
     HUGS_TRP(i, 3)
   }
 #undef GP_ITER
@@ -1297,8 +1246,7 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ s
 static int gemm_nt_impl(int tile_mode, int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,
                         const void* Bt, int ldb, const float* bias, const float* row_bias, int row_div, int ld_rb,
                         int relu, const void* mask, int ld_mask, const float* r1_row, const float* r1_col,
-                        void* out, int ldc, uint32_t* bits_out, const uint32_t* bits_in, void* stream,
-                        const float* dot_w = nullptr, float* dot_out = nullptr, int dot_ld = 0);
+                        void* out, int ldc, uint32_t* bits_out, const uint32_t* bits_in, void* stream);
 
 extern "C" int hugs_gemm_nt(int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,
                             const void* Bt, int ldb, const float* bias, const float* row_bias, int row_div, int ld_rb,
@@ -1330,26 +1278,10 @@ extern "C" int hugs_gemm_nt_bits(int dtype, int M, int N, int K1, int K2, const 
                       r1_row, r1_col, out, ldc, bits_out, bits_in, stream);
 }
 
-// hugs_gemm_nt_bits with the density head fused into the epilogue (models.py:456 raw_density = Dense(1)(x) on the last trunk
-// layer's output): dot_out[N/64][dot_ld >= M] (slice-major) receives, per 64-column slice and row, sum_n out[m, n] * dot_w[n] over
-// the slice (out as stored: after bias, relu and bf16 rounding); hugs_density_from_partials adds the N/64 partials in a fixed order.
-// Needs the relu + bits_out form (the forward trunk layer) -- -3 otherwise.
-extern "C" int hugs_gemm_nt_bits_dot(int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,
-                                     const void* Bt, int ldb, const float* bias, const float* dot_w, float* dot_out, int dot_ld, void* out,
-                                     int ldc, uint32_t* bits_out, void* stream) {
-  HUGS_REQUIRE(dtype == 1 && M % 256 == 0 && N % 256 == 0 && ldc == N && (K1 + K2) % 64 == 0 && K1 + K2 >= 256, -3,
-               "hugs_gemm_nt_bits_dot: needs bf16, M=%d N=%d multiples of 256, ldc == N, K=%d a multiple of 64 and >= 256", M, N, K1 + K2);
-  HUGS_REQUIRE(bias && dot_w && dot_out && bits_out && dot_ld >= M, -3,
-               "hugs_gemm_nt_bits_dot: bias, dot_w, dot_out and bits_out are all required, dot_ld (%d) >= M (%d)", dot_ld, M);
-  return gemm_nt_impl(0, dtype, M, N, K1, K2, A1, lda1, A2, lda2, Bt, ldb, bias, nullptr, 1, 0, 1, nullptr, 0, nullptr, nullptr, out, ldc,
-                      bits_out, nullptr, stream, dot_w, dot_out, dot_ld);
-}
-
 static int gemm_nt_impl(int tile_mode, int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2,
                         int lda2, const void* Bt, int ldb, const float* bias, const float* row_bias, int row_div, int ld_rb,
                         int relu, const void* mask, int ld_mask, const float* r1_row, const float* r1_col,
-                        void* out, int ldc, uint32_t* bits_out, const uint32_t* bits_in, void* stream,
-                        const float* dot_w, float* dot_out, int dot_ld) {
+                        void* out, int ldc, uint32_t* bits_out, const uint32_t* bits_in, void* stream) {
   HUGS_REQUIRE(dtype == 0 || dtype == 1, -2, "hugs_gemm_nt: dtype must be 0 (fp32) or 1 (bf16)");
   const int bk = dtype ? GB_BK : GF_BK;
   HUGS_REQUIRE(M % 128 == 0 && N % 128 == 0 && K1 % bk == 0 && K2 % bk == 0 && K1 > 0, -3,
@@ -1359,14 +1291,14 @@ static int gemm_nt_impl(int tile_mode, int dtype, int M, int N, int K1, int K2, 
   const bool bits = bits_out || bits_in;
   HUGS_REQUIRE(!bits || (tile_mode != 1 && tile_mode != 3), -3, "hugs_gemm_nt_bits: needs the 256x256 kernels (tile_mode 0 or 5)");
   if (bits_in) mask = nullptr;       // (the EPI_MASK specialisation is selected through `epi_mask` below)
-  GemmEpi E{bias, row_bias, row_div, ld_rb, relu, mask, ld_mask, r1_row, r1_col, out, ldc, bits_out, bits_in, dot_w, dot_out, dot_ld};
+  GemmEpi E{bias, row_bias, row_div, ld_rb, relu, mask, ld_mask, r1_row, r1_col, out, ldc, bits_out, bits_in};
   const int grid = (M / 128) * (N / 128);
   // (four K-stages of 32 are the shortest pipeline the ring kernels run: K >= 128)
   if (dtype && M % 256 == 0 && N % 256 == 0 && (K1 + K2) % 64 == 0 && K1 + K2 >= 128 && tile_mode != 1 && tile_mode != 3)
   {
     // epilogue specialisations for the combinations the trunks use (bit set = term present); anything else -> generic
     const int epi = row_bias ? -1 : (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0) | (mask ? EPI_MASK : 0) | (r1_row ? EPI_R1 : 0) |
-                                    (bits_in ? EPI_BIN : 0) | (bits_out ? EPI_BOUT : 0) | (dot_w ? EPI_DOT : 0);
+                                    (bits_in ? EPI_BIN : 0) | (bits_out ? EPI_BOUT : 0);
     const int ntiles = (M / 256) * (N / 256), nstage = (K1 + K2) / 32;
     static int ncu = 0;
     if (!ncu) {
@@ -1385,7 +1317,6 @@ static int gemm_nt_impl(int tile_mode, int dtype, int M, int N, int K1, int K2, 
       switch (epi) {
         case EPI_BIAS | EPI_RELU: HUGS_NTP_LAUNCH(EPI_BIAS | EPI_RELU); break;
         case EPI_BIAS | EPI_RELU | EPI_BOUT: HUGS_NTP_LAUNCH(EPI_BIAS | EPI_RELU | EPI_BOUT); break;   // forward trunk, mask bits out
-        case EPI_BIAS | EPI_RELU | EPI_BOUT | EPI_DOT: HUGS_NTP_LAUNCH(EPI_BIAS | EPI_RELU | EPI_BOUT | EPI_DOT); break;   // last trunk layer + density head
         case EPI_BIN: HUGS_NTP_LAUNCH(EPI_BIN); break;                                                 // dX, mask bits in
         case EPI_BIN | EPI_R1: HUGS_NTP_LAUNCH(EPI_BIN | EPI_R1); break;                               // G of the last trunk layer
         case EPI_BIAS: HUGS_NTP_LAUNCH(EPI_BIAS); break;
@@ -1404,7 +1335,6 @@ static int gemm_nt_impl(int tile_mode, int dtype, int M, int N, int K1, int K2, 
     switch (epi) {
       case EPI_BIAS | EPI_RELU: HUGS_NT_LAUNCH(EPI_BIAS | EPI_RELU); break;   // forward trunk layer
       case EPI_BIAS | EPI_RELU | EPI_BOUT: HUGS_NT_LAUNCH(EPI_BIAS | EPI_RELU | EPI_BOUT); break;
-      case EPI_BIAS | EPI_RELU | EPI_BOUT | EPI_DOT: HUGS_NT_LAUNCH(EPI_BIAS | EPI_RELU | EPI_BOUT | EPI_DOT); break;
       case EPI_BIN: HUGS_NT_LAUNCH(EPI_BIN); break;
       case EPI_BIN | EPI_R1: HUGS_NT_LAUNCH(EPI_BIN | EPI_R1); break;
       case EPI_BIAS: HUGS_NT_LAUNCH(EPI_BIAS); break;                          // bottleneck

@@ -65,20 +65,6 @@ __global__ __launch_bounds__(256) void k_density_fwd(int M, int K, const void* _
   }
 }
 
-// density head from the partial dot products the last trunk layer's GEMM epilogue left (hugs_gemm_nt_bits_dot, slice-major
-// part[p][m]): raw[m] = b + sum_p part[p][m] in index order (deterministic), density = softplus(raw + density_bias).
-// P = N / 64 (16 at width 1024).
-__global__ __launch_bounds__(256) void k_density_from_partials(int M, int P, const float* __restrict__ part, const float* __restrict__ b,
-                                                               float density_bias, float* __restrict__ raw, float* __restrict__ density) {
-  const int m = blockIdx.x * 256 + threadIdx.x;
-  if (m >= M) return;
-  float acc = 0.f;
-  for (int p = 0; p < P; ++p) acc += part[(size_t)p * M + m];
-  const float r = acc + b[0];
-  raw[m] = r;
-  density[m] = softplusf(r + density_bias);
-}
-
 // d_raw[m] = d_density[m] * sigmoid(raw[m] + density_bias)
 __global__ void k_density_bwd_raw(int M, const float* __restrict__ d_density, const float* __restrict__ raw,
                                   float density_bias, float* __restrict__ d_raw) {
@@ -300,15 +286,6 @@ extern "C" int hugs_density_fwd(int dtype, int M, int K, const void* Y, int ldy,
   if (dtype) hipLaunchKernelGGL(k_density_fwd<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, K, Y, ldy, w, b, density_bias, raw, density);
   else hipLaunchKernelGGL(k_density_fwd<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, K, Y, ldy, w, b, density_bias, raw, density);
   HUGS_CHECK_LAUNCH("hugs_density_fwd");
-  return 0;
-}
-
-extern "C" int hugs_density_from_partials(int M, int P, const float* partials, const float* b, float density_bias, float* raw,
-                                          float* density, void* stream) {
-  HUGS_REQUIRE(P >= 1, -3, "hugs_density_from_partials: P=%d", P);
-  if (M <= 0) return 0;
-  hipLaunchKernelGGL(k_density_from_partials, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, M, P, partials, b, density_bias, raw, density);
-  HUGS_CHECK_LAUNCH("hugs_density_from_partials");
   return 0;
 }
 

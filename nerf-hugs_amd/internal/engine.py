@@ -13,7 +13,6 @@ from . import stepfun
 
 CHUNK = 16384
 _USE_BITS = __import__('os').environ.get('HUGS_RELU_BITS', '1') != '0'        # A/B knob: 1-bit relu masks for the dX GEMMs
-_FUSED_DENSITY = __import__('os').environ.get('HUGS_FUSED_DENSITY', '1') != '0'    # A/B knob: density head in the last trunk layer's epilogue
 _CHUNK_BYTES = int(float(__import__('os').environ.get('HUGS_FWD_CHUNK_MB', '1e9')) * 1e6)   # forward row-chunk size (A/B knob)
 
 
@@ -329,12 +328,6 @@ class Engine:
     mc = M // nchunk
     ld = spec.layers[spec.net_depth]
     wd = lay.view(theta, (spec.name, ld['name'], 'kernel'), padded=True).reshape(-1)
-    # The density head (Dense(1) on the last trunk layer's output, models.py:456) rides in that layer's GEMM epilogue as
-    # per-row partial dot products over 64-column slices (hugs_gemm_nt_bits_dot): the separate pass re-read the whole
-    # [M, W] activation (268 MB at cfg2) for a 1-column output.
-    last = spec.net_depth - 1
-    fuse_density = bool(_FUSED_DENSITY and bits[last] is not None and not spec.layers[last]['concat'])
-    dparts = ws.get(f'{tag}/dens_parts', (W // 64, M)) if fuse_density else None      # slice-major partials
     for c in range(nchunk):
       rows = slice(c * mc, (c + 1) * mc)
       x = X0[rows]
@@ -344,10 +337,7 @@ class Engine:
         bias = lay.view(theta, (spec.name, l['name'], 'bias'), padded=True)
         Y = Ys[i][rows]
         bts = None if bits[i] is None else bits[i][c * (mc * W // 32):(c + 1) * (mc * W // 32)]
-        if bts is not None and fuse_density and i == last:
-          K = l['kpad']
-          _lib.call('hugs_gemm_nt_bits_dot', dt, mc, W, K, 0, x, K, None, 0, self.wt[path], K, bias, wd, dparts[0, c * mc:], M, Y, W, bts)
-        elif bts is not None:
+        if bts is not None:
           if l['concat']:
             _lib.call('hugs_gemm_nt_bits', dt, mc, W, W, spec.Fp, x, W, X0[rows], spec.Fp, self.wt[path], l['kpad'], bias, 1, None,
                       None, Y, W, bts, None)
@@ -367,10 +357,7 @@ class Engine:
     raw = ws.get(tag + '/raw', (M,))
     density = ws.get(tag + '/density', (M,))
     bd = lay.view(theta, (spec.name, ld['name'], 'bias'))
-    if fuse_density:
-      _lib.call('hugs_density_from_partials', M, W // 64, dparts, bd, spec.density_bias, raw, density)
-    else:
-      _lib.call('hugs_density_fwd', dt, M, W, x, W, wd, bd, spec.density_bias, raw, density)
+    _lib.call('hugs_density_fwd', dt, M, W, x, W, wd, bd, spec.density_bias, raw, density)
     out = dict(X0=X0, acts=acts, raw=raw, density=density, rgb=None, bits=bits if nchunk == 1 else [None] * len(bits))
     if not spec.disable_rgb:
       lb, lv, lr = spec.layers[spec.net_depth + 1:spec.net_depth + 4]

@@ -19,7 +19,6 @@ out = {
   "nt_fwd_nobits": dict(hbm(find('pers<3>')), kernel='k_gemm_nt_bf16_pers<3>'),
   "nt_dx_bf16mask": dict(hbm(find('pers<4>')), kernel='k_gemm_nt_bf16_pers<4>'),
   "tn_dw": dict(hbm(find('k_gemm_tn_bf16_big'), [red]), kernel='k_gemm_tn_bf16_big + 2 x k_slab_reduce'),
-  "nt_fwd_dot": dict(hbm(find('pers<99>')), kernel='k_gemm_nt_bf16_pers<99> (last trunk layer + fused density head)'),
   "_source": "scratch/pmc_run2.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 4 launches each, trunk shape "
              "M=131072 N=K=1024); HBM bytes = 2 x FETCH_SIZE(KB) x 1024 (gfx950 64-B request correction, MI355X_MICROARCH.md) "
              "+ WRITE_SIZE(KB) x 1024",

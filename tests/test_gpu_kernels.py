@@ -402,35 +402,3 @@ def test_gemm_ring_kernels_over_stage_counts(shape):
   L.call('hugs_gemm_nt', 1, M, N, K1, K2, A1, K1, A2, K2, Bt, K1 + K2, None, None, 1, 0, 0, mk, N, None, None, out, N)
   ref = (A.double() @ Bt.double().T) * (mk.double() > 0)
   assert float((out.double() - ref).abs().max()) < 2e-2 * max(1.0, float(ref.abs().max()))
-
-
-@pytest.mark.parametrize('shape', [(512, 256, 256), (131072, 1024, 1024), (1024, 512, 320)])
-def test_density_head_fused_into_the_trunk_epilogue(shape):
-  """hugs_gemm_nt_bits_dot + hugs_density_from_partials (the density head of models.py:456,467 riding in the last trunk
-  layer's GEMM epilogue; persistent and one-tile-per-workgroup kernels) against the separate pass over the stored
-  activation (hugs_density_fwd): same bf16 inputs, fp32 sums in a different order -> 1e-5; the layer output and the
-  relu-mask bits are bit-identical to the unfused launch."""
-  L = _L()
-  M, N, K = shape
-  g = torch.Generator(device=dev).manual_seed(M + N)
-  A = torch.randn(M, K, generator=g, device=dev).bfloat16(); Bt = (torch.randn(N, K, generator=g, device=dev) / K**0.5).bfloat16()
-  bias = torch.randn(N, generator=g, device=dev) * 0.1
-  wd = torch.randn(N, generator=g, device=dev) / N**0.5; bd = torch.tensor([0.3], device=dev)
-  nb = L.lib().cdll.hugs_gemm_nt_bits_bytes(M, N) // 4
-  out0, out1 = (torch.empty(M, N, device=dev, dtype=torch.bfloat16) for _ in range(2))
-  bits0, bits1 = (torch.empty(nb, device=dev, dtype=torch.int32) for _ in range(2))
-  L.call('hugs_gemm_nt_bits', 1, M, N, K, 0, A, K, None, 0, Bt, K, bias, 1, None, None, out0, N, bits0, None)
-  raw0, den0 = torch.empty(M, device=dev), torch.empty(M, device=dev)
-  L.call('hugs_density_fwd', 1, M, N, out0, N, wd, bd, -1.0, raw0, den0)
-  parts = torch.empty(N // 64, M, device=dev)
-  L.call('hugs_gemm_nt_bits_dot', 1, M, N, K, 0, A, K, None, 0, Bt, K, bias, wd, parts, M, out1, N, bits1)
-  raw1, den1 = torch.empty(M, device=dev), torch.empty(M, device=dev)
-  L.call('hugs_density_from_partials', M, N // 64, parts, bd, -1.0, raw1, den1)
-  torch.cuda.synchronize()
-  assert torch.equal(out0, out1) and torch.equal(bits0, bits1)
-  sc = float(raw0.abs().max())
-  assert float((raw1 - raw0).abs().max()) <= 1e-5 * sc and float((den1 - den0).abs().max()) <= 1e-5 * max(1.0, float(den0.max()))
-  ref = (out0.double() @ wd.double() + 0.3)
-  assert float((raw1.double() - ref).abs().max()) <= 1e-5 * sc
-  with pytest.raises(L.HugsError):
-    L.call('hugs_gemm_nt_bits_dot', 1, M, N, K, 0, A, K, None, 0, Bt, K, None, wd, parts, M, out1, N, bits1)
