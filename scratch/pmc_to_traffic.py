@@ -11,7 +11,7 @@ def hbm(e, extra=()):
   rd = 2 * e['FETCH_SIZE'] * 1024 + sum(2 * x['FETCH_SIZE'] * 1024 * x.get('per', 1) for x in extra)
   wr = e['WRITE_SIZE'] * 1024 + sum(x['WRITE_SIZE'] * 1024 * x.get('per', 1) for x in extra)
   return {"hbm_bytes_per_launch": rd + wr, "read": rd, "write": wr, "avg_us_profiled": round(e.get('avg_us_profiled', float('nan')), 1),
-          "mfma_busy_frac": round(e['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * 256 * e['GRBM_GUI_ACTIVE']), 4) if 'GRBM_GUI_ACTIVE' in e else None}
+          "mfma_busy_frac": round(e['SQ_VALU_MFMA_BUSY_CYCLES'] / (e['GRBM_GUI_ACTIVE'] / 8 * 1024)     # GRBM_GUI_ACTIVE sums the 8 XCDs; 1024 SIMDs, 4) if 'GRBM_GUI_ACTIVE' in e else None}
 red = dict(find('k_slab_reduce'), per=2)      # a TN call = the GEMM + two slab reductions (weights, bias)
 out = {
   "nt_fwd": dict(hbm(find('pers<35>')), kernel='k_gemm_nt_bf16_pers<35>'),
