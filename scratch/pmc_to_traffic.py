@@ -11,7 +11,7 @@ def hbm(e, extra=()):
   rd = 2 * e['FETCH_SIZE'] * 1024 + sum(2 * x['FETCH_SIZE'] * 1024 * x.get('per', 1) for x in extra)
   wr = e['WRITE_SIZE'] * 1024 + sum(x['WRITE_SIZE'] * 1024 * x.get('per', 1) for x in extra)
   return {"hbm_bytes_per_launch": rd + wr, "read": rd, "write": wr, "avg_us_profiled": round(e.get('avg_us_profiled', float('nan')), 1),
-          "mfma_busy_frac": round(e['SQ_VALU_MFMA_BUSY_CYCLES'] / (e['GRBM_GUI_ACTIVE'] / 8 * 1024)     # GRBM_GUI_ACTIVE sums the 8 XCDs; 1024 SIMDs, 4) if 'GRBM_GUI_ACTIVE' in e else None}
+          "mfma_busy_frac": round(e['SQ_VALU_MFMA_BUSY_CYCLES'] / (e['GRBM_GUI_ACTIVE'] / 8 * 1024), 4) if 'GRBM_GUI_ACTIVE' in e else None}
 red = dict(find('k_slab_reduce'), per=2)      # a TN call = the GEMM + two slab reductions (weights, bias)
 out = {
   "nt_fwd": dict(hbm(find('pers<35>')), kernel='k_gemm_nt_bf16_pers<35>'),
@@ -19,6 +19,7 @@ out = {
   "nt_fwd_nobits": dict(hbm(find('pers<3>')), kernel='k_gemm_nt_bf16_pers<3>'),
   "nt_dx_bf16mask": dict(hbm(find('pers<4>')), kernel='k_gemm_nt_bf16_pers<4>'),
   "tn_dw": dict(hbm(find('k_gemm_tn_bf16_big'), [red]), kernel='k_gemm_tn_bf16_big + 2 x k_slab_reduce'),
+  "_mfma_busy": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)",
   "_source": "scratch/pmc_run2.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 4 launches each, trunk shape "
              "M=131072 N=K=1024); HBM bytes = 2 x FETCH_SIZE(KB) x 1024 (gfx950 64-B request correction, MI355X_MICROARCH.md) "
              "+ WRITE_SIZE(KB) x 1024",
