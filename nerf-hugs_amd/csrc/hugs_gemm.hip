@@ -912,7 +912,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers5(
   HUGS_STAGGER()
   // this lane's 16 bias values of the NEXT tile (the accumulators start from them): loaded in front of the extra stage and
   // the epilogue's stores, so that their wait at the tile start never includes a store acknowledgement
-  float4 bv[4];
+  // The loads are inline asm and so is their wait: a load the compiler knows about that is consumed across the tile loop's back
+  // edge gets `s_waitcnt vmcnt(0)` from it at the loop head -- every store of the previous tile acknowledged at every tile start,
+  // the very stall this kernel exists to avoid.  bv is written by the asm loads and "modified" by the asm wait (the dependency
+  // that keeps every use behind the wait); nothing may touch those registers in between (checked in the ISA: no spill, no copy).
+  f32x4_t bv[4];
   auto load_bias = [&](int bid_) {
     if constexpr (HAS_BIAS) {
       const int t = xcd_remap(bid_ < ntiles ? bid_ : (int)blockIdx.x, ntiles);
@@ -922,15 +926,18 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers5(
       int ln_ = threadIdx.x;
       asm volatile("" : "+v"(ln_));
       const float* bp = E.bias + nn + wn * 64;       // wave-uniform
-      const int ko = ((ln_ >> 4) & 3) * 4;
-#pragma unroll
-      for (int b = 0; b < 4; ++b) bv[b] = *(const float4*)(bp + b * 16 + ko);
+      const unsigned ko = (unsigned)((ln_ >> 4) & 3) * 16u;      // bytes
+      asm volatile("global_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:64\n\t"
+                   "global_load_dwordx4 %2, %4, %5 offset:128\n\tglobal_load_dwordx4 %3, %4, %5 offset:192"
+                   : "=&v"(bv[0]), "=&v"(bv[1]), "=&v"(bv[2]), "=&v"(bv[3]) : "v"(ko), "s"(bp) : "memory");
     }
   };
+#define GP_BIAS_WAIT(VM) asm volatile("s_waitcnt vmcnt(" #VM ")" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]) :: "memory")
   load_bias(blockIdx.x);
 #pragma unroll
   for (int q = 0; q < NSLOT; ++q) issue();
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if constexpr (HAS_BIAS) GP_BIAS_WAIT(0);
   __syncthreads();
   int c_bid = blockIdx.x;
   for (int i = 0; i < nmine; ++i, c_bid += G) {
@@ -941,7 +948,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers5(
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int a = 0; a < 8; ++a) acc[a][b] = f32x4_t{bv[b].x, bv[b].y, bv[b].z, bv[b].w};
+        for (int a = 0; a < 8; ++a) acc[a][b] = bv[b];
     } else {
 #pragma unroll
       for (int a = 0; a < 8; ++a)
@@ -967,8 +974,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers5(
     asm volatile("" ::: "memory");
     issue();
     nt_epilogue_direct<EPI, HAS_BIAS, true>(acc, E, m0, n0, wm, wn, r16, kb, nullptr, nullptr);
+    // the bias loads are older than stage 4 of the next tile (4 DMAs) and the S_ stores: they have landed once at most 4 + S_
+    // operations are outstanding -- no store needs to be acknowledged for that
+    if constexpr (HAS_BIAS) { if constexpr (S_ == 20) GP_BIAS_WAIT(24); else GP_BIAS_WAIT(20); }
     HUGS_TRP(i, 3)
   }
+#undef GP_BIAS_WAIT
 #undef GP_ITER_NI
 #undef GP_ITERQ_LAST
 #undef GP_ITER
