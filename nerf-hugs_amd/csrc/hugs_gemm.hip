@@ -715,14 +715,26 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
     }
     HUGS_TRP(i, 0)
     // the previous tile's 16 stores (+ 4 mask-bit words) are in the queue behind the two younger stages
+    // (round 3: the quartered form for these four iterations too.  Issued back to back, the four DMAs of a stage cost ~0.7k
+    // cycles more per iteration -- scratch/ntp_trace.py: 2.1-2.2k against 1.4k -- which was most of what looked like a
+    // store-acknowledgement stall at the tile boundary; a five-slot ring that requests stage 4 ahead of the stores removed
+    // only ~0.5k of it)
+#ifndef HUGS_NT_FIRST_UNQUARTERED
+    // (iteration 0 keeps the unfenced form: the bias is still live as the first MFMAs' C operand there, and the fenced quarters
+    // leave the compiler no order in which 16 bias + 96 fragment + 128 accumulator registers fit)
+    if (EPI >= 0 && (EPI & EPI_BOUT)) { GP_ITER(f0, f1, 28) GP_ITERQ(f1, f0, 28) GP_ITERQ(f0, f1, 28) }
+    else { GP_ITER(f0, f1, 24) GP_ITERQ(f1, f0, 24) GP_ITERQ(f0, f1, 24) }
+    GP_ITERQ(f1, f0, 8)
+#else
     if (EPI >= 0 && (EPI & EPI_BOUT)) { GP_ITER(f0, f1, 28) GP_ITER(f1, f0, 28) GP_ITER(f0, f1, 28) }
     else { GP_ITER(f0, f1, 24) GP_ITER(f1, f0, 24) GP_ITER(f0, f1, 24) }
     GP_ITER(f1, f0, 8)
+#endif
     HUGS_TRP(i, 1)
 #pragma unroll 1
     for (int st = 4; st < ns; st += 2) { GP_ITERQ(f0, f1, 8) GP_ITERQ(f1, f0, 8) }
     HUGS_TRP(i, 2)
-    nt_epilogue_direct<EPI, (EPI >= 0 && (EPI & EPI_BIAS) != 0)>(acc, E, m0, n0, wm, wn, r16, kb, lds_bias, lds_r1);
+    nt_epilogue_direct<EPI, (EPI >= 0 && (EPI & EPI_BIAS) != 0), true>(acc, E, m0, n0, wm, wn, r16, kb, lds_bias, lds_r1);
     HUGS_TRP(i, 3)
   }
 #undef GP_ITER
@@ -889,12 +901,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers5(
     asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");                     \
     __builtin_amdgcn_s_barrier();                                                         \
     asm volatile("" ::: "memory");                                                        \
-    load_frags(nxt);                                                                      \
-    mfmas(cur);                                                                           \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                    \
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                  \
-      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                                  \
-    }                                                                                     \
+    mfma_piece(cur, 0); mfma_piece(cur, 1); mfma_piece(cur, 2); mfma_piece(cur, 3);       \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    load_frags(nxt);       /* behind the MFMAs: with the 16 bias registers (their C operands) still live there is */ \
+    __builtin_amdgcn_sched_barrier(0);   /* no room for a second fragment set next to the accumulators being born */ \
   }
   // last iteration of a tile: no fragment prefetch (the next tile reads its first fragments itself, under the accumulator
   // initialisation): the epilogue then runs with 96 dead fragment registers instead of 48
@@ -961,9 +971,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers5(
     // wait for stage g+1 may leave everything younger outstanding: iteration 3 (stage 4) no longer needs one store to be
     // acknowledged -- the first wait that does is iteration 4's, 5.7k cycles after the last store instead of 4.3k.
     constexpr int S_ = 16 + ((EPI & EPI_BOUT) ? 4 : 0), B_ = HAS_BIAS ? 4 : 0;
-    if constexpr (S_ == 20 && B_ == 4) { GP_ITER_NI(f0, f1, 36) GP_ITER(f1, f0, 32) GP_ITER(f0, f1, 32) GP_ITER(f1, f0, 28) }
-    else if constexpr (S_ == 16 && B_ == 4) { GP_ITER_NI(f0, f1, 32) GP_ITER(f1, f0, 28) GP_ITER(f0, f1, 28) GP_ITER(f1, f0, 24) }
-    else { GP_ITER_NI(f0, f1, 28) GP_ITER(f1, f0, 24) GP_ITER(f0, f1, 24) GP_ITER(f1, f0, 24) }
+    // (the quartered form for these iterations too: issued back to back, the four DMAs of a stage cost ~0.7k cycles more per
+    // iteration -- scratch/ntp_trace.py: 2.1k against 1.4k)
+    if constexpr (S_ == 20 && B_ == 4) { GP_ITER_NI(f0, f1, 36) GP_ITERQ(f1, f0, 32) GP_ITERQ(f0, f1, 32) GP_ITERQ(f1, f0, 28) }
+    else if constexpr (S_ == 16 && B_ == 4) { GP_ITER_NI(f0, f1, 32) GP_ITERQ(f1, f0, 28) GP_ITERQ(f0, f1, 28) GP_ITERQ(f1, f0, 24) }
+    else { GP_ITER_NI(f0, f1, 28) GP_ITERQ(f1, f0, 24) GP_ITERQ(f0, f1, 24) GP_ITERQ(f1, f0, 24) }
     HUGS_TRP(i, 1)
 #pragma unroll 1
     for (int st = 4; st < ns - 2; st += 2) { GP_ITERQ(f0, f1, 8) GP_ITERQ(f1, f0, 8) }
