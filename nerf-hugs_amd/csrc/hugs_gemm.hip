@@ -715,21 +715,16 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
     }
     HUGS_TRP(i, 0)
     // the previous tile's 16 stores (+ 4 mask-bit words) are in the queue behind the two younger stages
-    // (round 3: the quartered form for these four iterations too.  Issued back to back, the four DMAs of a stage cost ~0.7k
-    // cycles more per iteration -- scratch/ntp_trace.py: 2.1-2.2k against 1.4k -- which was most of what looked like a
-    // store-acknowledgement stall at the tile boundary; a five-slot ring that requests stage 4 ahead of the stores removed
-    // only ~0.5k of it)
-#ifndef HUGS_NT_FIRST_UNQUARTERED
-    // (iteration 0 keeps the unfenced form: the bias is still live as the first MFMAs' C operand there, and the fenced quarters
-    // leave the compiler no order in which 16 bias + 96 fragment + 128 accumulator registers fit)
+    // Round 3: iterations 1-3 in the quartered form too (issued back to back, the four DMAs of a stage cost ~0.7k cycles more
+    // per iteration, scratch/ntp_trace.py: first four iterations 8.7k -> 8.0k cycles, forward layer 255 -> 252 us in-step).
+    // Iteration 0 keeps the unfenced form: the bias is still live as the first MFMAs' C operand there, and the fenced quarters
+    // leave the compiler no order in which 16 bias + 96 fragment + 128 accumulator registers fit (every specialisation spilled).
+    // What remains of the tile-boundary cost is NOT mainly a store-acknowledgement stall: a five-slot ring that requests
+    // stage 4 ahead of the stores (bias from VGPRs, all 160 KiB of LDS) took only ~0.5k off these iterations and lost 1.9k in
+    // its epilogue -- measured, removed; DESIGN.md section 4.
     if (EPI >= 0 && (EPI & EPI_BOUT)) { GP_ITER(f0, f1, 28) GP_ITERQ(f1, f0, 28) GP_ITERQ(f0, f1, 28) }
     else { GP_ITER(f0, f1, 24) GP_ITERQ(f1, f0, 24) GP_ITERQ(f0, f1, 24) }
     GP_ITERQ(f1, f0, 8)
-#else
-    if (EPI >= 0 && (EPI & EPI_BOUT)) { GP_ITER(f0, f1, 28) GP_ITER(f1, f0, 28) GP_ITER(f0, f1, 28) }
-    else { GP_ITER(f0, f1, 24) GP_ITER(f1, f0, 24) GP_ITER(f0, f1, 24) }
-    GP_ITER(f1, f0, 8)
-#endif
     HUGS_TRP(i, 1)
 #pragma unroll 1
     for (int st = 4; st < ns; st += 2) { GP_ITERQ(f0, f1, 8) GP_ITERQ(f1, f0, 8) }
@@ -737,263 +732,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
     nt_epilogue_direct<EPI, (EPI >= 0 && (EPI & EPI_BIAS) != 0), true>(acc, E, m0, n0, wm, wn, r16, kb, lds_bias, lds_r1);
     HUGS_TRP(i, 3)
   }
-#undef GP_ITER
-#undef GP_ITERQ
-#undef GP_Q
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dead stages past the last tile must land before the LDS is released
-}
-
-// ------------------------------------------------------------------------------------------------
-// bf16 NT, persistent, FIVE ring slots (all 160 KiB of LDS; round 3).  The four-slot kernel above pays ~3.7k of a tile's ~56k
-// cycles at every tile boundary: the wait for stage 4 of the new tile (requested after the previous tile's 16 output stores,
-// the earliest a four-slot ring has room for it) shares the in-order vmcnt queue with those stores, i.e. it waits for the
-// acknowledgement of the 32 MB all workgroups write at the same moment (scratch/ntp_trace.py: first four iterations 9.3k
-// cycles against 5.6k).  With a fifth slot stage 4 is requested BEFORE the stores; the first wait behind them is then
-// iteration 4's, 5.7k cycles after the last store.  What pays for the slot: the bias / rank-1 vectors leave LDS -- the bias of
-// the next tile is loaded into 16 VGPRs ahead of that extra stage (the accumulators start from it), which fits because the
-// last iteration of a tile no longer prefetches the next tile's first fragments (they are read under the accumulator
-// initialisation instead): the epilogue runs with 96 dead fragment registers.  Epilogues without loads of their own only
-// (bias / relu / mask bits out: the forward trunk layers); everything else stays on the four-slot kernel.
-// ------------------------------------------------------------------------------------------------
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers5(
-    int M, int N, int K1, int K2, const uint16_t* __restrict__ A1, int lda1, const uint16_t* __restrict__ A2, int lda2,
-    const uint16_t* __restrict__ Bt, int ldb, GemmEpi E, int ntiles) {
-  static_assert(EPI >= 0 && (EPI & ~(EPI_BIAS | EPI_RELU | EPI_BOUT)) == 0, "pers5: epilogues without loads of their own only");
-  constexpr int NSLOT = 5, A_BYTES = 256 * 64, STAGE = 2 * A_BYTES;
-  constexpr bool HAS_BIAS = (EPI & EPI_BIAS) != 0;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[NSLOT * STAGE];      // all 160 KiB
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ntn = N >> 8;
-  const int wm = wv >> 2, wn = wv & 3;
-  const int ns = (K1 + K2) >> 5;
-  const int G = gridDim.x;
-  const int nmine = (ntiles - (int)blockIdx.x + G - 1) / G;
-
-  // ---- loader state (wave-uniform, SGPRs): tile being fetched, stage within it, ring slot ----
-  // Every LDS-DMA takes its global address as (64-bit SGPR base) + (32-bit per-lane byte offset): the per-lane part
-  // is constant for the whole kernel (6 VGPRs), the base is scalar arithmetic -- no VALU and no address VGPR pairs in
-  // the loop (the builtin's 64-bit per-lane addresses cost 3 VALU + a VGPR pair per load and pushed the kernel into
-  // scratch spills, whose reloads are VMEM operations that drain the counted DMA queue).
-  int l_bid = blockIdx.x, l_st = 0, l_slot = 0;
-  int lm0, ln0;
-  { const int t = xcd_remap(l_bid, ntiles); lm0 = (t / ntn) << 8; ln0 = (t % ntn) << 8; }
-  const int prow = tid >> 2, pcol = ((tid & 3) ^ (3 * ((prow >> 2) & 1))) * 8;   // this thread's chunk of rows 0..127
-  // (rows 128..255 of a stage: the same per-lane offset on a base advanced by 128 rows)
-  const unsigned oA1 = (unsigned)(prow * lda1 + pcol) * 2u, oA2 = (unsigned)(prow * lda2 + pcol) * 2u;
-  const unsigned oB = (unsigned)(prow * ldb + pcol) * 2u;
-  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)wv * 1024u;
-  auto dma = [&](const char* sbase, unsigned voff, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory", "m0");
-  };
-  auto issue = [&]() {
-    const int kglob = l_st << 5;
-    const unsigned la = lds_base + (unsigned)l_slot * STAGE;
-    const char* bb = (const char*)Bt + ((size_t)ln0 * ldb + kglob) * 2;
-    if (kglob < K1) {
-      const char* ab = (const char*)A1 + ((size_t)lm0 * lda1 + kglob) * 2;
-      dma(ab, oA1, la); dma(ab + (size_t)lda1 * 256, oA1, la + 8192);
-    } else {
-      const char* ab = (const char*)A2 + ((size_t)lm0 * lda2 + (kglob - K1)) * 2;
-      dma(ab, oA2, la); dma(ab + (size_t)lda2 * 256, oA2, la + 8192);
-    }
-    dma(bb, oB, la + A_BYTES); dma(bb + (size_t)ldb * 256, oB, la + A_BYTES + 8192);
-    l_slot = l_slot == NSLOT - 1 ? 0 : l_slot + 1;
-    if (++l_st == ns) {
-      l_st = 0;
-      if (l_bid + G < ntiles) {
-        l_bid += G;
-        const int t = xcd_remap(l_bid, ntiles);
-        lm0 = (t / ntn) << 8; ln0 = (t % ntn) << 8;
-      }   // else: keep re-reading the last tile (dead slots, uniform counts)
-    }
-  };
-
-  f32x4_t acc[8][4];
-  const int r16 = lane & 15, kb = lane >> 4;
-  const int frag_off = r16 * 64 + ((kb ^ (3 * ((r16 >> 2) & 1))) << 4);
-  struct Frags { bf16x8_t wb[4], xa[8]; };
-  int c_slot = 0;       // ring slot of the stage whose fragments are loaded next
-  auto load_frags = [&](Frags& f) {
-    const unsigned char* la = lds + c_slot * STAGE + (wm * 128) * 64 + frag_off;
-    const unsigned char* lb = lds + c_slot * STAGE + A_BYTES + (wn * 64) * 64 + frag_off;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) f.wb[j] = *(const bf16x8_t*)(lb + j * 16 * 64);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) f.xa[i] = *(const bf16x8_t*)(la + i * 16 * 64);
-    c_slot = c_slot == NSLOT - 1 ? 0 : c_slot + 1;
-  };
-  auto mfmas = [&](const Frags& f) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wb[j], f.xa[i], acc[i][j], 0, 0, 0);
-  };
-  // The same work in four fenced quarters of {1 LDS-DMA, 3 fragment reads, 8 MFMAs}: the four DMAs
-  // of a stage are not pushed into the CU's vector-memory path back to back by all 8 waves at once.
-  auto issue_piece = [&](int q) {
-    const int kglob = l_st << 5;
-    const unsigned la = lds_base + (unsigned)l_slot * STAGE;
-    if (q < 2) {
-      if (kglob < K1) dma((const char*)A1 + ((size_t)lm0 * lda1 + kglob) * 2 + (q ? (size_t)lda1 * 256 : 0), oA1, la + q * 8192);
-      else dma((const char*)A2 + ((size_t)lm0 * lda2 + (kglob - K1)) * 2 + (q ? (size_t)lda2 * 256 : 0), oA2, la + q * 8192);
-    } else {
-      dma((const char*)Bt + ((size_t)ln0 * ldb + kglob) * 2 + (q == 3 ? (size_t)ldb * 256 : 0), oB, la + A_BYTES + (q - 2) * 8192);
-    }
-    if (q == 3) {
-      l_slot = l_slot == NSLOT - 1 ? 0 : l_slot + 1;
-      if (++l_st == ns) {
-        l_st = 0;
-        if (l_bid + G < ntiles) {
-          l_bid += G;
-          const int t = xcd_remap(l_bid, ntiles);
-          lm0 = (t / ntn) << 8; ln0 = (t % ntn) << 8;
-        }
-      }
-    }
-  };
-  auto frags_piece = [&](Frags& f, int q) {      // reads 3q .. 3q+2 of {wb[0..3], xa[0..7]}
-    const unsigned char* la = lds + c_slot * STAGE + wm * 128 * 64 + frag_off;
-    const unsigned char* lb = lds + c_slot * STAGE + A_BYTES + wn * 64 * 64 + frag_off;
-#pragma unroll
-    for (int r = 3 * q; r < 3 * q + 3; ++r) {
-      if (r < 4) f.wb[r] = *(const bf16x8_t*)(lb + r * 16 * 64);
-      else f.xa[r - 4] = *(const bf16x8_t*)(la + (r - 4) * 16 * 64);
-    }
-    if (q == 3) c_slot = c_slot == NSLOT - 1 ? 0 : c_slot + 1;
-  };
-  auto mfma_piece = [&](const Frags& f, int q) {
-#pragma unroll
-    for (int i = 2 * q; i < 2 * q + 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wb[j], f.xa[i], acc[i][j], 0, 0, 0);
-  };
-#define GP_Q(cur, nxt, q)                                                                                   \
-    issue_piece(q); frags_piece(nxt, q); mfma_piece(cur, q);                                                 \
-    __builtin_amdgcn_sched_barrier(0);
-  // iteration for stage g: frags(g) are in `cur`; make stage g+1 visible, refill the slot of stage g with stage g+4,
-  // start reading frags(g+1) into `nxt`, run the MFMAs of stage g.
-#define GP_ITERQ(cur, nxt, VM)                                                           \
-  {                                                                                       \
-    asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");                     \
-    __builtin_amdgcn_s_barrier();                                                         \
-    asm volatile("" ::: "memory");                                                        \
-    GP_Q(cur, nxt, 0) GP_Q(cur, nxt, 1) GP_Q(cur, nxt, 2) GP_Q(cur, nxt, 3)               \
-  }
-#define GP_ITER(cur, nxt, VM)                                                            \
-  {                                                                                       \
-    asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");                     \
-    __builtin_amdgcn_s_barrier();                                                         \
-    asm volatile("" ::: "memory");                                                        \
-    issue();                                                                              \
-    load_frags(nxt);                                                                      \
-    mfmas(cur);                                                                           \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                    \
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                  \
-      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                                  \
-    }                                                                                     \
-  }
-  // ---- iteration forms of this kernel -------------------------------------------------------------------------------
-  // no-issue iteration (the first of a tile: the loader is FIVE stages ahead across the epilogue, four everywhere else)
-#define GP_ITER_NI(cur, nxt, VM)                                                         \
-  {                                                                                       \
-    asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");                     \
-    __builtin_amdgcn_s_barrier();                                                         \
-    asm volatile("" ::: "memory");                                                        \
-    mfma_piece(cur, 0); mfma_piece(cur, 1); mfma_piece(cur, 2); mfma_piece(cur, 3);       \
-    __builtin_amdgcn_sched_barrier(0);                                                    \
-    load_frags(nxt);       /* behind the MFMAs: with the 16 bias registers (their C operands) still live there is */ \
-    __builtin_amdgcn_sched_barrier(0);   /* no room for a second fragment set next to the accumulators being born */ \
-  }
-  // last iteration of a tile: no fragment prefetch (the next tile reads its first fragments itself, under the accumulator
-  // initialisation): the epilogue then runs with 96 dead fragment registers instead of 48
-#define GP_ITERQ_LAST(cur, VM)                                                           \
-  {                                                                                       \
-    asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");                     \
-    __builtin_amdgcn_s_barrier();                                                         \
-    asm volatile("" ::: "memory");                                                        \
-    issue_piece(0); mfma_piece(cur, 0); __builtin_amdgcn_sched_barrier(0);                \
-    issue_piece(1); mfma_piece(cur, 1); __builtin_amdgcn_sched_barrier(0);                \
-    issue_piece(2); mfma_piece(cur, 2); __builtin_amdgcn_sched_barrier(0);                \
-    issue_piece(3); mfma_piece(cur, 3); __builtin_amdgcn_sched_barrier(0);                \
-  }
-  Frags f0, f1;
-  HUGS_STAGGER()
-  // this lane's 16 bias values of the NEXT tile (the accumulators start from them): loaded in front of the extra stage and
-  // the epilogue's stores, so that their wait at the tile start never includes a store acknowledgement
-  // The loads are inline asm and so is their wait: a load the compiler knows about that is consumed across the tile loop's back
-  // edge gets `s_waitcnt vmcnt(0)` from it at the loop head -- every store of the previous tile acknowledged at every tile start,
-  // the very stall this kernel exists to avoid.  bv is written by the asm loads and "modified" by the asm wait (the dependency
-  // that keeps every use behind the wait); nothing may touch those registers in between (checked in the ISA: no spill, no copy).
-  f32x4_t bv[4];
-  auto load_bias = [&](int bid_) {
-    if constexpr (HAS_BIAS) {
-      const int t = xcd_remap(bid_ < ntiles ? bid_ : (int)blockIdx.x, ntiles);
-      const int nn = (t % ntn) << 8;
-      // (the lane's column offset is recomputed from an opaque copy of the thread index: kept as a 64-bit per-lane address across
-      // the main loop it is one of the values that do not fit -- a scratch reload per tile is a VMEM wait that drains the ring)
-      int ln_ = threadIdx.x;
-      asm volatile("" : "+v"(ln_));
-      const float* bp = E.bias + nn + wn * 64;       // wave-uniform
-      const unsigned ko = (unsigned)((ln_ >> 4) & 3) * 16u;      // bytes
-      asm volatile("global_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:64\n\t"
-                   "global_load_dwordx4 %2, %4, %5 offset:128\n\tglobal_load_dwordx4 %3, %4, %5 offset:192"
-                   : "=&v"(bv[0]), "=&v"(bv[1]), "=&v"(bv[2]), "=&v"(bv[3]) : "v"(ko), "s"(bp) : "memory");
-    }
-  };
-#define GP_BIAS_WAIT(VM) asm volatile("s_waitcnt vmcnt(" #VM ")" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]) :: "memory")
-  load_bias(blockIdx.x);
-#pragma unroll
-  for (int q = 0; q < NSLOT; ++q) issue();
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  if constexpr (HAS_BIAS) GP_BIAS_WAIT(0);
-  __syncthreads();
-  int c_bid = blockIdx.x;
-  for (int i = 0; i < nmine; ++i, c_bid += G) {
-    int m0, n0;
-    { const int t = xcd_remap(c_bid, ntiles); m0 = (t / ntn) << 8; n0 = (t % ntn) << 8; }
-    load_frags(f0);       // stage 0 of this tile landed (and was made visible) iterations ago; read under the accumulator init
-    if constexpr (HAS_BIAS) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int a = 0; a < 8; ++a) acc[a][b] = bv[b];
-    } else {
-#pragma unroll
-      for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    }
-    HUGS_TRP(i, 0)
-    // Queue of this wave at this point (oldest first): stages 1 2 3 of this tile (12), [4 bias loads, done by now], stage 4
-    // (4, requested BEFORE the epilogue into the fifth slot), the previous tile's S = 16 (+ 4 mask-bit words) stores.  The
-    // wait for stage g+1 may leave everything younger outstanding: iteration 3 (stage 4) no longer needs one store to be
-    // acknowledged -- the first wait that does is iteration 4's, 5.7k cycles after the last store instead of 4.3k.
-    constexpr int S_ = 16 + ((EPI & EPI_BOUT) ? 4 : 0), B_ = HAS_BIAS ? 4 : 0;
-    // (the quartered form for these iterations too: issued back to back, the four DMAs of a stage cost ~0.7k cycles more per
-    // iteration -- scratch/ntp_trace.py: 2.1k against 1.4k)
-    if constexpr (S_ == 20 && B_ == 4) { GP_ITER_NI(f0, f1, 36) GP_ITERQ(f1, f0, 32) GP_ITERQ(f0, f1, 32) GP_ITERQ(f1, f0, 28) }
-    else if constexpr (S_ == 16 && B_ == 4) { GP_ITER_NI(f0, f1, 32) GP_ITERQ(f1, f0, 28) GP_ITERQ(f0, f1, 28) GP_ITERQ(f1, f0, 24) }
-    else { GP_ITER_NI(f0, f1, 28) GP_ITERQ(f1, f0, 24) GP_ITERQ(f0, f1, 24) GP_ITERQ(f1, f0, 24) }
-    HUGS_TRP(i, 1)
-#pragma unroll 1
-    for (int st = 4; st < ns - 2; st += 2) { GP_ITERQ(f0, f1, 8) GP_ITERQ(f1, f0, 8) }
-    GP_ITERQ(f0, f1, 8)
-    GP_ITERQ_LAST(f1, 8)
-    HUGS_TRP(i, 2)
-    load_bias(c_bid + G);          // next tile's bias, then its stage 4: both ahead of the stores in the queue
-    asm volatile("" ::: "memory");
-    issue();
-    nt_epilogue_direct<EPI, HAS_BIAS, true>(acc, E, m0, n0, wm, wn, r16, kb, nullptr, nullptr);
-    // the bias loads are older than stage 4 of the next tile (4 DMAs) and the S_ stores: they have landed once at most 4 + S_
-    // operations are outstanding -- no store needs to be acknowledged for that
-    if constexpr (HAS_BIAS) { if constexpr (S_ == 20) GP_BIAS_WAIT(24); else GP_BIAS_WAIT(20); }
-    HUGS_TRP(i, 3)
-  }
-#undef GP_BIAS_WAIT
-#undef GP_ITER_NI
-#undef GP_ITERQ_LAST
 #undef GP_ITER
 #undef GP_ITERQ
 #undef GP_Q
@@ -1587,16 +1325,6 @@ static int gemm_nt_impl(int tile_mode, int dtype, int M, int N, int K1, int K2, 
       const dim3 gp(ncu), bp(512);
 #define HUGS_NTP_LAUNCH(EPI_) hipLaunchKernelGGL((k_gemm_nt_bf16_pers<EPI_>), gp, bp, 0, (hipStream_t)stream, M, N, K1, K2, \
                        (const uint16_t*)A1, lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E, ntiles)
-#define HUGS_NTP5_LAUNCH(EPI_) hipLaunchKernelGGL((k_gemm_nt_bf16_pers5<EPI_>), gp, bp, 0, (hipStream_t)stream, M, N, K1, K2, \
-                       (const uint16_t*)A1, lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E, ntiles)
-      static int use5 = -1;
-      if (use5 < 0) { const char* e_ = getenv("HUGS_NT_PERS5"); use5 = !(e_ && e_[0] == '0'); }     // A/B switch (measurement)
-      if (use5 && nstage >= 8 && (epi == (EPI_BIAS | EPI_RELU) || epi == (EPI_BIAS | EPI_RELU | EPI_BOUT))) {
-        if (epi == (EPI_BIAS | EPI_RELU)) HUGS_NTP5_LAUNCH(EPI_BIAS | EPI_RELU); else HUGS_NTP5_LAUNCH(EPI_BIAS | EPI_RELU | EPI_BOUT);
-        HUGS_CHECK_LAUNCH("hugs_gemm_nt(persistent, 5 slots)");
-        return 0;
-      }
-#undef HUGS_NTP5_LAUNCH
       switch (epi) {
         case EPI_BIAS | EPI_RELU: HUGS_NTP_LAUNCH(EPI_BIAS | EPI_RELU); break;
         case EPI_BIAS | EPI_RELU | EPI_BOUT: HUGS_NTP_LAUNCH(EPI_BIAS | EPI_RELU | EPI_BOUT); break;   // forward trunk, mask bits out
