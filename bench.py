@@ -190,7 +190,7 @@ def nerfacto_roofline(model, step_fn, N, steps=3):
       g = grids.get((L_, F))
       dense = sum(1 for l in range(L_) if g is not None and int(g.resolutions[l]) ** 3 <= int(g.offsets[l + 1] - g.offsets[l]))
       if key[0] == 'hg_fwd':
-        by = n * L_ * 8 * F * 4 + n * L_ * F * 2 + n * 12
+        by = n * L_ * 8 * F * (2 if model.amp else 4) + n * L_ * F * 2 + n * 12
         ent.update(kernel=f"k_hashgrid_fwd {n} samples x {L_} levels", bound="hbm", achieved=round(by / (us * 1e-6) / 1e9, 1), peak=8000.0,
                    unit="GB/s", frac=round(by / (us * 1e-6) / 8e12, 4), algorithmic_bytes=by)
       else:
@@ -259,13 +259,14 @@ def bench_nerfacto(args, device, world, rank):
   kernels = nerfacto_roofline(model, step, N) if world == 1 else None
   if rank == 0:
     st = res['stats'].cpu().numpy()
+    extra = {"loss_scale_last": model.loss_scale()} if model.amp else {}
     line = {"metric": "train rays/sec (nerfacto, 16384-ray batch per GPU, 512+256+128 samples)", "value": round(N * world * args.steps / dt, 1),
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "windows": len(wins), "value_min": round(N * world * args.steps / max(wins), 1), "value_max": round(N * world * args.steps / min(wins), 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "configs[4] restatement: nerfacto hash-grid fields (phototourism_nerfacto_base.yml sizes), "
                                    "16384 rays/GPU, full train step", "params": int(model.flat.numel()), "parallelism": f"dp{world}"},
-            "loss_rgb_last": round(float(st[1]), 6)}
+            "loss_rgb_last": round(float(st[1]), 6), **extra}
     if kernels:
       line["roofline"] = kernels[0]
       line["instep_kernels"] = kernels[1:12]
@@ -281,7 +282,9 @@ def main():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=30)
   ap.add_argument('--warmup', type=int, default=10)
-  ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+  ap.add_argument('--dtype', default=None, choices=['bf16', 'fp32', 'fp16'],
+                  help="compute dtype; default bf16 (BASELINE config 2) and, for --config cfg5, fp16 (the reference's enable_amp: half operands,\n"
+                       "half table copies, dynamic loss scaling)")
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--min-time', type=float, default=2.0,
                   help='repeat the K-step timed window until this many seconds of timed steps have run; value = median window')
@@ -294,6 +297,10 @@ def main():
                        'contract + reciprocal, GLO 4, 1024 rays/GPU) and cfg5 (nerfacto hash-grid path, 16384 rays/GPU,\n'
                        'phototourism_nerfacto_base.yml sizes) are informational')
   args = ap.parse_args()
+  if args.dtype is None:
+    args.dtype = 'fp16' if args.config == 'cfg5' else 'bf16'
+  if args.dtype == 'fp16' and args.config != 'cfg5':
+    ap.error('fp16 is the nerfacto path (cfg5) mode; the Mip-NeRF 360 path runs bf16 or fp32')
   import torch.distributed as dist
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))

@@ -12,6 +12,10 @@
  * the device between steps: nerf-hugs_amd/internal/stepfun.py `_UB_CACHE`, train_utils.py `cache['thr_dev']`.)  Return 0 = ok, <0 = error (message via hugs_last_error(), thread local):
  *   -2 invalid argument for which the reference raises ValueError, -3 unsupported shape, -100 launch failure.
  * dtype: 0 = float32 (parity mode, v_mfma_f32_16x16x4_f32), 1 = bfloat16 operands with fp32 accumulate.
+ *   2 = IEEE half operands with fp32 accumulate (v_mfma_f32_16x16x32_f16): accepted by hugs_gemm_nt / _tn / _nt_bits,
+ *   hugs_cast_weights(_batch), the hash-grid / SH entries, the hugs_nf_* glue and fused proposal kernels, hugs_rank1_mask,
+ *   hugs_mask_head_*, hugs_embed_scatter_add and the other head kernels -- what the nerfacto path's fp16 mode uses (the
+ *   reference's enable_amp); the Mip-NeRF 360 encoder stays bf16 / fp32 (its 2^k x frequencies need the fp32 exponent range).
  * Activations/weights in `dtype`, everything per-ray / per-sample scalar in float32.  Row-major.
  */
 #ifndef HUGS_H
@@ -244,7 +248,8 @@ int hugs_nerfw_loss(int N, int L, const float* pred, const float* gt, const floa
 /* ---- nerfacto encodings (groundwork; PARITY UNPINNED: tiny-cuda-nn is not available, the
  * algorithm is restated in oracle/hashgrid_ref.py).  nerfacto/models/nerfacto.py:714-733,761-770,921-947 HashGrid:
  * x01 [n,3] in [0,1]; table fp32 [level_offsets[L], features]; level tables are HOST arrays (offsets [L+1] in entries,
- * resolutions [L], scales [L]); out [n, row_pitch] (first L*features columns written) bf16 or fp32.  The backward
+ * resolutions [L], scales [L]); out [n, row_pitch] (first L*features columns written) in the dtype code given (0 fp32, 1 bf16, 2 fp16; the
+ * `*_bf16` arguments below are that code).  The backward
  * ADDS into d_table (fp32 atomics; runs of consecutive samples inside one cell are summed in the wavefront first).
  * nerfacto.py:693-700 SphericalHarmonics degree 4: 16 columns from col0. */
 int hugs_hashgrid_fwd(int n, int n_levels, int features, const long long* level_offsets, const int* level_resolutions,
@@ -254,6 +259,12 @@ int hugs_hashgrid_bwd(int n, int n_levels, int features, const long long* level_
                       const float* level_scales, const float* x01, const void* d_out, int d_out_bf16, int row_pitch,
                       float* d_table_accum, void* stream);
 int hugs_sh4_fwd(int n, const float* dirs01, int out_bf16, int row_pitch, int col0, void* out, void* stream);
+/* hugs_hashgrid_fwd with the table given as an IEEE-half copy (table_dtype 2; 0 = fp32): the fp16 mode, the reference's
+ * `enable_amp: True` (nerfacto/configs/phototourism_nerfacto_base.yml:3; tiny-cuda-nn evaluates the grid on half
+ * parameters, nerfacto.py:699,770 dtype=None).  Interpolation accumulates in fp32; out_dtype 0 fp32 / 1 bf16 / 2 fp16. */
+int hugs_hashgrid_fwd_t(int n, int n_levels, int features, const long long* level_offsets, const int* level_resolutions,
+                        const float* level_scales, const float* x01, const void* table, int table_dtype, int out_dtype,
+                        int row_pitch, void* out, void* stream);
 /* nerfacto.py:1036-1047,1080-1091 (HA-NeRF ImplicitMask of the nerfacto model): 2-D hash grid of per-RAY image coordinates
  * x01 [n,2] (resolution^2 dense entries / two-prime hash, bilinear).  The forward writes the mask MLP's whole input row
  * out[n, :row_pitch] = [grid (n_levels*features) | extra[n, :T] (the ray's transient embedding row) | zeros]; the backward
@@ -315,6 +326,20 @@ int hugs_nf_rgb_act(long long M, int dtype, const void* Y, int ldy, float rgb_bi
 int hugs_nf_rgb_grad(long long M, int dtype, const float* rgb, const float* d_rgb, void* G, int ldg, void* stream);
 int hugs_nf_adam(long long n, float* theta, const float* grad, float* m, float* v, float lr, float b1, float b2, float eps,
                  float bc1, float bc2, void* stream);
+/* Dynamic loss scaling of the fp16 mode = torch.cuda.amp.GradScaler as nerfacto/train.py:168,210-213 drives it
+ * (scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()), with found_inf kept on the device.
+ * state: 3 floats {scale, growth tracker, found_inf}; counts: per parameter group, the number of Adam updates it has taken
+ * (torch keeps `step` per parameter; a skipped step does not advance it); bc: 2 floats per group {1 - b1^k, 1 - b2^k}.
+ *   hugs_amp_check(n, grad, state)      state[2] = 1 if any of grad[0..n) is inf / nan        (unscale_'s inf check)
+ *   hugs_amp_prepare(G, counts, b1, b2, bc)   bias corrections of each group's NEXT update (double arithmetic)
+ *   hugs_nf_adam_amp(...)               Adam on grad / state[0]; a no-op when state[2] != 0   (scaler.step)
+ *   hugs_amp_update(state, counts, mask, growth, backoff, interval)   counts[g] += 1 for g in mask unless skipped; scale *=
+ *       backoff on overflow, *= growth after `interval` clean steps in a row; found_inf cleared   (scaler.update) */
+int hugs_amp_check(long long n, const float* grad, float* state, void* stream);
+int hugs_amp_prepare(int ngroups, const float* counts, float b1, float b2, float* bc, void* stream);
+int hugs_nf_adam_amp(long long n, float* theta, const float* grad, float* m, float* v, float lr, float b1, float b2, float eps,
+                     const float* state, const float* bc, void* stream);
+int hugs_amp_update(float* state, float* counts, unsigned group_mask, float growth, float backoff, float interval, void* stream);
 
 /* test/bench forms of hugs_gemm_nt / hugs_gemm_tn with an explicit kernel selection (a call argument: no process
  * state): tile_mode 0 = the default choice (what the plain entry points use), 1 = force the 128x128-tile kernels,

@@ -60,6 +60,7 @@ _PROTOS = {
     'hugs_nerfw_loss': 'iipppifpfppps',
     'hugs_hashgrid_fwd': 'iiippppp' 'iips',
     'hugs_hashgrid_bwd': 'iiippppp' 'iips',
+    'hugs_hashgrid_fwd_t': 'iiippppp' 'iiips',
     'hugs_sh4_fwd': 'ipiiips',
     'hugs_hashgrid2d_fwd': 'iiippppp' 'piiips',
     'hugs_hashgrid2d_bwd': 'iiippppp' 'iips',
@@ -75,6 +76,10 @@ _PROTOS = {
     'hugs_nf_rgb_act': 'qipifps',
     'hugs_nf_rgb_grad': 'qipppis',
     'hugs_nf_adam': 'qppppffffffs',
+    'hugs_amp_check': 'qpps',
+    'hugs_amp_prepare': 'ipffps',
+    'hugs_nf_adam_amp': 'qppppffffpps',
+    'hugs_amp_update': 'ppifffs',
     'hugs_gemm_nt_tiles': 'i' 'iiiii' 'pipipi' 'pp' 'iii' 'pi' 'pp' 'pi' 's',
     'hugs_gemm_tn_tiles': 'i' 'iiiiipipippps',
 }
@@ -105,6 +110,7 @@ _PROFILED = {'hugs_gemm_nt': lambda a: ('nt', a[1], a[2], a[3] + a[4], 'mask' if
              'hugs_gemm_tn': lambda a: ('tn', a[1], a[2], a[3], f'split{a[4]}'),
              # nerfacto (bench.py --config cfg5): (kind, samples, levels, features) / (kind, samples, in_dim, hidden)
              'hugs_hashgrid_fwd': lambda a: ('hg_fwd', a[0], a[1], a[2]),
+             'hugs_hashgrid_fwd_t': lambda a: ('hg_fwd', a[0], a[1], a[2]),
              'hugs_hashgrid_bwd': lambda a: ('hg_bwd', a[0], a[1], a[2]),
              'hugs_nf_prop_fwd': lambda a: ('prop_fwd', a[0], a[1], a[2]),
              'hugs_nf_prop_bwd': lambda a: ('prop_bwd', a[0], a[1], a[2])}

@@ -10,7 +10,9 @@ pids=()
 for f in hugs_*.hip; do
   extra=""
   [ "$f" = "hugs_stepfun.hip" ] && extra="-ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt"
-  if [ ! -f "_obj/${f%.hip}.o" ] || [ "$f" -nt "_obj/${f%.hip}.o" ] || [ hugs_common.h -nt "_obj/${f%.hip}.o" ]; then
+  dep="$f"
+  [ "$f" = "hugs_gemm_f16.hip" ] && dep="hugs_gemm.hip"      # (it is hugs_gemm.hip compiled with half operands)
+  if [ ! -f "_obj/${f%.hip}.o" ] || [ "$f" -nt "_obj/${f%.hip}.o" ] || [ "$dep" -nt "_obj/${f%.hip}.o" ] || [ hugs_common.h -nt "_obj/${f%.hip}.o" ]; then
     $HIPCC $FLAGS $extra -c "$f" -o "_obj/${f%.hip}.o" &
     pids+=($!)
   fi

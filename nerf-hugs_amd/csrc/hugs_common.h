@@ -68,3 +68,9 @@ __device__ __forceinline__ uint16_t f_to_bf16(float f) {  // round-to-nearest-ev
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
+// IEEE half (dtype 2: the nerfacto path's fp16 mode) and the run-time 16-bit operand format switch (dt: 1 = bf16, 2 = half)
+__device__ __forceinline__ float h16_to_f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ uint16_t f_to_h16(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }   // RNE; > 65504 -> inf
+__device__ __forceinline__ float op16_to_f(uint16_t h, int dt) { return dt == 2 ? h16_to_f(h) : bf16_to_f(h); }
+__device__ __forceinline__ uint16_t f_to_op16(float f, int dt) { return dt == 2 ? f_to_h16(f) : f_to_bf16(f); }
+__device__ __forceinline__ uint32_t f2_to_op16(float a, float b, int dt) { return (uint32_t)f_to_op16(a, dt) | ((uint32_t)f_to_op16(b, dt) << 16); }

@@ -16,9 +16,30 @@
 #include "hugs_common.h"
 #include <type_traits>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+// The 16-bit operand kernels are compiled twice from this one source: as written (bf16, dtype 1) and, through
+// hugs_gemm_f16.hip (#define HUGS_GEMM_F16, #include "hugs_gemm.hip"), with IEEE half operands (dtype 2: the nerfacto
+// path's fp16 mode, the reference's `enable_amp`).  Only the MFMA opcode, the transpose-read builtin, the fp32 -> operand
+// conversion and the constant 1.0 differ; relu (signed 16-bit max), the "> 0" mask tests and the 1-bit masks are sign /
+// magnitude tests that hold for both formats.  The names keep their bf16 spelling in both passes.
+#ifdef HUGS_GEMM_F16
+typedef _Float16 hugs_op_t;
+#define HUGS_GEMM_NS gemm_f16
+#define HUGS_MFMA_16X16X32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+__device__ __forceinline__ uint16_t f_to_op16(float f) { const _Float16 h = (_Float16)f; return *(const uint16_t*)&h; }
+#else
+typedef __bf16 hugs_op_t;
+#define HUGS_GEMM_NS gemm_bf16
+#define HUGS_MFMA_16X16X32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+__device__ __forceinline__ uint16_t f_to_op16(float f) { return f_to_bf16(f); }
+#endif
+typedef __attribute__((ext_vector_type(8))) hugs_op_t bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) hugs_op_t bf16x4_t;
+// (the transposing LDS read moves 16-bit patterns: the bf16-typed builtin serves both formats)
+typedef __attribute__((ext_vector_type(4))) __bf16 hugs_raw16x4_t;
+#define HUGS_DS_READ_TR16(p_) __builtin_bit_cast(bf16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((hugs_raw16x4_t __attribute__((address_space(3)))*)(p_)))
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+namespace HUGS_GEMM_NS {
 
 struct GemmEpi {
   const float* bias;      // [N] added per column, or null
@@ -88,8 +109,8 @@ __device__ __forceinline__ void epi_store4(const GemmEpi& E, int m, int n, f32x4
       if (!((mk.y >> 16 & 0x7fffu) && !(mk.y >> 31))) x[3] = 0.f;
     }
     uint2 pk;
-    pk.x = f_to_bf16(x[0]) | ((uint32_t)f_to_bf16(x[1]) << 16);
-    pk.y = f_to_bf16(x[2]) | ((uint32_t)f_to_bf16(x[3]) << 16);
+    pk.x = f_to_op16(x[0]) | ((uint32_t)f_to_op16(x[1]) << 16);
+    pk.y = f_to_op16(x[2]) | ((uint32_t)f_to_op16(x[3]) << 16);
     *(uint2*)((uint16_t*)E.out + (size_t)m * E.ldc + n) = pk;
   } else {
     if (E.mask) {
@@ -171,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_bf16(int M, int N, int K1, i
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = HUGS_MFMA_16X16X32(wb[j], xa[i], acc[i][j], 0, 0, 0);
     }
   }
 #pragma unroll
@@ -224,7 +245,7 @@ __device__ __forceinline__ uint32_t pk_relu_bf16(uint32_t u) {
   return *(const uint32_t*)&r;
 }
 typedef float __attribute__((ext_vector_type(2))) f32x2_t;
-typedef __bf16 __attribute__((ext_vector_type(2))) bf16x2_t;
+typedef hugs_op_t __attribute__((ext_vector_type(2))) bf16x2_t;
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {      // one v_cvt_pk_bf16_f32
   const f32x2_t f = {a, b};
   const bf16x2_t h = __builtin_convertvector(f, bf16x2_t);
@@ -420,7 +441,7 @@ __global__ __launch_bounds__(128 * WN, 2) void k_gemm_nt_bf16_big(
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wb[j], f.xa[i], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) acc[i][j] = HUGS_MFMA_16X16X32(f.wb[j], f.xa[i], acc[i][j], 0, 0, 0);
   };
   constexpr int G = AIT + BIT;   // LDS-DMA instructions per thread per stage
   // iteration st: frags(st) are in `cur`; make stage st+1 visible, refill slot st%NSLOT with stage st+NSLOT,
@@ -494,7 +515,7 @@ __global__ __launch_bounds__(128 * WN, 2) void k_gemm_nt_bf16_big(
       if (rbp) { const float4 b = *(const float4*)(rbp + j * 16); x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w; }
       if (E.relu) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
       bf16x4_t pk;   // v_cvt_pk_bf16_f32 (round to nearest even)
-      pk[0] = (__bf16)x[0]; pk[1] = (__bf16)x[1]; pk[2] = (__bf16)x[2]; pk[3] = (__bf16)x[3];
+      pk[0] = (hugs_op_t)x[0]; pk[1] = (hugs_op_t)x[1]; pk[2] = (hugs_op_t)x[2]; pk[3] = (hugs_op_t)x[3];
       *(bf16x4_t*)(lds + ml * CPITCH + nl * 2) = pk;
     }
   }
@@ -621,7 +642,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wb[j], f.xa[i], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) acc[i][j] = HUGS_MFMA_16X16X32(f.wb[j], f.xa[i], acc[i][j], 0, 0, 0);
   };
   // The same work in four fenced quarters of {1 LDS-DMA, 3 fragment reads, 8 MFMAs}: the four DMAs
   // of a stage are not pushed into the CU's vector-memory path back to back by all 8 waves at once.
@@ -660,7 +681,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
 #pragma unroll
     for (int i = 2 * q; i < 2 * q + 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wb[j], f.xa[i], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) acc[i][j] = HUGS_MFMA_16X16X32(f.wb[j], f.xa[i], acc[i][j], 0, 0, 0);
   };
 #define GP_Q(cur, nxt, q)                                                                                   \
     issue_piece(q); frags_piece(nxt, q); mfma_piece(cur, q);                                                 \
@@ -790,7 +811,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(int Mrows, int Kc, int 
   for (int i = 0; i < 4; ++i) accb[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   bf16x8_t ones;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) ones[q] = (__bf16)1.0f;
+  for (int q = 0; q < 8; ++q) ones[q] = (hugs_op_t)1.0f;
 
   stage(0, 0);
   const int g = lane >> 4, s = lane & 15;
@@ -812,14 +833,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(int Mrows, int Kc, int 
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int q = (wn * 64 + i * 16) >> 4;  // 32-byte granule of the fragment's 16 columns
-            bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            bf16x4_t v = HUGS_DS_READ_TR16(
                 (bf16x4_t __attribute__((address_space(3)))*)(lg + row * 256 + ((q ^ sw) << 5) + ((s & 3) << 3)));
             ga[i][h * 4 + 0] = v[0]; ga[i][h * 4 + 1] = v[1]; ga[i][h * 4 + 2] = v[2]; ga[i][h * 4 + 3] = v[3];
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int q = (wk * 64 + j * 16) >> 4;
-            bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            bf16x4_t v = HUGS_DS_READ_TR16(
                 (bf16x4_t __attribute__((address_space(3)))*)(lx + row * 256 + ((q ^ sw) << 5) + ((s & 3) << 3)));
             xb[j][h * 4 + 0] = v[0]; xb[j][h * 4 + 1] = v[1]; xb[j][h * 4 + 2] = v[2]; xb[j][h * 4 + 3] = v[3];
           }
@@ -828,10 +849,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(int Mrows, int Kc, int 
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[i], xb[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = HUGS_MFMA_16X16X32(ga[i], xb[j], acc[i][j], 0, 0, 0);
         if constexpr (COLSUM) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[i], ones, accb[i], 0, 0, 0);
+          for (int i = 0; i < 4; ++i) accb[i] = HUGS_MFMA_16X16X32(ga[i], ones, accb[i], 0, 0, 0);
         }
       }
     }
@@ -918,7 +939,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
   f32x4_t accb[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
   bf16x8_t ones;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) ones[q] = (__bf16)1.0f;
+  for (int q = 0; q < 8; ++q) ones[q] = (hugs_op_t)1.0f;
 
   const int g = lane >> 4, s = lane & 15;
   struct Frags { bf16x8_t ga[8], xb[4]; };
@@ -931,12 +952,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4_t __attribute__((address_space(3)))*)(lg + lo + h * 512 + ((wn * 8 + i) << 5)));
+        bf16x4_t v = HUGS_DS_READ_TR16((bf16x4_t __attribute__((address_space(3)))*)(lg + lo + h * 512 + ((wn * 8 + i) << 5)));
         f.ga[i][h * 4 + 0] = v[0]; f.ga[i][h * 4 + 1] = v[1]; f.ga[i][h * 4 + 2] = v[2]; f.ga[i][h * 4 + 3] = v[3];
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4_t __attribute__((address_space(3)))*)(lx + lo + h * 512 + ((wk * 4 + j) << 5)));
+        bf16x4_t v = HUGS_DS_READ_TR16((bf16x4_t __attribute__((address_space(3)))*)(lx + lo + h * 512 + ((wk * 4 + j) << 5)));
         f.xb[j][h * 4 + 0] = v[0]; f.xb[j][h * 4 + 1] = v[1]; f.xb[j][h * 4 + 2] = v[2]; f.xb[j][h * 4 + 3] = v[3];
       }
     }
@@ -951,10 +972,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[i], f.xb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = HUGS_MFMA_16X16X32(f.ga[i], f.xb[j], acc[i][j], 0, 0, 0);
       if constexpr (WK >= 0) {   // wave (wn, wk) owns the column sums of its N fragments 2wk, 2wk+1
-        accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[2 * WK], ones, accb[0], 0, 0, 0);
-        accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[2 * WK + 1], ones, accb[1], 0, 0, 0);
+        accb[0] = HUGS_MFMA_16X16X32(f.ga[2 * WK], ones, accb[0], 0, 0, 0);
+        accb[1] = HUGS_MFMA_16X16X32(f.ga[2 * WK + 1], ones, accb[1], 0, 0, 0);
       }
     };
     // An iteration in four fenced quarters of {1 LDS-DMA, 6 transpose reads, 8 MFMAs}.  With the four
@@ -975,10 +996,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
       for (int r = 6 * q; r < 6 * q + 6; ++r) {
         const int h = r / 12, idx = r % 12;
         if (idx < 8) {
-          bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4_t __attribute__((address_space(3)))*)(lg + lo + h * 512 + ((wn * 8 + idx) << 5)));
+          bf16x4_t v = HUGS_DS_READ_TR16((bf16x4_t __attribute__((address_space(3)))*)(lg + lo + h * 512 + ((wn * 8 + idx) << 5)));
           f.ga[idx][h * 4 + 0] = v[0]; f.ga[idx][h * 4 + 1] = v[1]; f.ga[idx][h * 4 + 2] = v[2]; f.ga[idx][h * 4 + 3] = v[3];
         } else {
-          bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4_t __attribute__((address_space(3)))*)(lx + lo + h * 512 + ((wk * 4 + idx - 8) << 5)));
+          bf16x4_t v = HUGS_DS_READ_TR16((bf16x4_t __attribute__((address_space(3)))*)(lx + lo + h * 512 + ((wk * 4 + idx - 8) << 5)));
           f.xb[idx - 8][h * 4 + 0] = v[0]; f.xb[idx - 8][h * 4 + 1] = v[1]; f.xb[idx - 8][h * 4 + 2] = v[2]; f.xb[idx - 8][h * 4 + 3] = v[3];
         }
       }
@@ -987,11 +1008,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
 #pragma unroll
       for (int i = 2 * q; i < 2 * q + 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[i], f.xb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = HUGS_MFMA_16X16X32(f.ga[i], f.xb[j], acc[i][j], 0, 0, 0);
       if constexpr (WK >= 0) {
         if (q == WK) {
-          accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[2 * WK], ones, accb[0], 0, 0, 0);
-          accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ga[2 * WK + 1], ones, accb[1], 0, 0, 0);
+          accb[0] = HUGS_MFMA_16X16X32(f.ga[2 * WK], ones, accb[0], 0, 0, 0);
+          accb[1] = HUGS_MFMA_16X16X32(f.ga[2 * WK + 1], ones, accb[1], 0, 0, 0);
         }
       }
     };
@@ -1065,6 +1086,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
   }
 }
 
+#ifndef HUGS_GEMM_F16
 // ------------------------------------------------------------------------------------------------
 // fp32 parity path: 128x128x16 tiles on v_mfma_f32_16x16x4_f32, register-staged, padded LDS.
 // ------------------------------------------------------------------------------------------------
@@ -1221,6 +1243,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_f32(int Mrows, int Kc, int N
   if (do_colsum && tid < 128) colsum_slab[(size_t)split * N + n0 + tid] = csum;
 }
 
+#endif  // !HUGS_GEMM_F16 (the fp32 kernels exist once)
+
 // sum fp32 slabs: out[i] = sum_s slab[s][i]   (fixed order: deterministic).  Eight slab loads are kept in flight
 // per thread; a 16-slab, 4 MB-per-slab reduction is an HBM stream, not a latency chain.
 // A second (small) range -- the bias-gradient slabs -- rides in the same launch: blocks past the first range's reduce it
@@ -1248,16 +1272,46 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ s
   *(float4*)(out + i) = a;
 }
 
+}  // namespace HUGS_GEMM_NS
+using namespace HUGS_GEMM_NS;
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
 // tile_mode (hugs_gemm_nt_tiles / hugs_gemm_tn_tiles; the plain entry points pass 0): 0 = default kernel selection
 // (persistent 256x256, else 256x256, else 256x128, else 128x128), 1 = force 128x128, 3 = force 256x128 where 256x256
 // would be chosen, 5 = 256x256 without the persistent form.
-static int gemm_nt_impl(int tile_mode, int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,
-                        const void* Bt, int ldb, const float* bias, const float* row_bias, int row_div, int ld_rb,
-                        int relu, const void* mask, int ld_mask, const float* r1_row, const float* r1_col,
-                        void* out, int ldc, uint32_t* bits_out, const uint32_t* bits_in, void* stream);
+#ifdef HUGS_GEMM_F16
+#define HUGS_NT_IMPL hugs_gemm_nt_impl_f16
+#define HUGS_TN_IMPL hugs_gemm_tn_impl_f16
+#define HUGS_OP_DTYPE 2
+#else
+#define HUGS_NT_IMPL hugs_gemm_nt_impl_bf16
+#define HUGS_TN_IMPL hugs_gemm_tn_impl_bf16
+#define HUGS_OP_DTYPE 1
+#endif
+#define HUGS_NT_ARGS int tile_mode, int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,            \
+                     const void* Bt, int ldb, const float* bias, const float* row_bias, int row_div, int ld_rb, int relu, const void* mask, \
+                     int ld_mask, const float* r1_row, const float* r1_col, void* out, int ldc, uint32_t* bits_out,                         \
+                     const uint32_t* bits_in, void* stream
+#define HUGS_TN_ARGS int tile_mode, int dtype, int Mrows, int Kc, int N, int nsplit, const void* X, int ldx, const void* G, int ldg, \
+                     float* dW, float* dbias, void* ws, void* stream
+int hugs_gemm_nt_impl_bf16(HUGS_NT_ARGS);
+int hugs_gemm_nt_impl_f16(HUGS_NT_ARGS);       // hugs_gemm_f16.hip
+int hugs_gemm_tn_impl_bf16(HUGS_TN_ARGS);
+int hugs_gemm_tn_impl_f16(HUGS_TN_ARGS);
+
+#ifndef HUGS_GEMM_F16
+static int gemm_nt_impl(HUGS_NT_ARGS) {
+  return dtype == 2 ? hugs_gemm_nt_impl_f16(tile_mode, dtype, M, N, K1, K2, A1, lda1, A2, lda2, Bt, ldb, bias, row_bias, row_div, ld_rb, relu, mask,
+                                            ld_mask, r1_row, r1_col, out, ldc, bits_out, bits_in, stream)
+                    : hugs_gemm_nt_impl_bf16(tile_mode, dtype, M, N, K1, K2, A1, lda1, A2, lda2, Bt, ldb, bias, row_bias, row_div, ld_rb, relu, mask,
+                                             ld_mask, r1_row, r1_col, out, ldc, bits_out, bits_in, stream);
+}
+static int gemm_tn_impl(HUGS_TN_ARGS) {
+  return dtype == 2 ? hugs_gemm_tn_impl_f16(tile_mode, dtype, Mrows, Kc, N, nsplit, X, ldx, G, ldg, dW, dbias, ws, stream)
+                    : hugs_gemm_tn_impl_bf16(tile_mode, dtype, Mrows, Kc, N, nsplit, X, ldx, G, ldg, dW, dbias, ws, stream);
+}
 
 extern "C" int hugs_gemm_nt(int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,
                             const void* Bt, int ldb, const float* bias, const float* row_bias, int row_div, int ld_rb,
@@ -1282,19 +1336,17 @@ extern "C" int hugs_gemm_nt_bits(int dtype, int M, int N, int K1, int K2, const 
                                  const void* Bt, int ldb, const float* bias, int relu, const float* r1_row,
                                  const float* r1_col, void* out, int ldc, uint32_t* bits_out, const uint32_t* bits_in,
                                  void* stream) {
-  HUGS_REQUIRE(dtype == 1 && M % 256 == 0 && N % 256 == 0 && ldc == N && (K1 + K2) % 64 == 0 && K1 + K2 >= 256, -3,
-               "hugs_gemm_nt_bits: needs bf16, M=%d N=%d multiples of 256, ldc == N, K=%d a multiple of 64 and >= 256", M, N, K1 + K2);
+  HUGS_REQUIRE((dtype == 1 || dtype == 2) && M % 256 == 0 && N % 256 == 0 && ldc == N && (K1 + K2) % 64 == 0 && K1 + K2 >= 256, -3,
+               "hugs_gemm_nt_bits: needs bf16 / fp16, M=%d N=%d multiples of 256, ldc == N, K=%d a multiple of 64 and >= 256", M, N, K1 + K2);
   HUGS_REQUIRE(!bits_out || relu, -3, "hugs_gemm_nt_bits: bits_out needs a relu epilogue");
   return gemm_nt_impl(0, dtype, M, N, K1, K2, A1, lda1, A2, lda2, Bt, ldb, bias, nullptr, 1, 0, relu, bits_in ? (const void*)1 : nullptr, 0,
                       r1_row, r1_col, out, ldc, bits_out, bits_in, stream);
 }
+#endif  // !HUGS_GEMM_F16
 
-static int gemm_nt_impl(int tile_mode, int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2,
-                        int lda2, const void* Bt, int ldb, const float* bias, const float* row_bias, int row_div, int ld_rb,
-                        int relu, const void* mask, int ld_mask, const float* r1_row, const float* r1_col,
-                        void* out, int ldc, uint32_t* bits_out, const uint32_t* bits_in, void* stream) {
-  HUGS_REQUIRE(dtype == 0 || dtype == 1, -2, "hugs_gemm_nt: dtype must be 0 (fp32) or 1 (bf16)");
-  const int bk = dtype ? GB_BK : GF_BK;
+int HUGS_NT_IMPL(HUGS_NT_ARGS) {
+  HUGS_REQUIRE(dtype == HUGS_OP_DTYPE || (HUGS_OP_DTYPE == 1 && dtype == 0), -2, "hugs_gemm_nt: dtype must be 0 (fp32), 1 (bf16) or 2 (fp16)");
+  const int bk = dtype ? GB_BK : 16 /* GF_BK */;
   HUGS_REQUIRE(M % 128 == 0 && N % 128 == 0 && K1 % bk == 0 && K2 % bk == 0 && K1 > 0, -3,
                "hugs_gemm_nt: shape M=%d N=%d K=%d+%d not tile aligned (128,128,%d)", M, N, K1, K2, bk);
   HUGS_REQUIRE(!row_bias || row_div > 0, -3, "hugs_gemm_nt: row_div must be > 0");
@@ -1362,20 +1414,21 @@ static int gemm_nt_impl(int tile_mode, int dtype, int M, int N, int K1, int K2, 
   else if (dtype)
     hipLaunchKernelGGL(k_gemm_nt_bf16, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, N, K1, K2, (const uint16_t*)A1,
                        lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E);
+#ifndef HUGS_GEMM_F16
   else
     hipLaunchKernelGGL(k_gemm_nt_f32, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, N, K1, K2, (const float*)A1, lda1,
                        (const float*)A2, lda2, (const float*)Bt, ldb, E);
+#endif
   HUGS_CHECK_LAUNCH("hugs_gemm_nt");
   return 0;
 }
 
+#ifndef HUGS_GEMM_F16
 extern "C" long long hugs_gemm_tn_ws_bytes(int Kc, int N, int nsplit) {
   return (long long)nsplit * ((long long)Kc * N + N) * 4;
 }
 
 // dW[Kc, ldw(:N)] = X^T G, dbias[N] = colsum(G) (if dbias != null). ws: hugs_gemm_tn_ws_bytes().
-static int gemm_tn_impl(int tile_mode, int dtype, int Mrows, int Kc, int N, int nsplit, const void* X, int ldx, const void* G, int ldg,
-                        float* dW, float* dbias, void* ws, void* stream);
 extern "C" int hugs_gemm_tn(int dtype, int Mrows, int Kc, int N, int nsplit, const void* X, int ldx, const void* G, int ldg,
                             float* dW, float* dbias, void* ws, void* stream) {
   return gemm_tn_impl(0, dtype, Mrows, Kc, N, nsplit, X, ldx, G, ldg, dW, dbias, ws, stream);
@@ -1385,9 +1438,10 @@ extern "C" int hugs_gemm_tn_tiles(int tile_mode, int dtype, int Mrows, int Kc, i
   HUGS_REQUIRE(tile_mode == 0 || tile_mode == 1, -2, "hugs_gemm_tn_tiles: tile_mode %d (0 default, 1 force 128x128)", tile_mode);
   return gemm_tn_impl(tile_mode, dtype, Mrows, Kc, N, nsplit, X, ldx, G, ldg, dW, dbias, ws, stream);
 }
-static int gemm_tn_impl(int tile_mode, int dtype, int Mrows, int Kc, int N, int nsplit, const void* X, int ldx, const void* G, int ldg,
-                        float* dW, float* dbias, void* ws, void* stream) {
-  HUGS_REQUIRE(dtype == 0 || dtype == 1, -2, "hugs_gemm_tn: dtype must be 0 (fp32) or 1 (bf16)");
+#endif  // !HUGS_GEMM_F16
+
+int HUGS_TN_IMPL(HUGS_TN_ARGS) {
+  HUGS_REQUIRE(dtype == HUGS_OP_DTYPE || (HUGS_OP_DTYPE == 1 && dtype == 0), -2, "hugs_gemm_tn: dtype must be 0 (fp32), 1 (bf16) or 2 (fp16)");
   const int step = dtype ? 64 : 16;
   HUGS_REQUIRE(Kc % 128 == 0 && N % 128 == 0 && nsplit >= 1 && Mrows % (nsplit * step) == 0, -3,
                "hugs_gemm_tn: shape rows=%d Kc=%d N=%d split=%d not tile aligned", Mrows, Kc, N, nsplit);
@@ -1403,9 +1457,11 @@ static int gemm_tn_impl(int tile_mode, int dtype, int Mrows, int Kc, int N, int 
   else if (dtype)
     hipLaunchKernelGGL(k_gemm_tn_bf16, dim3(grid), dim3(256), 0, (hipStream_t)stream, Mrows, Kc, N, nsplit,
                        (const uint16_t*)X, ldx, (const uint16_t*)G, ldg, slab, N, cs);
+#ifndef HUGS_GEMM_F16
   else
     hipLaunchKernelGGL(k_gemm_tn_f32, dim3(grid), dim3(256), 0, (hipStream_t)stream, Mrows, Kc, N, nsplit, (const float*)X,
                        ldx, (const float*)G, ldg, slab, N, cs);
+#endif
   HUGS_CHECK_LAUNCH("hugs_gemm_tn");
   const size_t per = (size_t)Kc * N;
   const unsigned nb1 = (unsigned)((per / 4 + 255) / 256), nb2 = dbias ? (unsigned)((N / 4 + 255) / 256) : 0u;

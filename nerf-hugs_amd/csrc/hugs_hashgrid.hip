@@ -33,9 +33,24 @@ __device__ __forceinline__ uint32_t hg_index(uint32_t cx, uint32_t cy, uint32_t 
   return (entries & (entries - 1u)) == 0u ? (idx & (entries - 1u)) : idx % entries;
 }
 
-template <int F, bool BF16>
+// one table entry (F features) as floats; TH: the table is an IEEE-half copy (the fp16 mode: 4 / 8 bytes per corner instead of 8 / 16)
+template <int F, bool TH>
+__device__ __forceinline__ void hg_entry(const void* __restrict__ table, size_t entry, float (&t)[F]) {
+  if (TH) {
+    if (F == 2) { const uint32_t u = ((const uint32_t*)table)[entry]; t[0] = h16_to_f((uint16_t)u); t[1] = h16_to_f((uint16_t)(u >> 16)); }
+    else {
+      const uint2 u = ((const uint2*)table)[entry];
+      t[0] = h16_to_f((uint16_t)u.x); t[1] = h16_to_f((uint16_t)(u.x >> 16)); t[F - 2] = h16_to_f((uint16_t)u.y); t[F - 1] = h16_to_f((uint16_t)(u.y >> 16));
+    }
+  } else {
+#pragma unroll
+    for (int f = 0; f < F; ++f) t[f] = ((const float*)table)[entry * F + f];
+  }
+}
+
+template <int F, int BF16, bool TH>
 __global__ void __launch_bounds__(256)
-k_hashgrid_fwd(int n, int L, HgLevels lv, const float* __restrict__ x, const float* __restrict__ table, int row_pitch,
+k_hashgrid_fwd(int n, int L, HgLevels lv, const float* __restrict__ x, const void* __restrict__ table, int row_pitch,
                void* __restrict__ out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -48,7 +63,6 @@ k_hashgrid_fwd(int n, int L, HgLevels lv, const float* __restrict__ x, const flo
     const float gx = floorf(fx), gy = floorf(fy), gz = floorf(fz);
     const float wx = fx - gx, wy = fy - gy, wz = fz - gz;
     const uint32_t cx = (uint32_t)(int)gx, cy = (uint32_t)(int)gy, cz = (uint32_t)(int)gz;
-    const float* tb = table + (size_t)lv.off[l] * F;
     float acc[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) acc[f] = 0.f;
@@ -56,12 +70,14 @@ k_hashgrid_fwd(int n, int L, HgLevels lv, const float* __restrict__ x, const flo
     for (int c = 0; c < 8; ++c) {
       const float w = ((c & 1) ? wx : 1.f - wx) * ((c & 2) ? wy : 1.f - wy) * ((c & 4) ? wz : 1.f - wz);
       const uint32_t idx = hg_index<F>(cx + (c & 1), cy + ((c >> 1) & 1), cz + ((c >> 2) & 1), res, entries, dense);
+      float t[F];
+      hg_entry<F, TH>(table, (size_t)lv.off[l] + idx, t);
 #pragma unroll
-      for (int f = 0; f < F; ++f) acc[f] += w * tb[(size_t)idx * F + f];
+      for (int f = 0; f < F; ++f) acc[f] += w * t[f];
     }
 #pragma unroll
     for (int f = 0; f < F; ++f) {
-      if (BF16) ((uint16_t*)out)[(size_t)i * row_pitch + l * F + f] = f_to_bf16(acc[f]);
+      if (BF16) ((uint16_t*)out)[(size_t)i * row_pitch + l * F + f] = f_to_op16(acc[f], BF16);
       else ((float*)out)[(size_t)i * row_pitch + l * F + f] = acc[f];
     }
   }
@@ -73,7 +89,7 @@ k_hashgrid_fwd(int n, int L, HgLevels lv, const float* __restrict__ x, const flo
 // the nerfacto step (1.7 G fp32 atomics at ~21 G/s, worse where they collide); instead each run is summed inside the
 // wave first -- a segmented inclusive scan over the lanes, keyed by the cell -- and only the last lane of a run issues
 // atomics.  Levels where no two neighbouring lanes share a cell skip the scan (one ballot).
-template <int F, bool BF16>
+template <int F, int BF16>
 __global__ void __launch_bounds__(256)
 k_hashgrid_bwd(int n, int L, HgLevels lv, const float* __restrict__ x, const void* __restrict__ d_out, int row_pitch,
                float* __restrict__ d_table, int l_begin) {
@@ -93,7 +109,7 @@ k_hashgrid_bwd(int n, int L, HgLevels lv, const float* __restrict__ x, const voi
     float g[F];
 #pragma unroll
     for (int f = 0; f < F; ++f)
-      g[f] = !live ? 0.f : BF16 ? bf16_to_f(((const uint16_t*)d_out)[(size_t)ii * row_pitch + l * F + f])
+      g[f] = !live ? 0.f : BF16 ? op16_to_f(((const uint16_t*)d_out)[(size_t)ii * row_pitch + l * F + f], BF16)
                                 : ((const float*)d_out)[(size_t)ii * row_pitch + l * F + f];
     float v[8][F];
 #pragma unroll
@@ -175,7 +191,7 @@ k_hashgrid_bwd(int n, int L, HgLevels lv, const float* __restrict__ x, const voi
 // the global kernel) and adds the copy to the table once at the end: neighbouring lanes, neighbouring floats, so 16 floats per
 // atomic transaction.  Used when the level is dense and fits HG_L0_MAX_FLOATS.
 #define HG_L0_MAX_FLOATS 12288      // 48 KiB
-template <int F, bool BF16>
+template <int F, int BF16>
 __global__ void __launch_bounds__(256)
 k_hashgrid_bwd_l0(int n, HgLevels lv, const float* __restrict__ x, const void* __restrict__ d_out, int row_pitch,
                   float* __restrict__ d_table) {
@@ -198,7 +214,7 @@ k_hashgrid_bwd_l0(int n, HgLevels lv, const float* __restrict__ x, const void* _
     float g[F];
 #pragma unroll
     for (int f = 0; f < F; ++f)
-      g[f] = !live ? 0.f : BF16 ? bf16_to_f(((const uint16_t*)d_out)[(size_t)ii * row_pitch + f])
+      g[f] = !live ? 0.f : BF16 ? op16_to_f(((const uint16_t*)d_out)[(size_t)ii * row_pitch + f], BF16)
                                 : ((const float*)d_out)[(size_t)ii * row_pitch + f];
     float v[8][F];
 #pragma unroll
@@ -248,7 +264,7 @@ k_hashgrid_bwd_l0(int n, HgLevels lv, const float* __restrict__ x, const void* _
   }
 }
 
-template <bool BF16>
+template <int BF16>
 __global__ void __launch_bounds__(256)
 k_sh4(int n, const float* __restrict__ d01, int row_pitch, int col0, void* __restrict__ out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -274,7 +290,7 @@ k_sh4(int n, const float* __restrict__ d01, int row_pitch, int col0, void* __res
   o[15] = 0.59004358992664352f * x * (-x2 + 3.f * y2);
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    if (BF16) ((uint16_t*)out)[(size_t)i * row_pitch + col0 + k] = f_to_bf16(o[k]);
+    if (BF16) ((uint16_t*)out)[(size_t)i * row_pitch + col0 + k] = f_to_op16(o[k], BF16);
     else ((float*)out)[(size_t)i * row_pitch + col0 + k] = o[k];
   }
 }
@@ -282,7 +298,7 @@ k_sh4(int n, const float* __restrict__ d01, int row_pitch, int col0, void* __res
 // ---- 2-D grid: HA-NeRF's ImplicitMask in the nerfacto model (nerfacto.py:1036-1047, 1080-1091) encodes the pixel coordinate
 // of a RAY (not a sample): resolution^2 dense entries or the two-prime hash, bilinear over 4 corners.  One thread per ray
 // writes the whole input row of the mask MLP: [grid features | per-ray transient embedding | zero padding].
-template <int F, bool BF16>
+template <int F, int BF16>
 __global__ void __launch_bounds__(256)
 k_hashgrid2d_fwd(int n, int L, HgLevels lv, const float* __restrict__ x, const float* __restrict__ table,
                  const float* __restrict__ extra, int T, int row_pitch, void* __restrict__ out) {
@@ -290,7 +306,7 @@ k_hashgrid2d_fwd(int n, int L, HgLevels lv, const float* __restrict__ x, const f
   if (i >= n) return;
   const float px = x[2 * i], py = x[2 * i + 1];
   auto put = [&](int col, float v) {
-    if (BF16) ((uint16_t*)out)[(size_t)i * row_pitch + col] = f_to_bf16(v);
+    if (BF16) ((uint16_t*)out)[(size_t)i * row_pitch + col] = f_to_op16(v, BF16);
     else ((float*)out)[(size_t)i * row_pitch + col] = v;
   };
   for (int l = 0; l < L; ++l) {
@@ -320,7 +336,7 @@ k_hashgrid2d_fwd(int n, int L, HgLevels lv, const float* __restrict__ x, const f
   for (int c = L * F + T; c < row_pitch; ++c) put(c, 0.f);
 }
 
-template <int F, bool BF16>
+template <int F, int BF16>
 __global__ void __launch_bounds__(256)
 k_hashgrid2d_bwd(int n, int L, HgLevels lv, const float* __restrict__ x, const void* __restrict__ d_out, int row_pitch,
                  float* __restrict__ d_table) {
@@ -339,7 +355,7 @@ k_hashgrid2d_bwd(int n, int L, HgLevels lv, const float* __restrict__ x, const v
     float g[F];
 #pragma unroll
     for (int f = 0; f < F; ++f)
-      g[f] = BF16 ? bf16_to_f(((const uint16_t*)d_out)[(size_t)i * row_pitch + l * F + f]) : ((const float*)d_out)[(size_t)i * row_pitch + l * F + f];
+      g[f] = BF16 ? op16_to_f(((const uint16_t*)d_out)[(size_t)i * row_pitch + l * F + f], BF16) : ((const float*)d_out)[(size_t)i * row_pitch + l * F + f];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float w = ((c & 1) ? wx : 1.f - wx) * ((c & 2) ? wy : 1.f - wy);
@@ -363,9 +379,26 @@ int fill_levels(HgLevels& lv, int L, const long long* off, const int* res, const
 
 }  // namespace
 
+static int hashgrid_fwd_impl(int n, int n_levels, int features, const long long* level_offsets, const int* level_resolutions,
+                             const float* level_scales, const float* x01, const void* table, int table_half, int out_bf16,
+                             int row_pitch, void* out, void* stream);
 extern "C" int hugs_hashgrid_fwd(int n, int n_levels, int features, const long long* level_offsets,
                                  const int* level_resolutions, const float* level_scales, const float* x01,
                                  const float* table, int out_bf16, int row_pitch, void* out, void* stream) {
+  return hashgrid_fwd_impl(n, n_levels, features, level_offsets, level_resolutions, level_scales, x01, table, 0, out_bf16, row_pitch, out, stream);
+}
+/* The same with the table given as an IEEE-half copy (table_dtype 2; 0 = fp32 as above): the fp16 mode's forward gathers
+ * 4 / 8 bytes per corner (tiny-cuda-nn keeps half parameters under the reference's enable_amp). */
+extern "C" int hugs_hashgrid_fwd_t(int n, int n_levels, int features, const long long* level_offsets,
+                                   const int* level_resolutions, const float* level_scales, const float* x01,
+                                   const void* table, int table_dtype, int out_dtype, int row_pitch, void* out, void* stream) {
+  HUGS_REQUIRE(table_dtype == 0 || table_dtype == 2, -2, "hugs_hashgrid_fwd_t: table dtype %d (0 = fp32, 2 = fp16)", table_dtype);
+  return hashgrid_fwd_impl(n, n_levels, features, level_offsets, level_resolutions, level_scales, x01, table, table_dtype == 2, out_dtype, row_pitch, out, stream);
+}
+static int hashgrid_fwd_impl(int n, int n_levels, int features, const long long* level_offsets, const int* level_resolutions,
+                             const float* level_scales, const float* x01, const void* table, int table_half, int out_bf16,
+                             int row_pitch, void* out, void* stream) {
+  HUGS_REQUIRE(out_bf16 >= 0 && out_bf16 <= 2, -2, "hugs_hashgrid_fwd: output dtype %d", out_bf16);
   HgLevels lv;
   int rc = fill_levels(lv, n_levels, level_offsets, level_resolutions, level_scales, "hugs_hashgrid_fwd");
   if (rc) return rc;
@@ -375,11 +408,11 @@ extern "C" int hugs_hashgrid_fwd(int n, int n_levels, int features, const long l
   const dim3 g((n + 255) / 256), b(256);
   hipStream_t st = (hipStream_t)stream;
   if (features == 2) {
-    if (out_bf16) k_hashgrid_fwd<2, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out);
-    else k_hashgrid_fwd<2, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out);
+    switch (out_bf16 + 3 * table_half) { case 0: k_hashgrid_fwd<2, 0, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break; case 1: k_hashgrid_fwd<2, 1, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break; case 2: k_hashgrid_fwd<2, 2, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break;
+      case 3: k_hashgrid_fwd<2, 0, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break; case 4: k_hashgrid_fwd<2, 1, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break; default: k_hashgrid_fwd<2, 2, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break; }
   } else {
-    if (out_bf16) k_hashgrid_fwd<4, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out);
-    else k_hashgrid_fwd<4, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out);
+    switch (out_bf16 + 3 * table_half) { case 0: k_hashgrid_fwd<4, 0, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break; case 1: k_hashgrid_fwd<4, 1, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break; case 2: k_hashgrid_fwd<4, 2, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break;
+      case 3: k_hashgrid_fwd<4, 0, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break; case 4: k_hashgrid_fwd<4, 1, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break; default: k_hashgrid_fwd<4, 2, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break; }
   }
   HUGS_CHECK_LAUNCH("k_hashgrid_fwd");
   return 0;
@@ -402,21 +435,17 @@ extern "C" int hugs_hashgrid_bwd(int n, int n_levels, int features, const long l
   if (r0 * r0 * r0 <= e0 && (long long)e0 * features <= HG_L0_MAX_FLOATS && n >= 65536) {
     const int g0 = (int)(((n + 255) / 256) < 768 ? ((n + 255) / 256) : 768);
     if (features == 2) {
-      if (d_out_bf16) k_hashgrid_bwd_l0<2, true><<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum);
-      else k_hashgrid_bwd_l0<2, false><<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum);
+      switch (d_out_bf16) { case 0: k_hashgrid_bwd_l0<2, 0><<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum); break; case 1: k_hashgrid_bwd_l0<2, 1><<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum); break; default: k_hashgrid_bwd_l0<2, 2><<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum); break; }
     } else {
-      if (d_out_bf16) k_hashgrid_bwd_l0<4, true><<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum);
-      else k_hashgrid_bwd_l0<4, false><<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum);
+      switch (d_out_bf16) { case 0: k_hashgrid_bwd_l0<4, 0><<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum); break; case 1: k_hashgrid_bwd_l0<4, 1><<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum); break; default: k_hashgrid_bwd_l0<4, 2><<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum); break; }
     }
     l_begin = 1;
     if (n_levels == 1) { HUGS_CHECK_LAUNCH("k_hashgrid_bwd_l0"); return 0; }
   }
   if (features == 2) {
-    if (d_out_bf16) k_hashgrid_bwd<2, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin);
-    else k_hashgrid_bwd<2, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin);
+    switch (d_out_bf16) { case 0: k_hashgrid_bwd<2, 0><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin); break; case 1: k_hashgrid_bwd<2, 1><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin); break; default: k_hashgrid_bwd<2, 2><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin); break; }
   } else {
-    if (d_out_bf16) k_hashgrid_bwd<4, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin);
-    else k_hashgrid_bwd<4, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin);
+    switch (d_out_bf16) { case 0: k_hashgrid_bwd<4, 0><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin); break; case 1: k_hashgrid_bwd<4, 1><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin); break; default: k_hashgrid_bwd<4, 2><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin); break; }
   }
   HUGS_CHECK_LAUNCH("k_hashgrid_bwd");
   return 0;
@@ -425,8 +454,7 @@ extern "C" int hugs_hashgrid_bwd(int n, int n_levels, int features, const long l
 extern "C" int hugs_sh4_fwd(int n, const float* dirs01, int out_bf16, int row_pitch, int col0, void* out, void* stream) {
   HUGS_REQUIRE(row_pitch >= col0 + 16 && col0 >= 0, -2, "hugs_sh4_fwd: row pitch %d, first column %d", row_pitch, col0);
   if (n <= 0) return 0;
-  if (out_bf16) k_sh4<true><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, dirs01, row_pitch, col0, out);
-  else k_sh4<false><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, dirs01, row_pitch, col0, out);
+  switch (out_bf16) { case 0: k_sh4<0><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, dirs01, row_pitch, col0, out); break; case 1: k_sh4<1><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, dirs01, row_pitch, col0, out); break; default: k_sh4<2><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, dirs01, row_pitch, col0, out); break; }
   HUGS_CHECK_LAUNCH("k_sh4");
   return 0;
 }
@@ -447,11 +475,9 @@ extern "C" int hugs_hashgrid2d_fwd(int n, int n_levels, int features, const long
   const dim3 g((n + 255) / 256), b(256);
   hipStream_t st = (hipStream_t)stream;
   if (features == 2) {
-    if (out_bf16) k_hashgrid2d_fwd<2, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, extra, T, row_pitch, out);
-    else k_hashgrid2d_fwd<2, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, extra, T, row_pitch, out);
+    switch (out_bf16) { case 0: k_hashgrid2d_fwd<2, 0><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, extra, T, row_pitch, out); break; case 1: k_hashgrid2d_fwd<2, 1><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, extra, T, row_pitch, out); break; default: k_hashgrid2d_fwd<2, 2><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, extra, T, row_pitch, out); break; }
   } else {
-    if (out_bf16) k_hashgrid2d_fwd<4, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, extra, T, row_pitch, out);
-    else k_hashgrid2d_fwd<4, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, extra, T, row_pitch, out);
+    switch (out_bf16) { case 0: k_hashgrid2d_fwd<4, 0><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, extra, T, row_pitch, out); break; case 1: k_hashgrid2d_fwd<4, 1><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, extra, T, row_pitch, out); break; default: k_hashgrid2d_fwd<4, 2><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, extra, T, row_pitch, out); break; }
   }
   HUGS_CHECK_LAUNCH("k_hashgrid2d_fwd");
   return 0;
@@ -468,11 +494,9 @@ extern "C" int hugs_hashgrid2d_bwd(int n, int n_levels, int features, const long
   const dim3 g((n + 255) / 256), b(256);
   hipStream_t st = (hipStream_t)stream;
   if (features == 2) {
-    if (d_out_bf16) k_hashgrid2d_bwd<2, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum);
-    else k_hashgrid2d_bwd<2, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum);
+    switch (d_out_bf16) { case 0: k_hashgrid2d_bwd<2, 0><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum); break; case 1: k_hashgrid2d_bwd<2, 1><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum); break; default: k_hashgrid2d_bwd<2, 2><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum); break; }
   } else {
-    if (d_out_bf16) k_hashgrid2d_bwd<4, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum);
-    else k_hashgrid2d_bwd<4, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum);
+    switch (d_out_bf16) { case 0: k_hashgrid2d_bwd<4, 0><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum); break; case 1: k_hashgrid2d_bwd<4, 1><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum); break; default: k_hashgrid2d_bwd<4, 2><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum); break; }
   }
   HUGS_CHECK_LAUNCH("k_hashgrid2d_bwd");
   return 0;

@@ -6,9 +6,13 @@
 // hoisted into a per-ray bias; :514-519 rgb = sigmoid(Dense(3)) * (1+2*pad) - pad.
 #include "hugs_common.h"
 
-template <bool BF16>
+template <int BF16>
 __device__ __forceinline__ void load8(const void* base, size_t elem_off, float v[8]) {
-  if (BF16) {
+  if (BF16 == 2) {
+    const uint4 p = *(const uint4*)((const uint16_t*)base + elem_off);
+    v[0] = h16_to_f((uint16_t)p.x); v[1] = h16_to_f((uint16_t)(p.x >> 16)); v[2] = h16_to_f((uint16_t)p.y); v[3] = h16_to_f((uint16_t)(p.y >> 16));
+    v[4] = h16_to_f((uint16_t)p.z); v[5] = h16_to_f((uint16_t)(p.z >> 16)); v[6] = h16_to_f((uint16_t)p.w); v[7] = h16_to_f((uint16_t)(p.w >> 16));
+  } else if (BF16) {
     const uint4 p = *(const uint4*)((const uint16_t*)base + elem_off);
     v[0] = __uint_as_float(p.x << 16); v[1] = __uint_as_float(p.x & 0xffff0000u);
     v[2] = __uint_as_float(p.y << 16); v[3] = __uint_as_float(p.y & 0xffff0000u);
@@ -20,14 +24,12 @@ __device__ __forceinline__ void load8(const void* base, size_t elem_off, float v
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
   }
 }
-template <bool BF16>
+template <int BF16>
 __device__ __forceinline__ void store8(void* base, size_t elem_off, const float v[8]) {
   if (BF16) {
     uint4 pk;
-    pk.x = f_to_bf16(v[0]) | ((uint32_t)f_to_bf16(v[1]) << 16);
-    pk.y = f_to_bf16(v[2]) | ((uint32_t)f_to_bf16(v[3]) << 16);
-    pk.z = f_to_bf16(v[4]) | ((uint32_t)f_to_bf16(v[5]) << 16);
-    pk.w = f_to_bf16(v[6]) | ((uint32_t)f_to_bf16(v[7]) << 16);
+    pk.x = f2_to_op16(v[0], v[1], BF16); pk.y = f2_to_op16(v[2], v[3], BF16);
+    pk.z = f2_to_op16(v[4], v[5], BF16); pk.w = f2_to_op16(v[6], v[7], BF16);
     *(uint4*)((uint16_t*)base + elem_off) = pk;
   } else {
     *(float4*)((float*)base + elem_off) = make_float4(v[0], v[1], v[2], v[3]);
@@ -40,7 +42,7 @@ __device__ __forceinline__ float softplusf(float x) {  // logaddexp(x, 0)
 }
 
 // ---- density head forward: raw[m] = Y[m,:] . w + b ; density = softplus(raw + density_bias) ----
-template <bool BF16>
+template <int BF16>
 __global__ __launch_bounds__(256) void k_density_fwd(int M, int K, const void* __restrict__ Y, int ldy,
                                                      const float* __restrict__ w, const float* __restrict__ b,
                                                      float density_bias, float* __restrict__ raw,
@@ -73,7 +75,7 @@ __global__ void k_density_bwd_raw(int M, const float* __restrict__ d_density, co
 }
 
 // weighted column sums: slab[blk][k] = sum_{m in blk} r[m] * Y[m,k]; slab[blk][K] = sum r[m]   (K <= 2048)
-template <bool BF16>
+template <int BF16>
 __global__ __launch_bounds__(256) void k_wcolsum(int M, int K, int rows_per_blk, const void* __restrict__ Y, int ldy,
                                                  const float* __restrict__ r, float* __restrict__ slab) {
   // thread t owns columns [8t, 8t+8) (K/8 <= 256 threads active); rows are walked sequentially
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(1024) void k_slab_reduce_small(const float* __restr
 }
 
 // out[m,n] = r[m] * c[n] * (Y[m,n] > 0)   (PropMLP: gradient entering the last trunk layer)
-template <bool BF16>
+template <int BF16>
 __global__ void k_rank1_mask(int M, int N, const float* __restrict__ r, const float* __restrict__ c,
                              const void* __restrict__ Y, int ldy, void* __restrict__ out, int ldo) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -152,7 +154,7 @@ __global__ void k_raybias_fwd(int nrays, int H, int nd, int ng, const float* __r
 
 // backward of the per-ray part: d_rb[ray,j] = sum_s G[ray*S+s, j];  then
 //   dWv_tail[c,j] = sum_ray enc[ray,c] d_rb[ray,j];  d_glo[ray,g] = sum_j d_rb[ray,j] Wv_tail[nd+g, j]
-template <bool BF16>
+template <int BF16>
 __global__ void k_segsum(int nrays, int S, int H, const void* __restrict__ G, int ldg, float* __restrict__ d_rb) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nrays * H) return;
@@ -160,7 +162,7 @@ __global__ void k_segsum(int nrays, int S, int H, const void* __restrict__ G, in
   float a = 0.f;
   for (int s = 0; s < S; ++s) {
     const size_t off = (size_t)(ray * S + s) * ldg + j;
-    a += BF16 ? bf16_to_f(((const uint16_t*)G)[off]) : ((const float*)G)[off];
+    a += BF16 ? op16_to_f(((const uint16_t*)G)[off], BF16) : ((const float*)G)[off];
   }
   d_rb[i] = a;
 }
@@ -200,7 +202,7 @@ __global__ void k_glo_gather(int nrays, int ng, const float* __restrict__ embedd
 }
 
 // ---- rgb head: 16 lanes per row (H = 128 -> 8 elements per lane) ----
-template <bool BF16>
+template <int BF16>
 __global__ __launch_bounds__(256) void k_rgb_fwd(int M, int H, const void* __restrict__ Hact, int ldh,
                                                  const float* __restrict__ W /*[H,3]*/, const float* __restrict__ b,
                                                  float pad, float* __restrict__ rgb) {
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256) void k_rgb_fwd(int M, int H, const void* __res
 // backward: dz[c] = d_rgb[c] * (1+2pad) * s(1-s), s = (rgb+pad)/(1+2pad)
 //   G[m,j] = (h[m,j] > 0) * sum_c dz[c] W[j,c]     (gradient at the view layer's pre-activation)
 //   slab[blk] accumulates dW[j,c] = sum_m h[m,j] dz[m,c] and db[c] = sum_m dz[m,c]
-template <bool BF16>
+template <int BF16>
 __global__ __launch_bounds__(256) void k_rgb_bwd(int M, int H, int rows_per_blk, const void* __restrict__ Hact, int ldh,
                                                  const float* __restrict__ W, const float* __restrict__ rgb,
                                                  const float* __restrict__ d_rgb, float pad, void* __restrict__ G,
@@ -283,8 +285,9 @@ extern "C" int hugs_density_fwd(int dtype, int M, int K, const void* Y, int ldy,
   HUGS_REQUIRE(K % 8 == 0, -3, "hugs_density_fwd: K=%d must be a multiple of 8", K);
   if (M <= 0) return 0;
   const int grid = min((M + 3) / 4, 2048);
-  if (dtype) hipLaunchKernelGGL(k_density_fwd<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, K, Y, ldy, w, b, density_bias, raw, density);
-  else hipLaunchKernelGGL(k_density_fwd<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, K, Y, ldy, w, b, density_bias, raw, density);
+  if (dtype == 2) hipLaunchKernelGGL(k_density_fwd<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, K, Y, ldy, w, b, density_bias, raw, density);
+  else if (dtype) hipLaunchKernelGGL(k_density_fwd<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, K, Y, ldy, w, b, density_bias, raw, density);
+  else hipLaunchKernelGGL(k_density_fwd<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, K, Y, ldy, w, b, density_bias, raw, density);
   HUGS_CHECK_LAUNCH("hugs_density_fwd");
   return 0;
 }
@@ -308,8 +311,9 @@ extern "C" int hugs_density_bwd(int dtype, int M, int K, const void* Y, int ldy,
   const int rpb = (M + WCS_BLOCKS - 1) / WCS_BLOCKS;
   const int nblk = (M + rpb - 1) / rpb;
   float* slab = (float*)ws;
-  if (dtype) hipLaunchKernelGGL(k_wcolsum<true>, dim3(nblk), dim3(256), 0, st, M, K, rpb, Y, ldy, d_raw, slab);
-  else hipLaunchKernelGGL(k_wcolsum<false>, dim3(nblk), dim3(256), 0, st, M, K, rpb, Y, ldy, d_raw, slab);
+  if (dtype == 2) hipLaunchKernelGGL(k_wcolsum<2>, dim3(nblk), dim3(256), 0, st, M, K, rpb, Y, ldy, d_raw, slab);
+  else if (dtype) hipLaunchKernelGGL(k_wcolsum<1>, dim3(nblk), dim3(256), 0, st, M, K, rpb, Y, ldy, d_raw, slab);
+  else hipLaunchKernelGGL(k_wcolsum<0>, dim3(nblk), dim3(256), 0, st, M, K, rpb, Y, ldy, d_raw, slab);
   hipLaunchKernelGGL(k_slab_reduce_small, dim3((K + 1 + 63) / 64), dim3(1024), 0, st, slab, nblk, K, K + 4, dw, 1, db);
   HUGS_CHECK_LAUNCH("hugs_density_bwd");
   return 0;
@@ -320,8 +324,9 @@ extern "C" int hugs_rank1_mask(int dtype, int M, int N, const float* r, const fl
   HUGS_REQUIRE(N % 8 == 0, -3, "hugs_rank1_mask: N=%d must be a multiple of 8", N);
   const size_t n = (size_t)M * (N / 8);
   if (n == 0) return 0;
-  if (dtype) hipLaunchKernelGGL(k_rank1_mask<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, N, r, c, Y, ldy, out, ldo);
-  else hipLaunchKernelGGL(k_rank1_mask<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, N, r, c, Y, ldy, out, ldo);
+  if (dtype == 2) hipLaunchKernelGGL(k_rank1_mask<2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, N, r, c, Y, ldy, out, ldo);
+  else if (dtype) hipLaunchKernelGGL(k_rank1_mask<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, N, r, c, Y, ldy, out, ldo);
+  else hipLaunchKernelGGL(k_rank1_mask<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, N, r, c, Y, ldy, out, ldo);
   HUGS_CHECK_LAUNCH("hugs_rank1_mask");
   return 0;
 }
@@ -350,8 +355,9 @@ extern "C" int hugs_raybias_bwd(int dtype, int nrays, int S, int H, int nd, int 
   HUGS_REQUIRE(H == 128, -3, "hugs_raybias_bwd: view width %d unsupported (128)", H);
   if (nrays <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype) hipLaunchKernelGGL(k_segsum<true>, dim3((nrays * H + 255) / 256), dim3(256), 0, st, nrays, S, H, G, ldg, d_rb);
-  else hipLaunchKernelGGL(k_segsum<false>, dim3((nrays * H + 255) / 256), dim3(256), 0, st, nrays, S, H, G, ldg, d_rb);
+  if (dtype == 2) hipLaunchKernelGGL(k_segsum<2>, dim3((nrays * H + 255) / 256), dim3(256), 0, st, nrays, S, H, G, ldg, d_rb);
+  else if (dtype) hipLaunchKernelGGL(k_segsum<1>, dim3((nrays * H + 255) / 256), dim3(256), 0, st, nrays, S, H, G, ldg, d_rb);
+  else hipLaunchKernelGGL(k_segsum<0>, dim3((nrays * H + 255) / 256), dim3(256), 0, st, nrays, S, H, G, ldg, d_rb);
   hipLaunchKernelGGL(k_raybias_bwd_w, dim3(nd + ng), dim3(1024), 0, st, nrays, H, nd, ng, dir_enc, glo, d_rb, dWv_tail);
   if (ng > 0 && d_embedding)
     hipLaunchKernelGGL(k_glo_bwd, dim3((nrays * ng + 255) / 256), dim3(256), 0, st, nrays, H, nd, ng, d_rb, Wv_tail, embed_idx, d_embedding);
@@ -364,8 +370,9 @@ extern "C" int hugs_rgb_fwd(int dtype, int M, int H, const void* Hact, int ldh, 
   HUGS_REQUIRE(H % 8 == 0, -3, "hugs_rgb_fwd: H=%d must be a multiple of 8", H);
   if (M <= 0) return 0;
   const int grid = (int)(((long long)M * 16 + 255) / 256);
-  if (dtype) hipLaunchKernelGGL(k_rgb_fwd<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, H, Hact, ldh, W, b, pad, rgb);
-  else hipLaunchKernelGGL(k_rgb_fwd<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, H, Hact, ldh, W, b, pad, rgb);
+  if (dtype == 2) hipLaunchKernelGGL(k_rgb_fwd<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, H, Hact, ldh, W, b, pad, rgb);
+  else if (dtype) hipLaunchKernelGGL(k_rgb_fwd<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, H, Hact, ldh, W, b, pad, rgb);
+  else hipLaunchKernelGGL(k_rgb_fwd<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, H, Hact, ldh, W, b, pad, rgb);
   HUGS_CHECK_LAUNCH("hugs_rgb_fwd");
   return 0;
 }
@@ -382,8 +389,9 @@ extern "C" int hugs_rgb_bwd(int dtype, int M, int H, const void* Hact, int ldh, 
   rpb = (rpb + 15) / 16 * 16;
   const int nblk = (M + rpb - 1) / rpb;
   float* slab = (float*)ws;
-  if (dtype) hipLaunchKernelGGL(k_rgb_bwd<true>, dim3(nblk), dim3(256), 0, st, M, H, rpb, Hact, ldh, W, rgb, d_rgb, pad, G, ldg, slab);
-  else hipLaunchKernelGGL(k_rgb_bwd<false>, dim3(nblk), dim3(256), 0, st, M, H, rpb, Hact, ldh, W, rgb, d_rgb, pad, G, ldg, slab);
+  if (dtype == 2) hipLaunchKernelGGL(k_rgb_bwd<2>, dim3(nblk), dim3(256), 0, st, M, H, rpb, Hact, ldh, W, rgb, d_rgb, pad, G, ldg, slab);
+  else if (dtype) hipLaunchKernelGGL(k_rgb_bwd<1>, dim3(nblk), dim3(256), 0, st, M, H, rpb, Hact, ldh, W, rgb, d_rgb, pad, G, ldg, slab);
+  else hipLaunchKernelGGL(k_rgb_bwd<0>, dim3(nblk), dim3(256), 0, st, M, H, rpb, Hact, ldh, W, rgb, d_rgb, pad, G, ldg, slab);
   hipLaunchKernelGGL(k_slab_reduce_small, dim3(7), dim3(1024), 0, st, slab, nblk, 384, 388, dW, 3, db);
   HUGS_CHECK_LAUNCH("hugs_rgb_bwd");
   return 0;

@@ -14,11 +14,12 @@
 
 #define NF_CAP 1025
 
+// (`bf16` is the dtype code of the C ABI: 0 = fp32, 1 = bf16, 2 = IEEE half)
 __device__ __forceinline__ float nf_load(const void* p, size_t i, int bf16) {
-  return bf16 ? bf16_to_f(((const uint16_t*)p)[i]) : ((const float*)p)[i];
+  return bf16 ? op16_to_f(((const uint16_t*)p)[i], bf16) : ((const float*)p)[i];
 }
 __device__ __forceinline__ void nf_store(void* p, size_t i, int bf16, float v) {
-  if (bf16) ((uint16_t*)p)[i] = f_to_bf16(v); else ((float*)p)[i] = v;
+  if (bf16) ((uint16_t*)p)[i] = f_to_op16(v, bf16); else ((float*)p)[i] = v;
 }
 
 // spacing functions of models/nerfacto.py:231-241: 0 uniform, 1 piecewise, 2 reciprocal
@@ -361,8 +362,8 @@ __global__ void k_nf_density_act(long long M, int bf16, const void* __restrict__
 __device__ __forceinline__ void nf_store8(void* p, size_t i, int bf16, const float (&v)[8]) {
   if (bf16) {
     uint4 u;
-    u.x = f_to_bf16(v[0]) | ((uint32_t)f_to_bf16(v[1]) << 16); u.y = f_to_bf16(v[2]) | ((uint32_t)f_to_bf16(v[3]) << 16);
-    u.z = f_to_bf16(v[4]) | ((uint32_t)f_to_bf16(v[5]) << 16); u.w = f_to_bf16(v[6]) | ((uint32_t)f_to_bf16(v[7]) << 16);
+    u.x = f2_to_op16(v[0], v[1], bf16); u.y = f2_to_op16(v[2], v[3], bf16);
+    u.z = f2_to_op16(v[4], v[5], bf16); u.w = f2_to_op16(v[6], v[7], bf16);
     *(uint4*)((uint16_t*)p + i) = u;
   } else {
     *(float4*)((float*)p + i) = make_float4(v[0], v[1], v[2], v[3]);
@@ -513,7 +514,7 @@ extern "C" int hugs_nf_rgb_grad(long long M, int dtype, const float* rgb, const 
 #define PM_H 64
 __host__ __device__ __forceinline__ constexpr int pm_slab_width(int KP) { return KP * PM_H + 2 * PM_H + 4; }
 
-template <bool BF16, int KP>
+template <int BF16, int KP>
 __device__ __forceinline__ void pm_load_x(const void* X, long long m, int ldx, float (&x)[KP]) {
   if (BF16) {
 #pragma unroll
@@ -521,7 +522,10 @@ __device__ __forceinline__ void pm_load_x(const void* X, long long m, int ldx, f
       const uint4 u = *(const uint4*)((const uint16_t*)X + (size_t)m * ldx + c * 8);
       const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { x[c * 8 + 2 * q] = __uint_as_float(w[q] << 16); x[c * 8 + 2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u); }
+      for (int q = 0; q < 4; ++q) {
+        if (BF16 == 2) { x[c * 8 + 2 * q] = h16_to_f((uint16_t)w[q]); x[c * 8 + 2 * q + 1] = h16_to_f((uint16_t)(w[q] >> 16)); }
+        else { x[c * 8 + 2 * q] = __uint_as_float(w[q] << 16); x[c * 8 + 2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u); }
+      }
     }
   } else {
 #pragma unroll
@@ -560,7 +564,7 @@ __device__ __forceinline__ void pm_stage_weights(int in_dim, int H, const float*
   }
 }
 
-template <bool BF16, int KP>
+template <int BF16, int KP>
 __global__ __launch_bounds__(256) void k_nf_prop_fwd(long long M, int in_dim, int H, const void* __restrict__ X, int ldx,
                                                      const float* __restrict__ W0, int ldw0, const float* __restrict__ b0,
                                                      const float* __restrict__ w1, int ldw1, const float* __restrict__ b1,
@@ -587,7 +591,7 @@ __global__ __launch_bounds__(256) void k_nf_prop_fwd(long long M, int in_dim, in
   }
 }
 
-template <bool BF16, int KP>
+template <int BF16, int KP>
 __global__ __launch_bounds__(256, 2) void k_nf_prop_bwd(long long M, int in_dim, int H, const void* __restrict__ X, int ldx,
                                                         const float* __restrict__ W0, int ldw0, const float* __restrict__ b0,
                                                         const float* __restrict__ w1, int ldw1, const float* __restrict__ raw,
@@ -686,8 +690,8 @@ __global__ __launch_bounds__(256, 2) void k_nf_prop_bwd(long long M, int in_dim,
 #pragma unroll
         for (int c = 0; c < KP / 8; ++c) {
           uint4 u;
-          u.x = f_to_bf16(dx[c * 8]) | ((uint32_t)f_to_bf16(dx[c * 8 + 1]) << 16); u.y = f_to_bf16(dx[c * 8 + 2]) | ((uint32_t)f_to_bf16(dx[c * 8 + 3]) << 16);
-          u.z = f_to_bf16(dx[c * 8 + 4]) | ((uint32_t)f_to_bf16(dx[c * 8 + 5]) << 16); u.w = f_to_bf16(dx[c * 8 + 6]) | ((uint32_t)f_to_bf16(dx[c * 8 + 7]) << 16);
+          u.x = f2_to_op16(dx[c * 8], dx[c * 8 + 1], BF16); u.y = f2_to_op16(dx[c * 8 + 2], dx[c * 8 + 3], BF16);
+          u.z = f2_to_op16(dx[c * 8 + 4], dx[c * 8 + 5], BF16); u.w = f2_to_op16(dx[c * 8 + 6], dx[c * 8 + 7], BF16);
           *(uint4*)((uint16_t*)dX + (size_t)m * ldx + c * 8) = u;
         }
       } else {
@@ -766,8 +770,9 @@ extern "C" int hugs_nf_prop_fwd(long long M, int in_dim, int hidden, int dtype, 
   const int grid = (int)((M + 255) / 256 < 2048 ? (M + 255) / 256 : 2048);
   hipStream_t st = (hipStream_t)stream;
 #define PM_FWD(B, K) hipLaunchKernelGGL((k_nf_prop_fwd<B, K>), dim3(grid), dim3(256), 0, st, M, in_dim, hidden, X, ldx, W0, ldw0, b0, w1, ldw1, b1, sel, raw, density)
-  if (dtype) { if (KP == 16) PM_FWD(true, 16); else PM_FWD(true, 32); }
-  else { if (KP == 16) PM_FWD(false, 16); else PM_FWD(false, 32); }
+  if (dtype == 2) { if (KP == 16) PM_FWD(2, 16); else PM_FWD(2, 32); }
+  else if (dtype) { if (KP == 16) PM_FWD(1, 16); else PM_FWD(1, 32); }
+  else { if (KP == 16) PM_FWD(0, 16); else PM_FWD(0, 32); }
 #undef PM_FWD
   HUGS_CHECK_LAUNCH("hugs_nf_prop_fwd");
   return 0;
@@ -785,8 +790,9 @@ extern "C" int hugs_nf_prop_bwd(long long M, int in_dim, int hidden, int dtype, 
   hipStream_t st = (hipStream_t)stream;
   float* slab = (float*)ws;
 #define PM_BWD(B, K) hipLaunchKernelGGL((k_nf_prop_bwd<B, K>), dim3(grid), dim3(256), 0, st, M, in_dim, hidden, X, ldx, W0, ldw0, b0, w1, ldw1, raw, sel, d_density, dX, slab)
-  if (dtype) { if (KP == 16) PM_BWD(true, 16); else PM_BWD(true, 32); }
-  else { if (KP == 16) PM_BWD(false, 16); else PM_BWD(false, 32); }
+  if (dtype == 2) { if (KP == 16) PM_BWD(2, 16); else PM_BWD(2, 32); }
+  else if (dtype) { if (KP == 16) PM_BWD(1, 16); else PM_BWD(1, 32); }
+  else { if (KP == 16) PM_BWD(0, 16); else PM_BWD(0, 32); }
 #undef PM_BWD
   hipLaunchKernelGGL(k_nf_prop_reduce, dim3((pm_slab_width(KP) + 63) / 64), dim3(256), 0, st, slab, grid, KP, in_dim, hidden, gW0, ldw0,
                      gb0, gw1, ldw1, gb1);
@@ -812,5 +818,85 @@ extern "C" int hugs_nf_adam(long long n, float* theta, const float* grad, float*
                             float eps, float bc1, float bc2, void* stream) {
   NF_LAUNCH1D(k_nf_adam, n, n, theta, grad, m, v, lr, b1, b2, eps, bc1, bc2);
   HUGS_CHECK_LAUNCH("hugs_nf_adam");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dynamic loss scaling for the fp16 mode: torch.cuda.amp.GradScaler as nerfacto/train.py:168,210-213 drives it
+// (scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()), entirely on the device -- no host read of
+// found_inf.  state[0] = scale, state[1] = growth tracker, state[2] = found_inf of the step in flight (fp32).
+//   hugs_amp_check   : state[2] = 1 if any gradient in the range is non-finite (the unscale_ pass's inf check)
+//   hugs_amp_prepare : per parameter group, the bias corrections of ITS next update from its own update count (torch keeps
+//                      `step` per parameter; a skipped step does not advance it), in double like torch's Python scalars
+//   hugs_nf_adam_amp : torch.optim.Adam on grad / scale; does nothing when state[2] != 0 (scaler.step skips optimizer.step)
+//   hugs_amp_update  : counts of the groups that took part += 1 unless skipped; scale *= backoff on overflow, *= growth
+//                      after `interval` clean steps in a row (torch._amp_update_scale_); clears found_inf
+// ------------------------------------------------------------------------------------------------
+__global__ void k_amp_check(long long n, const float* __restrict__ grad, float* __restrict__ state) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  bool bad = false;
+  if (i + 4 <= n) {
+    const float4 g = *(const float4*)(grad + i);
+    bad = !(fabsf(g.x) <= 3.4028234664e38f) || !(fabsf(g.y) <= 3.4028234664e38f) || !(fabsf(g.z) <= 3.4028234664e38f) || !(fabsf(g.w) <= 3.4028234664e38f);
+  } else {
+    for (long long k = i; k < n; ++k) bad = bad || !(fabsf(grad[k]) <= 3.4028234664e38f);
+  }
+  if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) state[2] = 1.f;
+}
+__global__ void k_amp_prepare(int ngroups, const float* __restrict__ counts, double b1, double b2, float* __restrict__ bc) {
+  const int g = threadIdx.x;
+  if (g >= ngroups) return;
+  const double k = (double)counts[g] + 1.0;
+  bc[2 * g] = (float)(1.0 - pow(b1, k));
+  bc[2 * g + 1] = (float)(1.0 - pow(b2, k));
+}
+__global__ void k_nf_adam_amp(long long n, float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m,
+                              float* __restrict__ v, float lr, float b1, float b2, float eps, const float* __restrict__ state,
+                              const float* __restrict__ bc) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || state[2] != 0.f) return;
+  const float inv = 1.f / state[0], bc1 = bc[0], bc2 = bc[1];
+  float g = grad[i] * inv;
+  if (g != g) g = 0.f;
+  const float mi = b1 * m[i] + (1.f - b1) * g, vi = b2 * v[i] + (1.f - b2) * g * g;
+  m[i] = mi; v[i] = vi;
+  theta[i] -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+}
+__global__ void k_amp_update(float* __restrict__ state, float* __restrict__ counts, unsigned group_mask, float growth, float backoff,
+                             float interval) {
+  if (threadIdx.x || blockIdx.x) return;
+  if (state[2] != 0.f) { state[0] *= backoff; state[1] = 0.f; }
+  else {
+    for (int g = 0; g < 32; ++g) if (group_mask >> g & 1u) counts[g] += 1.f;
+    const float t = state[1] + 1.f;
+    if (t >= interval) { state[0] *= growth; state[1] = 0.f; } else state[1] = t;
+  }
+  state[2] = 0.f;
+}
+
+extern "C" int hugs_amp_check(long long n, const float* grad, float* state, void* stream) {
+  HUGS_REQUIRE(grad && state && ((uintptr_t)grad & 15) == 0, -2, "hugs_amp_check: null or unaligned pointer");
+  NF_LAUNCH1D(k_amp_check, (n + 3) / 4, n, grad, state);
+  HUGS_CHECK_LAUNCH("hugs_amp_check");
+  return 0;
+}
+extern "C" int hugs_amp_prepare(int ngroups, const float* counts, float b1, float b2, float* bc, void* stream) {
+  HUGS_REQUIRE(ngroups >= 1 && ngroups <= 32 && counts && bc, -2, "hugs_amp_prepare: %d groups (1..32)", ngroups);
+  hipLaunchKernelGGL(k_amp_prepare, dim3(1), dim3(32), 0, (hipStream_t)stream, ngroups, counts, (double)b1, (double)b2, bc);
+  HUGS_CHECK_LAUNCH("hugs_amp_prepare");
+  return 0;
+}
+extern "C" int hugs_nf_adam_amp(long long n, float* theta, const float* grad, float* m, float* v, float lr, float b1, float b2,
+                                float eps, const float* state, const float* bc, void* stream) {
+  NF_LAUNCH1D(k_nf_adam_amp, n, n, theta, grad, m, v, lr, b1, b2, eps, state, bc);
+  HUGS_CHECK_LAUNCH("hugs_nf_adam_amp");
+  return 0;
+}
+extern "C" int hugs_amp_update(float* state, float* counts, unsigned group_mask, float growth, float backoff, float interval,
+                               void* stream) {
+  HUGS_REQUIRE(state && counts, -2, "hugs_amp_update: null pointer");
+  hipLaunchKernelGGL(k_amp_update, dim3(1), dim3(64), 0, (hipStream_t)stream, state, counts, group_mask, growth, backoff, interval);
+  HUGS_CHECK_LAUNCH("hugs_amp_update");
   return 0;
 }

@@ -137,7 +137,7 @@ __global__ void k_opt_finalize2(int nleaf, const int4* __restrict__ leaf_info, c
 }
 
 // W fp32 [K,N] -> Wn (natural, [K,N]) and Wt (transposed, [N,K]) in the compute dtype. 32x32 LDS tiles.
-template <bool BF16>
+template <int BF16>
 __global__ __launch_bounds__(256) void k_cast_weights(int K, int N, const float* __restrict__ W, void* __restrict__ Wn,
                                                       void* __restrict__ Wt) {
   __shared__ float tile[32][33];
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_cast_weights(int K, int N, const float*
     float x = 0.f;
     if (k < K && n < N) {
       x = W[(size_t)k * N + n];
-      if (Wn) { if (BF16) ((uint16_t*)Wn)[(size_t)k * N + n] = f_to_bf16(x); else ((float*)Wn)[(size_t)k * N + n] = x; }
+      if (Wn) { if (BF16) ((uint16_t*)Wn)[(size_t)k * N + n] = f_to_op16(x, BF16); else ((float*)Wn)[(size_t)k * N + n] = x; }
     }
     tile[r][tx] = x;
   }
@@ -158,14 +158,14 @@ __global__ __launch_bounds__(256) void k_cast_weights(int K, int N, const float*
       const int n = n0 + r, k = k0 + tx;
       if (k < K && n < N) {
         const float x = tile[tx][r];
-        if (BF16) ((uint16_t*)Wt)[(size_t)n * K + k] = f_to_bf16(x); else ((float*)Wt)[(size_t)n * K + k] = x;
+        if (BF16) ((uint16_t*)Wt)[(size_t)n * K + k] = f_to_op16(x, BF16); else ((float*)Wt)[(size_t)n * K + k] = x;
       }
     }
 }
 
 // The same cast for a table of matrices in ONE launch (a train step refreshes 14 operand pairs: 14 launches of ~5 us).
 struct CastItem { const float* W; void* Wn; void* Wt; int K, N, blk0, nbx; };
-template <bool BF16>
+template <int BF16>
 __global__ __launch_bounds__(256) void k_cast_weights_batch(int nitems, const CastItem* __restrict__ items) {
   __shared__ float tile[32][33];
   int it = 0;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k_cast_weights_batch(int nitems, const Ca
     float x = 0.f;
     if (k < K && n < N) {
       x = I.W[(size_t)k * N + n];
-      if (I.Wn) { if (BF16) ((uint16_t*)I.Wn)[(size_t)k * N + n] = f_to_bf16(x); else ((float*)I.Wn)[(size_t)k * N + n] = x; }
+      if (I.Wn) { if (BF16) ((uint16_t*)I.Wn)[(size_t)k * N + n] = f_to_op16(x, BF16); else ((float*)I.Wn)[(size_t)k * N + n] = x; }
     }
     tile[r][tx] = x;
   }
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_cast_weights_batch(int nitems, const Ca
       const int n = n0 + r, k = k0 + tx;
       if (k < K && n < N) {
         const float x = tile[tx][r];
-        if (BF16) ((uint16_t*)I.Wt)[(size_t)n * K + k] = f_to_bf16(x); else ((float*)I.Wt)[(size_t)n * K + k] = x;
+        if (BF16) ((uint16_t*)I.Wt)[(size_t)n * K + k] = f_to_op16(x, BF16); else ((float*)I.Wt)[(size_t)n * K + k] = x;
       }
     }
 }
@@ -221,8 +221,9 @@ extern "C" int hugs_opt_adam(int nchunks, int nleaf, const void* chunks, const v
 
 extern "C" int hugs_cast_weights_batch(int dtype, int nitems, const void* items, int total_blocks, void* stream) {
   if (nitems <= 0 || total_blocks <= 0) return 0;
-  if (dtype) hipLaunchKernelGGL(k_cast_weights_batch<true>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, nitems, (const CastItem*)items);
-  else hipLaunchKernelGGL(k_cast_weights_batch<false>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, nitems, (const CastItem*)items);
+  if (dtype == 2) hipLaunchKernelGGL(k_cast_weights_batch<2>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, nitems, (const CastItem*)items);
+  else if (dtype) hipLaunchKernelGGL(k_cast_weights_batch<1>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, nitems, (const CastItem*)items);
+  else hipLaunchKernelGGL(k_cast_weights_batch<0>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, nitems, (const CastItem*)items);
   HUGS_CHECK_LAUNCH("hugs_cast_weights_batch");
   return 0;
 }
@@ -230,8 +231,9 @@ extern "C" int hugs_cast_weights_batch(int dtype, int nitems, const void* items,
 extern "C" int hugs_cast_weights(int dtype, int K, int N, const float* W, void* Wn, void* Wt, void* stream) {
   if (K <= 0 || N <= 0) return 0;
   dim3 grid((N + 31) / 32, (K + 31) / 32);
-  if (dtype) hipLaunchKernelGGL(k_cast_weights<true>, grid, dim3(256), 0, (hipStream_t)stream, K, N, W, Wn, Wt);
-  else hipLaunchKernelGGL(k_cast_weights<false>, grid, dim3(256), 0, (hipStream_t)stream, K, N, W, Wn, Wt);
+  if (dtype == 2) hipLaunchKernelGGL(k_cast_weights<2>, grid, dim3(256), 0, (hipStream_t)stream, K, N, W, Wn, Wt);
+  else if (dtype) hipLaunchKernelGGL(k_cast_weights<1>, grid, dim3(256), 0, (hipStream_t)stream, K, N, W, Wn, Wt);
+  else hipLaunchKernelGGL(k_cast_weights<0>, grid, dim3(256), 0, (hipStream_t)stream, K, N, W, Wn, Wt);
   HUGS_CHECK_LAUNCH("hugs_cast_weights");
   return 0;
 }

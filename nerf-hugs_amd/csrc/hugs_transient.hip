@@ -7,7 +7,7 @@
 namespace {
 
 // X[n, :] = [x0, x1, sin(2^k x_c), sin(2^k x_c + pi/2), tra[n, :], 0 ...]   (coord.py:136-147 layout: k-major, c-minor)
-template <bool BF16>
+template <int BF16>
 __global__ void __launch_bounds__(256)
 k_mask_input(int N, int T, int deg, const float* __restrict__ pix, const float* __restrict__ tra, int kpad,
              void* __restrict__ X) {
@@ -27,17 +27,17 @@ k_mask_input(int N, int T, int deg, const float* __restrict__ pix, const float* 
   } else if (f < E + T) {
     v = tra ? tra[(size_t)n * T + (f - E)] : 0.f;
   }
-  if (BF16) ((uint16_t*)X)[i] = f_to_bf16(v);
+  if (BF16) ((uint16_t*)X)[i] = f_to_op16(v, BF16);
   else ((float*)X)[i] = v;
 }
 
-template <bool BF16>
+template <int BF16>
 __device__ __forceinline__ float ldx(const void* X, size_t i) {
-  return BF16 ? bf16_to_f(((const uint16_t*)X)[i]) : ((const float*)X)[i];
+  return BF16 ? op16_to_f(((const uint16_t*)X)[i], BF16) : ((const float*)X)[i];
 }
 
 // mask[n] = sigmoid(X[n,:] . w + b), one wave per ray
-template <bool BF16>
+template <int BF16>
 __global__ void __launch_bounds__(256)
 k_mask_head_fwd(int N, int W, const void* __restrict__ X, int ldxv, const float* __restrict__ w,
                 const float* __restrict__ b, float* __restrict__ mask) {
@@ -60,7 +60,7 @@ k_mask_head_draw(int N, int Npad, const float* __restrict__ mask, const float* _
 }
 
 // dW[k] = sum_n d_raw[n] X[n,k]; db = sum_n d_raw[n].  One thread per column, fixed order (deterministic).
-template <bool BF16>
+template <int BF16>
 __global__ void __launch_bounds__(64)
 k_mask_head_dw(int N, int W, const void* __restrict__ X, int ldxv, const float* __restrict__ d_raw,
                float* __restrict__ dW, float* __restrict__ db) {
@@ -78,7 +78,7 @@ k_mask_head_dw(int N, int W, const void* __restrict__ X, int ldxv, const float* 
 }
 
 // d_embedding[embed_idx[n], :] += dX[n, col0 : col0+T]
-template <bool BF16>
+template <int BF16>
 __global__ void __launch_bounds__(256)
 k_embed_scatter(int N, int T, const void* __restrict__ dX, int ldxv, int col0, const int* __restrict__ embed_idx,
                 float* __restrict__ d_emb) {
@@ -145,8 +145,9 @@ extern "C" int hugs_mask_input_fwd(int N, int T, int deg, const float* pix_coord
                "hugs_mask_input_fwd: N=%d T=%d deg=%d kpad=%d", N, T, deg, kpad);
   if (N == 0) return 0;
   const int n = N * kpad;
-  if (dtype) k_mask_input<true><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(N, T, deg, pix_coords, tra_vec, kpad, X);
-  else k_mask_input<false><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(N, T, deg, pix_coords, tra_vec, kpad, X);
+  if (dtype == 2) k_mask_input<2><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(N, T, deg, pix_coords, tra_vec, kpad, X);
+  else if (dtype) k_mask_input<1><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(N, T, deg, pix_coords, tra_vec, kpad, X);
+  else k_mask_input<0><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(N, T, deg, pix_coords, tra_vec, kpad, X);
   HUGS_CHECK_LAUNCH("k_mask_input");
   return 0;
 }
@@ -154,8 +155,9 @@ extern "C" int hugs_mask_input_fwd(int N, int T, int deg, const float* pix_coord
 extern "C" int hugs_mask_head_fwd(int dtype, int N, int W, const void* X, int ldx, const float* w, const float* b,
                                   float* mask, void* stream) {
   if (N <= 0) return 0;
-  if (dtype) k_mask_head_fwd<true><<<(N + 3) / 4, 256, 0, (hipStream_t)stream>>>(N, W, X, ldx, w, b, mask);
-  else k_mask_head_fwd<false><<<(N + 3) / 4, 256, 0, (hipStream_t)stream>>>(N, W, X, ldx, w, b, mask);
+  if (dtype == 2) k_mask_head_fwd<2><<<(N + 3) / 4, 256, 0, (hipStream_t)stream>>>(N, W, X, ldx, w, b, mask);
+  else if (dtype) k_mask_head_fwd<1><<<(N + 3) / 4, 256, 0, (hipStream_t)stream>>>(N, W, X, ldx, w, b, mask);
+  else k_mask_head_fwd<0><<<(N + 3) / 4, 256, 0, (hipStream_t)stream>>>(N, W, X, ldx, w, b, mask);
   HUGS_CHECK_LAUNCH("k_mask_head_fwd");
   return 0;
 }
@@ -167,8 +169,9 @@ extern "C" int hugs_mask_head_bwd(int dtype, int N, int Npad, int W, const void*
   if (Npad == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   k_mask_head_draw<<<(Npad + 255) / 256, 256, 0, st>>>(N, Npad, mask, d_mask, d_raw);
-  if (dtype) k_mask_head_dw<true><<<W / 64 + 1, 64, 0, st>>>(N, W, X, ldx, d_raw, dW, db);
-  else k_mask_head_dw<false><<<W / 64 + 1, 64, 0, st>>>(N, W, X, ldx, d_raw, dW, db);
+  if (dtype == 2) k_mask_head_dw<2><<<W / 64 + 1, 64, 0, st>>>(N, W, X, ldx, d_raw, dW, db);
+  else if (dtype) k_mask_head_dw<1><<<W / 64 + 1, 64, 0, st>>>(N, W, X, ldx, d_raw, dW, db);
+  else k_mask_head_dw<0><<<W / 64 + 1, 64, 0, st>>>(N, W, X, ldx, d_raw, dW, db);
   HUGS_CHECK_LAUNCH("k_mask_head_bwd");
   return 0;
 }
@@ -177,8 +180,9 @@ extern "C" int hugs_embed_scatter_add(int dtype, int N, int T, const void* dX, i
                                       float* d_embedding, void* stream) {
   if (N <= 0 || T <= 0) return 0;
   const int n = N * T;
-  if (dtype) k_embed_scatter<true><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(N, T, dX, ldx, col0, embed_idx, d_embedding);
-  else k_embed_scatter<false><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(N, T, dX, ldx, col0, embed_idx, d_embedding);
+  if (dtype == 2) k_embed_scatter<2><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(N, T, dX, ldx, col0, embed_idx, d_embedding);
+  else if (dtype) k_embed_scatter<1><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(N, T, dX, ldx, col0, embed_idx, d_embedding);
+  else k_embed_scatter<0><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(N, T, dX, ldx, col0, embed_idx, d_embedding);
   HUGS_CHECK_LAUNCH("k_embed_scatter");
   return 0;
 }
@@ -349,7 +353,7 @@ k_dual_composite_bwd(int nrays, int S, const float* __restrict__ dens_s, const f
 }
 
 // G[m,n] += (r1[m] c1[n] + r2[m] c2[n]) * (X[m,n] > 0)
-template <bool BF16>
+template <int BF16>
 __global__ void __launch_bounds__(256)
 k_rank1_add2_mask(int M, int N, const float* __restrict__ r1, const float* __restrict__ c1, const float* __restrict__ r2,
                   const float* __restrict__ c2, const void* __restrict__ X, int ldxv, void* __restrict__ G, int ldg) {
@@ -361,7 +365,7 @@ k_rank1_add2_mask(int M, int N, const float* __restrict__ r1, const float* __res
     const float add = r1[m] * c1[n] + r2[m] * c2[n];
     if (BF16) {
       uint16_t* g = (uint16_t*)G + (size_t)m * ldg + n;
-      *g = f_to_bf16(bf16_to_f(*g) + add);
+      *g = f_to_op16(op16_to_f(*g, BF16) + add, BF16);
     } else {
       ((float*)G)[(size_t)m * ldg + n] += add;
     }
@@ -444,8 +448,9 @@ extern "C" int hugs_rank1_add2_mask(int dtype, int M, int N, const float* r1, co
                                     const float* c2, const void* X, int ldx, void* G, int ldg, void* stream) {
   const size_t n = (size_t)M * N;
   if (n == 0) return 0;
-  if (dtype) k_rank1_add2_mask<true><<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(M, N, r1, c1, r2, c2, X, ldx, G, ldg);
-  else k_rank1_add2_mask<false><<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(M, N, r1, c1, r2, c2, X, ldx, G, ldg);
+  if (dtype == 2) k_rank1_add2_mask<2><<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(M, N, r1, c1, r2, c2, X, ldx, G, ldg);
+  else if (dtype) k_rank1_add2_mask<1><<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(M, N, r1, c1, r2, c2, X, ldx, G, ldg);
+  else k_rank1_add2_mask<0><<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(M, N, r1, c1, r2, c2, X, ldx, G, ldg);
   HUGS_CHECK_LAUNCH("k_rank1_add2_mask");
   return 0;
 }

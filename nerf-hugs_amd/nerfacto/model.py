@@ -123,8 +123,14 @@ class NerfactoModel:
       raise L.HugsError('no GPU visible: the hugs path has no CPU fallback')
     L.lib()
     self.cfg, self.device = cfg, torch.device(device)
-    self.dt = 1 if compute_dtype == 'bf16' else 0
-    self.tdt = torch.bfloat16 if self.dt else torch.float32
+    if compute_dtype not in ('fp32', 'bf16', 'fp16'):
+      raise ValueError(f"compute_dtype {compute_dtype!r}: 'fp32' (parity), 'bf16' or 'fp16' (the reference's enable_amp)")
+    self.dt = {'fp32': 0, 'bf16': 1, 'fp16': 2}[compute_dtype]
+    self.tdt = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}[self.dt]
+    # fp16 mode = the reference's `enable_amp: True` (phototourism_nerfacto_base.yml:3): half MFMA operands and activations,
+    # half copies of the hash tables for the forward gathers (tiny-cuda-nn's parameter precision), fp32 master parameters and
+    # accumulation, and torch.cuda.amp.GradScaler's dynamic loss scale (train.py:168,210-213) kept on the device
+    self.amp = self.dt == 2
     self.ws = Workspace(self.device)
     self.L = cfg.num_proposal_iterations
     self.lay = _Layout()
@@ -179,6 +185,14 @@ class NerfactoModel:
     self.grad = torch.zeros_like(self.flat)
     self.step = 0
     self.wt, self.wn = {}, {}
+    if self.amp:
+      # GradScaler defaults (torch/amp/grad_scaler.py): init_scale 2^16, growth 2, backoff 0.5, growth_interval 2000
+      self.amp_state = torch.tensor([65536.0, 0.0, 0.0], device=self.device)       # scale, growth tracker, found_inf
+      self.amp_opts = dict(growth_factor=2.0, backoff_factor=0.5, growth_interval=2000)
+      self.amp_counts = torch.zeros(32, device=self.device)                         # Adam updates taken, per group
+      self.amp_bc = torch.zeros(64, device=self.device)
+      self.group_order = [g for g, _ in sorted(self.groups.items(), key=lambda kv: kv[1][0])]
+      self.flat_h = torch.zeros(self.lay.size, dtype=torch.float16, device=self.device)     # half copy (tables are read from it)
     self._init(seed)
     self.refresh_weights()
 
@@ -236,6 +250,8 @@ class NerfactoModel:
     return out
 
   def refresh_weights(self):
+    if self.amp:
+      self.flat_h.copy_(self.flat)             # one cast of the whole buffer; only the table ranges are read from it
     for name, (off, pshape, shape) in self.lay.items.items():
       leaf = name.split('/')[-1]
       if len(pshape) == 2 and leaf != 'table' and name not in ('appearance', 'transient', 'mask/m2'):
@@ -292,8 +308,12 @@ class NerfactoModel:
   def _grid_fwd(self, name, x01, X0):
     g = self.grids[name]
     o, r, s = g._tables()
-    L.call('hugs_hashgrid_fwd', x01.shape[0], g.n_levels, g.features, o, r, s, x01, self.lay.view(self.flat, f'{name}/table'),
-           self.dt, X0.stride(0), X0)
+    if self.amp:
+      L.call('hugs_hashgrid_fwd_t', x01.shape[0], g.n_levels, g.features, o, r, s, x01, self.lay.view(self.flat_h, f'{name}/table'), 2,
+             self.dt, X0.stride(0), X0)
+    else:
+      L.call('hugs_hashgrid_fwd', x01.shape[0], g.n_levels, g.features, o, r, s, x01, self.lay.view(self.flat, f'{name}/table'),
+             self.dt, X0.stride(0), X0)
 
   def _grid_bwd(self, name, x01, dX0):
     g = self.grids[name]
@@ -547,6 +567,16 @@ class NerfactoModel:
       L.call('hugs_distortion', N, Sf, fin['sbins'], fin['weights'], c.distortion_loss_mult / N, loss_ray, d_w[self.L])
       L.call('hugs_sum', N, loss_ray, c.distortion_loss_mult / N, stats[8:9])
     # ---- backward ----
+    if self.amp:
+      # scaler.scale(loss).backward(): every gradient seed times the current scale (a device scalar: no host read); the
+      # loss VALUES above are unscaled.  Adam divides it out again (apply_gradients)
+      sc = self.amp_state[0:1]
+      d_pred.mul_(sc)
+      for d in d_w:
+        if d is not None:
+          d.mul_(sc)
+      if d_mask is not None:
+        d_mask.mul_(sc)
     self.grad.zero_()
     want = lambda group: self.trainable is None or group in self.trainable
     for l in range(self.L, -1, -1):
@@ -597,6 +627,9 @@ class NerfactoModel:
                     betas=tuple(betas), eps=eps)
     self.m.zero_(); self.v.zero_()
     self.counts, self._updates = {}, 0
+    if self.amp:
+      self.amp_counts.zero_()              # a new optimizer and a new GradScaler per stage (train.py:159-168)
+      self.amp_state.copy_(torch.tensor([65536.0, 0.0, 0.0]))
 
   def apply_gradients(self, prop_updated=True):
     """optimizer.step() + scheduler.step() (train.py:213-215): the k-th scheduler step's factor applies to update k.
@@ -607,6 +640,8 @@ class NerfactoModel:
     o = self._opt()
     k_sched = getattr(self, '_updates', 0)
     lr, (b1, b2) = self.lr(k_sched), o['betas']
+    if self.amp:
+      return self._apply_gradients_amp(prop_updated, lr, b1, b2, o['eps'], k_sched)
     todo = []
     for gname, (lo, hi) in sorted(self.groups.items(), key=lambda kv: kv[1][0]):
       if hi <= lo or (self.trainable is not None and gname not in self.trainable) or (gname == 'proposal' and not prop_updated):
@@ -622,6 +657,30 @@ class NerfactoModel:
              1.0 - b1**(k + 1), 1.0 - b2**(k + 1))
     self._updates = k_sched + 1
     self.refresh_weights()
+
+  def _apply_gradients_amp(self, prop_updated, lr, b1, b2, eps, k_sched):
+    """scaler.step(optimizer); scaler.update(); scheduler.step() (train.py:211-214) without a host read: the inf check, the
+    skip, the per-group update counts and the scale update all stay on the device (csrc/hugs_nerfacto.hip k_amp_*).  The
+    scheduler advances whether or not the step was skipped, as the reference's does."""
+    part = [(gi, gname) + self.groups[gname] for gi, gname in enumerate(self.group_order)
+            if self.groups[gname][1] > self.groups[gname][0] and (self.trainable is None or gname in self.trainable)
+            and not (gname == 'proposal' and not prop_updated)]
+    for gi, gname, lo, hi in part:
+      L.call('hugs_amp_check', hi - lo, self.grad[lo:hi], self.amp_state)
+    L.call('hugs_amp_prepare', len(self.group_order), self.amp_counts, b1, b2, self.amp_bc)
+    mask = 0
+    for gi, gname, lo, hi in part:
+      L.call('hugs_nf_adam_amp', hi - lo, self.flat[lo:hi], self.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], lr, b1, b2, eps,
+             self.amp_state, self.amp_bc[2 * gi:2 * gi + 2])
+      mask |= 1 << gi
+    a = self.amp_opts
+    L.call('hugs_amp_update', self.amp_state, self.amp_counts, mask, a['growth_factor'], a['backoff_factor'], float(a['growth_interval']))
+    self._updates = k_sched + 1
+    self.refresh_weights()
+
+  def loss_scale(self):
+    """GradScaler.get_scale() (fp16 mode; a host read)."""
+    return float(self.amp_state[0]) if self.amp else 1.0
 
   def _backward_level(self, st, rays, N, d_rgb_out, d_w_extra):
     c, ws, dt = self.cfg, self.ws, self.dt

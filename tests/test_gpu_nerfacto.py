@@ -373,8 +373,10 @@ def test_cfg5_yml_sizes_vs_oracle():
       assert err < 1e-2, f'cfg5 grad {name}/{k}: rel err {err:.2e} (max |g| {sc:.2e})'
 
 
-def test_cfg5_16384_rays_bf16_properties():
-  """The benchmarked configuration itself (16384 rays x (512 + 256 + 128) samples, yml-size model, bf16 operands): every
+@pytest.mark.parametrize('cdt', ['bf16', 'fp16'])
+def test_cfg5_16384_rays_bf16_properties(cdt):
+  """The benchmarked configuration itself (16384 rays x (512 + 256 + 128) samples, yml-size model; bf16 operands, and the
+  fp16 mode = the reference's enable_amp that `bench.py --config cfg5` reports): every
   statistic finite, the rgb loss falls over 30 steps, and two runs from the same seed agree (float atomics in the table
   gradients make the low bits order-dependent: close, not bit-wise)."""
   from nerf_hugs_amd.nerfacto.model import NerfactoConfig, NerfactoModel
@@ -382,7 +384,7 @@ def test_cfg5_16384_rays_bf16_properties():
   N = 16384
   runs = []
   for rep in range(2):
-    model = NerfactoModel(NerfactoConfig(**dict(YML, warmup_steps=10)), compute_dtype='bf16', seed=3)
+    model = NerfactoModel(NerfactoConfig(**dict(YML, warmup_steps=10)), compute_dtype=cdt, seed=3)
     g = torch.Generator(device=dev).manual_seed(100)
     d = torch.randn(N, 3, generator=g, device=dev); d = d / d.norm(dim=-1, keepdim=True)
     # a learnable target: colour is a smooth function of the ray
