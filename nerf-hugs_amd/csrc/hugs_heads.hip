@@ -231,21 +231,25 @@ __global__ __launch_bounds__(256) void k_rgb_fwd(int M, int H, const void* __res
 // backward: dz[c] = d_rgb[c] * (1+2pad) * s(1-s), s = (rgb+pad)/(1+2pad)
 //   G[m,j] = (h[m,j] > 0) * sum_c dz[c] W[j,c]     (gradient at the view layer's pre-activation)
 //   slab[blk] accumulates dW[j,c] = sum_m h[m,j] dz[m,c] and db[c] = sum_m dz[m,c]
-template <int BF16>
-__global__ __launch_bounds__(256) void k_rgb_bwd(int M, int H, int rows_per_blk, const void* __restrict__ Hact, int ldh,
+// H = 128 P (P = 1: the Mip-NeRF 360 view layer; P = 2: nerfacto's 256-wide colour MLP): 16 lanes per row, lane `sub` owns the
+// P chunks of 8 consecutive j at p * 128 + sub * 8.
+template <int BF16, int P>
+__global__ __launch_bounds__(256) void k_rgb_bwd(int M, int rows_per_blk, const void* __restrict__ Hact, int ldh,
                                                  const float* __restrict__ W, const float* __restrict__ rgb,
                                                  const float* __restrict__ d_rgb, float pad, void* __restrict__ G,
                                                  int ldg, float* __restrict__ slab) {
-  // 16 lanes per row, each lane 8 consecutive j (H == 128); a block walks rows_per_blk rows, 16 at a time
+  constexpr int H = 128 * P;
   const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const int m0 = blockIdx.x * rows_per_blk, m1 = min(M, m0 + rows_per_blk);
-  const int j0 = sub * 8;
-  float w[8][3];
+  float w[P][8][3], dW[P][8][3];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) { w[q][0] = W[(j0 + q) * 3]; w[q][1] = W[(j0 + q) * 3 + 1]; w[q][2] = W[(j0 + q) * 3 + 2]; }
-  float dW[8][3];
+  for (int p = 0; p < P; ++p)
 #pragma unroll
-  for (int q = 0; q < 8; ++q) dW[q][0] = dW[q][1] = dW[q][2] = 0.f;
+    for (int q = 0; q < 8; ++q) {
+      const int j = p * 128 + sub * 8 + q;
+      w[p][q][0] = W[j * 3]; w[p][q][1] = W[j * 3 + 1]; w[p][q][2] = W[j * 3 + 2];
+      dW[p][q][0] = dW[p][q][1] = dW[p][q][2] = 0.f;
+    }
   float db[3] = {0.f, 0.f, 0.f};
   const float sc = 1.f + 2.f * pad;
   for (int m = m0 + grp; m < m1; m += 16) {
@@ -255,27 +259,36 @@ __global__ __launch_bounds__(256) void k_rgb_bwd(int M, int H, int rows_per_blk,
       const float s = (rgb[(size_t)m * 3 + c] + pad) / sc;
       dz[c] = d_rgb[(size_t)m * 3 + c] * sc * s * (1.f - s);
     }
-    float h[8], g[8];
-    load8<BF16>(Hact, (size_t)m * ldh + j0, h);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      g[q] = h[q] > 0.f ? dz[0] * w[q][0] + dz[1] * w[q][1] + dz[2] * w[q][2] : 0.f;
-      dW[q][0] += h[q] * dz[0]; dW[q][1] += h[q] * dz[1]; dW[q][2] += h[q] * dz[2];
+    for (int p = 0; p < P; ++p) {
+      const int j0 = p * 128 + sub * 8;
+      float h[8], g[8];
+      load8<BF16>(Hact, (size_t)m * ldh + j0, h);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        g[q] = h[q] > 0.f ? dz[0] * w[p][q][0] + dz[1] * w[p][q][1] + dz[2] * w[p][q][2] : 0.f;
+        dW[p][q][0] += h[q] * dz[0]; dW[p][q][1] += h[q] * dz[1]; dW[p][q][2] += h[q] * dz[2];
+      }
+      store8<BF16>(G, (size_t)m * ldg + j0, g);
     }
-    store8<BF16>(G, (size_t)m * ldg + j0, g);
     if (sub == 0) { db[0] += dz[0]; db[1] += dz[1]; db[2] += dz[2]; }
   }
   // reduce the 16 row-groups of the block through LDS in a fixed order
-  __shared__ float red[16][128 * 3 + 4];
+  __shared__ float red[16][H * 3 + 4];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) { red[grp][(j0 + q) * 3] = dW[q][0]; red[grp][(j0 + q) * 3 + 1] = dW[q][1]; red[grp][(j0 + q) * 3 + 2] = dW[q][2]; }
-  if (sub == 0) { red[grp][384] = db[0]; red[grp][385] = db[1]; red[grp][386] = db[2]; }
+  for (int p = 0; p < P; ++p)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int j = p * 128 + sub * 8 + q;
+      red[grp][j * 3] = dW[p][q][0]; red[grp][j * 3 + 1] = dW[p][q][1]; red[grp][j * 3 + 2] = dW[p][q][2];
+    }
+  if (sub == 0) { red[grp][H * 3] = db[0]; red[grp][H * 3 + 1] = db[1]; red[grp][H * 3 + 2] = db[2]; }
   __syncthreads();
-  for (int i = threadIdx.x; i < 387; i += 256) {
+  for (int i = threadIdx.x; i < H * 3 + 3; i += 256) {
     float a = 0.f;
 #pragma unroll
     for (int gph = 0; gph < 16; ++gph) a += red[gph][i];
-    slab[(size_t)blockIdx.x * 388 + i] = a;
+    slab[(size_t)blockIdx.x * (H * 3 + 4) + i] = a;
   }
 }
 
@@ -378,21 +391,23 @@ extern "C" int hugs_rgb_fwd(int dtype, int M, int H, const void* Hact, int ldh, 
 }
 
 #define RGB_BLOCKS 1024
-extern "C" long long hugs_rgb_bwd_ws_bytes(void) { return (long long)RGB_BLOCKS * 388 * 4; }
+/* workspace of hugs_rgb_bwd for the widest head it takes (H = 256) */
+extern "C" long long hugs_rgb_bwd_ws_bytes(void) { return (long long)RGB_BLOCKS * (256 * 3 + 4) * 4; }
 
 extern "C" int hugs_rgb_bwd(int dtype, int M, int H, const void* Hact, int ldh, const float* W, const float* rgb,
                             const float* d_rgb, float pad, void* G, int ldg, float* dW, float* db, void* ws, void* stream) {
-  HUGS_REQUIRE(H == 128, -3, "hugs_rgb_bwd: view width %d unsupported (128)", H);
+  HUGS_REQUIRE(H == 128 || H == 256, -3, "hugs_rgb_bwd: head width %d unsupported (128 or 256)", H);
   if (M <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   int rpb = (M + RGB_BLOCKS - 1) / RGB_BLOCKS;
   rpb = (rpb + 15) / 16 * 16;
   const int nblk = (M + rpb - 1) / rpb;
   float* slab = (float*)ws;
-  if (dtype == 2) hipLaunchKernelGGL(k_rgb_bwd<2>, dim3(nblk), dim3(256), 0, st, M, H, rpb, Hact, ldh, W, rgb, d_rgb, pad, G, ldg, slab);
-  else if (dtype) hipLaunchKernelGGL(k_rgb_bwd<1>, dim3(nblk), dim3(256), 0, st, M, H, rpb, Hact, ldh, W, rgb, d_rgb, pad, G, ldg, slab);
-  else hipLaunchKernelGGL(k_rgb_bwd<0>, dim3(nblk), dim3(256), 0, st, M, H, rpb, Hact, ldh, W, rgb, d_rgb, pad, G, ldg, slab);
-  hipLaunchKernelGGL(k_slab_reduce_small, dim3(7), dim3(1024), 0, st, slab, nblk, 384, 388, dW, 3, db);
+#define RGB_BWD(DT_, P_) hipLaunchKernelGGL((k_rgb_bwd<DT_, P_>), dim3(nblk), dim3(256), 0, st, M, rpb, Hact, ldh, W, rgb, d_rgb, pad, G, ldg, slab)
+  if (H == 128) { if (dtype == 2) RGB_BWD(2, 1); else if (dtype) RGB_BWD(1, 1); else RGB_BWD(0, 1); }
+  else { if (dtype == 2) RGB_BWD(2, 2); else if (dtype) RGB_BWD(1, 2); else RGB_BWD(0, 2); }
+#undef RGB_BWD
+  hipLaunchKernelGGL(k_slab_reduce_small, dim3((H * 3 + 3 + 63) / 64), dim3(1024), 0, st, slab, nblk, H * 3, H * 3 + 4, dW, 3, db);
   HUGS_CHECK_LAUNCH("hugs_rgb_bwd");
   return 0;
 }

@@ -148,7 +148,15 @@ class NerfactoModel:
     self.napp = cfg.appearance_embedding_dim if cfg.use_appearance_embedding else 0
     self._add_net('field', g, [(g.n_output_dims, cfg.hidden_dim), (cfg.hidden_dim, 1 + cfg.geo_feat_dim)])
     hin = 16 + cfg.geo_feat_dim + self.napp
+    # the colour MLP's last layer (hidden -> 3) + sigmoid is ONE pass over the hidden activation (csrc/hugs_heads.hip k_rgb_fwd /
+    # k_rgb_bwd, the Mip-NeRF 360 rgb head's kernels) instead of a GEMM padded from 3 to 128 output columns: its weight is
+    # stored [hidden_padded, 3]
+    self.rgb_head = _rup(cfg.hidden_dim_color) in (128, 256) and os.environ.get('HUGS_NF_RGB_HEAD', '1') != '0'
     for j, (fi, fo) in enumerate([(hin, cfg.hidden_dim_color), (cfg.hidden_dim_color, cfg.hidden_dim_color), (cfg.hidden_dim_color, 3)]):
+      if j == 2 and self.rgb_head:
+        self.lay.add('field/c2', (_rup(fi), 3), (fi, 3))
+        self.lay.add('field/cb2', (3,), (3,))
+        continue
       self.lay.add(f'field/c{j}', (_rup(fi), _rup(fo)), (fi, fo))
       self.lay.add(f'field/cb{j}', (_rup(fo),), (fo,))
     if self.napp:
@@ -254,7 +262,7 @@ class NerfactoModel:
       self.flat_h.copy_(self.flat)             # one cast of the whole buffer; only the table ranges are read from it
     for name, (off, pshape, shape) in self.lay.items.items():
       leaf = name.split('/')[-1]
-      if len(pshape) == 2 and leaf != 'table' and name not in ('appearance', 'transient', 'mask/m2'):
+      if len(pshape) == 2 and leaf != 'table' and name not in ('appearance', 'transient', 'mask/m2') and not (name == 'field/c2' and self.rgb_head):
         K, N = pshape
         if name not in self.wt:
           self.wt[name] = torch.empty(N, K, dtype=self.tdt, device=self.device)
@@ -396,12 +404,18 @@ class NerfactoModel:
         Xh = ws.get('Xh', (M, Kh), self.tdt)
         L.call('hugs_nf_head_input', M, S, dt, sh, Y1, N1, c.geo_feat_dim, app, self.napp, Xh, Kh)
         H0, H1 = ws.get('H0', (M, H), self.tdt), ws.get('H1', (M, H), self.tdt)
-        Yc = ws.get('Yc', (M, self.lay.items['field/c2'][1][1]), self.tdt)
         self._nt(M, 'field/c0', Xh, self.lay.view(self.flat, 'field/cb0'), True, H0)
         self._nt(M, 'field/c1', H0, self.lay.view(self.flat, 'field/cb1'), True, H1)
-        self._nt(M, 'field/c2', H1, self.lay.view(self.flat, 'field/cb2'), False, Yc)
         rgb = ws.get('rgb_s', (M, 3))
-        L.call('hugs_nf_rgb_act', M, dt, Yc, Yc.shape[1], c.rgb_bias, rgb)
+        Yc = None
+        if self.rgb_head:
+          beff = ws.get('cb2_eff', (4,))
+          torch.add(self.lay.view(self.flat, 'field/cb2'), float(c.rgb_bias), out=beff[:3])      # sigmoid(raw + rgb_bias), nerfacto.py:711
+          L.call('hugs_rgb_fwd', dt, M, H, H1, H, self.lay.view(self.flat, 'field/c2'), beff, 0.0, rgb)
+        else:
+          Yc = ws.get('Yc', (M, self.lay.items['field/c2'][1][1]), self.tdt)
+          self._nt(M, 'field/c2', H1, self.lay.view(self.flat, 'field/cb2'), False, Yc)
+          L.call('hugs_nf_rgb_act', M, dt, Yc, Yc.shape[1], c.rgb_bias, rgb)
         st.update(rgb=rgb, Xh=Xh, H0=H0, H1=H1, Yc=Yc, app=app)
         rgb_out = ws.get('rgb_out', (N, 3))
       w = ws.get(f'w{lvl}', (N, S))
@@ -706,12 +720,17 @@ class NerfactoModel:
     dXh = None
     if st['rgb'] is not None:
       H = st['H0'].shape[1]
-      Nc = st['Yc'].shape[1]
-      Gc = ws.get('Gc', (M, Nc), self.tdt)
-      L.call('hugs_nf_rgb_grad', M, dt, st['rgb'], d_rgb_s, Gc, Nc)
-      self._tn(M, 'field/c2', st['H1'], Gc, 'field/cb2')
       G1 = ws.get('G1', (M, H), self.tdt)
-      self._nt(M, 'field/c2', Gc, None, False, G1, mask=st['H1'], transpose=True)
+      if self.rgb_head:
+        rws = ws.get('rgb_bwd_ws', (L.lib().cdll.hugs_rgb_bwd_ws_bytes() // 4,))
+        L.call('hugs_rgb_bwd', dt, M, H, st['H1'], H, self.lay.view(self.flat, 'field/c2'), st['rgb'], d_rgb_s, 0.0, G1, H,
+               self.lay.view(self.grad, 'field/c2'), self.lay.view(self.grad, 'field/cb2'), rws)
+      else:
+        Nc = st['Yc'].shape[1]
+        Gc = ws.get('Gc', (M, Nc), self.tdt)
+        L.call('hugs_nf_rgb_grad', M, dt, st['rgb'], d_rgb_s, Gc, Nc)
+        self._tn(M, 'field/c2', st['H1'], Gc, 'field/cb2')
+        self._nt(M, 'field/c2', Gc, None, False, G1, mask=st['H1'], transpose=True)
       self._tn(M, 'field/c1', st['H0'], G1, 'field/cb1')
       G0 = ws.get('G0', (M, H), self.tdt)
       self._nt(M, 'field/c1', G1, None, False, G0, mask=st['H0'], transpose=True)
