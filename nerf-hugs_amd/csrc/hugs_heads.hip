@@ -201,30 +201,58 @@ __global__ void k_glo_gather(int nrays, int ng, const float* __restrict__ embedd
   glo[i] = zero_glo ? 0.f : embedding[(size_t)embed_idx[i / ng] * ng + (i % ng)];
 }
 
-// ---- rgb head: 16 lanes per row (H = 128 -> 8 elements per lane) ----
-template <int BF16>
+// ---- rgb head: 16 lanes per row, lane `sub` owns the chunks of 8 consecutive k at p * 128 + sub * 8 ----
+// P > 0: H = 128 P and the lane's 24 P weights stay in registers while its group walks ROWS rows (P = 1 the Mip-NeRF 360 view
+// layer, P = 2 nerfacto's colour MLP: with the weights re-read from L1 for every row the pass ran at 2.6 TB/s); P = 0: any H.
+template <int BF16, int P>
 __global__ __launch_bounds__(256) void k_rgb_fwd(int M, int H, const void* __restrict__ Hact, int ldh,
                                                  const float* __restrict__ W /*[H,3]*/, const float* __restrict__ b,
                                                  float pad, float* __restrict__ rgb) {
+  constexpr int ROWS = P > 0 ? 8 : 1;
   const int sub = threadIdx.x & 15;
-  const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-  if (row >= M) return;   // whole 16-lane groups exit together
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-  for (int k0 = sub * 8; k0 < H; k0 += 128) {
-    float v[8];
-    load8<BF16>(Hact, (size_t)row * ldh + k0, v);
+  const long long row0 = (((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4) * ROWS;
+  if (row0 >= M) return;   // whole 16-lane groups exit together
+  float w[P > 0 ? P : 1][8][3];
+  if (P > 0) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      a0 += v[q] * W[(k0 + q) * 3]; a1 += v[q] * W[(k0 + q) * 3 + 1]; a2 += v[q] * W[(k0 + q) * 3 + 2];
-    }
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = p * 128 + sub * 8 + q;
+        w[p][q][0] = W[k * 3]; w[p][q][1] = W[k * 3 + 1]; w[p][q][2] = W[k * 3 + 2];
+      }
   }
+  const float sc = 1.f + 2.f * pad, b0 = b[0], b1 = b[1], b2 = b[2];
+#pragma unroll 2
+  for (int r = 0; r < ROWS; ++r) {
+    const long long row = row0 + r;
+    if (row >= M) break;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if (P > 0) {
 #pragma unroll
-  for (int d = 1; d < 16; d <<= 1) { a0 += __shfl_xor(a0, d); a1 += __shfl_xor(a1, d); a2 += __shfl_xor(a2, d); }
-  if (sub == 0) {
-    const float sc = 1.f + 2.f * pad;
-    rgb[row * 3] = sc / (1.f + expf(-(a0 + b[0]))) - pad;
-    rgb[row * 3 + 1] = sc / (1.f + expf(-(a1 + b[1]))) - pad;
-    rgb[row * 3 + 2] = sc / (1.f + expf(-(a2 + b[2]))) - pad;
+      for (int p = 0; p < P; ++p) {
+        float v[8];
+        load8<BF16>(Hact, (size_t)row * ldh + p * 128 + sub * 8, v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { a0 += v[q] * w[p][q][0]; a1 += v[q] * w[p][q][1]; a2 += v[q] * w[p][q][2]; }
+      }
+    } else {
+      for (int k0 = sub * 8; k0 < H; k0 += 128) {
+        float v[8];
+        load8<BF16>(Hact, (size_t)row * ldh + k0, v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          a0 += v[q] * W[(k0 + q) * 3]; a1 += v[q] * W[(k0 + q) * 3 + 1]; a2 += v[q] * W[(k0 + q) * 3 + 2];
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) { a0 += __shfl_xor(a0, d); a1 += __shfl_xor(a1, d); a2 += __shfl_xor(a2, d); }
+    if (sub == 0) {
+      rgb[row * 3] = sc / (1.f + expf(-(a0 + b0))) - pad;
+      rgb[row * 3 + 1] = sc / (1.f + expf(-(a1 + b1))) - pad;
+      rgb[row * 3 + 2] = sc / (1.f + expf(-(a2 + b2))) - pad;
+    }
   }
 }
 
@@ -382,10 +410,14 @@ extern "C" int hugs_rgb_fwd(int dtype, int M, int H, const void* Hact, int ldh, 
                             float* rgb, void* stream) {
   HUGS_REQUIRE(H % 8 == 0, -3, "hugs_rgb_fwd: H=%d must be a multiple of 8", H);
   if (M <= 0) return 0;
-  const int grid = (int)(((long long)M * 16 + 255) / 256);
-  if (dtype == 2) hipLaunchKernelGGL(k_rgb_fwd<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, H, Hact, ldh, W, b, pad, rgb);
-  else if (dtype) hipLaunchKernelGGL(k_rgb_fwd<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, H, Hact, ldh, W, b, pad, rgb);
-  else hipLaunchKernelGGL(k_rgb_fwd<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, H, Hact, ldh, W, b, pad, rgb);
+  const int P = H == 128 ? 1 : H == 256 ? 2 : 0;
+  const long long groups = P ? ((long long)M + 7) / 8 : (long long)M;
+  const int grid = (int)((groups * 16 + 255) / 256);
+#define RGB_FWD(DT_, P_) hipLaunchKernelGGL((k_rgb_fwd<DT_, P_>), dim3(grid), dim3(256), 0, (hipStream_t)stream, M, H, Hact, ldh, W, b, pad, rgb)
+#define RGB_FWD_DT(P_) do { if (dtype == 2) RGB_FWD(2, P_); else if (dtype) RGB_FWD(1, P_); else RGB_FWD(0, P_); } while (0)
+  if (P == 1) RGB_FWD_DT(1); else if (P == 2) RGB_FWD_DT(2); else RGB_FWD_DT(0);
+#undef RGB_FWD_DT
+#undef RGB_FWD
   HUGS_CHECK_LAUNCH("hugs_rgb_fwd");
   return 0;
 }

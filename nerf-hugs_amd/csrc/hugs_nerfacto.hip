@@ -371,6 +371,14 @@ __device__ __forceinline__ void nf_store8(void* p, size_t i, int bf16, const flo
   }
 }
 
+// element index -> (row, 8-column chunk): a shift when the chunks-per-row count is a power of two (every pitch the model uses),
+// one 32-bit division otherwise (a 64-bit division per thread was most of these kernels' time); totals stay below 2^32
+// (checked by the launchers).
+__device__ __forceinline__ void nf_row_chunk(unsigned e, unsigned cpr, unsigned& m, unsigned& c0) {
+  if ((cpr & (cpr - 1u)) == 0u) { const unsigned sh = 31u - (unsigned)__clz((int)cpr); m = e >> sh; c0 = (e & (cpr - 1u)) * 8u; }
+  else { m = e / cpr; c0 = (e - m * cpr) * 8u; }
+}
+
 // G[M, ldg] = gradient at the base MLP's output: column 0 = d_density * exp(clamp(raw, -15, 15)) * selector
 // (custom_functions.py:46-50), columns 1 .. ngeo = dXhead[:, geo_col0 ...] (the head's input gradient), the rest 0.
 __global__ void k_nf_base_grad(long long M, int bf16, const void* __restrict__ Y, int ldy, const float* __restrict__ sel,
@@ -387,18 +395,17 @@ __global__ void k_nf_base_grad(long long M, int bf16, const void* __restrict__ Y
     nf_store(G, (size_t)m * ldg + c, bf16, v);
     return;
   }
-  const int cpr = ldg >> 3;
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long m = e / cpr;
-  const int c0 = (int)(e - m * cpr) * 8;
+  unsigned m, c0;
+  nf_row_chunk(blockIdx.x * blockDim.x + threadIdx.x, (unsigned)ldg >> 3, m, c0);
   if (m >= M) return;
-  float v[8];
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if ((int)c0 <= ngeo) {                           // (chunks behind the last real column are all zero: no loads)
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int c = c0 + q;
-    v[q] = 0.f;
-    if (c == 0) v[q] = d_density[m] * expf(fminf(fmaxf(nf_load(Y, (size_t)m * ldy, bf16), -15.f), 15.f)) * sel[m];
-    else if (c <= ngeo && dXh) v[q] = nf_load(dXh, (size_t)m * ldx + geo_col0 + c - 1, bf16);
+    for (int q = 0; q < 8; ++q) {
+      const int c = (int)c0 + q;
+      if (c == 0) v[q] = d_density[m] * expf(fminf(fmaxf(nf_load(Y, (size_t)m * ldy, bf16), -15.f), 15.f)) * sel[m];
+      else if (c <= ngeo && dXh) v[q] = nf_load(dXh, (size_t)m * ldx + geo_col0 + c - 1, bf16);
+    }
   }
   nf_store8(G, (size_t)m * ldg + c0, bf16, v);
 }
@@ -406,20 +413,24 @@ __global__ void k_nf_base_grad(long long M, int bf16, const void* __restrict__ Y
 // head input X[M, ldx] = [SH(viewdir) (16, per ray) | geo = Ybase[:, 1 .. ngeo] | appearance embedding (per ray) | 0 ...]
 __global__ void k_nf_head_input(long long M, int S, int bf16, const float* __restrict__ sh, const void* __restrict__ Yb, int ldy,
                                 int ngeo, const float* __restrict__ app, int napp, void* __restrict__ X, int ldx) {
-  const int cpr = ldx >> 3;                       // ldx is a multiple of 8 (checked by the launcher)
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long m = e / cpr;
-  const int c0 = (int)(e - m * cpr) * 8;
+  unsigned m, c0;                                 // ldx is a multiple of 8 (checked by the launcher)
+  nf_row_chunk(blockIdx.x * blockDim.x + threadIdx.x, (unsigned)ldx >> 3, m, c0);
   if (m >= M) return;
-  const long long ray = m / S;
-  float v[8];
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if ((int)c0 < 16 + ngeo + napp) {                // (the zero padding behind the last real column needs no loads)
+    const unsigned ray = ((unsigned)S & ((unsigned)S - 1u)) == 0u ? m >> (31u - (unsigned)__clz(S)) : m / (unsigned)S;
+    if (c0 + 8u <= 16u) {                          // a whole chunk of the per-ray SH block: two 16-byte loads
+      const float4 a = *(const float4*)(sh + (size_t)ray * 16 + c0), b = *(const float4*)(sh + (size_t)ray * 16 + c0 + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int c = c0 + q;
-    v[q] = 0.f;
-    if (c < 16) v[q] = sh[ray * 16 + c];
-    else if (c < 16 + ngeo) v[q] = nf_load(Yb, (size_t)m * ldy + 1 + (c - 16), bf16);
-    else if (c < 16 + ngeo + napp) v[q] = app[ray * napp + (c - 16 - ngeo)];
+      for (int q = 0; q < 8; ++q) {
+        const int c = (int)c0 + q;
+        if (c < 16) v[q] = sh[(size_t)ray * 16 + c];
+        else if (c < 16 + ngeo) v[q] = nf_load(Yb, (size_t)m * ldy + 1 + (c - 16), bf16);
+        else if (c < 16 + ngeo + napp) v[q] = app[(size_t)ray * napp + (c - 16 - ngeo)];
+      }
+    }
   }
   nf_store8(X, (size_t)m * ldx + c0, bf16, v);
 }
@@ -427,12 +438,15 @@ __global__ void k_nf_head_input(long long M, int S, int bf16, const float* __res
 // d_app[ray, :] = sum over the ray's samples of dX[:, col0 .. col0 + napp); scatter-added into the embedding row
 __global__ void k_nf_app_bwd(int nrays, int S, int bf16, const void* __restrict__ dX, int ldx, int col0, int napp,
                              const int* __restrict__ embed_idx, float* __restrict__ d_embedding) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nrays * napp) return;
-  const int ray = e / napp, c = e % napp;
-  float s = 0.f;
-  for (int k = 0; k < S; ++k) s += nf_load(dX, ((size_t)ray * S + k) * ldx + col0 + c, bf16);
-  atomicAdd(&d_embedding[(size_t)embed_idx[ray] * napp + c], s);
+  // one wave per ray (4 rays per block): lane = embedding column, so a sample's napp columns are one contiguous segment per load
+  // (one thread per (ray, column) walking S rows read a separate 64-byte sector per element)
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (ray >= nrays) return;
+  for (int c = lane; c < napp; c += 64) {
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += nf_load(dX, ((size_t)ray * S + k) * ldx + col0 + c, bf16);
+    atomicAdd(&d_embedding[(size_t)embed_idx[ray] * napp + c], s);
+  }
 }
 
 // rgb = sigmoid(Y[:, 0..2] + rgb_bias)
@@ -472,6 +486,7 @@ extern "C" int hugs_nf_density_act(long long M, int dtype, const void* Y, int ld
 }
 extern "C" int hugs_nf_base_grad(long long M, int dtype, const void* Y, int ldy, const float* sel, const float* d_density,
                                  const void* dXh, int ldx, int geo_col0, int ngeo, void* G, int ldg, void* stream) {
+  HUGS_REQUIRE(M * (long long)((ldg & 7) ? ldg : (ldg >> 3)) < (1ll << 32), -3, "hugs_nf_base_grad: %lld x %d elements exceed the 32-bit index", M, ldg);
   NF_LAUNCH1D(k_nf_base_grad, (ldg & 7) ? M * ldg : M * (ldg >> 3), M, dtype, Y, ldy, sel, d_density, dXh, ldx, geo_col0, ngeo, G, ldg);
   HUGS_CHECK_LAUNCH("hugs_nf_base_grad");
   return 0;
@@ -479,13 +494,15 @@ extern "C" int hugs_nf_base_grad(long long M, int dtype, const void* Y, int ldy,
 extern "C" int hugs_nf_head_input(long long M, int S, int dtype, const float* sh, const void* Yb, int ldy, int ngeo, const float* app,
                                   int napp, void* X, int ldx, void* stream) {
   HUGS_REQUIRE(16 + ngeo + napp <= ldx && ldx % 8 == 0, -3, "hugs_nf_head_input: %d columns do not fit the pitch %d (a multiple of 8)", 16 + ngeo + napp, ldx);
+  HUGS_REQUIRE(M * (long long)(ldx >> 3) < (1ll << 32) && S > 0, -3, "hugs_nf_head_input: %lld x %d elements exceed the 32-bit index", M, ldx);
   NF_LAUNCH1D(k_nf_head_input, M * (ldx >> 3), M, S, dtype, sh, Yb, ldy, ngeo, app, napp, X, ldx);
   HUGS_CHECK_LAUNCH("hugs_nf_head_input");
   return 0;
 }
 extern "C" int hugs_nf_app_bwd(int nrays, int S, int dtype, const void* dX, int ldx, int col0, int napp, const int* embed_idx,
                                float* d_embedding, void* stream) {
-  NF_LAUNCH1D(k_nf_app_bwd, (long long)nrays * napp, nrays, S, dtype, dX, ldx, col0, napp, embed_idx, d_embedding);
+  if (nrays > 0 && napp > 0)
+    hipLaunchKernelGGL(k_nf_app_bwd, dim3((nrays + 3) / 4), dim3(256), 0, (hipStream_t)stream, nrays, S, dtype, dX, ldx, col0, napp, embed_idx, d_embedding);
   HUGS_CHECK_LAUNCH("hugs_nf_app_bwd");
   return 0;
 }
