@@ -48,14 +48,28 @@ __device__ __forceinline__ void hg_entry(const void* __restrict__ table, size_t 
   }
 }
 
+// Forward.  Blocks are (group of HG_LG levels, 256 samples) with the level groups OUTERMOST in launch order: at any moment the
+// chip works on one or two groups, whose tables (2^19 x 2 halfs = 2 MB per hashed level of the field grid) stay in every XCD's
+// 4 MB L2 -- with one thread walking all 16 levels of its sample the waves were spread over all levels at once (32 MB of tables)
+// and every fine-level gather was a 64-byte sector from MALL / HBM.  Same-box (scratch/hg_lm.py, fp16 tables): field grid
+// 968 -> 670 us, proposal grids 519 -> 466 and 416 -> 293 us; groups of 1 or 2 levels help the field as much but cost the
+// proposal grids their contiguous output runs.  A thread writes its group's HG_LG x F outputs as one contiguous run.
+#define HG_LG 4
 template <int F, int BF16, bool TH>
 __global__ void __launch_bounds__(256)
-k_hashgrid_fwd(int n, int L, HgLevels lv, const float* __restrict__ x, const void* __restrict__ table, int row_pitch,
+k_hashgrid_fwd(int n, int nblk, int L, HgLevels lv, const float* __restrict__ x, const void* __restrict__ table, int row_pitch,
                void* __restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int g = blockIdx.x / nblk;
+  const int i = (blockIdx.x - g * nblk) * 256 + threadIdx.x;
   if (i >= n) return;
   const float px = x[3 * i], py = x[3 * i + 1], pz = x[3 * i + 2];
-  for (int l = 0; l < L; ++l) {
+  float o[HG_LG][F];
+#pragma unroll
+  for (int q = 0; q < HG_LG; ++q) {
+    const int l = g * HG_LG + q;
+#pragma unroll
+    for (int f = 0; f < F; ++f) o[q][f] = 0.f;
+    if (l >= L) continue;
     const uint32_t res = lv.res[l], entries = lv.off[l + 1] - lv.off[l];
     const bool dense = (uint64_t)res * res * res <= entries;
     const float sc = lv.scale[l];
@@ -63,9 +77,6 @@ k_hashgrid_fwd(int n, int L, HgLevels lv, const float* __restrict__ x, const voi
     const float gx = floorf(fx), gy = floorf(fy), gz = floorf(fz);
     const float wx = fx - gx, wy = fy - gy, wz = fz - gz;
     const uint32_t cx = (uint32_t)(int)gx, cy = (uint32_t)(int)gy, cz = (uint32_t)(int)gz;
-    float acc[F];
-#pragma unroll
-    for (int f = 0; f < F; ++f) acc[f] = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const float w = ((c & 1) ? wx : 1.f - wx) * ((c & 2) ? wy : 1.f - wy) * ((c & 4) ? wz : 1.f - wz);
@@ -73,14 +84,26 @@ k_hashgrid_fwd(int n, int L, HgLevels lv, const float* __restrict__ x, const voi
       float t[F];
       hg_entry<F, TH>(table, (size_t)lv.off[l] + idx, t);
 #pragma unroll
-      for (int f = 0; f < F; ++f) acc[f] += w * t[f];
-    }
-#pragma unroll
-    for (int f = 0; f < F; ++f) {
-      if (BF16) ((uint16_t*)out)[(size_t)i * row_pitch + l * F + f] = f_to_op16(acc[f], BF16);
-      else ((float*)out)[(size_t)i * row_pitch + l * F + f] = acc[f];
+      for (int f = 0; f < F; ++f) o[q][f] += w * t[f];
     }
   }
+  const int nl = min(HG_LG, L - g * HG_LG);
+  const size_t e0 = (size_t)i * row_pitch + (size_t)g * HG_LG * F;
+  if (BF16 && F == 2 && nl == HG_LG && (row_pitch & 7) == 0) {      // a whole group in a 16-bit format: one 16-byte store
+    uint4 u;
+    u.x = f2_to_op16(o[0][0], o[0][1], BF16); u.y = f2_to_op16(o[1][0], o[1][1], BF16);
+    u.z = f2_to_op16(o[2][0], o[2][1], BF16); u.w = f2_to_op16(o[3][0], o[3][1], BF16);
+    *(uint4*)((uint16_t*)out + e0) = u;
+    return;
+  }
+#pragma unroll
+  for (int q = 0; q < HG_LG; ++q)
+    if (q < nl)
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        if (BF16) ((uint16_t*)out)[e0 + q * F + f] = f_to_op16(o[q][f], BF16);
+        else ((float*)out)[e0 + q * F + f] = o[q][f];
+      }
 }
 
 // Table gradient.  Thread = sample, and consecutive samples are consecutive points of one ray: at every level whose
@@ -405,14 +428,15 @@ static int hashgrid_fwd_impl(int n, int n_levels, int features, const long long*
   HUGS_REQUIRE(features == 2 || features == 4, -2, "hugs_hashgrid_fwd: %d features per level (2 or 4)", features);
   HUGS_REQUIRE(row_pitch >= n_levels * features, -2, "hugs_hashgrid_fwd: row pitch %d < %d", row_pitch, n_levels * features);
   if (n <= 0) return 0;
-  const dim3 g((n + 255) / 256), b(256);
+  const int nblk = (n + 255) / 256;
+  const dim3 g((unsigned)nblk * (unsigned)((n_levels + HG_LG - 1) / HG_LG)), b(256);
   hipStream_t st = (hipStream_t)stream;
   if (features == 2) {
-    switch (out_bf16 + 3 * table_half) { case 0: k_hashgrid_fwd<2, 0, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break; case 1: k_hashgrid_fwd<2, 1, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break; case 2: k_hashgrid_fwd<2, 2, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break;
-      case 3: k_hashgrid_fwd<2, 0, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break; case 4: k_hashgrid_fwd<2, 1, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break; default: k_hashgrid_fwd<2, 2, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break; }
+    switch (out_bf16 + 3 * table_half) { case 0: k_hashgrid_fwd<2, 0, false><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break; case 1: k_hashgrid_fwd<2, 1, false><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break; case 2: k_hashgrid_fwd<2, 2, false><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break;
+      case 3: k_hashgrid_fwd<2, 0, true><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break; case 4: k_hashgrid_fwd<2, 1, true><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break; default: k_hashgrid_fwd<2, 2, true><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break; }
   } else {
-    switch (out_bf16 + 3 * table_half) { case 0: k_hashgrid_fwd<4, 0, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break; case 1: k_hashgrid_fwd<4, 1, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break; case 2: k_hashgrid_fwd<4, 2, false><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break;
-      case 3: k_hashgrid_fwd<4, 0, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break; case 4: k_hashgrid_fwd<4, 1, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break; default: k_hashgrid_fwd<4, 2, true><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, row_pitch, out); break; }
+    switch (out_bf16 + 3 * table_half) { case 0: k_hashgrid_fwd<4, 0, false><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break; case 1: k_hashgrid_fwd<4, 1, false><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break; case 2: k_hashgrid_fwd<4, 2, false><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break;
+      case 3: k_hashgrid_fwd<4, 0, true><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break; case 4: k_hashgrid_fwd<4, 1, true><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break; default: k_hashgrid_fwd<4, 2, true><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break; }
   }
   HUGS_CHECK_LAUNCH("k_hashgrid_fwd");
   return 0;
