@@ -5,8 +5,11 @@ width zero-padded to the 128-column tile), density -> weights -> colour, interle
 hand-scheduled backward pass and Adam.  SURVEY 8f row 3, BASELINE config 5.
 
 Field form: the `enable_tcnn_mlp: False` one (torch Linear layers, what configs/phototourism_nerfacto_base.yml
-selects); the reference runs them under fp16 autocast, here the GEMM operands are bf16 with fp32 accumulation
-(`compute_dtype='bf16'`) or fp32 (`'fp32'`, parity mode).  PARITY UNPINNED for the encodings themselves (tiny-cuda-nn);
+selects); the reference runs them under fp16 autocast + GradScaler (`enable_amp: True`) = `compute_dtype='fp16'` here
+(half MFMA operands / activations / table copies, fp32 accumulation and master parameters, the dynamic loss scale on the
+device); `'bf16'` is the same structure with bf16 operands and no loss scale, `'fp32'` the parity mode.  The colour MLP's
+last layer (hidden -> 3) + sigmoid is one pass over the hidden activation (the rgb head kernels of csrc/hugs_heads.hip)
+rather than a GEMM padded to 128 columns.  PARITY UNPINNED for the encodings themselves (tiny-cuda-nn);
 the sampler / weights / losses are pinned by vectors from the reference's pure-torch utils, and the field / model / loss
 WIRING by vectors recorded from executing the reference's own `Model` / `Loss` classes over a stand-in `tinycudann`
 (tests/golden/gen_nerfacto_model_fixtures.py -> tests/test_gpu_nerfacto_reference.py).
