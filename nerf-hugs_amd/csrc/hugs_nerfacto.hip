@@ -400,39 +400,62 @@ __global__ void k_nf_base_grad(long long M, int bf16, const void* __restrict__ Y
   if (m >= M) return;
   float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if ((int)c0 <= ngeo) {                           // (chunks behind the last real column are all zero: no loads)
+    if (bf16 && dXh && ngeo <= 15 && (geo_col0 & 7) == 0 && (ldx & 7) == 0) {
+      // the head's geo gradients = 16 consecutive 16-bit columns of its input gradient row: two aligned 16-byte loads
+      const uint4 a = *(const uint4*)((const uint16_t*)dXh + (size_t)m * ldx + geo_col0), b = *(const uint4*)((const uint16_t*)dXh + (size_t)m * ldx + geo_col0 + 8);
+      const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      float y16[16];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int c = (int)c0 + q;
-      if (c == 0) v[q] = d_density[m] * expf(fminf(fmaxf(nf_load(Y, (size_t)m * ldy, bf16), -15.f), 15.f)) * sel[m];
-      else if (c <= ngeo && dXh) v[q] = nf_load(dXh, (size_t)m * ldx + geo_col0 + c - 1, bf16);
+      for (int j = 0; j < 8; ++j) { y16[2 * j] = op16_to_f((uint16_t)w[j], bf16); y16[2 * j + 1] = op16_to_f((uint16_t)(w[j] >> 16), bf16); }
+      if (c0 == 0u) {
+        v[0] = d_density[m] * expf(fminf(fmaxf(nf_load(Y, (size_t)m * ldy, bf16), -15.f), 15.f)) * sel[m];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) v[q] = q <= ngeo ? y16[q - 1] : 0.f;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = 8 + q <= ngeo ? y16[q + 7] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = (int)c0 + q;
+        if (c == 0) v[q] = d_density[m] * expf(fminf(fmaxf(nf_load(Y, (size_t)m * ldy, bf16), -15.f), 15.f)) * sel[m];
+        else if (c <= ngeo && dXh) v[q] = nf_load(dXh, (size_t)m * ldx + geo_col0 + c - 1, bf16);
+      }
     }
   }
   nf_store8(G, (size_t)m * ldg + c0, bf16, v);
 }
 
 // head input X[M, ldx] = [SH(viewdir) (16, per ray) | geo = Ybase[:, 1 .. ngeo] | appearance embedding (per ray) | 0 ...]
-__global__ void k_nf_head_input(long long M, int S, int bf16, const float* __restrict__ sh, const void* __restrict__ Yb, int ldy,
-                                int ngeo, const float* __restrict__ app, int napp, void* __restrict__ X, int ldx) {
-  unsigned m, c0;                                 // ldx is a multiple of 8 (checked by the launcher)
-  nf_row_chunk(blockIdx.x * blockDim.x + threadIdx.x, (unsigned)ldx >> 3, m, c0);
-  if (m >= M) return;
-  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if ((int)c0 < 16 + ngeo + napp) {                // (the zero padding behind the last real column needs no loads)
-    const unsigned ray = ((unsigned)S & ((unsigned)S - 1u)) == 0u ? m >> (31u - (unsigned)__clz(S)) : m / (unsigned)S;
-    if (c0 + 8u <= 16u) {                          // a whole chunk of the per-ray SH block: two 16-byte loads
-      const float4 a = *(const float4*)(sh + (size_t)ray * 16 + c0), b = *(const float4*)(sh + (size_t)ray * 16 + c0 + 4);
-      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-    } else {
+// One workgroup per ray: everything but the geo columns is the same for the ray's S samples, so the row is built once as a
+// template in LDS (in the output format) and every (sample, 8-column chunk) is a 16-byte copy of it -- only the chunks that
+// hold geo columns touch the base output.  (One thread per chunk re-reading sh / app for every sample: 447 us for the
+// cfg5 batch; a plain fill of the same 0.54 GB is 81 us.)
+__global__ __launch_bounds__(256) void k_nf_head_input(int nrays, int S, int bf16, const float* __restrict__ sh, const void* __restrict__ Yb,
+                                                       int ldy, int ngeo, const float* __restrict__ app, int napp, void* __restrict__ X,
+                                                       int ldx) {
+  __shared__ __attribute__((aligned(16))) float tmpl[1024];       // the row in fp32 (ldx <= 1024, checked by the launcher)
+  const int ray = blockIdx.x;
+  for (int c = threadIdx.x; c < ldx; c += 256)
+    tmpl[c] = c < 16 ? sh[(size_t)ray * 16 + c] : (c >= 16 + ngeo && c < 16 + ngeo + napp) ? app[(size_t)ray * napp + (c - 16 - ngeo)] : 0.f;
+  __syncthreads();
+  const int cpr = ldx >> 3;
+  for (int e = threadIdx.x; e < S * cpr; e += 256) {
+    const int k = e / cpr, c0 = (e - k * cpr) * 8;
+    const size_t m = (size_t)ray * S + k;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = tmpl[c0 + q];
+    if (c0 < 16 + ngeo && c0 + 8 > 16) {                          // this chunk holds geo columns
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int c = (int)c0 + q;
-        if (c < 16) v[q] = sh[(size_t)ray * 16 + c];
-        else if (c < 16 + ngeo) v[q] = nf_load(Yb, (size_t)m * ldy + 1 + (c - 16), bf16);
-        else if (c < 16 + ngeo + napp) v[q] = app[(size_t)ray * napp + (c - 16 - ngeo)];
+        const int c = c0 + q;
+        if (c >= 16 && c < 16 + ngeo) v[q] = nf_load(Yb, m * ldy + 1 + (c - 16), bf16);
       }
     }
+    nf_store8(X, m * ldx + c0, bf16, v);
   }
-  nf_store8(X, (size_t)m * ldx + c0, bf16, v);
 }
 
 // d_app[ray, :] = sum over the ray's samples of dX[:, col0 .. col0 + napp); scatter-added into the embedding row
@@ -443,9 +466,14 @@ __global__ void k_nf_app_bwd(int nrays, int S, int bf16, const void* __restrict_
   const int ray = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (ray >= nrays) return;
   for (int c = lane; c < napp; c += 64) {
-    float s = 0.f;
-    for (int k = 0; k < S; ++k) s += nf_load(dX, ((size_t)ray * S + k) * ldx + col0 + c, bf16);
-    atomicAdd(&d_embedding[(size_t)embed_idx[ray] * napp + c], s);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // four loads in flight (fixed combination order: deterministic per ray)
+    int k = 0;
+    for (; k + 4 <= S; k += 4) {
+      const size_t r0 = ((size_t)ray * S + k) * ldx + col0 + c;
+      s0 += nf_load(dX, r0, bf16); s1 += nf_load(dX, r0 + ldx, bf16); s2 += nf_load(dX, r0 + 2 * (size_t)ldx, bf16); s3 += nf_load(dX, r0 + 3 * (size_t)ldx, bf16);
+    }
+    for (; k < S; ++k) s0 += nf_load(dX, ((size_t)ray * S + k) * ldx + col0 + c, bf16);
+    atomicAdd(&d_embedding[(size_t)embed_idx[ray] * napp + c], (s0 + s1) + (s2 + s3));
   }
 }
 
@@ -493,9 +521,9 @@ extern "C" int hugs_nf_base_grad(long long M, int dtype, const void* Y, int ldy,
 }
 extern "C" int hugs_nf_head_input(long long M, int S, int dtype, const float* sh, const void* Yb, int ldy, int ngeo, const float* app,
                                   int napp, void* X, int ldx, void* stream) {
-  HUGS_REQUIRE(16 + ngeo + napp <= ldx && ldx % 8 == 0, -3, "hugs_nf_head_input: %d columns do not fit the pitch %d (a multiple of 8)", 16 + ngeo + napp, ldx);
-  HUGS_REQUIRE(M * (long long)(ldx >> 3) < (1ll << 32) && S > 0, -3, "hugs_nf_head_input: %lld x %d elements exceed the 32-bit index", M, ldx);
-  NF_LAUNCH1D(k_nf_head_input, M * (ldx >> 3), M, S, dtype, sh, Yb, ldy, ngeo, app, napp, X, ldx);
+  HUGS_REQUIRE(16 + ngeo + napp <= ldx && ldx % 8 == 0 && ldx <= 1024, -3, "hugs_nf_head_input: %d columns do not fit the pitch %d (a multiple of 8, <= 1024)", 16 + ngeo + napp, ldx);
+  HUGS_REQUIRE(S > 0 && M % S == 0 && M / S < (1ll << 31), -3, "hugs_nf_head_input: %lld rows are not whole rays of %d samples", M, S);
+  if (M > 0) hipLaunchKernelGGL(k_nf_head_input, dim3((unsigned)(M / S)), dim3(256), 0, (hipStream_t)stream, (int)(M / S), S, dtype, sh, Yb, ldy, ngeo, app, napp, X, ldx);
   HUGS_CHECK_LAUNCH("hugs_nf_head_input");
   return 0;
 }
