@@ -780,6 +780,196 @@ __global__ __launch_bounds__(256, 2) void k_nf_prop_bwd(long long M, int in_dim,
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same proposal networks on the matrix cores, for 16-bit feature rows (in_dim <= 16, hidden <= 64): v_mfma_f32_16x16x16
+// f16 / bf16, a wave per 64 samples.  Everything is arranged so that NO cross-lane transpose of the hidden layer is needed:
+//   (1) Ht[n][s] = W0^T X^T   (A = W0^T rows n, B = X^T: a lane's B operand is 4 consecutive k of one sample = 8 contiguous
+//       bytes of the feature row) leaves lane l with units 4(l/16)+j of sample l%16 -- which IS the B-operand layout of
+//   (2) dX^T[k][s] = W0[k][:] dHt[:][s]   (K = units), whose result is 4 consecutive k of one sample: an 8-byte store;
+//   (3) H[s][n] = X W0 computed a second time in the other orientation (A = X rows s: the registers of (1)'s B operand)
+//       leaves lane l with unit l%16 of samples 4(l/16)+j -- the B-operand layout of
+//   (4) dW0[k][n] += X^T[k][s] dH[s][n]   (K = samples), accumulated in registers over all tiles of the wave; only X^T
+//       (64 x 16 values) goes through LDS.
+// 64 MFMAs of 16 passes per 64 samples in the backward (16 in the forward) against ~400 k lane-FMAs on the VALU.  Operands
+// are the 16-bit format of the mode (the weights are rounded to it: what the reference's autocast does to these Linear
+// layers); accumulation, bias, relu and the reductions are fp32.  Weight-gradient slabs have the layout of the VALU kernels.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) float pmf4_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 pmh4_t;
+typedef __attribute__((ext_vector_type(4))) short pms4_t;
+template <int DT>
+__device__ __forceinline__ pmf4_t pm_mfma(uint2 a, uint2 b, pmf4_t c) {
+  if (DT == 2) return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(pmh4_t, a), __builtin_bit_cast(pmh4_t, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(pms4_t, a), __builtin_bit_cast(pms4_t, b), c, 0, 0, 0);
+}
+template <int DT>
+__device__ __forceinline__ uint2 pm_pack4(float a, float b, float c, float d) { return make_uint2(f2_to_op16(a, b, DT), f2_to_op16(c, d, DT)); }
+
+// per-lane constants of both kernels: weight fragments and the bias / head vectors in the two accumulator layouts
+template <int DT>
+struct PmConst {
+  uint2 wA[4];      // [nb]: W0[k = 4(l/16)+j][n = 16 nb + l%16]      (A of (1), B of (3))
+  uint2 wX[4];      // [nb]: W0[k = l%16][n = 16 nb + 4(l/16)+j]      (A of (2))
+  float b0a[4][4], w1a[4][4];   // units 16 nb + 4(l/16)+j  (layout of (1))
+  float b0b[4], w1b[4];         // unit 16 nb + l%16        (layout of (3))
+  __device__ __forceinline__ void load(int lane, int in_dim, int H, const float* W0, int ldw0, const float* b0, const float* w1, int ldw1) {
+    const int lr = lane & 15, lq = lane >> 4;
+    auto w = [&](int k, int n) { return (k < in_dim && n < H) ? W0[(size_t)k * ldw0 + n] : 0.f; };
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      wA[nb] = pm_pack4<DT>(w(4 * lq, 16 * nb + lr), w(4 * lq + 1, 16 * nb + lr), w(4 * lq + 2, 16 * nb + lr), w(4 * lq + 3, 16 * nb + lr));
+      wX[nb] = pm_pack4<DT>(w(lr, 16 * nb + 4 * lq), w(lr, 16 * nb + 4 * lq + 1), w(lr, 16 * nb + 4 * lq + 2), w(lr, 16 * nb + 4 * lq + 3));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = 16 * nb + 4 * lq + j;
+        b0a[nb][j] = n < H ? b0[n] : 0.f;
+        w1a[nb][j] = n < H ? w1[(size_t)n * ldw1] : 0.f;
+      }
+      const int n = 16 * nb + lr;
+      b0b[nb] = n < H ? b0[n] : 0.f;
+      w1b[nb] = n < H ? w1[(size_t)n * ldw1] : 0.f;
+    }
+  }
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_nf_prop_fwd_mfma(long long M, int in_dim, int H, const uint16_t* __restrict__ X, int ldx,
+                                                          const float* __restrict__ W0, int ldw0, const float* __restrict__ b0,
+                                                          const float* __restrict__ w1, int ldw1, const float* __restrict__ b1,
+                                                          const float* __restrict__ sel, float* __restrict__ raw, float* __restrict__ density) {
+  const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+  PmConst<DT> C;
+  C.load(lane, in_dim, H, W0, ldw0, b0, w1, ldw1);
+  const float b1v = b1[0];
+  const long long ntile = (M + 63) >> 6, wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (long long)gridDim.x * 4;
+  for (long long t = wave; t < ntile; t += nwave) {
+    const long long s0 = t << 6;
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb) {
+      const long long s = s0 + 16 * sb + lr;
+      const uint2 xf = s < M ? *(const uint2*)(X + (size_t)s * ldx + 4 * lq) : make_uint2(0u, 0u);
+      float o = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        pmf4_t acc = {C.b0a[nb][0], C.b0a[nb][1], C.b0a[nb][2], C.b0a[nb][3]};
+        acc = pm_mfma<DT>(C.wA[nb], xf, acc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o = fmaf(fmaxf(acc[j], 0.f), C.w1a[nb][j], o);
+      }
+      o += __shfl_xor(o, 16);
+      o += __shfl_xor(o, 32);
+      if (lq == 0 && s < M) {
+        o += b1v;
+        raw[s] = o;
+        density[s] = expf(o) * sel[s];             // custom_functions.py:38-44 trunc_exp forward, nerfacto.py:984-988 selector
+      }
+    }
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_nf_prop_bwd_mfma(long long M, int in_dim, int H, const uint16_t* __restrict__ X, int ldx,
+                                                          const float* __restrict__ W0, int ldw0, const float* __restrict__ b0,
+                                                          const float* __restrict__ w1, int ldw1, const float* __restrict__ raw,
+                                                          const float* __restrict__ sel, const float* __restrict__ d_density,
+                                                          uint16_t* __restrict__ dX, float* __restrict__ slab) {
+  constexpr int KP = 16;
+  __shared__ __attribute__((aligned(16))) uint16_t sXT[4][64 * 16];     // per wave: the tile's feature rows [sample][k]
+  __shared__ float sR[4][64];
+  __shared__ float sRed[4][(KP + 2) * 64 + 4];
+  const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4, wv = threadIdx.x >> 6;
+  PmConst<DT> C;
+  C.load(lane, in_dim, H, W0, ldw0, b0, w1, ldw1);
+  pmf4_t aW0[4];
+  float ab0[4] = {0.f, 0.f, 0.f, 0.f}, aw1[4] = {0.f, 0.f, 0.f, 0.f}, ab1 = 0.f;
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) aW0[nb] = pmf4_t{0.f, 0.f, 0.f, 0.f};
+  uint16_t* xt = sXT[wv];
+  float* rs = sR[wv];
+  const long long ntile = (M + 63) >> 6, wave = (long long)blockIdx.x * 4 + wv, nwave = (long long)gridDim.x * 4;
+#define PM_WAVE_SYNC() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+  for (long long t = wave; t < ntile; t += nwave) {
+    const long long s0 = t << 6;
+    // d raw = d density * exp(clamp(raw, -15, 15)) * selector (custom_functions.py:46-50), sample s0 + lane
+    const long long sm = s0 + lane;
+    const float r = sm < M ? d_density[sm] * expf(fminf(fmaxf(raw[sm], -15.f), 15.f)) * sel[sm] : 0.f;
+    ab1 += r;
+    if (__ballot(r != 0.f) == 0ull) {             // a tile without gradient (outside the box, zero weight): dX = 0, done
+#pragma unroll
+      for (int sb = 0; sb < 4; ++sb) {
+        const long long s = s0 + 16 * sb + lr;
+        if (s < M) *(uint2*)(dX + (size_t)s * ldx + 4 * lq) = make_uint2(0u, 0u);
+      }
+      continue;
+    }
+    uint2 xf[4];
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb) {
+      const long long s = s0 + 16 * sb + lr;
+      xf[sb] = s < M ? *(const uint2*)(X + (size_t)s * ldx + 4 * lq) : make_uint2(0u, 0u);
+      *(uint2*)(xt + (16 * sb + lr) * 16 + 4 * lq) = xf[sb];
+    }
+    rs[lane] = r;
+    PM_WAVE_SYNC()
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb) {
+      // ---- (1) + (2): dX rows of the 16 samples of this block ----
+      const float r1 = rs[16 * sb + lr];
+      pmf4_t dxacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        pmf4_t acc = {C.b0a[nb][0], C.b0a[nb][1], C.b0a[nb][2], C.b0a[nb][3]};
+        acc = pm_mfma<DT>(C.wA[nb], xf[sb], acc);
+        const uint2 dh = pm_pack4<DT>(acc[0] > 0.f ? r1 * C.w1a[nb][0] : 0.f, acc[1] > 0.f ? r1 * C.w1a[nb][1] : 0.f,
+                                      acc[2] > 0.f ? r1 * C.w1a[nb][2] : 0.f, acc[3] > 0.f ? r1 * C.w1a[nb][3] : 0.f);
+        dxacc = pm_mfma<DT>(C.wX[nb], dh, dxacc);
+      }
+      const long long s = s0 + 16 * sb + lr;
+      if (s < M) *(uint2*)(dX + (size_t)s * ldx + 4 * lq) = pm_pack4<DT>(dxacc[0], dxacc[1], dxacc[2], dxacc[3]);
+      // ---- (3) + (4): this block's 16 samples into the weight gradients ----
+      const float4 r4 = *(const float4*)(rs + 16 * sb + 4 * lq);
+      const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
+      // X^T fragment: k = lr, samples 16 sb + 4 lq + j
+      const uint16_t* xcol = xt + (16 * sb + 4 * lq) * 16 + lr;
+      const uint2 xtf = make_uint2((uint32_t)xcol[0] | ((uint32_t)xcol[16] << 16), (uint32_t)xcol[32] | ((uint32_t)xcol[48] << 16));
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        pmf4_t acc = {C.b0b[nb], C.b0b[nb], C.b0b[nb], C.b0b[nb]};
+        acc = pm_mfma<DT>(xf[sb], C.wA[nb], acc);               // H[s = 4 lq + j][n = 16 nb + lr]
+        float d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          aw1[nb] = fmaf(fmaxf(acc[j], 0.f), rr[j], aw1[nb]);
+          d[j] = acc[j] > 0.f ? rr[j] * C.w1b[nb] : 0.f;
+          ab0[nb] += d[j];
+        }
+        aW0[nb] = pm_mfma<DT>(xtf, pm_pack4<DT>(d[0], d[1], d[2], d[3]), aW0[nb]);    // dW0[k = 4 lq + j][n = 16 nb + lr]
+      }
+    }
+    PM_WAVE_SYNC()
+  }
+#undef PM_WAVE_SYNC
+  // ---- lane groups (db0 / dw1 are partial over the group's samples), then the four waves in a fixed order -> slab row ----
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    ab0[nb] += __shfl_xor(ab0[nb], 16); ab0[nb] += __shfl_xor(ab0[nb], 32);
+    aw1[nb] += __shfl_xor(aw1[nb], 16); aw1[nb] += __shfl_xor(aw1[nb], 32);
+  }
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) ab1 += __shfl_xor(ab1, d);
+  float* red = sRed[wv];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[(4 * lq + j) * 64 + 16 * nb + lr] = aW0[nb][j];
+    if (lq == 0) { red[KP * 64 + 16 * nb + lr] = ab0[nb]; red[(KP + 1) * 64 + 16 * nb + lr] = aw1[nb]; }
+  }
+  if (lane == 0) red[(KP + 2) * 64] = ab1;
+  __syncthreads();
+  float* row = slab + (size_t)blockIdx.x * pm_slab_width(KP);
+  for (int e = threadIdx.x; e <= (KP + 2) * 64; e += 256) row[e] = (sRed[0][e] + sRed[1][e]) + (sRed[2][e] + sRed[3][e]);
+}
+
 // slab [nblk][width] -> the four gradient leaves (fixed summation order over the workgroups)
 __global__ __launch_bounds__(256) void k_nf_prop_reduce(const float* __restrict__ slab, int nblk, int KP, int in_dim, int H,
                                                         float* __restrict__ gW0, int ldw0, float* __restrict__ gb0,
@@ -814,6 +1004,14 @@ extern "C" int hugs_nf_prop_fwd(long long M, int in_dim, int hidden, int dtype, 
   if (M <= 0) return 0;
   const int grid = (int)((M + 255) / 256 < 2048 ? (M + 255) / 256 : 2048);
   hipStream_t st = (hipStream_t)stream;
+  if (dtype && KP == 16 && ldx % 4 == 0) {        // 16-bit rows of <= 16 features: the matrix-core form
+    const long long ntile = (M + 63) / 64;
+    const int gm = (int)((ntile + 3) / 4 < 4096 ? (ntile + 3) / 4 : 4096);
+    if (dtype == 2) hipLaunchKernelGGL(k_nf_prop_fwd_mfma<2>, dim3(gm), dim3(256), 0, st, M, in_dim, hidden, (const uint16_t*)X, ldx, W0, ldw0, b0, w1, ldw1, b1, sel, raw, density);
+    else hipLaunchKernelGGL(k_nf_prop_fwd_mfma<1>, dim3(gm), dim3(256), 0, st, M, in_dim, hidden, (const uint16_t*)X, ldx, W0, ldw0, b0, w1, ldw1, b1, sel, raw, density);
+    HUGS_CHECK_LAUNCH("hugs_nf_prop_fwd(mfma)");
+    return 0;
+  }
 #define PM_FWD(B, K) hipLaunchKernelGGL((k_nf_prop_fwd<B, K>), dim3(grid), dim3(256), 0, st, M, in_dim, hidden, X, ldx, W0, ldw0, b0, w1, ldw1, b1, sel, raw, density)
   if (dtype == 2) { if (KP == 16) PM_FWD(2, 16); else PM_FWD(2, 32); }
   else if (dtype) { if (KP == 16) PM_FWD(1, 16); else PM_FWD(1, 32); }
@@ -834,6 +1032,16 @@ extern "C" int hugs_nf_prop_bwd(long long M, int in_dim, int hidden, int dtype, 
   const int grid = (int)(ntile < 1024 ? ntile : 1024);
   hipStream_t st = (hipStream_t)stream;
   float* slab = (float*)ws;
+  if (dtype && KP == 16 && ldx % 4 == 0) {        // 16-bit rows of <= 16 features: the matrix-core form (same slab layout)
+    const long long nt64 = (M + 63) / 64;
+    const int gm = (int)((nt64 + 3) / 4 < 1024 ? (nt64 + 3) / 4 : 1024);
+    if (dtype == 2) hipLaunchKernelGGL(k_nf_prop_bwd_mfma<2>, dim3(gm), dim3(256), 0, st, M, in_dim, hidden, (const uint16_t*)X, ldx, W0, ldw0, b0, w1, ldw1, raw, sel, d_density, (uint16_t*)dX, slab);
+    else hipLaunchKernelGGL(k_nf_prop_bwd_mfma<1>, dim3(gm), dim3(256), 0, st, M, in_dim, hidden, (const uint16_t*)X, ldx, W0, ldw0, b0, w1, ldw1, raw, sel, d_density, (uint16_t*)dX, slab);
+    hipLaunchKernelGGL(k_nf_prop_reduce, dim3((pm_slab_width(KP) + 63) / 64), dim3(256), 0, st, slab, gm, KP, in_dim, hidden, gW0, ldw0,
+                       gb0, gw1, ldw1, gb1);
+    HUGS_CHECK_LAUNCH("hugs_nf_prop_bwd(mfma)");
+    return 0;
+  }
 #define PM_BWD(B, K) hipLaunchKernelGGL((k_nf_prop_bwd<B, K>), dim3(grid), dim3(256), 0, st, M, in_dim, hidden, X, ldx, W0, ldw0, b0, w1, ldw1, raw, sel, d_density, dX, slab)
   if (dtype == 2) { if (KP == 16) PM_BWD(2, 16); else PM_BWD(2, 32); }
   else if (dtype) { if (KP == 16) PM_BWD(1, 16); else PM_BWD(1, 32); }
