@@ -169,7 +169,8 @@ def nerfacto_roofline(model, step_fn, N, steps=3):
   table updates the algorithm must apply, counted as atomic TRANSACTIONS (adjacent floats of one instruction share one:
   4 per sample and level where the x-neighbour entry is adjacent, i.e. dense levels, 8 on hashed ones -- before the
   kernel's run merging, which is why `frac` can exceed 1) against the 21 G transactions/s this chip retires
-  (scratch/atomic_pair.hip); GEMMs = 2 M K N against the dense bf16 MFMA peak."""
+  (scratch/atomic_pair.hip); GEMMs = 2 M K N against the dense 16-bit MFMA peak; the fused proposal networks = their algorithmic
+  flops against the 16x16x16 MFMA rate (16-bit modes) or the fp32 VALU peak (parity mode)."""
   from nerf_hugs_amd import _lib
   _lib.PROFILE = []
   for _ in range(steps):
@@ -201,8 +202,12 @@ def nerfacto_roofline(model, step_fn, N, steps=3):
     elif key[0] in ('prop_fwd', 'prop_bwd'):
       n, i_, h_ = key[1:]
       fl = 2.0 * n * (i_ * h_ + h_) * (1 if key[0] == 'prop_fwd' else 3)
-      ent.update(kernel=f"k_nf_{key[0]} {n} samples {i_}->{h_}->1 (fp32 VALU)", bound="valu", achieved=round(fl / (us * 1e-6) / 1e12, 2),
-                 peak=157.3, unit="TFLOP/s", frac=round(fl / (us * 1e-6) / 157.3e12, 4))
+      if model.dt and i_ <= 16:      # 16-bit feature rows: the matrix-core kernels (v_mfma_f32_16x16x16: half the 16x16x32 rate)
+        ent.update(kernel=f"k_nf_{key[0]}_mfma {n} samples {i_}->{h_}->1 (algorithmic flops; the kernel pads {i_} -> 16 inputs)", bound="mfma",
+                   achieved=round(fl / (us * 1e-6) / 1e12, 2), peak=PEAK_BF16 / 2e12, unit="TFLOP/s", frac=round(fl / (us * 1e-6) / (PEAK_BF16 / 2), 4))
+      else:
+        ent.update(kernel=f"k_nf_{key[0]} {n} samples {i_}->{h_}->1 (fp32 VALU)", bound="valu", achieved=round(fl / (us * 1e-6) / 1e12, 2),
+                   peak=157.3, unit="TFLOP/s", frac=round(fl / (us * 1e-6) / 157.3e12, 4))
     else:
       fl = 2.0 * key[1] * key[2] * key[3]
       ent.update(kernel=f"gemm_{key[0]} M={key[1]} {key[2]}x{key[3]} {key[4]} (padded shape)", bound="mfma",

@@ -122,6 +122,17 @@ k_hashgrid_bwd(int n, int L, HgLevels lv, const float* __restrict__ x, const voi
   const int ii = live ? i : n - 1;
   const float px = x[3 * ii], py = x[3 * ii + 1], pz = x[3 * ii + 2];
   for (int l = l_begin; l < L; ++l) {
+    float g[F];
+    bool gnz = false;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      g[f] = !live ? 0.f : BF16 ? op16_to_f(((const uint16_t*)d_out)[(size_t)ii * row_pitch + l * F + f], BF16)
+                                : ((const float*)d_out)[(size_t)ii * row_pitch + l * F + f];
+      gnz |= g[f] != 0.f;
+    }
+    // a wave whose 64 samples all have a zero output gradient at this level (outside the box, behind the surface, or -- in the
+    // fp16 mode -- flushed below half's subnormals) has nothing to scatter: skip the index arithmetic and the scan
+    if (__ballot(gnz) == 0ull) continue;
     const uint32_t res = lv.res[l], entries = lv.off[l + 1] - lv.off[l];
     const bool dense = (uint64_t)res * res * res <= entries;
     const float sc = lv.scale[l];
@@ -129,11 +140,6 @@ k_hashgrid_bwd(int n, int L, HgLevels lv, const float* __restrict__ x, const voi
     const float gx = floorf(fx), gy = floorf(fy), gz = floorf(fz);
     const float wx = fx - gx, wy = fy - gy, wz = fz - gz;
     const uint32_t cx = (uint32_t)(int)gx, cy = (uint32_t)(int)gy, cz = (uint32_t)(int)gz;
-    float g[F];
-#pragma unroll
-    for (int f = 0; f < F; ++f)
-      g[f] = !live ? 0.f : BF16 ? op16_to_f(((const uint16_t*)d_out)[(size_t)ii * row_pitch + l * F + f], BF16)
-                                : ((const float*)d_out)[(size_t)ii * row_pitch + l * F + f];
     float v[8][F];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
