@@ -1336,8 +1336,8 @@ extern "C" int hugs_gemm_nt_bits(int dtype, int M, int N, int K1, int K2, const 
                                  const void* Bt, int ldb, const float* bias, int relu, const float* r1_row,
                                  const float* r1_col, void* out, int ldc, uint32_t* bits_out, const uint32_t* bits_in,
                                  void* stream) {
-  HUGS_REQUIRE((dtype == 1 || dtype == 2) && M % 256 == 0 && N % 256 == 0 && ldc == N && (K1 + K2) % 64 == 0 && K1 + K2 >= 256, -3,
-               "hugs_gemm_nt_bits: needs bf16 / fp16, M=%d N=%d multiples of 256, ldc == N, K=%d a multiple of 64 and >= 256", M, N, K1 + K2);
+  HUGS_REQUIRE((dtype == 1 || dtype == 2) && M % 256 == 0 && N % 256 == 0 && ldc == N && (K1 + K2) % 64 == 0 && K1 + K2 >= 128, -3,
+               "hugs_gemm_nt_bits: needs bf16 / fp16, M=%d N=%d multiples of 256, ldc == N, K=%d a multiple of 64 and >= 128", M, N, K1 + K2);
   HUGS_REQUIRE(!bits_out || relu, -3, "hugs_gemm_nt_bits: bits_out needs a relu epilogue");
   return gemm_nt_impl(0, dtype, M, N, K1, K2, A1, lda1, A2, lda2, Bt, ldb, bias, nullptr, 1, 0, relu, bits_in ? (const void*)1 : nullptr, 0,
                       r1_row, r1_col, out, ldc, bits_out, bits_in, stream);

@@ -276,11 +276,22 @@ class NerfactoModel:
           self.wn[name] = W
 
   # ---- GEMM helpers ---------------------------------------------------------------------------------------------------
-  def _nt(self, M, name, X, bias, relu, out, mask=None, transpose=False):
-    """out[M,N] = act(X W + b) (transpose=False) or out[M,K] = (X W^T) (* mask > 0) (transpose=True, the dX form)."""
+  def _bits_ok(self, M, width, k):
+    """1-bit relu masks (hugs_gemm_nt_bits: written by the forward layer in the dX kernel's own lane layout, M*width/8 bytes
+    instead of a re-read of the 16-bit activation): 16-bit modes, whole 256 x 256 tiles, K >= 128."""
+    return bool(self.dt and M % 256 == 0 and width % 256 == 0 and k % 64 == 0 and k >= 128 and os.environ.get('HUGS_NF_RELU_BITS', '1') != '0')
+
+  def _nt(self, M, name, X, bias, relu, out, mask=None, transpose=False, bits=None):
+    """out[M,N] = act(X W + b) (transpose=False; bits: relu mask bits written) or out[M,K] = (X W^T) (* mask > 0)
+    (transpose=True, the dX form; bits: the mask as bits instead of the activation `mask`)."""
     K, N = self.lay.items[name][1]
     if not transpose:
-      L.call('hugs_gemm_nt', self.dt, M, N, K, 0, X, K, None, 0, self.wt[name], K, bias, None, 1, 0, int(relu), None, 0, None, None, out, N)
+      if bits is not None:
+        L.call('hugs_gemm_nt_bits', self.dt, M, N, K, 0, X, K, None, 0, self.wt[name], K, bias, int(relu), None, None, out, N, bits, None)
+      else:
+        L.call('hugs_gemm_nt', self.dt, M, N, K, 0, X, K, None, 0, self.wt[name], K, bias, None, 1, 0, int(relu), None, 0, None, None, out, N)
+    elif bits is not None:
+      L.call('hugs_gemm_nt_bits', self.dt, M, K, N, 0, X, N, None, 0, self.wn[name], N, None, 0, None, None, out, K, None, bits)
     else:
       L.call('hugs_gemm_nt', self.dt, M, K, N, 0, X, N, None, 0, self.wn[name], N, None, None, 1, 0, 0, mask, K if mask is not None else 0,
              None, None, out, K)
@@ -383,10 +394,12 @@ class NerfactoModel:
           X0.zero_(); ws.bufs[(f'X0z_{lvl}', M)] = True
         self._grid_fwd(name, x01, X0)
         Y0, Y1 = ws.get(f'Y0_{lvl}', (M, N0), self.tdt), ws.get(f'Y1_{lvl}', (M, N1), self.tdt)
-        self._nt(M, f'{name}/w0', X0, self.lay.view(self.flat, f'{name}/b0'), True, Y0)
+        # (the dX GEMM that consumes Y0's mask has K = N1: both shapes must suit the bit-mask kernels)
+        bY0 = ws.get(f'bitsY0_{lvl}', (M * N0 // 32,), torch.int32) if training and self._bits_ok(M, N0, K0) and self._bits_ok(M, N0, N1) else None
+        self._nt(M, f'{name}/w0', X0, self.lay.view(self.flat, f'{name}/b0'), True, Y0, bits=bY0)
         self._nt(M, f'{name}/w1', Y0, self.lay.view(self.flat, f'{name}/b1'), False, Y1)
         L.call('hugs_nf_density_act', M, dt, Y1, N1, 0, sel, dens)
-        st = dict(S=S, M=M, name=name, sbins=sb, ebins=eb, x01=x01, sel=sel, X0=X0, Y0=Y0, Y1=Y1, density=dens, rgb=None)
+        st = dict(S=S, M=M, name=name, sbins=sb, ebins=eb, x01=x01, sel=sel, X0=X0, Y0=Y0, Y1=Y1, density=dens, rgb=None, bY0=bY0)
       rgb_out = None
       if not is_prop:
         sh = ws.get('sh', (N, 16))
@@ -407,8 +420,10 @@ class NerfactoModel:
         Xh = ws.get('Xh', (M, Kh), self.tdt)
         L.call('hugs_nf_head_input', M, S, dt, sh, Y1, N1, c.geo_feat_dim, app, self.napp, Xh, Kh)
         H0, H1 = ws.get('H0', (M, H), self.tdt), ws.get('H1', (M, H), self.tdt)
-        self._nt(M, 'field/c0', Xh, self.lay.view(self.flat, 'field/cb0'), True, H0)
+        bH0 = ws.get('bitsH0', (M * H // 32,), torch.int32) if training and self._bits_ok(M, H, Kh) and self._bits_ok(M, H, H) else None
+        self._nt(M, 'field/c0', Xh, self.lay.view(self.flat, 'field/cb0'), True, H0, bits=bH0)
         self._nt(M, 'field/c1', H0, self.lay.view(self.flat, 'field/cb1'), True, H1)
+        st['bH0'] = bH0
         rgb = ws.get('rgb_s', (M, 3))
         Yc = None
         if self.rgb_head:
@@ -736,7 +751,7 @@ class NerfactoModel:
         self._nt(M, 'field/c2', Gc, None, False, G1, mask=st['H1'], transpose=True)
       self._tn(M, 'field/c1', st['H0'], G1, 'field/cb1')
       G0 = ws.get('G0', (M, H), self.tdt)
-      self._nt(M, 'field/c1', G1, None, False, G0, mask=st['H0'], transpose=True)
+      self._nt(M, 'field/c1', G1, None, False, G0, mask=st['H0'], transpose=True, bits=st.get('bH0'))
       self._tn(M, 'field/c0', st['Xh'], G0, 'field/cb0')
       Kh = st['Xh'].shape[1]
       dXh = ws.get('dXh', (M, Kh), self.tdt)
@@ -750,7 +765,7 @@ class NerfactoModel:
     self._tn(M, f'{name}/w1', st['Y0'], Gb, f'{name}/b1')
     N0 = st['Y0'].shape[1]
     Gy0 = ws.get(f'Gy0_{name}', (M, N0), self.tdt)
-    self._nt(M, f'{name}/w1', Gb, None, False, Gy0, mask=st['Y0'], transpose=True)
+    self._nt(M, f'{name}/w1', Gb, None, False, Gy0, mask=st['Y0'], transpose=True, bits=st.get('bY0'))
     self._tn(M, f'{name}/w0', st['X0'], Gy0, f'{name}/b0')
     K0 = st['X0'].shape[1]
     dX0 = ws.get(f'dX0_{name}', (M, K0), self.tdt)
