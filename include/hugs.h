@@ -277,7 +277,7 @@ int hugs_hashgrid2d_bwd(int n, int n_levels, int features, const long long* leve
                         float* d_table_accum, void* stream);
 
 /* hugs_gemm_nt with 1-bit relu masks in the 256x256 kernels' own register layout (bf16; M, N multiples of 256, ldc == N,
- * K a multiple of 64 and >= 256): a relu epilogue writes bits_out (hugs_gemm_nt_bits_bytes(M, N) = M*N/8 bytes: per
+ * K a multiple of 64 and >= 128): a relu epilogue writes bits_out (hugs_gemm_nt_bits_bytes(M, N) = M*N/8 bytes: per
  * tile, wave and lane one 16-byte word), the backward GEMM that produces the same [M, N] shape multiplies its output by
  * bits_in instead of re-reading the bf16 activation (models.py:451-456 relu; its autodiff, train_utils.py:454). */
 long long hugs_gemm_nt_bits_bytes(int M, int N);
