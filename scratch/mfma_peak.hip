@@ -83,7 +83,7 @@ void run(const char* name, int wg_per_cu, int iters, size_t lds, float seed = 1.
 // magnitudes in [0.25, 4)), successive MFMAs alternate between them -> the multiplier inputs toggle on every issue.
 __device__ inline unsigned hash32(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 template <int NACC, int NSET>
-__global__ __launch_bounds__(256) void k_mfma_rand(int iters, int zero_frac_256, float* out, unsigned long long* clk) {
+__global__ __launch_bounds__(256) void k_mfma_rand(int iters, int zero_frac_256, int zero_frac_b, float* out, unsigned long long* clk) {
   f32x4_t acc[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -95,9 +95,9 @@ __global__ __launch_bounds__(256) void k_mfma_rand(int iters, int zero_frac_256,
     for (int i = 0; i < 4; ++i) {
       unsigned ha = hash32(threadIdx.x * 131u + s * 17u + i), hb = hash32(threadIdx.x * 977u + s * 29u + i + 1000u);
       // two bf16 per word: sign | exponent 125..128 | 7 mantissa bits
-      auto mk = [&](unsigned h) { unsigned lo = (h & 0x807fu) | ((125u + ((h >> 8) & 3u)) << 7); unsigned hi = ((h >> 16) & 0x807fu) | ((125u + ((h >> 24) & 3u)) << 7);
+      auto mk = [&](unsigned h, int zero_frac_256) { unsigned lo = (h & 0x807fu) | ((125u + ((h >> 8) & 3u)) << 7); unsigned hi = ((h >> 16) & 0x807fu) | ((125u + ((h >> 24) & 3u)) << 7);
                                   if ((int)(h >> 20 & 255u) < zero_frac_256) lo = 0; if ((int)(h >> 4 & 255u) < zero_frac_256) hi = 0; return lo | (hi << 16); };
-      a[s][i] = mk(ha); b[s][i] = mk(hb);
+      a[s][i] = mk(ha, zero_frac_256); b[s][i] = mk(hb, zero_frac_b);
     }
   const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int it = 0; it < iters; ++it) {
@@ -117,14 +117,15 @@ __global__ __launch_bounds__(256) void k_mfma_rand(int iters, int zero_frac_256,
   if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
 }
 
-void run_rand(const char* name, int iters, int zero_frac_256) {
+void run_rand(const char* name, int iters, int zero_frac_256, int zero_frac_b = -1) {
+  if (zero_frac_b < 0) zero_frac_b = zero_frac_256;
   float* out; unsigned long long* clk;
   hipMalloc(&out, 4); hipMalloc(&clk, 16);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float best = 1e30f; unsigned long long h[2] = {0, 1};
   for (int rep = 0; rep < 4; ++rep) {
     hipEventRecord(e0);
-    k_mfma_rand<32, 4><<<256, 256, 100 * 1024>>>(iters, zero_frac_256, out, clk);
+    k_mfma_rand<32, 4><<<256, 256, 100 * 1024>>>(iters, zero_frac_256, zero_frac_b, out, clk);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (rep && ms < best) { best = ms; hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost); }
@@ -140,6 +141,10 @@ int main() {
     run_rand("16x16x32 bf16, RANDOM operands, 4x4 register sets", it, 0);
     run_rand("  same, half of the operand values zero", it, 128);
     run_rand("  same, all operand values zero", it, 256);
+    run_rand("  A operand (srcA) half zeros, B dense", it, 128, 0);
+    run_rand("  B operand (srcB) half zeros, A dense", it, 0, 128);
+    run_rand("  A operand all zeros, B dense", it, 256, 0);
+    run_rand("  B operand all zeros, A dense", it, 0, 256);
   }
   const int it = 20000;
   run<32>("16x16x32 bf16, 1 wave/SIMD, data", 1, it, 100 * 1024);
