@@ -408,6 +408,13 @@ int fill_levels(HgLevels& lv, int L, const long long* off, const int* res, const
 
 }  // namespace
 
+// launch K<F, DT> (or K<F, DT, TH>) for the run-time dtype code dt_ (0 fp32 / 1 bf16 / 2 half); the variadic part is the
+// <<<grid, block, lds, stream>>>(arguments...) text
+#define HG_BY_DTYPE(dt_, K_, F_, ...)                                                                                     \
+  do { if ((dt_) == 0) K_<F_, 0> __VA_ARGS__; else if ((dt_) == 1) K_<F_, 1> __VA_ARGS__; else K_<F_, 2> __VA_ARGS__; } while (0)
+#define HG_BY_DTYPE_T(dt_, K_, F_, TH_, ...)                                                                              \
+  do { if ((dt_) == 0) K_<F_, 0, TH_> __VA_ARGS__; else if ((dt_) == 1) K_<F_, 1, TH_> __VA_ARGS__; else K_<F_, 2, TH_> __VA_ARGS__; } while (0)
+
 static int hashgrid_fwd_impl(int n, int n_levels, int features, const long long* level_offsets, const int* level_resolutions,
                              const float* level_scales, const float* x01, const void* table, int table_half, int out_bf16,
                              int row_pitch, void* out, void* stream);
@@ -438,11 +445,11 @@ static int hashgrid_fwd_impl(int n, int n_levels, int features, const long long*
   const dim3 g((unsigned)nblk * (unsigned)((n_levels + HG_LG - 1) / HG_LG)), b(256);
   hipStream_t st = (hipStream_t)stream;
   if (features == 2) {
-    switch (out_bf16 + 3 * table_half) { case 0: k_hashgrid_fwd<2, 0, false><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break; case 1: k_hashgrid_fwd<2, 1, false><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break; case 2: k_hashgrid_fwd<2, 2, false><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break;
-      case 3: k_hashgrid_fwd<2, 0, true><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break; case 4: k_hashgrid_fwd<2, 1, true><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break; default: k_hashgrid_fwd<2, 2, true><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break; }
+    if (table_half) HG_BY_DTYPE_T(out_bf16, k_hashgrid_fwd, 2, true, <<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out));
+    else HG_BY_DTYPE_T(out_bf16, k_hashgrid_fwd, 2, false, <<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out));
   } else {
-    switch (out_bf16 + 3 * table_half) { case 0: k_hashgrid_fwd<4, 0, false><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break; case 1: k_hashgrid_fwd<4, 1, false><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break; case 2: k_hashgrid_fwd<4, 2, false><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break;
-      case 3: k_hashgrid_fwd<4, 0, true><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break; case 4: k_hashgrid_fwd<4, 1, true><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break; default: k_hashgrid_fwd<4, 2, true><<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out); break; }
+    if (table_half) HG_BY_DTYPE_T(out_bf16, k_hashgrid_fwd, 4, true, <<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out));
+    else HG_BY_DTYPE_T(out_bf16, k_hashgrid_fwd, 4, false, <<<g, b, 0, st>>>(n, nblk, n_levels, lv, x01, table, row_pitch, out));
   }
   HUGS_CHECK_LAUNCH("k_hashgrid_fwd");
   return 0;
@@ -465,17 +472,17 @@ extern "C" int hugs_hashgrid_bwd(int n, int n_levels, int features, const long l
   if (r0 * r0 * r0 <= e0 && (long long)e0 * features <= HG_L0_MAX_FLOATS && n >= 65536) {
     const int g0 = (int)(((n + 255) / 256) < 768 ? ((n + 255) / 256) : 768);
     if (features == 2) {
-      switch (d_out_bf16) { case 0: k_hashgrid_bwd_l0<2, 0><<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum); break; case 1: k_hashgrid_bwd_l0<2, 1><<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum); break; default: k_hashgrid_bwd_l0<2, 2><<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum); break; }
+      HG_BY_DTYPE(d_out_bf16, k_hashgrid_bwd_l0, 2, <<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum));
     } else {
-      switch (d_out_bf16) { case 0: k_hashgrid_bwd_l0<4, 0><<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum); break; case 1: k_hashgrid_bwd_l0<4, 1><<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum); break; default: k_hashgrid_bwd_l0<4, 2><<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum); break; }
+      HG_BY_DTYPE(d_out_bf16, k_hashgrid_bwd_l0, 4, <<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum));
     }
     l_begin = 1;
     if (n_levels == 1) { HUGS_CHECK_LAUNCH("k_hashgrid_bwd_l0"); return 0; }
   }
   if (features == 2) {
-    switch (d_out_bf16) { case 0: k_hashgrid_bwd<2, 0><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin); break; case 1: k_hashgrid_bwd<2, 1><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin); break; default: k_hashgrid_bwd<2, 2><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin); break; }
+    HG_BY_DTYPE(d_out_bf16, k_hashgrid_bwd, 2, <<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin));
   } else {
-    switch (d_out_bf16) { case 0: k_hashgrid_bwd<4, 0><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin); break; case 1: k_hashgrid_bwd<4, 1><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin); break; default: k_hashgrid_bwd<4, 2><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin); break; }
+    HG_BY_DTYPE(d_out_bf16, k_hashgrid_bwd, 4, <<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin));
   }
   HUGS_CHECK_LAUNCH("k_hashgrid_bwd");
   return 0;
@@ -484,7 +491,11 @@ extern "C" int hugs_hashgrid_bwd(int n, int n_levels, int features, const long l
 extern "C" int hugs_sh4_fwd(int n, const float* dirs01, int out_bf16, int row_pitch, int col0, void* out, void* stream) {
   HUGS_REQUIRE(row_pitch >= col0 + 16 && col0 >= 0, -2, "hugs_sh4_fwd: row pitch %d, first column %d", row_pitch, col0);
   if (n <= 0) return 0;
-  switch (out_bf16) { case 0: k_sh4<0><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, dirs01, row_pitch, col0, out); break; case 1: k_sh4<1><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, dirs01, row_pitch, col0, out); break; default: k_sh4<2><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, dirs01, row_pitch, col0, out); break; }
+  switch (out_bf16) {
+    case 0: k_sh4<0><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, dirs01, row_pitch, col0, out); break;
+    case 1: k_sh4<1><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, dirs01, row_pitch, col0, out); break;
+    default: k_sh4<2><<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, dirs01, row_pitch, col0, out); break;
+  }
   HUGS_CHECK_LAUNCH("k_sh4");
   return 0;
 }
@@ -505,9 +516,9 @@ extern "C" int hugs_hashgrid2d_fwd(int n, int n_levels, int features, const long
   const dim3 g((n + 255) / 256), b(256);
   hipStream_t st = (hipStream_t)stream;
   if (features == 2) {
-    switch (out_bf16) { case 0: k_hashgrid2d_fwd<2, 0><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, extra, T, row_pitch, out); break; case 1: k_hashgrid2d_fwd<2, 1><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, extra, T, row_pitch, out); break; default: k_hashgrid2d_fwd<2, 2><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, extra, T, row_pitch, out); break; }
+    HG_BY_DTYPE(out_bf16, k_hashgrid2d_fwd, 2, <<<g, b, 0, st>>>(n, n_levels, lv, x01, table, extra, T, row_pitch, out));
   } else {
-    switch (out_bf16) { case 0: k_hashgrid2d_fwd<4, 0><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, extra, T, row_pitch, out); break; case 1: k_hashgrid2d_fwd<4, 1><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, extra, T, row_pitch, out); break; default: k_hashgrid2d_fwd<4, 2><<<g, b, 0, st>>>(n, n_levels, lv, x01, table, extra, T, row_pitch, out); break; }
+    HG_BY_DTYPE(out_bf16, k_hashgrid2d_fwd, 4, <<<g, b, 0, st>>>(n, n_levels, lv, x01, table, extra, T, row_pitch, out));
   }
   HUGS_CHECK_LAUNCH("k_hashgrid2d_fwd");
   return 0;
@@ -524,9 +535,9 @@ extern "C" int hugs_hashgrid2d_bwd(int n, int n_levels, int features, const long
   const dim3 g((n + 255) / 256), b(256);
   hipStream_t st = (hipStream_t)stream;
   if (features == 2) {
-    switch (d_out_bf16) { case 0: k_hashgrid2d_bwd<2, 0><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum); break; case 1: k_hashgrid2d_bwd<2, 1><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum); break; default: k_hashgrid2d_bwd<2, 2><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum); break; }
+    HG_BY_DTYPE(d_out_bf16, k_hashgrid2d_bwd, 2, <<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum));
   } else {
-    switch (d_out_bf16) { case 0: k_hashgrid2d_bwd<4, 0><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum); break; case 1: k_hashgrid2d_bwd<4, 1><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum); break; default: k_hashgrid2d_bwd<4, 2><<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum); break; }
+    HG_BY_DTYPE(d_out_bf16, k_hashgrid2d_bwd, 4, <<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum));
   }
   HUGS_CHECK_LAUNCH("k_hashgrid2d_bwd");
   return 0;
