@@ -108,8 +108,6 @@ class MLPSpec:
       raise NotImplementedError('transient MLP: width 128, 2 <= depth <= skip_layer_transient, rgb branch enabled')
     if self.bottleneck_noise > 0 or self.density_noise > 0:
       raise NotImplementedError('bottleneck/density noise is not built')
-    if self.rgb_premultiplier != 1. or self.rgb_bias != 0.:
-      raise NotImplementedError('rgb_premultiplier / rgb_bias are not built')
     if self.warp_fn is not None and getattr(self.warp_fn, 'name', self.warp_fn) != 'coord.contract':
       raise NotImplementedError(f'warp_fn {self.warp_fn!r}: only @coord.contract is built')
 
@@ -373,8 +371,8 @@ class Engine:
       _lib.call('hugs_gemm_nt', dt, M, H, Bw, 0, bott, Bw, None, 0, self.wt[(spec.name, lv['name'], 'kernel')], Bw, None, rb,
                 S, H, 1, None, 0, None, None, hact, H)
       rgb = ws.get(tag + '/rgb', (M, 3))
-      _lib.call('hugs_rgb_fwd', dt, M, H, hact, H, lay.view(theta, (spec.name, lr['name'], 'kernel')),
-                lay.view(theta, (spec.name, lr['name'], 'bias')), spec.rgb_padding, rgb)
+      Wr, br = self._rgb_head(theta, spec, lr, tag + '/rgbhead')
+      _lib.call('hugs_rgb_fwd', dt, M, H, hact, H, Wr, br, spec.rgb_padding, rgb)
       out.update(bott=bott, hview=hact, rgb=rgb)
       if spec.num_tra > 0 and tra is not None:
         # models.py:521-539: x = [bottleneck | tra_vec] -> (Dense+relu) x depth_t -> density_t, rgb_t, uncertainty.
@@ -402,8 +400,8 @@ class Engine:
         _lib.call('hugs_density_fwd', dt, M, Ht, x, Ht, lay.view(theta, (spec.name, ld_['name'], 'kernel')).reshape(-1),
                   lay.view(theta, (spec.name, ld_['name'], 'bias')), spec.density_bias, raw_t, dens_t)
         rgb_t = ws.get(tag + '/rgb_t', (M, 3))
-        _lib.call('hugs_rgb_fwd', dt, M, Ht, x, Ht, lay.view(theta, (spec.name, lr_['name'], 'kernel')),
-                  lay.view(theta, (spec.name, lr_['name'], 'bias')), spec.rgb_padding, rgb_t)
+        Wrt, brt = self._rgb_head(theta, spec, lr_, 'tbwd/rgbhead_t')
+        _lib.call('hugs_rgb_fwd', dt, M, Ht, x, Ht, Wrt, brt, spec.rgb_padding, rgb_t)
         raw_u, unc = ws.get(tag + '/raw_u', (M,)), ws.get(tag + '/unc', (M,))
         _lib.call('hugs_density_fwd', dt, M, Ht, x, Ht, lay.view(theta, (spec.name, lu_['name'], 'kernel')).reshape(-1),
                   lay.view(theta, (spec.name, lu_['name'], 'bias')), 0.0, raw_u, unc)      # softplus, no bias shift
@@ -498,6 +496,20 @@ class Engine:
     slab = self.ws.get(f'tn_slab/{torch.cuda.current_stream().cuda_stream}', (max(nbytes // 4, 1),))
     _lib.call('hugs_gemm_tn', self.dt, M, Kc, Nn, ns, X, ldx, G, ldg, dW, db, slab)
 
+  def _rgb_head(self, theta, spec, layer, tag):
+    """(W, b) the rgb head kernels see: rgb = sigmoid(premultiplier (h W + b) + rgb_bias) (models.py:514-516, :534-536) is
+    sigmoid(h (p W) + (p b + rgb_bias)); the kernels' weight / bias gradients are then those of (p W, p b + r): times p."""
+    W = self.layout.view(theta, (spec.name, layer['name'], 'kernel'))
+    b = self.layout.view(theta, (spec.name, layer['name'], 'bias'))
+    p_, r_ = float(spec.rgb_premultiplier), float(spec.rgb_bias)
+    if p_ == 1. and r_ == 0.:
+      return W, b
+    We, be = self.ws.get(tag + '/W_eff', tuple(W.shape)), self.ws.get(tag + '/b_eff', (4,))
+    torch.mul(W, p_, out=We)
+    torch.mul(b, p_, out=be[:3])
+    be[:3].add_(r_)
+    return We, be
+
   def backward_level(self, theta, grad, lv, rays, N, d_rgb_out, d_w_extra, nerfw=None, leaf_done=None, lane=0):
     """Backward of one level: compositing -> heads -> trunk.  Writes (=, not +=) the level's MLP gradients
     into `grad` (flat, same layout as theta); GLO embedding rows are scatter-added (caller zeroes them).
@@ -541,9 +553,13 @@ class Engine:
       Bw, H = spec.bottleneck_width, spec.net_width_viewdirs
       Gv = ws.get(tag + '/Gview', (M, H), self.tdt)
       rws = ws.get(tag + '/rgb_ws', (max(_lib.lib().cdll.hugs_rgb_bwd_ws_bytes() // 4, 1),))
-      _lib.call('hugs_rgb_bwd', dt, M, H, lv['hview'], H, lay.view(theta, (spec.name, lr['name'], 'kernel')), lv['rgb'],
+      Wr, _ = self._rgb_head(theta, spec, lr, tag + '/rgbhead')
+      _lib.call('hugs_rgb_bwd', dt, M, H, lv['hview'], H, Wr, lv['rgb'],
                 d_rgb_s, spec.rgb_padding, Gv, H, gview((spec.name, lr['name'], 'kernel')),
                 gview((spec.name, lr['name'], 'bias')), rws)
+      if spec.rgb_premultiplier != 1.:
+        gview((spec.name, lr['name'], 'kernel')).mul_(float(spec.rgb_premultiplier))
+        gview((spec.name, lr['name'], 'bias')).mul_(float(spec.rgb_premultiplier))
       gWv = gview((spec.name, lvw['name'], 'kernel'))
       Wv = lay.view(theta, (spec.name, lvw['name'], 'kernel'))
       d_rb = ws.get(tag + '/d_rb', (N, H))
@@ -662,8 +678,12 @@ class Engine:
     G = ws.get('tbwd/Ga', (M, Ht), self.tdt)
     other = ws.get('tbwd/Gb', (M, Ht), self.tdt)
     rws = ws.get('rgb_ws', (max(_lib.lib().cdll.hugs_rgb_bwd_ws_bytes() // 4, 1),))
-    _lib.call('hugs_rgb_bwd', dt, M, Ht, x3, Ht, lay.view(theta, (spec.name, lr_['name'], 'kernel')), lv['rgb_t'], d_ct,
+    Wrt, _ = self._rgb_head(theta, spec, lr_, 'tbwd/rgbhead_t')
+    _lib.call('hugs_rgb_bwd', dt, M, Ht, x3, Ht, Wrt, lv['rgb_t'], d_ct,
               spec.rgb_padding, G, Ht, gview((spec.name, lr_['name'], 'kernel')), gview((spec.name, lr_['name'], 'bias')), rws)
+    if spec.rgb_premultiplier != 1.:
+      gview((spec.name, lr_['name'], 'kernel')).mul_(float(spec.rgb_premultiplier))
+      gview((spec.name, lr_['name'], 'bias')).mul_(float(spec.rgb_premultiplier))
     dws = ws.get('dens_ws_t', (max(_lib.lib().cdll.hugs_density_bwd_ws_bytes(Ht) // 4, 1),))
     d_raw_t, d_raw_u = ws.get('tbwd/d_raw_t', (M,)), ws.get('tbwd/d_raw_u', (M,))
     _lib.call('hugs_density_bwd', dt, M, Ht, x3, Ht, d_dt, lv['raw_t'], spec.density_bias, d_raw_t,

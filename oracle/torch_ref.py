@@ -338,6 +338,7 @@ class ModelCfg:
     self.deg_view = 4
     self.density_bias = -1.
     self.rgb_padding = 0.001
+    self.rgb_premultiplier, self.rgb_bias = 1., 0.          # models.py:380-381
     # Config
     self.data_loss_type = 'charb'
     self.charb_padding = 0.001
@@ -475,7 +476,7 @@ def mlp_forward(cfg, mod, which, feats, viewdirs, glo_vec, taps=None, tra_vec=No
     taps.append(pre.detach())
   x = torch.relu(pre)
   L = mod[f'Dense_{depth + 3}']
-  rgb = torch.sigmoid(x @ L['kernel'] + L['bias'])
+  rgb = torch.sigmoid(cfg.rgb_premultiplier * (x @ L['kernel'] + L['bias']) + cfg.rgb_bias)      # models.py:514-516
   rgb = rgb * (1 + 2 * cfg.rgb_padding) - cfg.rgb_padding
   if tra_vec is None or which != 'nerf' or cfg.transient_type != 'nerfw':
     return density, rgb
@@ -490,7 +491,7 @@ def mlp_forward(cfg, mod, which, feats, viewdirs, glo_vec, taps=None, tra_vec=No
   j += cfg.transient_depth
   sp = lambda z: torch.logaddexp(z, torch.zeros_like(z))
   dens_t = sp((x @ mod[f'Dense_{j}']['kernel'] + mod[f'Dense_{j}']['bias'])[..., 0] + cfg.density_bias)
-  rgb_t = torch.sigmoid(x @ mod[f'Dense_{j + 1}']['kernel'] + mod[f'Dense_{j + 1}']['bias'])
+  rgb_t = torch.sigmoid(cfg.rgb_premultiplier * (x @ mod[f'Dense_{j + 1}']['kernel'] + mod[f'Dense_{j + 1}']['bias']) + cfg.rgb_bias)   # :534-536
   rgb_t = rgb_t * (1 + 2 * cfg.rgb_padding) - cfg.rgb_padding
   unc = sp(x @ mod[f'Dense_{j + 2}']['kernel'] + mod[f'Dense_{j + 2}']['bias'])
   return density, rgb, dict(density_transient=dens_t, rgb_transient=rgb_t, uncertainty=unc)

@@ -66,7 +66,8 @@ CASES = {
         Config={'transient_type': 'nerfw', 'randomized': True, 'patch_size': 4, 'distortion_loss_mult': 0.001},
         Model=dict(BASE_MODEL, num_levels=2, num_prop_samples=64, num_nerf_samples=64, num_glo_features=8,
                    num_transient_features=6),
-        NerfMLP=dict(SMALL_NERF, net_width_transient=128), PropMLP=SMALL_PROP,
+        # (rgb_premultiplier / rgb_bias, models.py:380-381,514-516,534-536: both rgb heads of this case)
+        NerfMLP=dict(SMALL_NERF, net_width_transient=128, rgb_premultiplier=1.5, rgb_bias=-0.3), PropMLP=SMALL_PROP,
         n_patch=2, P=4, near=0.1, far=1.2, hist_step=1),
     'hanerf': dict(
         Config={'transient_type': 'hanerf', 'randomized': True, 'patch_size': 4, 'distortion_loss_mult': 0.001,

@@ -100,6 +100,7 @@ def oracle_cfg(case):
   cfg = R.ModelCfg(**kw)
   if 'net_width_transient' in n:
     cfg.transient_width = n['net_width_transient']
+  cfg.rgb_premultiplier, cfg.rgb_bias = n.get('rgb_premultiplier', 1.), n.get('rgb_bias', 0.)
   return cfg
 
 
