@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_cast_ipe(int nrays, int S, const float*
     const float dx = dirs[ray * 3], dy = dirs[ray * 3 + 1], dz = dirs[ray * 3 + 2];
     const float rad = radii[ray];
     float t_mean, t_var, r_var;
-    if (ray_shape == 0) {  // cone, render.py:62-70
+    if ((ray_shape & 3) == 0) {  // cone, render.py:62-70
       const float mu = (t0 + t1) / 2, hw = (t1 - t0) / 2;
       const float den = fmaxf(HUGS_EPS, 3 * mu * mu + hw * hw);
       const float hw2 = hw * hw, hw4 = hw2 * hw2;
@@ -65,6 +65,10 @@ __global__ __launch_bounds__(256) void k_cast_ipe(int nrays, int S, const float*
     c[3] = t_var * dy * dy + r_var * (1 - dy * ey);
     c[4] = t_var * dy * dz + r_var * (0 - dy * ez);
     c[5] = t_var * dz * dz + r_var * (1 - dz * ez);
+    if (ray_shape & 4) {   // Model.disable_integration (models.py:223-226): zero covariances, "PE instead of IPE"
+#pragma unroll
+      for (int k = 0; k < 6; ++k) c[k] = 0.f;
+    }
     if (warp) {  // coord.py:21-27,39-60 with the closed-form Jacobian of contract
       const float n2 = fmaxf(HUGS_EPS, mx * mx + my * my + mz * mz);
       if (n2 > 1.0f) {
@@ -180,7 +184,7 @@ extern "C" int hugs_cast_ipe_fwd(int nrays, int num_samples, const float* tdist,
                                  const float* directions, const float* radii, const float* basis, int num_basis,
                                  int ray_shape, int warp_contract, int max_deg, int out_bf16, int row_pitch, void* out,
                                  void* stream) {
-  HUGS_REQUIRE(ray_shape == 0 || ray_shape == 1, -2, "ray_shape must be 'cone' or 'cylinder'");
+  HUGS_REQUIRE((ray_shape & ~4) == 0 || (ray_shape & ~4) == 1, -2, "ray_shape must be 'cone' or 'cylinder' (+4: zero covariances)");
   HUGS_REQUIRE(num_basis >= 1 && num_basis <= ENC_NB && max_deg >= 1 && max_deg <= 24, -3,
                "hugs_cast_ipe_fwd: basis size %d / max_deg %d unsupported", num_basis, max_deg);
   HUGS_REQUIRE(row_pitch % 8 == 0 && row_pitch >= 2 * num_basis * max_deg, -3,

@@ -305,7 +305,8 @@ class Engine:
     tag = f'{spec.name}/L{lvl}'
     X0 = ws.get(tag + '/X0', (M, spec.Fp), self.tdt)
     _lib.call('hugs_cast_ipe_fwd', N, S, tdist, rays['origins'], rays['directions'], rays['radii'], self.basis[spec.name],
-              spec.nb, 0 if self.model.ray_shape == 'cone' else 1, int(spec.warp_fn is not None), spec.max_deg_point,
+              spec.nb, (0 if self.model.ray_shape == 'cone' else 1) | (4 if self.model.disable_integration else 0),
+              int(spec.warp_fn is not None), spec.max_deg_point,
               dt, spec.Fp, X0)
     acts = [X0]
     x = X0

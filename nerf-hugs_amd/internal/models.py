@@ -46,8 +46,8 @@ class Model:
       raise NotImplementedError('randomised background intensity is not built (all HuGS gins use (1, 1))')
     # use_gpu_resampling only picks between two XLA formulations of the same inverse-CDF lookup (stepfun.py:153-161,
     # math.py:101-127); there is one HIP formulation, so the flag is accepted and has no effect.
-    if not self.stop_level_grad or not self.use_viewdirs or self.disable_integration:
-      raise NotImplementedError('stop_level_grad=False / use_viewdirs=False / disable_integration')
+    if not self.stop_level_grad or not self.use_viewdirs:
+      raise NotImplementedError('stop_level_grad=False / use_viewdirs=False')
     self.bg_intensity = float(self.bg_intensity_range[0])
     rd = self.raydist_fn
     name = None if rd is None else getattr(rd, 'name', rd)

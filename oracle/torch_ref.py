@@ -339,6 +339,7 @@ class ModelCfg:
     self.density_bias = -1.
     self.rgb_padding = 0.001
     self.rgb_premultiplier, self.rgb_bias = 1., 0.          # models.py:380-381
+    self.disable_integration = False                         # models.py:59
     # Config
     self.data_loss_type = 'charb'
     self.charb_padding = 0.001
@@ -547,6 +548,8 @@ def model_forward(cfg, variables, rays, train_frac, u01, compute_extras, zero_gl
     if override_samples is not None:   # tests: feed the sampler output of the implementation under test
       sdist, tdist = override_samples[lvl][0].to(dt), override_samples[lvl][1].to(dt)
     means, covs = cast_rays(tdist, rays['origins'], rays['directions'], rays['radii'], cfg.ray_shape)
+    if getattr(cfg, 'disable_integration', False):      # models.py:223-226
+      covs = torch.zeros_like(covs)
     if cfg.warp:
       means, covs = contract_track_linearize(means, covs)
     lm, lv = lift_and_diagonalize(means, covs, basis)

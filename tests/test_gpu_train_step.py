@@ -106,6 +106,18 @@ def test_train_step_piecewise_raydist():
   _run_case(gin, near=(0.0, 0.2), far=50.0, tol_grad=1e-1)
 
 
+def test_train_step_disable_integration_and_rgb_premultiplier():
+  """Model.disable_integration (models.py:223-226: zero covariances, PE instead of IPE) with the contraction, and
+  NerfMLP.rgb_premultiplier / rgb_bias (models.py:514-516)."""
+  gin = [g for g in SMALL] + ["Model.disable_integration = True", "NerfMLP.warp_fn = @coord.contract", "PropMLP.warp_fn = @coord.contract",
+                              "NerfMLP.rgb_premultiplier = 1.4", "NerfMLP.rgb_bias = -0.25",
+                              # (without the variance damping the 2^11 x frequencies turn 1 ulp of a position into O(1e-3) of a
+                              # feature: degrees up to 2^5 keep the float32 comparison meaningful)
+                              "NerfMLP.max_deg_point = 6", "PropMLP.max_deg_point = 6"]
+  # (the proposal density bias is ONE number, here a near-cancelling sum of magnitude 1e-6: 12 % of it is a single sample)
+  _run_case(gin, near=(0.05, 0.3), far=30.0, tol_grad=2e-1)
+
+
 def test_train_step_static_mask():
   gin = [g for g in SMALL if 'data_loss_type' not in g] + ["Config.transient_type = 'withmask'",
                                                            "Model.num_glo_features = 48"]
