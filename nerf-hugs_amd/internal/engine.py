@@ -60,14 +60,14 @@ class MLPSpec:
     self.basis = geopoly.generate_basis(self.basis_shape, self.basis_subdivisions).T.astype(np.float32).copy()  # [3,nb]
     self.nb = self.basis.shape[1]
     self.F = 2 * self.nb * (self.max_deg_point - self.min_deg_point)
-    self.Fp = _round_up(self.F, 64)
+    self.Fp = _round_up(self.F, 128)      # whole 128-wide K tiles of the weight-gradient GEMM (504 -> 512 at the default degree 12)
     self.nd = 3 + 6 * self.deg_view
     # Dense layers in flax creation order: (name, fan_in, fan_in_padded, fan_out, kind)
     # Trunk widths that are not a multiple of the 128-column MFMA tile (debug.gin's 64-wide PropMLP) are padded with
     # zero output columns / zero bias: relu(0) = 0 feeds zero rows of the next kernel, and every gradient of the
     # padding is exactly 0, so it stays 0 under Adam.
     self.Wp = _round_up(self.net_width, 128)
-    L, k, kp = [], self.F, _round_up(self.F, 64)
+    L, k, kp = [], self.F, self.Fp
     for i in range(self.net_depth):
       concat_in = i > 0 and (i - 1) % self.skip_layer == 0 and (i - 1) > 0
       L.append(dict(fan_in=k, kpad=(self.Wp + self.Fp) if concat_in else kp, fan_out=self.net_width, npad=self.Wp,

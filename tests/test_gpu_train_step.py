@@ -118,6 +118,22 @@ def test_train_step_disable_integration_and_rgb_premultiplier():
   _run_case(gin, near=(0.05, 0.3), far=30.0, tol_grad=2e-1)
 
 
+def test_encoder_width_that_is_not_a_multiple_of_64_trains():
+  """max_deg_point = 7: 294 IPE features, padded to 384 (whole 128-wide K tiles for the weight-gradient GEMM; a padding to 64
+  left Kc = 320 and hugs_gemm_tn refused it).  Three steps: finite, and the loss moves."""
+  from tests import hugs_testlib as H
+  gin = list(SMALL) + ["NerfMLP.max_deg_point = 7", "PropMLP.max_deg_point = 7"]
+  config, model, state, render_fn, train_step, cfg, oparams = H.make_pair(gin)
+  assert model.nerf_spec.F == 294 and model.nerf_spec.Fp == 384
+  batch = H.synth_rays(1, 8, 3)
+  gen = torch.Generator(device='cuda').manual_seed(5)
+  losses = []
+  for _ in range(3):
+    state, stats, gen = train_step(gen, state, batch, 0.5, None)
+    losses.append(float(stats['loss']))
+  assert all(np.isfinite(losses)) and bool(torch.isfinite(state.flat).all()) and losses[2] != losses[0], losses
+
+
 def test_train_step_static_mask():
   gin = [g for g in SMALL if 'data_loss_type' not in g] + ["Config.transient_type = 'withmask'",
                                                            "Model.num_glo_features = 48"]
