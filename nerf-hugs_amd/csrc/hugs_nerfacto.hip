@@ -400,20 +400,18 @@ __global__ void k_nf_base_grad(long long M, int bf16, const void* __restrict__ Y
   if (m >= M) return;
   float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if ((int)c0 <= ngeo) {                           // (chunks behind the last real column are all zero: no loads)
-    if (bf16 && dXh && ngeo <= 15 && (geo_col0 & 7) == 0 && (ldx & 7) == 0) {
-      // the head's geo gradients = 16 consecutive 16-bit columns of its input gradient row: two aligned 16-byte loads
-      const uint4 a = *(const uint4*)((const uint16_t*)dXh + (size_t)m * ldx + geo_col0), b = *(const uint4*)((const uint16_t*)dXh + (size_t)m * ldx + geo_col0 + 8);
-      const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-      float y16[16];
+    if (bf16 && dXh && (geo_col0 & 7) == 0 && geo_col0 >= 8 && (ldx & 7) == 0 && geo_col0 + (int)c0 + 8 <= ldx) {
+      // G columns c0 .. c0+7 = head-input-gradient columns geo_col0 + c0 - 1 ..: the 16 columns from geo_col0 + c0 - 8 as two
+      // aligned 16-byte loads, shifted by one element
+      const uint16_t* xr = (const uint16_t*)dXh + (size_t)m * ldx + geo_col0 + c0 - 8;
+      const uint4 lo = *(const uint4*)xr, hi = *(const uint4*)(xr + 8);
+      const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { y16[2 * j] = op16_to_f((uint16_t)w[j], bf16); y16[2 * j + 1] = op16_to_f((uint16_t)(w[j] >> 16), bf16); }
-      if (c0 == 0u) {
-        v[0] = d_density[m] * expf(fminf(fmaxf(nf_load(Y, (size_t)m * ldy, bf16), -15.f), 15.f)) * sel[m];
-#pragma unroll
-        for (int q = 1; q < 8; ++q) v[q] = q <= ngeo ? y16[q - 1] : 0.f;
-      } else {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = 8 + q <= ngeo ? y16[q + 7] : 0.f;
+      for (int q = 0; q < 8; ++q) {
+        const int c = (int)c0 + q, j = q + 7;                      // element geo_col0 + c0 - 8 + j = geo_col0 + c - 1
+        const uint16_t h = (uint16_t)((j & 1) ? (w[j >> 1] >> 16) : w[j >> 1]);
+        if (c == 0) v[q] = d_density[m] * expf(fminf(fmaxf(nf_load(Y, (size_t)m * ldy, bf16), -15.f), 15.f)) * sel[m];
+        else if (c <= ngeo) v[q] = op16_to_f(h, bf16);
       }
     } else {
 #pragma unroll
@@ -448,10 +446,25 @@ __global__ __launch_bounds__(256) void k_nf_head_input(int nrays, int S, int bf1
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = tmpl[c0 + q];
     if (c0 < 16 + ngeo && c0 + 8 > 16) {                          // this chunk holds geo columns
+      if (bf16 && (ldy & 7) == 0 && c0 <= ldy) {                  // (the 16-column window [c0-16, c0) lies inside the row)
+        // output columns c0 .. c0+7 = base-output columns c0-15 .. c0-8: the 16 columns from c0-16 as two aligned 16-byte loads,
+        // shifted by one element (eight 2-byte loads at odd element offsets before)
+        const uint16_t* yr = (const uint16_t*)Yb + m * ldy + (c0 - 16);
+        const uint4 lo = *(const uint4*)yr;
+        const uint4 hi = *(const uint4*)(yr + 8);
+        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int c = c0 + q;
-        if (c >= 16 && c < 16 + ngeo) v[q] = nf_load(Yb, m * ldy + 1 + (c - 16), bf16);
+        for (int q = 0; q < 8; ++q) {
+          const int j = q + 1;                                     // element c0 - 16 + j
+          const uint16_t h = (uint16_t)((j & 1) ? (w[j >> 1] >> 16) : w[j >> 1]);
+          if (c0 + q < 16 + ngeo) v[q] = op16_to_f(h, bf16);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int c = c0 + q;
+          if (c >= 16 && c < 16 + ngeo) v[q] = nf_load(Yb, m * ldy + 1 + (c - 16), bf16);
+        }
       }
     }
     nf_store8(X, m * ldx + c0, bf16, v);
