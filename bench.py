@@ -91,12 +91,12 @@ def instep_roofline(train_step, state, batch, gen, thr, steps=5):
   if fwd:
     k = max(fwd, key=lambda k: len(agg[k]))
     main = entry(k, 'nt_fwd', f"NT forward trunk [{k[1]}x1024]x[1024x1024]^T +bias +relu, writes 1-bit relu masks "
-                 "(k_gemm_nt_bf16_pers<35>)", 2.0 * k[1] * W * W, 2.0 * k[1] * W * 2 + W * W * 2 + k[1] * W / 8)
+                 "(gemm_bf16::k_gemm_nt_bf16_pers<35>)", 2.0 * k[1] * W * W, 2.0 * k[1] * W * 2 + W * W * 2 + k[1] * W / 8)
   M = 131072
   fl = 2.0 * M * W * W
-  others = [entry(('nt', M, W, W, 'mask'), 'nt_dx', "NT dX [131072x1024]x[1024x1024] *relu-mask bits (k_gemm_nt_bf16_pers<16>)", fl,
+  others = [entry(('nt', M, W, W, 'mask'), 'nt_dx', "NT dX [131072x1024]x[1024x1024] *relu-mask bits (gemm_bf16::k_gemm_nt_bf16_pers<16>)", fl,
                   2.0 * M * W * 2 + W * W * 2 + M * W / 8),
-            entry(('tn', M, W, W, 'split16'), 'tn_dw', "TN dW [1024x131072]x[131072x1024] + slab reduce (k_gemm_tn_bf16_big)", fl,
+            entry(('tn', M, W, W, 'split16'), 'tn_dw', "TN dW [1024x131072]x[131072x1024] + slab reduce (gemm_bf16::k_gemm_tn_bf16_big)", fl,
                   2.0 * M * W * 2 + W * W * 4)]
   shapes = {f"{k[0]} M={k[1]} {k[2]}x{k[3]} {k[4]}": [len(v), round(float(np.mean(v)), 1)] for k, v in sorted(agg.items(), key=str)}
   return main, [o for o in others if o], shapes, state, gen
