@@ -901,11 +901,27 @@ __global__ __launch_bounds__(256) void k_nf_prop_bwd_mfma(long long M, int in_di
   float* rs = sR[wv];
   const long long ntile = (M + 63) >> 6, wave = (long long)blockIdx.x * 4 + wv, nwave = (long long)gridDim.x * 4;
 #define PM_WAVE_SYNC() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+  // the next tile's inputs are requested before the current tile's MFMAs (one tile of loads in flight per wave: without it a
+  // wave sat through the full global-load latency at the top of every tile)
+  auto load_tile = [&](long long t, uint2 (&xq)[4], float& dq, float& rq, float& sq) {
+    const long long s0 = t << 6, sm = s0 + lane;
+    const bool in = t < ntile && sm < M;
+    dq = in ? d_density[sm] : 0.f; rq = in ? raw[sm] : 0.f; sq = in ? sel[sm] : 0.f;
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb) {
+      const long long s = s0 + 16 * sb + lr;
+      xq[sb] = (t < ntile && s < M) ? *(const uint2*)(X + (size_t)s * ldx + 4 * lq) : make_uint2(0u, 0u);
+    }
+  };
+  uint2 xn[4];
+  float dn, rn, sn;
+  load_tile(wave, xn, dn, rn, sn);
   for (long long t = wave; t < ntile; t += nwave) {
     const long long s0 = t << 6;
     // d raw = d density * exp(clamp(raw, -15, 15)) * selector (custom_functions.py:46-50), sample s0 + lane
-    const long long sm = s0 + lane;
-    const float r = sm < M ? d_density[sm] * expf(fminf(fmaxf(raw[sm], -15.f), 15.f)) * sel[sm] : 0.f;
+    const float r = dn * expf(fminf(fmaxf(rn, -15.f), 15.f)) * sn;
+    uint2 xf[4] = {xn[0], xn[1], xn[2], xn[3]};
+    load_tile(t + nwave, xn, dn, rn, sn);
     ab1 += r;
     if (__ballot(r != 0.f) == 0ull) {             // a tile without gradient (outside the box, zero weight): dX = 0, done
 #pragma unroll
@@ -915,13 +931,8 @@ __global__ __launch_bounds__(256) void k_nf_prop_bwd_mfma(long long M, int in_di
       }
       continue;
     }
-    uint2 xf[4];
 #pragma unroll
-    for (int sb = 0; sb < 4; ++sb) {
-      const long long s = s0 + 16 * sb + lr;
-      xf[sb] = s < M ? *(const uint2*)(X + (size_t)s * ldx + 4 * lq) : make_uint2(0u, 0u);
-      *(uint2*)(xt + (16 * sb + lr) * 16 + 4 * lq) = xf[sb];
-    }
+    for (int sb = 0; sb < 4; ++sb) *(uint2*)(xt + (16 * sb + lr) * 16 + 4 * lq) = xf[sb];
     rs[lane] = r;
     PM_WAVE_SYNC()
 #pragma unroll
