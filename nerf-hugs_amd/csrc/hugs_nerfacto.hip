@@ -855,12 +855,23 @@ __global__ __launch_bounds__(256) void k_nf_prop_fwd_mfma(long long M, int in_di
   C.load(lane, in_dim, H, W0, ldw0, b0, w1, ldw1);
   const float b1v = b1[0];
   const long long ntile = (M + 63) >> 6, wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (long long)gridDim.x * 4;
+  auto load_tile = [&](long long t, uint2 (&xq)[4]) {
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb) {
+      const long long s = (t << 6) + 16 * sb + lr;
+      xq[sb] = (t < ntile && s < M) ? *(const uint2*)(X + (size_t)s * ldx + 4 * lq) : make_uint2(0u, 0u);
+    }
+  };
+  uint2 xn[4];
+  load_tile(wave, xn);
   for (long long t = wave; t < ntile; t += nwave) {
     const long long s0 = t << 6;
+    const uint2 xc[4] = {xn[0], xn[1], xn[2], xn[3]};
+    load_tile(t + nwave, xn);                      // the next tile's rows are in flight during this tile's MFMAs
 #pragma unroll
     for (int sb = 0; sb < 4; ++sb) {
       const long long s = s0 + 16 * sb + lr;
-      const uint2 xf = s < M ? *(const uint2*)(X + (size_t)s * ldx + 4 * lq) : make_uint2(0u, 0u);
+      const uint2 xf = xc[sb];
       float o = 0.f;
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) {
