@@ -191,6 +191,9 @@ int hugs_expand_patches(int npatch, int patch_size, int dilation, const int32_t*
  * maxval) (stepfun.py:207-209).  n < 2^32. */
 int hugs_prng_bits(const uint32_t* key, long long n, uint32_t* out, void* stream);
 int hugs_prng_uniform(const uint32_t* key, long long n, float minval, float maxval, float* out, void* stream);
+/* jax.random.normal(key, [n]): sqrt(2) erf_inv(uniform(key, minval = nextafter(-1, 0), maxval = 1)) with XLA's f32 erf_inv
+ * polynomial (models.py:458-460,478-481 noise draws; the draws of flax's initialisers). */
+int hugs_prng_normal(const uint32_t* key, long long n, float* out, void* stream);
 /* One training step's consumption of the jax.random stream in ONE launch: key_out = first key of split(key_in)
  * (train_utils.py:408 `rng, key = random.split(rng)`); with the second key, per level l < L (<= 8): models.py:196 split ->
  * stepfun.py:207-209 random.uniform(key, [n[l]], maxval = maxval[l]) into out[l], models.py:230 split.  n, maxval and out

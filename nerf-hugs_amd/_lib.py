@@ -46,6 +46,7 @@ _PROTOS = {
     'hugs_expand_patches': 'iiipppppps',
     'hugs_prng_bits': 'pqps',
     'hugs_prng_uniform': 'pqffps',
+    'hugs_prng_normal': 'pqps',
     'hugs_prng_step_jitter': 'pipppps',
     'hugs_ssim': 'iiippffffpps',
     'hugs_mse': 'qpppps',

@@ -28,7 +28,29 @@ __device__ __forceinline__ void threefry2x32(uint32_t k0, uint32_t k1, uint32_t&
 
 // jax threefry_2x32(key, iota(n)): the counters are padded to even length, the first half feeds word 0, the
 // second half word 1; output = concat(word-0 results, word-1 results)[:n].  Thread i owns the pair (i, h+i).
-template <bool UNIFORM>
+// erf^-1 in single precision: M. Giles, "Approximating the erfinv function" (2012), the polynomial pair XLA's ErfInv uses for
+// f32 (w = -log((1 - x)(1 + x)); central branch w < 5, tail branch in sqrt(w)).  jax.random.normal is
+// sqrt(2) * erf_inv(uniform(key, shape, minval = nextafter(-1, 0), maxval = 1)).
+__device__ __forceinline__ float erfinv_f32(float x) {
+  float w = -logf((1.f - x) * (1.f + x)), p;
+  if (w < 5.f) {
+    w -= 2.5f;
+    p = 2.81022636e-08f;
+    p = fmaf(p, w, 3.43273939e-07f); p = fmaf(p, w, -3.5233877e-06f); p = fmaf(p, w, -4.39150654e-06f);
+    p = fmaf(p, w, 0.00021858087f); p = fmaf(p, w, -0.00125372503f); p = fmaf(p, w, -0.00417768164f);
+    p = fmaf(p, w, 0.246640727f); p = fmaf(p, w, 1.50140941f);
+  } else {
+    w = sqrtf(w) - 3.f;
+    p = -0.000200214257f;
+    p = fmaf(p, w, 0.000100950558f); p = fmaf(p, w, 0.00134934322f); p = fmaf(p, w, -0.00367342844f);
+    p = fmaf(p, w, 0.00573950773f); p = fmaf(p, w, -0.0076224613f); p = fmaf(p, w, 0.00943887047f);
+    p = fmaf(p, w, 1.00167406f); p = fmaf(p, w, 2.83297682f);
+  }
+  return p * x;
+}
+
+// MODE 0: raw bits, 1: uniform [lo, hi), 2: standard normal (lo / hi ignored)
+template <int MODE>
 __global__ void __launch_bounds__(256)
 k_threefry(const uint32_t* __restrict__ key, long long n, float lo, float hi, void* __restrict__ out) {
   long long h = (n + 1) >> 1;
@@ -36,7 +58,13 @@ k_threefry(const uint32_t* __restrict__ key, long long n, float lo, float hi, vo
   if (i >= h) return;
   uint32_t x0 = (uint32_t)i, x1 = (h + i < n) ? (uint32_t)(h + i) : 0u;
   threefry2x32(key[0], key[1], x0, x1);
-  if (UNIFORM) {   // random.py uniform: mantissa bits -> [1,2) - 1 -> scale, shift, clamp at minval
+  if (MODE == 2) {   // jax _normal_real: u in [nextafter(-1, 0), 1), then sqrt(2) erf_inv(u)
+    const float nlo = -0.99999994f, scale = __fsub_rn(1.f, nlo);
+    const float f0 = __fsub_rn(__uint_as_float((x0 >> 9) | 0x3F800000u), 1.f);
+    const float f1 = __fsub_rn(__uint_as_float((x1 >> 9) | 0x3F800000u), 1.f);
+    ((float*)out)[i] = 1.41421356f * erfinv_f32(fmaxf(nlo, __fadd_rn(__fmul_rn(f0, scale), nlo)));
+    if (h + i < n) ((float*)out)[h + i] = 1.41421356f * erfinv_f32(fmaxf(nlo, __fadd_rn(__fmul_rn(f1, scale), nlo)));
+  } else if (MODE == 1) {   // random.py uniform: mantissa bits -> [1,2) - 1 -> scale, shift, clamp at minval
     float scale = __fsub_rn(hi, lo);
     float f0 = __fsub_rn(__uint_as_float((x0 >> 9) | 0x3F800000u), 1.f);
     float f1 = __fsub_rn(__uint_as_float((x1 >> 9) | 0x3F800000u), 1.f);
@@ -116,7 +144,7 @@ extern "C" int hugs_prng_bits(const uint32_t* key, long long n, uint32_t* out, v
   HUGS_REQUIRE(n >= 0 && n < (1ll << 32), -2, "hugs_prng_bits: n=%lld outside [0, 2^32)", n);
   if (n == 0) return 0;
   long long h = (n + 1) >> 1;
-  k_threefry<false><<<(unsigned)((h + 255) / 256), 256, 0, (hipStream_t)stream>>>(key, n, 0.f, 1.f, out);
+  k_threefry<0><<<(unsigned)((h + 255) / 256), 256, 0, (hipStream_t)stream>>>(key, n, 0.f, 1.f, out);
   HUGS_CHECK_LAUNCH("k_threefry");
   return 0;
 }
@@ -127,7 +155,20 @@ extern "C" int hugs_prng_uniform(const uint32_t* key, long long n, float minval,
   HUGS_REQUIRE(n >= 0 && n < (1ll << 32), -2, "hugs_prng_uniform: n=%lld outside [0, 2^32)", n);
   if (n == 0) return 0;
   long long h = (n + 1) >> 1;
-  k_threefry<true><<<(unsigned)((h + 255) / 256), 256, 0, (hipStream_t)stream>>>(key, n, minval, maxval, out);
+  k_threefry<1><<<(unsigned)((h + 255) / 256), 256, 0, (hipStream_t)stream>>>(key, n, minval, maxval, out);
+  HUGS_CHECK_LAUNCH("k_threefry");
+  return 0;
+}
+
+/* jax.random.normal(key, [n]) (models.py:458-460,478-481 density / bottleneck noise, and the flax initialisers' draws): the
+ * uniform stream above through XLA's single-precision erf_inv polynomial.  Agrees with the float64 evaluation of the same
+ * definition (oracle/threefry_ref.py normal) to a few ulp. */
+extern "C" int hugs_prng_normal(const uint32_t* key, long long n, float* out, void* stream) {
+  HUGS_REQUIRE(key && (out || n == 0), -2, "hugs_prng_normal: null pointer");
+  HUGS_REQUIRE(n >= 0 && n < (1ll << 32), -2, "hugs_prng_normal: n=%lld outside [0, 2^32)", n);
+  if (n == 0) return 0;
+  long long h = (n + 1) >> 1;
+  k_threefry<2><<<(unsigned)((h + 255) / 256), 256, 0, (hipStream_t)stream>>>(key, n, 0.f, 1.f, out);
   HUGS_CHECK_LAUNCH("k_threefry");
   return 0;
 }

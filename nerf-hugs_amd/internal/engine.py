@@ -106,8 +106,6 @@ class MLPSpec:
     if self.num_tra > 0 and (self.disable_rgb or self.net_width_transient != 128 or self.net_depth_transient < 2 or
                              self.net_depth_transient > self.skip_layer_transient):
       raise NotImplementedError('transient MLP: width 128, 2 <= depth <= skip_layer_transient, rgb branch enabled')
-    if self.bottleneck_noise > 0 or self.density_noise > 0:
-      raise NotImplementedError('bottleneck/density noise is not built')
     if self.warp_fn is not None and getattr(self.warp_fn, 'name', self.warp_fn) != 'coord.contract':
       raise NotImplementedError(f'warp_fn {self.warp_fn!r}: only @coord.contract is built')
 
@@ -299,7 +297,7 @@ class Engine:
     return self._cast_src is not None and self._cast_src == (state.gen, state.flat.data_ptr(), state.flat._version)
 
   # ---- forward ------------------------------------------------------------------------------------
-  def _mlp_forward(self, spec, theta, lvl, N, S, tdist, rays, glo, keep, tra=None):
+  def _mlp_forward(self, spec, theta, lvl, N, S, tdist, rays, glo, keep, tra=None, mlp_key=None):
     M = N * S
     lay, ws, dt = self.layout, self.ws, self.dt
     tag = f'{spec.name}/L{lvl}'
@@ -357,6 +355,13 @@ class Engine:
     density = ws.get(tag + '/density', (M,))
     bd = lay.view(theta, (spec.name, ld['name'], 'bias'))
     _lib.call('hugs_density_fwd', dt, M, W, x, W, wd, bd, spec.density_bias, raw, density)
+    noise_key = None
+    if mlp_key is not None and (spec.density_noise > 0 or spec.bottleneck_noise > 0):
+      from . import random as hrandom
+      density_key, noise_key = hrandom.split(mlp_key)          # models.py:435 density_key, rng = random_split(rng)
+      if spec.density_noise > 0:                                  # models.py:458-460: raw_density += noise * normal(key, [N, S])
+        raw.add_(hrandom.normal(density_key, (M,)), alpha=float(spec.density_noise))
+        density.copy_(torch.logaddexp(raw + float(spec.density_bias), torch.zeros_like(raw)))   # softplus, as hugs_density_fwd
     out = dict(X0=X0, acts=acts, raw=raw, density=density, rgb=None, bits=bits if nchunk == 1 else [None] * len(bits))
     if not spec.disable_rgb:
       lb, lv, lr = spec.layers[spec.net_depth + 1:spec.net_depth + 4]
@@ -364,6 +369,10 @@ class Engine:
       bott = ws.get(tag + '/bott', (M, Bw), self.tdt)
       _lib.call('hugs_gemm_nt', dt, M, Bw, W, 0, x, W, None, 0, self.wt[(spec.name, lb['name'], 'kernel')], W,
                 lay.view(theta, (spec.name, lb['name'], 'bias')), None, 1, 0, 0, None, 0, None, None, bott, Bw)
+      if noise_key is not None and spec.bottleneck_noise > 0:   # models.py:478-481: bottleneck += noise * normal(key, [N, S, Bw])
+        from . import random as hrandom
+        kb, _ = hrandom.split(noise_key)
+        bott.add_(hrandom.normal(kb, (M, Bw)).to(bott.dtype), alpha=float(spec.bottleneck_noise))
       Wv = lay.view(theta, (spec.name, lv['name'], 'kernel'))
       rb = ws.get(tag + '/raybias', (N, H))
       _lib.call('hugs_raybias_fwd', N, H, spec.nd, spec.num_glo, rays['dir_enc'], glo, Wv[Bw:],
@@ -462,7 +471,9 @@ class Engine:
                                     mdl.resample_padding, S, None if scaled else draw, mdl.raydist, rays['near'],
                                     rays['far'], jitter=draw if scaled else None)
       spec = mdl.prop_spec if is_prop else mdl.nerf_spec
-      out = self._mlp_forward(spec, theta, lvl, N, S, td, rays, glo, True, None if is_prop else tra)
+      mkeys = getattr(u01, 'mlp_keys', None)
+      out = self._mlp_forward(spec, theta, lvl, N, S, td, rays, glo, True, None if is_prop else tra,
+                              mlp_key=None if mkeys is None else mkeys[lvl])
       w = ws.get(f'L{lvl}/weights', (N, S))
       rgb_all = ws.get('rgb_out_all', (mdl.num_levels, N, 3))
       rgb_out = rgb_all[lvl]

@@ -108,12 +108,18 @@ class Model:
     the MLP key (models.py:230; density / bottleneck noise are 0 in every shipped gin, the split still advances).
     Returns (stepfun.Jitter, rng after the last level)."""
     out = stepfun.Jitter()
+    out.mlp_keys = []
     for l in range(self.num_levels):
       S = self.num_prop_samples if l < self.num_levels - 1 else self.num_nerf_samples
       key, rng = hrandom.split(rng)
       out.append(hrandom.uniform(key, (N, 1 if self.single_jitter else S), maxval=stepfun.sample_u(S, True)[1]))
-      _, rng = hrandom.split(rng)
+      key, rng = hrandom.split(rng)
+      out.mlp_keys.append(key)
     return out, rng
+
+  def has_noise(self):
+    """density_noise / bottleneck_noise > 0 on either MLP (models.py:378-381): their draws need the per-level MLP keys."""
+    return any(sp.density_noise > 0 or sp.bottleneck_noise > 0 for sp in (self.prop_spec, self.nerf_spec) if sp is not None)
 
   def step_jitter(self, rng, N):
     """train_step's `rng, key = random.split(rng)` (train_utils.py:408) followed by level_jitter(key, N), as one launch.
@@ -154,6 +160,8 @@ class Model:
       r = {k: pad(v) for k, v in r.items()}
       if u01 is not None:
         padded = [pad(u) for u in u01]
+        if isinstance(u01, stepfun.Jitter) and u01.mlp_keys is not None and self.has_noise():
+          raise NotImplementedError('density / bottleneck noise with a ray count that needs padding to the GEMM tile')
         u01 = stepfun.Jitter(padded) if isinstance(u01, stepfun.Jitter) else padded
     take = lambda buf, *tail: buf.reshape((Np,) + tail)[:N].clone().reshape(lead + tail)
     if refresh_weights:

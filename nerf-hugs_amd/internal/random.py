@@ -7,6 +7,7 @@ and drawing cost one small launch each and no synchronisation.  Streams are bit-
   PRNGKey(seed)            train.py:46            key = (seed >> 32, seed & 0xffffffff)
   split(key, num=2)        train_utils.py:408     [num, 2] keys
   uniform(key, shape, ...) stepfun.py:207-209     float32 in [minval, maxval)
+  normal(key, shape)       models.py:458-460      float32 N(0, 1): sqrt(2) erf_inv(uniform(-1, 1)) like jax
   bits(key, shape)                                raw uint32 draws (as int32 bit patterns)
   permutation(key, n)      models.py:644          jax's sort-by-random-keys shuffle (ceil(3 ln n / ln 2^32) rounds)
 """
@@ -51,6 +52,14 @@ def uniform(key, shape=(), minval=0., maxval=1.):
   _check(key)
   out = torch.empty(tuple(shape), dtype=torch.float32, device=key.device)
   L.call('hugs_prng_uniform', key, out.numel(), minval, maxval, out)
+  return out
+
+
+def normal(key, shape=()):
+  """jax.random.normal(key, shape): float32 standard normal draws (models.py:458-460,478-481; flax's initialisers)."""
+  _check(key)
+  out = torch.empty(tuple(shape), dtype=torch.float32, device=key.device)
+  L.call('hugs_prng_normal', key, out.numel(), out)
   return out
 
 

@@ -14,8 +14,11 @@ EPS = float(np.finfo(np.float32).eps)
 
 
 class Jitter(list):
-  """Per-level jitter draws that are already scaled to [0, max_jitter) (the jax.random path)."""
+  """Per-level jitter draws that are already scaled to [0, max_jitter) (the jax.random path).  `mlp_keys`: the key each
+  level's MLP call receives (models.py:230), kept when the draws come from Model.level_jitter -- the density / bottleneck
+  noise draws are split off it (models.py:435,458-460,478-481)."""
   scaled = True
+  mlp_keys = None
 
 
 def sample_u(num_samples, randomized, deterministic_center=True):

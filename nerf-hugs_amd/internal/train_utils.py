@@ -227,7 +227,7 @@ def create_train_step(model, config, is_finetune=False):
         raise ValueError(f'explicit jitter needs one tensor per level ({L}), got {len(rng)}')
       u01 = [u.to(device=dev, dtype=torch.float32).contiguous() for u in rng]
     elif hrandom.is_key(rng):                        # jax stream: rng, key = random.split(rng) (train_utils.py:408)
-      if config.randomized and L <= 8:
+      if config.randomized and L <= 8 and not model.has_noise():
         u01, rng = model.step_jitter(rng, N)         # that split + every level's split / uniform / split in one launch
       else:
         rng, key = hrandom.split(rng)

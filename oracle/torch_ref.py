@@ -447,7 +447,7 @@ def implicit_mask_forward(cfg, mod, pix_coords, tra_vec, taps=None):
   return torch.sigmoid(x @ L['kernel'] + L['bias'])
 
 
-def mlp_forward(cfg, mod, which, feats, viewdirs, glo_vec, taps=None, tra_vec=None):
+def mlp_forward(cfg, mod, which, feats, viewdirs, glo_vec, taps=None, tra_vec=None, noise=None):
   """models.py:406-550 (no transient branch). feats [...,S,504].  taps: optional list that receives the
   relu pre-activations (tests use it to find samples sitting on a ReLU kink)."""
   depth = cfg.nerf_depth if which == 'nerf' else cfg.prop_depth
@@ -462,11 +462,15 @@ def mlp_forward(cfg, mod, which, feats, viewdirs, glo_vec, taps=None, tra_vec=No
       x = torch.cat([x, inputs], -1)
   L = mod[f'Dense_{depth}']
   raw_density = (x @ L['kernel'] + L['bias'])[..., 0]
+  if noise is not None and noise.get('density') is not None:      # models.py:458-460 (the draws are the caller's: the key chain
+    raw_density = raw_density + noise['density']                  # of models.py:230,435 restated by the test with oracle/threefry_ref)
   density = torch.logaddexp(raw_density + cfg.density_bias, torch.zeros_like(raw_density))
   if which == 'prop' and cfg.prop_disable_rgb:
     return density, torch.zeros(feats.shape[:-1] + (3,), dtype=feats.dtype)
   L = mod[f'Dense_{depth + 1}']
   bott = x @ L['kernel'] + L['bias']
+  if noise is not None and noise.get('bottleneck') is not None:   # models.py:478-481
+    bott = bott + noise['bottleneck']
   parts = [bott, pos_enc(viewdirs, 0, cfg.deg_view, True)[..., None, :].expand(bott.shape[:-1] + (-1,))]
   if glo_vec is not None:
     parts.append(glo_vec[..., None, :].expand(bott.shape[:-1] + (-1,)))
@@ -513,7 +517,7 @@ def sample_u_base(num_samples, randomized):
 
 
 def model_forward(cfg, variables, rays, train_frac, u01, compute_extras, zero_glo=False, taps=None,
-                  override_samples=None, override_feats=None, zero_tra=False, mask_taps=None):
+                  override_samples=None, override_feats=None, zero_tra=False, mask_taps=None, noise=None):
   """Model.__call__ (models.py:74-330).  rays: dict of [N,c] tensors.  u01: None
   (rng=None) or list[num_levels] of [N] float32 uniform draws (single_jitter)."""
   P = variables['params']
@@ -563,7 +567,7 @@ def model_forward(cfg, variables, rays, train_frac, u01, compute_extras, zero_gl
       tra = (torch.zeros(N, cfg.num_transient_features, dtype=dt) if zero_tra else
              P['TransientEmbed_0']['embedding'][rays['embed_idx'][:, 0].long()])
     res = mlp_forward(cfg, P['PropMLP_0' if is_prop else 'NerfMLP_0'], which, feats,
-                      rays['viewdirs'], None if is_prop else glo, lvl_taps, tra)
+                      rays['viewdirs'], None if is_prop else glo, lvl_taps, tra, None if noise is None else noise[lvl])
     density, rgb = res[0], res[1]
     if taps is not None:
       taps.append(lvl_taps)

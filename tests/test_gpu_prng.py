@@ -30,6 +30,20 @@ def test_bits_and_uniform_bit_exact(n):
         assert a.min() >= np.float32(lo) and (a.max() < np.float32(hi) if lo == 0 else a.max() <= np.float32(hi))
 
 
+@pytest.mark.parametrize('n', [1, 2, 7, 1000, 100001])
+def test_normal_vs_oracle(n):
+  """random.normal on the device (XLA's single-precision erf_inv polynomial) against the float64 evaluation of the same
+  definition (oracle/threefry_ref.py normal, which reproduces the reference's datasets_test golden poses): a few ulp."""
+  from nerf_hugs_amd.internal import random as hr
+  from oracle import threefry_ref as T
+  key, okey = hr.PRNGKey(1234 + n), T.prng_key(1234 + n)
+  got = hr.normal(key, (n,)).cpu().numpy()
+  ref = T.normal(okey, (n,))
+  np.testing.assert_allclose(got, ref, rtol=4e-6, atol=4e-7)
+  if n >= 100000:
+    assert abs(got.mean()) < 0.02 and abs(got.std() - 1.0) < 0.02 and np.abs(got).max() > 3.5
+
+
 def test_split_chain_and_shapes():
   from nerf_hugs_amd.internal import random as hr
   from oracle import threefry_ref as T

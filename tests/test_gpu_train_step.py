@@ -134,6 +134,50 @@ def test_encoder_width_that_is_not_a_multiple_of_64_trains():
   assert all(np.isfinite(losses)) and bool(torch.isfinite(state.flat).all()) and losses[2] != losses[0], losses
 
 
+def test_density_and_bottleneck_noise_stream_vs_oracle():
+  """NerfMLP.density_noise / bottleneck_noise, PropMLP.density_noise (models.py:378-381,435,458-460,478-481): the draws are
+  random.normal on keys split off the per-level MLP key.  The oracle gets the noise arrays from the SAME key chain restated
+  with oracle/threefry_ref.py (split / uniform / normal); the product gets the jax key.  Forward of every level."""
+  from tests import hugs_testlib as H
+  from oracle import torch_ref as R, threefry_ref as T
+  from nerf_hugs_amd.internal import random as hr, models as M
+  gin = list(SMALL) + ["NerfMLP.density_noise = 0.3", "NerfMLP.bottleneck_noise = 0.2", "PropMLP.density_noise = 0.5"]
+  config, model, state, render_fn, train_step, cfg, oparams = H.make_pair(gin)
+  batch = H.synth_rays(1, 8, 5)
+  N, Ss, Bw = 64, [64, 128], model.nerf_spec.bottleneck_width
+  seed = 77
+  # the reference's chain inside Model.__call__ (models.py:196,230) and MLP.__call__ (:435,:479)
+  okey = T.prng_key(seed)
+  ou01, onoise = [], []
+  from nerf_hugs_amd.internal import stepfun
+  for l, S in enumerate(Ss):
+    k, okey = T.split(okey)
+    ou01.append(torch.from_numpy(T.uniform(k, (N, 1), 0., stepfun.sample_u(S, True)[1]))[:, 0])
+    mk, okey = T.split(okey)
+    dk, r2 = T.split(mk)
+    nz = dict(density=torch.from_numpy(T.normal(dk, (N, S))) * (0.5 if l == 0 else 0.3))
+    if l == 1:
+      kb, _ = T.split(r2)
+      nz['bottleneck'] = torch.from_numpy(T.normal(kb, (N, S, Bw))) * 0.2
+    onoise.append(nz)
+  # the oracle takes U[0,1) draws and scales them itself: hand it draws / max_jitter
+  ou = [u / stepfun.sample_u(S, True)[1] for u, S in zip(ou01, Ss)]
+  orend, ohist = R.model_forward(cfg, oparams, H.oracle_rays(batch), 0.4, ou, False, noise=onoise)
+  rend, hist = model.apply(state.flat, hr.PRNGKey(seed), batch.rays, 0.4, False)
+  for l in range(2):
+    d = hist[l]['density'].reshape(N, -1).cpu()
+    assert H.relerr(d, ohist[l]['density']) < 2e-3, l          # (noise of 0.3-0.5 on raw: a missing or mis-keyed draw is O(1))
+    assert float((rend[l]['rgb'].reshape(N, 3).cpu() - orend[l]['rgb'].detach()).abs().max()) < 2e-3, l
+  # and the noise is really there: the same call without a key differs by O(noise)
+  rend0, hist0 = model.apply(state.flat, None, batch.rays, 0.4, False)
+  assert H.relerr(hist0[1]['density'].reshape(N, -1).cpu(), ohist[1]['density']) > 5e-2
+  # the train step takes the same route (random.split + level_jitter instead of the fused chain kernel) and stays finite
+  key = hr.PRNGKey(seed)
+  for _ in range(2):
+    state, stats, key = train_step(key, state, batch, 0.4, None)
+  assert np.isfinite(float(stats['loss'])) and bool(torch.isfinite(state.flat).all())
+
+
 def test_train_step_static_mask():
   gin = [g for g in SMALL if 'data_loss_type' not in g] + ["Config.transient_type = 'withmask'",
                                                            "Model.num_glo_features = 48"]
