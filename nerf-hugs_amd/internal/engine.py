@@ -478,8 +478,20 @@ class Engine:
       rgb_all = ws.get('rgb_out_all', (mdl.num_levels, N, 3))
       rgb_out = rgb_all[lvl]
       extras = ws.get(f'L{lvl}/extras', (N, 5)) if compute_extras else None
+      bgs = getattr(u01, 'bg_rgbs', None)
+      bg_rgb = bgs[lvl] if (mdl.bg_random and bgs) else None
       _lib.call('hugs_composite_fwd', N, S, out['density'], out['rgb'], td, rays['directions'],
-                int(mdl.opaque_background), mdl.bg_intensity, rays['far'].reshape(-1), w, rgb_out, extras)
+                int(mdl.opaque_background), 0.0 if bg_rgb is not None else mdl.bg_intensity, rays['far'].reshape(-1), w, rgb_out, extras)
+      if bg_rgb is not None:
+        # a per-ray, per-channel background (models.py:256-261): the kernel composites against black and the background term
+        # bg_w * bg with bg_w = max(0, 1 - sum w) (render.py:219-221) is added here; its gradient reaches the weights through
+        # d_w_extra in backward_level
+        if out.get('dens_t') is not None:
+          raise NotImplementedError('a random background together with the NeRF-W transient branch')
+        bgw = ws.get(f'L{lvl}/bgw', (N,))
+        torch.sum(w, dim=-1, out=bgw); bgw.neg_().add_(1.0).clamp_(min=0.0)
+        rgb_out.addcmul_(bgw[:, None], bg_rgb)      # (proposal levels too: their colours are zero, the background term is not)
+        out.update(bg_rgb=bg_rgb, bgw=bgw)
       if out.get('dens_t') is not None:     # models.py:285-307
         nw = {k: ws.get(f'L{lvl}/{k}', (N, 3)) for k in ('rgb_combined', 'rgb_static', 'rgb_transient')}
         nw['uncertainty'] = ws.get(f'L{lvl}/uncertainty', (N,))
@@ -535,8 +547,22 @@ class Engine:
     gview = lambda p, padded=False: lay.view(grad, p, padded)
     d_density = ws.get(tag + '/d_density', (M,))
     d_rgb_s = ws.get(tag + '/d_rgb_s', (M, 3)) if lv['rgb'] is not None else None
+    bg_int = self.model.bg_intensity
+    if lv.get('bg_rgb') is not None:
+      bg_int = 0.0
+      if d_rgb_out is not None:
+        # d/dw_s of bg_w * bg = -(bg . d_rgb_out) where 1 - sum w > 0, the same for every sample of the ray
+        dacc = ws.get(tag + '/d_bgw', (N,))
+        torch.sum(d_rgb_out * lv['bg_rgb'], dim=-1, out=dacc)
+        dacc.mul_((lv['bgw'] > 0).to(dacc.dtype)).neg_()
+        dwt = ws.get(tag + '/d_w_total', (N, S))
+        if d_w_extra is not None:
+          torch.add(d_w_extra, dacc[:, None], out=dwt)
+        else:
+          dwt.copy_(dacc[:, None].expand(N, S))
+        d_w_extra = dwt
     _lib.call('hugs_composite_bwd', N, S, lv['density'], lv['rgb'], lv['tdist'], rays['directions'],
-              int(self.model.opaque_background), self.model.bg_intensity, d_rgb_out, d_w_extra, d_density, d_rgb_s)
+              int(self.model.opaque_background), bg_int, d_rgb_out, d_w_extra, d_density, d_rgb_s)
     if nerfw is not None:
       # the loss saw rgb_combined and beta: their gradients reach sigma_s (added), c_s, sigma_t, c_t, u
       d_dt, d_ct, d_u = ws.get(tag + '/d_dens_t', (M,)), ws.get(tag + '/d_rgb_t', (M, 3)), ws.get(tag + '/d_unc', (M,))

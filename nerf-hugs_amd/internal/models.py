@@ -42,13 +42,14 @@ class Model:
       raise ValueError()
     if self.ray_shape not in ('cone', 'cylinder'):
       raise ValueError('ray_shape must be \'cone\' or \'cylinder\'')
-    if self.bg_intensity_range[0] != self.bg_intensity_range[1]:
-      raise NotImplementedError('randomised background intensity is not built (all HuGS gins use (1, 1))')
     # use_gpu_resampling only picks between two XLA formulations of the same inverse-CDF lookup (stepfun.py:153-161,
     # math.py:101-127); there is one HIP formulation, so the flag is accepted and has no effect.
     if not self.stop_level_grad or not self.use_viewdirs:
       raise NotImplementedError('stop_level_grad=False / use_viewdirs=False')
-    self.bg_intensity = float(self.bg_intensity_range[0])
+    # models.py:246-259: a fixed intensity, or -- with a range -- a uniform draw per ray and channel in training (rng given) and
+    # the midpoint when rendering deterministically
+    self.bg_random = float(self.bg_intensity_range[0]) != float(self.bg_intensity_range[1])
+    self.bg_intensity = 0.5 * (float(self.bg_intensity_range[0]) + float(self.bg_intensity_range[1]))
     rd = self.raydist_fn
     name = None if rd is None else getattr(rd, 'name', rd)
     self.raydist = None if name is None else (name[4:] if str(name).startswith('jnp.') else name)
@@ -108,18 +109,22 @@ class Model:
     the MLP key (models.py:230; density / bottleneck noise are 0 in every shipped gin, the split still advances).
     Returns (stepfun.Jitter, rng after the last level)."""
     out = stepfun.Jitter()
-    out.mlp_keys = []
+    out.mlp_keys, out.bg_rgbs = [], []
     for l in range(self.num_levels):
       S = self.num_prop_samples if l < self.num_levels - 1 else self.num_nerf_samples
       key, rng = hrandom.split(rng)
       out.append(hrandom.uniform(key, (N, 1 if self.single_jitter else S), maxval=stepfun.sample_u(S, True)[1]))
       key, rng = hrandom.split(rng)
       out.mlp_keys.append(key)
+      if self.bg_random:                         # models.py:256-261: key, rng = random_split(rng); uniform(key, [N, 3], lo, hi)
+        key, rng = hrandom.split(rng)
+        out.bg_rgbs.append(hrandom.uniform(key, (N, 3), float(self.bg_intensity_range[0]), float(self.bg_intensity_range[1])))
     return out, rng
 
   def has_noise(self):
-    """density_noise / bottleneck_noise > 0 on either MLP (models.py:378-381): their draws need the per-level MLP keys."""
-    return any(sp.density_noise > 0 or sp.bottleneck_noise > 0 for sp in (self.prop_spec, self.nerf_spec) if sp is not None)
+    """density_noise / bottleneck_noise > 0 on either MLP (models.py:378-381) or a random background (models.py:246-261): draws that
+    hang off the per-level keys, which only level_jitter (not the fused chain kernel) keeps."""
+    return self.bg_random or any(sp.density_noise > 0 or sp.bottleneck_noise > 0 for sp in (self.prop_spec, self.nerf_spec) if sp is not None)
 
   def step_jitter(self, rng, N):
     """train_step's `rng, key = random.split(rng)` (train_utils.py:408) followed by level_jitter(key, N), as one launch.
@@ -161,7 +166,7 @@ class Model:
       if u01 is not None:
         padded = [pad(u) for u in u01]
         if isinstance(u01, stepfun.Jitter) and u01.mlp_keys is not None and self.has_noise():
-          raise NotImplementedError('density / bottleneck noise with a ray count that needs padding to the GEMM tile')
+          raise NotImplementedError('density / bottleneck noise or a random background with a ray count that needs padding to the GEMM tile')
         u01 = stepfun.Jitter(padded) if isinstance(u01, stepfun.Jitter) else padded
     take = lambda buf, *tail: buf.reshape((Np,) + tail)[:N].clone().reshape(lead + tail)
     if refresh_weights:

@@ -19,6 +19,7 @@ class Jitter(list):
   noise draws are split off it (models.py:435,458-460,478-481)."""
   scaled = True
   mlp_keys = None
+  bg_rgbs = None      # per level [N, 3] background draws when Model.bg_intensity_range is a real range (models.py:256-261)
 
 
 def sample_u(num_samples, randomized, deterministic_center=True):

@@ -517,7 +517,7 @@ def sample_u_base(num_samples, randomized):
 
 
 def model_forward(cfg, variables, rays, train_frac, u01, compute_extras, zero_glo=False, taps=None,
-                  override_samples=None, override_feats=None, zero_tra=False, mask_taps=None, noise=None):
+                  override_samples=None, override_feats=None, zero_tra=False, mask_taps=None, noise=None, bg_rgbs=None):
   """Model.__call__ (models.py:74-330).  rays: dict of [N,c] tensors.  u01: None
   (rng=None) or list[num_levels] of [N] float32 uniform draws (single_jitter)."""
   P = variables['params']
@@ -572,7 +572,8 @@ def model_forward(cfg, variables, rays, train_frac, u01, compute_extras, zero_gl
     if taps is not None:
       taps.append(lvl_taps)
     weights = compute_alpha_weights(density, tdist, rays['directions'], cfg.opaque_background)[0]
-    rend = volumetric_rendering(rgb, weights, tdist, cfg.bg_intensity, far, compute_extras)
+    bg_l = cfg.bg_intensity if bg_rgbs is None else bg_rgbs[lvl]        # models.py:246-261 (a [N, 3] draw per level)
+    rend = volumetric_rendering(rgb, weights, tdist, bg_l, far, compute_extras)
     hist = dict(density=density, rgb=rgb, sdist=sdist, tdist=tdist, weights=weights)
     if len(res) == 3:                      # models.py:285-307
       tr = res[2]
@@ -745,7 +746,7 @@ def _natkey(s):
   return [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', s)]
 
 
-def loss_and_grad(cfg, variables, rays, gt_rgb, train_frac, u01, inlier_thresholds=None):
+def loss_and_grad(cfg, variables, rays, gt_rgb, train_frac, u01, inlier_thresholds=None, bg_rgbs=None):
   """The value_and_grad half of train_step (train_utils.py:404-455).  rays/gt flat [N,c];
   robustnerf reshapes to [n,P,P,c] patches."""
   leaves = flat_leaves(variables['params'])
@@ -757,7 +758,7 @@ def loss_and_grad(cfg, variables, rays, gt_rgb, train_frac, u01, inlier_threshol
     for k in ks[:-1]:
       d = d.setdefault(k, {})
     d[ks[-1]] = v
-  renderings, history = model_forward(cfg, {'params': P}, rays, train_frac, u01, False)
+  renderings, history = model_forward(cfg, {'params': P}, rays, train_frac, u01, False, bg_rgbs=bg_rgbs)
   losses, stats = {}, {}
   if cfg.transient_type is None:
     losses['data'], st = compute_data_loss(cfg, gt_rgb, rays, renderings, False)

@@ -178,6 +178,55 @@ def test_density_and_bottleneck_noise_stream_vs_oracle():
   assert np.isfinite(float(stats['loss'])) and bool(torch.isfinite(state.flat).all())
 
 
+def test_random_background_vs_oracle():
+  """Model.bg_intensity_range = (lo, hi) (models.py:246-261): per level one more key split and a uniform [N, 3] background
+  draw; rgb = sum w c + max(0, 1 - sum w) bg.  Forward against the oracle fed with the draws of the restated key chain
+  (oracle/threefry_ref.py), the train step's gradients against the oracle's autograd on the same draws, and the midpoint
+  background when rendering without a key."""
+  from tests import hugs_testlib as H
+  from oracle import torch_ref as R, threefry_ref as T
+  from nerf_hugs_amd.internal import random as hr, stepfun
+  gin = [g for g in SMALL if 'opaque_background' not in g] + ["Model.opaque_background = False", "Model.bg_intensity_range = (0.2, 0.9)"]
+  config, model, state, render_fn, train_step, cfg, oparams = H.make_pair(gin)
+  assert model.bg_random and abs(model.bg_intensity - 0.55) < 1e-7
+  batch = H.synth_rays(1, 8, 5)
+  N, Ss, seed = 64, [64, 128], 91
+
+  def chain(okey):
+    ou, obg = [], []
+    for S in Ss:
+      k, okey = T.split(okey)
+      ou.append(torch.from_numpy(T.uniform(k, (N, 1), 0., stepfun.sample_u(S, True)[1]))[:, 0] / stepfun.sample_u(S, True)[1])
+      _, okey = T.split(okey)
+      k, okey = T.split(okey)
+      obg.append(torch.from_numpy(T.uniform(k, (N, 3), 0.2, 0.9)))
+    return ou, obg
+  ou, obg = chain(T.prng_key(seed))
+  orend, ohist = R.model_forward(cfg, oparams, H.oracle_rays(batch), 0.4, ou, False, bg_rgbs=obg)
+  rend, hist = model.apply(state.flat, hr.PRNGKey(seed), batch.rays, 0.4, False)
+  for l in range(2):
+    assert float((rend[l]['rgb'].reshape(N, 3).cpu() - orend[l]['rgb'].detach()).abs().max()) < 1e-4, l
+  # without a key: the midpoint (models.py:251-253)
+  cfg.bg_intensity = 0.55
+  orend0, _ = R.model_forward(cfg, oparams, H.oracle_rays(batch), 0.4, None, False)
+  rend0, _ = model.apply(state.flat, None, batch.rays, 0.4, False)
+  assert float((rend0[1]['rgb'].reshape(N, 3).cpu() - orend0[1]['rgb'].detach()).abs().max()) < 1e-4
+  # train step: rng, key = random.split(rng) (train_utils.py:408), then the chain on `key`
+  okeys = T.split(T.prng_key(seed))
+  ou, obg = chain(okeys[1])
+  ostats, ograds, _, _ = R.loss_and_grad(cfg, oparams, H.oracle_rays(batch), batch.rgb.reshape(-1, 3), 0.4, ou, None, bg_rgbs=obg)
+  state, stats, _ = train_step(hr.PRNGKey(seed), state, batch, 0.4, None)
+  torch.cuda.synchronize()
+  assert abs(float(stats['loss']) / float(ostats['loss']) - 1) < 1e-4
+  eng = model.engine('cuda')
+  grad = eng.ws.get('grad', (model.layout.size + 64,))
+  for lf in model.layout.leaves:
+    name = '/'.join(lf['path'])
+    g, og = model.layout.view(grad, lf['path']).cpu().double(), ograds[name].double()
+    e = ((g - og).abs() / og.abs().max().clamp(min=1e-20)).flatten()
+    assert (e.numel() <= 8 or float(e.median()) < 3e-3) and float(e.max()) < 1e-1, f'grad {name}: median {float(e.median()):.2e} max {float(e.max()):.2e}'
+
+
 def test_train_step_static_mask():
   gin = [g for g in SMALL if 'data_loss_type' not in g] + ["Config.transient_type = 'withmask'",
                                                            "Model.num_glo_features = 48"]
