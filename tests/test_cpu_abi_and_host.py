@@ -118,8 +118,10 @@ def test_errors_like_reference():
   m = models.Model(configs.make_config(transient_type='nerfw'), num_transient_features=16)
   assert [l['kind'] for l in m.nerf_spec.layers[-7:]] == ['tview', 'ttrunk', 'ttrunk', 'ttrunk', 'tdensity', 'trgb', 'tuncert']
   assert m.prop_spec.num_tra == 0 and 'TransientEmbed_0' in m.layout.modules
+  mb = models.Model(configs.make_config(), bg_intensity_range=(0., 1.))       # models.py:246-261: a range -> random draws in training,
+  assert mb.bg_random and mb.bg_intensity == 0.5 and mb.has_noise()            # the midpoint when rendering without a key
   with pytest.raises(NotImplementedError):
-    models.Model(configs.make_config(), bg_intensity_range=(0., 1.))
+    models.Model(configs.make_config(), stop_level_grad=False)
 
 
 def test_host_helpers_match_oracle():
