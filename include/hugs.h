@@ -92,7 +92,9 @@ int hugs_raybias_fwd(int nrays, int H, int nd, int ng, const float* dir_enc, con
 int hugs_raybias_bwd(int dtype, int nrays, int S, int H, int nd, int ng, const void* G, int ldg, const float* dir_enc,
                      const float* glo, const float* Wv_tail, const int* embed_idx, float* d_rb, float* dWv_tail,
                      float* d_embedding, void* stream);
-/* models.py:514-519 rgb = sigmoid(Dense(3)(h)) * (1 + 2 pad) - pad */
+/* models.py:514-519 rgb = sigmoid(Dense(3)(h)) * (1 + 2 pad) - pad.  H: any multiple of 8 forward (128 / 256 with the weights in
+ * registers); backward: any multiple of 128 (128: the Mip-NeRF 360 view layer; 256: nerfacto's colour MLP; wider -- the head on the
+ * trunk when Model.use_viewdirs is False -- in column slabs).  G = (h > 0) * dz W^T, dW = h^T dz, db = sum dz. */
 int hugs_rgb_fwd(int dtype, int M, int H, const void* Hact, int ldh, const float* W, const float* b, float pad,
                  float* rgb, void* stream);
 long long hugs_rgb_bwd_ws_bytes(void);

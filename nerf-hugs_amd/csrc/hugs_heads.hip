@@ -428,18 +428,29 @@ extern "C" long long hugs_rgb_bwd_ws_bytes(void) { return (long long)RGB_BLOCKS 
 
 extern "C" int hugs_rgb_bwd(int dtype, int M, int H, const void* Hact, int ldh, const float* W, const float* rgb,
                             const float* d_rgb, float pad, void* G, int ldg, float* dW, float* db, void* ws, void* stream) {
-  HUGS_REQUIRE(H == 128 || H == 256, -3, "hugs_rgb_bwd: head width %d unsupported (128 or 256)", H);
+  HUGS_REQUIRE(H > 0 && H % 128 == 0, -3, "hugs_rgb_bwd: head width %d unsupported (a multiple of 128)", H);
   if (M <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   int rpb = (M + RGB_BLOCKS - 1) / RGB_BLOCKS;
   rpb = (rpb + 15) / 16 * 16;
   const int nblk = (M + rpb - 1) / rpb;
   float* slab = (float*)ws;
-#define RGB_BWD(DT_, P_) hipLaunchKernelGGL((k_rgb_bwd<DT_, P_>), dim3(nblk), dim3(256), 0, st, M, rpb, Hact, ldh, W, rgb, d_rgb, pad, G, ldg, slab)
-  if (H == 128) { if (dtype == 2) RGB_BWD(2, 1); else if (dtype) RGB_BWD(1, 1); else RGB_BWD(0, 1); }
-  else { if (dtype == 2) RGB_BWD(2, 2); else if (dtype) RGB_BWD(1, 2); else RGB_BWD(0, 2); }
+  // wider heads (use_viewdirs=False puts the rgb layer on the trunk: models.py:486-516) go in column slabs of 256 / 128: the
+  // pre-activation gradient dz is recomputed per slab (6 floats per row), everything else is per column
+  const int step = H % 256 == 0 ? 256 : 128;
+  const size_t esz = dtype ? 2 : 4;
+  for (int c0 = 0; c0 < H; c0 += step) {
+    const void* Hc = (const char*)Hact + (size_t)c0 * esz;
+    void* Gc = (char*)G + (size_t)c0 * esz;
+    const float* Wc = W + (size_t)c0 * 3;
+#define RGB_BWD(DT_, P_) hipLaunchKernelGGL((k_rgb_bwd<DT_, P_>), dim3(nblk), dim3(256), 0, st, M, rpb, Hc, ldh, Wc, rgb, d_rgb, pad, Gc, ldg, slab)
+    if (step == 128) { if (dtype == 2) RGB_BWD(2, 1); else if (dtype) RGB_BWD(1, 1); else RGB_BWD(0, 1); }
+    else { if (dtype == 2) RGB_BWD(2, 2); else if (dtype) RGB_BWD(1, 2); else RGB_BWD(0, 2); }
 #undef RGB_BWD
-  hipLaunchKernelGGL(k_slab_reduce_small, dim3((H * 3 + 3 + 63) / 64), dim3(1024), 0, st, slab, nblk, H * 3, H * 3 + 4, dW, 3, db);
+    // (the bias gradient is the same in every slab: written by the first)
+    hipLaunchKernelGGL(k_slab_reduce_small, dim3((step * 3 + 3 + 63) / 64), dim3(1024), 0, st, slab, nblk, step * 3, step * 3 + 4,
+                       dW + (size_t)c0 * 3, c0 == 0 ? 3 : 0, c0 == 0 ? db : nullptr);
+  }
   HUGS_CHECK_LAUNCH("hugs_rgb_bwd");
   return 0;
 }

@@ -23,9 +23,10 @@ def _round_up(x, m):
 class MLPSpec:
   """Static description of one MLP (models.py:359-391 attributes + gin bindings)."""
 
-  def __init__(self, name, is_prop, num_glo, num_transient=0, **kw):
+  def __init__(self, name, is_prop, num_glo, num_transient=0, use_viewdirs=True, **kw):
     self.name = name
     self.is_prop = is_prop
+    self.use_viewdirs = bool(use_viewdirs)      # Model.use_viewdirs (models.py:56,233): False -> the rgb head sits on the trunk
     self.net_depth = 8
     self.net_width = 256
     self.bottleneck_width = 256
@@ -75,7 +76,10 @@ class MLPSpec:
       k = self.net_width + self.F if (i % self.skip_layer == 0 and i > 0) else self.net_width
       kp = self.Wp
     L.append(dict(fan_in=k, kpad=kp, fan_out=1, kind='density'))
-    if not self.disable_rgb:
+    if not self.disable_rgb and not self.use_viewdirs:
+      # models.py:486-516 with viewdirs=None: no bottleneck, no view layer -- rgb = activation(Dense(3)(trunk output))
+      L.append(dict(fan_in=k, kpad=kp, fan_out=self.num_rgb_channels, kind='rgb'))
+    elif not self.disable_rgb:
       L.append(dict(fan_in=k, kpad=kp, fan_out=self.bottleneck_width, kind='bottleneck'))
       kv = self.bottleneck_width + self.nd + self.num_glo
       L.append(dict(fan_in=kv, kpad=kv, fan_out=self.net_width_viewdirs, kind='view'))
@@ -97,7 +101,9 @@ class MLPSpec:
     d = self.net_depth
     if (d - 1) > 0 and (d - 1) % self.skip_layer == 0:
       raise NotImplementedError('a skip-concat after the last trunk layer is not built')
-    if not self.disable_rgb and (self.bottleneck_width % 128 or self.net_width_viewdirs != 128):
+    if not self.use_viewdirs and self.num_tra > 0:
+      raise NotImplementedError('the NeRF-W transient branch hangs off the bottleneck, which use_viewdirs=False does not create (models.py:521-524)')
+    if not self.disable_rgb and self.use_viewdirs and (self.bottleneck_width % 128 or self.net_width_viewdirs != 128):
       raise NotImplementedError('bottleneck_width must be a multiple of 128 and net_width_viewdirs == 128 (MFMA tiles)')
     if self.net_width % 128 and self.net_depth > self.skip_layer + 1:
       raise NotImplementedError('a trunk width that is not a multiple of 128 together with a skip concat is not built')
@@ -363,7 +369,13 @@ class Engine:
         raw.add_(hrandom.normal(density_key, (M,)), alpha=float(spec.density_noise))
         density.copy_(torch.logaddexp(raw + float(spec.density_bias), torch.zeros_like(raw)))   # softplus, as hugs_density_fwd
     out = dict(X0=X0, acts=acts, raw=raw, density=density, rgb=None, bits=bits if nchunk == 1 else [None] * len(bits))
-    if not spec.disable_rgb:
+    if not spec.disable_rgb and not spec.use_viewdirs:
+      lr = spec.layers[spec.net_depth + 1]
+      rgb = ws.get(tag + '/rgb', (M, 3))
+      Wr, br = self._rgb_head(theta, spec, lr, tag + '/rgbhead', padded=True)
+      _lib.call('hugs_rgb_fwd', dt, M, W, x, W, Wr, br, spec.rgb_padding, rgb)
+      out.update(bott=None, hview=None, rgb=rgb)
+    elif not spec.disable_rgb:
       lb, lv, lr = spec.layers[spec.net_depth + 1:spec.net_depth + 4]
       Bw, H = spec.bottleneck_width, spec.net_width_viewdirs
       bott = ws.get(tag + '/bott', (M, Bw), self.tdt)
@@ -520,10 +532,10 @@ class Engine:
     slab = self.ws.get(f'tn_slab/{torch.cuda.current_stream().cuda_stream}', (max(nbytes // 4, 1),))
     _lib.call('hugs_gemm_tn', self.dt, M, Kc, Nn, ns, X, ldx, G, ldg, dW, db, slab)
 
-  def _rgb_head(self, theta, spec, layer, tag):
+  def _rgb_head(self, theta, spec, layer, tag, padded=False):
     """(W, b) the rgb head kernels see: rgb = sigmoid(premultiplier (h W + b) + rgb_bias) (models.py:514-516, :534-536) is
     sigmoid(h (p W) + (p b + rgb_bias)); the kernels' weight / bias gradients are then those of (p W, p b + r): times p."""
-    W = self.layout.view(theta, (spec.name, layer['name'], 'kernel'))
+    W = self.layout.view(theta, (spec.name, layer['name'], 'kernel'), padded)      # (padded: [Wp, 3] for a head on the padded trunk)
     b = self.layout.view(theta, (spec.name, layer['name'], 'bias'))
     p_, r_ = float(spec.rgb_premultiplier), float(spec.rgb_bias)
     if p_ == 1. and r_ == 0.:
@@ -574,7 +586,7 @@ class Engine:
     ld = spec.layers[spec.net_depth]
     d_raw = ws.get(tag + '/d_raw', (M,))
     dws = ws.get(tag + '/dens_ws', (max(_lib.lib().cdll.hugs_density_bwd_ws_bytes(W) // 4, 1),))
-    if spec.disable_rgb:
+    if spec.disable_rgb or not spec.use_viewdirs:
       _lib.call('hugs_density_bwd', dt, M, W, Ylast, W, d_density, lv['raw'], spec.density_bias, d_raw,
                 gview((spec.name, ld['name'], 'kernel'), True).reshape(-1), gview((spec.name, ld['name'], 'bias')), dws)
     else:
@@ -586,6 +598,19 @@ class Engine:
     Gb = ws.get(tag + '/Gb', (M, W), self.tdt)
     if spec.disable_rgb:
       _lib.call('hugs_rank1_mask', dt, M, W, d_raw, wd, Ylast, W, Ga, W)
+    elif not spec.use_viewdirs:
+      # G_last = (d_rgb W_rgb^T + d_raw (x) w_d) * (Ylast > 0): the rgb head's own backward (its G is already masked) + the
+      # density head's masked rank-1 term
+      lr = spec.layers[spec.net_depth + 1]
+      rws = ws.get(tag + '/rgb_ws', (max(_lib.lib().cdll.hugs_rgb_bwd_ws_bytes() // 4, 1),))
+      Wr, _ = self._rgb_head(theta, spec, lr, tag + '/rgbhead', padded=True)
+      _lib.call('hugs_rgb_bwd', dt, M, W, Ylast, W, Wr, lv['rgb'], d_rgb_s, spec.rgb_padding, Ga, W,
+                gview((spec.name, lr['name'], 'kernel'), True), gview((spec.name, lr['name'], 'bias')), rws)
+      if spec.rgb_premultiplier != 1.:
+        gview((spec.name, lr['name'], 'kernel'), True).mul_(float(spec.rgb_premultiplier))
+        gview((spec.name, lr['name'], 'bias')).mul_(float(spec.rgb_premultiplier))
+      _lib.call('hugs_rank1_mask', dt, M, W, d_raw, wd, Ylast, W, Gb, W)
+      Ga.add_(Gb)
     else:
       lb, lvw, lr = spec.layers[spec.net_depth + 1:spec.net_depth + 4]
       Bw, H = spec.bottleneck_width, spec.net_width_viewdirs
@@ -644,7 +669,7 @@ class Engine:
       else:
         _lib.call('hugs_gemm_nt', dt, M, W, Bw, 0, dB, Bw, None, 0, self.wn[(spec.name, lb['name'], 'kernel')], Bw, None, None,
                   1, 0, 0, Ylast, W, d_raw, wd, Ga, W)
-    if spec.disable_rgb and leaf_done is not None:
+    if (spec.disable_rgb or not spec.use_viewdirs) and leaf_done is not None:
       first = lay.by_path[(spec.name, spec.layers[spec.net_depth]['name'], 'kernel')]
       last = lay.by_path[(spec.name, spec.layers[-1]['name'], 'bias')]
       leaf_done(first['off'], last['off'] + int(np.prod(last['pshape'])))
@@ -700,7 +725,7 @@ class Engine:
         G, gi = ring[nxt], nxt
     for e in tn_done.values():
       main.wait_event(e)
-    if not spec.disable_rgb:
+    if not spec.disable_rgb and spec.use_viewdirs:
       main.wait_event(heads_done)
 
   def _transient_backward(self, theta, grad, lv, rays, N, d_dt, d_ct, d_u):

@@ -44,8 +44,8 @@ class Model:
       raise ValueError('ray_shape must be \'cone\' or \'cylinder\'')
     # use_gpu_resampling only picks between two XLA formulations of the same inverse-CDF lookup (stepfun.py:153-161,
     # math.py:101-127); there is one HIP formulation, so the flag is accepted and has no effect.
-    if not self.stop_level_grad or not self.use_viewdirs:
-      raise NotImplementedError('stop_level_grad=False / use_viewdirs=False')
+    if not self.stop_level_grad:
+      raise NotImplementedError('stop_level_grad=False (gradients through the resampling step) is not built')
     # models.py:246-259: a fixed intensity, or -- with a range -- a uniform draw per ray and channel in training (rng given) and
     # the midpoint when rendering deterministically
     self.bg_random = float(self.bg_intensity_range[0]) != float(self.bg_intensity_range[1])
@@ -57,8 +57,10 @@ class Model:
       raise NotImplementedError(f"raydist_fn {rd!r}: coord.py:78-90 knows None, 'piecewise' and @jnp.reciprocal / log / exp / sqrt / square")
     # models.py:104-105: NerfMLP(disable_transient=(transient_type != 'nerfw')), PropMLP(disable_transient=True)
     self.nerf_spec = _engine.MLPSpec('NerfMLP_0', False, self.num_glo_features,
-                                     self.num_transient_features if tt == 'nerfw' else 0, **configs.bindings('NerfMLP'))
-    self.prop_spec = _engine.MLPSpec('PropMLP_0', True, self.num_glo_features, **configs.bindings('PropMLP'))
+                                     self.num_transient_features if tt == 'nerfw' else 0, use_viewdirs=self.use_viewdirs,
+                                     **configs.bindings('NerfMLP'))
+    self.prop_spec = _engine.MLPSpec('PropMLP_0', True, self.num_glo_features, use_viewdirs=self.use_viewdirs,
+                                     **configs.bindings('PropMLP'))
     self.specs = [self.nerf_spec, self.prop_spec]
     self.mask_spec = None
     if tt == 'hanerf':      # models.py:107: ImplicitMask() is constructed after the two MLPs

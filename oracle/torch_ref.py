@@ -340,6 +340,7 @@ class ModelCfg:
     self.rgb_padding = 0.001
     self.rgb_premultiplier, self.rgb_bias = 1., 0.          # models.py:380-381
     self.disable_integration = False                         # models.py:59
+    self.use_viewdirs = True                                 # models.py:56
     # Config
     self.data_loss_type = 'charb'
     self.charb_padding = 0.001
@@ -467,6 +468,11 @@ def mlp_forward(cfg, mod, which, feats, viewdirs, glo_vec, taps=None, tra_vec=No
   density = torch.logaddexp(raw_density + cfg.density_bias, torch.zeros_like(raw_density))
   if which == 'prop' and cfg.prop_disable_rgb:
     return density, torch.zeros(feats.shape[:-1] + (3,), dtype=feats.dtype)
+  if not getattr(cfg, 'use_viewdirs', True):
+    # models.py:233 viewdirs=None -> :486-516: no bottleneck / view layer, the rgb layer reads the trunk output
+    L = mod[f'Dense_{depth + 1}']
+    rgb = torch.sigmoid(cfg.rgb_premultiplier * (x @ L['kernel'] + L['bias']) + cfg.rgb_bias)
+    return density, rgb * (1 + 2 * cfg.rgb_padding) - cfg.rgb_padding
   L = mod[f'Dense_{depth + 1}']
   bott = x @ L['kernel'] + L['bias']
   if noise is not None and noise.get('bottleneck') is not None:   # models.py:478-481

@@ -227,6 +227,27 @@ def test_random_background_vs_oracle():
     assert (e.numel() <= 8 or float(e.median()) < 3e-3) and float(e.max()) < 1e-1, f'grad {name}: median {float(e.median()):.2e} max {float(e.max()):.2e}'
 
 
+def test_train_step_without_viewdirs():
+  """Model.use_viewdirs = False (models.py:56,233,486-516): no bottleneck / view layer, the rgb head on the trunk output, GLO
+  vectors unused; with rgb_premultiplier / rgb_bias on that head."""
+  gin = list(SMALL) + ["Model.use_viewdirs = False", "Model.num_glo_features = 4", "NerfMLP.rgb_premultiplier = 1.3", "NerfMLP.rgb_bias = 0.2"]
+  _run_case(gin)
+
+
+def test_without_viewdirs_bf16_width_1024_trains():
+  """The same at the benchmarked trunk width in bf16: the rgb head's backward walks the 1024 columns in slabs of 256."""
+  from tests import hugs_testlib as H
+  gin = [g for g in SMALL if 'NerfMLP.net_width' not in g] + ["Model.use_viewdirs = False", "NerfMLP.net_width = 1024"]
+  config, model, state, render_fn, train_step, cfg, oparams = H.make_pair(gin, compute_dtype='bf16')
+  batch = H.synth_rays(1, 8, 3)
+  gen = torch.Generator(device='cuda').manual_seed(5)
+  losses = []
+  for _ in range(12):
+    state, stats, gen = train_step(gen, state, batch, 0.5, None)
+    losses.append(float(stats['loss']))
+  assert all(np.isfinite(losses)) and bool(torch.isfinite(state.flat).all()) and losses[-1] < losses[0], losses
+
+
 def test_train_step_static_mask():
   gin = [g for g in SMALL if 'data_loss_type' not in g] + ["Config.transient_type = 'withmask'",
                                                            "Model.num_glo_features = 48"]
