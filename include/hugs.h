@@ -50,7 +50,8 @@ int hugs_level_sample_fwd(int nrays, const float* t_prev, const float* w_prev, i
  * lift_and_diagonalize -> coord.py:102-126 integrated_pos_enc.  out [nrays*num_samples, row_pitch] in
  * bf16/fp32, columns >= 2*num_basis*max_deg zero.  basis [3, num_basis] fp32.  ray_shape 0 cone / 1 cylinder
  * (-2 otherwise, render.py:124); + 4: the Gaussians' covariances are set to zero after casting (Model.disable_integration,
- * models.py:223-226). */
+ * models.py:223-226); bits 8-15: min_deg_point -- the scales are 2^(min_deg + k), k < max_deg, i.e. `max_deg` counts the degrees
+ * (coord.py:107-126 integrated_pos_enc(mean, var, min_deg, max_deg)). */
 int hugs_cast_ipe_fwd(int nrays, int num_samples, const float* tdist, const float* origins, const float* directions,
                       const float* radii, const float* basis, int num_basis, int ray_shape, int warp_contract,
                       int max_deg, int out_bf16, int row_pitch, void* out, void* stream);

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void k_cast_ipe(int nrays, int S, const float*
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         jj[q] = j | (half << 16);
-        scs[q] = (float)(1 << k);
+        scs[q] = __int_as_float((127 + ((ray_shape >> 8) & 0xff) + k) << 23);      // 2^(min_deg + k)
         if (half < 2 && ++j == nb) { j = 0; if (++k == max_deg) { k = 0; ++half; } }
       }
     }
@@ -184,7 +184,8 @@ extern "C" int hugs_cast_ipe_fwd(int nrays, int num_samples, const float* tdist,
                                  const float* directions, const float* radii, const float* basis, int num_basis,
                                  int ray_shape, int warp_contract, int max_deg, int out_bf16, int row_pitch, void* out,
                                  void* stream) {
-  HUGS_REQUIRE((ray_shape & ~4) == 0 || (ray_shape & ~4) == 1, -2, "ray_shape must be 'cone' or 'cylinder' (+4: zero covariances)");
+  HUGS_REQUIRE((ray_shape & 3) <= 1 && (ray_shape & ~0xff07) == 0 && ((ray_shape >> 8) & 0xff) + max_deg <= 30, -2,
+               "ray_shape must be 'cone' or 'cylinder' (+4: zero covariances; bits 8-15: min_deg)");
   HUGS_REQUIRE(num_basis >= 1 && num_basis <= ENC_NB && max_deg >= 1 && max_deg <= 24, -3,
                "hugs_cast_ipe_fwd: basis size %d / max_deg %d unsupported", num_basis, max_deg);
   HUGS_REQUIRE(row_pitch % 8 == 0 && row_pitch >= 2 * num_basis * max_deg, -3,

@@ -107,8 +107,10 @@ class MLPSpec:
       raise NotImplementedError('bottleneck_width must be a multiple of 128 and net_width_viewdirs == 128 (MFMA tiles)')
     if self.net_width % 128 and self.net_depth > self.skip_layer + 1:
       raise NotImplementedError('a trunk width that is not a multiple of 128 together with a skip concat is not built')
-    if self.min_deg_point != 0 or self.net_depth_viewdirs != 1 or self.num_rgb_channels != 3:
-      raise NotImplementedError('min_deg_point != 0 / net_depth_viewdirs != 1 / num_rgb_channels != 3 are not built')
+    if self.net_depth_viewdirs != 1 or self.num_rgb_channels != 3:
+      raise NotImplementedError('net_depth_viewdirs != 1 / num_rgb_channels != 3 are not built')
+    if not 0 <= self.min_deg_point < self.max_deg_point:
+      raise ValueError(f'min_deg_point {self.min_deg_point} / max_deg_point {self.max_deg_point}')
     if self.num_tra > 0 and (self.disable_rgb or self.net_width_transient != 128 or self.net_depth_transient < 2 or
                              self.net_depth_transient > self.skip_layer_transient):
       raise NotImplementedError('transient MLP: width 128, 2 <= depth <= skip_layer_transient, rgb branch enabled')
@@ -309,8 +311,8 @@ class Engine:
     tag = f'{spec.name}/L{lvl}'
     X0 = ws.get(tag + '/X0', (M, spec.Fp), self.tdt)
     _lib.call('hugs_cast_ipe_fwd', N, S, tdist, rays['origins'], rays['directions'], rays['radii'], self.basis[spec.name],
-              spec.nb, (0 if self.model.ray_shape == 'cone' else 1) | (4 if self.model.disable_integration else 0),
-              int(spec.warp_fn is not None), spec.max_deg_point,
+              spec.nb, (0 if self.model.ray_shape == 'cone' else 1) | (4 if self.model.disable_integration else 0) | (spec.min_deg_point << 8),
+              int(spec.warp_fn is not None), spec.max_deg_point - spec.min_deg_point,
               dt, spec.Fp, X0)
     acts = [X0]
     x = X0

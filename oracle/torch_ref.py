@@ -563,7 +563,7 @@ def model_forward(cfg, variables, rays, train_frac, u01, compute_extras, zero_gl
     if cfg.warp:
       means, covs = contract_track_linearize(means, covs)
     lm, lv = lift_and_diagonalize(means, covs, basis)
-    feats = integrated_pos_enc(lm, lv, 0, cfg.max_deg_point)
+    feats = integrated_pos_enc(lm, lv, getattr(cfg, 'min_deg_point', 0), cfg.max_deg_point)
     if override_feats is not None:     # tests: identical MLP inputs on both sides
       feats = override_feats[lvl].to(dt)
     which = 'prop' if is_prop else 'nerf'

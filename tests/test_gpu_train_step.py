@@ -248,6 +248,12 @@ def test_without_viewdirs_bf16_width_1024_trains():
   assert all(np.isfinite(losses)) and bool(torch.isfinite(state.flat).all()) and losses[-1] < losses[0], losses
 
 
+def test_train_step_min_deg_point():
+  """NerfMLP / PropMLP.min_deg_point = 2, max_deg_point = 8 (coord.py:107-126: scales 2^2 .. 2^7, 252 features)."""
+  gin = list(SMALL) + ["NerfMLP.min_deg_point = 2", "PropMLP.min_deg_point = 2", "NerfMLP.max_deg_point = 8", "PropMLP.max_deg_point = 8"]
+  _run_case(gin)
+
+
 def test_train_step_static_mask():
   gin = [g for g in SMALL if 'data_loss_type' not in g] + ["Config.transient_type = 'withmask'",
                                                            "Model.num_glo_features = 48"]
