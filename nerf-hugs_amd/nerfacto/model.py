@@ -611,6 +611,15 @@ class NerfactoModel:
         d_mask.mul_(sc)
     self.grad.zero_()
     want = lambda group: self.trainable is None or group in self.trainable
+    # The levels' backward passes only share the loss gradients: the field's chain (GEMMs: HBM-bound) and the proposal levels'
+    # (fused MLP + table scatter: atomic-bound) run on separate streams and fill each other's idle units (a single stream kept
+    # the GPU 100 % busy with ONE kernel at a time).  HUGS_NF_BWD_STREAMS=0: everything on the caller's stream.
+    cur = torch.cuda.current_stream()
+    multi = os.environ.get('HUGS_NF_BWD_STREAMS', '1') != '0'
+    if multi and not hasattr(self, '_bwd_streams'):
+      self._bwd_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+    ev0 = torch.cuda.Event(); ev0.record(cur)
+    done = []
     for l in range(self.L, -1, -1):
       st = levels[l]
       is_prop = l < self.L
@@ -618,9 +627,25 @@ class NerfactoModel:
         continue
       if not is_prop and not (want('field') or want('appearance_embedding')):
         continue
-      self._backward_level(st, batch, N, d_pred[0] if not is_prop else None, d_w[l])
+      if multi and is_prop:
+        side = self._bwd_streams[l % 2]
+        with torch.cuda.stream(side):
+          side.wait_event(ev0)
+          self._backward_level(st, batch, N, None, d_w[l])
+          e = torch.cuda.Event(); e.record(side); done.append(e)
+      else:
+        self._backward_level(st, batch, N, d_pred[0] if not is_prop else None, d_w[l])
     if mask_st is not None:
-      self._mask_backward(mask_st, batch, N, d_mask)
+      if multi:
+        side = self._bwd_streams[2]
+        with torch.cuda.stream(side):
+          side.wait_event(ev0)
+          self._mask_backward(mask_st, batch, N, d_mask)
+          e = torch.cuda.Event(); e.record(side); done.append(e)
+      else:
+        self._mask_backward(mask_st, batch, N, d_mask)
+    for e in done:
+      cur.wait_event(e)
     if world > 1:
       import torch.distributed as dist
       dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
@@ -727,7 +752,7 @@ class NerfactoModel:
       N1 = self.lay.items[f'{name}/w1'][1][1]
       KP = st['X0'].shape[1]
       dX0 = ws.get(f'dX0f_{name}', (M, KP), self.tdt)
-      slab = ws.get('prop_slab', (L.lib().cdll.hugs_nf_prop_ws_bytes(in_dim) // 4,))
+      slab = ws.get(f'prop_slab_{name}', (L.lib().cdll.hugs_nf_prop_ws_bytes(in_dim) // 4,))      # (per level: the levels run concurrently)
       L.call('hugs_nf_prop_bwd', M, in_dim, hid, dt, st['X0'], KP, self.lay.view(self.flat, f'{name}/w0'), N0,
              self.lay.view(self.flat, f'{name}/b0'), self.lay.view(self.flat, f'{name}/w1'), N1, st['raw'], st['sel'], d_dens,
              dX0, self.lay.view(self.grad, f'{name}/w0'), self.lay.view(self.grad, f'{name}/b0'),

@@ -1,11 +1,12 @@
 """Analyse a rocprofv3 --kernel-trace CSV of bench.py: per-step timeline (kernel union busy time, per-kernel totals,
 concurrency)."""
-import csv, sys, glob, collections
+import csv, sys, glob, collections, os
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 ev = sorted([(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'][:60]) for r in rows])
 # find the Adam kernels as step boundaries
-adam = [i for i, e in enumerate(ev) if 'k_opt_adam' in e[2]]
+mark = os.environ.get('STEP_MARK', 'k_opt_adam')
+adam = [i for i, e in enumerate(ev) if mark in e[2]]
 print('steps seen', len(adam))
 import os
 k_ = int(os.environ.get('STEP', -4))
