@@ -307,7 +307,7 @@ class NerfactoModel:
     while units % ns:
       ns -= 1
     nbytes = L.lib().cdll.hugs_gemm_tn_ws_bytes(K, N, ns)
-    slab = self.ws.get('tn_slab', (max(nbytes // 4, 1),))
+    slab = self.ws.get(f'tn_slab_{torch.cuda.current_stream().cuda_stream}', (max(nbytes // 4, 1),))      # (one per stream: the levels' chains run concurrently)
     L.call('hugs_gemm_tn', self.dt, M, K, N, ns, X, K, G, N, self.lay.view(self.grad, name), self.lay.view(self.grad, bias_name), slab)
 
   # ---- forward ----------------------------------------------------------------------------------------------------------
