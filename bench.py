@@ -31,7 +31,13 @@ GIN_CFG3 = GIN[:2] + ["Config.distortion_loss_mult = 0.001", "Config.transient_t
 GIN_CFG4 = GIN[:2] + ["Config.distortion_loss_mult = 0.001", "Config.transient_type = 'robustnerf'",
                       "Config.robustnerf_inlier_quantile = 0.8", "Model.raydist_fn = @jnp.reciprocal", "Model.num_glo_features = 4",
                       "NerfMLP.warp_fn = @coord.contract", "PropMLP.warp_fn = @coord.contract"] + GIN[5:]
+# the reference-default shape (MipNeRF360/configs/360.gin + the Config / Model defaults, internal/configs.py:50,
+# models.py:50-52): L=3, S=(64,64,32), 16384 rays, contract + reciprocal spacing, charb, interlevel + distortion losses, GLO 0
+GIN_REF360 = ["Config.near = 0.2", "Config.far = 1e6", "Model.raydist_fn = @jnp.reciprocal", "Model.opaque_background = True",
+              "PropMLP.warp_fn = @coord.contract", "PropMLP.net_depth = 4", "PropMLP.net_width = 256", "PropMLP.disable_rgb = True",
+              "NerfMLP.warp_fn = @coord.contract", "NerfMLP.net_depth = 8", "NerfMLP.net_width = 1024"]
 FLOP_TRAIN_PER_RAY = 6.5036e9   # SURVEY 8d / BASELINE.md work model, cfg2
+FLOP_TRAIN_PER_RAY_REF360 = 1.8160e9   # BASELINE.md section 2 work model, L=3 S=(64,64,32)
 PEAK_BF16 = 2.5e15              # dense MFMA peak (MI355X_MICROARCH.md)
 
 
@@ -92,12 +98,12 @@ def instep_roofline(train_step, state, batch, gen, thr, steps=5):
     k = max(fwd, key=lambda k: len(agg[k]))
     main = entry(k, 'nt_fwd', f"NT forward trunk [{k[1]}x1024]x[1024x1024]^T +bias +relu, writes 1-bit relu masks "
                  "(gemm_bf16::k_gemm_nt_bf16_pers<35>)", 2.0 * k[1] * W * W, 2.0 * k[1] * W * 2 + W * W * 2 + k[1] * W / 8)
-  M = 131072
+  M = max(fwd, key=lambda k: len(agg[k]))[1] if fwd else 131072      # rows of the NerfMLP level (131072 at cfg2)
   fl = 2.0 * M * W * W
-  others = [entry(('nt', M, W, W, 'mask'), 'nt_dx', "NT dX [131072x1024]x[1024x1024] *relu-mask bits (gemm_bf16::k_gemm_nt_bf16_pers<16>)", fl,
-                  2.0 * M * W * 2 + W * W * 2 + M * W / 8),
-            entry(('tn', M, W, W, 'split16'), 'tn_dw', "TN dW [1024x131072]x[131072x1024] + slab reduce (gemm_bf16::k_gemm_tn_bf16_big)", fl,
-                  2.0 * M * W * 2 + W * W * 4)]
+  tnk = [k for k in agg if k[0] == 'tn' and k[1] == M and k[2] == W and k[3] == W]
+  others = [entry(('nt', M, W, W, 'mask'), 'nt_dx', f"NT dX [{M}x1024]x[1024x1024] *relu-mask bits (gemm_bf16::k_gemm_nt_bf16_pers<16>)", fl,
+                  2.0 * M * W * 2 + W * W * 2 + M * W / 8)] + [
+            entry(k, 'tn_dw', f"TN dW [1024x{M}]x[{M}x1024] {k[4]} (gemm_bf16::k_gemm_tn_bf16_big)", fl, 2.0 * M * W * 2 + W * W * 4) for k in tnk]
   shapes = {f"{k[0]} M={k[1]} {k[2]}x{k[3]} {k[4]}": [len(v), round(float(np.mean(v)), 1)] for k, v in sorted(agg.items(), key=str)}
   return main, [o for o in others if o], shapes, state, gen
 
@@ -291,16 +297,22 @@ def main():
                   help="compute dtype; default bf16 (BASELINE config 2) and, for --config cfg5, fp16 (the reference's enable_amp: half operands,\n"
                        "half table copies, dynamic loss scaling)")
   ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--min-time', type=float, default=2.0,
+  ap.add_argument('--min-time', type=float, default=8.0,
                   help='repeat the K-step timed window until this many seconds of timed steps have run; value = median window')
   ap.add_argument('--max-windows', type=int, default=400)
   ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                   help='weak: 1024 rays per GPU (the default the driver runs); strong: 1024 rays in total, split over the GPUs '
                        '(BASELINE.md promises both curves)')
-  ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3', 'cfg4', 'cfg5'],
+  ap.add_argument('--rays-per-gpu', type=int, default=None,
+                  help='override the per-GPU batch (a multiple of 64: whole 8x8 patches): the per-rank workload of the fixed-global-batch\n'
+                       'scaling curve on ONE GPU, e.g. 128 = what --scaling strong hands each of 8 ranks')
+  ap.add_argument('--step-graph', default=None, choices=['0', '1'],
+                  help='replay the train step as a captured hipGraph (HUGS_STEP_GRAPH); default: the library default')
+  ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3', 'cfg4', 'cfg5', 'ref360'],
                   help='cfg2 = the headline workload; cfg3 (static masks, 4096 rays, GLO 48, charb) and cfg4 (RobustNeRF 0.8,\n'
                        'contract + reciprocal, GLO 4, 1024 rays/GPU) and cfg5 (nerfacto hash-grid path, 16384 rays/GPU,\n'
-                       'phototourism_nerfacto_base.yml sizes) are informational')
+                       'phototourism_nerfacto_base.yml sizes) are informational; ref360 = the reference-default shape (360.gin: L=3,\n'
+                       'S=(64,64,32), 16384 rays, contract + reciprocal), the only shape with a published number (BASELINE.md section 1)')
   args = ap.parse_args()
   if args.dtype is None:
     args.dtype = 'fp16' if args.config == 'cfg5' else 'bf16'
@@ -327,9 +339,19 @@ def main():
     return bench_nerfacto(args, device, world, rank)
   from nerf_hugs_amd.internal import configs, train_utils
   configs.clear_config()
-  gin = {'cfg2': GIN, 'cfg3': GIN_CFG3, 'cfg4': GIN_CFG4}[args.config]
+  if args.step_graph is not None:
+    os.environ['HUGS_STEP_GRAPH'] = args.step_graph
+  # the CPU baseline runs FIRST (it used to run last: the driver's 5-s SMI poll then saw 12 s of idle GPU next to 2 s of work)
+  cpu_base = None
+  if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 'cfg2' and args.rays_per_gpu is None:
+    cpu_base = cpu_baseline(20200823)
+  gin = {'cfg2': GIN, 'cfg3': GIN_CFG3, 'cfg4': GIN_CFG4, 'ref360': GIN_REF360}[args.config]
   configs.parse_config_files_and_bindings(None, gin)
-  rays_per_gpu = 4096 if args.config == 'cfg3' else 1024
+  rays_per_gpu = {'cfg3': 4096, 'ref360': 16384}.get(args.config, 1024)
+  if args.rays_per_gpu is not None:
+    if args.rays_per_gpu % 64 or args.scaling == 'strong':
+      raise SystemExit('--rays-per-gpu: a multiple of 64 (whole 8x8 patches), not together with --scaling strong')
+    rays_per_gpu = args.rays_per_gpu
   P = 16
   if args.scaling == 'strong':
     if rays_per_gpu % world or (rays_per_gpu // world) % 64:
@@ -339,13 +361,20 @@ def main():
       if args.config == 'cfg4':
         raise SystemExit('RobustNeRF needs whole 16x16 patches per GPU: strong scaling stops at 4 GPUs for 1024 rays')
       P = 8                      # 128 rays per GPU = two 8x8 patches (the plain / static-mask losses have no patch structure)
+  if rays_per_gpu % 256:
+    if args.config == 'cfg4':
+      raise SystemExit('RobustNeRF needs whole 16x16 patches per GPU')
+    P = 8
   config = configs.make_config(batch_size=rays_per_gpu * world)
   model, state, _, train_step, _ = train_utils.setup_model(config, 20200823, compute_dtype=args.dtype, device=device)
   batch = synth_batch(rays_per_gpu // (P * P), P, 1000 + rank, device)
+  if args.config == 'ref360':     # 360.gin: near 0.2, far 1e6 (contracted space)
+    batch.rays.near.fill_(0.2)
+    batch.rays.far.fill_(1e6)
   if args.config == 'cfg4':       # distractor-like geometry: near in [0.05, 0.3], far 1e6
     batch.rays.near.uniform_(0.05, 0.3)
     batch.rays.far.fill_(1e6)
-  if args.config != 'cfg2':
+  if args.config in ('cfg3', 'cfg4'):
     batch.rays.embed_idx.copy_(torch.randint(0, 3500, (rays_per_gpu // (P * P), 1, 1, 1), device=device).expand_as(batch.rays.embed_idx))
     batch.rays.static_mask.copy_((torch.rand(rays_per_gpu // (P * P), P, P, 1, device=device) < 0.8).float())
   # the reference's stream: PRNGKey(20200823) split over the devices (train.py:46,80), threefry on the GPU
@@ -386,38 +415,51 @@ def main():
   dt = float(np.median(wins))
   loss = float(stats['loss'])
   psnr = float(stats['psnr'])
+  # host side of a step: wall time of enqueueing 8 steps onto an idle GPU without waiting for them (the launch queue is
+  # far deeper than 8 steps); host_enqueue_ms >= ms_per_step means the step is host-bound
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(8):
+    state, stats, gen = train_step(gen, state, batch, 0.5, thr)
+  host_ms = (time.perf_counter() - t0) / 8 * 1e3
+  torch.cuda.synchronize()
   roof = None
-  if args.dtype == 'bf16' and args.config == 'cfg2':
+  if args.dtype == 'bf16' and args.config in ('cfg2', 'ref360'):
     # after the timed region: a few more steps with the GEMM launches bracketed by HIP events (every rank runs them:
     # the steps contain the gradient all-reduce; rank 0 reports)
     roof, roof_others, roof_shapes, state, gen = instep_roofline(train_step, state, batch, gen, thr)
   eval_psnr = None
-  if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 'cfg2':
+  if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 'cfg2' and args.rays_per_gpu is None:
     eval_psnr = eval_psnr_vs_oracle(model, state, batch, args.dtype)
   if rank == 0:
     rps = rays_per_gpu * world * args.steps / dt
     line = {
-        "metric": "train rays/sec (%d-ray batch per GPU, 64+128 samples)" % rays_per_gpu, "value": round(rps, 1), "unit": "rays/s",
+        "metric": "train rays/sec (%d-ray batch per GPU, %s samples)" % (rays_per_gpu, "64+64+32" if args.config == 'ref360' else "64+128"), "value": round(rps, 1), "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "windows": len(wins), "timed_s": round(float(np.sum(wins)), 3),
+        "windows": len(wins), "timed_s": round(float(np.sum(wins)), 3), "gpu_timed_s": round(float(np.sum(wins)), 3),
+        "host_enqueue_ms_per_step": round(host_ms, 3), "step_graph": bool(getattr(train_step, 'graph_active', lambda: False)()),
         "value_min": round(rays_per_gpu * world * args.steps / max(wins), 1), "value_max": round(rays_per_gpu * world * args.steps / min(wins), 1),
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": {"cfg2": "configs[1]: MipNeRF360 base (kubric_1024_base.gin nets), 1024 rays x (64 prop + 128 fine) per GPU, "
                                         "full train step",
                                 "cfg3": "configs[2] restatement: + HuGS static masks, GLO 48, charb, 4096 rays x (64+128), full train step",
-                                "cfg4": "configs[3] restatement: RobustNeRF 0.8, contract + reciprocal, GLO 4, 1024 rays/GPU x (64+128)"}[args.config],
+                                "cfg4": "configs[3] restatement: RobustNeRF 0.8, contract + reciprocal, GLO 4, 1024 rays/GPU x (64+128)",
+                                "ref360": "reference-default shape (360.gin + Config/Model defaults): L=3, S=(64,64,32), 16384 rays/GPU, contract + "
+                                          "reciprocal, charb + interlevel + distortion losses, full train step (BASELINE.md section 1: ~177 k rays/s "
+                                          "derived from the upstream table, hardware not stated)"}[args.config],
                    "rays_per_gpu": rays_per_gpu, "global_batch": rays_per_gpu * world,
                    "parallelism": f"dp{world}", "params": model.layout.num_params()},
         "train_psnr_last": round(psnr, 3), "loss_last": round(loss, 6),
         "eval_psnr_vs_cpu_fp32_db": eval_psnr,
-        "step_mfma_frac": round(rps / world * FLOP_TRAIN_PER_RAY / (PEAK_BF16 if args.dtype == 'bf16' else 157.3e12), 4),
+        "step_mfma_frac": (round(rps / world * (FLOP_TRAIN_PER_RAY_REF360 if args.config == 'ref360' else FLOP_TRAIN_PER_RAY) /
+                                 (PEAK_BF16 if args.dtype == 'bf16' else 157.3e12), 4) if args.config in ('cfg2', 'ref360') else None),
     }
     if roof is not None:
       line["roofline"] = roof
       line["instep_kernels"] = roof_others
       line["instep_gemm_shapes_count_avg_us"] = roof_shapes
-    if world == 1 and not args.no_cpu_baseline and args.config == 'cfg2':
-      line["cpu_baseline"] = cpu_baseline(20200823)
+    if cpu_base is not None:
+      line["cpu_baseline"] = cpu_base
     print(json.dumps(line))
   if world > 1:
     dist.barrier()          # rank 0 measures the roofline / prints after the timed region: keep the group alive until then

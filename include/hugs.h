@@ -203,6 +203,8 @@ int hugs_prng_normal(const uint32_t* key, long long n, float* out, void* stream)
  * are HOST arrays (out[l] device pointers).  Bit-identical to the chain of hugs_prng_bits / hugs_prng_uniform calls. */
 int hugs_prng_step_jitter(const uint32_t* key_in, int L, const long long* n, const float* maxval, float* const* out,
                           uint32_t* key_out, void* stream);
+/* The largest L hugs_prng_step_jitter takes (the host side gates its fused launch on this, not on a literal). */
+int hugs_prng_step_jitter_max_levels(void);
 
 /* ---- eval metrics: image.py:127-141 MetricHarness.  hugs_ssim == dm_pix.ssim(a, b) for one
  * [H,W,C] fp32 image pair with dm_pix's defaults passed explicitly (max_val 1, 11 taps fixed, filter_sigma 1.5,

@@ -80,11 +80,12 @@ k_threefry(const uint32_t* __restrict__ key, long long n, float lo, float hi, vo
 // level models.py:196 `key, rng = random.split(rng)` -> stepfun.py:207-209 random.uniform(key, [n_l], maxval_l) and
 // models.py:230 `key, rng = random.split(rng)` for the MLP key): every thread re-derives the (1 + 2 L) splits -- two
 // threefry evaluations each, a few hundred integer ops -- and writes its pair of uniform draws of every level.
+#define HUGS_STEP_JITTER_MAX_LEVELS 8      // the ONE definition of the cap (exported: hugs_prng_step_jitter_max_levels)
 struct StepJitter {
   int L;
-  long long n[8];
-  float maxval[8];
-  float* out[8];
+  long long n[HUGS_STEP_JITTER_MAX_LEVELS];
+  float maxval[HUGS_STEP_JITTER_MAX_LEVELS];
+  float* out[HUGS_STEP_JITTER_MAX_LEVELS];
 };
 
 __device__ __forceinline__ void split2(uint32_t k0, uint32_t k1, uint32_t (&a)[2], uint32_t (&b)[2]) {
@@ -122,9 +123,11 @@ k_step_jitter(const uint32_t* __restrict__ key_in, StepJitter J, uint32_t* __res
 /* One training step's draws from the reference's jax.random stream in one launch: key_out = first half of split(key_in)
  * (train_utils.py:408), and for every level l < L (<= 8) out[l][0..n[l]) = random.uniform(k_l, [n[l]], maxval = maxval[l]) with
  * the keys of models.py:196,230.  n / maxval / out are HOST arrays.  Bit-identical to the split / uniform entry points. */
+extern "C" int hugs_prng_step_jitter_max_levels(void) { return HUGS_STEP_JITTER_MAX_LEVELS; }
 extern "C" int hugs_prng_step_jitter(const uint32_t* key_in, int L, const long long* n, const float* maxval, float* const* out,
                                      uint32_t* key_out, void* stream) {
-  HUGS_REQUIRE(key_in && key_out && n && maxval && out && L >= 0 && L <= 8, -2, "hugs_prng_step_jitter: null pointer or L=%d outside 0..8", L);
+  HUGS_REQUIRE(key_in && key_out && n && maxval && out && L >= 0 && L <= HUGS_STEP_JITTER_MAX_LEVELS, -2,
+               "hugs_prng_step_jitter: null pointer or L=%d outside 0..%d", L, HUGS_STEP_JITTER_MAX_LEVELS);
   StepJitter J;
   J.L = L;
   long long hmax = 1;

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void k_level_sample(
     }
     __syncthreads();
     float s = 1.0f;
-    if (live) s = ORDER == 1 ? sf_np_sum<3>(L.wd, m - 1, lane) : sf_wave_sum<C>(L.wd, m - 1, lane);
+    if (live) s = ORDER == 1 ? sf_np_sum<4>(L.wd, m - 1, lane) : sf_wave_sum<C>(L.wd, m - 1, lane);
     float den = s > eps2 ? s : eps2;
     n_in = 3 * n - 2;
     if (live) {
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void k_level_sample(
   if (live) for (int i = lane; i < n_in; i += 64) L.wd[i] = sf_expf(L.wd[i] - mx);
   __syncthreads();
   float den = 1.0f;
-  if (live) den = ORDER == 1 ? sf_np_sum<3>(L.wd, n_in, lane) : sf_wave_sum<C>(L.wd, n_in, lane);
+  if (live) den = ORDER == 1 ? sf_np_sum<4>(L.wd, n_in, lane) : sf_wave_sum<C>(L.wd, n_in, lane);
   if (live) for (int i = lane; i < n_in; i += 64) L.p[i] = L.wd[i] / den;
   __syncthreads();
   if (live && ORDER == 1) {

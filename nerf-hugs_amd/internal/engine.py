@@ -305,8 +305,9 @@ class Engine:
     return self._cast_src is not None and self._cast_src == (state.gen, state.flat.data_ptr(), state.flat._version)
 
   # ---- forward ------------------------------------------------------------------------------------
-  def _mlp_forward(self, spec, theta, lvl, N, S, tdist, rays, glo, keep, tra=None, mlp_key=None):
+  def _mlp_forward(self, spec, theta, lvl, N, S, tdist, rays, glo, keep, tra=None, mlp_key=None, n_real=None):
     M = N * S
+    Mr = M if n_real is None else n_real * S      # rows of real rays (Model.apply pads ragged batches at the END)
     lay, ws, dt = self.layout, self.ws, self.dt
     tag = f'{spec.name}/L{lvl}'
     X0 = ws.get(tag + '/X0', (M, spec.Fp), self.tdt)
@@ -368,7 +369,8 @@ class Engine:
       from . import random as hrandom
       density_key, noise_key = hrandom.split(mlp_key)          # models.py:435 density_key, rng = random_split(rng)
       if spec.density_noise > 0:                                  # models.py:458-460: raw_density += noise * normal(key, [N, S])
-        raw.add_(hrandom.normal(density_key, (M,)), alpha=float(spec.density_noise))
+        # the reference draws [n_real, S] values: a padded batch must not draw for its padding (another size = another stream)
+        raw[:Mr].add_(hrandom.normal(density_key, (Mr,)), alpha=float(spec.density_noise))
         density.copy_(torch.logaddexp(raw + float(spec.density_bias), torch.zeros_like(raw)))   # softplus, as hugs_density_fwd
     out = dict(X0=X0, acts=acts, raw=raw, density=density, rgb=None, bits=bits if nchunk == 1 else [None] * len(bits))
     if not spec.disable_rgb and not spec.use_viewdirs:
@@ -386,7 +388,7 @@ class Engine:
       if noise_key is not None and spec.bottleneck_noise > 0:   # models.py:478-481: bottleneck += noise * normal(key, [N, S, Bw])
         from . import random as hrandom
         kb, _ = hrandom.split(noise_key)
-        bott.add_(hrandom.normal(kb, (M, Bw)).to(bott.dtype), alpha=float(spec.bottleneck_noise))
+        bott[:Mr].add_(hrandom.normal(kb, (Mr, Bw)).to(bott.dtype), alpha=float(spec.bottleneck_noise))
       Wv = lay.view(theta, (spec.name, lv['name'], 'kernel'))
       rb = ws.get(tag + '/raybias', (N, H))
       _lib.call('hugs_raybias_fwd', N, H, spec.nd, spec.num_glo, rays['dir_enc'], glo, Wv[Bw:],
@@ -432,7 +434,7 @@ class Engine:
         out.update(tacts=tacts, raw_t=raw_t, dens_t=dens_t, rgb_t=rgb_t, raw_u=raw_u, unc=unc, tra=tra)
     return out
 
-  def forward(self, theta, rays, train_frac, u01, compute_extras, zero_glo=False, zero_tra=False):
+  def forward(self, theta, rays, train_frac, u01, compute_extras, zero_glo=False, zero_tra=False, n_real=None):
     """Model.__call__ (models.py:74-330).  rays: dict of contiguous [N,c] cuda tensors (+ 'dir_enc').
     u01: None, a list[num_levels] of U[0,1) draws, or a stepfun.Jitter list of scaled draws.  Returns per-level dicts (device tensors; buffers are
     reused by the next call)."""
@@ -487,7 +489,7 @@ class Engine:
       spec = mdl.prop_spec if is_prop else mdl.nerf_spec
       mkeys = getattr(u01, 'mlp_keys', None)
       out = self._mlp_forward(spec, theta, lvl, N, S, td, rays, glo, True, None if is_prop else tra,
-                              mlp_key=None if mkeys is None else mkeys[lvl])
+                              mlp_key=None if mkeys is None else mkeys[lvl], n_real=n_real)
       w = ws.get(f'L{lvl}/weights', (N, S))
       rgb_all = ws.get('rgb_out_all', (mdl.num_levels, N, 3))
       rgb_out = rgb_all[lvl]

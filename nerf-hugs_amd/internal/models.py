@@ -167,13 +167,19 @@ class Model:
       r = {k: pad(v) for k, v in r.items()}
       if u01 is not None:
         padded = [pad(u) for u in u01]
-        if isinstance(u01, stepfun.Jitter) and u01.mlp_keys is not None and self.has_noise():
-          raise NotImplementedError('density / bottleneck noise or a random background with a ray count that needs padding to the GEMM tile')
-        u01 = stepfun.Jitter(padded) if isinstance(u01, stepfun.Jitter) else padded
+        if isinstance(u01, stepfun.Jitter):
+          # the draws were made for the N real rays (level_jitter above); the noise draws inside the engine are sized by
+          # n_real too, so a padded batch consumes the reference's stream unchanged
+          pj = stepfun.Jitter(padded)
+          pj.mlp_keys = u01.mlp_keys
+          pj.bg_rgbs = None if not u01.bg_rgbs else [pad(b) for b in u01.bg_rgbs]
+          u01 = pj
+        else:
+          u01 = padded
     take = lambda buf, *tail: buf.reshape((Np,) + tail)[:N].clone().reshape(lead + tail)
     if refresh_weights:
       eng.refresh_weights(flat)
-    levels = eng.forward(flat, r, float(train_frac), u01, compute_extras, zero_glo, zero_tra)
+    levels = eng.forward(flat, r, float(train_frac), u01, compute_extras, zero_glo, zero_tra, n_real=N if Np != N else None)
     implicit_mask = None
     if self.mask_spec is not None:
       implicit_mask = eng.mask_forward(flat, r, Np, zero_tra)['mask'][:N].clone().reshape(lead + (1,))

@@ -63,6 +63,11 @@ def normal(key, shape=()):
   return out
 
 
+def step_jitter_max_levels():
+  """The level cap of the fused launch, read from the library (csrc/hugs_prng.hip HUGS_STEP_JITTER_MAX_LEVELS)."""
+  return int(L.lib().cdll.hugs_prng_step_jitter_max_levels())
+
+
 def step_jitter(key, sizes, maxvals):
   """One training step's whole consumption of the stream in ONE launch (csrc/hugs_prng.hip k_step_jitter), bit-identical to
 

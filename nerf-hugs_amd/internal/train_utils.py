@@ -138,7 +138,9 @@ def uncovered_ranges(layout, covered, total):
   for lf in layout.leaves:
     lo, hi = lf['off'], lf['off'] + int(np.prod(lf['pshape']))
     if not any(c0 <= lo and hi <= c1 for c0, c1 in cov):
-      if todo and todo[-1][1] >= lo - 4:         # merge neighbours (leaves are padded to 4 floats)
+      # merge neighbours (leaves are padded to 4 floats) -- but never across a covered leaf: a [1] / [3] bias of a covered
+      # layer sitting in that 4-float gap would be all-reduced (SUM) a second time
+      if todo and todo[-1][1] >= lo - 4 and not any(c0 < lo and c1 > todo[-1][1] for c0, c1 in cov):
         todo[-1][1] = hi
       else:
         todo.append([lo, hi])
@@ -146,6 +148,8 @@ def uncovered_ranges(layout, covered, total):
     todo[-1][1] = total
   elif layout.size < total:
     todo.append([layout.size, total])
+  for lo, hi in todo:      # what is reduced here must not overlap anything a bucket already reduced
+    assert not any(c0 < hi and lo < c1 for c0, c1 in cov), (lo, hi, cov)
   return [tuple(t) for t in todo]
 
 
@@ -227,7 +231,7 @@ def create_train_step(model, config, is_finetune=False):
         raise ValueError(f'explicit jitter needs one tensor per level ({L}), got {len(rng)}')
       u01 = [u.to(device=dev, dtype=torch.float32).contiguous() for u in rng]
     elif hrandom.is_key(rng):                        # jax stream: rng, key = random.split(rng) (train_utils.py:408)
-      if config.randomized and L <= 8 and not model.has_noise():
+      if config.randomized and L <= hrandom.step_jitter_max_levels() and not model.has_noise():
         u01, rng = model.step_jitter(rng, N)         # that split + every level's split / uniform / split in one launch
       else:
         rng, key = hrandom.split(rng)

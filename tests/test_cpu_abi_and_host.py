@@ -278,9 +278,17 @@ def test_allreduce_leftover_ranges_cover_every_leaf():
   dens_bias = lay.by_path[('NerfMLP_0', f'Dense_{m.nerf_spec.net_depth}', 'bias')]
   assert int(np.prod(dens_bias['pshape'])) == 1
   assert any(lo <= dens_bias['off'] < hi for lo, hi in todo)
-  # a bucket that cuts a leaf in half does not count as covering it
+  # a covered 1-float leaf (padded to 4) between two uncovered neighbours is NOT swallowed into a merged range (it would be
+  # summed over the ranks twice): nothing that is reduced here may overlap a bucket
+  i = next(k for k, lf in enumerate(lay.leaves) if lf is dens_bias)
+  todo = check([span(dens_bias)])
+  assert not any(lo < span(dens_bias)[1] and span(dens_bias)[0] < hi for lo, hi in todo)
+  assert any(hi == span(lay.leaves[i - 1])[1] for lo, hi in todo) and any(lo == span(lay.leaves[i + 1])[0] for lo, hi in todo)
+  # a bucket that cuts a leaf in half does not count as covering it -- and reducing the whole leaf on top of the half bucket
+  # would double-count: that is refused loudly
   k0 = kernels[0]
-  check([(k0[0], (k0[0] + k0[1]) // 2)] + kernels[1:])
+  with pytest.raises(AssertionError):
+    check([(k0[0], (k0[0] + k0[1]) // 2)] + kernels[1:])
   configs.clear_config()
 
 

@@ -82,6 +82,11 @@ def _run_level(N, n_prev, ns, dil, raydist, jitter, seed, wpow=1, zeros=False, a
     dict(N=40, n_prev=256, ns=256, dil=0.0031, raydist=1, jitter=True, wpow=3, zeros=True),
     dict(N=17, n_prev=256, ns=64, dil=0.0031, raydist=0, jitter=False),
     dict(N=9, n_prev=1000, ns=1024, dil=None, raydist=0, jitter=True, wpow=4),
+    # numpy's pairwise sum keeps halving until a block is <= 128: 1015 -> 511 -> 263 -> 135 needs a FOURTH split
+    dict(N=7, n_prev=1015, ns=64, dil=None, raydist=0, jitter=True, wpow=3),
+    dict(N=7, n_prev=1023, ns=64, dil=None, raydist=0, jitter=False, wpow=2),
+    dict(N=5, n_prev=339, ns=32, dil=0.002, raydist=0, jitter=True, wpow=3),       # 3*339 - 2 = 1015 dilated bins
+    dict(N=5, n_prev=341, ns=32, dil=0.002, raydist=1, jitter=True),               # 1021: the largest dilated level
     # the other raydist_fn curves of coord.py:84-90 (log, exp, sqrt, square)
     dict(N=200, n_prev=64, ns=64, dil=0.0103125, raydist=2, jitter=True),
     dict(N=200, n_prev=64, ns=64, dil=0.0103125, raydist=3, jitter=False),
