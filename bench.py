@@ -101,10 +101,14 @@ def instep_roofline(train_step, state, batch, gen, thr, steps=5):
   M = max(fwd, key=lambda k: len(agg[k]))[1] if fwd else 131072      # rows of the NerfMLP level (131072 at cfg2)
   fl = 2.0 * M * W * W
   tnk = [k for k in agg if k[0] == 'tn' and k[1] == M and k[2] == W and k[3] == W]
+  tnb = [k for k in agg if k[0] == 'tnb' and k[1] > 4 * fl]      # the NerfMLP trunk's batched weight-gradient launches
   others = [entry(('nt', M, W, W, 'mask'), 'nt_dx', f"NT dX [{M}x1024]x[1024x1024] *relu-mask bits (gemm_bf16::k_gemm_nt_bf16_pers<16>)", fl,
                   2.0 * M * W * 2 + W * W * 2 + M * W / 8)] + [
-            entry(k, 'tn_dw', f"TN dW [1024x{M}]x[{M}x1024] {k[4]} (gemm_bf16::k_gemm_tn_bf16_big)", fl, 2.0 * M * W * 2 + W * W * 4) for k in tnk]
-  shapes = {f"{k[0]} M={k[1]} {k[2]}x{k[3]} {k[4]}": [len(v), round(float(np.mean(v)), 1)] for k, v in sorted(agg.items(), key=str)}
+            entry(k, 'tn_dw', f"TN dW [1024x{M}]x[{M}x1024] {k[4]} (gemm_bf16::k_gemm_tn_bf16_big)", fl, 2.0 * M * W * 2 + W * W * 4) for k in tnk] + [
+            entry(k, 'tn_dw_batch', f"TN dW of {k[2]} trunk items in one launch, {k[3]} reduction pieces per tile + the reduce "
+                                    f"(gemm_bf16::k_gemm_tn_bf16_batch)", k[1], None) for k in tnb]
+  shapes = {(f"{k[0]} M={k[1]} {k[2]}x{k[3]} {k[4]}" if k[0] != 'tnb' else f"tnb {k[4]} GFLOP={k[1] / 1e9:.1f}"): [len(v), round(float(np.mean(v)), 1)]
+            for k, v in sorted(agg.items(), key=str)}
   return main, [o for o in others if o], shapes, state, gen
 
 

@@ -71,6 +71,19 @@ int hugs_gemm_nt(int dtype, int M, int N, int K1, int K2, const void* A1, int ld
 long long hugs_gemm_tn_ws_bytes(int Kc, int N, int nsplit);
 int hugs_gemm_tn(int dtype, int Mrows, int Kc, int N, int nsplit, const void* X, int ldx, const void* G, int ldg,
                  float* dW, float* dbias, void* ws, void* stream);
+/* The weight gradients of SEVERAL layers (train_utils.py:454: everything jax.value_and_grad derives for the Dense kernels of
+ * models.py:451-455) in one launch: item i is dW_i[Kc,N] = X_i[Mrows,Kc]^T G_i[Mrows,N] (+ dbias_i = colsum G_i when
+ * non-null).  bf16 / fp16 operands (dtype 1 / 2), Kc and N multiples of 256, Mrows a multiple of 64, <= 16 items.  The
+ * reduction rows of every item are cut into nsplit pieces (fixed partition, fp32 partial tiles summed in piece order:
+ * deterministic); hugs_gemm_tn_batch_nsplit returns #CUs / (total 256x256 tiles), the value that fills the chip once.
+ * `items` is a HOST array; ws: hugs_gemm_tn_batch_ws_bytes(nitems, items, nsplit) device bytes. */
+typedef struct HugsTnItem {
+  const void* X; const void* G; float* dW; float* dbias;
+  int ldx, ldg, Mrows, Kc, N, reserved;
+} HugsTnItem;
+int hugs_gemm_tn_batch_nsplit(int nitems, const HugsTnItem* items);
+long long hugs_gemm_tn_batch_ws_bytes(int nitems, const HugsTnItem* items, int nsplit);
+int hugs_gemm_tn_batch(int dtype, int nitems, const HugsTnItem* items, int nsplit, void* ws, void* stream);
 
 /* models.py:456 raw_density = Dense(1)(x)[...,0]; :467 density = softplus(raw + density_bias) */
 int hugs_density_fwd(int dtype, int M, int K, const void* Y, int ldy, const float* w, const float* b,

@@ -17,6 +17,8 @@ _PROTOS = {
     'hugs_gemm_nt': 'iiiii' 'pipipi' 'pp' 'iii' 'pi' 'pp' 'pi' 's',
     'hugs_gemm_nt_bits': 'iiiii' 'pipipi' 'p' 'i' 'pp' 'pi' 'pp' 's',
     'hugs_gemm_tn': 'iiiiipipippps',
+    'hugs_gemm_tn_batch': 'iipips',
+    'hugs_gemm_tn_batch_nsplit': 'ip',
     'hugs_density_fwd': 'iiipippfpps',
     'hugs_density_bwd': 'iiipippfpppps',
     'hugs_rank1_mask': 'iiipppipis',
@@ -126,8 +128,9 @@ class _Lib:
           'There is no CPU fallback.')
     self.cdll = ctypes.CDLL(LIB_PATH)
     self.cdll.hugs_last_error.restype = ctypes.c_char_p
-    for n_ in ('hugs_gemm_tn_ws_bytes', 'hugs_density_bwd_ws_bytes', 'hugs_rgb_bwd_ws_bytes', 'hugs_ssim_ws_bytes', 'hugs_gemm_nt_bits_bytes', 'hugs_nf_prop_ws_bytes'):
+    for n_ in ('hugs_gemm_tn_batch_ws_bytes', 'hugs_gemm_tn_ws_bytes', 'hugs_density_bwd_ws_bytes', 'hugs_rgb_bwd_ws_bytes', 'hugs_ssim_ws_bytes', 'hugs_gemm_nt_bits_bytes', 'hugs_nf_prop_ws_bytes'):
       getattr(self.cdll, n_).restype = ctypes.c_longlong
+    self.cdll.hugs_gemm_tn_batch_ws_bytes.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
     for name, sig in _PROTOS.items():
       fn = getattr(self.cdll, name)
       fn.argtypes = [_CT[c] for c in sig]

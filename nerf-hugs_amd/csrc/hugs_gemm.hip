@@ -887,11 +887,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(int Mrows, int Kc, int 
 // (Round-2 measurement builds -- no DMA / no fragment reads / no MFMA / L2-resident loads / no barrier / uncounted waits,
 // 8:6 / 4:3 / DS-first interleaves, an L2 prefetch of the XCD siblings' lines -- are in the git history; DESIGN.md
 // section 4 has their numbers.)
-__global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, int N, int nsplit,
-                                                              const uint16_t* __restrict__ X, int ldx,
-                                                              const uint16_t* __restrict__ G, int ldg,
-                                                              float* __restrict__ slab, int lds_out,
-                                                              float* __restrict__ colsum_slab) {
+// One 256x256 tile of D = X^T G over the reduction rows [mbeg, mbeg + 32 ns): the body shared by the per-layer kernel
+// (k_gemm_tn_bf16_big) and the batched one (k_gemm_tn_bf16_batch).  out: this split's fp32 slab [Kc, lds_out]; colsum:
+// this split's bias-gradient row [N] or null.  ns must be even and >= 8.
+__device__ __forceinline__ void tn_big_tile(const uint16_t* __restrict__ X, int ldx, const uint16_t* __restrict__ G, int ldg,
+                                            int mbeg, int ns, int c0, int n0, float* __restrict__ out, int lds_out,
+                                            float* __restrict__ colsum) {
   // stage layout: per operand 16 row PAIRS of 1 KiB (rows 2p, 2p+1 as the LDS-DMA writes them) at a 1056-byte
   // pitch: the 8 rows one 32-lane group of a transpose read touches have distinct p, so they land 8 banks apart
   // (1056 B = 264 dwords = 8 mod 64) with NO address swizzle: every fragment read is base + immediate.
@@ -900,16 +901,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
   __shared__ __attribute__((aligned(16))) unsigned char lds[RING];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ntn = N >> 8, ntk = Kc >> 8, tiles = ntn * ntk;
-  // all tiles of one M-split read the same X / G row block: keep them on one XCD so its L2 serves the re-reads
-  const int vb = xcd_remap(blockIdx.x, gridDim.x);
-  const int split = vb / tiles, tt = vb % tiles;
-  const int c0 = (tt / ntn) << 8, n0 = (tt % ntn) << 8;
-  const int rows_per = Mrows / nsplit, mbeg = split * rows_per;
-  const int ns = rows_per >> 5;
   const int wn = wv >> 2, wk = wv & 3;
-  const bool do_colsum = colsum_slab && c0 == 0;
-
+  const bool do_colsum = colsum && c0 == 0;
   // LDS-DMA as inline asm: (64-bit SGPR base) + (32-bit per-lane byte offset, constant for the whole kernel), M0 = LDS
   // destination.  Through the builtin the compiler knows the instruction writes LDS and puts an `s_waitcnt vmcnt(0)` in
   // front of the first transpose read of EVERY iteration (it cannot prove the ds_read_tr intrinsics do not alias the
@@ -1053,7 +1046,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
 
   // Epilogue: the fp32 tile leaves through LDS (the ring is free now) so that every wave instruction stores one
   // whole 1 KiB slab row instead of sixteen 64-byte runs.  Two passes of 128 Kc-rows (pitch 1040 B).
-  float* out = slab + (size_t)split * Kc * lds_out;
   constexpr int TP = 1040;
   __syncthreads();
 #pragma unroll
@@ -1081,9 +1073,53 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, 
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int n = n0 + wn * 128 + (2 * wk + q) * 16 + g * 4;
-      *(float4*)(colsum_slab + (size_t)split * N + n) = make_float4(accb[q][0], accb[q][1], accb[q][2], accb[q][3]);
+      *(float4*)(colsum + n) = make_float4(accb[q][0], accb[q][1], accb[q][2], accb[q][3]);
     }
   }
+}
+
+__global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_big(int Mrows, int Kc, int N, int nsplit,
+                                                              const uint16_t* __restrict__ X, int ldx,
+                                                              const uint16_t* __restrict__ G, int ldg,
+                                                              float* __restrict__ slab, int lds_out,
+                                                              float* __restrict__ colsum_slab) {
+  const int ntn = N >> 8, ntk = Kc >> 8, tiles = ntn * ntk;
+  // all tiles of one M-split read the same X / G row block: keep them on one XCD so its L2 serves the re-reads
+  const int vb = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = vb / tiles, tt = vb % tiles;
+  const int c0 = (tt / ntn) << 8, n0 = (tt % ntn) << 8;
+  const int rows_per = Mrows / nsplit, mbeg = split * rows_per;
+  tn_big_tile(X, ldx, G, ldg, mbeg, rows_per >> 5, c0, n0, slab + (size_t)split * Kc * lds_out, lds_out,
+              colsum_slab ? colsum_slab + (size_t)split * N : nullptr);
+}
+
+// Batched form (round 4): the weight gradients of SEVERAL layers in one launch -- every item an X^T G product with its own
+// operands and slab -- so that nsplit = #CUs / (total tiles) instead of #CUs / (one layer's tiles): the NerfMLP trunk's
+// 8 layers are 128 tiles, i.e. TWO reduction halves per tile instead of sixteen (8 MB of fp32 slabs per layer instead of 64,
+// 2048-stage main loops instead of 256, one reduce launch instead of eight).  The reduction rows of an item are cut into
+// nsplit near-equal pieces in units of 64 rows (unit u of piece s: [s U / nsplit, (s+1) U / nsplit)): any nsplit <= U.
+// vb order: item-major, then split, then tile -- the tiles of one (item, split) are neighbours in vb and therefore share
+// an XCD (xcd_remap), whose L2 serves their re-reads of the X / G row block.
+#define HUGS_TN_BATCH_MAX 16
+struct TnBatchItem {
+  const uint16_t* X; const uint16_t* G;
+  float* slab;          // [nsplit][Kc][N] fp32
+  float* colsum;        // [nsplit][N] or null
+  int ldx, ldg, Kc, N, units, wg0, tiles, pad_;
+};
+struct TnBatch { int nitems, nsplit; TnBatchItem it[HUGS_TN_BATCH_MAX]; };
+__global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_batch(const TnBatch B) {
+  const int vb = xcd_remap(blockIdx.x, gridDim.x);
+  int i = 0;
+  while (i + 1 < B.nitems && vb >= B.it[i + 1].wg0) ++i;
+  const TnBatchItem& I = B.it[i];
+  const int r = vb - I.wg0;
+  const int split = r / I.tiles, tt = r % I.tiles;
+  const int ntn = I.N >> 8;
+  const int c0 = (tt / ntn) << 8, n0 = (tt % ntn) << 8;
+  const int u0 = (int)(((long long)split * I.units) / B.nsplit), u1 = (int)(((long long)(split + 1) * I.units) / B.nsplit);
+  tn_big_tile(I.X, I.ldx, I.G, I.ldg, u0 << 6, (u1 - u0) << 1, c0, n0, I.slab + (size_t)split * I.Kc * I.N, I.N,
+              I.colsum ? I.colsum + (size_t)split * I.N : nullptr);
 }
 
 #ifndef HUGS_GEMM_F16
@@ -1272,6 +1308,33 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ s
   *(float4*)(out + i) = a;
 }
 
+// The same reduction for a table of ranges (the weight and bias gradients of every item of a batched TN launch) in one launch.
+struct RedItem { const float* slab; float* out; unsigned long long per; unsigned blk0, pad_; };
+struct RedBatch { int nitems, nsplit; RedItem it[2 * HUGS_TN_BATCH_MAX]; };
+__global__ __launch_bounds__(256) void k_slab_reduce_batch(const RedBatch B) {
+  int k = 0;
+  while (k + 1 < B.nitems && blockIdx.x >= B.it[k + 1].blk0) ++k;
+  const RedItem& I = B.it[k];
+  const size_t per = I.per;
+  const size_t i = ((size_t)(blockIdx.x - I.blk0) * 256 + threadIdx.x) * 4;
+  if (i >= per) return;
+  const float* slab = I.slab;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  int s = 0;
+  for (; s + 4 <= B.nsplit; s += 4) {
+    f32x4_t b[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b[q] = __builtin_nontemporal_load((const f32x4_t*)(slab + (size_t)(s + q) * per + i));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { a.x += b[q][0]; a.y += b[q][1]; a.z += b[q][2]; a.w += b[q][3]; }
+  }
+  for (; s < B.nsplit; ++s) {
+    const f32x4_t b = __builtin_nontemporal_load((const f32x4_t*)(slab + (size_t)s * per + i));
+    a.x += b[0]; a.y += b[1]; a.z += b[2]; a.w += b[3];
+  }
+  *(float4*)(I.out + i) = a;
+}
+
 }  // namespace HUGS_GEMM_NS
 using namespace HUGS_GEMM_NS;
 
@@ -1423,7 +1486,91 @@ int HUGS_NT_IMPL(HUGS_NT_ARGS) {
   return 0;
 }
 
+// ---- batched TN (include/hugs.h hugs_gemm_tn_batch) ----
+struct HugsTnItem { const void* X; const void* G; float* dW; float* dbias; int ldx, ldg, Mrows, Kc, N, reserved; };
+#ifdef HUGS_GEMM_F16
+#define HUGS_TNB_IMPL hugs_gemm_tn_batch_impl_f16
+#else
+#define HUGS_TNB_IMPL hugs_gemm_tn_batch_impl_bf16
+#endif
+int hugs_gemm_tn_batch_impl_bf16(int nitems, const HugsTnItem* items, int nsplit, void* ws, void* stream);
+int hugs_gemm_tn_batch_impl_f16(int nitems, const HugsTnItem* items, int nsplit, void* ws, void* stream);
+int HUGS_TNB_IMPL(int nitems, const HugsTnItem* items, int nsplit, void* ws, void* stream) {
+  TnBatch B;
+  RedBatch R;
+  B.nitems = nitems; B.nsplit = nsplit;
+  R.nitems = 0; R.nsplit = nsplit;
+  float* w = (float*)ws;
+  int wg = 0;
+  unsigned blk = 0;
+  for (int i = 0; i < nitems; ++i) {
+    const HugsTnItem& h = items[i];
+    TnBatchItem& t = B.it[i];
+    t.X = (const uint16_t*)h.X; t.G = (const uint16_t*)h.G; t.ldx = h.ldx; t.ldg = h.ldg; t.Kc = h.Kc; t.N = h.N;
+    t.units = h.Mrows >> 6; t.wg0 = wg; t.tiles = (h.Kc >> 8) * (h.N >> 8); t.pad_ = 0;
+    t.slab = w; w += (size_t)nsplit * h.Kc * h.N;
+    t.colsum = nullptr;
+    if (h.dbias) { t.colsum = w; w += (size_t)nsplit * h.N; }
+    wg += t.tiles * nsplit;
+    RedItem& r = R.it[R.nitems++];
+    r.slab = t.slab; r.out = h.dW; r.per = (unsigned long long)h.Kc * h.N; r.blk0 = blk; r.pad_ = 0;
+    blk += (unsigned)((r.per / 4 + 255) / 256);
+    if (h.dbias) {
+      RedItem& q = R.it[R.nitems++];
+      q.slab = t.colsum; q.out = h.dbias; q.per = (unsigned long long)h.N; q.blk0 = blk; q.pad_ = 0;
+      blk += (unsigned)((q.per / 4 + 255) / 256);
+    }
+  }
+  hipLaunchKernelGGL(k_gemm_tn_bf16_batch, dim3(wg), dim3(512), 0, (hipStream_t)stream, B);
+  HUGS_CHECK_LAUNCH("hugs_gemm_tn_batch");
+  hipLaunchKernelGGL(k_slab_reduce_batch, dim3(blk), dim3(256), 0, (hipStream_t)stream, R);
+  HUGS_CHECK_LAUNCH("hugs_gemm_tn_batch(reduce)");
+  return 0;
+}
+
 #ifndef HUGS_GEMM_F16
+static int tn_batch_check(int dtype, int nitems, const HugsTnItem* items) {
+  HUGS_REQUIRE(dtype == 1 || dtype == 2, -2, "hugs_gemm_tn_batch: dtype must be 1 (bf16) or 2 (fp16), got %d", dtype);
+  HUGS_REQUIRE(items && nitems >= 1 && nitems <= HUGS_TN_BATCH_MAX, -3, "hugs_gemm_tn_batch: 1..%d items, got %d", HUGS_TN_BATCH_MAX, nitems);
+  for (int i = 0; i < nitems; ++i) {
+    const HugsTnItem& h = items[i];
+    HUGS_REQUIRE(h.X && h.G && h.dW && h.Kc > 0 && h.N > 0 && h.Kc % 256 == 0 && h.N % 256 == 0 && h.Mrows >= 512 && h.Mrows % 64 == 0 &&
+                     h.ldx % 8 == 0 && h.ldg % 8 == 0 && h.ldx >= h.Kc && h.ldg >= h.N, -3,
+                 "hugs_gemm_tn_batch: item %d: rows=%d Kc=%d N=%d ldx=%d ldg=%d (Kc, N multiples of 256; rows a multiple of 64, >= 512)", i,
+                 h.Mrows, h.Kc, h.N, h.ldx, h.ldg);
+  }
+  return 0;
+}
+// nsplit the launch would use for nsplit_request <= 0: #CUs / (total tiles), at least 1, at most rows/512 of the shortest item
+extern "C" int hugs_gemm_tn_batch_nsplit(int nitems, const HugsTnItem* items) {
+  if (!items || nitems < 1) return 1;
+  int dev = 0, ncu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) ncu = 256;
+  long long tiles = 0;
+  int cap = 1 << 30;
+  for (int i = 0; i < nitems; ++i) {
+    tiles += (long long)(items[i].Kc >> 8) * (items[i].N >> 8);
+    if (items[i].Mrows / 512 < cap) cap = items[i].Mrows / 512;
+  }
+  long long ns = tiles > 0 ? ncu / tiles : 1;
+  if (ns > cap) ns = cap;
+  return ns < 1 ? 1 : (int)ns;
+}
+extern "C" long long hugs_gemm_tn_batch_ws_bytes(int nitems, const HugsTnItem* items, int nsplit) {
+  long long n = 0;
+  for (int i = 0; i < nitems; ++i) n += (long long)nsplit * ((long long)items[i].Kc * items[i].N + items[i].N);
+  return n * 4;
+}
+extern "C" int hugs_gemm_tn_batch(int dtype, int nitems, const HugsTnItem* items, int nsplit, void* ws, void* stream) {
+  if (int rc = tn_batch_check(dtype, nitems, items)) return rc;
+  HUGS_REQUIRE(ws && nsplit >= 1, -3, "hugs_gemm_tn_batch: nsplit %d (use hugs_gemm_tn_batch_nsplit), ws %p", nsplit, ws);
+  for (int i = 0; i < nitems; ++i)
+    HUGS_REQUIRE(items[i].Mrows / nsplit >= 512, -3, "hugs_gemm_tn_batch: item %d: %d rows in %d pieces: fewer than 512 rows per piece", i,
+                 items[i].Mrows, nsplit);
+  return dtype == 2 ? hugs_gemm_tn_batch_impl_f16(nitems, items, nsplit, ws, stream)
+                    : hugs_gemm_tn_batch_impl_bf16(nitems, items, nsplit, ws, stream);
+}
+
 extern "C" long long hugs_gemm_tn_ws_bytes(int Kc, int N, int nsplit) {
   return (long long)nsplit * ((long long)Kc * N + N) * 4;
 }

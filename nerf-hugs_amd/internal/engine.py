@@ -13,6 +13,12 @@ from . import stepfun
 
 CHUNK = 16384
 _USE_BITS = __import__('os').environ.get('HUGS_RELU_BITS', '1') != '0'        # A/B knob: 1-bit relu masks for the dX GEMMs
+# Trunk weight gradients (A/B switch): 0 = one hugs_gemm_tn per layer next to the dX chain (rounds 1-3), 1 (default) = ONE
+# batched launch of all layers after the dX chain, 2 = two batched launches (upper half of the layers under the lower half's
+# dX GEMMs, the rest after the chain)
+_TN_BATCH = int(__import__('os').environ.get('HUGS_TN_BATCH', '1'))
+_TN_ITEM = np.dtype([('X', np.uint64), ('G', np.uint64), ('dW', np.uint64), ('db', np.uint64), ('ldx', np.int32), ('ldg', np.int32),
+                     ('Mrows', np.int32), ('Kc', np.int32), ('N', np.int32), ('reserved', np.int32)])      # include/hugs.h HugsTnItem
 _CHUNK_BYTES = int(float(__import__('os').environ.get('HUGS_FWD_CHUNK_MB', '1e9')) * 1e6)   # forward row-chunk size (A/B knob)
 
 
@@ -536,6 +542,31 @@ class Engine:
     slab = self.ws.get(f'tn_slab/{torch.cuda.current_stream().cuda_stream}', (max(nbytes // 4, 1),))
     _lib.call('hugs_gemm_tn', self.dt, M, Kc, Nn, ns, X, ldx, G, ldg, dW, db, slab)
 
+  def _tn_batch(self, items):
+    """hugs_gemm_tn_batch: items = [(Mrows, Kc, N, X, ldx, G, ldg, dW, dbias or None)], one launch + one reduce."""
+    key = tuple((it[0], it[1], it[2], it[3].data_ptr(), it[4], it[5].data_ptr(), it[6], it[7].data_ptr(),
+                 0 if it[8] is None else it[8].data_ptr()) for it in items)
+    cache = self.ws.bufs.setdefault('tn_batch_tables', {})
+    ent = cache.get(key)
+    if ent is None:
+      arr = np.zeros(len(items), _TN_ITEM)
+      for k, (Mr, Kc, Nn, X, ldx, G, ldg, dW, db) in enumerate(key):
+        arr[k] = (X, G, dW, db, ldx, ldg, Mr, Kc, Nn, 0)
+      ns = int(_lib.lib().cdll.hugs_gemm_tn_batch_nsplit(len(items), __import__('ctypes').c_void_p(arr.ctypes.data)))
+      nbytes = int(_lib.lib().cdll.hugs_gemm_tn_batch_ws_bytes(len(items), arr.ctypes.data, ns))
+      ent = cache[key] = (arr, ns, nbytes)
+    arr, ns, nbytes = ent
+    slab = self.ws.get(f'tn_slab/{torch.cuda.current_stream().cuda_stream}', (max(nbytes // 4, 1),))
+    if _lib.PROFILE is not None:      # bench.py's in-step timing: (kind, total flops, items, pieces, tag)
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record()
+      _lib.call('hugs_gemm_tn_batch', self.dt, len(items), arr.ctypes.data, ns, slab)
+      e1.record()
+      _lib.PROFILE.append(('hugs_gemm_tn_batch', ('tnb', sum(2.0 * it[0] * it[1] * it[2] for it in items), len(items), ns,
+                                                  f'items{len(items)}_split{ns}'), e0, e1))
+      return
+    _lib.call('hugs_gemm_tn_batch', self.dt, len(items), arr.ctypes.data, ns, slab)
+
   def _rgb_head(self, theta, spec, layer, tag, padded=False):
     """(W, b) the rgb head kernels see: rgb = sigmoid(premultiplier (h W + b) + rgb_bias) (models.py:514-516, :534-536) is
     sigmoid(h (p W) + (p b + rgb_bias)); the kernels' weight / bias gradients are then those of (p W, p b + r): times p."""
@@ -686,6 +717,63 @@ class Engine:
     # layer boundary was a ~40 us bubble (dX_{i-1} waited for dW_i to release the buffer it writes).
     main = torch.cuda.current_stream()
     side = self._side_stream(lane)
+    depth = spec.net_depth
+    trunk = spec.layers[:depth]
+    nitem = depth + sum(1 for l in trunk if l['concat'])
+    if (_TN_BATCH > 0 and dt and W % 256 == 0 and spec.Fp % 256 == 0 and M >= 2048 and M % 64 == 0 and nitem <= 16 and
+        all(l['concat'] or l['kpad'] % 256 == 0 for l in trunk)):
+      # Round 4: the dX chain runs alone on the main stream (every G_i keeps its own buffer) and the weight gradients of the
+      # layers leave as batched launches (hugs_gemm_tn_batch): next to each other the two kernels of a layer took 430 + 270 us
+      # for 250 + 200 us of work alone (profiles/r03_step_timeline.txt), and one launch over all layers cuts the reduction
+      # into #CUs / 128 tiles = 2 pieces instead of 16 per layer.
+      # (two launches -- the upper half under the lower half's dX GEMMs -- measured: 6.80 ms against 6.61 for one launch and
+      # 6.83 for the per-layer form, same box: what is lost is the concurrency itself.  The data-parallel step therefore keeps
+      # ONE launch as well and releases the whole trunk's gradient range to its all-reduce behind it.)
+      two = _TN_BATCH == 2
+      cuts = [depth // 2, 0] if (two and depth >= 2) else [0]
+      Gs = [Ga, Gb] + [ws.get(f'{tag}/G{k}', (M, W), self.tdt) for k in range(2, depth)]
+      g_of, hi = {}, depth - 1
+      done = []
+      for i in range(depth - 1, -1, -1):
+        l = trunk[i]
+        path = (spec.name, l['name'], 'kernel')
+        G = Gs[depth - 1 - i]
+        g_of[i] = G
+        if i in cuts:          # G_hi .. G_i are final: their weight gradients go out as one launch on the side stream
+          ev = torch.cuda.Event(); ev.record(main)
+          with torch.cuda.stream(side):
+            side.wait_event(ev)
+            items = []
+            for j in range(hi, i - 1, -1):
+              lj = trunk[j]
+              gW = gview((spec.name, lj['name'], 'kernel'), padded=True)
+              gb = gview((spec.name, lj['name'], 'bias'), True)
+              if lj['concat']:
+                items.append((M, W, W, acts[j], W, g_of[j], W, gW[:W], gb))
+                items.append((M, spec.Fp, W, X0, spec.Fp, g_of[j], W, gW[W:], None))
+              else:
+                items.append((M, lj['kpad'], W, acts[j], lj['kpad'], g_of[j], W, gW, gb))
+            self._tn_batch(items)
+            e = torch.cuda.Event(); e.record(side)
+            done.append(e)
+            if leaf_done is not None:
+              lk = lay.by_path[(spec.name, trunk[i]['name'], 'kernel')]
+              lb_ = lay.by_path[(spec.name, trunk[hi]['name'], 'bias')]
+              leaf_done(lk['off'], lb_['off'] + int(np.prod(lb_['pshape'])))
+          hi = i - 1
+        if i > 0:
+          bprev = lv['bits'][i - 1] if lv.get('bits') else None
+          Wn_ = self.wn[path][:W] if l['concat'] else self.wn[path]
+          if bprev is not None:
+            _lib.call('hugs_gemm_nt_bits', dt, M, W, W, 0, G, W, None, 0, Wn_, W, None, 0, None, None, Gs[depth - i], W, None, bprev)
+          else:
+            _lib.call('hugs_gemm_nt', dt, M, W, W, 0, G, W, None, 0, Wn_, W, None, None, 1, 0, 0, acts[i], W, None, None,
+                      Gs[depth - i], W)
+      for e in done:
+        main.wait_event(e)
+      if not spec.disable_rgb and spec.use_viewdirs:
+        main.wait_event(heads_done)
+      return
     Gc = ws.get(tag + '/Gc', (M, W), self.tdt)
     Gd = ws.get(tag + '/Gd', (M, W), self.tdt)
     ring = [Ga, Gb, Gc, Gd]
@@ -840,6 +928,8 @@ class Engine:
     if lane not in self._side:
       import os
       # HUGS_SINGLE_STREAM=1 (measurement hook): everything stays on the compute stream
-      self._side[lane] = (torch.cuda.current_stream() if os.environ.get('HUGS_SINGLE_STREAM') == '1'
-                          else torch.cuda.Stream(device=self.device))
+      # HUGS_SIDE_LANES=0,3 (measurement hook): only the listed lanes get a stream of their own
+      lanes = os.environ.get('HUGS_SIDE_LANES')
+      single = os.environ.get('HUGS_SINGLE_STREAM') == '1' or (lanes is not None and str(lane) not in lanes.split(','))
+      self._side[lane] = torch.cuda.current_stream() if single else torch.cuda.Stream(device=self.device)
     return self._side[lane]

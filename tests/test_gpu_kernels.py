@@ -407,3 +407,50 @@ def test_gemm_ring_kernels_over_stage_counts(shape):
   L.call('hugs_gemm_nt', 1, M, N, K1, K2, A1, K1, A2, K2, Bt, K1 + K2, None, None, 1, 0, 0, mk, N, None, None, out, N)
   ref = (A.double() @ Bt.double().T) * (mk.double() > 0)
   assert float((out.double() - ref).abs().max()) < 2e-2 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+def test_gemm_tn_batch_vs_matmul(dtype):
+  """hugs_gemm_tn_batch (round 4: the weight gradients of several layers in one launch, reduction rows cut into #CUs / tiles
+  uneven pieces): every item against the float64 product of the same 16-bit operands, bias gradients included, for piece
+  counts that do not divide the row units, and bit-identical between two runs (fixed partition, fixed summation order)."""
+  import ctypes
+  from nerf_hugs_amd import _lib
+  from nerf_hugs_amd.internal import engine as E
+  td = torch.bfloat16 if dtype == 'bf16' else torch.float16
+  dt = 1 if dtype == 'bf16' else 2
+  g = torch.Generator(device='cuda').manual_seed(5)
+  shapes = [(4096, 256, 256, True), (4096, 512, 256, False), (8192 + 64 * 3, 256, 512, True), (4096, 1024, 256, True)]
+  Xs, Gs, dWs, dbs = [], [], [], []
+  for (M, Kc, N, hb) in shapes:
+    ldx, ldg = Kc + 64, N            # a leading dimension wider than the panel (the skip layer reads a window of [W | Fp])
+    Xs.append((torch.randn(M, ldx, generator=g, device='cuda') * 0.5).to(td))
+    Gs.append((torch.randn(M, ldg, generator=g, device='cuda') * 0.5).to(td))
+    dWs.append(torch.empty(Kc, N, device='cuda'))
+    dbs.append(torch.empty(N, device='cuda') if hb else None)
+  arr = np.zeros(len(shapes), E._TN_ITEM)
+  for k, (M, Kc, N, hb) in enumerate(shapes):
+    arr[k] = (Xs[k].data_ptr(), Gs[k].data_ptr(), dWs[k].data_ptr(), dbs[k].data_ptr() if hb else 0, Xs[k].shape[1], Gs[k].shape[1], M, Kc, N, 0)
+  lib = _lib.lib().cdll
+  auto = int(lib.hugs_gemm_tn_batch_nsplit(len(shapes), ctypes.c_void_p(arr.ctypes.data)))
+  assert auto == 256 // (1 + 2 + 2 + 4) or auto >= 1
+  for ns in (auto, 7, 1, 8):
+    ws = torch.empty(int(lib.hugs_gemm_tn_batch_ws_bytes(len(shapes), arr.ctypes.data, ns)) // 4, device='cuda')
+    outs = []
+    for rep in range(2):
+      for t in dWs + [d for d in dbs if d is not None]:
+        t.fill_(float('nan'))
+      _lib.call('hugs_gemm_tn_batch', dt, len(shapes), arr.ctypes.data, ns, ws)
+      torch.cuda.synchronize()
+      outs.append([t.clone() for t in dWs] + [d.clone() for d in dbs if d is not None])
+    for a, b in zip(*outs):
+      assert torch.equal(a, b), 'two runs differ'
+    for k, (M, Kc, N, hb) in enumerate(shapes):
+      ref = Xs[k][:, :Kc].double().T @ Gs[k].double()
+      err = float((dWs[k].double() - ref).abs().max() / ref.abs().max())
+      assert err < 2e-5, (ns, k, err)
+      if hb:
+        rb = Gs[k].double().sum(0)
+        assert float((dbs[k].double() - rb).abs().max() / rb.abs().max()) < 2e-5, (ns, k)
+  with pytest.raises(_lib.HugsError):      # fewer than 512 rows per piece
+    _lib.call('hugs_gemm_tn_batch', dt, len(shapes), arr.ctypes.data, 9, ws)
