@@ -320,6 +320,8 @@ def main():
   args = ap.parse_args()
   if args.dtype is None:
     args.dtype = 'fp16' if args.config == 'cfg5' else 'bf16'
+  if args.step_graph is not None:      # (read when nerf_hugs_amd.internal.train_utils is imported)
+    os.environ['HUGS_STEP_GRAPH'] = args.step_graph
   if args.dtype == 'fp16' and args.config != 'cfg5':
     ap.error('fp16 is the nerfacto path (cfg5) mode; the Mip-NeRF 360 path runs bf16 or fp32')
   import torch.distributed as dist
@@ -343,8 +345,6 @@ def main():
     return bench_nerfacto(args, device, world, rank)
   from nerf_hugs_amd.internal import configs, train_utils
   configs.clear_config()
-  if args.step_graph is not None:
-    os.environ['HUGS_STEP_GRAPH'] = args.step_graph
   # the CPU baseline runs FIRST (it used to run last: the driver's 5-s SMI poll then saw 12 s of idle GPU next to 2 s of work)
   cpu_base = None
   if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 'cfg2' and args.rays_per_gpu is None:

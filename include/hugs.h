@@ -44,6 +44,12 @@ int hugs_level_sample_fwd(int nrays, const float* t_prev, const float* w_prev, i
                           const float* u_base, const float* jitter, int jitter_stride, int num_samples, int raydist,
                           int sum_order, const float* near, const float* far, float* sdist, float* tdist, int32_t* idx_out,
                           float* t_in_out, float* w_in_out, void* stream);
+/* The same launch with `anneal` read from device memory (no test hooks): the form a captured (hipGraph) train step uses, whose
+ * per-step scalars must not be baked into kernel arguments. */
+int hugs_level_sample_fwd_dyn(int nrays, const float* t_prev, const float* w_prev, int n_prev, int do_dilate,
+                              float dilation, float domain_lo, float domain_hi, const float* anneal_dev, float resample_padding,
+                              const float* u_base, const float* jitter, int jitter_stride, int num_samples, int raydist,
+                              int sum_order, const float* near, const float* far, float* sdist, float* tdist, void* stream);
 
 /* render.py:103-127 cast_rays (cone :44-78 / cylinder :81-100, lift_gaussian :21-41 diag=False) ->
  * coord.py:21-27,39-60 contract + track_linearize (closed-form Jacobian) -> coord.py:129-133
@@ -172,6 +178,12 @@ int hugs_opt_adam(int nchunks, int nleaf, const void* chunks, const void* leaf_i
                   float* m, float* v, const float* mod_scale, const int* trainable, float gscale, float max_val,
                   float lr, float b1, float b2, float eps, float bias_corr1, float bias_corr2, float* part2_ws,
                   float* leaf_upd, void* stream);
+/* hugs_opt_adam with {lr, bias_corr1, bias_corr2} read from 3 device floats, and the launch that writes up to 4 such per-step
+ * scalars from its kernel arguments: together they let the train step be replayed as a captured hipGraph. */
+int hugs_opt_adam_dyn(int nchunks, int nleaf, const void* chunks, const void* leaf_info, float* theta, const float* grad,
+                      float* m, float* v, const float* mod_scale, const int* trainable, float gscale, float max_val,
+                      const float* dyn, float b1, float b2, float eps, float* part2_ws, float* leaf_upd, void* stream);
+int hugs_set_floats(float* dst, int n, float a, float b, float c, float d, void* stream);
 /* fp32 master [K,N] -> compute-dtype copies Wn [K,N] and Wt [N,K] (either may be NULL) */
 int hugs_cast_weights(int dtype, int K, int N, const float* W, void* Wn, void* Wt, void* stream);
 /* The same cast for a device table of matrices in one launch.  items: nitems records of 40 bytes

@@ -41,6 +41,9 @@ _PROTOS = {
     'hugs_axpy': 'qfpps',
     'hugs_opt_stats': 'iiippppfffppps',
     'hugs_opt_adam': 'iippppppppffffffffpps',
+    'hugs_opt_adam_dyn': 'iippppppppffpfffpps',
+    'hugs_set_floats': 'piffffs',
+    'hugs_level_sample_fwd_dyn': 'ippiifffpfppiiiipppps',
     'hugs_cast_weights': 'iiippps',
     'hugs_cast_weights_batch': 'iipis',
     'hugs_pixels_to_rays': 'ipppipppipippppppps',

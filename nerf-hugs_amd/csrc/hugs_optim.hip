@@ -86,8 +86,9 @@ __global__ __launch_bounds__(256) void k_opt_adam(const OptChunk* __restrict__ c
                                                   float* __restrict__ v, const float* __restrict__ mod_scale,
                                                   const int* __restrict__ trainable, float gscale, float max_val,
                                                   float lr, float b1, float b2, float eps, float bc1, float bc2,
-                                                  float* __restrict__ part2) {
+                                                  float* __restrict__ part2, const float* __restrict__ dyn) {
   __shared__ float red[4];
+  if (dyn) { lr = dyn[0]; bc1 = dyn[1]; bc2 = dyn[2]; }      // hugs_opt_adam_dyn: the step's scalars from device memory
   const OptChunk c = chunks[blockIdx.x];
   float sd = 0.f, md = 0.f;
   if (!trainable || trainable[c.leaf]) {
@@ -207,15 +208,42 @@ extern "C" int hugs_opt_stats(int nchunks, int nleaf, int nmod, const void* chun
   return 0;
 }
 
+static int opt_adam_impl(int nchunks, int nleaf, const void* chunks, const void* leaf_info, float* theta, const float* grad, float* m, float* v,
+                         const float* mod_scale, const int* trainable, float gscale, float max_val, float lr, float b1,
+                         float b2, float eps, float bias_corr1, float bias_corr2, float* part2_ws, float* leaf_upd,
+                         const float* dyn, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_opt_adam, dim3(nchunks), dim3(256), 0, st, (const OptChunk*)chunks, theta, grad, m, v, mod_scale,
+                     trainable, gscale, max_val, lr, b1, b2, eps, bias_corr1, bias_corr2, part2_ws, dyn);
+  hipLaunchKernelGGL(k_opt_finalize2, dim3(1), dim3(256), 0, st, nleaf, (const int4*)leaf_info, part2_ws, leaf_upd);
+  HUGS_CHECK_LAUNCH("hugs_opt_adam");
+  return 0;
+}
 extern "C" int hugs_opt_adam(int nchunks, int nleaf, const void* chunks, const void* leaf_info, float* theta, const float* grad, float* m, float* v,
                              const float* mod_scale, const int* trainable, float gscale, float max_val, float lr, float b1,
                              float b2, float eps, float bias_corr1, float bias_corr2, float* part2_ws, float* leaf_upd,
                              void* stream) {
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_opt_adam, dim3(nchunks), dim3(256), 0, st, (const OptChunk*)chunks, theta, grad, m, v, mod_scale,
-                     trainable, gscale, max_val, lr, b1, b2, eps, bias_corr1, bias_corr2, part2_ws);
-  hipLaunchKernelGGL(k_opt_finalize2, dim3(1), dim3(256), 0, st, nleaf, (const int4*)leaf_info, part2_ws, leaf_upd);
-  HUGS_CHECK_LAUNCH("hugs_opt_adam");
+  return opt_adam_impl(nchunks, nleaf, chunks, leaf_info, theta, grad, m, v, mod_scale, trainable, gscale, max_val, lr, b1, b2, eps,
+                       bias_corr1, bias_corr2, part2_ws, leaf_upd, nullptr, stream);
+}
+// dyn: 3 device floats {lr, bias_corr1, bias_corr2}: the per-step scalars of a captured (hipGraph) train step
+extern "C" int hugs_opt_adam_dyn(int nchunks, int nleaf, const void* chunks, const void* leaf_info, float* theta, const float* grad, float* m,
+                                 float* v, const float* mod_scale, const int* trainable, float gscale, float max_val, const float* dyn,
+                                 float b1, float b2, float eps, float* part2_ws, float* leaf_upd, void* stream) {
+  HUGS_REQUIRE(dyn, -2, "hugs_opt_adam_dyn: dyn is null");
+  return opt_adam_impl(nchunks, nleaf, chunks, leaf_info, theta, grad, m, v, mod_scale, trainable, gscale, max_val, 0.f, b1, b2, eps, 1.f,
+                       1.f, part2_ws, leaf_upd, dyn, stream);
+}
+__global__ void k_set_floats(float* dst, int n, float a, float b, float c, float d) {
+  const float v[4] = {a, b, c, d};
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = v[threadIdx.x];
+}
+// dst[0..n) = {a, b, c, d}[0..n), n <= 4: per-step scalars enter a captured step through the kernel arguments of this launch
+extern "C" int hugs_set_floats(float* dst, int n, float a, float b, float c, float d, void* stream) {
+  HUGS_REQUIRE(dst && n >= 0 && n <= 4, -2, "hugs_set_floats: n=%d outside 0..4", n);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_set_floats, dim3(1), dim3(64), 0, (hipStream_t)stream, dst, n, a, b, c, d);
+  HUGS_CHECK_LAUNCH("hugs_set_floats");
   return 0;
 }
 

@@ -156,8 +156,9 @@ __global__ __launch_bounds__(256) void k_level_sample(
     float dilation, float dlo, float dhi, float anneal, float pad, const float* __restrict__ u_base,
     const float* __restrict__ jitter, int jitter_stride, int ns, int raydist, const float* __restrict__ near,
     const float* __restrict__ far, float* __restrict__ sdist, float* __restrict__ tdist, int32_t* __restrict__ idx_out,
-    float* __restrict__ t_in_out, float* __restrict__ w_in_out) {
+    float* __restrict__ t_in_out, float* __restrict__ w_in_out, const float* __restrict__ anneal_dev) {
   __shared__ SfLds<C> lds[4];
+  if (anneal_dev) anneal = *anneal_dev;      // hugs_level_sample_fwd_dyn: the per-step value lives in device memory (captured step)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ray = blockIdx.x * 4 + wv;
   const bool live = ray < nrays;
@@ -333,12 +334,12 @@ __global__ void k_explog(const float* x, int n, float* ye, float* yl) {
   if (i < n) { ye[i] = sf_expf(x[i]); yl[i] = sf_logf(x[i]); }
 }
 
-extern "C" int hugs_level_sample_fwd(int nrays, const float* t_prev, const float* w_prev, int n_prev, int do_dilate,
-                                     float dilation, float domain_lo, float domain_hi, float anneal,
-                                     float resample_padding, const float* u_base, const float* jitter,
-                                     int jitter_stride, int num_samples, int raydist, int sum_order, const float* near,
-                                     const float* far, float* sdist, float* tdist, int32_t* idx_out,
-                                     float* t_in_out, float* w_in_out, void* stream) {
+static int level_sample_impl(int nrays, const float* t_prev, const float* w_prev, int n_prev, int do_dilate,
+                             float dilation, float domain_lo, float domain_hi, float anneal,
+                             float resample_padding, const float* u_base, const float* jitter,
+                             int jitter_stride, int num_samples, int raydist, int sum_order, const float* near,
+                             const float* far, float* sdist, float* tdist, int32_t* idx_out,
+                             float* t_in_out, float* w_in_out, const float* anneal_dev, void* stream) {
   HUGS_REQUIRE(num_samples > 1, -2, "num_samples must be > 1, is %d.", num_samples);
   HUGS_REQUIRE(num_samples <= SF_CAP, -3, "hugs_level_sample_fwd: num_samples %d > capacity %d", num_samples, SF_CAP);
   int n_in = do_dilate ? 3 * n_prev : n_prev;
@@ -351,13 +352,33 @@ extern "C" int hugs_level_sample_fwd(int nrays, const float* t_prev, const float
   const int big = n_in > num_samples ? n_in : num_samples;
 #define HUGS_LS_LAUNCH(C_, O_) hipLaunchKernelGGL((k_level_sample<C_, O_>), dim3((nrays + 3) / 4), dim3(256), 0, (hipStream_t)stream, nrays, \
     t_prev, w_prev, n_prev, do_dilate, dilation, domain_lo, domain_hi, anneal, resample_padding, u_base, jitter, jitter_stride, \
-    num_samples, raydist, near, far, sdist, tdist, idx_out, t_in_out, w_in_out)
+    num_samples, raydist, near, far, sdist, tdist, idx_out, t_in_out, w_in_out, anneal_dev)
   if (big <= 256) { if (sum_order) HUGS_LS_LAUNCH(4, 1); else HUGS_LS_LAUNCH(4, 0); }
   else if (big <= 512) { if (sum_order) HUGS_LS_LAUNCH(8, 1); else HUGS_LS_LAUNCH(8, 0); }
   else { if (sum_order) HUGS_LS_LAUNCH(16, 1); else HUGS_LS_LAUNCH(16, 0); }      // 256 samples per level dilate to 766 bins
 #undef HUGS_LS_LAUNCH
   HUGS_CHECK_LAUNCH("hugs_level_sample_fwd");
   return 0;
+}
+extern "C" int hugs_level_sample_fwd(int nrays, const float* t_prev, const float* w_prev, int n_prev, int do_dilate,
+                                     float dilation, float domain_lo, float domain_hi, float anneal,
+                                     float resample_padding, const float* u_base, const float* jitter,
+                                     int jitter_stride, int num_samples, int raydist, int sum_order, const float* near,
+                                     const float* far, float* sdist, float* tdist, int32_t* idx_out,
+                                     float* t_in_out, float* w_in_out, void* stream) {
+  return level_sample_impl(nrays, t_prev, w_prev, n_prev, do_dilate, dilation, domain_lo, domain_hi, anneal, resample_padding, u_base,
+                           jitter, jitter_stride, num_samples, raydist, sum_order, near, far, sdist, tdist, idx_out, t_in_out, w_in_out,
+                           nullptr, stream);
+}
+extern "C" int hugs_level_sample_fwd_dyn(int nrays, const float* t_prev, const float* w_prev, int n_prev, int do_dilate,
+                                         float dilation, float domain_lo, float domain_hi, const float* anneal_dev,
+                                         float resample_padding, const float* u_base, const float* jitter,
+                                         int jitter_stride, int num_samples, int raydist, int sum_order, const float* near,
+                                         const float* far, float* sdist, float* tdist, void* stream) {
+  HUGS_REQUIRE(anneal_dev, -2, "hugs_level_sample_fwd_dyn: anneal_dev is null");
+  return level_sample_impl(nrays, t_prev, w_prev, n_prev, do_dilate, dilation, domain_lo, domain_hi, 0.f, resample_padding, u_base,
+                           jitter, jitter_stride, num_samples, raydist, sum_order, near, far, sdist, tdist, nullptr, nullptr, nullptr,
+                           anneal_dev, stream);
 }
 
 __global__ void k_arith(const float* a, const float* b, int n, float* o) {

@@ -22,6 +22,16 @@ _TN_ITEM = np.dtype([('X', np.uint64), ('G', np.uint64), ('dW', np.uint64), ('db
 _CHUNK_BYTES = int(float(__import__('os').environ.get('HUGS_FWD_CHUNK_MB', '1e9')) * 1e6)   # forward row-chunk size (A/B knob)
 
 
+KEEP_EVENTS = None      # a list while a train step is being captured into a hipGraph: its events must outlive the capture
+
+
+def new_event():
+  e = torch.cuda.Event()
+  if KEEP_EVENTS is not None:
+    KEEP_EVENTS.append(e)
+  return e
+
+
 def _round_up(x, m):
   return (x + m - 1) // m * m
 
@@ -440,7 +450,7 @@ class Engine:
         out.update(tacts=tacts, raw_t=raw_t, dens_t=dens_t, rgb_t=rgb_t, raw_u=raw_u, unc=unc, tra=tra)
     return out
 
-  def forward(self, theta, rays, train_frac, u01, compute_extras, zero_glo=False, zero_tra=False, n_real=None):
+  def forward(self, theta, rays, train_frac, u01, compute_extras, zero_glo=False, zero_tra=False, n_real=None, anneal_dev=None):
     """Model.__call__ (models.py:74-330).  rays: dict of contiguous [N,c] cuda tensors (+ 'dir_enc').
     u01: None, a list[num_levels] of U[0,1) draws, or a stepfun.Jitter list of scaled draws.  Returns per-level dicts (device tensors; buffers are
     reused by the next call)."""
@@ -483,10 +493,10 @@ class Engine:
       dilation = mdl.dilation_bias + mdl.dilation_multiplier * (init_s_far - init_s_near) / prod
       prod *= S
       use_dilation = mdl.dilation_bias > 0 or mdl.dilation_multiplier > 0
-      if mdl.anneal_slope > 0:
-        anneal = (mdl.anneal_slope * train_frac) / ((mdl.anneal_slope - 1) * train_frac + 1)
+      if anneal_dev is not None:      # captured step: the value anneal_factor() gives for this step, in device memory
+        anneal = anneal_dev
       else:
-        anneal = 1.
+        anneal = self.anneal_factor(train_frac)
       draw = None if u01 is None else u01[lvl]
       scaled = getattr(u01, 'scaled', False)     # stepfun.Jitter: draws already in [0, max_jitter)
       sd, td = stepfun.level_sample(sdist, weights, lvl > 0 and use_dilation, dilation, (init_s_near, init_s_far), anneal,
@@ -525,6 +535,13 @@ class Engine:
       levels.append(out)
       sdist, weights = sd, w
     return levels
+
+  def anneal_factor(self, train_frac):
+    """models.py:185-190: the annealing exponent of the resampling logits at this point of training."""
+    mdl = self.model
+    if mdl.anneal_slope > 0:
+      return (mdl.anneal_slope * train_frac) / ((mdl.anneal_slope - 1) * train_frac + 1)
+    return 1.
 
   # ---- backward -----------------------------------------------------------------------------------
   def _tn(self, M, Kc, Nn, X, ldx, G, ldg, dW, db):
@@ -667,7 +684,7 @@ class Engine:
       # underneath the trunk GEMMs.
       cur = torch.cuda.current_stream()
       hl = self._side_stream(lane + 3)
-      ev_gv = torch.cuda.Event(); ev_gv.record(cur)
+      ev_gv = new_event(); ev_gv.record(cur)
       with torch.cuda.stream(hl):
         hl.wait_event(ev_gv)
         _lib.call('hugs_density_bwd', dt, M, W, Ylast, W, None, lv['raw'], spec.density_bias, d_raw,
@@ -687,7 +704,7 @@ class Engine:
         # dBott = Gv Wv[:Bw]^T
         _lib.call('hugs_gemm_nt', dt, M, Bw, H, 0, Gv, H, None, 0, self.wn[(spec.name, lvw['name'], 'kernel')], H, None,
                   None, 1, 0, 0, None, 0, None, None, dB, Bw)
-      ev_db = torch.cuda.Event(); ev_db.record(cur)
+      ev_db = new_event(); ev_db.record(cur)
       with torch.cuda.stream(hl):
         hl.wait_event(ev_db)
         self._tn(M, W, Bw, Ylast, W, dB, Bw, gview((spec.name, lb['name'], 'kernel'), True), gview((spec.name, lb['name'], 'bias')))
@@ -695,7 +712,7 @@ class Engine:
           first = lay.by_path[(spec.name, spec.layers[spec.net_depth]['name'], 'kernel')]
           last = lay.by_path[(spec.name, spec.layers[-1]['name'], 'bias')]
           leaf_done(first['off'], last['off'] + int(np.prod(last['pshape'])))
-        heads_done = torch.cuda.Event(); heads_done.record(hl)
+        heads_done = new_event(); heads_done.record(hl)
       # G_last = (dBott Wb^T + d_raw (x) w_d) * (Ylast > 0)
       blast = lv['bits'][spec.net_depth - 1] if lv.get('bits') else None
       if blast is not None and Bw >= 256:
@@ -740,7 +757,7 @@ class Engine:
         G = Gs[depth - 1 - i]
         g_of[i] = G
         if i in cuts:          # G_hi .. G_i are final: their weight gradients go out as one launch on the side stream
-          ev = torch.cuda.Event(); ev.record(main)
+          ev = new_event(); ev.record(main)
           with torch.cuda.stream(side):
             side.wait_event(ev)
             items = []
@@ -754,7 +771,7 @@ class Engine:
               else:
                 items.append((M, lj['kpad'], W, acts[j], lj['kpad'], g_of[j], W, gW, gb))
             self._tn_batch(items)
-            e = torch.cuda.Event(); e.record(side)
+            e = new_event(); e.record(side)
             done.append(e)
             if leaf_done is not None:
               lk = lay.by_path[(spec.name, trunk[i]['name'], 'kernel')]
@@ -778,7 +795,7 @@ class Engine:
     Gd = ws.get(tag + '/Gd', (M, W), self.tdt)
     ring = [Ga, Gb, Gc, Gd]
     gi = 0
-    ev_g = torch.cuda.Event()
+    ev_g = new_event()
     ev_g.record(main)
     tn_done = {}
     for i in range(spec.net_depth - 1, -1, -1):
@@ -794,7 +811,7 @@ class Engine:
           self._tn(M, spec.Fp, W, X0, spec.Fp, G, W, gW[W:], None)
         else:
           self._tn(M, l['kpad'], W, xin, l['kpad'], G, W, gW, gb)
-        e = torch.cuda.Event()
+        e = new_event()
         e.record(side)
         tn_done[gi] = e
         if leaf_done is not None:
@@ -812,7 +829,7 @@ class Engine:
         else:
           _lib.call('hugs_gemm_nt', dt, M, W, W, 0, G, W, None, 0, self.wn[path][:W] if l['concat'] else self.wn[path], W, None,
                     None, 1, 0, 0, acts[i], W, None, None, ring[nxt], W)
-        ev_g = torch.cuda.Event()
+        ev_g = new_event()
         ev_g.record(main)
         G, gi = ring[nxt], nxt
     for e in tn_done.values():
@@ -923,6 +940,8 @@ class Engine:
   def _side_stream(self, lane=0):
     """HIP streams next to the caller's: lane 0 carries the weight-gradient GEMMs of the NerfMLP backward (and the
     HA-NeRF mask MLP), lane 1 the whole proposal-level backward, lane 2 its weight-gradient GEMMs."""
+    if getattr(self, 'single_stream', False):      # a step being captured into a hipGraph: everything on the capture stream
+      return torch.cuda.current_stream()
     if not hasattr(self, '_side'):
       self._side = {}
     if lane not in self._side:

@@ -93,6 +93,13 @@ def level_sample(t_prev, w_prev, do_dilate, dilation, domain, anneal, resample_p
   if rd is None:
     raise NotImplementedError(f"raydist_fn {raydist!r}: coord.py:78-90 knows None, 'piecewise' and jnp.reciprocal / log / exp / "
                               "sqrt / square")
+  if torch.is_tensor(anneal):      # a captured train step: the annealing factor is a device scalar (train_utils._GraphStep)
+    if return_debug:
+      raise ValueError('level_sample: the debug outputs are not available with a device-resident anneal')
+    _lib.call('hugs_level_sample_fwd_dyn', N, t_prev.contiguous(), w_prev.contiguous(), n_prev, int(do_dilate), dilation,
+              domain[0], domain[1], anneal, resample_padding, ub, jitter, stride, num_samples, rd,
+              SUM_ORDER if sum_order is None else int(sum_order), near.reshape(-1).contiguous(), far.reshape(-1).contiguous(), sdist, tdist)
+    return sdist, tdist
   _lib.call('hugs_level_sample_fwd', N, t_prev.contiguous(), w_prev.contiguous(), n_prev, int(do_dilate), dilation,
             domain[0], domain[1], anneal, resample_padding, ub, jitter, stride, num_samples, rd,
             SUM_ORDER if sum_order is None else int(sum_order), near.reshape(-1).contiguous(), far.reshape(-1).contiguous(), sdist, tdist, idx, t_in, w_in)

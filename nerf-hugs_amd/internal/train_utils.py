@@ -12,6 +12,7 @@ import torch
 import torch.distributed as dist
 
 from .. import _lib
+from . import engine as _engine
 from . import image
 from . import math as hmath
 from . import models
@@ -127,6 +128,10 @@ def _summarize(layout, per_leaf, reduce, post=lambda x: x):
 
 
 _AR_BUCKETS = __import__('os').environ.get('HUGS_AR_BUCKETS', '1') != '0'
+# Replay of the train step as a captured hipGraph: '0' never, '1' whenever the step is capturable, 'auto' (default) when it is
+# capturable AND small enough to be host-bound (rays x samples per step <= HUGS_STEP_GRAPH_ROWS)
+_STEP_GRAPH = __import__('os').environ.get('HUGS_STEP_GRAPH', 'auto')
+_STEP_GRAPH_ROWS = int(__import__('os').environ.get('HUGS_STEP_GRAPH_ROWS', '32768'))
 
 
 def uncovered_ranges(layout, covered, total):
@@ -184,7 +189,7 @@ def create_train_step(model, config, is_finetune=False):
           decay.append((lf['off'], int(np.prod(lf['pshape'])), float(mult)))
   cache = {}
 
-  def optimizer_step(state, grad, gscale=1.0):
+  def optimizer_step(state, grad, gscale=1.0, dyn=None):
     """The second half of the reference's train_step on a gradient buffer in the flat layout
     (train_utils.py:461-473): grad_norms / grad_maxes, clip_gradients per module (value clip, then norm clip with
     `eps + norm`), nan_to_num, Adam (optax.adam: bias-corrected moments, eps outside the sqrt, schedule at the
@@ -204,18 +209,48 @@ def create_train_step(model, config, is_finetune=False):
     lr = h['lr_fn'](count)
     t = count + 1
     part2 = ws.get('opt_part2', (nch * 2,))
-    _lib.call('hugs_opt_adam', nch, nleaf, eng.chunks, eng.leaf_info, state.flat, grad, state.m, state.v, mod_scale, h['trainable'], gscale,
-              config.grad_max_val, lr, h['b1'], h['b2'], h['eps'], 1.0 - h['b1']**t, 1.0 - h['b2']**t, part2,
-              leaf_stats[nleaf * 4:nleaf * 6])
+    if dyn is not None:     # a step being captured: {lr, 1 - b1^t, 1 - b2^t} are read from dyn[1:4] (step_scalars below writes them)
+      _lib.call('hugs_opt_adam_dyn', nch, nleaf, eng.chunks, eng.leaf_info, state.flat, grad, state.m, state.v, mod_scale, h['trainable'],
+                gscale, config.grad_max_val, dyn[1:4], h['b1'], h['b2'], h['eps'], part2, leaf_stats[nleaf * 4:nleaf * 6])
+    else:
+      _lib.call('hugs_opt_adam', nch, nleaf, eng.chunks, eng.leaf_info, state.flat, grad, state.m, state.v, mod_scale, h['trainable'], gscale,
+                config.grad_max_val, lr, h['b1'], h['b2'], h['eps'], 1.0 - h['b1']**t, 1.0 - h['b2']**t, part2,
+                leaf_stats[nleaf * 4:nleaf * 6])
     eng.refresh_weights(state.flat, owner=state)
     state.step += 1
     return leaf_stats
 
+  def step_scalars(state, train_frac):
+    """The per-step scalars a captured step reads from device memory: (anneal, lr, 1 - b1^t, 1 - b2^t)."""
+    h = state.hyper
+    t = state.step + 1
+    return (model.engine(state.flat.device).anneal_factor(float(train_frac)), h['lr_fn'](state.step), 1.0 - h['b1']**t, 1.0 - h['b2']**t)
+
+  def graph_signature(rng, state, N, train_frac, inlier_thresholds):
+    """None when this step cannot be replayed from a captured hipGraph, else the key of its graph.  Capturable: one
+    process (an all-reduce sits in the middle of the step otherwise), the plain / static-mask losses, jitter from a jax key
+    through the fused chain kernel (or none), no near-plane annealing (its histogram is rewritten from the host)."""
+    if _STEP_GRAPH == '0' or _lib.PROFILE is not None or _world() > 1 or tt not in (None, 'withmask') or inlier_thresholds is not None:
+      return None
+    if model.near_anneal_rate is not None or model.has_noise() or model.nerf_spec.num_tra > 0 or model.mask_spec is not None:
+      return None
+    if hrandom.is_key(rng):
+      if not (config.randomized and L <= hrandom.step_jitter_max_levels()):
+        return None
+      kind = 'key'
+    elif rng is None:
+      kind = 'none'
+    else:
+      return None           # a torch.Generator (its philox offset lives on the host) or explicit draws
+    if _STEP_GRAPH == 'auto' and N * (model.num_prop_samples * (L - 1) + model.num_nerf_samples) > _STEP_GRAPH_ROWS:
+      return None           # large batches are GPU-bound and gain from the side streams a capture gives up
+    return (kind, N, state.gen, state.flat.data_ptr(), state.m.data_ptr(), is_finetune)
+
+  graphs = {}
+
   def train_step(rng, state, batch, train_frac, inlier_thresholds):
     eng = model.engine(state.flat.device)
     dev = state.flat.device
-    ws = eng.ws
-    world = _world()
     rays = models.rays_to_dict(batch.rays, dev)
     gt = batch.rgb[..., :3].reshape(-1, 3).to(device=dev, dtype=torch.float32).contiguous()
     N = gt.shape[0]
@@ -225,6 +260,62 @@ def create_train_step(model, config, is_finetune=False):
                          'use a batch size that is a multiple of 4 (eval pads ragged chunks itself)')
     if not eng.weights_current(state):
       eng.refresh_weights(state.flat, owner=state)
+    sig = graph_signature(rng, state, N, train_frac, inlier_thresholds)
+    ent = None
+    if sig is not None:
+      ent = graphs.setdefault(sig, {'calls': 0})
+      ent['calls'] += 1
+    if ent is None or ent['calls'] <= 2:       # (two eager steps first: every workspace buffer and cache exists before the capture)
+      packed, rng = step_core(state, rays, gt, N, rng, train_frac, inlier_thresholds, None)
+      return state, LazyStats(packed, stats_builder(state)), rng
+    # ---- replay (capture on first use) of the step as ONE hipGraph on the current stream: ~0.05 ms of host time instead of
+    # ~1.6 ms of Python / ctypes for ~90 launches.  Inputs are staged into the buffers the graph was captured on, the
+    # per-step scalars enter through one small launch, the jax key advances in place in a buffer that is handed back.
+    if 'graph' not in ent:
+      ent['rays'] = {k: torch.empty_like(v) for k, v in rays.items()}
+      ent['gt'] = torch.empty_like(gt)
+      ent['dyn'] = torch.zeros(4, dtype=torch.float32, device=dev)
+      ent['key'] = torch.zeros(2, dtype=torch.int32, device=dev) if sig[0] == 'key' else None
+    names = list(rays)      # (the engine adds derived entries -- 'dir_enc' -- to the dict it is handed: they are not inputs)
+    srcs = [rays[k] for k in names if rays[k].data_ptr() != ent['rays'][k].data_ptr()] + ([gt] if gt.data_ptr() != ent['gt'].data_ptr() else [])
+    dsts = [ent['rays'][k] for k in names if rays[k].data_ptr() != ent['rays'][k].data_ptr()] + ([ent['gt']] if gt.data_ptr() != ent['gt'].data_ptr() else [])
+    for dt_ in (torch.float32, torch.int32):
+      d_ = [d for d in dsts if d.dtype == dt_]
+      if d_:
+        torch._foreach_copy_(d_, [s_ for s_ in srcs if s_.dtype == dt_])
+    if ent['key'] is not None and rng.data_ptr() != ent['key'].data_ptr():
+      ent['key'].copy_(rng)
+    _lib.call('hugs_set_floats', ent['dyn'], 4, *step_scalars(state, train_frac))
+    if 'graph' not in ent:
+      g = torch.cuda.CUDAGraph()
+      cap = torch.cuda.Stream(device=dev)
+      cap.wait_stream(torch.cuda.current_stream())
+      step0 = state.step
+      eng.single_stream = True
+      _engine.KEEP_EVENTS = []
+      try:
+        with torch.cuda.graph(g, stream=cap, capture_error_mode='thread_local'):
+          packed, key_out = step_core(state, ent['rays'], ent['gt'], N, ent['key'], train_frac, None, ent['dyn'])
+          if ent['key'] is not None:
+            ent['key'].copy_(key_out)
+      finally:
+        eng.single_stream = False
+        ent['events'], _engine.KEEP_EVENTS = _engine.KEEP_EVENTS, None
+      torch.cuda.current_stream().wait_stream(cap)
+      state.step = step0            # (the capture ran the host side of the step once without executing anything)
+      ent['graph'], ent['packed'] = g, packed
+    ent['graph'].replay()
+    state.step += 1
+    eng._cast_src = (state.gen, state.flat.data_ptr(), state.flat._version)      # the graph ends with the weight re-cast
+    return state, LazyStats(ent['packed'], stats_builder(state)), (ent['key'] if ent['key'] is not None else rng)
+
+  def step_core(state, rays, gt, N, rng, train_frac, inlier_thresholds, dyn):
+    """Everything the step enqueues (forward, losses, backward, pmean, clip / Adam, stat packing).  dyn: None, or the
+    device scalars of a captured step.  Returns (packed stats buffer, advanced rng)."""
+    eng = model.engine(state.flat.device)
+    dev = state.flat.device
+    ws = eng.ws
+    world = _world()
     u01 = None
     if isinstance(rng, (list, tuple)):             # explicit U[0,1) draws, one [N] (or [N,S]) tensor per level: the
       if len(rng) != L:                            # numbers jax.random.uniform handed the reference (fixtures, tests)
@@ -247,12 +338,12 @@ def create_train_step(model, config, is_finetune=False):
       # the per-ray ImplicitMask MLP is independent of the level pipeline until the loss: it runs on the side stream
       # underneath the NerfMLP forward (and its backward underneath the level backward)
       main_s, side_s = torch.cuda.current_stream(), eng._side_stream()
-      ev0 = torch.cuda.Event(); ev0.record(main_s)
+      ev0 = _engine.new_event(); ev0.record(main_s)
       with torch.cuda.stream(side_s):
         side_s.wait_event(ev0)
         mask_st = eng.mask_forward(state.flat, rays, N)
-        ev_mask = torch.cuda.Event(); ev_mask.record(side_s)
-    levels = eng.forward(state.flat, rays, float(train_frac), u01, False, False)
+        ev_mask = _engine.new_event(); ev_mask.record(side_s)
+    levels = eng.forward(state.flat, rays, float(train_frac), u01, False, False, anneal_dev=None if dyn is None else dyn[0:1])
     if mask_st is not None:
       main_s.wait_event(ev_mask)
 
@@ -344,11 +435,11 @@ def create_train_step(model, config, is_finetune=False):
       last = layout.by_path[('NerfMLP_0', sp.layers[-1]['name'], 'bias')]
       grad[lo:last['off'] + int(np.prod(last['pshape']))].zero_()
     if mask_st is not None:
-      ev1 = torch.cuda.Event(); ev1.record(main_s)          # loss gradients and the zeroed embedding rows are ready
+      ev1 = _engine.new_event(); ev1.record(main_s)          # loss gradients and the zeroed embedding rows are ready
       with torch.cuda.stream(side_s):
         side_s.wait_event(ev1)
         eng.mask_backward(state.flat, grad, mask_st, rays, d_mask)
-        ev_mask_bwd = torch.cuda.Event(); ev_mask_bwd.record(side_s)
+        ev_mask_bwd = _engine.new_event(); ev_mask_bwd.record(side_s)
     elif model.mask_spec is not None:            # finetune stage of a hanerf model: the mask is not in the loss
       lo = layout.by_path[('ImplicitMask_0', 'Dense_0', 'kernel')]['off']
       last = [lf for lf in layout.leaves if lf['path'][0] == 'ImplicitMask_0'][-1]
@@ -397,14 +488,14 @@ def create_train_step(model, config, is_finetune=False):
     # underneath the NerfMLP trunk backward (whose GEMMs fill the chip; the proposal kernels fit in their tails).
     bwd_main = torch.cuda.current_stream()
     prop_stream = eng._side_stream(1)
-    ev_loss = torch.cuda.Event(); ev_loss.record(bwd_main)
+    ev_loss = _engine.new_event(); ev_loss.record(bwd_main)
     with torch.cuda.stream(prop_stream):
       prop_stream.wait_event(ev_loss)
       for l in range(L - 2, -1, -1):
         level_backward(l, 2)
       if not prop_done:
         grad[prop_lo:prop_hi].zero_()
-      ev_prop = torch.cuda.Event(); ev_prop.record(prop_stream)
+      ev_prop = _engine.new_event(); ev_prop.record(prop_stream)
     level_backward(L - 1, 0)
     bwd_main.wait_event(ev_prop)
     if ev_mask_bwd is not None:
@@ -420,7 +511,7 @@ def create_train_step(model, config, is_finetune=False):
     for off, n_, mult in decay:        # after pmean; the kernels below scale the buffer by gscale, hence the 1/gscale
       _lib.call('hugs_axpy', n_, 2.0 * mult / gscale, state.flat[off:off + n_], grad[off:off + n_])
     nleaf = len(layout.leaves)
-    leaf_stats = optimizer_step(state, grad, gscale)
+    leaf_stats = optimizer_step(state, grad, gscale, dyn)
     # ---- stats (lazy) -------------------------------------------------------------------------------
     packed = ws.get('stats_packed', (STAT_TAIL + nleaf * 6 + 16,))
     packed[:STAT_TAIL].copy_(tail)
@@ -429,7 +520,10 @@ def create_train_step(model, config, is_finetune=False):
     assert leaf_stats.data_ptr() == packed[STAT_TAIL:].data_ptr()
     if tt == 'robustnerf':
       cache['thr_dev'] = packed[o_rob:o_rob + 5 * L].reshape(L, 5)[:, :1].clone()
+    return packed, rng
 
+  def stats_builder(state):
+    nleaf = len(layout.leaves)
     msm_now = cache.get('mask_size_mult', 0.0)
 
     def build(hst):
@@ -470,9 +564,10 @@ def create_train_step(model, config, is_finetune=False):
       stats['opt_update_maxes'] = {k: T(v) for k, v in _summarize(layout, lu[:, 1], max).items()}
       return stats
 
-    return state, LazyStats(packed, build), rng
+    return build
 
   train_step.optimizer_step = optimizer_step
+  train_step.graph_active = lambda: any('graph' in e for e in graphs.values())
   return train_step
 
 

@@ -1,0 +1,74 @@
+"""The train step replayed from a captured hipGraph (train_utils.create_train_step, HUGS_STEP_GRAPH) against the same steps
+enqueued launch by launch: the same kernels in the same order on one stream, so parameters, Adam moments, the advanced
+jax key and every stat must be BIT-identical, with the per-step scalars (annealing factor, learning rate, bias corrections)
+changing from step to step."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.test_gpu_train_step import SMALL
+
+
+def _run(mode, gin, nsteps, rng_kind, n_patch=2):
+  from tests import hugs_testlib as H
+  from nerf_hugs_amd.internal import train_utils, random as hr
+  old = train_utils._STEP_GRAPH
+  train_utils._STEP_GRAPH = mode
+  try:
+    config, model, state, render_fn, train_step, cfg, oparams = H.make_pair(gin, compute_dtype='bf16')
+    batches = [H.synth_rays(n_patch, 8, 5 + (i % 3)) for i in range(nsteps)]      # fresh tensors every step: inputs are staged
+    key = hr.PRNGKey(123) if rng_kind == 'key' else None
+    out = []
+    for i in range(nsteps):
+      state, stats, key = train_step(key, state, batches[i], 0.1 + 0.07 * i, None)
+      out.append((float(stats['loss']), float(stats['psnr']), float(stats['grad_norms']['NerfMLP_0']), float(stats['opt_update_maxes']['PropMLP_0'])))
+    torch.cuda.synchronize()
+    return (state.flat.clone(), state.m.clone(), state.v.clone(), None if key is None else key.clone(), out, state.step,
+            train_step.graph_active(), model.layout)
+  finally:
+    train_utils._STEP_GRAPH = old
+
+
+@pytest.mark.parametrize('rng_kind', ['key', 'none'])
+@pytest.mark.parametrize('variant', ['base', 'withmask_glo'])
+def test_graph_replay_is_bit_identical_to_the_eager_step(rng_kind, variant):
+  gin = list(SMALL)
+  if variant == 'withmask_glo':
+    gin += ["Config.transient_type = 'withmask'", "Model.num_glo_features = 4", "Config.data_loss_type = 'charb'"]
+  e = _run('0', gin, 7, rng_kind)
+  g = _run('1', gin, 7, rng_kind)
+  assert not e[6] and g[6], 'the graph path did not engage'
+  assert e[5] == g[5] == 7
+  for a, b, name in zip(e[:3], g[:3], ('params', 'adam m', 'adam v')):
+    if variant == 'withmask_glo':
+      # the GLO rows are a float-atomic scatter-add (hugs_embed_scatter_add): equal to rounding only within a step, and the
+      # rounding reaches every parameter through the next step's forward pass -- two EAGER runs differ by as much
+      sc = float(a.abs().max())
+      assert float((a - b).abs().max()) <= 2e-3 * sc, (name, float((a - b).abs().max()), sc)
+    else:
+      assert torch.equal(a, b), name
+  if rng_kind == 'key':
+    assert torch.equal(e[3], g[3]), 'jax key after 7 steps'
+  if variant == 'base':
+    assert e[4] == g[4], (e[4], g[4])
+  else:
+    np.testing.assert_allclose(np.array(e[4]), np.array(g[4]), rtol=2e-3)
+
+
+def test_graph_is_not_used_where_the_step_cannot_be_captured():
+  """RobustNeRF thresholds fed from the host, explicit jitter draws, a torch.Generator: eager enqueue, same results as ever."""
+  from tests import hugs_testlib as H
+  from nerf_hugs_amd.internal import train_utils
+  old = train_utils._STEP_GRAPH
+  train_utils._STEP_GRAPH = '1'
+  try:
+    config, model, state, render_fn, train_step, cfg, oparams = H.make_pair(list(SMALL), compute_dtype='bf16')
+    batch = H.synth_rays(1, 8, 5)
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    for _ in range(4):
+      state, stats, gen = train_step(gen, state, batch, 0.5, None)
+    assert not train_step.graph_active() and np.isfinite(float(stats['loss']))
+  finally:
+    train_utils._STEP_GRAPH = old
