@@ -25,11 +25,28 @@ _CHUNK_BYTES = int(float(__import__('os').environ.get('HUGS_FWD_CHUNK_MB', '1e9'
 KEEP_EVENTS = None      # a list while a train step is being captured into a hipGraph: its events must outlive the capture
 
 
+class _Event(torch.cuda.Event):
+  """torch.cuda.Event that remembers the stream it was recorded on (wait_event below skips a stream's wait on itself)."""
+
+  def record(self, stream=None):
+    stream = torch.cuda.current_stream() if stream is None else stream
+    self.sid = stream.cuda_stream
+    super().record(stream)
+
+
 def new_event():
-  e = torch.cuda.Event()
+  e = _Event()
   if KEEP_EVENTS is not None:
     KEEP_EVENTS.append(e)
   return e
+
+
+def wait_event(stream, ev):
+  """stream.wait_event(ev), except when `ev` was recorded on `stream` itself: stream order already holds there, and a
+  hipGraph capture on ROCm 7.2 dies in hipStreamEndCapture when a FORKED stream waits on (or forks again from) an event
+  of its own (scratch/graph_probe2.py: lanes whose events stay on the origin stream capture fine)."""
+  if getattr(ev, 'sid', None) != stream.cuda_stream:
+    stream.wait_event(ev)
 
 
 def _round_up(x, m):
@@ -686,7 +703,7 @@ class Engine:
       hl = self._side_stream(lane + 3)
       ev_gv = new_event(); ev_gv.record(cur)
       with torch.cuda.stream(hl):
-        hl.wait_event(ev_gv)
+        wait_event(hl, ev_gv)
         _lib.call('hugs_density_bwd', dt, M, W, Ylast, W, None, lv['raw'], spec.density_bias, d_raw,
                   gview((spec.name, ld['name'], 'kernel'), True).reshape(-1), gview((spec.name, ld['name'], 'bias')), dws)
         _lib.call('hugs_raybias_bwd', dt, N, S, H, spec.nd, spec.num_glo, Gv, H, rays['dir_enc'], lv['glo'], Wv[Bw:],
@@ -706,7 +723,7 @@ class Engine:
                   None, 1, 0, 0, None, 0, None, None, dB, Bw)
       ev_db = new_event(); ev_db.record(cur)
       with torch.cuda.stream(hl):
-        hl.wait_event(ev_db)
+        wait_event(hl, ev_db)
         self._tn(M, W, Bw, Ylast, W, dB, Bw, gview((spec.name, lb['name'], 'kernel'), True), gview((spec.name, lb['name'], 'bias')))
         if leaf_done is not None:      # density / bottleneck / view / rgb (/ transient) layers: everything behind the trunk
           first = lay.by_path[(spec.name, spec.layers[spec.net_depth]['name'], 'kernel')]
@@ -759,7 +776,7 @@ class Engine:
         if i in cuts:          # G_hi .. G_i are final: their weight gradients go out as one launch on the side stream
           ev = new_event(); ev.record(main)
           with torch.cuda.stream(side):
-            side.wait_event(ev)
+            wait_event(side, ev)
             items = []
             for j in range(hi, i - 1, -1):
               lj = trunk[j]
@@ -787,9 +804,9 @@ class Engine:
             _lib.call('hugs_gemm_nt', dt, M, W, W, 0, G, W, None, 0, Wn_, W, None, None, 1, 0, 0, acts[i], W, None, None,
                       Gs[depth - i], W)
       for e in done:
-        main.wait_event(e)
+        wait_event(main, e)
       if not spec.disable_rgb and spec.use_viewdirs:
-        main.wait_event(heads_done)
+        wait_event(main, heads_done)
       return
     Gc = ws.get(tag + '/Gc', (M, W), self.tdt)
     Gd = ws.get(tag + '/Gd', (M, W), self.tdt)
@@ -805,7 +822,7 @@ class Engine:
       gb = gview((spec.name, l['name'], 'bias'), True)
       xin = acts[i]          # acts[0] = X0, acts[i] = Y_{i-1}
       with torch.cuda.stream(side):
-        side.wait_event(ev_g)                       # G_i is ready
+        wait_event(side, ev_g)                       # G_i is ready
         if l['concat']:
           self._tn(M, W, W, xin, W, G, W, gW[:W], gb)
           self._tn(M, spec.Fp, W, X0, spec.Fp, G, W, gW[W:], None)
@@ -820,7 +837,7 @@ class Engine:
       if i > 0:
         nxt = (gi + 1) % 4
         if nxt in tn_done:                           # the dW that last read this buffer must be finished
-          main.wait_event(tn_done.pop(nxt))
+          wait_event(main, tn_done.pop(nxt))
         # G_{i-1} = (G_i W_i[:W]^T) * (Y_{i-1} > 0)
         bprev = lv['bits'][i - 1] if lv.get('bits') else None
         if bprev is not None:
@@ -833,9 +850,9 @@ class Engine:
         ev_g.record(main)
         G, gi = ring[nxt], nxt
     for e in tn_done.values():
-      main.wait_event(e)
+      wait_event(main, e)
     if not spec.disable_rgb and spec.use_viewdirs:
-      main.wait_event(heads_done)
+      wait_event(main, heads_done)
 
   def _transient_backward(self, theta, grad, lv, rays, N, d_dt, d_ct, d_u):
     """Backward of the NeRF-W transient branch (heads -> trunk -> per-ray tra_vec part).  Returns G at the first
@@ -940,7 +957,8 @@ class Engine:
   def _side_stream(self, lane=0):
     """HIP streams next to the caller's: lane 0 carries the weight-gradient GEMMs of the NerfMLP backward (and the
     HA-NeRF mask MLP), lane 1 the whole proposal-level backward, lane 2 its weight-gradient GEMMs."""
-    if getattr(self, 'single_stream', False):      # a step being captured into a hipGraph: everything on the capture stream
+    cap = getattr(self, 'capture_lanes', None)      # a step being captured into a hipGraph: only these lanes fork
+    if cap is not None and lane not in cap:
       return torch.cuda.current_stream()
     if not hasattr(self, '_side'):
       self._side = {}

@@ -128,10 +128,14 @@ def _summarize(layout, per_leaf, reduce, post=lambda x: x):
 
 
 _AR_BUCKETS = __import__('os').environ.get('HUGS_AR_BUCKETS', '1') != '0'
-# Replay of the train step as a captured hipGraph: '0' never, '1' whenever the step is capturable, 'auto' (default) when it is
-# capturable AND small enough to be host-bound (rays x samples per step <= HUGS_STEP_GRAPH_ROWS)
+# Replay of the train step as a captured hipGraph: '0' never, '1' whenever the step is capturable, 'auto' (default): one
+# process -- whenever capturable; data parallel -- when the per-GPU step is small enough to be host-bound (rays x samples per
+# step <= HUGS_STEP_GRAPH_ROWS: the graphs give up the overlap of the bucketed all-reduces with the backward pass)
 _STEP_GRAPH = __import__('os').environ.get('HUGS_STEP_GRAPH', 'auto')
-_STEP_GRAPH_ROWS = int(__import__('os').environ.get('HUGS_STEP_GRAPH_ROWS', '32768'))
+# lanes (Engine._side_stream) that keep a stream of their own inside the captured step; the others run on the stream they are
+# called from.  Lane 2 (the proposal level's weight-gradient stream) forks from lane 1, a forked stream: see engine.wait_event
+_GRAPH_LANES = tuple(int(x) for x in __import__('os').environ.get('HUGS_STEP_GRAPH_LANES', '1,3').split(',') if x != '')
+_STEP_GRAPH_ROWS = int(__import__('os').environ.get('HUGS_STEP_GRAPH_ROWS', '100000'))
 
 
 def uncovered_ranges(layout, covered, total):
@@ -227,10 +231,11 @@ def create_train_step(model, config, is_finetune=False):
     return (model.engine(state.flat.device).anneal_factor(float(train_frac)), h['lr_fn'](state.step), 1.0 - h['b1']**t, 1.0 - h['b2']**t)
 
   def graph_signature(rng, state, N, train_frac, inlier_thresholds):
-    """None when this step cannot be replayed from a captured hipGraph, else the key of its graph.  Capturable: one
-    process (an all-reduce sits in the middle of the step otherwise), the plain / static-mask losses, jitter from a jax key
-    through the fused chain kernel (or none), no near-plane annealing (its histogram is rewritten from the host)."""
-    if _STEP_GRAPH == '0' or _lib.PROFILE is not None or _world() > 1 or tt not in (None, 'withmask') or inlier_thresholds is not None:
+    """None when this step cannot be replayed from captured hipGraphs, else the key of its graphs.  Capturable: the plain /
+    static-mask losses, jitter from a jax key through the fused chain kernel (or none), no near-plane annealing (its histogram
+    is rewritten from the host).  Data parallel: TWO graphs (forward + backward | clip + Adam) around ONE eager all-reduce of
+    the gradient buffer -- the collective is not captured."""
+    if _STEP_GRAPH == '0' or _lib.PROFILE is not None or tt not in (None, 'withmask') or inlier_thresholds is not None:
       return None
     if model.near_anneal_rate is not None or model.has_noise() or model.nerf_spec.num_tra > 0 or model.mask_spec is not None:
       return None
@@ -242,9 +247,9 @@ def create_train_step(model, config, is_finetune=False):
       kind = 'none'
     else:
       return None           # a torch.Generator (its philox offset lives on the host) or explicit draws
-    if _STEP_GRAPH == 'auto' and N * (model.num_prop_samples * (L - 1) + model.num_nerf_samples) > _STEP_GRAPH_ROWS:
-      return None           # large batches are GPU-bound and gain from the side streams a capture gives up
-    return (kind, N, state.gen, state.flat.data_ptr(), state.m.data_ptr(), is_finetune)
+    if _STEP_GRAPH == 'auto' and _world() > 1 and N * (model.num_prop_samples * (L - 1) + model.num_nerf_samples) > _STEP_GRAPH_ROWS:
+      return None           # data parallel, large per-GPU batches: the eager step hides its bucketed all-reduces under the backward
+    return (kind, N, state.gen, state.flat.data_ptr(), state.m.data_ptr(), is_finetune, _world())
 
   graphs = {}
 
@@ -266,7 +271,8 @@ def create_train_step(model, config, is_finetune=False):
       ent = graphs.setdefault(sig, {'calls': 0})
       ent['calls'] += 1
     if ent is None or ent['calls'] <= 2:       # (two eager steps first: every workspace buffer and cache exists before the capture)
-      packed, rng = step_core(state, rays, gt, N, rng, train_frac, inlier_thresholds, None)
+      rng = step_core(state, rays, gt, N, rng, train_frac, inlier_thresholds, None, True)
+      packed = step_finish(state, None)
       return state, LazyStats(packed, stats_builder(state)), rng
     # ---- replay (capture on first use) of the step as ONE hipGraph on the current stream: ~0.05 ms of host time instead of
     # ~1.6 ms of Python / ctypes for ~90 launches.  Inputs are staged into the buffers the graph was captured on, the
@@ -287,31 +293,41 @@ def create_train_step(model, config, is_finetune=False):
       ent['key'].copy_(rng)
     _lib.call('hugs_set_floats', ent['dyn'], 4, *step_scalars(state, train_frac))
     if 'graph' not in ent:
-      g = torch.cuda.CUDAGraph()
+      world = _world()
+      g, g2 = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if world > 1 else None)
       cap = torch.cuda.Stream(device=dev)
       cap.wait_stream(torch.cuda.current_stream())
       step0 = state.step
-      eng.single_stream = True
+      eng.capture_lanes = _GRAPH_LANES
       _engine.KEEP_EVENTS = []
       try:
         with torch.cuda.graph(g, stream=cap, capture_error_mode='thread_local'):
-          packed, key_out = step_core(state, ent['rays'], ent['gt'], N, ent['key'], train_frac, None, ent['dyn'])
+          key_out = step_core(state, ent['rays'], ent['gt'], N, ent['key'], train_frac, None, ent['dyn'], False)
           if ent['key'] is not None:
             ent['key'].copy_(key_out)
+          if world == 1:
+            packed = step_finish(state, ent['dyn'])
+        if world > 1:
+          with torch.cuda.graph(g2, stream=cap, capture_error_mode='thread_local'):
+            packed = step_finish(state, ent['dyn'])
       finally:
-        eng.single_stream = False
+        eng.capture_lanes = None
         ent['events'], _engine.KEEP_EVENTS = _engine.KEEP_EVENTS, None
       torch.cuda.current_stream().wait_stream(cap)
       state.step = step0            # (the capture ran the host side of the step once without executing anything)
-      ent['graph'], ent['packed'] = g, packed
+      ent['graph'], ent['graph_opt'], ent['packed'] = g, g2, packed
     ent['graph'].replay()
+    if ent['graph_opt'] is not None:      # pmean(grad), pmean(stats) (train_utils.py:457-459): one SUM over the whole buffer + stat tail
+      dist.all_reduce(eng.ws.get('grad', (layout.size + STAT_TAIL,)), op=dist.ReduceOp.SUM)
+      ent['graph_opt'].replay()
     state.step += 1
     eng._cast_src = (state.gen, state.flat.data_ptr(), state.flat._version)      # the graph ends with the weight re-cast
     return state, LazyStats(ent['packed'], stats_builder(state)), (ent['key'] if ent['key'] is not None else rng)
 
-  def step_core(state, rays, gt, N, rng, train_frac, inlier_thresholds, dyn):
-    """Everything the step enqueues (forward, losses, backward, pmean, clip / Adam, stat packing).  dyn: None, or the
-    device scalars of a captured step.  Returns (packed stats buffer, advanced rng)."""
+  def step_core(state, rays, gt, N, rng, train_frac, inlier_thresholds, dyn, reduce):
+    """The first part of the step: forward, losses, backward and -- when `reduce` -- the all-reduces of the gradient buffer
+    (buckets issued underneath the backward pass + the rest).  dyn: None, or the device scalars of a captured step.  Returns
+    the advanced rng."""
     eng = model.engine(state.flat.device)
     dev = state.flat.device
     ws = eng.ws
@@ -340,12 +356,12 @@ def create_train_step(model, config, is_finetune=False):
       main_s, side_s = torch.cuda.current_stream(), eng._side_stream()
       ev0 = _engine.new_event(); ev0.record(main_s)
       with torch.cuda.stream(side_s):
-        side_s.wait_event(ev0)
+        _engine.wait_event(side_s, ev0)
         mask_st = eng.mask_forward(state.flat, rays, N)
         ev_mask = _engine.new_event(); ev_mask.record(side_s)
     levels = eng.forward(state.flat, rays, float(train_frac), u01, False, False, anneal_dev=None if dyn is None else dyn[0:1])
     if mask_st is not None:
-      main_s.wait_event(ev_mask)
+      _engine.wait_event(main_s, ev_mask)
 
     grad = ws.get('grad', (layout.size + STAT_TAIL,))
     tail = grad[layout.size:]
@@ -437,7 +453,7 @@ def create_train_step(model, config, is_finetune=False):
     if mask_st is not None:
       ev1 = _engine.new_event(); ev1.record(main_s)          # loss gradients and the zeroed embedding rows are ready
       with torch.cuda.stream(side_s):
-        side_s.wait_event(ev1)
+        _engine.wait_event(side_s, ev1)
         eng.mask_backward(state.flat, grad, mask_st, rays, d_mask)
         ev_mask_bwd = _engine.new_event(); ev_mask_bwd.record(side_s)
     elif model.mask_spec is not None:            # finetune stage of a hanerf model: the mask is not in the loss
@@ -472,7 +488,7 @@ def create_train_step(model, config, is_finetune=False):
       tgt = grad
       if is_prop and prop_done:
         tgt = ws.get('grad_tmp', (layout.size + STAT_TAIL,))
-      bucketed = bucket_done if (world > 1 and not is_prop and not is_finetune and _AR_BUCKETS) else None
+      bucketed = bucket_done if (reduce and world > 1 and not is_prop and not is_finetune and _AR_BUCKETS) else None
       if tt == 'nerfw' and not is_prop:
         eng.backward_level(state.flat, tgt, levels[l], rays, N, None, d_w[l], nerfw=nw, leaf_done=bucketed, lane=lane)
       else:
@@ -490,23 +506,32 @@ def create_train_step(model, config, is_finetune=False):
     prop_stream = eng._side_stream(1)
     ev_loss = _engine.new_event(); ev_loss.record(bwd_main)
     with torch.cuda.stream(prop_stream):
-      prop_stream.wait_event(ev_loss)
+      _engine.wait_event(prop_stream, ev_loss)
       for l in range(L - 2, -1, -1):
         level_backward(l, 2)
       if not prop_done:
         grad[prop_lo:prop_hi].zero_()
       ev_prop = _engine.new_event(); ev_prop.record(prop_stream)
     level_backward(L - 1, 0)
-    bwd_main.wait_event(ev_prop)
+    _engine.wait_event(bwd_main, ev_prop)
     if ev_mask_bwd is not None:
-      torch.cuda.current_stream().wait_event(ev_mask_bwd)
+      _engine.wait_event(torch.cuda.current_stream(), ev_mask_bwd)
     # ---- pmean(grad), pmean(stats) ------------------------------------------------------------------
-    if world > 1:
+    if world > 1 and reduce:
       # whatever no bucket covered (PropMLP, embeddings, ImplicitMask, the stat tail; everything in the finetune stage)
       for lo, hi in uncovered_ranges(layout, ar_ranges, grad.numel()):
         ar_works.append(dist.all_reduce(grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
       for w in ar_works:
         w.wait()
+    return rng
+
+  def step_finish(state, dyn):
+    """The second part: weight decay, stats / clip / Adam / re-cast, stat packing.  Returns the packed stats buffer."""
+    eng = model.engine(state.flat.device)
+    ws = eng.ws
+    world = _world()
+    grad = ws.get('grad', (layout.size + STAT_TAIL,))
+    tail = grad[layout.size:]
     gscale = 1.0 / world
     for off, n_, mult in decay:        # after pmean; the kernels below scale the buffer by gscale, hence the 1/gscale
       _lib.call('hugs_axpy', n_, 2.0 * mult / gscale, state.flat[off:off + n_], grad[off:off + n_])
@@ -520,7 +545,7 @@ def create_train_step(model, config, is_finetune=False):
     assert leaf_stats.data_ptr() == packed[STAT_TAIL:].data_ptr()
     if tt == 'robustnerf':
       cache['thr_dev'] = packed[o_rob:o_rob + 5 * L].reshape(L, 5)[:, :1].clone()
-    return packed, rng
+    return packed
 
   def stats_builder(state):
     nleaf = len(layout.leaves)

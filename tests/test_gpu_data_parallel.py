@@ -21,7 +21,7 @@ HANERF = GIN + ["Config.transient_type = 'hanerf'", "Model.num_transient_feature
                 "NerfMLP.bottleneck_width = 128"]
 
 
-def _step(rank, world, port, out_dir, gin, backend='gloo'):
+def _step(rank, world, port, out_dir, gin, backend='gloo', nsteps=1, graph='0'):
   import sys
   sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
   from tests import hugs_testlib as H
@@ -33,6 +33,7 @@ def _step(rank, world, port, out_dir, gin, backend='gloo'):
       dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
     else:
       dist.init_process_group('gloo', rank=rank, world_size=world)
+  train_utils._STEP_GRAPH = graph
   configs.clear_config()
   configs.parse_config_files_and_bindings(None, gin)
   config = configs.make_config()
@@ -41,18 +42,20 @@ def _step(rank, world, port, out_dir, gin, backend='gloo'):
   batch = H.synth_rays(4, 8, 5)
   if world > 1:
     batch = parallel.shard_batch(batch, rank, world)
-  state, stats, _ = train_step(None, state, batch, 0.4, None)
+  for i in range(nsteps):
+    state, stats, _ = train_step(None, state, batch, 0.4 + 0.01 * i, None)
   torch.cuda.synchronize()
+  assert train_step.graph_active() == (graph == '1' and nsteps > 2)
   if rank == 0:
     torch.save({'flat': state.flat.cpu(), 'loss': float(stats['loss']), 'mses': stats['mses']}, os.path.join(out_dir, f'w{world}.pt'))
   if world > 1:
     dist.destroy_process_group()
 
 
-def _compare(tmp_path, gin, backend):
+def _compare(tmp_path, gin, backend, nsteps=1, graph='0'):
   s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-  mp.spawn(_step, args=(1, port, str(tmp_path), gin, backend), nprocs=1, join=True)
-  mp.spawn(_step, args=(2, port, str(tmp_path), gin, backend), nprocs=2, join=True)
+  mp.spawn(_step, args=(1, port, str(tmp_path), gin, backend, nsteps, graph), nprocs=1, join=True)
+  mp.spawn(_step, args=(2, port, str(tmp_path), gin, backend, nsteps, graph), nprocs=2, join=True)
   a = torch.load(tmp_path / 'w1.pt'); b = torch.load(tmp_path / 'w2.pt')
   from tests import hugs_testlib as H
   from nerf_hugs_amd.internal import configs, models
@@ -71,6 +74,12 @@ def _compare(tmp_path, gin, backend):
 @pytest.mark.parametrize('gin', [GIN, HANERF], ids=['base', 'hanerf'])
 def test_two_rank_step_equals_single_process(tmp_path, gin):
   _compare(tmp_path, gin, 'gloo')
+
+
+def test_two_rank_graph_steps_equal_single_process(tmp_path):
+  """The captured form of the data-parallel step (two hipGraphs around one all-reduce of the whole gradient buffer,
+  train_utils.create_train_step) over four steps -- two eager, the capture, one replay -- against the single-process graph."""
+  _compare(tmp_path, GIN, 'gloo', nsteps=4, graph='1')
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL needs one GPU per rank: runs on multi-GPU nodes only')
