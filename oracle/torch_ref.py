@@ -448,17 +448,44 @@ def implicit_mask_forward(cfg, mod, pix_coords, tra_vec, taps=None):
   return torch.sigmoid(x @ L['kernel'] + L['bias'])
 
 
-def mlp_forward(cfg, mod, which, feats, viewdirs, glo_vec, taps=None, tra_vec=None, noise=None):
+class _QuantSTE(torch.autograd.Function):
+  """Round to bf16 (kept as float32 values) in the forward AND the backward pass: what a 16-bit operand copy of a tensor
+  is to the product's bf16 mode (weights, activations and the gradients that flow back through them)."""
+
+  @staticmethod
+  def forward(ctx, x):
+    return x.to(torch.bfloat16).to(x.dtype)
+
+  @staticmethod
+  def backward(ctx, g):
+    return g.to(torch.bfloat16).to(g.dtype)
+
+
+def _relu(pre, masks):
+  """relu, or -- tests that replay the implementation under test's own ReLU decisions -- pre * mask with the next mask of
+  the list (consumed in call order: trunk layers, then the view layer)."""
+  if masks is None:
+    return torch.relu(pre)
+  m = masks.pop(0)
+  return pre * m.reshape(pre.shape).to(pre.dtype)
+
+
+def mlp_forward(cfg, mod, which, feats, viewdirs, glo_vec, taps=None, tra_vec=None, noise=None, relu_masks=None, quant=False):
   """models.py:406-550 (no transient branch). feats [...,S,504].  taps: optional list that receives the
-  relu pre-activations (tests use it to find samples sitting on a ReLU kink)."""
+  relu pre-activations (tests use it to find samples sitting on a ReLU kink).  relu_masks: optional list of 0/1 masks that
+  replace the ReLU decisions (see _relu).  quant: emulate the product's bf16 mode -- GEMM operands (weights, layer inputs)
+  rounded to bf16 with fp32 accumulation, gradients rounded on the way back."""
   depth = cfg.nerf_depth if which == 'nerf' else cfg.prop_depth
+  q = _QuantSTE.apply if quant else (lambda t: t)
+  feats = q(feats)
+  masks = None if relu_masks is None else list(relu_masks)
   x, inputs = feats, feats
   for i in range(depth):
     L = mod[f'Dense_{i}']
-    pre = x @ L['kernel'] + L['bias']
+    pre = x @ q(L['kernel']) + L['bias']
     if taps is not None:
       taps.append(pre.detach())
-    x = torch.relu(pre)
+    x = q(_relu(pre, masks))
     if i % cfg.skip_layer == 0 and i > 0:
       x = torch.cat([x, inputs], -1)
   L = mod[f'Dense_{depth}']
@@ -474,7 +501,7 @@ def mlp_forward(cfg, mod, which, feats, viewdirs, glo_vec, taps=None, tra_vec=No
     rgb = torch.sigmoid(cfg.rgb_premultiplier * (x @ L['kernel'] + L['bias']) + cfg.rgb_bias)
     return density, rgb * (1 + 2 * cfg.rgb_padding) - cfg.rgb_padding
   L = mod[f'Dense_{depth + 1}']
-  bott = x @ L['kernel'] + L['bias']
+  bott = q(x @ q(L['kernel']) + L['bias'])
   if noise is not None and noise.get('bottleneck') is not None:   # models.py:478-481
     bott = bott + noise['bottleneck']
   parts = [bott, pos_enc(viewdirs, 0, cfg.deg_view, True)[..., None, :].expand(bott.shape[:-1] + (-1,))]
@@ -482,10 +509,14 @@ def mlp_forward(cfg, mod, which, feats, viewdirs, glo_vec, taps=None, tra_vec=No
     parts.append(glo_vec[..., None, :].expand(bott.shape[:-1] + (-1,)))
   x = torch.cat(parts, -1)
   L = mod[f'Dense_{depth + 2}']
-  pre = x @ L['kernel'] + L['bias']
+  if quant:      # the product keeps the view-direction / GLO rows of this kernel in fp32 (a per-ray bias): only the bottleneck rows are 16-bit
+    Bw = bott.shape[-1]
+    pre = bott @ q(L['kernel'][:Bw]) + x[..., Bw:] @ L['kernel'][Bw:] + L['bias']
+  else:
+    pre = x @ L['kernel'] + L['bias']
   if taps is not None:
     taps.append(pre.detach())
-  x = torch.relu(pre)
+  x = q(_relu(pre, masks))
   L = mod[f'Dense_{depth + 3}']
   rgb = torch.sigmoid(cfg.rgb_premultiplier * (x @ L['kernel'] + L['bias']) + cfg.rgb_bias)      # models.py:514-516
   rgb = rgb * (1 + 2 * cfg.rgb_padding) - cfg.rgb_padding
@@ -523,7 +554,8 @@ def sample_u_base(num_samples, randomized):
 
 
 def model_forward(cfg, variables, rays, train_frac, u01, compute_extras, zero_glo=False, taps=None,
-                  override_samples=None, override_feats=None, zero_tra=False, mask_taps=None, noise=None, bg_rgbs=None):
+                  override_samples=None, override_feats=None, zero_tra=False, mask_taps=None, noise=None, bg_rgbs=None,
+                  relu_masks=None, quant=False):
   """Model.__call__ (models.py:74-330).  rays: dict of [N,c] tensors.  u01: None
   (rng=None) or list[num_levels] of [N] float32 uniform draws (single_jitter)."""
   P = variables['params']
@@ -573,7 +605,8 @@ def model_forward(cfg, variables, rays, train_frac, u01, compute_extras, zero_gl
       tra = (torch.zeros(N, cfg.num_transient_features, dtype=dt) if zero_tra else
              P['TransientEmbed_0']['embedding'][rays['embed_idx'][:, 0].long()])
     res = mlp_forward(cfg, P['PropMLP_0' if is_prop else 'NerfMLP_0'], which, feats,
-                      rays['viewdirs'], None if is_prop else glo, lvl_taps, tra, None if noise is None else noise[lvl])
+                      rays['viewdirs'], None if is_prop else glo, lvl_taps, tra, None if noise is None else noise[lvl],
+                      relu_masks=None if relu_masks is None else relu_masks[lvl], quant=quant)
     density, rgb = res[0], res[1]
     if taps is not None:
       taps.append(lvl_taps)
@@ -752,7 +785,7 @@ def _natkey(s):
   return [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', s)]
 
 
-def loss_and_grad(cfg, variables, rays, gt_rgb, train_frac, u01, inlier_thresholds=None, bg_rgbs=None):
+def loss_and_grad(cfg, variables, rays, gt_rgb, train_frac, u01, inlier_thresholds=None, bg_rgbs=None, **forward_kw):
   """The value_and_grad half of train_step (train_utils.py:404-455).  rays/gt flat [N,c];
   robustnerf reshapes to [n,P,P,c] patches."""
   leaves = flat_leaves(variables['params'])
@@ -764,7 +797,7 @@ def loss_and_grad(cfg, variables, rays, gt_rgb, train_frac, u01, inlier_threshol
     for k in ks[:-1]:
       d = d.setdefault(k, {})
     d[ks[-1]] = v
-  renderings, history = model_forward(cfg, {'params': P}, rays, train_frac, u01, False, bg_rgbs=bg_rgbs)
+  renderings, history = model_forward(cfg, {'params': P}, rays, train_frac, u01, False, bg_rgbs=bg_rgbs, **forward_kw)
   losses, stats = {}, {}
   if cfg.transient_type is None:
     losses['data'], st = compute_data_loss(cfg, gt_rgb, rays, renderings, False)
