@@ -5,6 +5,12 @@ follows flax.serialization's documented wire format (msgpack with ExtType 1 = nd
 msgpack encoder / decoder written from the msgpack spec (tests/test_cpu_checkpoint_bytes.py); a file written by real
 flax has still never been read (none is available offline): "parity unpinned" in that sense.
 
+`step` and the optimizer counts are written as 0-d int32 ARRAYS (ext 1) -- what flax emits for the jax scalars a TrainState
+holds -- not as numpy scalars (ext 3); the reader takes either, plus flax's chunked form of arrays above 2**30 bytes and
+bfloat16 leaves.  tests/flax_wire.py restates flax.serialization's rules (to_state_dict of tuples / NamedTuples / the
+TrainState dataclass, _ndarray_to_bytes, _chunk) independently of this file and tests/test_cpu_checkpoint_bytes.py feeds its
+output to restore_checkpoint.
+
 Layout written / read:
   {'step': i32, 'params': {'params': {module: {Dense_i: {'kernel','bias'}}, 'GloEmbed_0': {'embedding'}}},
    'opt_state': {'0': {'count': i32, 'mu': {'params': ...}, 'nu': {'params': ...}}, '1': {'count': i32}}}
@@ -42,18 +48,49 @@ def _pack_ext(x):
 
 def _unpack_ext(code, data):
   if code in (_EXT_NDARRAY, _EXT_NPSCALAR):
-    shape, dtype, buf = msgpack.unpackb(data, raw=False)
-    arr = np.frombuffer(buf, dtype=np.dtype(dtype)).reshape(shape)
+    shape, dtype, buf = msgpack.unpackb(data, raw=True)      # (flax reads the triple raw: the dtype name arrives as bytes)
+    dtype = dtype.decode() if isinstance(dtype, bytes) else dtype
+    if dtype == 'bfloat16':      # flax maps the name to jax.numpy.bfloat16; here: widen to float32 (exact)
+      u = np.frombuffer(buf, dtype=np.uint16).astype(np.uint32) << 16
+      arr = u.view(np.float32).reshape(shape)
+    else:
+      arr = np.frombuffer(buf, dtype=np.dtype(dtype)).reshape(shape)
     return arr if code == _EXT_NDARRAY else arr[()]
   return msgpack.ExtType(code, data)
 
 
-def to_bytes(tree):
-  return msgpack.packb(tree, default=_pack_ext, strict_types=True, use_bin_type=True)
+def _unchunk(tree):
+  """flax.serialization._unchunk_array_leaves_in_place: an array above 2**30 bytes is written as
+  {'__msgpack_chunked_array__': True, 'shape': {'0': d0, ...}, 'chunks': {'0': flat piece, ...}}."""
+  if isinstance(tree, dict):
+    if '__msgpack_chunked_array__' in tree:
+      order = lambda d: [d[str(i)] for i in range(len(d))]
+      return np.concatenate([np.asarray(c).reshape(-1) for c in order(tree['chunks'])]).reshape(tuple(int(x) for x in order(tree['shape'])))
+    return {k: _unchunk(v) for k, v in tree.items()}
+  return tree
+
+
+_MAX_CHUNK = 2 ** 30
+
+
+def _chunk(tree, max_chunk):
+  """flax.serialization._chunk_array_leaves_in_place (the writer side of _unchunk)."""
+  if isinstance(tree, dict):
+    return {k: _chunk(v, max_chunk) for k, v in tree.items()}
+  if isinstance(tree, np.ndarray) and tree.size * tree.dtype.itemsize > max_chunk:
+    n = max(1, int(max_chunk / tree.dtype.itemsize))
+    flat = tree.reshape(-1)
+    return {'__msgpack_chunked_array__': True, 'shape': {str(i): int(d) for i, d in enumerate(tree.shape)},
+            'chunks': {str(i): flat[s_:s_ + n] for i, s_ in enumerate(range(0, flat.size, n))}}
+  return tree
+
+
+def to_bytes(tree, max_chunk=_MAX_CHUNK):
+  return msgpack.packb(_chunk(tree, max_chunk), default=_pack_ext, strict_types=True, use_bin_type=True)
 
 
 def from_bytes(b):
-  return msgpack.unpackb(b, ext_hook=_unpack_ext, raw=False, strict_map_key=False)
+  return _unchunk(msgpack.unpackb(b, ext_hook=_unpack_ext, raw=False, strict_map_key=False))
 
 
 def _tree_np(model, flat):
@@ -73,15 +110,15 @@ def state_dict(state):
   model = state.model
   if getattr(state, 'hyper', {}).get('finetune'):      # finetune stage: optax.multi_transform state
     keep = lambda path: 'embedding' in path
-    adam = {'0': {'count': np.int32(state.step), 'mu': _mask_tree(_tree_np(model, state.m), keep),
+    adam = {'0': {'count': np.array(state.step, np.int32), 'mu': _mask_tree(_tree_np(model, state.m), keep),
                   'nu': _mask_tree(_tree_np(model, state.v), keep)},
-            '1': {'count': np.int32(state.step)}}
-    return {'step': np.int32(state.step), 'params': _tree_np(model, state.flat),
+            '1': {'count': np.array(state.step, np.int32)}}
+    return {'step': np.array(state.step, np.int32), 'params': _tree_np(model, state.flat),
             'opt_state': {'inner_states': {'trainable': {'inner_state': adam}, 'frozen': {'inner_state': {}}}}}
-  return {'step': np.int32(state.step), 'params': _tree_np(model, state.flat),
-          'opt_state': {'0': {'count': np.int32(state.step), 'mu': _tree_np(model, state.m),
+  return {'step': np.array(state.step, np.int32), 'params': _tree_np(model, state.flat),
+          'opt_state': {'0': {'count': np.array(state.step, np.int32), 'mu': _tree_np(model, state.m),
                               'nu': _tree_np(model, state.v)},
-                        '1': {'count': np.int32(state.step)}}}
+                        '1': {'count': np.array(state.step, np.int32)}}}
 
 
 def save_checkpoint(ckpt_dir, state, step, keep=100):

@@ -179,3 +179,84 @@ def test_finetune_stage_checkpoint_layout(tmp_path):
       assert torch.equal(got, model.layout.view(fstate.v, lf['path']))
     else:
       assert float(got.abs().max()) == 0.0
+
+
+# ---- round 4: the reader against a test-side restatement of flax.serialization (tests/flax_wire.py) -------------------
+def _assert_restored(model, state, params, mu, nu, step, moments_at=lambda path: True):
+  assert state.step == step
+  for lf in model.layout.leaves:
+    for buf, tree, is_moment in ((state.flat, params, False), (state.m, mu, True), (state.v, nu, True)):
+      ref = tree['params']
+      for k in lf['path']:
+        ref = ref[k]
+      got = model.layout.view(buf, lf['path'])
+      if is_moment and not moments_at(lf['path']):
+        assert float(got.abs().max()) == 0.0, lf['path']
+      else:
+        assert torch.equal(got, torch.from_numpy(np.asarray(ref, np.float32))), lf['path']
+
+
+def test_restore_from_flax_wire_train_state_with_chunked_arrays_and_scalar_forms(tmp_path):
+  """TrainState -> to_state_dict -> msgpack_serialize as flax.serialization publishes them: tuple opt_state as '0' / '1',
+  NamedTuple states as field dicts, 0-d ARRAY step / counts (ext 1), arrays above the chunk limit (forced down to 1 KiB here)
+  in the `__msgpack_chunked_array__` form -- and the same file with numpy-scalar counts (ext 3) and native ints."""
+  from tests import flax_wire as FW
+  from nerf_hugs_amd.internal import checkpoints
+  model, state = _model()
+  params, mu, nu = _known_tree(model, 11), _known_tree(model, 12), _known_tree(model, 13)
+  for k, (counts_as, max_chunk) in enumerate([(np.array, FW.MAX_CHUNK_SIZE), (np.array, 1024), (FW.NpScalar, 4096), (int, 1 << 16)]):
+    ts = FW.adam_train_state(900 + k, params, mu, nu, counts_as=counts_as)
+    sd = FW.to_state_dict(ts)
+    assert set(sd) == {'step', 'params', 'opt_state'} and set(sd['opt_state']) == {'0', '1'} and set(sd['opt_state']['1']) == {'count'}
+    blob = FW.msgpack_serialize(sd, max_chunk=max_chunk)
+    if max_chunk <= 4096:
+      assert b'__msgpack_chunked_array__' in blob
+    d = tmp_path / f'case{k}'
+    d.mkdir()
+    (d / f'checkpoint_{900 + k}').write_bytes(blob)
+    fresh_model, fresh = _model()
+    fresh = checkpoints.restore_checkpoint(str(d), fresh)
+    _assert_restored(fresh_model, fresh, params, mu, nu, 900 + k)
+
+
+def test_restore_from_flax_wire_finetune_state_masked_nodes(tmp_path):
+  """optax.multi_transform state as published: MultiTransformState(inner_states={'trainable': MaskedState((adam states)),
+  'frozen': MaskedState(EmptyState())}), MaskedNode() at every non-embedding leaf of mu / nu (NamedTuples without fields
+  serialise to {})."""
+  from tests import flax_wire as FW
+  from nerf_hugs_amd.internal import checkpoints, configs, train_utils
+  model, state = _model()
+  params, mu, nu = _known_tree(model, 21), _known_tree(model, 22), _known_tree(model, 23)
+  is_tr = lambda path: 'embedding' in path
+  sd = FW.to_state_dict(FW.finetune_train_state(55, params, mu, nu, is_tr))
+  inner = sd['opt_state']['inner_states']
+  assert inner['frozen'] == {'inner_state': {}} and inner['trainable']['inner_state']['0']['mu']['params']['NerfMLP_0']['Dense_0']['kernel'] == {}
+  (tmp_path / 'checkpoint_55').write_bytes(FW.msgpack_serialize(sd, max_chunk=2048))
+  fresh, _ = train_utils.create_finetune_optimizer(configs.make_config(), state.flat.clone(), model)
+  fresh.m.fill_(7.0); fresh.v.fill_(7.0)           # stale moments of a reused state must not survive at frozen leaves
+  fresh = checkpoints.restore_checkpoint(str(tmp_path), fresh)
+  _assert_restored(model, fresh, params, mu, nu, 55, moments_at=lambda path: 'embedding' in path)
+
+
+def test_product_writer_emits_what_flax_wire_describes(tmp_path):
+  """The product's save_checkpoint decoded by the independent reader: step / counts are ext-1 0-d arrays, a forced-small
+  chunk limit produces flax's chunked form, and from_bytes(to_bytes(x)) is the identity on it."""
+  from nerf_hugs_amd.internal import checkpoints
+  model, state = _model()
+  state.step = 31
+  raw = checkpoints.to_bytes(checkpoints.state_dict(state))
+  i = raw.index(b'\xa4step') + 5
+  assert raw[i] in (0xc7, 0xc8, 0xc9) and raw[i + 2 if raw[i] == 0xc7 else (i + 3 if raw[i] == 0xc8 else i + 5)] == 1, 'step must be ext type 1 (0-d ndarray)'
+  small = checkpoints.to_bytes(checkpoints.state_dict(state), max_chunk=512)
+  assert b'__msgpack_chunked_array__' in small
+  a, b = checkpoints.from_bytes(raw), checkpoints.from_bytes(small)
+  k = a['params']['params']['NerfMLP_0']['Dense_0']['kernel']
+  assert np.array_equal(k, b['params']['params']['NerfMLP_0']['Dense_0']['kernel']) and k.dtype == np.float32
+  # bfloat16 leaves (a checkpoint of a bf16-parameter run): widened exactly
+  import struct
+  from tests import flax_wire as FW
+  vals = np.array([1.0, -2.5, 3.140625], np.float32)
+  bf = (vals.view(np.uint32) >> 16).astype(np.uint16)
+  payload = FW._enc_basic([[3], 'bfloat16', bf.tobytes()])
+  blob = b'\x81' + FW._enc_basic('x') + FW._ext(1, payload)
+  assert np.array_equal(checkpoints.from_bytes(blob)['x'], vals)
