@@ -228,6 +228,9 @@ int hugs_prng_normal(const uint32_t* key, long long n, float* out, void* stream)
  * are HOST arrays (out[l] device pointers).  Bit-identical to the chain of hugs_prng_bits / hugs_prng_uniform calls. */
 int hugs_prng_step_jitter(const uint32_t* key_in, int L, const long long* n, const float* maxval, float* const* out,
                           uint32_t* key_out, void* stream);
+/* jax.random.fold_in(key, data) (threefry_2x32(key, (0, data))): how flax derives a parameter's initialiser key from the
+ * `params` rng -- the hash of the module path and the per-scope counter folded in (models.py:333-357 `model.init(rng, ...)`) */
+int hugs_prng_fold_in(const uint32_t* key, uint32_t data, uint32_t* key_out, void* stream);
 /* The largest L hugs_prng_step_jitter takes (the host side gates its fused launch on this, not on a literal). */
 int hugs_prng_step_jitter_max_levels(void);
 

@@ -120,6 +120,22 @@ k_step_jitter(const uint32_t* __restrict__ key_in, StepJitter J, uint32_t* __res
 
 }  // namespace
 
+namespace {
+__global__ void k_fold_in(const uint32_t* __restrict__ key, uint32_t data, uint32_t* __restrict__ out) {
+  if (threadIdx.x == 0) {      // jax threefry_fold_in: threefry_2x32(key, threefry_seed(data)) with seed words (0, data)
+    uint32_t x0 = 0u, x1 = data;
+    threefry2x32(key[0], key[1], x0, x1);
+    out[0] = x0; out[1] = x1;
+  }
+}
+}  // namespace
+extern "C" int hugs_prng_fold_in(const uint32_t* key, uint32_t data, uint32_t* key_out, void* stream) {
+  HUGS_REQUIRE(key && key_out, -2, "hugs_prng_fold_in: null pointer");
+  k_fold_in<<<1, 64, 0, (hipStream_t)stream>>>(key, data, key_out);
+  HUGS_CHECK_LAUNCH("k_fold_in");
+  return 0;
+}
+
 /* One training step's draws from the reference's jax.random stream in one launch: key_out = first half of split(key_in)
  * (train_utils.py:408), and for every level l < L (<= 8) out[l][0..n[l]) = random.uniform(k_l, [n[l]], maxval = maxval[l]) with
  * the keys of models.py:196,230.  n / maxval / out are HOST arrays.  Bit-identical to the split / uniform entry points. */

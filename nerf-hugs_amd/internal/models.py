@@ -78,9 +78,13 @@ class Model:
       self._engine = _engine.Engine(self, device, self.compute_dtype)
     return self._engine
 
-  def init(self, seed, device='cuda'):
+  def init(self, seed, device='cuda', flax_rng=None):
     """Random-init parameters: he_uniform kernels, zero biases (models.py:372,432-433), N(0,1/G) GLO rows
-    (flax nn.Embed default).  Returns the flat fp32 buffer."""
+    (flax nn.Embed default).  Returns the flat fp32 buffer.  `seed`: an int (torch's generator: the distributions, not the
+    stream, of the reference) or a jax key from internal/random.py -- then the reference's own stream, `model.init(rng, ...)`
+    of models.py:348-356, through init_flax."""
+    if hrandom.is_key(seed):
+      return self.init_flax(seed, flax_rng or __import__('os').environ.get('HUGS_FLAX_RNG', 'lazy'))
     g = torch.Generator().manual_seed(int(seed))
     flat = torch.zeros(self.layout.size, dtype=torch.float32)
     for lf in self.layout.leaves:
@@ -91,6 +95,25 @@ class Model:
       elif lf['path'][-1] == 'embedding':
         v.copy_((torch.randn(lf['shape'], generator=g, dtype=torch.float64) / math.sqrt(lf['shape'][1])).float())
     return flat.to(device)
+
+  def init_flax(self, key, variant='lazy'):
+    """flax's initialisation stream on the device: every Dense kernel = jax.nn.initializers.he_uniform()(k, [in, out]) =
+    random.uniform(k, shape, minval=-1) * sqrt(3 * 2 / in) (variance_scaling(2, 'fan_in', 'uniform')), every nn.Embed table =
+    random.normal(k, shape) * sqrt(1 / features) (variance_scaling(1, 'fan_in', 'normal', out_axis=0)), biases zero, with
+    k = random.flax_param_key(rng, module path, 1): a function of the parameter's PATH, not of the creation order.
+    jax's non-partitionable threefry (the default before jax 0.5) as everywhere in internal/random.py.  PARITY UNPINNED: flax
+    and jax are absent from the reference tree and this image; the folding rule is selectable (random.flax_param_key)."""
+    flat = torch.zeros(self.layout.size, dtype=torch.float32, device=key.device)
+    for lf in self.layout.leaves:
+      v = self.layout.view(flat, lf['path'])
+      if lf['path'][-1] == 'kernel':
+        k = hrandom.flax_param_key(key, lf['path'][:-1], 1, variant)
+        scale = np.sqrt(np.float32(3.0) * np.float32(2.0 / lf['shape'][0]))      # jnp: float32 variance, float32 sqrt
+        v.copy_(hrandom.uniform(k, lf['shape'], -1.0, 1.0) * float(np.float32(scale)))
+      elif lf['path'][-1] == 'embedding':
+        k = hrandom.flax_param_key(key, lf['path'][:-1], 1, variant)
+        v.copy_(hrandom.normal(k, lf['shape']) * float(np.sqrt(np.float32(1.0 / lf['shape'][1]))))
+    return flat
 
   def variables(self, flat):
     """flax-style view tree {'params': {...}} sharing memory with `flat` (reference TrainState.params)."""
@@ -238,8 +261,9 @@ def rays_to_dict(rays, device):
 
 
 def construct_model(rng, rays, config, compute_dtype=None, device='cuda'):
-  """Construct a mip-NeRF 360 model (models.py:333-357).  `rng`: int seed.  Returns (model, variables) with
-  variables = the flat fp32 parameter buffer on `device` (use model.variables(flat) for the flax-style tree)."""
+  """Construct a mip-NeRF 360 model (models.py:333-357).  `rng`: an int seed, or a jax key (internal/random.PRNGKey) for
+  flax's own initialisation stream (Model.init_flax).  Returns (model, variables) with variables = the flat fp32 parameter
+  buffer on `device` (use model.variables(flat) for the flax-style tree)."""
   model = Model(config=config, compute_dtype=compute_dtype)
   return model, model.init(rng if rng is not None else 0, device)
 

@@ -63,6 +63,37 @@ def normal(key, shape=()):
   return out
 
 
+def fold_in(key, data):
+  """jax.random.fold_in(key, data) for a uint32 `data`."""
+  _check(key)
+  out = torch.empty(2, dtype=torch.int32, device=key.device)
+  L.call('hugs_prng_fold_in', key, int(data) & 0xFFFFFFFF, out)
+  return out
+
+
+def flax_param_key(root, path, counter, variant='lazy'):
+  """The key flax hands a parameter's initialiser: module `path` (tuple of scope names) and the scope's make_rng counter
+  (1 for the first `self.param` of the scope: nn.Dense's kernel, nn.Embed's embedding) folded into the `params` rng.
+  flax.core.scope is un-vendored and unversioned in the reference (requirements_jax.txt: `flax`), and the folding changed
+  between releases, hence the variants (restated from the published source; PARITY UNPINNED):
+    'lazy'      flax >= 0.6.x LazyRng: ONE fold_in of uint32(sha1(path strings + counter bytes)[:4])   (default)
+    'lazy_sep'  the same with config.flax_fix_rng_separator: a 0x00 byte in front of every component
+    'legacy'    older flax: fold_in(sha1(name)[:4]) per scope name on the way down, then fold_in(counter)"""
+  import hashlib
+  h32 = lambda b: int.from_bytes(hashlib.sha1(b).digest()[:4], 'big')
+  ib = lambda x: x.to_bytes((x.bit_length() + 7) // 8, 'big')
+  if variant == 'legacy':
+    k = root
+    for name in path:
+      k = fold_in(k, h32(name.encode('utf-8')))
+    return fold_in(k, counter)
+  if variant not in ('lazy', 'lazy_sep'):
+    raise ValueError(f'flax rng variant {variant!r}')
+  sep = b'\x00' if variant == 'lazy_sep' else b''
+  data = b''.join(sep + (x.encode('utf-8') if isinstance(x, str) else ib(x)) for x in tuple(path) + (counter,))
+  return fold_in(root, h32(data))
+
+
 def step_jitter_max_levels():
   """The level cap of the fused launch, read from the library (csrc/hugs_prng.hip HUGS_STEP_JITTER_MAX_LEVELS)."""
   return int(L.lib().cdll.hugs_prng_step_jitter_max_levels())

@@ -78,3 +78,38 @@ def normal(key, shape=()):
   lo = np.nextafter(np.float32(-1.), np.float32(0.))
   u = uniform(key, shape, lo, 1.)
   return (np.float32(np.sqrt(2)) * erfinv(u.astype(np.float64)).astype(np.float32)).astype(np.float32)
+
+
+def fold_in(key, data):
+  """jax.random.fold_in(key, data): threefry_2x32(key, threefry_seed(uint32 data)) -- the seed words are (0, data)."""
+  y0, y1 = threefry2x32(key, np.array([0], np.uint32), np.array([int(data) & 0xFFFFFFFF], np.uint32))
+  return np.array([y0[0], y1[0]], np.uint32)
+
+
+def flax_param_key(root, path, counter, variant='lazy'):
+  """The initialiser key of a flax parameter (restated from flax/core/scope.py as published; flax is absent here: UNPINNED).
+  'lazy' (LazyRng, flax >= 0.6): fold_in(root, uint32(sha1(b''.join(path names as utf-8 + counter big-endian bytes))[:4]));
+  'lazy_sep': the same with a 0x00 byte before every component (config.flax_fix_rng_separator);
+  'legacy': fold_in(sha1(name)[:4]) per scope on the way down (Scope.push / _fold_in_str), then fold_in(counter)."""
+  import hashlib
+  h32 = lambda b: int.from_bytes(hashlib.sha1(b).digest()[:4], 'big')
+  if variant == 'legacy':
+    k = root
+    for name in path:
+      k = fold_in(k, h32(name.encode()))
+    return fold_in(k, counter)
+  sep = b'\x00' if variant == 'lazy_sep' else b''
+  parts = [sep + (x.encode() if isinstance(x, str) else x.to_bytes((x.bit_length() + 7) // 8, 'big')) for x in tuple(path) + (counter,)]
+  return fold_in(root, h32(b''.join(parts)))
+
+
+def he_uniform(key, shape):
+  """jax.nn.initializers.he_uniform()(key, shape, float32) = variance_scaling(2.0, 'fan_in', 'uniform'):
+  random.uniform(key, shape, float32, -1) * sqrt(3 * variance), variance = float32(2 / fan_in), fan_in = shape[-2]."""
+  variance = np.float32(2.0 / shape[-2])
+  return (uniform(key, shape, -1.0, 1.0) * np.sqrt(np.float32(3.0) * variance)).astype(np.float32)
+
+
+def embed_init(key, shape):
+  """flax nn.Embed's default_embed_init = variance_scaling(1.0, 'fan_in', 'normal', out_axis=0): fan_in = features."""
+  return (normal(key, shape) * np.sqrt(np.float32(1.0 / shape[-1]))).astype(np.float32)

@@ -173,3 +173,43 @@ def test_train_step_consumes_the_stream_as_before():
   for a, b in zip(fused, chain):
     assert a.shape == b.shape and torch.equal(a, b)
   configs.clear_config()
+
+
+def test_fold_in_and_flax_init_stream_vs_oracle():
+  """random.fold_in and Model.init_flax (flax's `model.init(rng, ...)` stream, models.py:348-356: he_uniform Dense kernels,
+  nn.Embed's normal tables, keys folded from the parameter path) bit for bit against the restatement in
+  oracle/threefry_ref.py, for the three published folding rules.  The restatement itself is UNPINNED (no flax / jax here)."""
+  from oracle import threefry_ref as T
+  from nerf_hugs_amd.internal import configs, models, random as hr
+  key = hr.PRNGKey(20200823)
+  okey = T.prng_key(20200823)
+  for d in (0, 1, 7, 0x9E3779B9, 0xFFFFFFFF):
+    assert np.array_equal(hr.fold_in(key, d).cpu().numpy().view(np.uint32), T.fold_in(okey, d)), d
+  # fold_in(key, d) is split's first counter pair generalised: split(key)[0] uses counters (0, 2), fold_in(key, 2) uses (0, 2)
+  assert np.array_equal(T.fold_in(okey, 2), np.array([T.split(okey)[0][0], T.split(okey)[1][0]], np.uint32))
+  configs.clear_config()
+  configs.parse_config_files_and_bindings(None, ["NerfMLP.net_width = 128", "PropMLP.net_width = 128", "NerfMLP.net_depth = 6", "PropMLP.net_depth = 2",
+                                                 "Model.num_glo_features = 4", "Model.num_embeddings = 12", "PropMLP.disable_rgb = True"])
+  model = models.Model(configs.make_config())
+  for variant in ('lazy', 'lazy_sep', 'legacy'):
+    flat = model.init(key, flax_rng=variant)
+    seen = set()
+    for lf in model.layout.leaves:
+      got = model.layout.view(flat, lf['path']).cpu().numpy()
+      if lf['path'][-1] == 'bias':
+        assert not got.any()
+        continue
+      k = T.flax_param_key(okey, lf['path'][:-1], 1, variant)
+      ref = T.he_uniform(k, lf['shape']) if lf['path'][-1] == 'kernel' else T.embed_init(k, lf['shape'])
+      if lf['path'][-1] == 'kernel':
+        assert np.array_equal(got, ref), (variant, lf['path'])
+        lim = np.sqrt(6.0 / lf['shape'][0])
+        assert np.abs(got).max() <= lim * (1 + 1e-6) and got.std() > 0.5 * lim      # U(-lim, lim): std = lim / sqrt(3)
+      else:
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-7)      # (erf_inv: the device polynomial vs scipy, as test_normal_vs_oracle)
+      seen.add(tuple(k))
+    assert len(seen) == sum(1 for lf in model.layout.leaves if lf['path'][-1] != 'bias'), 'every parameter has its own key'
+  # construct_model(key, ...) takes the flax stream, construct_model(int, ...) torch's generator (the distributions only)
+  _, v1 = models.construct_model(key, None, configs.make_config())
+  assert torch.equal(v1, model.init(key, flax_rng='lazy'))
+  configs.clear_config()
