@@ -52,7 +52,7 @@ _PROTOS = {
     'hugs_prng_bits': 'pqps',
     'hugs_prng_uniform': 'pqffps',
     'hugs_prng_normal': 'pqps',
-    'hugs_prng_fold_in': 'pqps',
+    'hugs_prng_fold_in': 'pips',
     'hugs_prng_step_jitter': 'pipppps',
     'hugs_ssim': 'iiippffffpps',
     'hugs_mse': 'qpppps',

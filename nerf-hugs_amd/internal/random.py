@@ -67,7 +67,8 @@ def fold_in(key, data):
   """jax.random.fold_in(key, data) for a uint32 `data`."""
   _check(key)
   out = torch.empty(2, dtype=torch.int32, device=key.device)
-  L.call('hugs_prng_fold_in', key, int(data) & 0xFFFFFFFF, out)
+  d = int(data) & 0xFFFFFFFF
+  L.call('hugs_prng_fold_in', key, d - (1 << 32) if d >= (1 << 31) else d, out)      # (the same 32 bits as a C int)
   return out
 
 
