@@ -1426,17 +1426,24 @@ int HUGS_NT_IMPL(HUGS_NT_ARGS) {
     const int epi = row_bias ? -1 : (bias ? EPI_BIAS : 0) | (relu ? EPI_RELU : 0) | (mask ? EPI_MASK : 0) | (r1_row ? EPI_R1 : 0) |
                                     (bits_in ? EPI_BIN : 0) | (bits_out ? EPI_BOUT : 0);
     const int ntiles = (M / 256) * (N / 256), nstage = (K1 + K2) / 32;
-    static int ncu = 0;
-    if (!ncu) {
-      int dev = 0, n = 0;
-      HUGS_REQUIRE(hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess,
+    static int ncu_of[64] = {0};      // per device (a process may drive GPUs of different sizes)
+    int dev = 0;
+    HUGS_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, -100, "hugs_gemm_nt: hipGetDevice");
+    if (!ncu_of[dev]) {
+      int n = 0;
+      HUGS_REQUIRE(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess,
                    -100, "hugs_gemm_nt: cannot query the device's CU count");
       n &= ~7;
-      ncu = n < 8 ? 8 : n;
+      ncu_of[dev] = n < 8 ? 8 : n;
     }
+    const int ncu = ncu_of[dev];
     // more than one tile per CU: the persistent kernel (ring carried across tiles).  Needs an even number of stages
     // (fragment double buffer parity) and N <= 4096 (bias / r1 vectors in the 32 KiB the ring leaves).
-    if (ntiles > ncu && nstage % 2 == 0 && nstage >= 8 && N <= 4096 && tile_mode != 5) {
+    // (an epilogue combination without a specialisation -- a per-ray row bias, bias without relu + mask, ... -- stays on the
+    // one-tile-per-workgroup kernel: the run-time-flag epilogue on top of the persistent loop's live state spilled 44 VGPRs)
+    const bool pers_epi = epi == (EPI_BIAS | EPI_RELU) || epi == (EPI_BIAS | EPI_RELU | EPI_BOUT) || epi == EPI_BIN || epi == (EPI_BIN | EPI_R1) ||
+                          epi == EPI_BIAS || epi == EPI_MASK || epi == (EPI_MASK | EPI_R1) || epi == 0;
+    if (ntiles > ncu && nstage % 2 == 0 && nstage >= 8 && N <= 4096 && tile_mode != 5 && pers_epi) {
       const dim3 gp(ncu), bp(512);
 #define HUGS_NTP_LAUNCH(EPI_) hipLaunchKernelGGL((k_gemm_nt_bf16_pers<EPI_>), gp, bp, 0, (hipStream_t)stream, M, N, K1, K2, \
                        (const uint16_t*)A1, lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E, ntiles)
@@ -1448,8 +1455,7 @@ int HUGS_NT_IMPL(HUGS_NT_ARGS) {
         case EPI_BIAS: HUGS_NTP_LAUNCH(EPI_BIAS); break;
         case EPI_MASK: HUGS_NTP_LAUNCH(EPI_MASK); break;
         case EPI_MASK | EPI_R1: HUGS_NTP_LAUNCH(EPI_MASK | EPI_R1); break;
-        case 0: HUGS_NTP_LAUNCH(0); break;
-        default: HUGS_NTP_LAUNCH(-1); break;
+        default: HUGS_NTP_LAUNCH(0); break;      // epi == 0
       }
 #undef HUGS_NTP_LAUNCH
       HUGS_CHECK_LAUNCH("hugs_gemm_nt(persistent)");

@@ -332,3 +332,14 @@ def test_nerfacto_yml_configs():
   kw = C.yml_to_kwargs(yaml.safe_load(open(os.path.join(ref, 'phototourism_nerfacto_base.yml'))))
   kw.pop('use_transient_embedding')
   assert kw == C.PHOTOTOURISM_NERFACTO_BASE
+
+
+def test_stop_level_grad_false_is_refused_at_construction():
+  """Model.stop_level_grad = False (models.py:55,208-209: gradients through the resampling step) is not built: it raises when
+  the model is configured, not somewhere inside a step (INTEGRATION.md lists the refused options)."""
+  from nerf_hugs_amd.internal import configs, models
+  configs.clear_config()
+  configs.parse_config_files_and_bindings(None, ["Model.stop_level_grad = False"])
+  with pytest.raises(NotImplementedError, match='stop_level_grad'):
+    models.Model(configs.make_config())
+  configs.clear_config()
