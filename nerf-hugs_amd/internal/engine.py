@@ -17,6 +17,8 @@ _USE_BITS = __import__('os').environ.get('HUGS_RELU_BITS', '1') != '0'        # 
 # batched launch of all layers after the dX chain, 2 = two batched launches (upper half of the layers under the lower half's
 # dX GEMMs, the rest after the chain)
 _TN_BATCH = int(__import__('os').environ.get('HUGS_TN_BATCH', '1'))
+_DW_AFTER_PROP = __import__('os').environ.get('HUGS_DW_AFTER_PROP', '1') == '1'
+_SIDE_LATE = __import__('os').environ.get('HUGS_SIDE_LATE', '0') == '1'      # A/B: side-stream work released behind the G_last GEMM
 _TN_ITEM = np.dtype([('X', np.uint64), ('G', np.uint64), ('dW', np.uint64), ('db', np.uint64), ('ldx', np.int32), ('ldg', np.int32),
                      ('Mrows', np.int32), ('Kc', np.int32), ('N', np.int32), ('reserved', np.int32)])      # include/hugs.h HugsTnItem
 _CHUNK_BYTES = int(float(__import__('os').environ.get('HUGS_FWD_CHUNK_MB', '1e9')) * 1e6)   # forward row-chunk size (A/B knob)
@@ -615,7 +617,8 @@ class Engine:
     be[:3].add_(r_)
     return We, be
 
-  def backward_level(self, theta, grad, lv, rays, N, d_rgb_out, d_w_extra, nerfw=None, leaf_done=None, lane=0):
+  def backward_level(self, theta, grad, lv, rays, N, d_rgb_out, d_w_extra, nerfw=None, leaf_done=None, lane=0, after_heads=None,
+                     before_dw=None):
     """Backward of one level: compositing -> heads -> trunk.  Writes (=, not +=) the level's MLP gradients
     into `grad` (flat, same layout as theta); GLO embedding rows are scatter-added (caller zeroes them).
     leaf_done(lo, hi): optional callback, called on the stream that produced them as soon as the gradient
@@ -701,15 +704,19 @@ class Engine:
       # underneath the trunk GEMMs.
       cur = torch.cuda.current_stream()
       hl = self._side_stream(lane + 3)
-      ev_gv = new_event(); ev_gv.record(cur)
-      with torch.cuda.stream(hl):
-        wait_event(hl, ev_gv)
+
+      def head_dw_1():
         _lib.call('hugs_density_bwd', dt, M, W, Ylast, W, None, lv['raw'], spec.density_bias, d_raw,
                   gview((spec.name, ld['name'], 'kernel'), True).reshape(-1), gview((spec.name, ld['name'], 'bias')), dws)
         _lib.call('hugs_raybias_bwd', dt, N, S, H, spec.nd, spec.num_glo, Gv, H, rays['dir_enc'], lv['glo'], Wv[Bw:],
                   rays.get('embed_idx'), d_rb, gWv[Bw:], demb)
         # dWv[:Bw] = bott^T Gv ; db_v = colsum(Gv)
         self._tn(M, Bw, H, lv['bott'], Bw, Gv, H, gWv[:Bw], gview((spec.name, lvw['name'], 'bias')))
+      if not _SIDE_LATE:
+        ev_gv = new_event(); ev_gv.record(cur)
+        with torch.cuda.stream(hl):
+          wait_event(hl, ev_gv)
+          head_dw_1()
       dB = ws.get(tag + '/dBott', (M, Bw), self.tdt)
       if nerfw is not None:
         G0t = self._transient_backward(theta, grad, lv, rays, N, d_dt, d_ct, d_u)
@@ -721,15 +728,18 @@ class Engine:
         # dBott = Gv Wv[:Bw]^T
         _lib.call('hugs_gemm_nt', dt, M, Bw, H, 0, Gv, H, None, 0, self.wn[(spec.name, lvw['name'], 'kernel')], H, None,
                   None, 1, 0, 0, None, 0, None, None, dB, Bw)
-      ev_db = new_event(); ev_db.record(cur)
-      with torch.cuda.stream(hl):
-        wait_event(hl, ev_db)
+      def head_dw_2():
         self._tn(M, W, Bw, Ylast, W, dB, Bw, gview((spec.name, lb['name'], 'kernel'), True), gview((spec.name, lb['name'], 'bias')))
         if leaf_done is not None:      # density / bottleneck / view / rgb (/ transient) layers: everything behind the trunk
           first = lay.by_path[(spec.name, spec.layers[spec.net_depth]['name'], 'kernel')]
           last = lay.by_path[(spec.name, spec.layers[-1]['name'], 'bias')]
           leaf_done(first['off'], last['off'] + int(np.prod(last['pshape'])))
-        heads_done = new_event(); heads_done.record(hl)
+      if not _SIDE_LATE:
+        ev_db = new_event(); ev_db.record(cur)
+        with torch.cuda.stream(hl):
+          wait_event(hl, ev_db)
+          head_dw_2()
+          heads_done = new_event(); heads_done.record(hl)
       # G_last = (dBott Wb^T + d_raw (x) w_d) * (Ylast > 0)
       blast = lv['bits'][spec.net_depth - 1] if lv.get('bits') else None
       if blast is not None and Bw >= 256:
@@ -738,6 +748,14 @@ class Engine:
       else:
         _lib.call('hugs_gemm_nt', dt, M, W, Bw, 0, dB, Bw, None, 0, self.wn[(spec.name, lb['name'], 'kernel')], Bw, None, None,
                   1, 0, 0, Ylast, W, d_raw, wd, Ga, W)
+      if _SIDE_LATE:      # (A/B: the head weight gradients and whatever `after_heads` launches start behind G_last)
+        ev_gl = new_event(); ev_gl.record(cur)
+        with torch.cuda.stream(hl):
+          wait_event(hl, ev_gl)
+          head_dw_1(); head_dw_2()
+          heads_done = new_event(); heads_done.record(hl)
+    if after_heads is not None:
+      after_heads()
     if (spec.disable_rgb or not spec.use_viewdirs) and leaf_done is not None:
       first = lay.by_path[(spec.name, spec.layers[spec.net_depth]['name'], 'kernel')]
       last = lay.by_path[(spec.name, spec.layers[-1]['name'], 'bias')]
@@ -777,6 +795,12 @@ class Engine:
           ev = new_event(); ev.record(main)
           with torch.cuda.stream(side):
             wait_event(side, ev)
+            if i == 0 and before_dw is not None and _DW_AFTER_PROP:
+              # the batched launch holds every CU for its whole duration (one workgroup per CU, all registers): whatever another
+              # stream still has queued would sit behind it -- at the reference-default shape the proposal levels' last dX GEMM
+              # ran 7.0 ms next to it and their own weight-gradient launch came after (profiles/r04_ref360_timeline.txt)
+              for e_ in before_dw():
+                wait_event(side, e_)
             items = []
             for j in range(hi, i - 1, -1):
               lj = trunk[j]

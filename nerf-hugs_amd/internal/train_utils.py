@@ -477,7 +477,7 @@ def create_train_step(model, config, is_finetune=False):
       ar_ranges.append((lo, hi))
       ar_works.append(dist.all_reduce(grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
-    def level_backward(l, lane):
+    def level_backward(l, lane, after=None, before_dw=None):
       nonlocal prop_done
       coef = config.data_loss_mult if l == L - 1 else config.data_coarse_loss_mult
       is_prop = l < L - 1
@@ -490,10 +490,11 @@ def create_train_step(model, config, is_finetune=False):
         tgt = ws.get('grad_tmp', (layout.size + STAT_TAIL,))
       bucketed = bucket_done if (reduce and world > 1 and not is_prop and not is_finetune and _AR_BUCKETS) else None
       if tt == 'nerfw' and not is_prop:
-        eng.backward_level(state.flat, tgt, levels[l], rays, N, None, d_w[l], nerfw=nw, leaf_done=bucketed, lane=lane)
+        eng.backward_level(state.flat, tgt, levels[l], rays, N, None, d_w[l], nerfw=nw, leaf_done=bucketed, lane=lane, after_heads=after,
+                           before_dw=before_dw)
       else:
         eng.backward_level(state.flat, tgt, levels[l], rays, N, d_pred[l] if coef != 0 else None, d_w[l], leaf_done=bucketed,
-                           lane=lane)
+                           lane=lane, after_heads=after, before_dw=before_dw)
       if is_prop and prop_done:
         _lib.call('hugs_add_inplace', prop_hi - prop_lo, tgt[prop_lo:prop_hi], grad[prop_lo:prop_hi])
       if is_prop:
@@ -504,16 +505,24 @@ def create_train_step(model, config, is_finetune=False):
     # underneath the NerfMLP trunk backward (whose GEMMs fill the chip; the proposal kernels fit in their tails).
     bwd_main = torch.cuda.current_stream()
     prop_stream = eng._side_stream(1)
-    ev_loss = _engine.new_event(); ev_loss.record(bwd_main)
-    with torch.cuda.stream(prop_stream):
-      _engine.wait_event(prop_stream, ev_loss)
-      for l in range(L - 2, -1, -1):
-        level_backward(l, 2)
-      if not prop_done:
-        grad[prop_lo:prop_hi].zero_()
-      ev_prop = _engine.new_event(); ev_prop.record(prop_stream)
-    level_backward(L - 1, 0)
-    _engine.wait_event(bwd_main, ev_prop)
+    box = {}
+
+    def launch_prop():
+      ev_loss = _engine.new_event(); ev_loss.record(bwd_main)
+      with torch.cuda.stream(prop_stream):
+        _engine.wait_event(prop_stream, ev_loss)
+        for l in range(L - 2, -1, -1):
+          level_backward(l, 2)
+        if not prop_done:
+          grad[prop_lo:prop_hi].zero_()
+        box['ev'] = _engine.new_event(); box['ev'].record(prop_stream)
+    prop_events = lambda: [box['ev']] if 'ev' in box else []
+    if _engine._SIDE_LATE:
+      level_backward(L - 1, 0, after=launch_prop, before_dw=prop_events)
+    else:
+      launch_prop()
+      level_backward(L - 1, 0, before_dw=prop_events)
+    _engine.wait_event(bwd_main, box['ev'])
     if ev_mask_bwd is not None:
       _engine.wait_event(torch.cuda.current_stream(), ev_mask_bwd)
     # ---- pmean(grad), pmean(stats) ------------------------------------------------------------------
