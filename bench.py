@@ -61,7 +61,7 @@ def instep_roofline(train_step, state, batch, gen, thr, steps=5):
   events on the stream it is launched on (nerf_hugs_amd/_lib.py PROFILE hook; the side stream for the weight-gradient
   GEMMs).  `roofline` is the forward NerfMLP trunk layer [131072,1024]x[1024,1024]^T + bias + relu; the masked dX and
   the dW GEMM of the same shape are reported next to it.  `traffic` = HBM bytes per launch from the rocprofv3 PMC
-  passes of THIS round's kernels, committed as profiles/r03_gemm_traffic.json (2 x FETCH_SIZE + WRITE_SIZE,
+  passes of THIS round's kernels, committed as profiles/r04_gemm_traffic.json (2 x FETCH_SIZE + WRITE_SIZE,
   MI355X_MICROARCH.md HBM section; `traffic_source` names the file and the kernel's duration under the profiler next to
   the in-step one), null when that file is absent."""
   from nerf_hugs_amd import _lib
@@ -74,7 +74,7 @@ def instep_roofline(train_step, state, batch, gen, thr, steps=5):
   for name, key, e0, e1 in recs:
     agg.setdefault(key, []).append(e0.elapsed_time(e1) * 1e3)     # us
   traffic = {}
-  tpath = os.path.join(ROOT, 'profiles', 'r03_gemm_traffic.json')
+  tpath = os.path.join(ROOT, 'profiles', 'r04_gemm_traffic.json')
   if os.path.exists(tpath):
     traffic = json.load(open(tpath))
 
@@ -86,8 +86,8 @@ def instep_roofline(train_step, state, batch, gen, thr, steps=5):
     t = traffic.get(tkey, {})
     return {"bound": "mfma", "kernel": label, "launches": len(agg[key]), "avg_us": round(us, 1), "achieved": round(tf, 1),
             "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(tf * 1e12 / PEAK_BF16, 4),
-            "traffic": t.get("hbm_bytes_per_launch"), "algorithmic_bytes": alg_bytes,
-            "traffic_source": (f"profiles/r03_gemm_traffic.json[{tkey}]: separate rocprofv3 --pmc passes, {t.get('avg_us_profiled')} us per launch "
+            "traffic": t.get("hbm_bytes_per_launch"), "algorithmic_bytes": alg_bytes if alg_bytes is not None else t.get("algorithmic_bytes"),
+            "traffic_source": (f"profiles/r04_gemm_traffic.json[{tkey}]: separate rocprofv3 --pmc passes, {t.get('avg_us_profiled')} us per launch "
                                f"under the profiler vs {round(us, 1)} us in-step") if t else None}
 
   W = 1024

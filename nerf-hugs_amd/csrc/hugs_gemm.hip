@@ -887,12 +887,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(int Mrows, int Kc, int 
 // (Round-2 measurement builds -- no DMA / no fragment reads / no MFMA / L2-resident loads / no barrier / uncounted waits,
 // 8:6 / 4:3 / DS-first interleaves, an L2 prefetch of the XCD siblings' lines -- are in the git history; DESIGN.md
 // section 4 has their numbers.)
+#ifndef HUGS_TN_SYNC
+#define HUGS_TN_SYNC 128      // batched launch: stages between two re-alignments of a tile group (even)
+#endif
 // One 256x256 tile of D = X^T G over the reduction rows [mbeg, mbeg + 32 ns): the body shared by the per-layer kernel
 // (k_gemm_tn_bf16_big) and the batched one (k_gemm_tn_bf16_batch).  out: this split's fp32 slab [Kc, lds_out]; colsum:
 // this split's bias-gradient row [N] or null.  ns must be even and >= 8.
 __device__ __forceinline__ void tn_big_tile(const uint16_t* __restrict__ X, int ldx, const uint16_t* __restrict__ G, int ldg,
                                             int mbeg, int ns, int c0, int n0, float* __restrict__ out, int lds_out,
-                                            float* __restrict__ colsum) {
+                                            float* __restrict__ colsum, unsigned* sync_ctr = nullptr, int sync_n = 0) {
   // stage layout: per operand 16 row PAIRS of 1 KiB (rows 2p, 2p+1 as the LDS-DMA writes them) at a 1056-byte
   // pitch: the 8 rows one 32-lane group of a transpose read touches have distinct p, so they land 8 banks apart
   // (1056 B = 264 dwords = 8 mod 64) with NO address swizzle: every fragment read is base + immediate.
@@ -1028,6 +1031,25 @@ __device__ __forceinline__ void tn_big_tile(const uint16_t* __restrict__ X, int 
     asm volatile("" ::: "memory");
     load_frags(f0, 0);
     int st = 0;
+    if (sync_ctr) {
+      // Best-effort re-alignment of the workgroups that share operand panels (the tiles of one (item, piece): same X / G row
+      // block, one XCD): over a 2048-stage loop they drift apart and the panel a neighbour fetched has left the 4 MB L2 by the
+      // time the next one asks for it (PMC: 1.58x the algorithmic bytes, against 1.28x for the 256-stage per-layer launch).
+      // Every HUGS_TN_SYNC stages one lane announces the group's arrival count and waits -- a BOUNDED number of polls, so a
+      // group member that is not resident yet (another kernel holds its CU) delays nobody for long.
+      unsigned epoch = 0;
+      for (int lim = HUGS_TN_SYNC; lim + 5 < ns; lim += HUGS_TN_SYNC) {
+        for (; st < lim; st += 2) { GT_ITER4(f0, f1, st, 8, 1) GT_ITER4(f1, f0, st + 1, 8, 1) }
+        ++epoch;
+        if (threadIdx.x == 0) {
+          __hip_atomic_fetch_add(sync_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned want = epoch * (unsigned)sync_n;
+          for (int spin = 0; spin < 512 && __hip_atomic_load(sync_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want; ++spin)
+            __builtin_amdgcn_s_sleep(8);
+        }
+        __builtin_amdgcn_s_barrier();
+      }
+    }
     for (; st + 5 < ns; st += 2) { GT_ITER4(f0, f1, st, 8, 1) GT_ITER4(f1, f0, st + 1, 8, 1) }
     GT_ITER4(f0, f1, st, 8, 0)
     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
@@ -1107,7 +1129,7 @@ struct TnBatchItem {
   float* colsum;        // [nsplit][N] or null
   int ldx, ldg, Kc, N, units, wg0, tiles, pad_;
 };
-struct TnBatch { int nitems, nsplit; TnBatchItem it[HUGS_TN_BATCH_MAX]; };
+struct TnBatch { int nitems, nsplit; unsigned* sync; TnBatchItem it[HUGS_TN_BATCH_MAX]; };
 __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_batch(const TnBatch B) {
   const int vb = xcd_remap(blockIdx.x, gridDim.x);
   int i = 0;
@@ -1119,7 +1141,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_tn_bf16_batch(const TnBatch B) 
   const int c0 = (tt / ntn) << 8, n0 = (tt % ntn) << 8;
   const int u0 = (int)(((long long)split * I.units) / B.nsplit), u1 = (int)(((long long)(split + 1) * I.units) / B.nsplit);
   tn_big_tile(I.X, I.ldx, I.G, I.ldg, u0 << 6, (u1 - u0) << 1, c0, n0, I.slab + (size_t)split * I.Kc * I.N, I.N,
-              I.colsum ? I.colsum + (size_t)split * I.N : nullptr);
+              I.colsum ? I.colsum + (size_t)split * I.N : nullptr, B.sync ? B.sync + (i * B.nsplit + split) : nullptr, I.tiles);
 }
 
 #ifndef HUGS_GEMM_F16
@@ -1507,6 +1529,18 @@ int HUGS_TNB_IMPL(int nitems, const HugsTnItem* items, int nsplit, void* ws, voi
   B.nitems = nitems; B.nsplit = nsplit;
   R.nitems = 0; R.nsplit = nsplit;
   float* w = (float*)ws;
+  // group arrival counters (one per (item, piece)) in front of the slabs: zeroed by a memset node ahead of the launch.  Only where
+  // a group is more than one workgroup and the loop is long enough to drift (HUGS_TN_BATCH_SYNC=0: off)
+  static const bool sync_on = []() { const char* e = getenv("HUGS_TN_BATCH_SYNC"); return !(e && e[0] == '0'); }();
+  bool want_sync = sync_on && nitems * nsplit <= 256;
+  for (int i = 0; i < nitems; ++i)
+    if ((items[i].Kc >> 8) * (items[i].N >> 8) < 2 || (items[i].Mrows >> 5) / nsplit <= 2 * HUGS_TN_SYNC) want_sync = false;
+  B.sync = nullptr;
+  if (want_sync) {
+    B.sync = (unsigned*)w;
+    if (hipMemsetAsync(w, 0, 256 * sizeof(float), (hipStream_t)stream) != hipSuccess) B.sync = nullptr;
+  }
+  w += 256;
   int wg = 0;
   unsigned blk = 0;
   for (int i = 0; i < nitems; ++i) {
@@ -1565,7 +1599,7 @@ extern "C" int hugs_gemm_tn_batch_nsplit(int nitems, const HugsTnItem* items) {
 extern "C" long long hugs_gemm_tn_batch_ws_bytes(int nitems, const HugsTnItem* items, int nsplit) {
   long long n = 0;
   for (int i = 0; i < nitems; ++i) n += (long long)nsplit * ((long long)items[i].Kc * items[i].N + items[i].N);
-  return n * 4;
+  return (n + 256) * 4;      // + the tile groups' arrival counters
 }
 extern "C" int hugs_gemm_tn_batch(int dtype, int nitems, const HugsTnItem* items, int nsplit, void* ws, void* stream) {
   if (int rc = tn_batch_check(dtype, nitems, items)) return rc;
