@@ -109,6 +109,8 @@ int hugs_glo_gather(int nrays, int ng, const float* embedding, const int* embed_
 /* models.py:488-512: the per-ray constant part of the view layer, rb[ray] = b + [dir_enc|glo] * Wv[bottleneck:] */
 int hugs_raybias_fwd(int nrays, int H, int nd, int ng, const float* dir_enc, const float* glo, const float* Wv_tail,
                      const float* bias, float* rb, void* stream);
+/* (d_rb: workspace of hugs_raybias_bwd_ws_rows(nrays, nd, ng) rows of H floats: the per-ray sums + the ray chunks' partial products) */
+long long hugs_raybias_bwd_ws_rows(int nrays, int nd, int ng);
 int hugs_raybias_bwd(int dtype, int nrays, int S, int H, int nd, int ng, const void* G, int ldg, const float* dir_enc,
                      const float* glo, const float* Wv_tail, const int* embed_idx, float* d_rb, float* dWv_tail,
                      float* d_embedding, void* stream);

@@ -132,7 +132,7 @@ class _Lib:
           'There is no CPU fallback.')
     self.cdll = ctypes.CDLL(LIB_PATH)
     self.cdll.hugs_last_error.restype = ctypes.c_char_p
-    for n_ in ('hugs_gemm_tn_batch_ws_bytes', 'hugs_gemm_tn_ws_bytes', 'hugs_density_bwd_ws_bytes', 'hugs_rgb_bwd_ws_bytes', 'hugs_ssim_ws_bytes', 'hugs_gemm_nt_bits_bytes', 'hugs_nf_prop_ws_bytes'):
+    for n_ in ('hugs_raybias_bwd_ws_rows', 'hugs_gemm_tn_batch_ws_bytes', 'hugs_gemm_tn_ws_bytes', 'hugs_density_bwd_ws_bytes', 'hugs_rgb_bwd_ws_bytes', 'hugs_ssim_ws_bytes', 'hugs_gemm_nt_bits_bytes', 'hugs_nf_prop_ws_bytes'):
       getattr(self.cdll, n_).restype = ctypes.c_longlong
     self.cdll.hugs_gemm_tn_batch_ws_bytes.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
     for name, sig in _PROTOS.items():

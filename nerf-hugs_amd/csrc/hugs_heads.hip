@@ -5,6 +5,7 @@
 // :488-512 view-direction / GLO concat feeding Dense(128) -- the per-ray constant part of that matmul is
 // hoisted into a per-ray bias; :514-519 rgb = sigmoid(Dense(3)) * (1+2*pad) - pad.
 #include "hugs_common.h"
+#include <algorithm>
 
 template <int BF16>
 __device__ __forceinline__ void load8(const void* base, size_t elem_off, float v[8]) {
@@ -42,27 +43,36 @@ __device__ __forceinline__ float softplusf(float x) {  // logaddexp(x, 0)
 }
 
 // ---- density head forward: raw[m] = Y[m,:] . w + b ; density = softplus(raw + density_bias) ----
+// LPR = lanes that share a row = min(64, K/8 rounded up to a power of two): a 256-wide PropMLP row is 32 lanes x 16 bytes, so a
+// wave reads TWO rows per load instruction (round 4: with one row per wave half the lanes idled and every row paid a 6-step
+// shuffle reduction: 300 us per 1 M x 256 rows = 1.7 TB/s); two row groups are kept in flight.
 template <int BF16>
-__global__ __launch_bounds__(256) void k_density_fwd(int M, int K, const void* __restrict__ Y, int ldy,
+__global__ __launch_bounds__(256) void k_density_fwd(int M, int K, int lpr, const void* __restrict__ Y, int ldy,
                                                      const float* __restrict__ w, const float* __restrict__ b,
                                                      float density_bias, float* __restrict__ raw,
                                                      float* __restrict__ density) {
   const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int rpw = 64 / lpr, sub = lane / lpr, l = lane % lpr;          // rows per wave, this lane's row of the group, its column lane
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
   const float bb = b[0];
-  for (int m = wave; m < M; m += nwaves) {
+  auto dot = [&](long long m) {
     float acc = 0.f;
-    for (int k0 = lane * 8; k0 < K; k0 += 512) {
-      float v[8];
-      load8<BF16>(Y, (size_t)m * ldy + k0, v);
-      const float4 w0 = *(const float4*)(w + k0), w1 = *(const float4*)(w + k0 + 4);
-      acc += v[0] * w0.x + v[1] * w0.y + v[2] * w0.z + v[3] * w0.w + v[4] * w1.x + v[5] * w1.y + v[6] * w1.z + v[7] * w1.w;
-    }
-    acc = wave_sum_f(acc);
-    if (lane == 0) {
-      const float r = acc + bb;
-      raw[m] = r;
-      density[m] = softplusf(r + density_bias);
+    if (m < M)
+      for (int k0 = l * 8; k0 < K; k0 += lpr * 8) {
+        float v[8];
+        load8<BF16>(Y, (size_t)m * ldy + k0, v);
+        const float4 w0 = *(const float4*)(w + k0), w1 = *(const float4*)(w + k0 + 4);
+        acc += v[0] * w0.x + v[1] * w0.y + v[2] * w0.z + v[3] * w0.w + v[4] * w1.x + v[5] * w1.y + v[6] * w1.z + v[7] * w1.w;
+      }
+    return acc;
+  };
+  for (long long g = wave * 2; g * rpw < M; g += nwaves * 2) {
+    const long long m0 = g * rpw + sub, m1 = (g + 1) * rpw + sub;
+    float a0 = dot(m0), a1 = dot(m1);
+    for (int d = 1; d < lpr; d <<= 1) { a0 += __shfl_xor(a0, d); a1 += __shfl_xor(a1, d); }
+    if (l == 0) {
+      if (m0 < M) { const float r = a0 + bb; raw[m0] = r; density[m0] = softplusf(r + density_bias); }
+      if (m1 < M) { const float r = a1 + bb; raw[m1] = r; density[m1] = softplusf(r + density_bias); }
     }
   }
 }
@@ -75,30 +85,42 @@ __global__ void k_density_bwd_raw(int M, const float* __restrict__ d_density, co
 }
 
 // weighted column sums: slab[blk][k] = sum_{m in blk} r[m] * Y[m,k]; slab[blk][K] = sum r[m]   (K <= 2048)
+// Thread (rr, c): column chunk c of C = K/8, row lane rr of R = 256 / C: a block reads R rows per step, 16 bytes per lane, every
+// lane busy (round 4: with one thread per chunk walking all rows a 256-wide PropMLP used 32 of 256 threads: 0.36 TB/s).  The R
+// partial sums of a column are added in LDS in row-lane order: deterministic.
 template <int BF16>
 __global__ __launch_bounds__(256) void k_wcolsum(int M, int K, int rows_per_blk, const void* __restrict__ Y, int ldy,
                                                  const float* __restrict__ r, float* __restrict__ slab) {
-  // thread t owns columns [8t, 8t+8) (K/8 <= 256 threads active); rows are walked sequentially
-  const int t = threadIdx.x;
+  __shared__ float red[256 * 9];
+  const int t = threadIdx.x, C = K >> 3, R = C >= 256 ? 1 : 256 / C;
+  const int c = t % C, rr = t / C;
   const int m0 = blockIdx.x * rows_per_blk, m1 = min(M, m0 + rows_per_blk);
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   float rs = 0.f;
-  if (t * 8 < K) {
+  if (rr < R) {
 #pragma unroll 4
-    for (int m = m0; m < m1; ++m) {
+    for (int m = m0 + rr; m < m1; m += R) {
       float v[8];
-      load8<BF16>(Y, (size_t)m * ldy + t * 8, v);
+      load8<BF16>(Y, (size_t)m * ldy + c * 8, v);
       const float rm = r[m];
 #pragma unroll
       for (int q = 0; q < 8; ++q) acc[q] += rm * v[q];
+      rs += rm;
     }
-    float* o = slab + (size_t)blockIdx.x * (K + 4) + t * 8;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) o[q] = acc[q];
   }
-  if (t == 255) {
-    for (int m = m0; m < m1; ++m) rs += r[m];
-    slab[(size_t)blockIdx.x * (K + 4) + K] = rs;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) red[t * 9 + q] = acc[q];
+  red[t * 9 + 8] = rs;
+  __syncthreads();
+  if (t < C) {
+    float o[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int g = 0; g < R; ++g)
+#pragma unroll
+      for (int q = 0; q < 9; ++q) o[q] += red[(g * C + t) * 9 + q];
+    float* dst = slab + (size_t)blockIdx.x * (K + 4) + t * 8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dst[q] = o[q];
+    if (t == 0) slab[(size_t)blockIdx.x * (K + 4) + K] = o[8];
   }
 }
 
@@ -156,32 +178,43 @@ __global__ void k_raybias_fwd(int nrays, int H, int nd, int ng, const float* __r
 //   dWv_tail[c,j] = sum_ray enc[ray,c] d_rb[ray,j];  d_glo[ray,g] = sum_j d_rb[ray,j] Wv_tail[nd+g, j]
 template <int BF16>
 __global__ void k_segsum(int nrays, int S, int H, const void* __restrict__ G, int ldg, float* __restrict__ d_rb) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nrays * H) return;
-  const int ray = i / H, j = i % H;
-  float a = 0.f;
+  // thread = (ray, 8-column chunk): 16-byte loads, H/8 lanes per row (round 4; a thread per column read 2 bytes per lane)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, C = H >> 3;
+  if (i >= nrays * C) return;
+  const int ray = i / C, c = i % C;
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
   for (int s = 0; s < S; ++s) {
-    const size_t off = (size_t)(ray * S + s) * ldg + j;
-    a += BF16 ? op16_to_f(((const uint16_t*)G)[off], BF16) : ((const float*)G)[off];
+    float v[8];
+    load8<BF16>(G, (size_t)(ray * S + s) * ldg + c * 8, v);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] += v[q];
   }
-  d_rb[i] = a;
+  float* o = d_rb + (size_t)ray * H + c * 8;
+  *(float4*)o = make_float4(a[0], a[1], a[2], a[3]);
+  *(float4*)(o + 4) = make_float4(a[4], a[5], a[6], a[7]);
 }
+#define RBW_CHUNK 512      // rays per workgroup of k_raybias_bwd_w
 __global__ __launch_bounds__(1024) void k_raybias_bwd_w(int nrays, int H, int nd, int ng, const float* __restrict__ dir_enc,
                                                         const float* __restrict__ glo, const float* __restrict__ d_rb,
-                                                        float* __restrict__ dWv_tail) {
-  // one workgroup per encoding column c: 128 j-lanes x 8 ray groups, LDS reduce in fixed order (H == 128)
+                                                        float* __restrict__ dWv_tail, float* __restrict__ part) {
+  // workgroup (c, chunk): encoding column c, rays [chunk * RBW_CHUNK, +RBW_CHUNK): 128 j-lanes x 8 ray groups, LDS reduce in
+  // fixed order (H == 128).  One chunk (<= RBW_CHUNK rays): the result goes straight to dWv_tail; more: to part[chunk][c][j],
+  // summed by k_slab_reduce_small in chunk order (round 4: one workgroup per column walked ALL rays -- 1.2 ms at 16 384 rays).
   __shared__ float red[8][129];
   const int c = blockIdx.x, j = threadIdx.x & 127, rg = threadIdx.x >> 7;
+  const int r0 = blockIdx.y * RBW_CHUNK, r1 = min(nrays, r0 + RBW_CHUNK);
   float a = 0.f;
-  if (c < nd) for (int r = rg; r < nrays; r += 8) a += dir_enc[r * nd + c] * d_rb[(size_t)r * H + j];
-  else for (int r = rg; r < nrays; r += 8) a += glo[r * ng + (c - nd)] * d_rb[(size_t)r * H + j];
+  if (c < nd) for (int r = r0 + rg; r < r1; r += 8) a += dir_enc[r * nd + c] * d_rb[(size_t)r * H + j];
+  else for (int r = r0 + rg; r < r1; r += 8) a += glo[r * ng + (c - nd)] * d_rb[(size_t)r * H + j];
   red[rg][j] = a;
   __syncthreads();
   if (rg == 0) {
     float t = 0.f;
 #pragma unroll
     for (int g = 0; g < 8; ++g) t += red[g][j];
-    dWv_tail[c * H + j] = t;
+    if (gridDim.y == 1) dWv_tail[c * H + j] = t;
+    else part[((size_t)blockIdx.y * gridDim.x + c) * H + j] = t;
   }
 }
 __global__ void k_glo_bwd(int nrays, int H, int nd, int ng, const float* __restrict__ d_rb,
@@ -325,15 +358,18 @@ extern "C" int hugs_density_fwd(int dtype, int M, int K, const void* Y, int ldy,
                                 float density_bias, float* raw, float* density, void* stream) {
   HUGS_REQUIRE(K % 8 == 0, -3, "hugs_density_fwd: K=%d must be a multiple of 8", K);
   if (M <= 0) return 0;
-  const int grid = min((M + 3) / 4, 2048);
-  if (dtype == 2) hipLaunchKernelGGL(k_density_fwd<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, K, Y, ldy, w, b, density_bias, raw, density);
-  else if (dtype) hipLaunchKernelGGL(k_density_fwd<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, K, Y, ldy, w, b, density_bias, raw, density);
-  else hipLaunchKernelGGL(k_density_fwd<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, K, Y, ldy, w, b, density_bias, raw, density);
+  int lpr = 1;
+  while (lpr < 64 && lpr * 8 < K) lpr <<= 1;
+  const long long groups = ((long long)M * lpr + 63) / 64;                   // wave-loads of 64 / lpr rows
+  const int grid = (int)std::min<long long>((groups + 7) / 8, 4096);          // 4 waves per block, 2 groups per wave iteration
+  if (dtype == 2) hipLaunchKernelGGL(k_density_fwd<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, K, lpr, Y, ldy, w, b, density_bias, raw, density);
+  else if (dtype) hipLaunchKernelGGL(k_density_fwd<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, K, lpr, Y, ldy, w, b, density_bias, raw, density);
+  else hipLaunchKernelGGL(k_density_fwd<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, M, K, lpr, Y, ldy, w, b, density_bias, raw, density);
   HUGS_CHECK_LAUNCH("hugs_density_fwd");
   return 0;
 }
 
-#define WCS_BLOCKS 512
+#define WCS_BLOCKS 1024
 extern "C" long long hugs_density_bwd_ws_bytes(int K) { return (long long)WCS_BLOCKS * (K + 4) * 4; }
 
 // d_raw = d_density * sigmoid(raw + bias); dw[K] = Y^T d_raw; db = sum d_raw
@@ -389,17 +425,27 @@ extern "C" int hugs_raybias_fwd(int nrays, int H, int nd, int ng, const float* d
 }
 
 // G: gradient at the view layer pre-activation [nrays*S, H]. Outputs dWv_tail[(nd+ng), H] and scatter-adds into
-// d_embedding (must be zeroed by the caller once per step). d_rb is workspace [nrays, H].
+// d_embedding (must be zeroed by the caller once per step). d_rb is workspace [hugs_raybias_bwd_ws_rows(nrays, nd, ng), H].
+extern "C" long long hugs_raybias_bwd_ws_rows(int nrays, int nd, int ng) {
+  const long long nchunk = ((long long)nrays + RBW_CHUNK - 1) / RBW_CHUNK;
+  return (long long)nrays + (nchunk > 1 ? nchunk * (nd + ng) : 0);
+}
 extern "C" int hugs_raybias_bwd(int dtype, int nrays, int S, int H, int nd, int ng, const void* G, int ldg,
                                 const float* dir_enc, const float* glo, const float* Wv_tail, const int* embed_idx,
                                 float* d_rb, float* dWv_tail, float* d_embedding, void* stream) {
   HUGS_REQUIRE(H == 128, -3, "hugs_raybias_bwd: view width %d unsupported (128)", H);
   if (nrays <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == 2) hipLaunchKernelGGL(k_segsum<2>, dim3((nrays * H + 255) / 256), dim3(256), 0, st, nrays, S, H, G, ldg, d_rb);
-  else if (dtype) hipLaunchKernelGGL(k_segsum<1>, dim3((nrays * H + 255) / 256), dim3(256), 0, st, nrays, S, H, G, ldg, d_rb);
-  else hipLaunchKernelGGL(k_segsum<0>, dim3((nrays * H + 255) / 256), dim3(256), 0, st, nrays, S, H, G, ldg, d_rb);
-  hipLaunchKernelGGL(k_raybias_bwd_w, dim3(nd + ng), dim3(1024), 0, st, nrays, H, nd, ng, dir_enc, glo, d_rb, dWv_tail);
+  const int nseg = nrays * (H / 8);
+  if (dtype == 2) hipLaunchKernelGGL(k_segsum<2>, dim3((nseg + 255) / 256), dim3(256), 0, st, nrays, S, H, G, ldg, d_rb);
+  else if (dtype) hipLaunchKernelGGL(k_segsum<1>, dim3((nseg + 255) / 256), dim3(256), 0, st, nrays, S, H, G, ldg, d_rb);
+  else hipLaunchKernelGGL(k_segsum<0>, dim3((nseg + 255) / 256), dim3(256), 0, st, nrays, S, H, G, ldg, d_rb);
+  // ray chunks: their partial sums live behind the [nrays, H] ray sums in d_rb (hugs_raybias_bwd_ws_rows rows in all)
+  const int nchunk = (nrays + RBW_CHUNK - 1) / RBW_CHUNK;
+  float* part = nchunk > 1 ? d_rb + (size_t)nrays * H : nullptr;
+  hipLaunchKernelGGL(k_raybias_bwd_w, dim3(nd + ng, nchunk), dim3(1024), 0, st, nrays, H, nd, ng, dir_enc, glo, d_rb, dWv_tail, part);
+  if (nchunk > 1)
+    hipLaunchKernelGGL(k_slab_reduce_small, dim3(((nd + ng) * H + 63) / 64), dim3(1024), 0, st, part, nchunk, (nd + ng) * H, (nd + ng) * H, dWv_tail);
   if (ng > 0 && d_embedding)
     hipLaunchKernelGGL(k_glo_bwd, dim3((nrays * ng + 255) / 256), dim3(256), 0, st, nrays, H, nd, ng, d_rb, Wv_tail, embed_idx, d_embedding);
   HUGS_CHECK_LAUNCH("hugs_raybias_bwd");

@@ -697,7 +697,7 @@ class Engine:
         gview((spec.name, lr['name'], 'bias')).mul_(float(spec.rgb_premultiplier))
       gWv = gview((spec.name, lvw['name'], 'kernel'))
       Wv = lay.view(theta, (spec.name, lvw['name'], 'kernel'))
-      d_rb = ws.get(tag + '/d_rb', (N, H))
+      d_rb = ws.get(tag + '/d_rb', (int(_lib.lib().cdll.hugs_raybias_bwd_ws_rows(N, spec.nd, spec.num_glo)), H))
       demb = gview(('GloEmbed_0', 'embedding')) if spec.num_glo > 0 else None
       # Only Gv -> dBott -> G_last is on the way to the trunk backward.  The head weight gradients (view-layer ray-bias
       # part + GLO rows, view dW, bottleneck dW: ~0.3 ms of reductions and skinny GEMMs) go to their own stream and run
@@ -915,7 +915,7 @@ class Engine:
     lt = spec.layers[t0]
     gWt0 = gview((spec.name, lt['name'], 'kernel'))
     Wt0 = lay.view(theta, (spec.name, lt['name'], 'kernel'))
-    d_rb = ws.get('tbwd/d_rb', (N, Ht))
+    d_rb = ws.get('tbwd/d_rb', (int(_lib.lib().cdll.hugs_raybias_bwd_ws_rows(N, 0, spec.num_tra)), Ht))
     _lib.call('hugs_raybias_bwd', dt, N, S, Ht, 0, spec.num_tra, G, Ht, None, lv['tra'], Wt0[Bw:], rays.get('embed_idx'), d_rb,
               gWt0[Bw:], gview(('TransientEmbed_0', 'embedding')))
     self._tn(M, Bw, Ht, lv['bott'], Bw, G, Ht, gWt0[:Bw], gview((spec.name, lt['name'], 'bias')))
