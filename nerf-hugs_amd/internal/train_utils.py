@@ -232,11 +232,11 @@ def create_train_step(model, config, is_finetune=False):
 
   def graph_signature(rng, state, N, train_frac, inlier_thresholds):
     """None when this step cannot be replayed from captured hipGraphs, else the key of its graphs.  Capturable: the plain /
-    static-mask losses, jitter from a jax key through the fused chain kernel (or none), no near-plane annealing (its histogram
+    static-mask / RobustNeRF losses, jitter from a jax key through the fused chain kernel (or none), no near-plane annealing (its histogram
     is rewritten from the host).  Data parallel: TWO graphs (forward + backward | clip + Adam) around ONE eager all-reduce of
     the gradient buffer -- the collective is not captured."""
-    if _STEP_GRAPH == '0' or _lib.PROFILE is not None or tt not in (None, 'withmask') or inlier_thresholds is not None:
-      return None
+    if _STEP_GRAPH == '0' or _lib.PROFILE is not None or tt not in (None, 'withmask', 'robustnerf') or inlier_thresholds is not None:
+      return None      # (RobustNeRF: with the thresholds fed back on the device -- inlier_thresholds=None -- not handed over by the host)
     if model.near_anneal_rate is not None or model.has_noise() or model.nerf_spec.num_tra > 0 or model.mask_spec is not None:
       return None
     if hrandom.is_key(rng):
@@ -383,8 +383,8 @@ def create_train_step(model, config, is_finetune=False):
         # device-side feedback of the previous step's (rank-averaged) thresholds: what train.py:145-148 does through
         # the host, without the device->host->device round trip (a synchronisation point in every step)
         thr = cache.get('thr_dev')
-        if thr is None:
-          thr = torch.ones((L, 1), dtype=torch.float32, device=dev)          # train.py:130
+        if thr is None:      # (ONE buffer for the life of the step function, updated in place: a captured step reads it by address)
+          thr = cache['thr_dev'] = torch.ones((L, 1), dtype=torch.float32, device=dev)          # train.py:130
       else:
         thr = torch.as_tensor(np.asarray(inlier_thresholds, dtype=np.float32) if not torch.is_tensor(inlier_thresholds)
                               else inlier_thresholds).to(device=dev, dtype=torch.float32).reshape(L, -1)[:, :1].contiguous()
@@ -553,7 +553,9 @@ def create_train_step(model, config, is_finetune=False):
       packed[:STAT_TAIL].mul_(gscale)
     assert leaf_stats.data_ptr() == packed[STAT_TAIL:].data_ptr()
     if tt == 'robustnerf':
-      cache['thr_dev'] = packed[o_rob:o_rob + 5 * L].reshape(L, 5)[:, :1].clone()
+      if 'thr_dev' not in cache:
+        cache['thr_dev'] = torch.ones((L, 1), dtype=torch.float32, device=packed.device)
+      cache['thr_dev'].copy_(packed[o_rob:o_rob + 5 * L].reshape(L, 5)[:, :1])
     return packed
 
   def stats_builder(state):

@@ -11,14 +11,14 @@ pytestmark = pytest.mark.gpu
 from tests.test_gpu_train_step import SMALL
 
 
-def _run(mode, gin, nsteps, rng_kind, n_patch=2):
+def _run(mode, gin, nsteps, rng_kind, n_patch=2, P=8):
   from tests import hugs_testlib as H
   from nerf_hugs_amd.internal import train_utils, random as hr
   old = train_utils._STEP_GRAPH
   train_utils._STEP_GRAPH = mode
   try:
     config, model, state, render_fn, train_step, cfg, oparams = H.make_pair(gin, compute_dtype='bf16')
-    batches = [H.synth_rays(n_patch, 8, 5 + (i % 3)) for i in range(nsteps)]      # fresh tensors every step: inputs are staged
+    batches = [H.synth_rays(n_patch, P, 5 + (i % 3)) for i in range(nsteps)]      # fresh tensors every step: inputs are staged
     key = hr.PRNGKey(123) if rng_kind == 'key' else None
     out = []
     for i in range(nsteps):
@@ -32,13 +32,17 @@ def _run(mode, gin, nsteps, rng_kind, n_patch=2):
 
 
 @pytest.mark.parametrize('rng_kind', ['key', 'none'])
-@pytest.mark.parametrize('variant', ['base', 'withmask_glo'])
+@pytest.mark.parametrize('variant', ['base', 'withmask_glo', 'robustnerf'])
 def test_graph_replay_is_bit_identical_to_the_eager_step(rng_kind, variant):
   gin = list(SMALL)
+  kw = {}
   if variant == 'withmask_glo':
     gin += ["Config.transient_type = 'withmask'", "Model.num_glo_features = 4", "Config.data_loss_type = 'charb'"]
-  e = _run('0', gin, 7, rng_kind)
-  g = _run('1', gin, 7, rng_kind)
+  if variant == 'robustnerf':      # thresholds fed back on the device from step to step (train.py:145-148 through the host)
+    gin = [g_.replace('patch_size = 8', 'patch_size = 16') for g_ in gin] + ["Config.transient_type = 'robustnerf'", "Config.robustnerf_inlier_quantile = 0.8"]
+    kw = dict(n_patch=1, P=16)
+  e = _run('0', gin, 7, rng_kind, **kw)
+  g = _run('1', gin, 7, rng_kind, **kw)
   assert not e[6] and g[6], 'the graph path did not engage'
   assert e[5] == g[5] == 7
   for a, b, name in zip(e[:3], g[:3], ('params', 'adam m', 'adam v')):
@@ -51,7 +55,7 @@ def test_graph_replay_is_bit_identical_to_the_eager_step(rng_kind, variant):
       assert torch.equal(a, b), name
   if rng_kind == 'key':
     assert torch.equal(e[3], g[3]), 'jax key after 7 steps'
-  if variant == 'base':
+  if variant in ('base', 'robustnerf'):
     assert e[4] == g[4], (e[4], g[4])
   else:
     np.testing.assert_allclose(np.array(e[4]), np.array(g[4]), rtol=2e-3)
