@@ -18,6 +18,8 @@ _USE_BITS = __import__('os').environ.get('HUGS_RELU_BITS', '1') != '0'        # 
 # dX GEMMs, the rest after the chain)
 _TN_BATCH = int(__import__('os').environ.get('HUGS_TN_BATCH', '1'))
 _DW_AFTER_PROP = __import__('os').environ.get('HUGS_DW_AFTER_PROP', '1') == '1'
+# G_last through the folded matrix P = W_bottleneck W_view[:Bw] (one K = 128 GEMM on the critical chain instead of two; A/B switch)
+_HEAD_FOLD = __import__('os').environ.get('HUGS_HEAD_FOLD', '1') == '1'
 _SIDE_LATE = __import__('os').environ.get('HUGS_SIDE_LATE', '0') == '1'      # A/B: side-stream work released behind the G_last GEMM
 _TN_ITEM = np.dtype([('X', np.uint64), ('G', np.uint64), ('dW', np.uint64), ('db', np.uint64), ('ldx', np.int32), ('ldg', np.int32),
                      ('Mrows', np.int32), ('Kc', np.int32), ('N', np.int32), ('reserved', np.int32)])      # include/hugs.h HugsTnItem
@@ -326,6 +328,24 @@ class Engine:
       tab = (theta.data_ptr(), torch.from_numpy(raw).to(self.device), len(rec), blk)
       self._cast_table = tab
     _lib.call('hugs_cast_weights_batch', self.dt, tab[2], tab[1], tab[3])
+    if _HEAD_FOLD:
+      # P [Wp, H] = W_b [Wp, Bw] W_v[:Bw] [Bw, H]: the trunk's output gradient is (G_view W_v[:Bw]^T) W_b^T = G_view P^T, one
+      # K = H GEMM straight from the view layer's gradient instead of dBott (K = H) followed by a K = Bw one -- 34 instead of 77
+      # GFLOP on the critical chain of the backward pass at cfg2 (dBott itself is still needed, for the bottleneck's weight
+      # gradient: it moves to the head stream).  67 MFLOP per refresh.
+      for spec in self.model.specs:
+        if spec.disable_rgb or not spec.use_viewdirs:
+          continue
+        lb, lv = spec.layers[spec.net_depth + 1], spec.layers[spec.net_depth + 2]
+        kb, kv = (spec.name, lb['name'], 'kernel'), (spec.name, lv['name'], 'kernel')
+        Bw, H = spec.bottleneck_width, spec.net_width_viewdirs
+        Wp = self.wn[kb].shape[0]
+        if not hasattr(self, 'wfold'):
+          self.wfold = {}
+        if spec.name not in self.wfold:
+          self.wfold[spec.name] = torch.empty(Wp, H, dtype=self.tdt, device=self.device)
+        _lib.call('hugs_gemm_nt', self.dt, Wp, H, Bw, 0, self.wn[kb], Bw, None, 0, self.wt[kv], Bw, None, None, 1, 0, 0, None, 0, None,
+                  None, self.wfold[spec.name], H)
     for spec in self.model.specs:
       if spec.num_tra > 0:      # dBottleneck = [G_view | G_transient0] [Wv[:Bw] | Wt0[:Bw]]^T in one two-segment GEMM
         lv, lt = spec.layers[spec.net_depth + 2], spec.layers[spec.t0]
@@ -718,17 +738,24 @@ class Engine:
           wait_event(hl, ev_gv)
           head_dw_1()
       dB = ws.get(tag + '/dBott', (M, Bw), self.tdt)
-      if nerfw is not None:
+      fold = _HEAD_FOLD and nerfw is None and hasattr(self, 'wfold') and spec.name in self.wfold
+
+      def dbott():      # dBott = Gv Wv[:Bw]^T
+        _lib.call('hugs_gemm_nt', dt, M, Bw, H, 0, Gv, H, None, 0, self.wn[(spec.name, lvw['name'], 'kernel')], H, None,
+                  None, 1, 0, 0, None, 0, None, None, dB, Bw)
+      if fold:
+        pass            # (computed on the head stream, in front of the bottleneck's weight gradient: head_dw_2)
+      elif nerfw is not None:
         G0t = self._transient_backward(theta, grad, lv, rays, N, d_dt, d_ct, d_u)
         Ht = spec.net_width_transient
         # dBott = Gv Wv[:Bw]^T + G0t Wt0[:Bw]^T: one GEMM over the two K segments
         _lib.call('hugs_gemm_nt', dt, M, Bw, H, Ht, Gv, H, G0t, Ht, self.wcat, H + Ht, None, None, 1, 0, 0, None, 0, None,
                   None, dB, Bw)
       else:
-        # dBott = Gv Wv[:Bw]^T
-        _lib.call('hugs_gemm_nt', dt, M, Bw, H, 0, Gv, H, None, 0, self.wn[(spec.name, lvw['name'], 'kernel')], H, None,
-                  None, 1, 0, 0, None, 0, None, None, dB, Bw)
+        dbott()
       def head_dw_2():
+        if fold:
+          dbott()
         self._tn(M, W, Bw, Ylast, W, dB, Bw, gview((spec.name, lb['name'], 'kernel'), True), gview((spec.name, lb['name'], 'bias')))
         if leaf_done is not None:      # density / bottleneck / view / rgb (/ transient) layers: everything behind the trunk
           first = lay.by_path[(spec.name, spec.layers[spec.net_depth]['name'], 'kernel')]
@@ -742,7 +769,13 @@ class Engine:
           heads_done = new_event(); heads_done.record(hl)
       # G_last = (dBott Wb^T + d_raw (x) w_d) * (Ylast > 0)
       blast = lv['bits'][spec.net_depth - 1] if lv.get('bits') else None
-      if blast is not None and Bw >= 256:
+      if fold:      # G_last = (Gv P^T + d_raw (x) w_d) * (Ylast > 0)
+        P_ = self.wfold[spec.name]
+        if blast is not None and H >= 128:
+          _lib.call('hugs_gemm_nt_bits', dt, M, W, H, 0, Gv, H, None, 0, P_, H, None, 0, d_raw, wd, Ga, W, None, blast)
+        else:
+          _lib.call('hugs_gemm_nt', dt, M, W, H, 0, Gv, H, None, 0, P_, H, None, None, 1, 0, 0, Ylast, W, d_raw, wd, Ga, W)
+      elif blast is not None and Bw >= 256:
         _lib.call('hugs_gemm_nt_bits', dt, M, W, Bw, 0, dB, Bw, None, 0, self.wn[(spec.name, lb['name'], 'kernel')], Bw, None, 0,
                   d_raw, wd, Ga, W, None, blast)
       else:
