@@ -67,7 +67,10 @@ def _compare(tmp_path, gin, backend, nsteps=1, graph='0', dtype='fp32'):
   # clipped-Adam's first update is ~ lr * g/(|g|+eps): compare the updates leaf by leaf
   for lf in m.layout.leaves:
     ua, ub = m.layout.view(da, lf['path']), m.layout.view(db, lf['path'])
-    assert float((ua - ub).abs().max()) <= 2e-3 * float(ua.abs().max()) + 3e-8, lf['path']
+    # (several steps: Adam turns a gradient that differs in its last bits into an update that differs by ~lr * relative error,
+    # and the reassociated gradient sums of the two shardings drift apart step by step: 5e-3 of the largest update per leaf)
+    tol = 2e-3 if nsteps == 1 else 5e-3
+    assert float((ua - ub).abs().max()) <= tol * float(ua.abs().max()) + 3e-8, lf['path']
   assert abs(a['loss'] / b['loss'] - 1) < 1e-4      # pmean of per-shard losses == the full-batch loss here
 
 
