@@ -107,6 +107,7 @@ __device__ __forceinline__ float sf_np_block(const float* a, int n, int lane) { 
   if (n < 8) { float r = 0.0f; for (int i = 0; i < n; ++i) r = r + a[i]; return r; }
   const int nb = n - (n & 7);
   float r = lane < 8 ? a[lane] : 0.0f;
+#pragma unroll 4
   for (int i = 8; i < nb; i += 8) { if (lane < 8) r = r + a[i + lane]; }
   float t = r + __shfl_xor(r, 1);
   t = t + __shfl_xor(t, 2);
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void k_level_sample(
     const float* __restrict__ jitter, int jitter_stride, int ns, int raydist, const float* __restrict__ near,
     const float* __restrict__ far, float* __restrict__ sdist, float* __restrict__ tdist, int32_t* __restrict__ idx_out,
     float* __restrict__ t_in_out, float* __restrict__ w_in_out, const float* __restrict__ anneal_dev) {
-  __shared__ SfLds<C> lds[4];
+  __shared__ __attribute__((aligned(16))) SfLds<C> lds[4];
   if (anneal_dev) anneal = *anneal_dev;      // hugs_level_sample_fwd_dyn: the per-step value lives in device memory (captured step)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ray = blockIdx.x * 4 + wv;
@@ -253,7 +254,16 @@ __global__ __launch_bounds__(256) void k_level_sample(
     if (lane == 0) {
       float run = 0.0f;
       L.td[0] = 0.0f;
-      for (int i = 0; i < n_in - 1; ++i) { run = run + L.p[i]; L.td[i + 1] = run < 1.0f ? run : 1.0f; }
+      // (four weights per LDS read: the additions stay strictly left to right, only the read latency is paid once per four)
+      int i = 0;
+      for (; i + 4 <= n_in - 1; i += 4) {
+        const float4 v = *(const float4*)&L.p[i];
+        run = run + v.x; L.td[i + 1] = run < 1.0f ? run : 1.0f;
+        run = run + v.y; L.td[i + 2] = run < 1.0f ? run : 1.0f;
+        run = run + v.z; L.td[i + 3] = run < 1.0f ? run : 1.0f;
+        run = run + v.w; L.td[i + 4] = run < 1.0f ? run : 1.0f;
+      }
+      for (; i < n_in - 1; ++i) { run = run + L.p[i]; L.td[i + 1] = run < 1.0f ? run : 1.0f; }
       L.td[n_in] = 1.0f;
     }
   } else if (live) {
