@@ -73,9 +73,9 @@ def _compare(tmp_path, gin, backend, nsteps=1, graph='0', dtype='fp32'):
       assert float((ua - ub).abs().max()) <= 2e-3 * float(ua.abs().max()) + 3e-8, lf['path']
     else:      # a population statement: one ReLU decision that flips in step 2 moves single entries by a sample's contribution
       sc = float(ua.abs().max())
-      bad = float(((ua - ub).abs() > 5e-3 * sc + 3e-8).double().mean())
+      bad = int(((ua - ub).abs() > 5e-3 * sc + 3e-8).sum())
       worst = float((ua - ub).abs().max()) / max(sc, 1e-30)
-      assert (bad < 5e-3 or ua.numel() <= 8) and worst < 1e-1, (lf["path"], bad, worst)
+      assert bad <= max(2, 5e-3 * ua.numel()) and worst < 1e-1, (lf["path"], bad, ua.numel(), worst)
   assert abs(a['loss'] / b['loss'] - 1) < 1e-4      # pmean of per-shard losses == the full-batch loss here
 
 
