@@ -125,21 +125,26 @@ __global__ __launch_bounds__(256) void k_wcolsum(int M, int K, int rows_per_blk,
 }
 
 // out[i] = sum_b slab[b*stride + i], i < width; columns width .. width+width2-1 go to out2 (the bias gradient next to the
-// weight gradient: one launch).  1024 threads = 64 columns x 16 row groups, fixed order.
+// weight gradient: one launch).  1024 threads = 16 columns x 64 row groups, fixed order (round 4: 64 columns x 16 groups put a
+// 388-column reduction of 1024 partial rows on SEVEN workgroups with 64 dependent loads per thread: 20-26 us, twice on the
+// backward's critical chain).
+#define SRS_COLS 16
 __global__ __launch_bounds__(1024) void k_slab_reduce_small(const float* __restrict__ slab, int nblk, int width, int stride,
                                                             float* __restrict__ out, int width2 = 0, float* __restrict__ out2 = nullptr) {
-  __shared__ float red[16][65];
-  const int cx = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + cx;
+  __shared__ float red[64][SRS_COLS + 1];
+  const int cx = threadIdx.x & (SRS_COLS - 1), rg = threadIdx.x / SRS_COLS;
+  const int i = blockIdx.x * SRS_COLS + cx;
   float a = 0.f;
-  if (i < width + width2)
-    for (int b = rg; b < nblk; b += 16) a += slab[(size_t)b * stride + i];
+  if (i < width + width2) {
+#pragma unroll 4
+    for (int b = rg; b < nblk; b += 64) a += slab[(size_t)b * stride + i];
+  }
   red[rg][cx] = a;
   __syncthreads();
   if (rg == 0 && i < width + width2) {
     float t = 0.f;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) t += red[g][cx];
+    for (int g = 0; g < 64; ++g) t += red[g][cx];
     if (i < width) out[i] = t; else out2[i - width] = t;
   }
 }
@@ -391,7 +396,7 @@ extern "C" int hugs_density_bwd(int dtype, int M, int K, const void* Y, int ldy,
   if (dtype == 2) hipLaunchKernelGGL(k_wcolsum<2>, dim3(nblk), dim3(256), 0, st, M, K, rpb, Y, ldy, d_raw, slab);
   else if (dtype) hipLaunchKernelGGL(k_wcolsum<1>, dim3(nblk), dim3(256), 0, st, M, K, rpb, Y, ldy, d_raw, slab);
   else hipLaunchKernelGGL(k_wcolsum<0>, dim3(nblk), dim3(256), 0, st, M, K, rpb, Y, ldy, d_raw, slab);
-  hipLaunchKernelGGL(k_slab_reduce_small, dim3((K + 1 + 63) / 64), dim3(1024), 0, st, slab, nblk, K, K + 4, dw, 1, db);
+  hipLaunchKernelGGL(k_slab_reduce_small, dim3((K + 1 + SRS_COLS - 1) / SRS_COLS), dim3(1024), 0, st, slab, nblk, K, K + 4, dw, 1, db);
   HUGS_CHECK_LAUNCH("hugs_density_bwd");
   return 0;
 }
@@ -445,7 +450,7 @@ extern "C" int hugs_raybias_bwd(int dtype, int nrays, int S, int H, int nd, int 
   float* part = nchunk > 1 ? d_rb + (size_t)nrays * H : nullptr;
   hipLaunchKernelGGL(k_raybias_bwd_w, dim3(nd + ng, nchunk), dim3(1024), 0, st, nrays, H, nd, ng, dir_enc, glo, d_rb, dWv_tail, part);
   if (nchunk > 1)
-    hipLaunchKernelGGL(k_slab_reduce_small, dim3(((nd + ng) * H + 63) / 64), dim3(1024), 0, st, part, nchunk, (nd + ng) * H, (nd + ng) * H, dWv_tail);
+    hipLaunchKernelGGL(k_slab_reduce_small, dim3(((nd + ng) * H + SRS_COLS - 1) / SRS_COLS), dim3(1024), 0, st, part, nchunk, (nd + ng) * H, (nd + ng) * H, dWv_tail);
   if (ng > 0 && d_embedding)
     hipLaunchKernelGGL(k_glo_bwd, dim3((nrays * ng + 255) / 256), dim3(256), 0, st, nrays, H, nd, ng, d_rb, Wv_tail, embed_idx, d_embedding);
   HUGS_CHECK_LAUNCH("hugs_raybias_bwd");
@@ -494,7 +499,7 @@ extern "C" int hugs_rgb_bwd(int dtype, int M, int H, const void* Hact, int ldh, 
     else { if (dtype == 2) RGB_BWD(2, 2); else if (dtype) RGB_BWD(1, 2); else RGB_BWD(0, 2); }
 #undef RGB_BWD
     // (the bias gradient is the same in every slab: written by the first)
-    hipLaunchKernelGGL(k_slab_reduce_small, dim3((step * 3 + 3 + 63) / 64), dim3(1024), 0, st, slab, nblk, step * 3, step * 3 + 4,
+    hipLaunchKernelGGL(k_slab_reduce_small, dim3((step * 3 + 3 + SRS_COLS - 1) / SRS_COLS), dim3(1024), 0, st, slab, nblk, step * 3, step * 3 + 4,
                        dW + (size_t)c0 * 3, c0 == 0 ? 3 : 0, c0 == 0 ? db : nullptr);
   }
   HUGS_CHECK_LAUNCH("hugs_rgb_bwd");
