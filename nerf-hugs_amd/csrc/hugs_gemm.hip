@@ -1465,7 +1465,10 @@ int HUGS_NT_IMPL(HUGS_NT_ARGS) {
     // one-tile-per-workgroup kernel: the run-time-flag epilogue on top of the persistent loop's live state spilled 44 VGPRs)
     const bool pers_epi = epi == (EPI_BIAS | EPI_RELU) || epi == (EPI_BIAS | EPI_RELU | EPI_BOUT) || epi == EPI_BIN || epi == (EPI_BIN | EPI_R1) ||
                           epi == EPI_BIAS || epi == EPI_MASK || epi == (EPI_MASK | EPI_R1) || epi == 0;
-    if (ntiles > ncu && nstage % 2 == 0 && nstage >= 8 && N <= 4096 && tile_mode != 5 && pers_epi) {
+    // (nstage >= 4: a tile of four stages is exactly one ring fill -- the next tile's stages are requested during this tile's four
+    //  iterations and the first three waits see the same two younger stages + 16 stores as with longer tiles.  Round 4: the
+    //  trunk's output gradient is a K = 128 product, 8192 tiles at the reference-default shape)
+    if (ntiles > ncu && nstage % 2 == 0 && nstage >= 4 && N <= 4096 && tile_mode != 5 && pers_epi) {
       const dim3 gp(ncu), bp(512);
 #define HUGS_NTP_LAUNCH(EPI_) hipLaunchKernelGGL((k_gemm_nt_bf16_pers<EPI_>), gp, bp, 0, (hipStream_t)stream, M, N, K1, K2, \
                        (const uint16_t*)A1, lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E, ntiles)

@@ -387,7 +387,7 @@ def test_torch_library_custom_ops():
 
 
 @pytest.mark.parametrize('shape', [(256, 256, 128, 0), (512, 256, 192, 0), (768, 512, 320, 0), (256, 768, 1024, 0), (1280, 256, 128, 512),
-                                   (66560, 256, 192, 0), (67072, 512, 256, 64)])
+                                   (66560, 256, 192, 0), (67072, 512, 256, 64), (66560, 256, 128, 0), (33280, 1024, 128, 0), (66560, 256, 64, 64)])
 def test_gemm_ring_kernels_over_stage_counts(shape):
   """The 256x256 ring kernels (one tile per workgroup, and the persistent form once there are more tiles than CUs) over
   stage counts 4, 6, 10, 32, 20 and two-segment K: bias + relu forward against float64, and the masked dX form."""
@@ -407,6 +407,15 @@ def test_gemm_ring_kernels_over_stage_counts(shape):
   L.call('hugs_gemm_nt', 1, M, N, K1, K2, A1, K1, A2, K2, Bt, K1 + K2, None, None, 1, 0, 0, mk, N, None, None, out, N)
   ref = (A.double() @ Bt.double().T) * (mk.double() > 0)
   assert float((out.double() - ref).abs().max()) < 2e-2 * max(1.0, float(ref.abs().max()))
+  if (K1 + K2) >= 128 and (K1 + K2) % 64 == 0 and M % 256 == 0 and N % 256 == 0:
+    # the 1-bit mask forms (forward writes the bits, the dX form reads them, with the rank-1 term of the last trunk layer)
+    bits = torch.empty(M * N // 32, dtype=torch.int32, device=dev)
+    y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    L.call('hugs_gemm_nt_bits', 1, M, N, K1, K2, A1, K1, A2, K2, Bt, K1 + K2, bias, 1, None, None, y, N, bits, None)
+    r1r, r1c = rn(M), rn(N)
+    L.call('hugs_gemm_nt_bits', 1, M, N, K1, K2, A1, K1, A2, K2, Bt, K1 + K2, None, 0, r1r, r1c, out, N, None, bits)
+    ref = (A.double() @ Bt.double().T + r1r.double()[:, None] * r1c.double()[None]) * (y.double() > 0)
+    assert float((out.double() - ref).abs().max()) < 2e-2 * max(1.0, float(ref.abs().max()))
 
 
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
