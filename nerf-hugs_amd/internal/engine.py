@@ -300,6 +300,7 @@ class Engine:
     """Cast the fp32 masters to the GEMM operand copies: Wn [Kp,N] (dX) and Wt [N,Kp] (forward).  owner: the
     TrainState whose buffer `theta` is (the train step's own refresh), None for any other caller."""
     self._cast_src = None if owner is None else (owner.gen, theta.data_ptr(), theta._version)
+    self.weights_stale = False
     tab = getattr(self, '_cast_table', None)
     if tab is None or tab[0] != theta.data_ptr():
       # one 40-byte record per GEMM operand pair (include/hugs.h hugs_cast_weights_batch): device ADDRESSES only, a pure
@@ -360,7 +361,7 @@ class Engine:
     return self._cast_src is not None and self._cast_src == (state.gen, state.flat.data_ptr(), state.flat._version)
 
   # ---- forward ------------------------------------------------------------------------------------
-  def _mlp_forward(self, spec, theta, lvl, N, S, tdist, rays, glo, keep, tra=None, mlp_key=None, n_real=None):
+  def _mlp_forward(self, spec, theta, lvl, N, S, tdist, rays, glo, keep, tra=None, mlp_key=None, n_real=None, weights_ready=None):
     M = N * S
     Mr = M if n_real is None else n_real * S      # rows of real rays (Model.apply pads ragged batches at the END)
     lay, ws, dt = self.layout, self.ws, self.dt
@@ -370,6 +371,8 @@ class Engine:
               spec.nb, (0 if self.model.ray_shape == 'cone' else 1) | (4 if self.model.disable_integration else 0) | (spec.min_deg_point << 8),
               int(spec.warp_fn is not None), spec.max_deg_point - spec.min_deg_point,
               dt, spec.Fp, X0)
+    if weights_ready is not None:      # the operand copies are cast on their own lane at the start of a train step
+      wait_event(torch.cuda.current_stream(), weights_ready)
     acts = [X0]
     x = X0
     W = spec.Wp
@@ -489,13 +492,18 @@ class Engine:
         out.update(tacts=tacts, raw_t=raw_t, dens_t=dens_t, rgb_t=rgb_t, raw_u=raw_u, unc=unc, tra=tra)
     return out
 
-  def forward(self, theta, rays, train_frac, u01, compute_extras, zero_glo=False, zero_tra=False, n_real=None, anneal_dev=None):
+  def forward(self, theta, rays, train_frac, u01, compute_extras, zero_glo=False, zero_tra=False, n_real=None, anneal_dev=None,
+              weights_ready=None):
     """Model.__call__ (models.py:74-330).  rays: dict of contiguous [N,c] cuda tensors (+ 'dir_enc').
     u01: None, a list[num_levels] of U[0,1) draws, or a stepfun.Jitter list of scaled draws.  Returns per-level dicts (device tensors; buffers are
     reused by the next call)."""
     mdl = self.model
     N = rays['origins'].shape[0]
     ws = self.ws
+    if getattr(self, 'weights_stale', False) and weights_ready is None:
+      # an optimizer step has moved the masters since the operand copies were cast (the train step re-casts at the START of the
+      # next step): a caller that drives the engine directly gets fresh copies here
+      self.refresh_weights(theta)
     glo = None
     if mdl.num_glo_features > 0:
       glo = ws.get('glo', (N, mdl.num_glo_features))
@@ -544,7 +552,7 @@ class Engine:
       spec = mdl.prop_spec if is_prop else mdl.nerf_spec
       mkeys = getattr(u01, 'mlp_keys', None)
       out = self._mlp_forward(spec, theta, lvl, N, S, td, rays, glo, True, None if is_prop else tra,
-                              mlp_key=None if mkeys is None else mkeys[lvl], n_real=n_real)
+                              mlp_key=None if mkeys is None else mkeys[lvl], n_real=n_real, weights_ready=weights_ready if lvl == 0 else None)
       w = ws.get(f'L{lvl}/weights', (N, S))
       rgb_all = ws.get('rgb_out_all', (mdl.num_levels, N, 3))
       rgb_out = rgb_all[lvl]

@@ -134,7 +134,7 @@ _AR_BUCKETS = __import__('os').environ.get('HUGS_AR_BUCKETS', '1') != '0'
 _STEP_GRAPH = __import__('os').environ.get('HUGS_STEP_GRAPH', 'auto')
 # lanes (Engine._side_stream) that keep a stream of their own inside the captured step; the others run on the stream they are
 # called from.  Lane 2 (the proposal level's weight-gradient stream) forks from lane 1, a forked stream: see engine.wait_event
-_GRAPH_LANES = tuple(int(x) for x in __import__('os').environ.get('HUGS_STEP_GRAPH_LANES', '1,3').split(',') if x != '')
+_GRAPH_LANES = tuple(int(x) for x in __import__('os').environ.get('HUGS_STEP_GRAPH_LANES', '1,3,4').split(',') if x != '')
 _STEP_GRAPH_ROWS = int(__import__('os').environ.get('HUGS_STEP_GRAPH_ROWS', '100000'))
 
 
@@ -220,7 +220,10 @@ def create_train_step(model, config, is_finetune=False):
       _lib.call('hugs_opt_adam', nch, nleaf, eng.chunks, eng.leaf_info, state.flat, grad, state.m, state.v, mod_scale, h['trainable'], gscale,
                 config.grad_max_val, lr, h['b1'], h['b2'], h['eps'], 1.0 - h['b1']**t, 1.0 - h['b2']**t, part2,
                 leaf_stats[nleaf * 4:nleaf * 6])
-    eng.refresh_weights(state.flat, owner=state)
+    # (the compute-dtype operand copies are re-cast at the START of the next step, on a lane of their own underneath its
+    # jitter / sampler / encoder launches -- step_core -- instead of here at the end of the serial optimizer tail)
+    eng._cast_src = None
+    eng.weights_stale = True
     state.step += 1
     return leaf_stats
 
@@ -263,8 +266,6 @@ def create_train_step(model, config, is_finetune=False):
       if (N * S_) % 128:
         raise ValueError(f'per-device batch of {N} rays x {S_} samples is not a multiple of the 128-row GEMM tile: '
                          'use a batch size that is a multiple of 4 (eval pads ragged chunks itself)')
-    if not eng.weights_current(state):
-      eng.refresh_weights(state.flat, owner=state)
     sig = graph_signature(rng, state, N, train_frac, inlier_thresholds)
     ent = None
     if sig is not None:
@@ -321,7 +322,8 @@ def create_train_step(model, config, is_finetune=False):
       dist.all_reduce(eng.ws.get('grad', (layout.size + STAT_TAIL,)), op=dist.ReduceOp.SUM)
       ent['graph_opt'].replay()
     state.step += 1
-    eng._cast_src = (state.gen, state.flat.data_ptr(), state.flat._version)      # the graph ends with the weight re-cast
+    eng._cast_src = None          # (the replayed Adam update has moved the masters; the next step re-casts first thing)
+    eng.weights_stale = True
     return state, LazyStats(ent['packed'], stats_builder(state)), (ent['key'] if ent['key'] is not None else rng)
 
   def step_core(state, rays, gt, N, rng, train_frac, inlier_thresholds, dyn, reduce):
@@ -332,6 +334,15 @@ def create_train_step(model, config, is_finetune=False):
     dev = state.flat.device
     ws = eng.ws
     world = _world()
+    # operand copies of the weights (bf16 Wt / Wn, the folded head matrix): cast on a lane of their own; the first MLP GEMM waits
+    ev_w = None
+    if dyn is not None or not eng.weights_current(state):
+      main_w, lane_w = torch.cuda.current_stream(), eng._side_stream(4)
+      e0 = _engine.new_event(); e0.record(main_w)
+      with torch.cuda.stream(lane_w):
+        _engine.wait_event(lane_w, e0)
+        eng.refresh_weights(state.flat, owner=state)
+        ev_w = _engine.new_event(); ev_w.record(lane_w)
     u01 = None
     if isinstance(rng, (list, tuple)):             # explicit U[0,1) draws, one [N] (or [N,S]) tensor per level: the
       if len(rng) != L:                            # numbers jax.random.uniform handed the reference (fixtures, tests)
@@ -357,9 +368,12 @@ def create_train_step(model, config, is_finetune=False):
       ev0 = _engine.new_event(); ev0.record(main_s)
       with torch.cuda.stream(side_s):
         _engine.wait_event(side_s, ev0)
+        if ev_w is not None:
+          _engine.wait_event(side_s, ev_w)
         mask_st = eng.mask_forward(state.flat, rays, N)
         ev_mask = _engine.new_event(); ev_mask.record(side_s)
-    levels = eng.forward(state.flat, rays, float(train_frac), u01, False, False, anneal_dev=None if dyn is None else dyn[0:1])
+    levels = eng.forward(state.flat, rays, float(train_frac), u01, False, False, anneal_dev=None if dyn is None else dyn[0:1],
+                         weights_ready=ev_w)
     if mask_st is not None:
       _engine.wait_event(main_s, ev_mask)
 
