@@ -91,6 +91,14 @@ int hugs_gemm_tn_batch_nsplit(int nitems, const HugsTnItem* items);
 long long hugs_gemm_tn_batch_ws_bytes(int nitems, const HugsTnItem* items, int nsplit);
 int hugs_gemm_tn_batch(int dtype, int nitems, const HugsTnItem* items, int nsplit, void* ws, void* stream);
 
+/* models.py:451-456,467 for a 256-wide trunk behind its first layer, in ONE launch: Y_l = relu(Y_{l-1} W_l + b_l), l = 1..nl (every
+ * Wt[l-1] is the [256 (out), 256 (in)] bf16 operand copy, Y[l-1] [M,256] bf16 is written for the backward pass, bits[l-1] -- if
+ * non-null -- receives the 1-bit relu masks in hugs_gemm_nt_bits' layout), then raw = Y_nl . wd + bd, density = softplus(raw +
+ * density_bias) (wd null: no head).  A 128-row activation tile stays in LDS from layer to layer.  Wt / bias / Y / bits are HOST
+ * arrays of nl device pointers; M a multiple of 256, nl <= 7, dtype 1 (bf16). */
+int hugs_mlp256_tail_fwd(int dtype, int M, int nl, const void* Y0, const void* const* Wt, const float* const* bias,
+                         void* const* Y, uint32_t* const* bits, const float* wd, const float* bd, float density_bias, float* raw,
+                         float* density, void* stream);
 /* models.py:456 raw_density = Dense(1)(x)[...,0]; :467 density = softplus(raw + density_bias) */
 int hugs_density_fwd(int dtype, int M, int K, const void* Y, int ldy, const float* w, const float* b,
                      float density_bias, float* raw, float* density, void* stream);

@@ -19,6 +19,7 @@ _USE_BITS = __import__('os').environ.get('HUGS_RELU_BITS', '1') != '0'        # 
 _TN_BATCH = int(__import__('os').environ.get('HUGS_TN_BATCH', '1'))
 _DW_AFTER_PROP = __import__('os').environ.get('HUGS_DW_AFTER_PROP', '1') == '1'
 # G_last through the folded matrix P = W_bottleneck W_view[:Bw] (one K = 128 GEMM on the critical chain instead of two; A/B switch)
+_MLP_FUSE_ROWS = int(__import__('os').environ.get('HUGS_MLP_FUSE_ROWS', '32768'))      # 0: never fuse the 256-wide trunk tail
 _HEAD_FOLD = __import__('os').environ.get('HUGS_HEAD_FOLD', '1') == '1'
 _SIDE_LATE = __import__('os').environ.get('HUGS_SIDE_LATE', '0') == '1'      # A/B: side-stream work released behind the G_last GEMM
 _TN_ITEM = np.dtype([('X', np.uint64), ('G', np.uint64), ('dW', np.uint64), ('db', np.uint64), ('ldx', np.int32), ('ldg', np.int32),
@@ -392,10 +393,16 @@ class Engine:
     mc = M // nchunk
     ld = spec.layers[spec.net_depth]
     wd = lay.view(theta, (spec.name, ld['name'], 'kernel'), padded=True).reshape(-1)
+    # Round 4: layers 1.. of a 256-wide trunk + its density head as ONE launch with the activations LDS-resident
+    # (hugs_mlp256_tail_fwd), where it is faster than the per-layer GEMMs: up to _MLP_FUSE_ROWS rows (stand-alone, 3 layers + head:
+    # 24 vs 45 us at 16 384 rows -- the launch-bound regime of small per-GPU batches --, 81 vs 67 us at 65 536, 1.05 vs 0.85 ms at
+    # 1 M rows, where the per-layer launches already run at the HBM rate and the fused kernel's phases do not overlap well enough)
+    fuse_tail = (dt == 1 and nchunk == 1 and W == 256 and spec.net_width == 256 and spec.net_depth >= 2 and M % 256 == 0 and
+                 M <= _MLP_FUSE_ROWS and not any(l['concat'] for l in spec.layers[1:spec.net_depth]))
     for c in range(nchunk):
       rows = slice(c * mc, (c + 1) * mc)
       x = X0[rows]
-      for i in range(spec.net_depth):
+      for i in range(1 if fuse_tail else spec.net_depth):
         l = spec.layers[i]
         path = (spec.name, l['name'], 'kernel')
         bias = lay.view(theta, (spec.name, l['name'], 'bias'), padded=True)
@@ -421,7 +428,19 @@ class Engine:
     raw = ws.get(tag + '/raw', (M,))
     density = ws.get(tag + '/density', (M,))
     bd = lay.view(theta, (spec.name, ld['name'], 'bias'))
-    _lib.call('hugs_density_fwd', dt, M, W, x, W, wd, bd, spec.density_bias, raw, density)
+    if fuse_tail:
+      nl = spec.net_depth - 1
+      key = ('mlp_tail', tag, theta.data_ptr(), M)
+      tab = ws.bufs.get(key)
+      if tab is None:      # host arrays of device pointers (a function of buffer addresses only)
+        ptr = lambda ts: np.ascontiguousarray([0 if t is None else t.data_ptr() for t in ts], np.uint64)
+        tab = ws.bufs[key] = (ptr([self.wt[(spec.name, spec.layers[i]['name'], 'kernel')] for i in range(1, spec.net_depth)]),
+                              ptr([lay.view(theta, (spec.name, spec.layers[i]['name'], 'bias'), padded=True) for i in range(1, spec.net_depth)]),
+                              ptr(Ys[1:]), ptr(bits[1:]))
+      _lib.call('hugs_mlp256_tail_fwd', dt, M, nl, Ys[0], tab[0].ctypes.data, tab[1].ctypes.data, tab[2].ctypes.data,
+                tab[3].ctypes.data, wd, bd, spec.density_bias, raw, density)
+    else:
+      _lib.call('hugs_density_fwd', dt, M, W, x, W, wd, bd, spec.density_bias, raw, density)
     noise_key = None
     if mlp_key is not None and (spec.density_noise > 0 or spec.bottleneck_noise > 0):
       from . import random as hrandom

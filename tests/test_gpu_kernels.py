@@ -463,3 +463,40 @@ def test_gemm_tn_batch_vs_matmul(dtype):
         assert float((dbs[k].double() - rb).abs().max() / rb.abs().max()) < 2e-5, (ns, k)
   with pytest.raises(_lib.HugsError):      # fewer than 512 rows per piece
     _lib.call('hugs_gemm_tn_batch', dt, len(shapes), arr.ctypes.data, 9, ws)
+
+
+@pytest.mark.parametrize('M,nl', [(256, 1), (1280, 3), (66560, 3), (512, 7)])
+def test_mlp256_tail_fused_forward_vs_layer_by_layer(M, nl):
+  """hugs_mlp256_tail_fwd (round 4: layers 1.. of a 256-wide trunk + the density head in one launch, activations LDS-resident)
+  against the float64 chain on the same bf16 operands (every layer's output re-rounded to bf16 as the stored activation is),
+  the stored Y_l, the density head, and the 1-bit masks -- consumed by the dX form of hugs_gemm_nt_bits exactly as the
+  backward pass consumes them."""
+  L = _L()
+  g = torch.Generator(device=dev).manual_seed(M + nl)
+  rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+  Y0 = rn(M, 256).clamp_(min=0).bfloat16()
+  Wt = [(rn(256, 256) * (2.0 / 256)**0.5).bfloat16() for _ in range(nl)]      # [out, in]
+  bias = [rn(256) * 0.1 for _ in range(nl)]
+  wd, bd = rn(256) * 0.1, rn(1)
+  Y = [torch.empty(M, 256, device=dev, dtype=torch.bfloat16) for _ in range(nl)]
+  bits = [torch.zeros(M * 256 // 32, dtype=torch.int32, device=dev) for _ in range(nl)]
+  raw, dens = torch.empty(M, device=dev), torch.empty(M, device=dev)
+  ptrs = lambda ts: np.ascontiguousarray([t.data_ptr() for t in ts], np.uint64)
+  a_w, a_b, a_y, a_bits = ptrs(Wt), ptrs(bias), ptrs(Y), ptrs(bits)
+  L.call('hugs_mlp256_tail_fwd', 1, M, nl, Y0, a_w.ctypes.data, a_b.ctypes.data, a_y.ctypes.data, a_bits.ctypes.data, wd, bd, -1.0, raw, dens)
+  torch.cuda.synchronize()
+  x = Y0.double()
+  for l in range(nl):
+    ref = (x @ Wt[l].double().T + bias[l].double()).clamp(min=0)
+    got = Y[l].double()
+    assert float((got - ref).abs().max()) < 1e-2 * max(1.0, float(ref.abs().max())), l      # bf16 rounding of the output
+    # the masks: dX = (G W) * (Y_l > 0) through the bit-mask GEMM against the same product masked by the stored activation
+    G = rn(M, 256).bfloat16()
+    out = torch.empty(M, 256, device=dev, dtype=torch.bfloat16)
+    L.call('hugs_gemm_nt_bits', 1, M, 256, 256, 0, G, 256, None, 0, Wt[l], 256, None, 0, None, None, out, 256, None, bits[l])
+    refm = (G.double() @ Wt[l].double().T) * (Y[l].double() > 0)
+    assert float((out.double() - refm).abs().max()) < 2e-2 * max(1.0, float(refm.abs().max())), ('mask bits', l)
+    x = Y[l].double()      # the next layer reads the bf16-rounded activation
+  r = Y[-1].double() @ wd.double() + bd.double()
+  np.testing.assert_allclose(raw.cpu().numpy(), r.cpu().numpy(), rtol=2e-5, atol=2e-5)
+  np.testing.assert_allclose(dens.cpu().numpy(), torch.nn.functional.softplus(r - 1.0).cpu().numpy(), rtol=2e-5, atol=2e-6)
