@@ -62,6 +62,18 @@ __global__ __launch_bounds__(256 * WM, 2) void k_mlp256_tail_fwd(const MlpTail P
 
   for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
     const int m0 = t * MF_ROWS;
+    // weights three K-stages ahead in registers; the first three stages of a layer are requested BEFORE the previous layer's
+    // epilogue (for layer 0: before the tile load is waited for), so that their L2 latency hides under it
+    mf_bf16x8_t wq[4][4];
+    const size_t wlane = (size_t)(wn * 64 + r16) * 256 + kb * 8;      // lane's row of fragment j: + j*16*256; stage s: + s*32
+    auto prefetch3 = [&](int l_) {
+      const uint16_t* W_ = P.Wt[l_] + wlane;
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wq[s][j] = *(const mf_bf16x8_t*)(W_ + (size_t)j * 16 * 256 + s * 32);
+    };
+    prefetch3(0);
     __syncthreads();      // (the previous tile's readers of act[] / dred are done)
     // ---- Y0 tile -> act[0] in the stage layout: chunk p = it*512 + tid -> row p>>5, 16-byte chunk p&31 of the 512-byte row
 #pragma unroll
@@ -74,7 +86,7 @@ __global__ __launch_bounds__(256 * WM, 2) void k_mlp256_tail_fwd(const MlpTail P
     for (int l = 0; l < P.nl; ++l) {
       const unsigned char* A = act[l & 1];
       unsigned char* An = act[(l + 1) & 1];
-      const uint16_t* W = P.Wt[l] + (size_t)(wn * 64 + r16) * 256 + kb * 8;      // lane's row of fragment j: + j*16*256; stage s: + s*32
+      const uint16_t* W = P.Wt[l] + wlane;
       mf_f32x4_t acc[4][4];
       {
         const float* b = P.bias[l] + wn * 64 + kb * 4;
@@ -85,12 +97,6 @@ __global__ __launch_bounds__(256 * WM, 2) void k_mlp256_tail_fwd(const MlpTail P
           for (int i = 0; i < 4; ++i) acc[i][j] = mf_f32x4_t{bb.x, bb.y, bb.z, bb.w};
         }
       }
-      // weights three K-stages ahead in registers, activations fragment-double-buffered from LDS
-      mf_bf16x8_t wq[4][4];
-#pragma unroll
-      for (int s = 0; s < 3; ++s)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wq[s][j] = *(const mf_bf16x8_t*)(W + (size_t)j * 16 * 256 + s * 32);
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
 #ifndef MF_NOWLOAD
@@ -109,6 +115,7 @@ __global__ __launch_bounds__(256 * WM, 2) void k_mlp256_tail_fwd(const MlpTail P
       }
       // ---- epilogue: relu, bf16, -> next layer's LDS tile + HBM + mask bits (+ the density head on the last layer)
       const bool last = l + 1 == P.nl;
+      if (!last) prefetch3(l + 1);
       uint16_t* Yout = P.Y[l] + (size_t)(m0 + wm * 64 + r16) * 256 + wn * 64 + kb * 4;
       uint32_t* bout = P.bits[l];
       // bits: NT tile = 256 rows x 256 columns, its wave (wm_nt, wn) covers 128 rows = fragment rows i_nt 0..7; row m0 + wm*64 + i*16
