@@ -2,7 +2,7 @@
 
  * whole-step gradients WITHOUT masking rays: the oracle replays the HIP path's own ReLU decisions (pre * mask instead of
    relu(pre), masks = "stored activation > 0"), so a pre-activation of +-1e-7 that the two float32 implementations put on
-   different sides of zero no longer moves a weight gradient by a whole sample -- every leaf must agree to 5e-4 of its max;
+   different sides of zero no longer moves a weight gradient by a whole sample -- every leaf must agree to 1e-4 of its max;
  * the benchmarked bf16 mode against the oracle evaluated with bf16-rounded GEMM operands (weights, layer inputs, and the
    gradients that flow back through them; fp32 accumulation): per-leaf relative L2 error instead of a cosine;
  * BASELINE config 1's shape (base / mse, L=2, S=(64,64), 1024 rays, the 8x1024 + 4x256 nets) through the HIP path;
@@ -83,7 +83,8 @@ def test_whole_step_gradient_every_leaf_with_replayed_relu_masks(variant):
   assert abs(float(stats['loss']) / float(ostats['loss']) - 1) < 1e-4
   worst = max(errs.items(), key=lambda kv: kv[1][0])
   for name, (emax, el2, n) in errs.items():
-    assert emax <= 5e-4, f'{variant}: {name}: max err {emax:.2e} of the leaf max (L2 {el2:.2e}); worst {worst}'
+    # (measured, profiles/r04_parity_margins.txt: 3.3e-5 at worst) -- north_star's own 1e-4
+    assert emax <= 1e-4, f'{variant}: {name}: max err {emax:.2e} of the leaf max (L2 {el2:.2e}); worst {worst}'
 
 
 def test_bf16_full_width_gradients_vs_bf16_rounded_oracle():
@@ -99,7 +100,7 @@ def test_bf16_full_width_gradients_vs_bf16_rounded_oracle():
   for name, (emax, el2, n) in big:
     assert el2 < 1.5e-2, f'{name}: relative L2 error {el2:.3e} (max {emax:.2e})'
   for name, (emax, el2, n) in rep.items():        # biases and heads too (1 .. 1024 numbers each): looser, a few samples decide them
-    assert el2 < 6e-2, f'{name}: relative L2 error {el2:.3e}'
+    assert el2 < 2e-2, f'{name}: relative L2 error {el2:.3e}'
 
 
 def test_train_step_config1_shape_full_width_1024_rays():
