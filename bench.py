@@ -176,10 +176,8 @@ def nerfacto_roofline(model, step_fn, N, steps=3):
   """Per-kernel figures of the nerfacto step, measured INSIDE extra train steps (HIP events around every launch of the
   hash-grid, fused-proposal and GEMM entry points on the stream they run on).  Bounds: hash-grid forward = gathered table
   bytes (8 corners x features x 4 B per sample and level) + the row written, against HBM 8 TB/s; hash-grid backward = the
-  table updates the algorithm must apply, counted as atomic TRANSACTIONS (adjacent floats of one instruction share one:
-  4 per sample and level where the x-neighbour entry is adjacent, i.e. dense levels, 8 on hashed ones -- before the
-  kernel's run merging, which is why `frac` can exceed 1) against the 21 G transactions/s this chip retires
-  (scratch/atomic_pair.hip); GEMMs = 2 M K N against the dense 16-bit MFMA peak; the fused proposal networks = their algorithmic
+  gradient rows read + one read-modify-write of the touched table entries against HBM 8 TB/s (its real limiter, the L2 float-atomic
+  rate, is reported beside the bound as `atomic_updates_per_s`); GEMMs = 2 M K N against the dense 16-bit MFMA peak; the fused proposal networks = their algorithmic
   flops against the 16x16x16 MFMA rate (16-bit modes) or the fp32 VALU peak (parity mode)."""
   from nerf_hugs_amd import _lib
   # round 4: the profiled steps run on ONE stream (HUGS_NF_BWD_STREAMS=0 for their duration): with the per-level backward streams
@@ -227,10 +225,16 @@ def nerfacto_roofline(model, step_fn, N, steps=3):
         ent.update(kernel=f"k_hashgrid_fwd {n} samples x {L_} levels", bound="hbm", achieved=round(by / (us * 1e-6) / 1e9, 1), peak=8000.0,
                    unit="GB/s", frac=round(by / (us * 1e-6) / 8e12, 4), algorithmic_bytes=by)
       else:
-        tx = n * (4 * dense + 8 * (L_ - dense))
-        ent.update(kernel=f"k_hashgrid_bwd(+_l0) {n} samples x {L_} levels ({dense} dense)", bound="atomic",
-                   achieved=round(tx / (us * 1e-6) / 1e9, 2), peak=21.0, unit="Gtransactions/s", frac=round(tx / (us * 1e-6) / 21e9, 4),
-                   algorithmic_transactions=tx)
+        # bound (every kernel by max(bytes / 8 TB/s, flops / peak)): the gradient rows read + the sample
+        # positions + one read-modify-write of every table entry the samples can touch (at most the levels' tables).  The
+        # kernel's own limiter is the L2 float-atomic rate, reported beside it: `atomic_updates` = the 8 x F products per sample
+        # and level BEFORE the kernel merges runs of lanes that hit one cell (its issued count is data-dependent and lower).
+        tbl = float(g.offsets[L_] - g.offsets[0]) * F * 4 if g is not None else float('inf')
+        by = n * L_ * F * (2 if model.dt else 4) + n * 12 + 2 * min(float(n) * L_ * 8 * F * 4, tbl)
+        ent.update(kernel=f"k_hashgrid_bwd(+_l0) {n} samples x {L_} levels ({dense} dense)")
+        two_bounds(ent, us, by, 0.0, PEAK_BF16, "mfma")
+        ent.update(atomic_updates=n * L_ * 8 * F, atomic_updates_per_s=round(n * L_ * 8 * F / (us * 1e-6) / 1e9, 1),
+                   limiter="L2 float atomics (scratch/atomic_pair.hip: ~21 G distinct-address transactions/s on this chip)")
     elif key[0] in ('prop_fwd', 'prop_bwd'):
       n, i_, h_ = key[1:]
       fl = 2.0 * n * (i_ * h_ + h_) * (1 if key[0] == 'prop_fwd' else 3)

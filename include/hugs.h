@@ -371,6 +371,20 @@ int hugs_nf_app_bwd(int nrays, int S, int dtype, const void* dX, int ldx, int co
                     float* d_embedding, void* stream);
 int hugs_nf_rgb_act(long long M, int dtype, const void* Y, int ldy, float rgb_bias, float* rgb, void* stream);
 int hugs_nf_rgb_grad(long long M, int dtype, const float* rgb, const float* d_rgb, void* G, int ldg, void* stream);
+/* Fused nerfacto field forward (models/nerfacto.py:693-759 base network + colour network; csrc/hugs_fieldfuse.hip), the shape class
+ * of phototourism_nerfacto_base.yml: <= 32 hash features -> 256 relu -> 1 + ngeo; [SH16 | ngeo | napp] (<= 128) -> 256 relu -> 256
+ * relu -> 3 sigmoid; tmpl = hugs_nf_head_template's per-ray rows.  16-bit [n][k] weight copies: W0t [256][ldw0] (columns 0..31
+ * read); W1x [128][256] = the base network's second layer in HEAD-INPUT row order (row 0 = raw density, rows 16 .. 16 + ngeo = the
+ * geo features, the rest zero) with b1x [128] ordered alike; C0t [256][128]; C1t [256][256]; c2 [256,3] fp32, cb2 3 floats
+ * (rgb_bias already added).  Outputs: Y0, H0, H1 [M,256], raw [M] (16-bit raw density), Xh [M,128] (the head input), relu mask bits
+ * of Y0 / H0 in the hugs_gemm_nt_bits layout (or null), density = exp(raw) * sel, rgb [M,3].  M: a multiple of 256, whole rays of
+ * S samples; ngeo a multiple of 4. */
+int hugs_nf_field_fwd(int dtype, long long M, int S, const void* X0, int ldx0, const void* W0t, int ldw0, const void* W1x,
+                      const void* C0t, const void* C1t, const float* b0, const float* b1x, const float* cb0, const float* cb1,
+                      const float* c2, const float* cb2, const void* tmpl, int ngeo, const float* sel, void* Y0, void* raw, void* Xh,
+                      void* H0, void* H1, uint32_t* bY0, uint32_t* bH0, float* density, float* rgb, void* stream);
+/* per-ray head-input template of the kernel above: out[ray, 0..127] = [SH16 | 0 x ngeo | appearance | 0 ..] (16-bit) */
+int hugs_nf_head_template(int dtype, int nrays, const float* sh, const float* app, int ngeo, int napp, void* out, void* stream);
 int hugs_nf_adam(long long n, float* theta, const float* grad, float* m, float* v, float lr, float b1, float b2, float eps,
                  float bc1, float bc2, void* stream);
 /* Dynamic loss scaling of the fp16 mode = torch.cuda.amp.GradScaler as nerfacto/train.py:168,210-213 drives it

@@ -80,6 +80,8 @@ _PROTOS = {
     'hugs_nf_density_act': 'qipiipps',
     'hugs_nf_base_grad': 'qipipppiiipis',
     'hugs_nf_head_input': 'qiippiipipis',
+    'hugs_nf_field_fwd': 'iqipipippppppppppipppppppppps',
+    'hugs_nf_head_template': 'iippiips',
     'hugs_nf_app_bwd': 'iiipiiipps',
     'hugs_nf_rgb_act': 'qipifps',
     'hugs_nf_rgb_grad': 'qipppis',

@@ -274,6 +274,30 @@ class NerfactoModel:
         L.call('hugs_cast_weights', self.dt, K, N, W, self.wn[name], self.wt[name])
         if not self.dt:
           self.wn[name] = W
+    self._w1x_stale = True
+
+  def _refresh_w1x(self):
+    """The base network's second layer in head-input row order (csrc/hugs_fieldfuse.hip: row 0 = raw density, rows 16 .. 16 + ngeo
+    = the geo features): its outputs land in the colour network's input tile without a column shift.  Rebuilt on first use after
+    a weight refresh."""
+    g = self.cfg.geo_feat_dim
+    if 'field/w1x' not in self.wt:
+      self.wt['field/w1x'] = torch.zeros(128, self.wt['field/w1'].shape[1], dtype=self.tdt, device=self.device)
+      self.b1x = torch.zeros(128, device=self.device)
+    w1, b1 = self.wt['field/w1'], self.lay.view(self.flat, 'field/b1')
+    self.wt['field/w1x'][0].copy_(w1[0]); self.wt['field/w1x'][16:16 + g].copy_(w1[1:1 + g])
+    self.b1x[0:1].copy_(b1[0:1]); self.b1x[16:16 + g].copy_(b1[1:1 + g])
+    self._w1x_stale = False
+
+  def _field_fuse_ok(self):
+    """The fused field kernels (csrc/hugs_fieldfuse.hip) take the phototourism yml's shape class: 16-bit operands, <= 32 hash
+    features -> 256 -> 1 + geo, [SH16 | geo | appearance] = at most 128 columns -> 256 -> 256 -> 3 through the rgb head."""
+    c = self.cfg
+    if not self.dt or not self.rgb_head or os.environ.get('HUGS_NF_FIELD_FUSE', '0') != '1' or 'field/c0' not in self.lay.items:
+      return False
+    (K0, N0), (_, N1), (Kh, H) = (self.lay.items[k][1] for k in ('field/w0', 'field/w1', 'field/c0'))
+    return (self.lay.items['field/w0'][2][0] <= 32 and N0 == 256 and N1 == 128 and Kh == 128 and H == 256 and
+            self.lay.items['field/c1'][1] == (256, 256) and c.geo_feat_dim % 4 == 0 and 16 + c.geo_feat_dim + self.napp <= 128)
 
   # ---- GEMM helpers ---------------------------------------------------------------------------------------------------
   def _bits_ok(self, M, width, k):
@@ -388,6 +412,9 @@ class NerfactoModel:
                self.lay.view(self.flat, f'{name}/b0'), self.lay.view(self.flat, f'{name}/w1'), N1,
                self.lay.view(self.flat, f'{name}/b1'), sel, raw, dens)
         st = dict(S=S, M=M, name=name, sbins=sb, ebins=eb, x01=x01, sel=sel, X0=X0, Y0=None, Y1=None, raw=raw, density=dens, rgb=None)
+      elif not is_prop and M % 256 == 0 and self._field_fuse_ok():
+        st = self._field_forward_fused(lvl, rays, N, S, M, x01, sel, dens, training)
+        st.update(sbins=sb, ebins=eb)
       else:
         X0 = ws.get(f'X0_{lvl}', (M, K0), self.tdt)
         if (f'X0z_{lvl}', M) not in ws.bufs:        # the padding columns are written once and stay zero
@@ -401,7 +428,9 @@ class NerfactoModel:
         L.call('hugs_nf_density_act', M, dt, Y1, N1, 0, sel, dens)
         st = dict(S=S, M=M, name=name, sbins=sb, ebins=eb, x01=x01, sel=sel, X0=X0, Y0=Y0, Y1=Y1, density=dens, rgb=None, bY0=bY0)
       rgb_out = None
-      if not is_prop:
+      if st.get('fused_field'):
+        rgb_out = ws.get('rgb_out', (N, 3))
+      elif not is_prop:
         sh = ws.get('sh', (N, 16))
         vd01 = ws.get('vd01', (N, 3))
         torch.add(rays['viewdir'], 1.0, out=vd01); vd01.mul_(0.5)
@@ -444,6 +473,46 @@ class NerfactoModel:
       levels.append(st)
       bins, weights, nb = sb, w, S
     return levels
+
+  def _field_forward_fused(self, lvl, rays, N, S, M, x01, sel, dens, training):
+    """Base network + colour network of the field level in ONE launch (csrc/hugs_fieldfuse.hip k_field_fwd): the same state
+    dict as the layer-by-layer path, with the 16-bit raw density column in place of the padded base output."""
+    c, ws, dt = self.cfg, self.ws, self.dt
+    K0, N0 = self.lay.items['field/w0'][1]
+    Kh, H = self.lay.items['field/c0'][1]
+    X0 = ws.get(f'X0_{lvl}', (M, K0), self.tdt)
+    if (f'X0z_{lvl}', M) not in ws.bufs:        # the padding columns are written once and stay zero
+      X0.zero_(); ws.bufs[(f'X0z_{lvl}', M)] = True
+    self._grid_fwd('field', x01, X0)
+    sh, vd01 = ws.get('sh', (N, 16)), ws.get('vd01', (N, 3))
+    torch.add(rays['viewdir'], 1.0, out=vd01); vd01.mul_(0.5)
+    L.call('hugs_sh4_fwd', N, vd01, 0, 16, 0, sh)
+    app = None
+    if self.napp:
+      app = ws.get('app', (N, self.napp))
+      if training or c.eval_embedding == 'original':
+        L.call('hugs_glo_gather', N, self.napp, self.lay.view(self.flat, 'appearance'), rays['embed_idx'], 0, app)
+      elif c.eval_embedding == 'average':       # eval: every ray sees the mean embedding row (nerfacto.py:272-276)
+        app.copy_(self.lay.view(self.flat, 'appearance').mean(dim=0, keepdim=True).expand(N, -1))
+      else:
+        app.zero_()
+    if getattr(self, '_w1x_stale', True):
+      self._refresh_w1x()
+    tmpl = ws.get('head_tmpl', (N, 128), self.tdt)
+    L.call('hugs_nf_head_template', dt, N, sh, app, c.geo_feat_dim, self.napp, tmpl)
+    Y0, raw16, Xh = ws.get(f'Y0_{lvl}', (M, N0), self.tdt), ws.get('raw16', (M, 1), self.tdt), ws.get('Xh', (M, Kh), self.tdt)
+    H0, H1 = ws.get('H0', (M, H), self.tdt), ws.get('H1', (M, H), self.tdt)
+    bY0 = ws.get(f'bitsY0_{lvl}', (M * N0 // 32,), torch.int32) if training and self._bits_ok(M, N0, 128) else None
+    bH0 = ws.get('bitsH0', (M * H // 32,), torch.int32) if training and self._bits_ok(M, H, H) else None
+    rgb = ws.get('rgb_s', (M, 3))
+    beff = ws.get('cb2_eff', (4,))
+    torch.add(self.lay.view(self.flat, 'field/cb2'), float(c.rgb_bias), out=beff[:3])      # sigmoid(raw + rgb_bias), nerfacto.py:711
+    V = lambda n: self.lay.view(self.flat, n)
+    L.call('hugs_nf_field_fwd', dt, M, S, X0, K0, self.wt['field/w0'], K0, self.wt['field/w1x'], self.wt['field/c0'], self.wt['field/c1'],
+           V('field/b0'), self.b1x, V('field/cb0'), V('field/cb1'), V('field/c2'), beff, tmpl, c.geo_feat_dim, sel,
+           Y0, raw16, Xh, H0, H1, bY0, bH0, dens, rgb)
+    return dict(S=S, M=M, name='field', x01=x01, sel=sel, X0=X0, Y0=Y0, Y1=raw16, density=dens, rgb=rgb, bY0=bY0, bH0=bH0,
+                Xh=Xh, H0=H0, H1=H1, Yc=None, app=app, fused_field=True)
 
   # ---- HA-NeRF ImplicitMask (per ray; nerfacto.py:403-408, 1080-1091) -------------------------------------------------
   def _mask_forward(self, rays, N, training):
@@ -759,7 +828,7 @@ class NerfactoModel:
              self.lay.view(self.grad, f'{name}/w1'), self.lay.view(self.grad, f'{name}/b1'), slab)
       self._grid_bwd(name, st['x01'], dX0)
       return
-    N1 = st['Y1'].shape[1]
+    N1 = self.lay.items[f'{name}/w1'][1][1]
     dXh = None
     if st['rgb'] is not None:
       H = st['H0'].shape[1]
@@ -785,7 +854,7 @@ class NerfactoModel:
         L.call('hugs_nf_app_bwd', N, S, dt, dXh, Kh, 16 + c.geo_feat_dim, self.napp, rays['embed_idx'],
                self.lay.view(self.grad, 'appearance'))
     Gb = ws.get(f'Gb_{name}', (M, N1), self.tdt)
-    L.call('hugs_nf_base_grad', M, dt, st['Y1'], N1, st['sel'], d_dens, dXh, 0 if dXh is None else dXh.shape[1], 16,
+    L.call('hugs_nf_base_grad', M, dt, st['Y1'], st['Y1'].shape[1], st['sel'], d_dens, dXh, 0 if dXh is None else dXh.shape[1], 16,
            c.geo_feat_dim if dXh is not None else 0, Gb, N1)
     self._tn(M, f'{name}/w1', st['Y0'], Gb, f'{name}/b1')
     N0 = st['Y0'].shape[1]

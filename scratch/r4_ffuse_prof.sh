@@ -1,0 +1,19 @@
+ROOT=$PWD
+for v in 1 0; do
+cd /tmp && export TMPDIR=/tmp
+HUGS_NF_FIELD_FUSE=$v timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $ROOT/gpurun_out/ffprof$v -o t -- python $ROOT/bench.py --config cfg5 --min-time 0 --steps 10 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+cd $ROOT
+python - $v <<'PY'
+import csv, glob, collections, sys
+f = glob.glob(f'gpurun_out/ffprof{sys.argv[1]}/**/*kernel_trace.csv', recursive=True)[0]
+agg = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    agg[r['Kernel_Name']].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+tot = sum(sum(v) for v in agg.values())
+print('FUSE', sys.argv[1])
+for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:26]:
+    print(f"{k[:90]:90s} {len(v):6d} {sum(v)/1e6:10.3f} {sum(v)/len(v)/1e3:10.2f} {min(v)/1e3:10.2f} {100*sum(v)/tot:6.2f}")
+print(f"TOTAL GPU kernel time {tot/1e6:.3f} ms over {sum(len(v) for v in agg.values())} dispatches")
+PY
+rm -rf gpurun_out/ffprof$v
+done

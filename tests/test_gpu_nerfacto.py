@@ -409,3 +409,87 @@ def test_cfg5_16384_rays_bf16_properties(cdt):
     runs.append(run)
   assert runs[0][-5:, 1].mean() < 0.6 * runs[0][:3, 1].mean(), runs[0][:, 1]
   np.testing.assert_allclose(runs[0][:, 1], runs[1][:, 1], rtol=3e-2)
+
+
+def _cfg5_model_and_batch(cdt, N, seed=3):
+  from nerf_hugs_amd.nerfacto.model import NerfactoConfig, NerfactoModel
+  from nerf_hugs_amd.nerfacto.configs import PHOTOTOURISM_NERFACTO_BASE as YML
+  model = NerfactoModel(NerfactoConfig(**YML), compute_dtype=cdt, seed=seed)
+  g = torch.Generator(device=dev).manual_seed(100)
+  # (tables at their U(+-1e-4) init leave the field at its biases: scale them so the hash features matter; biases off zero)
+  for name, (off, pshape, shape) in model.lay.items.items():
+    v = model.lay.view(model.flat, name)
+    if name.endswith('/table'):
+      v.mul_(3e3)
+    elif len(pshape) == 1:
+      v[:shape[0]] = 0.1 * torch.randn(shape[0], generator=g, device=dev)
+  model.refresh_weights()
+  d = torch.randn(N, 3, generator=g, device=dev); d = d / d.norm(dim=-1, keepdim=True)
+  o = (torch.rand(N, 3, generator=g, device=dev) - 0.5) * 0.6
+  batch = dict(origin=o, direction=d, viewdir=d, near=torch.full((N,), 0.05, device=dev), far=torch.full((N,), 3.0, device=dev),
+               embed_idx=torch.randint(0, 3500, (N,), generator=g, device=dev).int(), bg_rgb=torch.ones(N, 3, device=dev),
+               rgb=(0.5 + 0.5 * torch.sin(3.0 * d + 2.0 * o)).contiguous())
+  u01 = [torch.rand(N, generator=g, device=dev) for _ in range(3)]
+  return model, batch, u01
+
+
+@pytest.mark.parametrize('cdt', ['bf16', 'fp16'])
+def test_fused_field_forward_equals_layer_by_layer(cdt, monkeypatch):
+  """csrc/hugs_fieldfuse.hip k_field_fwd (base network + colour network of the yml-size field in one launch, activations in
+  LDS) against the GEMM-per-layer path on the same model, rays and draws: every stored activation, the relu mask bits, the
+  head input and the densities agree to the last 16-bit ulp or so (same operands, same K order of the fp32 accumulation up
+  to the GEMM kernels' zero-padding stages); the rgb head sums its 256 products in another order."""
+  N = 512
+  model, batch, u01 = _cfg5_model_and_batch(cdt, N)
+  monkeypatch.setenv('HUGS_NF_FIELD_FUSE', '1')
+  assert model._field_fuse_ok()
+  keys = ('Y0', 'Xh', 'H0', 'H1', 'bY0', 'bH0', 'density', 'rgb', 'rgb_out', 'weights')
+  got = {}
+  for mode in ('0', '1'):
+    monkeypatch.setenv('HUGS_NF_FIELD_FUSE', mode)
+    lv = model.forward(batch, 300, u01=u01, training=True)
+    torch.cuda.synchronize()
+    st = lv[-1]
+    assert bool(st.get('fused_field')) == (mode == '1')
+    got[mode] = {k: st[k].clone() for k in keys}
+    got[mode]['raw'] = (st['Y1'][:, 0] if mode == '0' else st['Y1'].reshape(-1)).clone()
+    got[mode]['geo'] = st['Y1'][:, 1:65].clone() if mode == '0' else st['Xh'][:, 16:80].clone()
+  a, b = got['0'], got['1']
+  assert float(a['Y0'].float().abs().max()) > 0.1 and float(a['H1'].float().abs().max()) > 0.05
+  assert 0.05 < float((a['H0'] > 0).float().mean()) < 0.95
+  ulp = 2.0 ** -7 if cdt == 'bf16' else 2.0 ** -10
+  # first layer: one 16-bit ulp on a handful of elements (the GEMM kernel adds its zero K-padding stages); deeper layers inherit it
+  for k, frac, nulp in (('Y0', 1e-3, 1), ('raw', 1e-2, 4), ('geo', 1e-2, 4), ('Xh', 1e-2, 4), ('H0', 1e-2, 4), ('H1', 2e-2, 8)):
+    x, y = a[k].float(), b[k].float()
+    d = (x - y).abs()
+    assert float((d > 0).float().mean()) <= frac, f'{cdt} {k}: {int((d > 0).sum())} of {d.numel()} elements differ'
+    # (a pre-activation within fp32 rounding of zero may be 0 on one side and a tiny positive number on the other)
+    excess = float((d - nulp * ulp * torch.maximum(x.abs(), y.abs())).max())
+    assert excess <= (2e-5 if k == 'Y0' else 2e-3) * float(x.abs().max()), f'{cdt} {k}: max diff {float(d.max()):.3e}, excess {excess:.3e}'
+  for k in ('bY0', 'bH0'):      # mask bits: a flipped bit needs a pre-activation within an ulp of zero
+    flips = (a[k] ^ b[k]).view(torch.uint8)
+    nflip = int(sum(((flips >> s) & 1).sum() for s in range(8)))
+    assert nflip <= 1e-4 * a[k].numel() * 32, f'{cdt} {k}: {nflip} mask bits differ'
+  assert float((a['density'] - b['density']).abs().max()) <= 4 * ulp * float(a['density'].abs().max())
+  for k in ('rgb', 'rgb_out', 'weights'):
+    assert float((a[k] - b[k]).abs().max()) < 2e-3, (k, float((a[k] - b[k]).abs().max()), float((a[k] - b[k]).abs().mean()))
+
+
+@pytest.mark.parametrize('cdt', ['bf16', 'fp16'])
+def test_fused_field_step_gradients_equal_layer_by_layer(cdt, monkeypatch):
+  """One whole train step (no update) with the fused field kernels vs the layer-by-layer path: the same loss statistics and
+  the same parameter gradients up to the rgb head's summation order and the float-atomic table scatter."""
+  N = 512
+  model, batch, u01 = _cfg5_model_and_batch(cdt, N)
+  out = {}
+  for mode in ('0', '1'):
+    monkeypatch.setenv('HUGS_NF_FIELD_FUSE', mode)
+    res = model.train_step(batch, curr_step=300, u01=u01, apply_update=False)
+    torch.cuda.synchronize()
+    out[mode] = (res['stats'].clone(), model.grad.clone())
+  np.testing.assert_allclose(out['0'][0].cpu().numpy(), out['1'][0].cpu().numpy(), rtol=2e-5, atol=1e-9)
+  for name, (off, pshape, shape) in model.lay.items.items():
+    ga, gb = model.lay.view(out['0'][1], name).float(), model.lay.view(out['1'][1], name).float()
+    sc = float(ga.abs().max())
+    assert sc > 0 or name in ('transient',), name
+    assert float((ga - gb).abs().max()) <= 2e-3 * sc + 1e-12, f'{cdt} {name}: {float((ga - gb).abs().max()):.3e} vs scale {sc:.3e}'
