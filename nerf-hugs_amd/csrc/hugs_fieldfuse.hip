@@ -66,47 +66,18 @@ __device__ __forceinline__ int ff_at(int row, int col) {
   return (col >> 5) * FF_STAGE + row * 64 + ((((col & 31) >> 3) ^ (3 * ((row >> 2) & 1))) << 4) + (col & 7) * 2;
 }
 
-// the first min(3, KST) K-stages of a layer's weights -> the register ring.  W = the matrix (uniform), wo = the lane's BYTE
-// offset: row (col0 + r16), k offset kb * 8 (32-bit lane offsets on scalar bases: 64-bit per-lane addresses of every load and
-// store of the straight-line tile were hoisted out of the tile loop and spilled)
-template <int F16, int KST, int NJ>
-__device__ __forceinline__ void ff_prefetch(const uint16_t* W, unsigned wo, int ldw, typename FfOps<F16>::x8_t (&wq)[4][4]) {
-  typedef typename FfOps<F16>::x8_t x8_t;
-  wo = ff_fresh(wo);
+// This thread's share of a finished activation tile (NST K-stages = 32 NST columns of all 64 rows) LDS -> HBM rows of 64 NST bytes:
+// 16 bytes per lane, a row's 64 NST bytes contiguous over 4 NST lanes.  Loads and stores retire through ONE in-order counter, so
+// a store issued ahead of a weight load is waited for with it: the copies sit in the NEXT layer's MFMA loop right after that
+// loop instead of in the epilogue that produced the tile, and the only loads of the tile loop (the next tile's inputs) are
+// requested ahead of them and consumed in straight-line code (counted vmcnt: the stores behind them stay in flight).
+template <int NST>
+__device__ __forceinline__ void ff_copy_out(const unsigned char* src, char* dst_tile, int tid) {
 #pragma unroll
-  for (int s = 0; s < (KST < 3 ? KST : 3); ++s)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) wq[s][j] = *(const x8_t*)((const char*)W + (wo + (unsigned)(j * 16 * ldw + s * 32) * 2u));
-}
-
-// acc[i][j] += sum over KST stages of W-fragment(j) x X-fragment(i); A = the activation tile (stage s0 first)
-template <int F16, int KST, int NJ>
-__device__ __forceinline__ void ff_mma(const unsigned char* A, int frag_off, const uint16_t* W, unsigned wo, int ldw,
-                                       typename FfOps<F16>::x8_t (&wq)[4][4], ff_f32x4_t (&acc)[4][4]) {
-  typedef typename FfOps<F16>::x8_t x8_t;
-  wo = ff_fresh(wo);
-#ifdef FF_NOMMA      // (timing builds, scratch/r4_ffuse_var.sh: -DFF_NOMMA / FF_NOSTORE / FF_NOWLOAD)
-  return;
-#endif
-#pragma unroll
-  for (int s = 0; s < KST; ++s) {
-#ifndef FF_NOWLOAD
-    if (s + 3 < KST)
-#else
-    if (false)
-#endif
-    {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) wq[(s + 3) & 3][j] = *(const x8_t*)((const char*)W + (wo + (unsigned)(j * 16 * ldw + (s + 3) * 32) * 2u));
-    }
-    x8_t xa[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) xa[i] = *(const x8_t*)(A + s * FF_STAGE + frag_off + i * 16 * 64);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[i][j] = FfOps<F16>::mfma(wq[s & 3][j], xa[i], acc[i][j]);
-    __builtin_amdgcn_sched_barrier(0);      // (keeps the weight loads three stages ahead, not eight: the straight-line tile spilled)
+  for (int q = 0; q < NST; ++q) {
+    const int id = q * 256 + tid, row = id / (NST * 4), cc = id % (NST * 4);
+    const uint4 v = *(const uint4*)(src + (cc >> 2) * FF_STAGE + row * 64 + (((cc & 3) ^ (3 * ((row >> 2) & 1))) << 4));
+    *(uint4*)(dst_tile + ff_fresh((unsigned)(row * (NST * 64) + cc * 16))) = v;
   }
 }
 
@@ -127,6 +98,13 @@ __device__ __forceinline__ void ff_acc_zero(ff_f32x4_t (&acc)[4][4]) {
     for (int i = 0; i < 4; ++i) acc[i][j] = ff_f32x4_t{0.f, 0.f, 0.f, 0.f};
 }
 
+#ifdef FF_TRACE      // (timing builds: s_memtime at the phase edges of workgroup 0's first tiles, waves 0 and 3)
+__device__ long long ff_trace_buf[2 * 8 * 16];
+#define FF_TP(k_) do { if (blockIdx.x == 0 && ti < 8 && (tid == 0 || tid == 192)) ff_trace_buf[((tid != 0) * 8 + ti) * 16 + (k_)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define FF_TP(k_) do { } while (0)
+#endif
+
 struct FieldFwd {
   int M, S, ldx0, ldw0, ngeo;
   const uint16_t* X0;                       // [M, ldx0] hash features, columns 0..31 real
@@ -142,11 +120,46 @@ struct FieldFwd {
   float* rgb;                               // [M, 3]
 };
 
-// relu + 16-bit rounding + {HBM row, next layer's LDS tile, mask bits} of one 64 x 64 wave block (NJ = 4)
-template <int F16, bool RELU, bool KEEP>
-__device__ __forceinline__ void ff_emit256(ff_f32x4_t (&acc)[4][4], int m0, int wn, int r16, int kb, int lane, uint16_t* Y /* [M,256] */,
-                                           unsigned char* An, uint32_t* bout, uint32_t (&keep)[4][4][2]) {
+// thread (row = tid >> 2, cc = tid & 3) requests its part of a tile's inputs: 16 bytes of the row's hash features and the 64
+// bytes [32 cc, 32 cc + 32) of its ray's head-input template (hugs_nf_head_template: [SH16 | 0 (geo) | appearance | 0], 16-bit)
+struct FfIn { uint4 x, t0, t1, t2, t3; };
+__device__ __forceinline__ FfIn ff_load_inputs(const FieldFwd& P, int m0, int tid) {
+  const int row = tid >> 2, cc = tid & 3;
+  FfIn r;
+  r.x = *(const uint4*)((const char*)(P.X0 + (size_t)m0 * P.ldx0) + ff_fresh((unsigned)(row * P.ldx0 + cc * 8) * 2u));
+  const unsigned ray = (unsigned)(m0 + row) / (unsigned)P.S;
+  const char* tp = (const char*)P.tmpl + ff_fresh(ray * 256u + (unsigned)cc * 64u);
+  r.t0 = *(const uint4*)tp; r.t1 = *(const uint4*)(tp + 16); r.t2 = *(const uint4*)(tp + 32); r.t3 = *(const uint4*)(tp + 48);
+  return r;
+}
+
+// One 256-wide relu layer of a tile for this wave (its 64 output columns of all 64 rows), 16-row block by 16-row block: the MFMAs
+// of row block i + 1 are issued ahead of the epilogue of block i (relu, 16-bit rounding, the next layer's LDS tile, mask bits;
+// LAST: the HBM row + the rgb head's partial sums), so that the epilogue's VALU work fills the issue slots between independent
+// MFMAs -- with one wave per SIMD nothing else would.  (The weights sit in registers, so the loop order is free.)
+template <int F16, int KST, int CP, bool LAST>
+__device__ __forceinline__ void ff_layer256(const unsigned char* A, int frag_off, const typename FfOps<F16>::x8_t (&w)[KST][4],
+                                            const float* bias /* + wn*64 + kb*4 */, int m0, int wn, int r16, int kb, int lane,
+                                            unsigned char* An, uint32_t* bout, uint16_t* Y, const unsigned char* cp_src, char* cp_dst,
+                                            int tid, const float* c2s, float (*red)[4][3]) {
+  typedef typename FfOps<F16>::x8_t x8_t;
   const int swz = 3 * ((r16 >> 2) & 1);
+  float4 bb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bb[j] = *(const float4*)(bias + j * 16);
+  ff_f32x4_t acc[2][4];
+  auto mma_rows = [&](int i, ff_f32x4_t (&a)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = ff_f32x4_t{bb[j].x, bb[j].y, bb[j].z, bb[j].w};
+#ifndef FF_NOMMA
+#pragma unroll
+    for (int s = 0; s < KST; ++s) {
+      const x8_t xa = *(const x8_t*)(A + s * FF_STAGE + frag_off + i * 16 * 64);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = FfOps<F16>::mfma(w[s][j], xa, a[j]);
+    }
+#endif
+  };
   uint16_t* Yout = Y ? Y + (size_t)m0 * 256 : nullptr;                    // (uniform)
   const unsigned yo = ff_fresh((unsigned)(r16 * 256 + wn * 64 + kb * 4) * 2u);      // (bytes)
   const unsigned bo = ff_fresh((unsigned)lane * 4u);
@@ -154,15 +167,17 @@ __device__ __forceinline__ void ff_emit256(ff_f32x4_t (&acc)[4][4], int m0, int 
   const int i_nt0 = ((m0 >> 6) & 1) * 4;
   uint32_t* btile = bout ? bout + ((size_t)(m0 >> 8) * 8 + (size_t)(((m0 >> 7) & 1) * 4 + wn)) * 256 : nullptr;      // (uniform)
   uint32_t bw = 0u;
+  mma_rows(0, acc[0]);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    if (i < 3) mma_rows(i + 1, acc[(i + 1) & 1]);
+    if constexpr (CP > 0) { if (i == 0) ff_copy_out<CP>(cp_src, cp_dst, tid); }
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float x0 = acc[i][j][0], x1 = acc[i][j][1], x2 = acc[i][j][2], x3 = acc[i][j][3];
-      if (RELU) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); x2 = fmaxf(x2, 0.f); x3 = fmaxf(x3, 0.f); }
+      const ff_f32x4_t v = acc[i & 1][j];
       uint2 u;
-      u.x = ff_cvt_pk<F16>(x0, x1); u.y = ff_cvt_pk<F16>(x2, x3);
-      if (KEEP) { keep[i][j][0] = u.x; keep[i][j][1] = u.y; }
+      u.x = ff_cvt_pk<F16>(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)); u.y = ff_cvt_pk<F16>(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
 #ifndef FF_NOSTORE
       if (Yout) *(uint2*)((char*)Yout + (yo + (unsigned)(i * 16 * 256 + j * 16) * 2u)) = u;
 #endif
@@ -175,69 +190,131 @@ __device__ __forceinline__ void ff_emit256(ff_f32x4_t (&acc)[4][4], int m0, int 
         bw |= ((u.x + 0x7fff7fffu) >> (15 - k)) & (0x00010001u << k);
         bw |= ((u.y + 0x7fff7fffu) >> (14 - k)) & (0x00010001u << (k + 1));
       }
+      if (LAST) {      // rgb head on the rounded activations: c2s [256][3] fp32
+        const float* wc = c2s + (wn * 64 + j * 16 + kb * 4) * 3;
+        const float4 w0 = *(const float4*)wc, w1 = *(const float4*)(wc + 4), w2 = *(const float4*)(wc + 8);
+        const float v0 = FfOps<F16>::lo(u.x), v1 = FfOps<F16>::hi(u.x), v2 = FfOps<F16>::lo(u.y), v3 = FfOps<F16>::hi(u.y);
+        a0 += v0 * w0.x + v1 * w0.w + v2 * w1.z + v3 * w2.y;
+        a1 += v0 * w0.y + v1 * w1.x + v2 * w1.w + v3 * w2.z;
+        a2 += v0 * w0.z + v1 * w1.y + v2 * w2.x + v3 * w2.w;
+      }
     }
     if (bout && (i & 1)) { *(uint32_t*)((char*)btile + (bo + (unsigned)(((i_nt0 + i) >> 1) * 64) * 4u)) = bw; bw = 0u; }
+    if (LAST) {
+      // sum over the four kb lane groups: v_permlane16_swap / v_permlane32_swap of a value with itself leave (x, neighbour's x) in
+      // the two results.  (__shfl_xor's ds_bpermute_b32 returned a stale FIRST operand here now and then -- the low half of the
+      // v_pk_add_f32 pair the compiler forms from a0 / a1 -- on ~0.7 % of the rows, run-to-run different: scratch/ffuse_bench.py.)
+      a0 = ff_sum_kb(a0); a1 = ff_sum_kb(a1); a2 = ff_sum_kb(a2);
+      if (kb == 0) { red[i * 16 + r16][wn][0] = a0; red[i * 16 + r16][wn][1] = a1; red[i * 16 + r16][wn][2] = a2; }
+    }
   }
 }
 
+// register-resident weights: stage s, fragment j of a [n][k] matrix for this lane (W uniform, wo = the lane's byte offset)
+template <int F16, int KST, int NJ>
+__device__ __forceinline__ void ff_load_w(const uint16_t* W, unsigned wo, int ldw, typename FfOps<F16>::x8_t (&w)[KST][NJ]) {
+  typedef typename FfOps<F16>::x8_t x8_t;
+#pragma unroll
+  for (int s = 0; s < KST; ++s)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) w[s][j] = *(const x8_t*)((const char*)W + (wo + (unsigned)(j * 16 * ldw + s * 32) * 2u));
+}
+
+// acc[i][j] += sum over KST stages of W-fragment(s, j) x X-fragment(i, s); A = the activation tile (its first stage).  CP > 0: the
+// copy-out job of an earlier tile (cp_src, CP stages) rides in this loop (ff_copy_out).
+template <int F16, int KST, int NJ, int CP = 0>
+__device__ __forceinline__ void ff_mma_r(const unsigned char* A, int frag_off, const typename FfOps<F16>::x8_t (&w)[KST][NJ],
+                                         ff_f32x4_t (&acc)[4][4], const unsigned char* cp_src = nullptr, char* cp_dst = nullptr,
+                                         int tid = 0) {
+  typedef typename FfOps<F16>::x8_t x8_t;
+#ifdef FF_NOMMA      // (timing builds, scratch/r4_ffuse_var.sh)
+  if constexpr (CP > 0) ff_copy_out<CP>(cp_src, cp_dst, tid);
+  return;
+#endif
+#pragma unroll
+  for (int s = 0; s < KST; ++s) {
+    if constexpr (CP > 0) { if (s == 1) ff_copy_out<CP>(cp_src, cp_dst, tid); }
+    x8_t xa[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xa[i] = *(const x8_t*)(A + s * FF_STAGE + frag_off + i * 16 * 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = FfOps<F16>::mfma(w[s][j], xa[i], acc[i][j]);
+  }
+}
+
+// a tile's inputs -> LDS: the thread's 16 bytes of hash features -> stage 7 of `A`, its 64 bytes of the head-input template ->
+// stage cc (the geo columns of stages 0..2 are overwritten by layer 1's epilogue), the selector of row tid -> sel_s
+__device__ __forceinline__ void ff_put_inputs(unsigned char* A, float* sel_s, const FfIn& nx, float nsel, int tid) {
+  const int row = tid >> 2, cc = tid & 3, sw = 3 * ((row >> 2) & 1);
+  *(uint4*)(A + 7 * FF_STAGE + row * 64 + ((cc ^ sw) << 4)) = nx.x;
+  unsigned char* tb = A + cc * FF_STAGE + row * 64;
+  *(uint4*)(tb + ((0 ^ sw) << 4)) = nx.t0; *(uint4*)(tb + ((1 ^ sw) << 4)) = nx.t1;
+  *(uint4*)(tb + ((2 ^ sw) << 4)) = nx.t2; *(uint4*)(tb + ((3 ^ sw) << 4)) = nx.t3;
+  if (tid < FF_ROWS) sel_s[tid] = nsel;
+}
+
+// One workgroup per CU, one wave per SIMD: the lane's share of ALL FOUR weight matrices (16 + 64 + 64 + 128 = 272 registers of the
+// 512) is loaded once and stays in registers for the whole kernel -- with two workgroups per CU and the weights streamed from L2
+// three K-stages ahead (the first form of this kernel, 1.6-1.9 ms for 2 M samples) every stage of every layer waited ~1.5 k
+// cycles for its weights (s_memtime trace: 14 k cycles in colour layer 1's loop for 2 k cycles of MFMAs) and the 272 KB per
+// 64-row tile added up to 9 GB of L2 reads.  No global load is waited for inside the tile loop except the NEXT tile's inputs,
+// requested a layer and a half before they are written to LDS (counted vmcnt in straight-line code: the stores behind them
+// stay in flight).
 template <int F16>
-__global__ __launch_bounds__(256, 2) void k_field_fwd(const FieldFwd P) {
+__global__ __launch_bounds__(256, 1) void k_field_fwd(const FieldFwd P) {
   typedef typename FfOps<F16>::x8_t x8_t;
   __shared__ __attribute__((aligned(16))) unsigned char act[2][FF_ACT];
   __shared__ float red[FF_ROWS][4][3];
+  __shared__ float sel_s[FF_ROWS];
   __shared__ __attribute__((aligned(16))) float c2s[256 * 3 + 4];
+  __shared__ __attribute__((aligned(16))) float bs[256 + 128 + 256 + 256];      // b0 | b1x | cb0 | cb1
   const int tid = threadIdx.x, lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, kb = lane >> 4;
   const int swz = 3 * ((r16 >> 2) & 1);
   const int frag_off = r16 * 64 + ((kb ^ swz) << 4);
-  const int ntile = P.M / FF_ROWS;
+  const int ntile = P.M / FF_ROWS, G = (int)gridDim.x;
   for (int e = tid; e < 256 * 3; e += 256) c2s[e] = P.c2[e];
   if (tid < 3) c2s[768 + tid] = P.cb2[tid];
-  // lane bases of the four weight matrices
-  const unsigned w0o = (unsigned)((wn * 64 + r16) * P.ldw0 + kb * 8) * 2u, w1o = (unsigned)((wn * 32 + r16) * 256 + kb * 8) * 2u;      // bytes
-  const unsigned c0o = (unsigned)((wn * 64 + r16) * 128 + kb * 8) * 2u, c1o = (unsigned)((wn * 64 + r16) * 256 + kb * 8) * 2u;
+  bs[tid] = P.b0[tid]; bs[384 + tid] = P.cb0[tid]; bs[640 + tid] = P.cb1[tid];
+  if (tid < 128) bs[256 + tid] = P.b1[tid];
   const bool l1_live = wn * 32 < 16 + P.ngeo;      // (wave-uniform) this wave's 32 columns of layer 1 hold real outputs
+  x8_t w0r[1][4], w1r[8][2], c0r[4][4], c1r[8][4];
+  ff_load_w<F16, 1, 4>(P.W0t, (unsigned)((wn * 64 + r16) * P.ldw0 + kb * 8) * 2u, P.ldw0, w0r);
+  ff_load_w<F16, 8, 2>(P.W1t, (unsigned)((wn * 32 + r16) * 256 + kb * 8) * 2u, 256, w1r);      // (rows past 16 + ngeo are zero)
+  ff_load_w<F16, 4, 4>(P.C0t, (unsigned)((wn * 64 + r16) * 128 + kb * 8) * 2u, 128, c0r);
+  ff_load_w<F16, 8, 4>(P.C1t, (unsigned)((wn * 64 + r16) * 256 + kb * 8) * 2u, 256, c1r);
 
-#ifdef FF_STAGGER      // (timing experiment: the second workgroup of a CU starts ~half a tile late)
-  if (blockIdx.x >= gridDim.x / 2)
-    for (int q = 0; q < FF_STAGGER; ++q) __builtin_amdgcn_s_sleep(127);
-#endif
-  for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+  FfIn nx;
+  float nsel = 0.f;
+  if ((int)blockIdx.x < ntile) {
+    nx = ff_load_inputs(P, (int)blockIdx.x * FF_ROWS, tid);
+    if (tid < FF_ROWS) nsel = P.sel[(size_t)blockIdx.x * FF_ROWS + tid];
+    ff_put_inputs(act[0], sel_s, nx, nsel, tid);
+  }
+  __syncthreads();
+  int ti = -1;
+  for (int t = blockIdx.x; t < ntile; t += G) {
     const int m0 = t * FF_ROWS;
-    x8_t wq[4][4];
+    const bool has_next = t + G < ntile;
+    ++ti;
+    FF_TP(0);
     ff_f32x4_t acc[4][4];
-    uint32_t keep[4][4][2];
-    ff_prefetch<F16, 1, 4>(P.W0t, w0o, P.ldw0, wq);
-    __syncthreads();      // the previous tile's readers of act[] / red are done (first tile: c2s is published)
-    {
-      // hash features -> act[0] stage 7 (the head input assembled below uses stages 0..3 of the same buffer)
-      const int row = tid >> 2, cc = tid & 3;
-      const uint4 v = *(const uint4*)((const char*)(P.X0 + (size_t)m0 * P.ldx0) + ff_fresh((unsigned)(row * P.ldx0 + cc * 8) * 2u));
-      *(uint4*)(act[0] + 7 * FF_STAGE + row * 64 + ((cc ^ (3 * ((row >> 2) & 1))) << 4)) = v;
-      // head-input template of the row's ray (hugs_nf_head_template: [SH16 | 0 (geo) | appearance | 0], 128 columns, 16-bit) ->
-      // stages 0..3; the geo columns are written by layer 1's epilogue, two barriers later.  thread = (row, 32-column stage cc)
-      const unsigned ray = (unsigned)(m0 + row) / (unsigned)P.S;
-      const char* tp = (const char*)P.tmpl + ff_fresh(ray * 256u + (unsigned)cc * 64u);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *(uint4*)(act[0] + cc * FF_STAGE + row * 64 + ((q ^ (3 * ((row >> 2) & 1))) << 4)) = *(const uint4*)(tp + q * 16);
-    }
-    __syncthreads();
     // ---- base layer 0: 32 -> 256, relu ------------------------------------------------------------------------------
-    ff_acc_bias<4>(acc, P.b0 + wn * 64 + kb * 4);
-    ff_mma<F16, 1, 4>(act[0] + 7 * FF_STAGE, frag_off, P.W0t, w0o, P.ldw0, wq, acc);
-    if (l1_live) ff_prefetch<F16, 8, 2>(P.W1t, w1o, 256, wq);
-    ff_emit256<F16, true, false>(acc, m0, wn, r16, kb, lane, P.Y0, act[1], P.bY0, keep);
+    ff_layer256<F16, 1, 0, false>(act[0] + 7 * FF_STAGE, frag_off, w0r, bs + wn * 64 + kb * 4, m0, wn, r16, kb, lane, act[1], P.bY0, nullptr,
+                                  nullptr, nullptr, tid, c2s, red);      // (Y0 -> HBM: in layer 1's loop)
+    FF_TP(1);
+    FF_TP(2);
     __syncthreads();
+    FF_TP(3);
     // ---- base layer 1: 256 -> 1 + ngeo (no activation), computed in HEAD-INPUT column order (W1t / b1 rows: 0 = raw density,
     // 16 .. 16 + ngeo = the geo features, the rest zero): the geo block lands in the head-input tile as aligned 8-byte writes
     if (l1_live) {
-      ff_acc_bias<2>(acc, P.b1 + wn * 32 + kb * 4);
-      ff_mma<F16, 8, 2>(act[1], frag_off, P.W1t, w1o, 256, wq, acc);
-    }
-    ff_prefetch<F16, 4, 4>(P.C0t, c0o, 128, wq);
-    if (l1_live) {
+      ff_acc_bias<2>(acc, bs + 256 + wn * 32 + kb * 4);
+      ff_mma_r<F16, 8, 2, 8>(act[1], frag_off, w1r, acc, act[1], (char*)(P.Y0 + (size_t)m0 * 256), tid);
+      FF_TP(4);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int n = wn * 32 + j * 16 + kb * 4;
@@ -250,60 +327,46 @@ __global__ __launch_bounds__(256, 2) void k_field_fwd(const FieldFwd P) {
           if (geo) *(uint2*)(act[0] + ((n >> 5) * FF_STAGE + row * 64 + ((((n & 31) >> 3) ^ swz) << 4) + (n & 4) * 2)) = u;
           if (n == 0) {
             *(uint16_t*)((char*)(P.raw + m0) + ff_fresh((unsigned)row * 2u)) = (uint16_t)u.x;
-            const unsigned ro = ff_fresh((unsigned)row * 4u);
-            *(float*)((char*)(P.density + m0) + ro) = expf(FfOps<F16>::lo(u.x)) * *(const float*)((const char*)(P.sel + m0) + ro);
+            *(float*)((char*)(P.density + m0) + ff_fresh((unsigned)row * 4u)) = expf(FfOps<F16>::lo(u.x)) * sel_s[row];
           }
         }
       }
+    } else {
+      ff_copy_out<8>(act[1], (char*)(P.Y0 + (size_t)m0 * 256), tid);
+      FF_TP(4);
     }
+    FF_TP(5);
     __syncthreads();
-    // ---- head input -> HBM (the colour network's first weight gradient reads it); colour layer 0: 128 -> 256, relu ------
-    {
-      const int row = tid >> 2, st = tid & 3;
-      const unsigned char* src = act[0] + st * FF_STAGE + row * 64;
-      char* dst = (char*)(P.Xh + (size_t)m0 * 128) + ff_fresh((unsigned)(row * 128 + st * 32) * 2u);
-      const int sw = 3 * ((row >> 2) & 1);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) *(uint4*)(dst + q * 16) = *(const uint4*)(src + ((q ^ sw) << 4));
+    FF_TP(6);
+    // ---- colour layer 0: 128 -> 256, relu (the head input goes to HBM in its loop: the first colour weight gradient reads it);
+    // the next tile's inputs are requested here and written to LDS after colour layer 1's loop
+    if (has_next) {
+      nx = ff_load_inputs(P, m0 + G * FF_ROWS, tid);
+      if (tid < FF_ROWS) nsel = *(const float*)((const char*)(P.sel + (size_t)m0 + (size_t)G * FF_ROWS) + ff_fresh((unsigned)tid * 4u));
     }
-    ff_acc_bias<4>(acc, P.cb0 + wn * 64 + kb * 4);
-    ff_mma<F16, 4, 4>(act[0], frag_off, P.C0t, c0o, 128, wq, acc);
-    ff_prefetch<F16, 8, 4>(P.C1t, c1o, 256, wq);
-    ff_emit256<F16, true, false>(acc, m0, wn, r16, kb, lane, P.H0, act[1], P.bH0, keep);
+    ff_layer256<F16, 4, 4, false>(act[0], frag_off, c0r, bs + 384 + wn * 64 + kb * 4, m0, wn, r16, kb, lane, act[1], P.bH0, nullptr,
+                                  act[0], (char*)(P.Xh + (size_t)m0 * 128), tid, c2s, red);      // (H0 -> HBM: in the next loop)
+    FF_TP(7);
+    FF_TP(8);
     __syncthreads();
+    FF_TP(9);
     // ---- colour layer 1: 256 -> 256, relu; rgb = sigmoid(H1 c2 + cb2) on the rounded activations ---------------------------
-    ff_acc_bias<4>(acc, P.cb1 + wn * 64 + kb * 4);
-    ff_mma<F16, 8, 4>(act[1], frag_off, P.C1t, c1o, 256, wq, acc);
-    ff_emit256<F16, true, true>(acc, m0, wn, r16, kb, lane, P.H1, nullptr, nullptr, keep);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float* w = c2s + (wn * 64 + j * 16 + kb * 4) * 3;
-        const float4 w0 = *(const float4*)w, w1 = *(const float4*)(w + 4), w2 = *(const float4*)(w + 8);
-        const float v0 = FfOps<F16>::lo(keep[i][j][0]), v1 = FfOps<F16>::hi(keep[i][j][0]);
-        const float v2 = FfOps<F16>::lo(keep[i][j][1]), v3 = FfOps<F16>::hi(keep[i][j][1]);
-        a0 += v0 * w0.x + v1 * w0.w + v2 * w1.z + v3 * w2.y;
-        a1 += v0 * w0.y + v1 * w1.x + v2 * w1.w + v3 * w2.z;
-        a2 += v0 * w0.z + v1 * w1.y + v2 * w2.x + v3 * w2.w;
-      }
-      // sum over the four kb lane groups: v_permlane16_swap / v_permlane32_swap of a value with itself leave (x, neighbour's x) in
-      // the two results.  (__shfl_xor's ds_bpermute_b32 returned a stale FIRST operand here now and then -- the low half of the
-      // v_pk_add_f32 pair the compiler forms from a0 / a1 -- on ~0.7 % of the rows, run-to-run different: scratch/ffuse_bench.py.)
-      a0 = ff_sum_kb(a0); a1 = ff_sum_kb(a1); a2 = ff_sum_kb(a2);
-      if (kb == 0) { red[i * 16 + r16][wn][0] = a0; red[i * 16 + r16][wn][1] = a1; red[i * 16 + r16][wn][2] = a2; }
-    }
+    if (has_next) ff_put_inputs(act[0], sel_s, nx, nsel, tid);      // (act[0] is free since the barrier above)
+    FF_TP(10);
+    ff_layer256<F16, 8, 8, true>(act[1], frag_off, c1r, bs + 640 + wn * 64 + kb * 4, m0, wn, r16, kb, lane, nullptr, nullptr, P.H1,
+                                 act[1], (char*)(P.H0 + (size_t)m0 * 256), tid, c2s, red);
+    FF_TP(11);
+    FF_TP(12);
     __syncthreads();
+    FF_TP(13);
     if (tid < FF_ROWS * 3) {
       const int row = tid / 3, c = tid - row * 3;
       const float a = ((red[row][0][c] + red[row][1][c]) + (red[row][2][c] + red[row][3][c])) + c2s[768 + c];
-
       *(float*)((char*)(P.rgb + (size_t)m0 * 3) + ff_fresh((unsigned)tid * 4u)) = 1.f / (1.f + expf(-a));
     }
+    FF_TP(14);
   }
 }
-
 
 // per-ray head-input template: out[ray, 0..127] = [SH16 | 0 x ngeo | appearance (napp) | 0 ...] in the 16-bit operand format
 __global__ void k_head_template(int nrays, int f16, const float* __restrict__ sh, const float* __restrict__ app, int ngeo, int napp,
@@ -316,6 +379,10 @@ __global__ void k_head_template(int nrays, int f16, const float* __restrict__ sh
 }
 
 }  // namespace
+
+#ifdef FF_TRACE
+extern "C" int hugs_ff_trace_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ff_trace_buf), sizeof(long long) * 256); }
+#endif
 
 // include/hugs.h hugs_nf_head_template
 extern "C" int hugs_nf_head_template(int dtype, int nrays, const float* sh, const float* app, int ngeo, int napp, void* out, void* stream) {
@@ -353,7 +420,7 @@ extern "C" int hugs_nf_field_fwd(int dtype, long long M, int S, const void* X0, 
   int dev = 0, ncu = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) ncu = 256;
   const int ntile = (int)(M / FF_ROWS);
-  const dim3 grid(ntile < 2 * ncu ? ntile : 2 * ncu), block(256);
+  const dim3 grid(ntile < ncu ? ntile : ncu), block(256);
   if (dtype == 2) hipLaunchKernelGGL(k_field_fwd<1>, grid, block, 0, (hipStream_t)stream, P);
   else hipLaunchKernelGGL(k_field_fwd<0>, grid, block, 0, (hipStream_t)stream, P);
   HUGS_CHECK_LAUNCH("hugs_nf_field_fwd");

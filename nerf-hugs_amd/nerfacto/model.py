@@ -293,7 +293,7 @@ class NerfactoModel:
     """The fused field kernels (csrc/hugs_fieldfuse.hip) take the phototourism yml's shape class: 16-bit operands, <= 32 hash
     features -> 256 -> 1 + geo, [SH16 | geo | appearance] = at most 128 columns -> 256 -> 256 -> 3 through the rgb head."""
     c = self.cfg
-    if not self.dt or not self.rgb_head or os.environ.get('HUGS_NF_FIELD_FUSE', '0') != '1' or 'field/c0' not in self.lay.items:
+    if not self.dt or not self.rgb_head or os.environ.get('HUGS_NF_FIELD_FUSE', '1') == '0' or 'field/c0' not in self.lay.items:
       return False
     (K0, N0), (_, N1), (Kh, H) = (self.lay.items[k][1] for k in ('field/w0', 'field/w1', 'field/c0'))
     return (self.lay.items['field/w0'][2][0] <= 32 and N0 == 256 and N1 == 128 and Kh == 128 and H == 256 and

@@ -29,3 +29,15 @@ print(os.environ.get('HUGS_LIB_PATH', 'default'), 'M', M, 'us', round(e0.elapsed
 ref = torch.sigmoid(H1.float() @ c2 + cb2[:3])
 d = (ref - rgb).abs()
 print('  rgb vs torch on the kernel H1: max', float(d.max()), 'bad rows per channel', (d > 1e-4).sum(dim=0).tolist())
+import ctypes, numpy as np
+cd = L.lib().cdll
+if hasattr(cd, 'hugs_ff_trace_read'):
+  buf = np.zeros(256, np.int64)
+  cd.hugs_ff_trace_read(buf.ctypes.data_as(ctypes.c_void_p))
+  tr = buf.reshape(2, 8, 16)
+  names = ['L0 mma', 'L0 emit', 'sync', 'sync2', 'L1 mma+copyY0', 'L1 epi', 'sync', 'C0 ld+mma+copyXh', 'C0 emit', 'sync', 'C1 mma+copyH0', 'put+C1 emit', 'rgb part', 'sync', 'final']
+  for w in range(2):
+    print('wave', 0 if w == 0 else 3, 'phase cycles per tile:')
+    for ti in range(1, 6):
+      d = np.diff(tr[w, ti][:15]); nxt = tr[w, ti + 1, 0] - tr[w, ti, 14]
+      print('   tile', ti, ' '.join(f'{n}={int(v)}' for n, v in zip(names, d)), 'loop=', int(nxt), 'total', int(tr[w, ti + 1, 0] - tr[w, ti, 0]))
