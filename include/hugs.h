@@ -383,6 +383,17 @@ int hugs_nf_field_fwd(int dtype, long long M, int S, const void* X0, int ldx0, c
                       const void* C0t, const void* C1t, const float* b0, const float* b1x, const float* cb0, const float* cb1,
                       const float* c2, const float* cb2, const void* tmpl, int ngeo, const float* sel, void* Y0, void* raw, void* Xh,
                       void* H0, void* H1, uint32_t* bY0, uint32_t* bH0, float* density, float* rgb, void* stream);
+/* Backward of the two networks above from colour layer 1's pre-activation gradient G1 [M,256] (hugs_rgb_bwd writes it) down to the
+ * hash-feature gradient, one launch: G0 = (G1 c1^T) relu'(H0), dXh = G0 c0^T, appearance columns summed per ray into d_embedding
+ * (+=, float atomics; null: skipped), Gb = [d_raw | 0 | d geo | 0] in HEAD-INPUT column order (d_raw = d_density exp(clamp(raw,
+ * +-15)) sel), Gy0 = (Gb W1x) relu'(Y0), dX0 = Gy0 w0^T (columns 0..31 of the pitch-ldx0 rows).  Weights as 16-bit [k_out][n]
+ * copies: C1n [256][256], C0n [128][256], W1xn [256][128] (= W1x transposed), W0n [>= 32][256]; bH0 / bY0 the forward's mask bits;
+ * raw its 16-bit raw density.  G0, Gb, Gy0 are the G operands of the weight-gradient GEMMs.  M a multiple of 256, S of 64, ngeo
+ * of 8, napp of 4 (<= 64). */
+int hugs_nf_field_bwd(int dtype, long long M, int S, const void* G1, const void* C1n, const void* C0n, const void* W1xn,
+                      const void* W0n, const uint32_t* bH0, const uint32_t* bY0, const float* d_density, const float* sel,
+                      const void* raw, int ngeo, int napp, const int* embed_idx, void* G0, void* Gb, void* Gy0, void* dX0, int ldx0,
+                      float* d_embedding, void* stream);
 /* per-ray head-input template of the kernel above: out[ray, 0..127] = [SH16 | 0 x ngeo | appearance | 0 ..] (16-bit) */
 int hugs_nf_head_template(int dtype, int nrays, const float* sh, const float* app, int ngeo, int napp, void* out, void* stream);
 int hugs_nf_adam(long long n, float* theta, const float* grad, float* m, float* v, float lr, float b1, float b2, float eps,

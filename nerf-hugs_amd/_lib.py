@@ -82,6 +82,7 @@ _PROTOS = {
     'hugs_nf_head_input': 'qiippiipipis',
     'hugs_nf_field_fwd': 'iqipipippppppppppipppppppppps',
     'hugs_nf_head_template': 'iippiips',
+    'hugs_nf_field_bwd': 'iqippppppppppiipppppips',
     'hugs_nf_app_bwd': 'iiipiiipps',
     'hugs_nf_rgb_act': 'qipifps',
     'hugs_nf_rgb_grad': 'qipppis',

@@ -368,6 +368,203 @@ __global__ __launch_bounds__(256, 1) void k_field_fwd(const FieldFwd P) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward of the same two networks from the colour layer 1 gradient down to the hash-feature gradient (models/nerfacto.py's
+// autograd through :693-759), one launch:
+//   G0  = (G1 c1^T) * relu'(H0)            [M,256]   (G1 = the gradient at colour layer 1's pre-activation: hugs_rgb_bwd writes it)
+//   dXh = G0 c0^T                          [M,128]   columns [16, 16+ngeo) = d geo features, [16+ngeo, +napp) summed per ray into the
+//                                                    appearance-embedding gradient, [0,16) (the SH of the direction) dropped
+//   Gb  = [d_raw | 0 x 15 | d geo | 0 ..]  [M,128]   d_raw = d_density * exp(clamp(raw, +-15)) * sel; HEAD-INPUT column order (as W1x)
+//   Gy0 = (Gb W1x) * relu'(Y0)             [M,256]
+//   dX0 = Gy0 w0^T                         [M,<=32]
+// Same geometry as the forward: one workgroup per CU, the lane's share of the four TRANSPOSED-use weight matrices ([k_out][n], the
+// `wn` copies: 128 + 64 + 64 + 32 = 288 registers) loaded once; every G written to HBM exactly once (the weight-gradient GEMMs
+// read them), riding in the next layer's loop; relu' from the forward's 1-bit masks (hugs_gemm_nt_bits lane layout).
+// Whole rays per tile: S must be a multiple of 64.
+// ------------------------------------------------------------------------------------------------
+struct FieldBwd {
+  int M, S, ldx0, ngeo, napp;
+  const uint16_t* G1;                       // [M,256]
+  const uint16_t *C1n, *C0n, *W1xn, *W0n;   // [256][256], [128][256], [256][128], [>=32][256]   ([k_out][n], 16-bit)
+  const uint32_t *bH0, *bY0;                // relu masks of H0 / Y0 (forward layout)
+  const float *d_density, *sel;             // [M]
+  const uint16_t* raw;                      // [M] 16-bit raw density (forward output)
+  const int* embed_idx;                     // [M / S]
+  uint16_t *G0, *Gb, *Gy0, *dX0;            // [M,256], [M,128], [M,256], [M, ldx0] (columns 0..31 written)
+  float* d_embedding;                       // [n_embeddings, napp] (+=, float atomics) or null
+};
+
+// mask-bit words of this lane for a 64-row tile of a 256-wide activation (forward layout): words (i_nt0 >> 1) and + 1
+__device__ __forceinline__ void ff_load_bits(const uint32_t* bits, int m0, int wn, int lane, uint32_t (&bin)[2]) {
+  const int i_nt0 = ((m0 >> 6) & 1) * 4;
+  const uint32_t* btile = bits + ((size_t)(m0 >> 8) * 8 + (size_t)(((m0 >> 7) & 1) * 4 + wn)) * 256;
+  const unsigned bo = ff_fresh((unsigned)lane * 4u);
+  bin[0] = *(const uint32_t*)((const char*)btile + (bo + (unsigned)((i_nt0 >> 1) * 64) * 4u));
+  bin[1] = *(const uint32_t*)((const char*)btile + (bo + (unsigned)(((i_nt0 >> 1) + 1) * 64) * 4u));
+}
+
+// One 256-wide masked layer of the backward for this wave (its 64 output columns): out = (A W^T) & mask -> the next LDS tile.
+// Row blocks pipelined as in ff_layer256.
+template <int F16, int KST, int CP>
+__device__ __forceinline__ void ff_layer256_bwd(const unsigned char* A, int frag_off, const typename FfOps<F16>::x8_t (&w)[KST][4],
+                                                const uint32_t (&bin)[2], int wn, int r16, int kb, unsigned char* An,
+                                                const unsigned char* cp_src, char* cp_dst, int tid) {
+  typedef typename FfOps<F16>::x8_t x8_t;
+  const int swz = 3 * ((r16 >> 2) & 1);
+  ff_f32x4_t acc[2][4];
+  auto mma_rows = [&](int i, ff_f32x4_t (&a)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = ff_f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KST; ++s) {
+      const x8_t xa = *(const x8_t*)(A + s * FF_STAGE + frag_off + i * 16 * 64);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = FfOps<F16>::mfma(w[s][j], xa, a[j]);
+    }
+  };
+  mma_rows(0, acc[0]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < 3) mma_rows(i + 1, acc[(i + 1) & 1]);
+    if constexpr (CP > 0) { if (i == 0) ff_copy_out<CP>(cp_src, cp_dst, tid); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const ff_f32x4_t v = acc[i & 1][j];
+      uint2 u;
+      u.x = ff_cvt_pk<F16>(v[0], v[1]); u.y = ff_cvt_pk<F16>(v[2], v[3]);
+      // hugs_gemm.hip nt_epilogue_direct: word (i_nt >> 1), pair k = (i_nt & 1) * 8 + j * 2 owns bit k (even column) and 16 + k (odd)
+      const int k = (i & 1) * 8 + j * 2;
+      const uint32_t t = bin[i >> 1] >> k;
+      u.x &= (t & 0x00010001u) * 0xffffu;
+      u.y &= ((t >> 1) & 0x00010001u) * 0xffffu;
+      const int st = wn * 2 + (j >> 1), ch = (j & 1) * 2 + (kb >> 1);
+      *(uint2*)(An + st * FF_STAGE + (i * 16 + r16) * 64 + ((ch ^ swz) << 4) + (kb & 1) * 8) = u;
+    }
+  }
+}
+
+template <int F16>
+__global__ __launch_bounds__(256, 1) void k_field_bwd(const FieldBwd P) {
+  typedef typename FfOps<F16>::x8_t x8_t;
+  __shared__ __attribute__((aligned(16))) unsigned char act[2][FF_ACT];
+  __shared__ float appsum[16][64];          // per-lane-row partial column sums of the appearance block (<= 64 columns used)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kb = lane >> 4;
+  const int swz = 3 * ((r16 >> 2) & 1);
+  const int frag_off = r16 * 64 + ((kb ^ swz) << 4);
+  const int ntile = P.M / FF_ROWS, G = (int)gridDim.x;
+  const int a0c = 16 + P.ngeo, a1c = a0c + P.napp;      // appearance columns of the head input
+  x8_t c1r[8][4], c0r[8][2], w1r[4][4], w0r[8][1];
+  ff_load_w<F16, 8, 4>(P.C1n, (unsigned)((wn * 64 + r16) * 256 + kb * 8) * 2u, 256, c1r);
+  ff_load_w<F16, 8, 2>(P.C0n, (unsigned)((wn * 32 + r16) * 256 + kb * 8) * 2u, 256, c0r);
+  ff_load_w<F16, 4, 4>(P.W1xn, (unsigned)((wn * 64 + r16) * 128 + kb * 8) * 2u, 128, w1r);
+  ff_load_w<F16, 8, 1>(P.W0n, (unsigned)(((wn & 1) * 16 + r16) * 256 + kb * 8) * 2u, 256, w0r);      // (waves 0, 1: hash features 0..15 / 16..31)
+
+  // a tile's inputs: this thread's 128 bytes of the G1 tile (chunk id = q * 256 + tid -> row id >> 5, 16-byte chunk id & 31) and the
+  // lane's mask words of both masked layers; requested one tile ahead (during the dXh layer) and written to LDS in the last phase
+  // (scalars, not an array: a loop-carried array assigned under a condition stays in scratch memory)
+  uint4 g0, g1, g2, g3, g4, g5, g6, g7;
+  uint32_t binH[2], binY[2], nH0 = 0u, nH1 = 0u, nY0 = 0u, nY1 = 0u;
+  auto load_tile = [&](int m0_) {
+    const char* src = (const char*)(P.G1 + (size_t)m0_ * 256);
+    auto ld = [&](int q) { return *(const uint4*)(src + ff_fresh((unsigned)(((q * 256 + tid) >> 5) * 512 + ((q * 256 + tid) & 31) * 16))); };
+    g0 = ld(0); g1 = ld(1); g2 = ld(2); g3 = ld(3); g4 = ld(4); g5 = ld(5); g6 = ld(6); g7 = ld(7);
+    uint32_t b[2];
+    ff_load_bits(P.bH0, m0_, wn, lane, b); nH0 = b[0]; nH1 = b[1];
+    ff_load_bits(P.bY0, m0_, wn, lane, b); nY0 = b[0]; nY1 = b[1];
+  };
+  auto put_tile = [&]() {
+    auto st = [&](int q, const uint4& v) {
+      const int id = q * 256 + tid, row = id >> 5, cc = id & 31;
+      *(uint4*)(act[0] + (cc >> 2) * FF_STAGE + row * 64 + (((cc & 3) ^ (3 * ((row >> 2) & 1))) << 4)) = v;
+    };
+    st(0, g0); st(1, g1); st(2, g2); st(3, g3); st(4, g4); st(5, g5); st(6, g6); st(7, g7);
+  };
+  if ((int)blockIdx.x < ntile) { load_tile((int)blockIdx.x * FF_ROWS); put_tile(); }
+  __syncthreads();
+  for (int t = blockIdx.x; t < ntile; t += G) {
+    const int m0 = t * FF_ROWS;
+    const bool has_next = t + G < ntile;
+    binH[0] = nH0; binH[1] = nH1; binY[0] = nY0; binY[1] = nY1;
+    // ---- G0 = (G1 c1^T) * relu'(H0) -> act[1] -------------------------------------------------------------------------------
+    ff_layer256_bwd<F16, 8, 0>(act[0], frag_off, c1r, binH, wn, r16, kb, act[1], nullptr, nullptr, tid);
+    __syncthreads();
+    // ---- dXh = G0 c0^T (this wave: head-input columns [32 wn, 32 wn + 32)); G0 -> HBM rides here ------------------------------
+    if (has_next) load_tile(m0 + G * FF_ROWS);
+    {
+      ff_f32x4_t acc[4][4];
+      ff_acc_zero<2>(acc);
+      ff_mma_r<F16, 8, 2, 8>(act[1], frag_off, c0r, acc, act[1], (char*)(P.G0 + (size_t)m0 * 256), tid);
+      // Gb tile (head-input column order) -> act[0] stages 0..3: geo columns from the registers; column 0 = d_raw, zeros elsewhere
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = wn * 32 + j * 16 + kb * 4;
+        const bool geo = n >= 16 && n < a0c;
+        float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = i * 16 + r16;
+          if (geo) {
+            uint2 u;
+            u.x = ff_cvt_pk<F16>(acc[i][j][0], acc[i][j][1]); u.y = ff_cvt_pk<F16>(acc[i][j][2], acc[i][j][3]);
+            *(uint2*)(act[0] + ((n >> 5) * FF_STAGE + row * 64 + ((((n & 31) >> 3) ^ swz) << 4) + (n & 4) * 2)) = u;
+          }
+          // (the appearance block sums the 16-bit rounded gradient, as the stand-alone kernel reads it)
+          const uint32_t p0 = ff_cvt_pk<F16>(acc[i][j][0], acc[i][j][1]), p1 = ff_cvt_pk<F16>(acc[i][j][2], acc[i][j][3]);
+          cs[0] += FfOps<F16>::lo(p0); cs[1] += FfOps<F16>::hi(p0); cs[2] += FfOps<F16>::lo(p1); cs[3] += FfOps<F16>::hi(p1);
+        }
+        if (n >= a0c && n < a1c && P.d_embedding) *(float4*)&appsum[r16][n - a0c] = make_float4(cs[0], cs[1], cs[2], cs[3]);
+      }
+      // per row: chunk (stage 0, 0) = [d_raw, 0 x 7]; zero chunks for columns 8..15 and [16 + ngeo, 128)
+      {
+        const int row = tid >> 2, part = tid & 3, sw = 3 * ((row >> 2) & 1);
+        unsigned char* rb = act[0] + row * 64;
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        if (part == 0) {
+          const float raw = FfOps<F16>::lo((uint32_t)*(const uint16_t*)((const char*)(P.raw + m0) + ff_fresh((unsigned)row * 2u)));
+          const unsigned ro = ff_fresh((unsigned)row * 4u);
+          const float dr = *(const float*)((const char*)(P.d_density + m0) + ro) * expf(fminf(fmaxf(raw, -15.f), 15.f)) *
+                           *(const float*)((const char*)(P.sel + m0) + ro);
+          *(uint4*)(rb + ((0 ^ sw) << 4)) = make_uint4(ff_cvt_pk<F16>(dr, 0.f), 0u, 0u, 0u);
+          *(uint4*)(rb + ((1 ^ sw) << 4)) = z;
+        }
+        // columns [a0c, 128): 8-column chunks (a0c is a multiple of 8 here: the launcher checks ngeo % 8 == 0)
+        for (int c8 = a0c / 8 + part; c8 < 16; c8 += 4) *(uint4*)(rb + (c8 >> 2) * FF_STAGE + (((c8 & 3) ^ sw) << 4)) = z;
+      }
+    }
+    __syncthreads();
+    // ---- appearance-embedding gradient of the tile's ray; Gy0 = (Gb W1x) * relu'(Y0) -> act[1]; Gb -> HBM rides here ---------------
+    if (P.d_embedding && tid < P.napp) {
+      float a = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a += appsum[r][tid];
+      const int ray = m0 / P.S;
+      atomicAdd(P.d_embedding + (size_t)P.embed_idx[ray] * P.napp + tid, a);
+    }
+    ff_layer256_bwd<F16, 4, 4>(act[0], frag_off, w1r, binY, wn, r16, kb, act[1], act[0], (char*)(P.Gb + (size_t)m0 * 128), tid);
+    __syncthreads();
+    // ---- dX0 = Gy0 w0^T (waves 0, 1: 16 hash features each) straight to HBM; Gy0 -> HBM rides here; the next tile's G1 -> act[0]
+    if (has_next) put_tile();
+    if (wn < 2) {
+      ff_f32x4_t acc[4][4];
+      ff_acc_zero<1>(acc);
+      ff_mma_r<F16, 8, 1, 8>(act[1], frag_off, w0r, acc, act[1], (char*)(P.Gy0 + (size_t)m0 * 256), tid);
+      char* dst = (char*)(P.dX0 + (size_t)m0 * P.ldx0);
+      const unsigned xo = ff_fresh((unsigned)(r16 * P.ldx0 + wn * 16 + kb * 4) * 2u);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint2 u;
+        u.x = ff_cvt_pk<F16>(acc[i][0][0], acc[i][0][1]); u.y = ff_cvt_pk<F16>(acc[i][0][2], acc[i][0][3]);
+        *(uint2*)(dst + (xo + (unsigned)(i * 16 * P.ldx0) * 2u)) = u;
+      }
+    } else {
+      ff_copy_out<8>(act[1], (char*)(P.Gy0 + (size_t)m0 * 256), tid);
+    }
+    __syncthreads();      // the next tile's G1 is complete in act[0]; act[1] (Gy0) is free for its G0
+  }
+}
+
 // per-ray head-input template: out[ray, 0..127] = [SH16 | 0 x ngeo | appearance (napp) | 0 ...] in the 16-bit operand format
 __global__ void k_head_template(int nrays, int f16, const float* __restrict__ sh, const float* __restrict__ app, int ngeo, int napp,
                                 uint16_t* __restrict__ out) {
@@ -424,5 +621,32 @@ extern "C" int hugs_nf_field_fwd(int dtype, long long M, int S, const void* X0, 
   if (dtype == 2) hipLaunchKernelGGL(k_field_fwd<1>, grid, block, 0, (hipStream_t)stream, P);
   else hipLaunchKernelGGL(k_field_fwd<0>, grid, block, 0, (hipStream_t)stream, P);
   HUGS_CHECK_LAUNCH("hugs_nf_field_fwd");
+  return 0;
+}
+
+// include/hugs.h hugs_nf_field_bwd
+extern "C" int hugs_nf_field_bwd(int dtype, long long M, int S, const void* G1, const void* C1n, const void* C0n, const void* W1xn,
+                                 const void* W0n, const uint32_t* bH0, const uint32_t* bY0, const float* d_density, const float* sel,
+                                 const void* raw, int ngeo, int napp, const int* embed_idx, void* G0, void* Gb, void* Gy0, void* dX0,
+                                 int ldx0, float* d_embedding, void* stream) {
+  HUGS_REQUIRE(dtype == 1 || dtype == 2, -2, "hugs_nf_field_bwd: 16-bit operands only (dtype 1 = bf16, 2 = half), got %d", dtype);
+  HUGS_REQUIRE(M > 0 && M % 256 == 0 && M < (1ll << 31) && S > 0 && S % FF_ROWS == 0 && M % S == 0, -3,
+               "hugs_nf_field_bwd: %lld rows (a positive multiple of 256), rays of %d samples (a multiple of 64)", M, S);
+  HUGS_REQUIRE(ngeo >= 0 && ngeo % 8 == 0 && napp >= 0 && napp <= 64 && napp % 4 == 0 && 16 + ngeo + napp <= 128 && ldx0 >= 32 && ldx0 % 8 == 0 && ldx0 <= 4096, -3,
+               "hugs_nf_field_bwd: %d geo (a multiple of 8) / %d appearance (a multiple of 4, <= 64) columns, feature pitch %d", ngeo, napp, ldx0);
+  HUGS_REQUIRE(G1 && C1n && C0n && W1xn && W0n && bH0 && bY0 && d_density && sel && raw && G0 && Gb && Gy0 && dX0 && (!d_embedding || napp == 0 || embed_idx), -2,
+               "hugs_nf_field_bwd: null pointer");
+  FieldBwd P;
+  P.M = (int)M; P.S = S; P.ldx0 = ldx0; P.ngeo = ngeo; P.napp = napp;
+  P.G1 = (const uint16_t*)G1; P.C1n = (const uint16_t*)C1n; P.C0n = (const uint16_t*)C0n; P.W1xn = (const uint16_t*)W1xn; P.W0n = (const uint16_t*)W0n;
+  P.bH0 = bH0; P.bY0 = bY0; P.d_density = d_density; P.sel = sel; P.raw = (const uint16_t*)raw; P.embed_idx = embed_idx;
+  P.G0 = (uint16_t*)G0; P.Gb = (uint16_t*)Gb; P.Gy0 = (uint16_t*)Gy0; P.dX0 = (uint16_t*)dX0; P.d_embedding = napp ? d_embedding : nullptr;
+  int dev = 0, ncu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) ncu = 256;
+  const int ntile = (int)(M / FF_ROWS);
+  const dim3 grid(ntile < ncu ? ntile : ncu), block(256);
+  if (dtype == 2) hipLaunchKernelGGL(k_field_bwd<1>, grid, block, 0, (hipStream_t)stream, P);
+  else hipLaunchKernelGGL(k_field_bwd<0>, grid, block, 0, (hipStream_t)stream, P);
+  HUGS_CHECK_LAUNCH("hugs_nf_field_bwd");
   return 0;
 }

@@ -287,6 +287,9 @@ class NerfactoModel:
     w1, b1 = self.wt['field/w1'], self.lay.view(self.flat, 'field/b1')
     self.wt['field/w1x'][0].copy_(w1[0]); self.wt['field/w1x'][16:16 + g].copy_(w1[1:1 + g])
     self.b1x[0:1].copy_(b1[0:1]); self.b1x[16:16 + g].copy_(b1[1:1 + g])
+    if not hasattr(self, 'w1xn'):
+      self.w1xn = torch.empty(self.wt['field/w1x'].shape[1], 128, dtype=self.tdt, device=self.device)
+    self.w1xn.copy_(self.wt['field/w1x'].t())      # [k_out][n]: the backward's form (csrc/hugs_fieldfuse.hip k_field_bwd)
     self._w1x_stale = False
 
   def _field_fuse_ok(self):
@@ -320,8 +323,8 @@ class NerfactoModel:
       L.call('hugs_gemm_nt', self.dt, M, K, N, 0, X, N, None, 0, self.wn[name], N, None, None, 1, 0, 0, mask, K if mask is not None else 0,
              None, None, out, K)
 
-  def _tn(self, M, name, X, G, bias_name):
-    """grad[name] = X^T G, grad[bias] = colsum(G)."""
+  def _tn(self, M, name, X, G, bias_name, out=None, out_bias=None):
+    """grad[name] = X^T G, grad[bias] = colsum(G) (out / out_bias: other destinations of the same shapes)."""
     K, N = self.lay.items[name][1]
     tiles, step, target = (K // 128) * (N // 128), (64 if self.dt else 16), 768
     if self.dt and K % 256 == 0 and N % 256 == 0 and M // (256 // max(1, (K // 256) * (N // 256))) >= 2048:
@@ -332,7 +335,8 @@ class NerfactoModel:
       ns -= 1
     nbytes = L.lib().cdll.hugs_gemm_tn_ws_bytes(K, N, ns)
     slab = self.ws.get(f'tn_slab_{torch.cuda.current_stream().cuda_stream}', (max(nbytes // 4, 1),))      # (one per stream: the levels' chains run concurrently)
-    L.call('hugs_gemm_tn', self.dt, M, K, N, ns, X, K, G, N, self.lay.view(self.grad, name), self.lay.view(self.grad, bias_name), slab)
+    L.call('hugs_gemm_tn', self.dt, M, K, N, ns, X, K, G, N, self.lay.view(self.grad, name) if out is None else out,
+           self.lay.view(self.grad, bias_name) if out_bias is None else out_bias, slab)
 
   # ---- forward ----------------------------------------------------------------------------------------------------------
   def _u_base(self, ns, randomized):
@@ -808,6 +812,28 @@ class NerfactoModel:
     """GradScaler.get_scale() (fp16 mode; a host read)."""
     return float(self.amp_state[0]) if self.amp else 1.0
 
+  def _field_backward_fused(self, st, rays, N, S, M, G1, d_dens):
+    """Colour layer 1 gradient -> hash-feature gradient in ONE launch (csrc/hugs_fieldfuse.hip k_field_bwd), then the three
+    remaining weight-gradient GEMMs on the G operands it wrote.  The base network's second layer runs in head-input column order
+    there (W1x): its weight / bias gradients come out in that order and are moved to the layout's columns."""
+    c, ws, dt = self.cfg, self.ws, self.dt
+    K0, N0 = self.lay.items['field/w0'][1]
+    Kh, H = self.lay.items['field/c0'][1]
+    N1, g = self.lay.items['field/w1'][1][1], c.geo_feat_dim
+    G0, Gb, Gy0 = ws.get('G0', (M, H), self.tdt), ws.get('Gb_field', (M, N1), self.tdt), ws.get('Gy0_field', (M, N0), self.tdt)
+    dX0 = ws.get('dX0_field', (M, K0), self.tdt)
+    L.call('hugs_nf_field_bwd', dt, M, S, G1, self.wn['field/c1'], self.wn['field/c0'], self.w1xn, self.wn['field/w0'], st['bH0'], st['bY0'],
+           d_dens, st['sel'], st['Y1'], g, self.napp, rays['embed_idx'] if self.napp else None, G0, Gb, Gy0, dX0, K0,
+           self.lay.view(self.grad, 'appearance') if self.napp else None)
+    self._tn(M, 'field/c0', st['Xh'], G0, 'field/cb0')
+    tw, tb = ws.get('gw1x', (N0, N1)), ws.get('gb1x', (N1,))
+    self._tn(M, 'field/w1', st['Y0'], Gb, 'field/b1', out=tw, out_bias=tb)
+    gw, gb = self.lay.view(self.grad, 'field/w1'), self.lay.view(self.grad, 'field/b1')
+    gw[:, 0:1].copy_(tw[:, 0:1]); gw[:, 1:1 + g].copy_(tw[:, 16:16 + g]); gw[:, 1 + g:].zero_()
+    gb[0:1].copy_(tb[0:1]); gb[1:1 + g].copy_(tb[16:16 + g]); gb[1 + g:].zero_()
+    self._tn(M, 'field/w0', st['X0'], Gy0, 'field/b0')
+    self._grid_bwd('field', st['x01'], dX0)
+
   def _backward_level(self, st, rays, N, d_rgb_out, d_w_extra):
     c, ws, dt = self.cfg, self.ws, self.dt
     S, M, name = st['S'], st['M'], st['name']
@@ -844,6 +870,10 @@ class NerfactoModel:
         self._tn(M, 'field/c2', st['H1'], Gc, 'field/cb2')
         self._nt(M, 'field/c2', Gc, None, False, G1, mask=st['H1'], transpose=True)
       self._tn(M, 'field/c1', st['H0'], G1, 'field/cb1')
+      if (st.get('fused_field') and S % 64 == 0 and st.get('bH0') is not None and st.get('bY0') is not None and
+          os.environ.get('HUGS_NF_FIELD_FUSE_BWD', '1') != '0'):
+        self._field_backward_fused(st, rays, N, S, M, G1, d_dens)
+        return
       G0 = ws.get('G0', (M, H), self.tdt)
       self._nt(M, 'field/c1', G1, None, False, G0, mask=st['H0'], transpose=True, bits=st.get('bH0'))
       self._tn(M, 'field/c0', st['Xh'], G0, 'field/cb0')

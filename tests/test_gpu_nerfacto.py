@@ -477,19 +477,23 @@ def test_fused_field_forward_equals_layer_by_layer(cdt, monkeypatch):
 
 @pytest.mark.parametrize('cdt', ['bf16', 'fp16'])
 def test_fused_field_step_gradients_equal_layer_by_layer(cdt, monkeypatch):
-  """One whole train step (no update) with the fused field kernels vs the layer-by-layer path: the same loss statistics and
-  the same parameter gradients up to the rgb head's summation order and the float-atomic table scatter."""
+  """One whole train step (no update) with the fused field kernels (forward only; forward + backward: k_field_fwd / k_field_bwd) vs
+  the layer-by-layer path: the same loss statistics and the same parameter gradients up to 16-bit rounding of the intermediate
+  gradients (the same roundings at the same places, other accumulation orders) and the float-atomic table / embedding scatter."""
   N = 512
   model, batch, u01 = _cfg5_model_and_batch(cdt, N)
   out = {}
-  for mode in ('0', '1'):
-    monkeypatch.setenv('HUGS_NF_FIELD_FUSE', mode)
+  for mode in (('0', '0'), ('1', '0'), ('1', '1')):
+    monkeypatch.setenv('HUGS_NF_FIELD_FUSE', mode[0])
+    monkeypatch.setenv('HUGS_NF_FIELD_FUSE_BWD', mode[1])
     res = model.train_step(batch, curr_step=300, u01=u01, apply_update=False)
     torch.cuda.synchronize()
     out[mode] = (res['stats'].clone(), model.grad.clone())
-  np.testing.assert_allclose(out['0'][0].cpu().numpy(), out['1'][0].cpu().numpy(), rtol=2e-5, atol=1e-9)
-  for name, (off, pshape, shape) in model.lay.items.items():
-    ga, gb = model.lay.view(out['0'][1], name).float(), model.lay.view(out['1'][1], name).float()
-    sc = float(ga.abs().max())
-    assert sc > 0 or name in ('transient',), name
-    assert float((ga - gb).abs().max()) <= 2e-3 * sc + 1e-12, f'{cdt} {name}: {float((ga - gb).abs().max()):.3e} vs scale {sc:.3e}'
+  for mode in (('1', '0'), ('1', '1')):
+    np.testing.assert_allclose(out['0', '0'][0].cpu().numpy(), out[mode][0].cpu().numpy(), rtol=2e-5, atol=1e-9)
+    for name, (off, pshape, shape) in model.lay.items.items():
+      ga, gb = model.lay.view(out['0', '0'][1], name).float(), model.lay.view(out[mode][1], name).float()
+      sc = float(ga.abs().max())
+      assert sc > 0 or name in ('transient',), name
+      err = float((ga - gb).abs().max())
+      assert err <= 2e-3 * sc + 1e-12, f'{cdt} {mode} {name}: {err:.3e} vs scale {sc:.3e}'
