@@ -235,6 +235,18 @@ def nerfacto_roofline(model, step_fn, N, steps=3):
         two_bounds(ent, us, by, 0.0, PEAK_BF16, "mfma")
         ent.update(atomic_updates=n * L_ * 8 * F, atomic_updates_per_s=round(n * L_ * 8 * F / (us * 1e-6) / 1e9, 1),
                    limiter="L2 float atomics (scratch/atomic_pair.hip: ~21 G distinct-address transactions/s on this chip)")
+    elif key[0] in ('field_fwd', 'field_bwd'):
+      # csrc/hugs_fieldfuse.hip, per sample (16-bit operands): forward reads 32 hash features (64 B) and writes Y0, H0, H1 (3 x 512),
+      # the head input (256), 2 x 32 B of mask bits, raw (2), density (4), rgb (12); backward reads G1 (512), the masks (64), raw /
+      # d_density / sel (10) and writes G0, Gy0 (2 x 512), Gb (256), the 32 feature gradients (64).  flops: the four matrices.
+      n, g_, a_ = key[1:]
+      mats = 32 * 256 + 256 * (1 + g_) + (16 + g_ + a_) * 256 + 256 * 256
+      if key[0] == 'field_fwd':
+        by, fl = n * (64 + 3 * 512 + 256 + 64 + 18), 2.0 * n * (mats + 256 * 3)
+      else:
+        by, fl = n * (512 + 64 + 10 + 2 * 512 + 256 + 64), 2.0 * n * mats
+      ent.update(kernel=f"k_{key[0]} {n} samples (32 -> 256 -> {1 + g_}; {16 + g_ + a_} -> 256 -> 256 -> 3), activations in LDS, weights in registers")
+      two_bounds(ent, us, by, fl, PEAK_BF16, "mfma")
     elif key[0] in ('prop_fwd', 'prop_bwd'):
       n, i_, h_ = key[1:]
       fl = 2.0 * n * (i_ * h_ + h_) * (1 if key[0] == 'prop_fwd' else 3)

@@ -124,7 +124,10 @@ _PROFILED = {'hugs_gemm_nt': lambda a: ('nt', a[1], a[2], a[3] + a[4], 'mask' if
              'hugs_hashgrid_fwd_t': lambda a: ('hg_fwd', a[0], a[1], a[2]),
              'hugs_hashgrid_bwd': lambda a: ('hg_bwd', a[0], a[1], a[2]),
              'hugs_nf_prop_fwd': lambda a: ('prop_fwd', a[0], a[1], a[2]),
-             'hugs_nf_prop_bwd': lambda a: ('prop_bwd', a[0], a[1], a[2])}
+             'hugs_nf_prop_bwd': lambda a: ('prop_bwd', a[0], a[1], a[2]),
+             # fused field networks: (kind, samples, geo features, appearance columns)
+             'hugs_nf_field_fwd': lambda a: ('field_fwd', a[1], a[17], 128 - 16 - a[17]),
+             'hugs_nf_field_bwd': lambda a: ('field_bwd', a[1], a[13], a[14])}
 
 
 class _Lib:
