@@ -36,6 +36,13 @@ template <> struct FfOps<1> {
   static __device__ __forceinline__ float lo(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(u & 0xffffu)); }
   static __device__ __forceinline__ float hi(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(u >> 16)); }
 };
+// relu of a packed pair of 16-bit floats: a signed 16-bit max with 0 (negative values have the sign bit set in both formats)
+__device__ __forceinline__ uint32_t ff_relu_pk(uint32_t u) {
+  typedef short __attribute__((ext_vector_type(2))) s2;
+  const s2 z = {0, 0};
+  const s2 r = __builtin_elementwise_max(__builtin_bit_cast(s2, u), z);
+  return __builtin_bit_cast(uint32_t, r);
+}
 template <int F16> __device__ __forceinline__ uint32_t ff_cvt_pk(float a, float b) {       // one v_cvt_pk_{bf16,f16}_f32 (RNE)
   const ff_f32x2_t f = {a, b};
   const typename FfOps<F16>::x2_t h = __builtin_convertvector(f, typename FfOps<F16>::x2_t);
@@ -46,16 +53,6 @@ template <int F16> __device__ __forceinline__ uint32_t ff_cvt_pk(float a, float 
 // lane offset) pair of its ~150 loads and stores was turned into a 64-bit per-lane address, hoisted out of the tile loop and
 // spilled (264 B of scratch per lane); an opaque copy per use keeps them as one 32-bit VGPR next to a scalar base.
 __device__ __forceinline__ unsigned ff_fresh(unsigned x) { asm volatile("" : "+v"(x)); return x; }
-
-// x summed over the lanes r16 + {0, 16, 32, 48} (every lane gets the sum)
-__device__ __forceinline__ float ff_sum_kb(float x) {
-  typedef unsigned __attribute__((ext_vector_type(2))) u2;
-  unsigned u = __float_as_uint(x);
-  const u2 s = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  u = __float_as_uint(__uint_as_float(s[0]) + __uint_as_float(s[1]));
-  const u2 t = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return __uint_as_float(t[0]) + __uint_as_float(t[1]);
-}
 
 #define FF_ROWS 64
 #define FF_STAGE (FF_ROWS * 64)        // one K-stage: 64 rows x 32 k x 2 B
@@ -141,7 +138,7 @@ template <int F16, int KST, int CP, bool LAST>
 __device__ __forceinline__ void ff_layer256(const unsigned char* A, int frag_off, const typename FfOps<F16>::x8_t (&w)[KST][4],
                                             const float* bias /* + wn*64 + kb*4 */, int m0, int wn, int r16, int kb, int lane,
                                             unsigned char* An, uint32_t* bout, uint16_t* Y, const unsigned char* cp_src, char* cp_dst,
-                                            int tid, const float* c2s, float (*red)[4][3]) {
+                                            int tid, const typename FfOps<F16>::x8_t (&c2f)[2][2], float (*red)[4][3]) {
   typedef typename FfOps<F16>::x8_t x8_t;
   const int swz = 3 * ((r16 >> 2) & 1);
   float4 bb[4];
@@ -172,12 +169,13 @@ __device__ __forceinline__ void ff_layer256(const unsigned char* A, int frag_off
   for (int i = 0; i < 4; ++i) {
     if (i < 3) mma_rows(i + 1, acc[(i + 1) & 1]);
     if constexpr (CP > 0) { if (i == 0) ff_copy_out<CP>(cp_src, cp_dst, tid); }
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    uint32_t uk[4][2];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const ff_f32x4_t v = acc[i & 1][j];
       uint2 u;
-      u.x = ff_cvt_pk<F16>(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)); u.y = ff_cvt_pk<F16>(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+      u.x = ff_relu_pk(ff_cvt_pk<F16>(v[0], v[1])); u.y = ff_relu_pk(ff_cvt_pk<F16>(v[2], v[3]));
+      uk[j][0] = u.x; uk[j][1] = u.y;
 #ifndef FF_NOSTORE
       if (Yout) *(uint2*)((char*)Yout + (yo + (unsigned)(i * 16 * 256 + j * 16) * 2u)) = u;
 #endif
@@ -190,22 +188,23 @@ __device__ __forceinline__ void ff_layer256(const unsigned char* A, int frag_off
         bw |= ((u.x + 0x7fff7fffu) >> (15 - k)) & (0x00010001u << k);
         bw |= ((u.y + 0x7fff7fffu) >> (14 - k)) & (0x00010001u << (k + 1));
       }
-      if (LAST) {      // rgb head on the rounded activations: c2s [256][3] fp32
-        const float* wc = c2s + (wn * 64 + j * 16 + kb * 4) * 3;
-        const float4 w0 = *(const float4*)wc, w1 = *(const float4*)(wc + 4), w2 = *(const float4*)(wc + 8);
-        const float v0 = FfOps<F16>::lo(u.x), v1 = FfOps<F16>::hi(u.x), v2 = FfOps<F16>::lo(u.y), v3 = FfOps<F16>::hi(u.y);
-        a0 += v0 * w0.x + v1 * w0.w + v2 * w1.z + v3 * w2.y;
-        a1 += v0 * w0.y + v1 * w1.x + v2 * w1.w + v3 * w2.z;
-        a2 += v0 * w0.z + v1 * w1.y + v2 * w2.x + v3 * w2.w;
-      }
     }
     if (bout && (i & 1)) { *(uint32_t*)((char*)btile + (bo + (unsigned)(((i_nt0 + i) >> 1) * 64) * 4u)) = bw; bw = 0u; }
     if (LAST) {
-      // sum over the four kb lane groups: v_permlane16_swap / v_permlane32_swap of a value with itself leave (x, neighbour's x) in
-      // the two results.  (__shfl_xor's ds_bpermute_b32 returned a stale FIRST operand here now and then -- the low half of the
-      // v_pk_add_f32 pair the compiler forms from a0 / a1 -- on ~0.7 % of the rows, run-to-run different: scratch/ffuse_bench.py.)
-      a0 = ff_sum_kb(a0); a1 = ff_sum_kb(a1); a2 = ff_sum_kb(a2);
-      if (kb == 0) { red[i * 16 + r16][wn][0] = a0; red[i * 16 + r16][wn][1] = a1; red[i * 16 + r16][wn][2] = a2; }
+      // rgb head on the rounded activations, on the matrix cores: the packed outputs of two neighbouring 16-column fragments ARE a
+      // B operand (lane (row, kb) holds k-slots kb*8 .. +7 = columns (2a)*16 + kb*4 .. +3 and (2a+1)*16 + kb*4 .. +3) once the
+      // A operand c2f[a] carries the rgb layer's weights in the same slot order; its fp32 weights enter as a 16-bit hi + lo pair.
+      // D[n][row]: the lanes kb == 0 end up with (r, g, b) partial sums of this wave's 64 columns for row r16 -- no lane shuffles.
+      ff_f32x4_t pr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        typedef unsigned __attribute__((ext_vector_type(4))) u4;
+        const u4 bw4 = {uk[2 * a][0], uk[2 * a][1], uk[2 * a + 1][0], uk[2 * a + 1][1]};
+        const x8_t bf = __builtin_bit_cast(x8_t, bw4);
+        pr = FfOps<F16>::mfma(c2f[a][0], bf, pr);
+        pr = FfOps<F16>::mfma(c2f[a][1], bf, pr);
+      }
+      if (kb == 0) { red[i * 16 + r16][wn][0] = pr[0]; red[i * 16 + r16][wn][1] = pr[1]; red[i * 16 + r16][wn][2] = pr[2]; }
     }
   }
 }
@@ -268,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void k_field_fwd(const FieldFwd P) {
   __shared__ __attribute__((aligned(16))) unsigned char act[2][FF_ACT];
   __shared__ float red[FF_ROWS][4][3];
   __shared__ float sel_s[FF_ROWS];
-  __shared__ __attribute__((aligned(16))) float c2s[256 * 3 + 4];
+  __shared__ float cb2s[4];
   __shared__ __attribute__((aligned(16))) float bs[256 + 128 + 256 + 256];      // b0 | b1x | cb0 | cb1
   const int tid = threadIdx.x, lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -276,8 +275,24 @@ __global__ __launch_bounds__(256, 1) void k_field_fwd(const FieldFwd P) {
   const int swz = 3 * ((r16 >> 2) & 1);
   const int frag_off = r16 * 64 + ((kb ^ swz) << 4);
   const int ntile = P.M / FF_ROWS, G = (int)gridDim.x;
-  for (int e = tid; e < 256 * 3; e += 256) c2s[e] = P.c2[e];
-  if (tid < 3) c2s[768 + tid] = P.cb2[tid];
+  if (tid < 3) cb2s[tid] = P.cb2[tid];
+  // the rgb layer [256, 3] fp32 as MFMA A operands in the slot order of ff_layer256's B operands: lane (n = r16, kb), slot e of
+  // half a -> column wn*64 + (2a + (e >> 2))*16 + kb*4 + (e & 3); rows n >= 3 are zero; each value as a 16-bit hi + lo pair
+  x8_t c2f[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    typedef unsigned __attribute__((ext_vector_type(4))) u4;
+    u4 hw, lw;
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      const int c0 = wn * 64 + (2 * a + (e2 >> 1)) * 16 + kb * 4 + (e2 & 1) * 2;
+      const float v0 = r16 < 3 ? P.c2[c0 * 3 + r16] : 0.f, v1 = r16 < 3 ? P.c2[(c0 + 1) * 3 + r16] : 0.f;
+      const uint32_t h = ff_cvt_pk<F16>(v0, v1);
+      hw[e2] = h;
+      lw[e2] = ff_cvt_pk<F16>(v0 - FfOps<F16>::lo(h), v1 - FfOps<F16>::hi(h));
+    }
+    c2f[a][0] = __builtin_bit_cast(x8_t, hw); c2f[a][1] = __builtin_bit_cast(x8_t, lw);
+  }
   bs[tid] = P.b0[tid]; bs[384 + tid] = P.cb0[tid]; bs[640 + tid] = P.cb1[tid];
   if (tid < 128) bs[256 + tid] = P.b1[tid];
   const bool l1_live = wn * 32 < 16 + P.ngeo;      // (wave-uniform) this wave's 32 columns of layer 1 hold real outputs
@@ -304,7 +319,7 @@ __global__ __launch_bounds__(256, 1) void k_field_fwd(const FieldFwd P) {
     ff_f32x4_t acc[4][4];
     // ---- base layer 0: 32 -> 256, relu ------------------------------------------------------------------------------
     ff_layer256<F16, 1, 0, false>(act[0] + 7 * FF_STAGE, frag_off, w0r, bs + wn * 64 + kb * 4, m0, wn, r16, kb, lane, act[1], P.bY0, nullptr,
-                                  nullptr, nullptr, tid, c2s, red);      // (Y0 -> HBM: in layer 1's loop)
+                                  nullptr, nullptr, tid, c2f, red);      // (Y0 -> HBM: in layer 1's loop)
     FF_TP(1);
     FF_TP(2);
     __syncthreads();
@@ -345,7 +360,7 @@ __global__ __launch_bounds__(256, 1) void k_field_fwd(const FieldFwd P) {
       if (tid < FF_ROWS) nsel = *(const float*)((const char*)(P.sel + (size_t)m0 + (size_t)G * FF_ROWS) + ff_fresh((unsigned)tid * 4u));
     }
     ff_layer256<F16, 4, 4, false>(act[0], frag_off, c0r, bs + 384 + wn * 64 + kb * 4, m0, wn, r16, kb, lane, act[1], P.bH0, nullptr,
-                                  act[0], (char*)(P.Xh + (size_t)m0 * 128), tid, c2s, red);      // (H0 -> HBM: in the next loop)
+                                  act[0], (char*)(P.Xh + (size_t)m0 * 128), tid, c2f, red);      // (H0 -> HBM: in the next loop)
     FF_TP(7);
     FF_TP(8);
     __syncthreads();
@@ -354,14 +369,14 @@ __global__ __launch_bounds__(256, 1) void k_field_fwd(const FieldFwd P) {
     if (has_next) ff_put_inputs(act[0], sel_s, nx, nsel, tid);      // (act[0] is free since the barrier above)
     FF_TP(10);
     ff_layer256<F16, 8, 8, true>(act[1], frag_off, c1r, bs + 640 + wn * 64 + kb * 4, m0, wn, r16, kb, lane, nullptr, nullptr, P.H1,
-                                 act[1], (char*)(P.H0 + (size_t)m0 * 256), tid, c2s, red);
+                                 act[1], (char*)(P.H0 + (size_t)m0 * 256), tid, c2f, red);
     FF_TP(11);
     FF_TP(12);
     __syncthreads();
     FF_TP(13);
     if (tid < FF_ROWS * 3) {
       const int row = tid / 3, c = tid - row * 3;
-      const float a = ((red[row][0][c] + red[row][1][c]) + (red[row][2][c] + red[row][3][c])) + c2s[768 + c];
+      const float a = ((red[row][0][c] + red[row][1][c]) + (red[row][2][c] + red[row][3][c])) + cb2s[c];
       *(float*)((char*)(P.rgb + (size_t)m0 * 3) + ff_fresh((unsigned)tid * 4u)) = 1.f / (1.f + expf(-a));
     }
     FF_TP(14);

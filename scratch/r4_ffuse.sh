@@ -1,7 +1,7 @@
-python -m pytest tests/test_gpu_nerfacto.py -q -x -k "fused_field" 2>&1 | grep -v "^E    " | tail -8
-python scratch/fbwd_bench.py; FOLD=1 python scratch/fbwd_bench.py
-for rep in 1 2; do for v in "0 0 0" "1 1 0" "1 1 1"; do set -- $v
-  HUGS_NF_FIELD_FUSE=$1 HUGS_NF_FIELD_FUSE_BWD=$2 HUGS_NF_RGB_FOLD=$3 python bench.py --config cfg5 --min-time 3 --steps 10 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
+python scratch/ffuse_bench.py 2>&1 | grep -v amdgpu
+python -m pytest tests/test_gpu_nerfacto.py -q -x -k "fused_field or cfg5" 2>&1 | grep -v "^E    " | tail -6
+for rep in 1 2; do for v in "0 0" "1 1"; do set -- $v
+  HUGS_NF_FIELD_FUSE=$1 HUGS_NF_FIELD_FUSE_BWD=$2 python bench.py --config cfg5 --min-time 3 --steps 10 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('cfg5 fp16 FUSE=$1 BWD=$2 FOLD=$3', d['ms_per_step'], d['value'])"
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('cfg5 fp16 FUSE=$1 BWD=$2', d['ms_per_step'], d['value'])"
 done; done
