@@ -149,12 +149,14 @@ __device__ __forceinline__ void ff_layer256(const unsigned char* A, int frag_off
 #pragma unroll
     for (int j = 0; j < 4; ++j) a[j] = ff_f32x4_t{bb[j].x, bb[j].y, bb[j].z, bb[j].w};
 #ifndef FF_NOMMA
+    x8_t xa[KST];      // (all of the row block's fragments requested before the first MFMA: one LDS latency per block, not per stage)
 #pragma unroll
-    for (int s = 0; s < KST; ++s) {
-      const x8_t xa = *(const x8_t*)(A + s * FF_STAGE + frag_off + i * 16 * 64);
+    for (int s = 0; s < KST; ++s) xa[s] = *(const x8_t*)(A + s * FF_STAGE + frag_off + i * 16 * 64);
+    __builtin_amdgcn_sched_barrier(0);      // (the scheduler sinks each read back in front of its MFMAs otherwise)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) a[j] = FfOps<F16>::mfma(w[s][j], xa, a[j]);
-    }
+    for (int s = 0; s < KST; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = FfOps<F16>::mfma(w[s][j], xa[s], a[j]);
 #endif
   };
   uint16_t* Yout = Y ? Y + (size_t)m0 * 256 : nullptr;                    // (uniform)
@@ -216,7 +218,15 @@ __device__ __forceinline__ void ff_load_w(const uint16_t* W, unsigned wo, int ld
 #pragma unroll
   for (int s = 0; s < KST; ++s)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) w[s][j] = *(const x8_t*)((const char*)W + (wo + (unsigned)(j * 16 * ldw + s * 32) * 2u));
+    for (int j = 0; j < NJ; ++j) {
+      w[s][j] = *(const x8_t*)((const char*)W + (wo + (unsigned)(j * 16 * ldw + s * 32) * 2u));
+#ifndef FF_W_ANY
+      // park the weights in the accumulation-register half of the file (MFMA takes its A operand from there): left to itself the
+      // allocator filled all 256 VGPRs with them, kept the ACCUMULATORS in AGPRs (a v_accvgpr_read per value in every epilogue)
+      // and had ONE 4-register buffer for the activation fragments -- every K-stage was ds_read, wait, 4 MFMAs, in series
+      asm volatile("" : "+a"(w[s][j]));
+#endif
+    }
 }
 
 // acc[i][j] += sum over KST stages of W-fragment(s, j) x X-fragment(i, s); A = the activation tile (its first stage).  CP > 0: the
@@ -230,16 +240,20 @@ __device__ __forceinline__ void ff_mma_r(const unsigned char* A, int frag_off, c
   if constexpr (CP > 0) ff_copy_out<CP>(cp_src, cp_dst, tid);
   return;
 #endif
+  x8_t xa[2][4];      // (the next stage's fragments are requested before this stage's MFMAs)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xa[0][i] = *(const x8_t*)(A + frag_off + i * 16 * 64);
 #pragma unroll
   for (int s = 0; s < KST; ++s) {
-    if constexpr (CP > 0) { if (s == 1) ff_copy_out<CP>(cp_src, cp_dst, tid); }
-    x8_t xa[4];
+    if (s + 1 < KST) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xa[i] = *(const x8_t*)(A + s * FF_STAGE + frag_off + i * 16 * 64);
+      for (int i = 0; i < 4; ++i) xa[(s + 1) & 1][i] = *(const x8_t*)(A + (s + 1) * FF_STAGE + frag_off + i * 16 * 64);
+    }
+    if constexpr (CP > 0) { if (s == 1) ff_copy_out<CP>(cp_src, cp_dst, tid); }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[i][j] = FfOps<F16>::mfma(w[s][j], xa[i], acc[i][j]);
+      for (int j = 0; j < NJ; ++j) acc[i][j] = FfOps<F16>::mfma(w[s][j], xa[s & 1][i], acc[i][j]);
   }
 }
 
@@ -430,12 +444,14 @@ __device__ __forceinline__ void ff_layer256_bwd(const unsigned char* A, int frag
   auto mma_rows = [&](int i, ff_f32x4_t (&a)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) a[j] = ff_f32x4_t{0.f, 0.f, 0.f, 0.f};
+    x8_t xa[KST];
 #pragma unroll
-    for (int s = 0; s < KST; ++s) {
-      const x8_t xa = *(const x8_t*)(A + s * FF_STAGE + frag_off + i * 16 * 64);
+    for (int s = 0; s < KST; ++s) xa[s] = *(const x8_t*)(A + s * FF_STAGE + frag_off + i * 16 * 64);
+    __builtin_amdgcn_sched_barrier(0);      // (the scheduler sinks each read back in front of its MFMAs otherwise)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) a[j] = FfOps<F16>::mfma(w[s][j], xa, a[j]);
-    }
+    for (int s = 0; s < KST; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = FfOps<F16>::mfma(w[s][j], xa[s], a[j]);
   };
   mma_rows(0, acc[0]);
 #pragma unroll
