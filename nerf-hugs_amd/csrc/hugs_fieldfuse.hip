@@ -159,7 +159,9 @@ __device__ __forceinline__ void ff_layer256(const unsigned char* A, int frag_off
       for (int j = 0; j < 4; ++j) a[j] = FfOps<F16>::mfma(w[s][j], xa[s], a[j]);
 #endif
   };
-  uint16_t* Yout = Y ? Y + (size_t)m0 * 256 : nullptr;                    // (uniform)
+  // (LAST <=> the layer's rows go to HBM from the registers, no LDS tile; the mask bits are always computed and only their store
+  //  depends on the pointer: a null test per fragment split the layer into ~35 basic blocks, and MFMAs do not move across those)
+  uint16_t* Yout = Y + (size_t)m0 * 256;                                  // (uniform)
   const unsigned yo = ff_fresh((unsigned)(r16 * 256 + wn * 64 + kb * 4) * 2u);      // (bytes)
   const unsigned bo = ff_fresh((unsigned)lane * 4u);
   // hugs_gemm.hip nt_epilogue_direct bit layout: NT tile = 256 rows; its wave (wm_nt, wn) covers 128 rows = fragment rows i_nt 0..7
@@ -178,20 +180,19 @@ __device__ __forceinline__ void ff_layer256(const unsigned char* A, int frag_off
       uint2 u;
       u.x = ff_relu_pk(ff_cvt_pk<F16>(v[0], v[1])); u.y = ff_relu_pk(ff_cvt_pk<F16>(v[2], v[3]));
       uk[j][0] = u.x; uk[j][1] = u.y;
+      if constexpr (LAST) {
 #ifndef FF_NOSTORE
-      if (Yout) *(uint2*)((char*)Yout + (yo + (unsigned)(i * 16 * 256 + j * 16) * 2u)) = u;
+        *(uint2*)((char*)Yout + (yo + (unsigned)(i * 16 * 256 + j * 16) * 2u)) = u;
 #endif
-      if (An) {
+      } else {
         const int st = wn * 2 + (j >> 1), ch = (j & 1) * 2 + (kb >> 1);
         *(uint2*)(An + st * FF_STAGE + (i * 16 + r16) * 64 + ((ch ^ swz) << 4) + (kb & 1) * 8) = u;
-      }
-      if (bout) {
         const int k = (i & 1) * 8 + j * 2;
         bw |= ((u.x + 0x7fff7fffu) >> (15 - k)) & (0x00010001u << k);
         bw |= ((u.y + 0x7fff7fffu) >> (14 - k)) & (0x00010001u << (k + 1));
       }
     }
-    if (bout && (i & 1)) { *(uint32_t*)((char*)btile + (bo + (unsigned)(((i_nt0 + i) >> 1) * 64) * 4u)) = bw; bw = 0u; }
+    if (!LAST && (i & 1)) { if (bout) *(uint32_t*)((char*)btile + (bo + (unsigned)(((i_nt0 + i) >> 1) * 64) * 4u)) = bw; bw = 0u; }
     if (LAST) {
       // rgb head on the rounded activations, on the matrix cores: the packed outputs of two neighbouring 16-column fragments ARE a
       // B operand (lane (row, kb) holds k-slots kb*8 .. +7 = columns (2a)*16 + kb*4 .. +3 and (2a+1)*16 + kb*4 .. +3) once the

@@ -35,7 +35,7 @@ if hasattr(cd, 'hugs_ff_trace_read'):
   buf = np.zeros(256, np.int64)
   cd.hugs_ff_trace_read(buf.ctypes.data_as(ctypes.c_void_p))
   tr = buf.reshape(2, 8, 16)
-  names = ['L0 mma', 'L0 emit', 'sync', 'sync2', 'L1 mma+copyY0', 'L1 epi', 'sync', 'C0 ld+mma+copyXh', 'C0 emit', 'sync', 'C1 mma+copyH0', 'put+C1 emit', 'rgb part', 'sync', 'final']
+  names = ['L0', '-', 'sync', 'L1 mma+copyY0', 'L1 epi', 'sync', 'C0(+loads,copyXh)', '-', 'sync', 'put inputs', 'C1(+copyH0,rgb)', '-', 'sync', 'final']
   for w in range(2):
     print('wave', 0 if w == 0 else 3, 'phase cycles per tile:')
     for ti in range(1, 6):
