@@ -8,6 +8,18 @@
 #include <algorithm>
 
 template <int BF16>
+__device__ __forceinline__ void decode8(const uint4 p, float v[8]) {      // eight 16-bit operands (BF16 = 1 bf16, 2 half) -> fp32
+  if (BF16 == 2) {
+    v[0] = h16_to_f((uint16_t)p.x); v[1] = h16_to_f((uint16_t)(p.x >> 16)); v[2] = h16_to_f((uint16_t)p.y); v[3] = h16_to_f((uint16_t)(p.y >> 16));
+    v[4] = h16_to_f((uint16_t)p.z); v[5] = h16_to_f((uint16_t)(p.z >> 16)); v[6] = h16_to_f((uint16_t)p.w); v[7] = h16_to_f((uint16_t)(p.w >> 16));
+  } else {
+    v[0] = __uint_as_float(p.x << 16); v[1] = __uint_as_float(p.x & 0xffff0000u);
+    v[2] = __uint_as_float(p.y << 16); v[3] = __uint_as_float(p.y & 0xffff0000u);
+    v[4] = __uint_as_float(p.z << 16); v[5] = __uint_as_float(p.z & 0xffff0000u);
+    v[6] = __uint_as_float(p.w << 16); v[7] = __uint_as_float(p.w & 0xffff0000u);
+  }
+}
+template <int BF16>
 __device__ __forceinline__ void load8(const void* base, size_t elem_off, float v[8]) {
   if (BF16 == 2) {
     const uint4 p = *(const uint4*)((const uint16_t*)base + elem_off);
@@ -318,18 +330,43 @@ __global__ __launch_bounds__(256) void k_rgb_bwd(int M, int rows_per_blk, const 
     }
   float db[3] = {0.f, 0.f, 0.f};
   const float sc = 1.f + 2.f * pad;
+  // (round 4, 16-bit activations: the next row's chunks and colours are requested before this row's arithmetic -- one row in flight
+  //  per 16-lane group left the pass at 3.5 TB/s)
+  uint4 nraw[P];
+  float nrgb[3], ndr[3];
+  auto fetch = [&](int m) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) nraw[p] = *(const uint4*)((const uint16_t*)Hact + (size_t)m * ldh + p * 128 + sub * 8);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { nrgb[c] = rgb[(size_t)m * 3 + c]; ndr[c] = d_rgb[(size_t)m * 3 + c]; }
+  };
+  constexpr bool PF = BF16 != 0 && P == 2;      // (the 128-wide head at 131 k rows is 8 % slower with it)
+  if (PF && m0 + grp < m1) fetch(m0 + grp);
   for (int m = m0 + grp; m < m1; m += 16) {
     float dz[3];
+    uint4 raw[P];
+    if (PF) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float s = (rgb[(size_t)m * 3 + c] + pad) / sc;
-      dz[c] = d_rgb[(size_t)m * 3 + c] * sc * s * (1.f - s);
+      for (int p = 0; p < P; ++p) raw[p] = nraw[p];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float s = (nrgb[c] + pad) / sc;
+        dz[c] = ndr[c] * sc * s * (1.f - s);
+      }
+      if (m + 16 < m1) fetch(m + 16);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float s = (rgb[(size_t)m * 3 + c] + pad) / sc;
+        dz[c] = d_rgb[(size_t)m * 3 + c] * sc * s * (1.f - s);
+      }
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int j0 = p * 128 + sub * 8;
       float h[8], g[8];
-      load8<BF16>(Hact, (size_t)m * ldh + j0, h);
+      if (PF) decode8<BF16>(raw[p], h);
+      else load8<BF16>(Hact, (size_t)m * ldh + j0, h);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         g[q] = h[q] > 0.f ? dz[0] * w[p][q][0] + dz[1] * w[p][q][1] + dz[2] * w[p][q][2] : 0.f;
