@@ -638,12 +638,31 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
     for (int i = 0; i < 8; ++i) f.xa[i] = *(const bf16x8_t*)(la + i * 16 * 64);
     c_slot = (c_slot + 1) & 3;
   };
+#ifdef HUGS_MFMA32_STANDIN
+  // TIMING STAND-IN (scratch/r4_mfma32.sh): the stage's 32 v_mfma_f32_16x16x32 replaced by 16
+  // v_mfma_f32_32x32x16 on the same fragment registers -- same flops, LDS bytes and accumulator registers, half the operand reads
+  // per flop; the products are NOT the GEMM's (the fragment layout of the 32x32 shape differs): for the clock only
+  typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+  f32x16_t acc16[4][2];
+  auto mfma32_q = [&](const Frags& f, int q) {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+        acc16[q][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.wb[cb * 2 + kh], f.xa[2 * q + kh], acc16[q][cb], 0, 0, 0);
+  };
+  auto mfmas = [&](const Frags& f) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mfma32_q(f, q);
+  };
+#else
   auto mfmas = [&](const Frags& f) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = HUGS_MFMA_16X16X32(f.wb[j], f.xa[i], acc[i][j], 0, 0, 0);
   };
+#endif
   // The same work in four fenced quarters of {1 LDS-DMA, 3 fragment reads, 8 MFMAs}: the four DMAs
   // of a stage are not pushed into the CU's vector-memory path back to back by all 8 waves at once.
   auto issue_piece = [&](int q) {
@@ -677,12 +696,16 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
     }
     if (q == 3) c_slot = (c_slot + 1) & 3;
   };
+#ifdef HUGS_MFMA32_STANDIN
+  auto mfma_piece = [&](const Frags& f, int q) { mfma32_q(f, q); };
+#else
   auto mfma_piece = [&](const Frags& f, int q) {
 #pragma unroll
     for (int i = 2 * q; i < 2 * q + 2; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = HUGS_MFMA_16X16X32(f.wb[j], f.xa[i], acc[i][j], 0, 0, 0);
   };
+#endif
 #define GP_Q(cur, nxt, q)                                                                                   \
     issue_piece(q); frags_piece(nxt, q); mfma_piece(cur, q);                                                 \
     __builtin_amdgcn_sched_barrier(0);
@@ -734,6 +757,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
+#ifdef HUGS_MFMA32_STANDIN
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc16[q][cb][e] = acc[2 * q + (e >> 3)][2 * cb + ((e >> 2) & 1)][e & 3];
+#endif
     HUGS_TRP(i, 0)
     // the previous tile's 16 stores (+ 4 mask-bit words) are in the queue behind the two younger stages
     // Round 3: iterations 1-3 in the quartered form too (issued back to back, the four DMAs of a stage cost ~0.7k cycles more
@@ -750,6 +781,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
 #pragma unroll 1
     for (int st = 4; st < ns; st += 2) { GP_ITERQ(f0, f1, 8) GP_ITERQ(f1, f0, 8) }
     HUGS_TRP(i, 2)
+#ifdef HUGS_MFMA32_STANDIN
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[2 * q + (e >> 3)][2 * cb + ((e >> 2) & 1)][e & 3] = acc16[q][cb][e];
+#endif
     nt_epilogue_direct<EPI, (EPI >= 0 && (EPI & EPI_BIAS) != 0), true>(acc, E, m0, n0, wm, wn, r16, kb, lds_bias, lds_r1);
     HUGS_TRP(i, 3)
   }
