@@ -815,8 +815,8 @@ class NerfactoModel:
     return float(self.amp_state[0]) if self.amp else 1.0
 
   def _field_backward_fused(self, st, rays, N, S, M, G1, d_dens):
-    """Colour layer 1 gradient -> hash-feature gradient in ONE launch (csrc/hugs_fieldfuse.hip k_field_bwd), then the three
-    remaining weight-gradient GEMMs on the G operands it wrote.  The base network's second layer runs in head-input column order
+    """Colour layer 1 gradient -> hash-feature gradient in ONE launch (csrc/hugs_fieldfuse.hip k_field_bwd), then the four
+    weight-gradient GEMMs on G1 and the G operands it wrote.  The base network's second layer runs in head-input column order
     there (W1x): its weight / bias gradients come out in that order and are moved to the layout's columns."""
     c, ws, dt = self.cfg, self.ws, self.dt
     K0, N0 = self.lay.items['field/w0'][1]
@@ -827,7 +827,7 @@ class NerfactoModel:
     L.call('hugs_nf_field_bwd', dt, M, S, G1, self.wn['field/c1'], self.wn['field/c0'], self.w1xn, self.wn['field/w0'], st['bH0'], st['bY0'],
            d_dens, st['sel'], st['Y1'], g, self.napp, rays['embed_idx'] if self.napp else None, G0, Gb, Gy0, dX0, K0,
            self.lay.view(self.grad, 'appearance') if self.napp else None)
-    # the field grid's table gradient (atomic-bound, 1.8 ms) needs only dX0: on its own stream next to the three weight-gradient
+    # the field grid's table gradient (atomic-bound, 1.8 ms) needs only dX0: on its own stream next to the four weight-gradient
     # GEMMs (HBM-bound) instead of behind them
     side = None
     if os.environ.get('HUGS_NF_BWD_STREAMS', '1') != '0' and os.environ.get('HUGS_NF_GRID_SIDE', '1') != '0':
@@ -843,6 +843,7 @@ class NerfactoModel:
         self._bwd_done.append(e)      # (train_step joins it with the levels' streams)
       else:
         cur.wait_event(e)
+    self._tn(M, 'field/c1', st['H0'], G1, 'field/cb1')
     self._tn(M, 'field/c0', st['Xh'], G0, 'field/cb0')
     tw, tb = ws.get('gw1x', (N0, N1)), ws.get('gb1x', (N1,))
     self._tn(M, 'field/w1', st['Y0'], Gb, 'field/b1', out=tw, out_bias=tb)
@@ -888,11 +889,11 @@ class NerfactoModel:
         L.call('hugs_nf_rgb_grad', M, dt, st['rgb'], d_rgb_s, Gc, Nc)
         self._tn(M, 'field/c2', st['H1'], Gc, 'field/cb2')
         self._nt(M, 'field/c2', Gc, None, False, G1, mask=st['H1'], transpose=True)
-      self._tn(M, 'field/c1', st['H0'], G1, 'field/cb1')
       if (st.get('fused_field') and S % 64 == 0 and st.get('bH0') is not None and st.get('bY0') is not None and
           os.environ.get('HUGS_NF_FIELD_FUSE_BWD', '1') != '0'):
-        self._field_backward_fused(st, rays, N, S, M, G1, d_dens)
+        self._field_backward_fused(st, rays, N, S, M, G1, d_dens)      # (runs all four weight-gradient GEMMs behind its launch)
         return
+      self._tn(M, 'field/c1', st['H0'], G1, 'field/cb1')
       G0 = ws.get('G0', (M, H), self.tdt)
       self._nt(M, 'field/c1', G1, None, False, G0, mask=st['H0'], transpose=True, bits=st.get('bH0'))
       self._tn(M, 'field/c0', st['Xh'], G0, 'field/cb0')
