@@ -138,7 +138,7 @@ template <int F16, int KST, int CP, bool LAST>
 __device__ __forceinline__ void ff_layer256(const unsigned char* A, int frag_off, const typename FfOps<F16>::x8_t (&w)[KST][4],
                                             const float* bias /* + wn*64 + kb*4 */, int m0, int wn, int r16, int kb, int lane,
                                             unsigned char* An, uint32_t* bout, uint16_t* Y, const unsigned char* cp_src, char* cp_dst,
-                                            int tid, const typename FfOps<F16>::x8_t (&c2f)[2][2], float (*red)[4][3]) {
+                                            int tid, const typename FfOps<F16>::x8_t (&c2f)[2][3], float (*red)[4][3]) {
   typedef typename FfOps<F16>::x8_t x8_t;
   const int swz = 3 * ((r16 >> 2) & 1);
   float4 bb[4];
@@ -196,7 +196,8 @@ __device__ __forceinline__ void ff_layer256(const unsigned char* A, int frag_off
     if (LAST) {
       // rgb head on the rounded activations, on the matrix cores: the packed outputs of two neighbouring 16-column fragments ARE a
       // B operand (lane (row, kb) holds k-slots kb*8 .. +7 = columns (2a)*16 + kb*4 .. +3 and (2a+1)*16 + kb*4 .. +3) once the
-      // A operand c2f[a] carries the rgb layer's weights in the same slot order; its fp32 weights enter as a 16-bit hi + lo pair.
+      // A operand c2f[a] carries the rgb layer's weights in the same slot order; its fp32 weights enter as 16-bit hi + lo (+ a third
+      // slice in bf16) operands.
       // D[n][row]: the lanes kb == 0 end up with (r, g, b) partial sums of this wave's 64 columns for row r16 -- no lane shuffles.
       ff_f32x4_t pr = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -206,6 +207,7 @@ __device__ __forceinline__ void ff_layer256(const unsigned char* A, int frag_off
         const x8_t bf = __builtin_bit_cast(x8_t, bw4);
         pr = FfOps<F16>::mfma(c2f[a][0], bf, pr);
         pr = FfOps<F16>::mfma(c2f[a][1], bf, pr);
+        if (!F16) pr = FfOps<F16>::mfma(c2f[a][2], bf, pr);      // (bf16: a third 8-bit slice, 24 bits of the fp32 weight in all)
       }
       if (kb == 0) { red[i * 16 + r16][wn][0] = pr[0]; red[i * 16 + r16][wn][1] = pr[1]; red[i * 16 + r16][wn][2] = pr[2]; }
     }
@@ -292,21 +294,23 @@ __global__ __launch_bounds__(256, 1) void k_field_fwd(const FieldFwd P) {
   const int ntile = P.M / FF_ROWS, G = (int)gridDim.x;
   if (tid < 3) cb2s[tid] = P.cb2[tid];
   // the rgb layer [256, 3] fp32 as MFMA A operands in the slot order of ff_layer256's B operands: lane (n = r16, kb), slot e of
-  // half a -> column wn*64 + (2a + (e >> 2))*16 + kb*4 + (e & 3); rows n >= 3 are zero; each value as a 16-bit hi + lo pair
-  x8_t c2f[2][2];
+  // half a -> column wn*64 + (2a + (e >> 2))*16 + kb*4 + (e & 3); rows n >= 3 are zero; each value as 16-bit hi + lo (+ third) slices
+  x8_t c2f[2][3];
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
     typedef unsigned __attribute__((ext_vector_type(4))) u4;
-    u4 hw, lw;
+    u4 hw, lw, tw;
 #pragma unroll
     for (int e2 = 0; e2 < 4; ++e2) {
       const int c0 = wn * 64 + (2 * a + (e2 >> 1)) * 16 + kb * 4 + (e2 & 1) * 2;
       const float v0 = r16 < 3 ? P.c2[c0 * 3 + r16] : 0.f, v1 = r16 < 3 ? P.c2[(c0 + 1) * 3 + r16] : 0.f;
       const uint32_t h = ff_cvt_pk<F16>(v0, v1);
-      hw[e2] = h;
-      lw[e2] = ff_cvt_pk<F16>(v0 - FfOps<F16>::lo(h), v1 - FfOps<F16>::hi(h));
+      const float r0 = v0 - FfOps<F16>::lo(h), r1 = v1 - FfOps<F16>::hi(h);
+      const uint32_t l = ff_cvt_pk<F16>(r0, r1);
+      hw[e2] = h; lw[e2] = l;
+      tw[e2] = ff_cvt_pk<F16>(r0 - FfOps<F16>::lo(l), r1 - FfOps<F16>::hi(l));
     }
-    c2f[a][0] = __builtin_bit_cast(x8_t, hw); c2f[a][1] = __builtin_bit_cast(x8_t, lw);
+    c2f[a][0] = __builtin_bit_cast(x8_t, hw); c2f[a][1] = __builtin_bit_cast(x8_t, lw); c2f[a][2] = __builtin_bit_cast(x8_t, tw);
   }
   bs[tid] = P.b0[tid]; bs[384 + tid] = P.cb0[tid]; bs[640 + tid] = P.cb1[tid];
   if (tid < 128) bs[256 + tid] = P.b1[tid];

@@ -497,3 +497,86 @@ def test_fused_field_step_gradients_equal_layer_by_layer(cdt, monkeypatch):
       assert sc > 0 or name in ('transient',), name
       err = float((ga - gb).abs().max())
       assert err <= 2e-3 * sc + 1e-12, f'{cdt} {mode} {name}: {err:.3e} vs scale {sc:.3e}'
+
+
+def _unpack_bits(bits, M, width=256):
+  """hugs_gemm_nt_bits lane layout -> bool [M, width] (hugs_gemm.hip nt_epilogue_direct: tile of 256 rows, wave (wm, wn), word
+  i >> 1 of fragment row i, lane (r16, kb): bit k = (i & 1) * 8 + j * 2 (+ 1) for columns 0, 2 (1, 3) -> bits k / k + 16)."""
+  w = bits.view(torch.int32).reshape(M // 256, 2, 4, 4, 64).cpu().numpy().astype(np.uint32)      # [tile][wm][wn][word][lane]
+  out = np.zeros((M, width), bool)
+  lane = np.arange(64); r16, kb = lane & 15, lane >> 4
+  for wm in range(2):
+    for wn in range(4):
+      for i in range(8):
+        for j in range(4):
+          k = (i & 1) * 8 + j * 2
+          word = w[:, wm, wn, i >> 1, :]                     # [tile, lane]
+          rows = (np.arange(M // 256)[:, None] * 256 + wm * 128 + i * 16 + r16[None, :])
+          for c in range(4):
+            bit = (word >> (k + (c >> 1) + 16 * (c & 1))) & 1
+            out[rows, wn * 64 + j * 16 + kb[None, :] * 4 + c] = bit.astype(bool)
+  return out
+
+
+@pytest.mark.parametrize('dt', [1, 2])
+def test_fused_field_kernels_vs_torch(dt):
+  """hugs_nf_field_fwd / hugs_nf_field_bwd through the C ABI on random operands against plain torch: fp32 matmuls of the same
+  16-bit operands with the activations rounded where the kernels round them (csrc/hugs_fieldfuse.hip; nerfacto.py:693-759)."""
+  from nerf_hugs_amd import _lib as L
+  tdt = torch.bfloat16 if dt == 1 else torch.float16
+  ulp = 2.0 ** -8 if dt == 1 else 2.0 ** -11
+  M, S, ngeo, napp = 1024, 128, 64, 48
+  N = M // S
+  g = torch.Generator(device=dev).manual_seed(11)
+  r = lambda *s, sc=1.0: torch.randn(*s, generator=g, device=dev) * sc
+  q = lambda x: x.to(tdt).float()
+  X0 = torch.zeros(M, 128, dtype=tdt, device=dev); X0[:, :32] = r(M, 32).to(tdt)
+  W0t, C0t, C1t = r(256, 128, sc=0.2).to(tdt), r(256, 128, sc=0.1).to(tdt), r(256, 256, sc=0.08).to(tdt)
+  W1x = torch.zeros(128, 256, dtype=tdt, device=dev); W1x[0] = r(256, sc=0.05).to(tdt); W1x[16:16 + ngeo] = r(ngeo, 256, sc=0.08).to(tdt)
+  b0, cb0, cb1, c2, cb2 = r(256, sc=0.1), r(256, sc=0.1), r(256, sc=0.1), r(256, 3, sc=0.2), r(4, sc=0.1)
+  b1x = torch.zeros(128, device=dev); b1x[0] = 0.1; b1x[16:16 + ngeo] = r(ngeo, sc=0.1)
+  sh, app = r(N, 16), r(N, napp)
+  sel = (torch.rand(M, generator=g, device=dev) > 0.2).float()
+  tmpl = torch.empty(N, 128, dtype=tdt, device=dev)
+  L.call('hugs_nf_head_template', dt, N, sh, app, ngeo, napp, tmpl)
+  ref_t = torch.zeros(N, 128, device=dev); ref_t[:, :16] = sh; ref_t[:, 16 + ngeo:16 + ngeo + napp] = app
+  assert torch.equal(tmpl, ref_t.to(tdt))
+  Y0, raw, Xh = (torch.empty(M, 256, dtype=tdt, device=dev), torch.empty(M, dtype=tdt, device=dev), torch.empty(M, 128, dtype=tdt, device=dev))
+  H0, H1 = torch.empty(M, 256, dtype=tdt, device=dev), torch.empty(M, 256, dtype=tdt, device=dev)
+  bY0, bH0 = torch.zeros(M * 8, dtype=torch.int32, device=dev), torch.zeros(M * 8, dtype=torch.int32, device=dev)
+  dens, rgb = torch.empty(M, device=dev), torch.empty(M, 3, device=dev)
+  L.call('hugs_nf_field_fwd', dt, M, S, X0, 128, W0t, 128, W1x, C0t, C1t, b0, b1x, cb0, cb1, c2, cb2, tmpl, ngeo, sel, Y0, raw, Xh, H0, H1, bY0, bH0, dens, rgb)
+  torch.cuda.synchronize()
+  # reference
+  rY0 = q(torch.relu(X0.float() @ W0t.float().T + b0))
+  y1 = rY0 @ W1x.float().T + b1x
+  rXh = ref_t.repeat_interleave(S, 0).to(tdt).float(); rXh[:, 16:16 + ngeo] = q(y1[:, 16:16 + ngeo])
+  rH0 = q(torch.relu(rXh @ C0t.float().T + cb0))
+  rH1 = q(torch.relu(rH0 @ C1t.float().T + cb1))
+  close = lambda a, b, n: float((a.float() - b).abs().max()) <= n * ulp * float(b.abs().max()) + 1e-6
+  assert close(Y0, rY0, 2) and close(Xh, rXh, 4) and close(H0, rH0, 6) and close(H1, rH1, 8)
+  assert close(raw, q(y1[:, 0]), 4)
+  np.testing.assert_allclose(dens.cpu().numpy(), (torch.exp(raw.float()) * sel).cpu().numpy(), rtol=2e-6)
+  # (the rgb layer's fp32 weights enter the matrix cores as 16-bit slices: three in bf16, two in half: 2^-24 / 2^-22 relative)
+  np.testing.assert_allclose(rgb.cpu().numpy(), torch.sigmoid(H1.float() @ c2 + cb2[:3]).cpu().numpy(), atol=2e-6)
+  assert np.array_equal(_unpack_bits(bY0, M), (Y0.float() > 0).cpu().numpy()) and np.array_equal(_unpack_bits(bH0, M), (H0.float() > 0).cpu().numpy())
+  # backward
+  G1 = r(M, 256, sc=0.1).to(tdt)
+  C1n, C0n, W1xn, W0n = C1t.t().contiguous(), C0t.t().contiguous(), W1x.t().contiguous(), W0t.t().contiguous()
+  d_dens = r(M, sc=0.1)
+  eidx = torch.randint(0, 5, (N,), generator=g, device=dev).int()
+  G0, Gb, Gy0 = torch.empty(M, 256, dtype=tdt, device=dev), torch.empty(M, 128, dtype=tdt, device=dev), torch.empty(M, 256, dtype=tdt, device=dev)
+  dX0 = torch.zeros(M, 128, dtype=tdt, device=dev)
+  demb = torch.zeros(5, napp, device=dev)
+  L.call('hugs_nf_field_bwd', dt, M, S, G1, C1n, C0n, W1xn, W0n, bH0, bY0, d_dens, sel, raw, ngeo, napp, eidx, G0, Gb, Gy0, dX0, 128, demb)
+  torch.cuda.synchronize()
+  rG0 = q((G1.float() @ C1t.float()) * (H0.float() > 0))
+  dXh = q(G0.float() @ C0t.float())                                     # (from the kernel's own rounded G0, as it computes it)
+  rGb = torch.zeros(M, 128, device=dev)
+  rGb[:, 0] = q(d_dens * torch.exp(raw.float().clamp(-15, 15)) * sel); rGb[:, 16:16 + ngeo] = dXh[:, 16:16 + ngeo]
+  rGy0 = q((Gb.float() @ W1x.float()) * (Y0.float() > 0))
+  rdX0 = q(Gy0.float() @ W0t.float())[:, :32]
+  assert close(G0, rG0, 2) and close(Gb, rGb, 4) and close(Gy0, rGy0, 4) and close(dX0[:, :32], rdX0, 4)
+  rde = torch.zeros(5, napp, device=dev)
+  rde.index_add_(0, eidx.long(), dXh[:, 16 + ngeo:16 + ngeo + napp].reshape(N, S, napp).sum(1))
+  assert float((demb - rde).abs().max()) <= 2e-3 * float(rde.abs().max())
