@@ -43,6 +43,13 @@ __device__ __forceinline__ uint32_t ff_relu_pk(uint32_t u) {
   const s2 r = __builtin_elementwise_max(__builtin_bit_cast(s2, u), z);
   return __builtin_bit_cast(uint32_t, r);
 }
+// 1 in each 16-bit half that is not zero (relu outputs: positive or +0): v_pk_min_u16 with 1 -- bits 0 and 16, the mask layout's pair
+__device__ __forceinline__ uint32_t ff_nz_pk(uint32_t u) {
+  typedef unsigned short __attribute__((ext_vector_type(2))) us2;
+  const us2 one = {1, 1};
+  const us2 r = __builtin_elementwise_min(__builtin_bit_cast(us2, u), one);
+  return __builtin_bit_cast(uint32_t, r);
+}
 template <int F16> __device__ __forceinline__ uint32_t ff_cvt_pk(float a, float b) {       // one v_cvt_pk_{bf16,f16}_f32 (RNE)
   const ff_f32x2_t f = {a, b};
   const typename FfOps<F16>::x2_t h = __builtin_convertvector(f, typename FfOps<F16>::x2_t);
@@ -188,8 +195,8 @@ __device__ __forceinline__ void ff_layer256(const unsigned char* A, int frag_off
         const int st = wn * 2 + (j >> 1), ch = (j & 1) * 2 + (kb >> 1);
         *(uint2*)(An + st * FF_STAGE + (i * 16 + r16) * 64 + ((ch ^ swz) << 4) + (kb & 1) * 8) = u;
         const int k = (i & 1) * 8 + j * 2;
-        bw |= ((u.x + 0x7fff7fffu) >> (15 - k)) & (0x00010001u << k);
-        bw |= ((u.y + 0x7fff7fffu) >> (14 - k)) & (0x00010001u << (k + 1));
+        bw |= ff_nz_pk(u.x) << k;
+        bw |= ff_nz_pk(u.y) << (k + 1);
       }
     }
     if (!LAST && (i & 1)) { if (bout) *(uint32_t*)((char*)btile + (bo + (unsigned)(((i_nt0 + i) >> 1) * 64) * 4u)) = bw; bw = 0u; }
