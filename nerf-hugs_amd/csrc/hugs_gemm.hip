@@ -815,7 +815,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_bf16(int Mrows, int Kc, int 
   const int ntn = N / 128, ntk = Kc / 128;
   const int tiles = ntn * ntk;
   const int bid = blockIdx.x;
-  const int split = bid / tiles, tt = bid % tiles;
+  // Round 4: the tiles of one M-split share an operand (a [rows,128] x [rows,256] product reads X in both of its tiles): with
+  // consecutive blocks dealt round-robin over the 8 XCDs, tile 0 and tile 1 of a split sat behind different L2s and the shared
+  // rows came from HBM twice (1024 B per row for 768).  In groups of 8 * tiles blocks, block r of a group is tile r / 8 of the
+  // group's split r % 8: a split's tiles are consecutive blocks of ONE XCD.
+  int split = bid / tiles, tt = bid % tiles;
+  if (nsplit % 8 == 0 && tiles > 1) {
+    const int grp = bid / (8 * tiles), r = bid - grp * 8 * tiles;
+    split = grp * 8 + (r & 7); tt = r >> 3;
+  }
   const int c0 = (tt / ntn) * 128, n0 = (tt % ntn) * 128;
   const int rows_per = Mrows / nsplit;
   const int mbeg = split * rows_per;
