@@ -56,27 +56,27 @@ def synth_batch(n_patch, P, seed, device):
   return utils.Batch(rays=rays, rgb=f(rng.uniform(size=shp + (3,))))
 
 
-def instep_roofline(train_step, state, batch, gen, thr, steps=5):
+def instep_roofline(train_step, state, next_batch, gen, thr, steps=5):
   """Dominant kernel, measured INSIDE the train steps: every GEMM launch of `steps` extra steps is bracketed by HIP
   events on the stream it is launched on (nerf_hugs_amd/_lib.py PROFILE hook; the side stream for the weight-gradient
   GEMMs).  `roofline` is the forward NerfMLP trunk layer [131072,1024]x[1024,1024]^T + bias + relu; the masked dX and
   the dW GEMM of the same shape are reported next to it.  `traffic` = HBM bytes per launch from the rocprofv3 PMC
-  passes of THIS round's kernels, committed as profiles/r04_gemm_traffic.json (2 x FETCH_SIZE + WRITE_SIZE,
+  passes of the shipped kernels, committed as profiles/r05_gemm_traffic.json (r04_... when absent; 2 x FETCH_SIZE + WRITE_SIZE,
   MI355X_MICROARCH.md HBM section; `traffic_source` names the file and the kernel's duration under the profiler next to
   the in-step one), null when that file is absent."""
   from nerf_hugs_amd import _lib
   _lib.PROFILE = []
   for _ in range(steps):
-    state, stats, gen = train_step(gen, state, batch, 0.5, thr)
+    state, stats, gen = train_step(gen, state, next_batch(), 0.5, thr)
   torch.cuda.synchronize()
   recs, _lib.PROFILE = _lib.PROFILE, None
   agg = {}
   for name, key, e0, e1 in recs:
     agg.setdefault(key, []).append(e0.elapsed_time(e1) * 1e3)     # us
   traffic = {}
-  tpath = os.path.join(ROOT, 'profiles', 'r04_gemm_traffic.json')
-  if os.path.exists(tpath):
-    traffic = json.load(open(tpath))
+  tname = next((n for n in ('r05_gemm_traffic.json', 'r04_gemm_traffic.json') if os.path.exists(os.path.join(ROOT, 'profiles', n))), None)
+  if tname is not None:
+    traffic = json.load(open(os.path.join(ROOT, 'profiles', tname)))
 
   def entry(key, tkey, label, flops, alg_bytes):
     if key not in agg:
@@ -87,7 +87,7 @@ def instep_roofline(train_step, state, batch, gen, thr, steps=5):
     return {"bound": "mfma", "kernel": label, "launches": len(agg[key]), "avg_us": round(us, 1), "achieved": round(tf, 1),
             "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(tf * 1e12 / PEAK_BF16, 4),
             "traffic": t.get("hbm_bytes_per_launch"), "algorithmic_bytes": alg_bytes if alg_bytes is not None else t.get("algorithmic_bytes"),
-            "traffic_source": (f"profiles/r04_gemm_traffic.json[{tkey}]: separate rocprofv3 --pmc passes, {t.get('avg_us_profiled')} us per launch "
+            "traffic_source": (f"profiles/{tname}[{tkey}]: separate rocprofv3 --pmc passes, {t.get('avg_us_profiled')} us per launch "
                                f"under the profiler vs {round(us, 1)} us in-step") if t else None}
 
   W = 1024
@@ -116,8 +116,9 @@ def cpu_baseline(seed):
   """Oracle (CPU restatement of the reference) full training step on a bounded sample: 64 rays of the same
   workload (same nets, 64+128 samples), all host cores."""
   from oracle import torch_ref as R
-  ncores = int(os.environ.get('HUGS_CPU_THREADS', min(os.cpu_count(), 16)))
-  torch.set_num_threads(ncores)
+  host = os.cpu_count()
+  model_name = next((l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name')), 'unknown') \
+      if os.path.exists('/proc/cpuinfo') else 'unknown'
   cfg = R.kubric_cfg(num_levels=2, num_prop_samples=64, num_nerf_samples=128)
   params = R.init_params(cfg, seed)
   n = 64
@@ -138,15 +139,25 @@ def cpu_baseline(seed):
     g = R.clip_gradients(cfg, grads)
     R.adam_update(cfg, leaves, g, m, v_, i)
 
-  step(0)
-  t0 = time.time()
-  k = 0
-  while time.time() - t0 < 12.0 or k < 2:
-    step(k + 1)
-    k += 1
-  dt = (time.time() - t0) / k
-  return {"value": round(n / dt, 2), "unit": "rays/s", "cores": ncores, "kind": "port",
-          "sample": f"{k} full train steps of 64 rays x (64+128) samples, oracle/torch_ref.py fp32"}
+  # thread counts tried: HUGS_CPU_THREADS, or 16 and every core of the box (a 64-ray step does not always scale past 16
+  # threads); the best one is the baseline, `cores` = the threads it used, `host_cpu_count` = what the box has
+  tries = [int(os.environ['HUGS_CPU_THREADS'])] if 'HUGS_CPU_THREADS' in os.environ else sorted({min(host, 16), host})
+  best, tried, kk = None, {}, 0
+  for ncores in tries:
+    torch.set_num_threads(ncores)
+    step(kk); kk += 1
+    t0 = time.time()
+    k = 0
+    while time.time() - t0 < 12.0 / len(tries) or k < 2:
+      step(kk); kk += 1
+      k += 1
+    dt = (time.time() - t0) / k
+    tried[str(ncores)] = round(n / dt, 2)
+    if best is None or n / dt > best[0]:
+      best = (n / dt, ncores, k)
+  return {"value": round(best[0], 2), "unit": "rays/s", "cores": best[1], "host_cpu_count": host, "cpu_model": model_name, "kind": "port",
+          "rays_per_s_by_threads": tried,
+          "sample": f"{best[2]} full train steps of 64 rays x (64+128) samples, oracle/torch_ref.py fp32, {best[1]} threads"}
 
 
 def eval_psnr_vs_oracle(model, state, batch, dtype):
@@ -356,6 +367,10 @@ def main():
                        'scaling curve on ONE GPU, e.g. 128 = what --scaling strong hands each of 8 ranks')
   ap.add_argument('--step-graph', default=None, choices=['0', '1'],
                   help='replay the train step as a captured hipGraph (HUGS_STEP_GRAPH); default: the library default')
+  ap.add_argument('--batch-pool', type=int, default=64,
+                  help='number of pre-generated synthetic batches (resident in HBM) cycled one per step, so that no batch is seen\n'
+                       'twice inside a timed window of <= this many steps (VERDICT r4 item 1a: the old bench trained ~1300 steps on ONE\n'
+                       'memorised batch; GEMM time depends on operand values).  The fixed-batch rate is reported beside it.')
   ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3', 'cfg4', 'cfg5', 'ref360'],
                   help='cfg2 = the headline workload; cfg3 (static masks, 4096 rays, GLO 48, charb) and cfg4 (RobustNeRF 0.8,\n'
                        'contract + reciprocal, GLO 4, 1024 rays/GPU) and cfg5 (nerfacto hash-grid path, 16384 rays/GPU,\n'
@@ -415,25 +430,38 @@ def main():
     P = 8
   config = configs.make_config(batch_size=rays_per_gpu * world)
   model, state, _, train_step, _ = train_utils.setup_model(config, 20200823, compute_dtype=args.dtype, device=device)
-  batch = synth_batch(rays_per_gpu // (P * P), P, 1000 + rank, device)
-  if args.config == 'ref360':     # 360.gin: near 0.2, far 1e6 (contracted space)
-    batch.rays.near.fill_(0.2)
-    batch.rays.far.fill_(1e6)
-  if args.config == 'cfg4':       # distractor-like geometry: near in [0.05, 0.3], far 1e6
-    batch.rays.near.uniform_(0.05, 0.3)
-    batch.rays.far.fill_(1e6)
-  if args.config in ('cfg3', 'cfg4'):
-    batch.rays.embed_idx.copy_(torch.randint(0, 3500, (rays_per_gpu // (P * P), 1, 1, 1), device=device).expand_as(batch.rays.embed_idx))
-    batch.rays.static_mask.copy_((torch.rand(rays_per_gpu // (P * P), P, P, 1, device=device) < 0.8).float())
+  def make_batch(i):
+    batch = synth_batch(rays_per_gpu // (P * P), P, 1000 + rank + 7919 * i, device)
+    if args.config == 'ref360':     # 360.gin: near 0.2, far 1e6 (contracted space)
+      batch.rays.near.fill_(0.2)
+      batch.rays.far.fill_(1e6)
+    if args.config == 'cfg4':       # distractor-like geometry: near in [0.05, 0.3], far 1e6
+      batch.rays.near.uniform_(0.05, 0.3)
+      batch.rays.far.fill_(1e6)
+    if args.config in ('cfg3', 'cfg4'):
+      batch.rays.embed_idx.copy_(torch.randint(0, 3500, (rays_per_gpu // (P * P), 1, 1, 1), device=device).expand_as(batch.rays.embed_idx))
+      batch.rays.static_mask.copy_((torch.rand(rays_per_gpu // (P * P), P, P, 1, device=device) < 0.8).float())
+    return batch
+  # a pool of distinct batches, all resident in HBM before the timed region; step i trains on pool[i % len(pool)]
+  pool = [make_batch(i) for i in range(max(1, args.batch_pool))]
+  batch = pool[0]
+  nstep = 0
+
+  def next_batch():
+    nonlocal nstep
+    b = pool[nstep % len(pool)]
+    nstep += 1
+    return b
   # the reference's stream: PRNGKey(20200823) split over the devices (train.py:46,80), threefry on the GPU
   from nerf_hugs_amd.internal import random as hrandom
   gen = hrandom.split(hrandom.PRNGKey(20200823, device), world)[rank].clone()
   thr = None      # RobustNeRF: thresholds are fed back on the device (first step: ones, train.py:130)
   for _ in range(args.warmup):
-    state, stats, gen = train_step(gen, state, batch, 0.5, thr)
+    state, stats, gen = train_step(gen, state, next_batch(), 0.5, thr)
 
-  def window():
-    """EXACTLY --steps steps between barrier + synchronize on both sides; returns the max over ranks (seconds)."""
+  def window(fixed=None):
+    """EXACTLY --steps steps between barrier + synchronize on both sides; returns the max over ranks (seconds).
+    fixed: None = one pool batch per step (the headline), a batch = every step on that one batch."""
     nonlocal state, stats, gen
     torch.cuda.synchronize()
     if world > 1:
@@ -441,7 +469,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-      state, stats, gen = train_step(gen, state, batch, 0.5, thr)
+      state, stats, gen = train_step(gen, state, next_batch() if fixed is None else fixed, 0.5, thr)
     torch.cuda.synchronize()
     if world > 1:
       dist.barrier()
@@ -463,19 +491,22 @@ def main():
   dt = float(np.median(wins))
   loss = float(stats['loss'])
   psnr = float(stats['psnr'])
+  # the same windows on ONE fixed batch (what rounds 1-4 reported): a quarter of the timed budget
+  fwins = [window(batch) for _ in range(max(3, nwin // 4))] if len(pool) > 1 else list(wins)
+  dt_fixed = float(np.median(fwins))
   # host side of a step: wall time of enqueueing 8 steps onto an idle GPU without waiting for them (the launch queue is
   # far deeper than 8 steps); host_enqueue_ms >= ms_per_step means the step is host-bound
   torch.cuda.synchronize()
   t0 = time.perf_counter()
   for _ in range(8):
-    state, stats, gen = train_step(gen, state, batch, 0.5, thr)
+    state, stats, gen = train_step(gen, state, next_batch(), 0.5, thr)
   host_ms = (time.perf_counter() - t0) / 8 * 1e3
   torch.cuda.synchronize()
   roof = None
   if args.dtype == 'bf16' and args.config in ('cfg2', 'ref360'):
     # after the timed region: a few more steps with the GEMM launches bracketed by HIP events (every rank runs them:
     # the steps contain the gradient all-reduce; rank 0 reports)
-    roof, roof_others, roof_shapes, state, gen = instep_roofline(train_step, state, batch, gen, thr)
+    roof, roof_others, roof_shapes, state, gen = instep_roofline(train_step, state, next_batch, gen, thr)
   eval_psnr = None
   if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 'cfg2' and args.rays_per_gpu is None:
     eval_psnr = eval_psnr_vs_oracle(model, state, batch, args.dtype)
@@ -487,7 +518,11 @@ def main():
         "windows": len(wins), "timed_s": round(float(np.sum(wins)), 3), "gpu_timed_s": round(float(np.sum(wins)), 3),
         "host_enqueue_ms_per_step": round(host_ms, 3), "step_graph": bool(getattr(train_step, 'graph_active', lambda: False)()),
         "value_min": round(rays_per_gpu * world * args.steps / max(wins), 1), "value_max": round(rays_per_gpu * world * args.steps / min(wins), 1),
-        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype,
+        "data": f"synthetic: {len(pool)} distinct pre-generated batches resident in HBM, one per step (no batch twice inside a window)",
+        "fixed_batch": {"value": round(rays_per_gpu * world * args.steps / dt_fixed, 1), "ms_per_step": round(dt_fixed / args.steps * 1e3, 3),
+                        "windows": len(fwins), "fresh_over_fixed": round(dt_fixed / dt, 4),
+                        "note": "every step on pool[0] (the rounds 1-4 protocol), timed after the headline windows"},
         "config": {"workload": {"cfg2": "configs[1]: MipNeRF360 base (kubric_1024_base.gin nets), 1024 rays x (64 prop + 128 fine) per GPU, "
                                         "full train step",
                                 "cfg3": "configs[2] restatement: + HuGS static masks, GLO 48, charb, 4096 rays x (64+128), full train step",

@@ -96,6 +96,7 @@ int hugs_gemm_tn_batch(int dtype, int nitems, const HugsTnItem* items, int nspli
  * non-null -- receives the 1-bit relu masks in hugs_gemm_nt_bits' layout), then raw = Y_nl . wd + bd, density = softplus(raw +
  * density_bias) (wd null: no head).  A 128-row activation tile stays in LDS from layer to layer.  Wt / bias / Y / bits are HOST
  * arrays of nl device pointers; M a multiple of 256, nl <= 7, dtype 1 (bf16). */
+int hugs_mlp256_tail_max_layers(void);      /* the nl cap of hugs_mlp256_tail_fwd (callers fall back to per-layer GEMMs above it) */
 int hugs_mlp256_tail_fwd(int dtype, int M, int nl, const void* Y0, const void* const* Wt, const float* const* bias,
                          void* const* Y, uint32_t* const* bits, const float* wd, const float* bd, float density_bias, float* raw,
                          float* density, void* stream);

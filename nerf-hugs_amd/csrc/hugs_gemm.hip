@@ -251,7 +251,7 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {      // one 
   const bf16x2_t h = __builtin_convertvector(f, bf16x2_t);
   return *(const uint32_t*)&h;
 }
-template <int EPI, bool BIAS_IN_ACC = false, bool FRESH_LANE = false>
+template <int EPI, bool BIAS_IN_ACC = false, bool FRESH_LANE = false, int MASK_AHEAD = 2>
 __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const GemmEpi& E, int m0, int n0, int wm, int wn,
                                                    int r16, int kb, const float* lds_bias, const float* lds_r1col) {
     // ---- epilogue straight from registers: bias / rank-1 / relu, v_cvt_pk_bf16_f32, one v_permlane16_swap pair
@@ -270,6 +270,9 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
     // index is re-derived from an opaque copy of the thread index here, so that nothing of it is live before the epilogue)
     int lane_ = threadIdx.x & 63;
     if (FRESH_LANE) { int t_ = threadIdx.x; asm volatile("" : "+v"(t_)); lane_ = t_ & 63; }
+    // (the bf16-mask specialisations' load / store geometry -- ccol, srow below -- is loop invariant in the persistent kernel and was
+    //  hoisted out of its tile loop into scratch: derive it from the opaque lane index there)
+    if (FRESH_LANE && EPI >= 0 && (EPI & EPI_MASK)) { r16 = lane_ & 15; kb = lane_ >> 4; }
     const size_t bits_at = (((size_t)(m0 >> 8) * (size_t)(E.ldc >> 8) + (size_t)(n0 >> 8)) * 8 + (size_t)(wm * 4 + wn)) * 256 + (size_t)lane_;
     const bool has_bin = GEN ? E.bits_in != nullptr : bool(EPI & EPI_BIN);
     const bool has_bout = GEN ? E.bits_out != nullptr : bool(EPI & EPI_BOUT);
@@ -297,18 +300,22 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
     const bool hi8 = (r16 & 8) != 0;
     const int srow = r16 & 7;                                            // row (within the 16-row group) of store A; B = +8
     const int ccol = n0 + wn * 64 + (kb & 1) * 16 + (kb >> 1) * 8 + (hi8 ? 32 : 0);
-    // relu-mask chunks (same whole-line geometry as the stores), fetched two fragment rows ahead of their use: all 16
-    // in flight at once would cost 64 registers on top of the 128 accumulators
+    // relu-mask chunks (same whole-line geometry as the stores), fetched MASK_AHEAD fragment rows ahead of their use: all 16
+    // in flight at once would cost 64 registers on top of the 128 accumulators (the persistent kernel, whose loader state is live
+    // across the epilogue, affords one row ahead: with two its bf16-mask specialisations spilled 2-3 registers)
     uint4 mkv[8][2];
     auto mask_load = [&](int i) {
 #pragma unroll
       for (int h = 0; h < 2; ++h)
         mkv[i][h] = *(const uint4*)((const uint16_t*)E.mask + (size_t)(m0 + wm * 128 + i * 16 + h * 8 + srow) * E.ld_mask + ccol);
     };
-    if (has_mask) { mask_load(0); mask_load(1); }
+    if (has_mask) {
+#pragma unroll
+      for (int a = 0; a < MASK_AHEAD; ++a) mask_load(a);
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      if (has_mask && i + 2 < 8) mask_load(i + 2);
+      if (has_mask && i + MASK_AHEAD < 8) mask_load(i + MASK_AHEAD);
       const int m = m0 + wm * 128 + i * 16 + r16;
       const float r1 = r1v[i];
       const float* rbp = has_rowb ? E.row_bias + (size_t)(m / E.row_div) * E.ld_rb + n0 + wn * 64 + kb * 4 : nullptr;
@@ -398,22 +405,33 @@ __global__ __launch_bounds__(128 * WN, 2) void k_gemm_nt_bf16_big(
 
   // staging: rows of 4 chunks(16 B); chunk id p = it*NT + tid -> row p>>2, physical pos p&3 holding logical
   // chunk pos ^ (3*((row>>2)&1)) (keeps the fragment ds_read_b128 conflict-free).
+  // Every LDS-DMA takes its global address as (64-bit SGPR base) + (32-bit per-lane byte offset), as the persistent kernel's
+  // does: chunk p = it*NT + tid sits in row it*(NT/4) + (tid >> 2) -- NT/4 is a multiple of 8, so the swizzle bit (row >> 2) & 1
+  // and with it the per-lane offset do not depend on `it` (3 VGPRs for the whole kernel), and the base is scalar arithmetic.
+  // (Round 5: the builtin's 64-bit per-lane addresses cost 3 VALU + a VGPR pair per load; every one-tile specialisation spilled
+  // 16-84 bytes per lane around them.)
+  const int prow = tid >> 2, pcol = ((tid & 3) ^ (3 * ((prow >> 2) & 1))) * 8;
+  const unsigned oA1 = (unsigned)(prow * lda1 + pcol) * 2u, oA2 = (unsigned)(prow * lda2 + pcol) * 2u;
+  const unsigned oB = (unsigned)(prow * ldb + pcol) * 2u;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + (unsigned)wv * 1024u;
+  auto dma = [&](const char* sbase, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory", "m0");
+  };
   auto stage = [&](int st) {
     const int kglob = st << 5;
-    const uint16_t* Abase; int lda, kcol;
-    if (kglob < K1) { Abase = A1; lda = lda1; kcol = kglob; } else { Abase = A2; lda = lda2; kcol = kglob - K1; }
-    unsigned char* la = lds + (st % NSLOT) * STAGE;
-    unsigned char* lb = la + A_BYTES;
+    const unsigned la = lds_base + (unsigned)(st % NSLOT) * STAGE;
+    if (kglob < K1) {
+      const char* ab = (const char*)A1 + ((size_t)m0 * lda1 + kglob) * 2;
 #pragma unroll
-    for (int it = 0; it < AIT; ++it) {
-      const int p = it * NT + tid, row = p >> 2, col = ((p & 3) ^ (3 * ((row >> 2) & 1))) * 8;
-      glds16(Abase + (size_t)(m0 + row) * lda + kcol + col, la + (it * NT + wv * 64) * 16);
-    }
+      for (int it = 0; it < AIT; ++it) dma(ab + (size_t)lda1 * 2 * (it * (NT / 4)), oA1, la + it * NT * 16);
+    } else {
+      const char* ab = (const char*)A2 + ((size_t)m0 * lda2 + (kglob - K1)) * 2;
 #pragma unroll
-    for (int it = 0; it < BIT; ++it) {
-      const int p = it * NT + tid, row = p >> 2, col = ((p & 3) ^ (3 * ((row >> 2) & 1))) * 8;
-      glds16(Bt + (size_t)(n0 + row) * ldb + kglob + col, lb + (it * NT + wv * 64) * 16);
+      for (int it = 0; it < AIT; ++it) dma(ab + (size_t)lda2 * 2 * (it * (NT / 4)), oA2, la + it * NT * 16);
     }
+    const char* bb = (const char*)Bt + ((size_t)n0 * ldb + kglob) * 2;
+#pragma unroll
+    for (int it = 0; it < BIT; ++it) dma(bb + (size_t)ldb * 2 * (it * (NT / 4)), oB, la + A_BYTES + it * NT * 16);
   };
 
   f32x4_t acc[8][4];
@@ -487,7 +505,10 @@ __global__ __launch_bounds__(128 * WN, 2) void k_gemm_nt_bf16_big(
 #undef GL_ITER
   HUGS_TR(2)
   if (WN == 4) {     // register-direct epilogue (A/B: +10 % over staging the C tile through LDS)
-    nt_epilogue_direct<EPI>(acc, E, m0, n0, wm, wn, r16, kb, nullptr, nullptr);
+    // (fenced off from the last MFMAs, lane index re-derived: scheduled into the tail iterations the epilogue's address arithmetic
+    //  and first conversions pushed 5-21 registers -- an accumulator fragment among them -- into scratch in most specialisations)
+    __builtin_amdgcn_sched_barrier(0);
+    nt_epilogue_direct<EPI, false, true>(acc, E, m0, n0, wm, wn, r16, kb, nullptr, nullptr);
     HUGS_TR(3)
     return;
   }
@@ -590,9 +611,20 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
   // is constant for the whole kernel (6 VGPRs), the base is scalar arithmetic -- no VALU and no address VGPR pairs in
   // the loop (the builtin's 64-bit per-lane addresses cost 3 VALU + a VGPR pair per load and pushed the kernel into
   // scratch spills, whose reloads are VMEM operations that drain the counted DMA queue).
-  int l_bid = blockIdx.x, l_st = 0, l_slot = 0;
+  // K rotation (round 5): a tile walks its K stages starting at l_k = rot(tile) and wraps.  The 8 workgroups of an XCD that
+  // share a weight column panel in a round (8 row bands x ntn column tiles on its 32 CUs) get 8 different rotations, the ntn
+  // workgroups that share a row band the same one: every K slice of the weight panel is then touched 8 times per round at evenly
+  // spaced moments instead of by all 8 at once and not again for a whole round (30 us, during which 4 MB of activations stream
+  // through the XCD's 4 MB L2 and push it out: the forward layer read 409 MB for 270 MB algorithmic,
+  // profiles/r04_gemm_traffic.json), while the activation slices are still fetched once and shared.  fp32 accumulation order
+  // changes per tile (deterministically); nothing else does.
+#ifndef HUGS_NT_KROT
+#define HUGS_NT_KROT 1
+#endif
+  auto rot_of = [&](int t) { return HUGS_NT_KROT ? ((((t / ntn) & 7) * ns) >> 3) : 0; };
+  int l_bid = blockIdx.x, l_st = 0, l_slot = 0, l_k;
   int lm0, ln0;
-  { const int t = xcd_remap(l_bid, ntiles); lm0 = (t / ntn) << 8; ln0 = (t % ntn) << 8; }
+  { const int t = xcd_remap(l_bid, ntiles); lm0 = (t / ntn) << 8; ln0 = (t % ntn) << 8; l_k = rot_of(t); }
   const int prow = tid >> 2, pcol = ((tid & 3) ^ (3 * ((prow >> 2) & 1))) * 8;   // this thread's chunk of rows 0..127
   // (rows 128..255 of a stage: the same per-lane offset on a base advanced by 128 rows)
   const unsigned oA1 = (unsigned)(prow * lda1 + pcol) * 2u, oA2 = (unsigned)(prow * lda2 + pcol) * 2u;
@@ -602,7 +634,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_addr) : "memory", "m0");
   };
   auto issue = [&]() {
-    const int kglob = l_st << 5;
+    const int kglob = l_k << 5;
     const unsigned la = lds_base + (unsigned)l_slot * STAGE;
     const char* bb = (const char*)Bt + ((size_t)ln0 * ldb + kglob) * 2;
     if (kglob < K1) {
@@ -614,12 +646,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
     }
     dma(bb, oB, la + A_BYTES); dma(bb + (size_t)ldb * 256, oB, la + A_BYTES + 8192);
     l_slot = (l_slot + 1) & 3;
+    if (++l_k == ns) l_k = 0;
     if (++l_st == ns) {
       l_st = 0;
       if (l_bid + G < ntiles) {
         l_bid += G;
         const int t = xcd_remap(l_bid, ntiles);
-        lm0 = (t / ntn) << 8; ln0 = (t % ntn) << 8;
+        lm0 = (t / ntn) << 8; ln0 = (t % ntn) << 8; l_k = rot_of(t);
       }   // else: keep re-reading the last tile (dead slots, uniform counts)
     }
   };
@@ -666,7 +699,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
   // The same work in four fenced quarters of {1 LDS-DMA, 3 fragment reads, 8 MFMAs}: the four DMAs
   // of a stage are not pushed into the CU's vector-memory path back to back by all 8 waves at once.
   auto issue_piece = [&](int q) {
-    const int kglob = l_st << 5;
+    const int kglob = l_k << 5;
     const unsigned la = lds_base + (unsigned)l_slot * STAGE;
     if (q < 2) {
       if (kglob < K1) dma((const char*)A1 + ((size_t)lm0 * lda1 + kglob) * 2 + (q ? (size_t)lda1 * 256 : 0), oA1, la + q * 8192);
@@ -676,12 +709,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
     }
     if (q == 3) {
       l_slot = (l_slot + 1) & 3;
+      if (++l_k == ns) l_k = 0;
       if (++l_st == ns) {
         l_st = 0;
         if (l_bid + G < ntiles) {
           l_bid += G;
           const int t = xcd_remap(l_bid, ntiles);
-          lm0 = (t / ntn) << 8; ln0 = (t % ntn) << 8;
+          lm0 = (t / ntn) << 8; ln0 = (t % ntn) << 8; l_k = rot_of(t);
         }
       }
     }
@@ -789,7 +823,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[2 * q + (e >> 3)][2 * cb + ((e >> 2) & 1)][e & 3] = acc16[q][cb][e];
 #endif
-    nt_epilogue_direct<EPI, (EPI >= 0 && (EPI & EPI_BIAS) != 0), true>(acc, E, m0, n0, wm, wn, r16, kb, lds_bias, lds_r1);
+    nt_epilogue_direct<EPI, (EPI >= 0 && (EPI & EPI_BIAS) != 0), true, 1>(acc, E, m0, n0, wm, wn, r16, kb, lds_bias, lds_r1);
     HUGS_TRP(i, 3)
   }
 #undef GP_ITER
@@ -1208,27 +1242,26 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_f32(int M, int N, int K1, in
   const int m0 = (t / ntn) * 128, n0 = (t % ntn) * 128;
   const int wm = wv >> 1, wn = wv & 1;
   const int nk = (K1 + K2) / GF_BK;
-  float4 ra[2], rb[2];
+  // (staging registers as four named values: as `float4 ra[2], rb[2]` indexed inside the lambdas' loops they lived in scratch --
+  //  64 bytes per lane written and re-read every K step)
+  float4 ra0, ra1, rb0, rb1;
+  const int prow = tid >> 2, pc = (tid & 3) * 4;      // chunk p = it * 256 + tid: row it * 64 + prow
   auto gload = [&](int kt) {
     const int kglob = kt * GF_BK;
     const float* Abase; int lda, kcol;
     if (kglob < K1) { Abase = A1; lda = lda1; kcol = kglob; } else { Abase = A2; lda = lda2; kcol = kglob - K1; }
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int p = it * 256 + tid, row = p >> 2, c = p & 3;
-      ra[it] = *(const float4*)(Abase + (size_t)(m0 + row) * lda + kcol + c * 4);
-      rb[it] = *(const float4*)(Bt + (size_t)(n0 + row) * ldb + kglob + c * 4);
-    }
+    ra0 = *(const float4*)(Abase + (size_t)(m0 + prow) * lda + kcol + pc);
+    ra1 = *(const float4*)(Abase + (size_t)(m0 + 64 + prow) * lda + kcol + pc);
+    rb0 = *(const float4*)(Bt + (size_t)(n0 + prow) * ldb + kglob + pc);
+    rb1 = *(const float4*)(Bt + (size_t)(n0 + 64 + prow) * ldb + kglob + pc);
   };
   auto lstore = [&](int buf) {
     float* la = lds + buf * 2 * 128 * GF_PITCH;
     float* lb = la + 128 * GF_PITCH;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int p = it * 256 + tid, row = p >> 2, c = p & 3;
-      *(float4*)(la + row * GF_PITCH + c * 4) = ra[it];
-      *(float4*)(lb + row * GF_PITCH + c * 4) = rb[it];
-    }
+    *(float4*)(la + prow * GF_PITCH + pc) = ra0;
+    *(float4*)(la + (64 + prow) * GF_PITCH + pc) = ra1;
+    *(float4*)(lb + prow * GF_PITCH + pc) = rb0;
+    *(float4*)(lb + (64 + prow) * GF_PITCH + pc) = rb1;
   };
   f32x4_t acc[4][4];
 #pragma unroll
@@ -1280,25 +1313,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_f32(int Mrows, int Kc, int N
   const int c0 = (tt / ntn) * 128, n0 = (tt % ntn) * 128;
   const int rows_per = Mrows / nsplit, mbeg = split * rows_per, nk = rows_per / 16;
   const int wk = wv >> 1, wn = wv & 1;
-  float4 rx[2], rg[2];
+  float4 rx0, rx1, rg0, rg1;      // (named, not arrays: see k_gemm_nt_f32)
+  const int prow = tid >> 5, pc = (tid & 31) * 4;     // chunk p = it * 256 + tid: row it * 8 + prow
   auto gload = [&](int kt) {
     const int mrow0 = mbeg + kt * 16;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int p = it * 256 + tid, row = p >> 5, c = p & 31;
-      rx[it] = *(const float4*)(X + (size_t)(mrow0 + row) * ldx + c0 + c * 4);
-      rg[it] = *(const float4*)(G + (size_t)(mrow0 + row) * ldg + n0 + c * 4);
-    }
+    rx0 = *(const float4*)(X + (size_t)(mrow0 + prow) * ldx + c0 + pc);
+    rx1 = *(const float4*)(X + (size_t)(mrow0 + 8 + prow) * ldx + c0 + pc);
+    rg0 = *(const float4*)(G + (size_t)(mrow0 + prow) * ldg + n0 + pc);
+    rg1 = *(const float4*)(G + (size_t)(mrow0 + 8 + prow) * ldg + n0 + pc);
   };
   auto lstore = [&](int buf) {
     float* lx = lds + buf * 2 * 16 * GF_TPITCH;
     float* lg = lx + 16 * GF_TPITCH;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int p = it * 256 + tid, row = p >> 5, c = p & 31;
-      *(float4*)(lx + row * GF_TPITCH + c * 4) = rx[it];
-      *(float4*)(lg + row * GF_TPITCH + c * 4) = rg[it];
-    }
+    *(float4*)(lx + prow * GF_TPITCH + pc) = rx0;
+    *(float4*)(lx + (8 + prow) * GF_TPITCH + pc) = rx1;
+    *(float4*)(lg + prow * GF_TPITCH + pc) = rg0;
+    *(float4*)(lg + (8 + prow) * GF_TPITCH + pc) = rg1;
   };
   f32x4_t acc[4][4];
 #pragma unroll

@@ -173,6 +173,8 @@ __global__ __launch_bounds__(256 * WM, 2) void k_mlp256_tail_fwd(const MlpTail P
 
 }  // namespace
 
+extern "C" int hugs_mlp256_tail_max_layers(void) { return MF_MAXL; }
+
 // include/hugs.h hugs_mlp256_tail_fwd
 extern "C" int hugs_mlp256_tail_fwd(int dtype, int M, int nl, const void* Y0, const void* const* Wt, const float* const* bias,
                                     void* const* Y, uint32_t* const* bits, const float* wd, const float* bd, float density_bias,

@@ -649,8 +649,10 @@ __global__ __launch_bounds__(256) void k_nf_prop_fwd(long long M, int in_dim, in
   }
 }
 
+// (KP = 32 -- rows of 17..32 features, no shipped config -- holds x, dx and two 32-wide accumulator rows per lane: one workgroup
+//  per CU, i.e. the whole register file, instead of 25 spilled registers at two)
 template <int BF16, int KP>
-__global__ __launch_bounds__(256, 2) void k_nf_prop_bwd(long long M, int in_dim, int H, const void* __restrict__ X, int ldx,
+__global__ __launch_bounds__(256, KP == 32 ? 1 : 2) void k_nf_prop_bwd(long long M, int in_dim, int H, const void* __restrict__ X, int ldx,
                                                         const float* __restrict__ W0, int ldw0, const float* __restrict__ b0,
                                                         const float* __restrict__ w1, int ldw1, const float* __restrict__ raw,
                                                         const float* __restrict__ sel, const float* __restrict__ d_density,

@@ -302,10 +302,15 @@ class Engine:
     TrainState whose buffer `theta` is (the train step's own refresh), None for any other caller."""
     self._cast_src = None if owner is None else (owner.gen, theta.data_ptr(), theta._version)
     self.weights_stale = False
-    tab = getattr(self, '_cast_table', None)
-    if tab is None or tab[0] != theta.data_ptr():
+    if not hasattr(self, '_cast_tables'):
+      self._cast_tables = {}
+    tab = self._cast_tables.get(theta.data_ptr())
+    if tab is None:
       # one 40-byte record per GEMM operand pair (include/hugs.h hugs_cast_weights_batch): device ADDRESSES only, a pure
-      # function of (buffer address, layout) -- rebuilt when the master buffer moves
+      # function of (buffer address, layout).  ONE table per master-buffer address, kept for the life of the engine: a captured
+      # train step has the table's address baked into its hipGraph, so a refresh on another buffer (Model.apply on a clone or a
+      # loaded checkpoint between steps) must neither free nor rewrite the table the graph reads (ADVICE r4).  The two eager
+      # steps in front of a capture build the table of the state's buffer, so no H2D copy happens inside the capture.
       rec, blk = [], 0
       for lf in self.layout.leaves:
         if lf['path'][-1] != 'kernel' or lf['layer']['kind'] not in ('trunk', 'bottleneck', 'view', 'tview', 'ttrunk'):
@@ -328,7 +333,7 @@ class Engine:
         raw[i, :3] = (pw, pn, pt)
         raw[i, 3:].view(np.int32)[:4] = (K, N, b0, nbx)
       tab = (theta.data_ptr(), torch.from_numpy(raw).to(self.device), len(rec), blk)
-      self._cast_table = tab
+      self._cast_tables[theta.data_ptr()] = tab
     _lib.call('hugs_cast_weights_batch', self.dt, tab[2], tab[1], tab[3])
     if _HEAD_FOLD:
       # P [Wp, H] = W_b [Wp, Bw] W_v[:Bw] [Bw, H]: the trunk's output gradient is (G_view W_v[:Bw]^T) W_b^T = G_view P^T, one
@@ -358,7 +363,8 @@ class Engine:
     """True when the operand copies were cast for this very TrainState (its process-unique generation number: a new
     state that inherits a freed buffer's address and version count is NOT current) and torch has not written to its
     buffer since (load_variables / restore_checkpoint bump the tensor version; Model.apply on any variables resets the
-    record).  The step's own Adam kernel writes through the raw pointer and refreshes the copies itself."""
+    record).  The step's own Adam kernel writes through the raw pointer: `optimizer_step` then sets `weights_stale` and the NEXT
+    step (or the next `forward` / `backward_level` / `mask_forward` call) re-casts -- nothing refreshes at the end of a step."""
     return self._cast_src is not None and self._cast_src == (state.gen, state.flat.data_ptr(), state.flat._version)
 
   # ---- forward ------------------------------------------------------------------------------------
@@ -398,7 +404,7 @@ class Engine:
     # 24 vs 45 us at 16 384 rows -- the launch-bound regime of small per-GPU batches --, 81 vs 67 us at 65 536, 1.05 vs 0.85 ms at
     # 1 M rows, where the per-layer launches already run at the HBM rate and the fused kernel's phases do not overlap well enough)
     fuse_tail = (dt == 1 and nchunk == 1 and W == 256 and spec.net_width == 256 and spec.net_depth >= 2 and M % 256 == 0 and
-                 M <= _MLP_FUSE_ROWS and not any(l['concat'] for l in spec.layers[1:spec.net_depth]))
+                 spec.net_depth - 1 <= int(_lib.lib().cdll.hugs_mlp256_tail_max_layers()) and M <= _MLP_FUSE_ROWS and not any(l['concat'] for l in spec.layers[1:spec.net_depth]))
     for c in range(nchunk):
       rows = slice(c * mc, (c + 1) * mc)
       x = X0[rows]
@@ -672,6 +678,7 @@ class Engine:
     range grad[lo:hi] is final (the heads once, then one trunk layer at a time): the data-parallel step starts that
     bucket's all-reduce there, underneath the rest of the backward pass."""
     spec, S, lay, ws, dt = lv['spec'], lv['S'], self.layout, self.ws, self.dt
+    self._require_fresh_weights()
     M = N * S
     tag = f'{spec.name}/bwd'
     W = spec.Wp
@@ -985,6 +992,8 @@ class Engine:
   def mask_forward(self, theta, rays, N, zero_tra=False):
     """renderings[-1]['implicit_mask'] (models.py:327-328).  Returns the state mask_backward needs."""
     spec, lay, ws, dt = self.model.mask_spec, self.layout, self.ws, self.dt
+    if getattr(self, 'weights_stale', False):      # (a caller that drives the engine directly after an optimizer step)
+      self.refresh_weights(theta)
     Np = _round_up(N, 128)
     tra = None
     if not zero_tra:
@@ -1037,6 +1046,13 @@ class Engine:
                   None, dX0, spec.kpad)
         _lib.call('hugs_embed_scatter_add', dt, N, spec.T, dX0, spec.kpad, spec.E, rays['embed_idx'],
                   gview(('TransientEmbed_0', 'embedding')))
+
+  def _require_fresh_weights(self):
+    """backward_level reads the operand copies (wn, wfold) the forward of the SAME step used: an optimizer step in between means
+    the caller mixed two parameter versions."""
+    if getattr(self, 'weights_stale', False):
+      raise _lib.HugsError('the operand copies of the weights are stale (an optimizer step has moved the masters since the last '
+                           'forward): call Engine.forward / refresh_weights first')
 
   def _side_stream(self, lane=0):
     """HIP streams next to the caller's: lane 0 carries the weight-gradient GEMMs of the NerfMLP backward (and the

@@ -157,8 +157,9 @@ def uncovered_ranges(layout, covered, total):
     todo[-1][1] = total
   elif layout.size < total:
     todo.append([layout.size, total])
-  for lo, hi in todo:      # what is reduced here must not overlap anything a bucket already reduced
-    assert not any(c0 < hi and lo < c1 for c0, c1 in cov), (lo, hi, cov)
+  for lo, hi in todo:      # what is reduced here must not overlap anything a bucket already reduced (a second SUM of a leaf)
+    if any(c0 < hi and lo < c1 for c0, c1 in cov):
+      raise RuntimeError(f'all-reduce ranges overlap: [{lo}, {hi}) against the buckets {cov}')
   return [tuple(t) for t in todo]
 
 
@@ -197,8 +198,10 @@ def create_train_step(model, config, is_finetune=False):
     """The second half of the reference's train_step on a gradient buffer in the flat layout
     (train_utils.py:461-473): grad_norms / grad_maxes, clip_gradients per module (value clip, then norm clip with
     `eps + norm`), nan_to_num, Adam (optax.adam: bias-corrected moments, eps outside the sqrt, schedule at the
-    0-based count), opt_update_* stats, refresh of the compute-dtype weight copies.  `gscale`: factor the kernels
-    apply to the buffer first (1/world after a SUM all-reduce).  Returns the per-leaf stat buffer."""
+    0-based count), opt_update_* stats.  The compute-dtype operand copies are NOT re-cast here: the step marks them stale
+    (`eng.weights_stale`) and the next step / `Engine.forward` / `mask_forward` re-casts first thing; `backward_level` raises on
+    stale copies.  `gscale`: factor the kernels apply to the buffer first (1/world after a SUM all-reduce).  Returns the per-leaf
+    stat buffer."""
     eng = model.engine(state.flat.device)
     ws = eng.ws
     nch, nleaf, nmod = layout.chunks.shape[0], len(layout.leaves), len(layout.modules)
@@ -301,6 +304,7 @@ def create_train_step(model, config, is_finetune=False):
       step0 = state.step
       eng.capture_lanes = _GRAPH_LANES
       _engine.KEEP_EVENTS = []
+      ok = False
       try:
         with torch.cuda.graph(g, stream=cap, capture_error_mode='thread_local'):
           key_out = step_core(state, ent['rays'], ent['gt'], N, ent['key'], train_frac, None, ent['dyn'], False)
@@ -311,11 +315,14 @@ def create_train_step(model, config, is_finetune=False):
         if world > 1:
           with torch.cuda.graph(g2, stream=cap, capture_error_mode='thread_local'):
             packed = step_finish(state, ent['dyn'])
+        ok = True
       finally:
         eng.capture_lanes = None
         ent['events'], _engine.KEEP_EVENTS = _engine.KEEP_EVENTS, None
+        state.step = step0          # (the capture ran the host side of the step once without executing anything)
+        if not ok:                  # a failed capture leaves no half-built entry behind: the next call starts over (eagerly)
+          graphs.pop(sig, None)
       torch.cuda.current_stream().wait_stream(cap)
-      state.step = step0            # (the capture ran the host side of the step once without executing anything)
       ent['graph'], ent['graph_opt'], ent['packed'] = g, g2, packed
     ent['graph'].replay()
     if ent['graph_opt'] is not None:      # pmean(grad), pmean(stats) (train_utils.py:457-459): one SUM over the whole buffer + stat tail
@@ -324,7 +331,9 @@ def create_train_step(model, config, is_finetune=False):
     state.step += 1
     eng._cast_src = None          # (the replayed Adam update has moved the masters; the next step re-casts first thing)
     eng.weights_stale = True
-    return state, LazyStats(ent['packed'], stats_builder(state)), (ent['key'] if ent['key'] is not None else rng)
+    # the advanced key is handed back as a fresh tensor, as the eager path does: ent['key'] is overwritten by every replay, and a
+    # caller that keeps an earlier key (a checkpoint of the rng, an eval stream) must not see it change
+    return state, LazyStats(ent['packed'], stats_builder(state)), (ent['key'].clone() if ent['key'] is not None else rng)
 
   def step_core(state, rays, gt, N, rng, train_frac, inlier_thresholds, dyn, reduce):
     """The first part of the step: forward, losses, backward and -- when `reduce` -- the all-reduces of the gradient buffer

@@ -300,7 +300,9 @@ class NerfactoModel:
       return False
     (K0, N0), (_, N1), (Kh, H) = (self.lay.items[k][1] for k in ('field/w0', 'field/w1', 'field/c0'))
     return (self.lay.items['field/w0'][2][0] <= 32 and N0 == 256 and N1 == 128 and Kh == 128 and H == 256 and
-            self.lay.items['field/c1'][1] == (256, 256) and c.geo_feat_dim % 4 == 0 and 16 + c.geo_feat_dim + self.napp <= 128)
+            self.lay.items['field/c1'][1] == (256, 256) and 16 + c.geo_feat_dim + self.napp <= 128 and
+            # (the backward kernel's shape class, hugs_nf_field_bwd: a forward it cannot differentiate must not be taken)
+            c.geo_feat_dim % 8 == 0 and self.napp % 4 == 0 and self.napp <= 64)
 
   # ---- GEMM helpers ---------------------------------------------------------------------------------------------------
   def _bits_ok(self, M, width, k):

@@ -7,11 +7,18 @@ reference lines it follows (paths under /root/reference/MipNeRF360/).  Gradients
 come from torch.autograd, i.e. they are independent of the hand-written HIP
 backward kernels they check.
 
-Pinned against tests/golden/ref_leaves.npz (the reference's own leaf modules
-executed under a numpy stand-in for jax) by tests/test_oracle_vs_reference.py.
-models.py / train_utils.py cannot be imported in the build container (flax, gin,
-optax missing): layer order, loss normalisers, clip and Adam below are restated
-from the cited lines and are "parity unpinned" beyond that.
+Pinned twice: (i) against tests/golden/ref_leaves.npz -- the
+reference's own leaf modules internal/{math,stepfun,render,coord,geopoly}.py
+executed under a numpy stand-in for jax -- by tests/test_oracle_vs_reference.py;
+(ii) against tests/golden/ref_model.npz -- the reference's internal/models.py and
+internal/train_utils.py themselves, executed unmodified under bookkeeping
+stand-ins for flax.linen / gin / optax (tests/golden/gen_model_fixtures.py):
+Model.__call__ outputs at every level, every inverse-CDF index, loss terms,
+clip_gradients, train_step stats and float64 finite differences of the
+reference's own loss_fn -- by tests/test_oracle_vs_reference_model.py.
+What stays "parity unpinned": third-party arithmetic that is not in
+/root/reference or this image (optax.adam, flax initialisers, XLA's float32
+summation order); Adam below follows optax's published formula.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
 """
