@@ -502,6 +502,20 @@ def main():
     state, stats, gen = train_step(gen, state, next_batch(), 0.5, thr)
   host_ms = (time.perf_counter() - t0) / 8 * 1e3
   torch.cuda.synchronize()
+  # N > 1: the part of the gradient exchange the backward pass does not hide (events on the compute stream around the point
+  # where the step waits for its all-reduces; train_utils.AR_PROFILE), over 10 extra untimed steps -- so that a SCALE run
+  # explains itself: ms_per_step(N) - ms_per_step(1) should be about this number
+  ar_exposed = None
+  if world > 1:
+    train_utils.AR_PROFILE = []
+    for _ in range(10):
+      state, stats, gen = train_step(gen, state, next_batch(), 0.5, thr)
+    torch.cuda.synchronize()
+    evs, train_utils.AR_PROFILE = train_utils.AR_PROFILE, None
+    if evs:
+      t_ = torch.tensor([float(np.mean([a.elapsed_time(b) for a, b in evs]))], device=device, dtype=torch.float64)
+      dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+      ar_exposed = round(float(t_.item()), 4)
   roof = None
   if args.dtype == 'bf16' and args.config in ('cfg2', 'ref360'):
     # after the timed region: a few more steps with the GEMM launches bracketed by HIP events (every rank runs them:
@@ -537,6 +551,10 @@ def main():
         "step_mfma_frac": (round(rps / world * (FLOP_TRAIN_PER_RAY_REF360 if args.config == 'ref360' else FLOP_TRAIN_PER_RAY) /
                                  (PEAK_BF16 if args.dtype == 'bf16' else 157.3e12), 4) if args.config in ('cfg2', 'ref360') else None),
     }
+    if world > 1:
+      line["allreduce_exposed_ms_per_step"] = ar_exposed
+      line["allreduce_form"] = ("two hipGraphs around one eager all-reduce" if line["step_graph"] else
+                                ("bucketed, issued under the backward pass" if os.environ.get('HUGS_AR_BUCKETS', '1') != '0' else "one all-reduce after the backward pass"))
     if roof is not None:
       line["roofline"] = roof
       line["instep_kernels"] = roof_others

@@ -244,6 +244,18 @@ __device__ __forceinline__ uint32_t pk_relu_bf16(uint32_t u) {
   const i16x2_t r = __builtin_elementwise_max(*(const i16x2_t*)&u, z);
   return *(const uint32_t*)&r;
 }
+typedef unsigned short __attribute__((ext_vector_type(2))) u16x2_t;
+// min(half, 1) of both 16-bit halves: ONE v_pk_min_u16 (the inline constant 1 feeds both halves: op_sel_hi 0 on it).  Written as
+// asm: from __builtin_elementwise_min the compiler makes two compares, two selects and a v_perm per pair.
+__device__ __forceinline__ uint32_t pk_min1_u16(uint32_t a) {
+  uint32_t r;
+  asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(r) : "v"(a));
+  return r;
+}
+__device__ __forceinline__ uint32_t pk_mul_u16(uint32_t a, uint32_t b) {
+  const u16x2_t r = *(const u16x2_t*)&a * *(const u16x2_t*)&b;
+  return *(const uint32_t*)&r;
+}
 typedef float __attribute__((ext_vector_type(2))) f32x2_t;
 typedef hugs_op_t __attribute__((ext_vector_type(2))) bf16x2_t;
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {      // one v_cvt_pk_bf16_f32
@@ -300,6 +312,8 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
     const bool hi8 = (r16 & 8) != 0;
     const int srow = r16 & 7;                                            // row (within the 16-row group) of store A; B = +8
     const int ccol = n0 + wn * 64 + (kb & 1) * 16 + (kb >> 1) * 8 + (hi8 ? 32 : 0);
+    char* const out_base = (char*)E.out + ((size_t)(m0 + wm * 128) * (size_t)E.ldc + (size_t)(n0 + wn * 64)) * 2;
+    const unsigned out_voff = (unsigned)(srow * E.ldc + (ccol - n0 - wn * 64)) * 2u;
     // relu-mask chunks (same whole-line geometry as the stores), fetched MASK_AHEAD fragment rows ahead of their use: all 16
     // in flight at once would cost 64 registers on top of the 128 accumulators (the persistent kernel, whose loader state is live
     // across the epilogue, affords one row ahead: with two its bf16-mask specialisations spilled 2-3 registers)
@@ -330,16 +344,21 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
         u.x = cvt_pk_bf16(x[0], x[1]); u.y = cvt_pk_bf16(x[2], x[3]);
         if (has_relu) { u.x = pk_relu_bf16(u.x); u.y = pk_relu_bf16(u.y); }
         const int k = (i & 1) * 8 + j * 2;
-        if (has_bin) {      // 0x00010001 * 0xffff = 0xffffffff, 0x1 * 0xffff = low half, 0x10000 * 0xffff = high half
+        if (has_bin) {      // each 16-bit half times its bit (v_pk_mul_lo_u16): 3 instructions per packed pair (round 5; was 4)
           const uint32_t t = bin[i >> 1] >> k;
-          u.x &= (t & 0x00010001u) * 0xffffu;
-          u.y &= ((t >> 1) & 0x00010001u) * 0xffffu;
+          u.x = pk_mul_u16(u.x, t & 0x00010001u);
+          u.y = pk_mul_u16(u.y, (t >> 1) & 0x00010001u);
         }
         pk[j][0] = u.x; pk[j][1] = u.y;
-        if (has_bout) {     // value > 0 <=> half != 0 once the relu cleared the negatives: half + 0x7fff carries into bit 15
-          const uint32_t ax = has_relu ? u.x : (u.x & 0x7fff7fffu), ay = has_relu ? u.y : (u.y & 0x7fff7fffu);
-          bw |= ((ax + 0x7fff7fffu) >> (15 - k)) & (0x00010001u << k);
-          bw |= ((ay + 0x7fff7fffu) >> (14 - k)) & (0x00010001u << (k + 1));
+        if (has_bout) {
+          if (has_relu) {   // the relu left every half in [0, 0x7fff]: min(half, 1) IS the bit (v_pk_min_u16), one v_lshl_or_b32 files it
+            bw |= pk_min1_u16(u.x) << k;
+            bw |= pk_min1_u16(u.y) << (k + 1);
+          } else {          // (unreachable through the C ABI: bits_out requires a relu epilogue) magnitude != 0: half + 0x7fff carries into bit 15
+            const uint32_t ax = u.x & 0x7fff7fffu, ay = u.y & 0x7fff7fffu;
+            bw |= ((ax + 0x7fff7fffu) >> (15 - k)) & (0x00010001u << k);
+            bw |= ((ay + 0x7fff7fffu) >> (14 - k)) & (0x00010001u << (k + 1));
+          }
         }
       }
       if (has_bout && (i & 1)) { E.bits_out[bits_at + (i >> 1) * 64] = bw; bw = 0u; }
@@ -375,8 +394,12 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
         // streaming (nontemporal) stores: the 32 MB all workgroups write at the same time do not push the operand panels
         // out of the 4 MB L2s (in-step A/B: step -1.8 %, forward layer 264 -> 254 us; explicit sc0 / sc1 / nt policy
         // bits measured within noise of it)
+        // address = (wave-uniform 64-bit base of row block (i, h): scalar arithmetic) + (ONE per-lane 32-bit byte offset, the same for
+        // all 16 stores): the store takes the SGPR-base form and costs no vector address arithmetic (round 5: ~50 of the epilogue's
+        // ~540 vector instructions were 64-bit per-lane address computations)
         { typedef unsigned __attribute__((ext_vector_type(4))) u32x4_t; const u32x4_t v_ = {vw[0], vw[1], vw[2], vw[3]};
-          u32x4_t* p_ = (u32x4_t*)((uint16_t*)E.out + (size_t)(m0 + wm * 128 + i * 16 + h * 8 + srow) * E.ldc + ccol);
+          char* rb_ = out_base + (size_t)(i * 16 + h * 8) * (size_t)E.ldc * 2;
+          u32x4_t* p_ = (u32x4_t*)(rb_ + out_voff);
           HUGS_EPI_STORE(v_, p_);
         }
       }

@@ -20,6 +20,10 @@ from . import random as hrandom
 from . import utils
 
 _STATE_GEN = __import__('itertools').count(1)
+# bench.py --gpus N: when a list, every data-parallel step appends (event, event) recorded on the compute stream around the point
+# where it waits for its gradient all-reduces: the elapsed time between the two is the part of the exchange that the backward
+# pass did NOT hide (the stream has nothing else to do there)
+AR_PROFILE = None
 STAT_TAIL = 64  # floats appended to the gradient buffer for the per-step scalars that get pmean'ed (<= 7 levels)
 
 
@@ -326,7 +330,12 @@ def create_train_step(model, config, is_finetune=False):
       ent['graph'], ent['graph_opt'], ent['packed'] = g, g2, packed
     ent['graph'].replay()
     if ent['graph_opt'] is not None:      # pmean(grad), pmean(stats) (train_utils.py:457-459): one SUM over the whole buffer + stat tail
+      if AR_PROFILE is not None:
+        e0_ = torch.cuda.Event(enable_timing=True); e0_.record()
       dist.all_reduce(eng.ws.get('grad', (layout.size + STAT_TAIL,)), op=dist.ReduceOp.SUM)
+      if AR_PROFILE is not None:
+        e1_ = torch.cuda.Event(enable_timing=True); e1_.record()
+        AR_PROFILE.append((e0_, e1_))
       ent['graph_opt'].replay()
     state.step += 1
     eng._cast_src = None          # (the replayed Adam update has moved the masters; the next step re-casts first thing)
@@ -551,10 +560,15 @@ def create_train_step(model, config, is_finetune=False):
     # ---- pmean(grad), pmean(stats) ------------------------------------------------------------------
     if world > 1 and reduce:
       # whatever no bucket covered (PropMLP, embeddings, ImplicitMask, the stat tail; everything in the finetune stage)
+      if AR_PROFILE is not None:
+        e0_ = torch.cuda.Event(enable_timing=True); e0_.record()
       for lo, hi in uncovered_ranges(layout, ar_ranges, grad.numel()):
         ar_works.append(dist.all_reduce(grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
       for w in ar_works:
         w.wait()
+      if AR_PROFILE is not None:
+        e1_ = torch.cuda.Event(enable_timing=True); e1_.record()
+        AR_PROFILE.append((e0_, e1_))
     return rng
 
   def step_finish(state, dyn):

@@ -22,3 +22,9 @@ errs, stats, ostats = _step_and_replay(ginb, 'bf16', quant=True)
 big = {k: v for k, v in errs.items() if v[2] >= 1024}
 show('bf16 full width vs bf16-rounded oracle (leaves >= 1024 entries)', big, stats, ostats)
 show('bf16 full width vs bf16-rounded oracle (all leaves)', errs, stats, ostats)
+
+# round 5: full width at 256 rays in fp32 with replayed masks; bf16 with the encoder inside the comparison
+show('fp32 FULL WIDTH (8x1024 + 4x256), 256 rays, ReLU decisions replayed, no ray masked', *_step_and_replay(ginb, 'fp32', n_patch=4, P=8))
+errs, stats, ostats = _step_and_replay(ginb, 'bf16', quant=True, replay_feats=False)
+show('bf16 full width, oracle computes its own IPE features (encoder inside; leaves >= 1024 entries)', {k: v for k, v in errs.items() if v[2] >= 1024}, stats, ostats)
+show('bf16 full width, oracle computes its own IPE features (all leaves)', errs, stats, ostats)

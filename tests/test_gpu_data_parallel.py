@@ -106,3 +106,31 @@ def test_two_rank_step_equals_single_process_rccl(tmp_path):
   """The same equality through backend 'nccl' (= RCCL over xGMI): the async all-reduce of the NerfMLP gradient
   segment overlapping the proposal backward, the side-stream dW GEMMs and RCCL's own stream in one step."""
   _compare(tmp_path, GIN, 'nccl')
+
+
+def test_bench_two_ranks_on_one_gpu_prints_the_contract_line():
+  """bench.py's N > 1 path end to end as the driver launches it (torch.distributed.run, one rank per process), two ranks on ONE
+  GPU over gloo (HUGS_FORCE_DEVICE / HUGS_DIST_BACKEND test hooks): exactly one JSON line from rank 0 with the contract's keys,
+  whole-job rays/s, and -- round 5 -- the exposed all-reduce time next to it."""
+  import json
+  import os
+  import socket
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  env = dict(os.environ, HUGS_FORCE_DEVICE='0', HUGS_DIST_BACKEND='gloo')
+  out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '3',
+                        '--min-time', '0', '--batch-pool', '4'], capture_output=True, text=True, env=env, timeout=600, cwd=root)
+  assert out.returncode == 0, out.stderr[-3000:]
+  lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1, out.stdout[-2000:]
+  d = json.loads(lines[0])
+  for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+            'data', 'config', 'fixed_batch', 'allreduce_exposed_ms_per_step', 'allreduce_form'):
+    assert k in d, k
+  assert d['n_gpus'] == 2 and d['steps'] == 4 and d['scaling'] == 'weak' and d['config']['global_batch'] == 2048
+  assert abs(d['value'] - 2048 * 4 / (d['ms_per_step'] * 4 * 1e-3)) < 1e-3 * d['value']      # whole-job rays/s
+  assert d['allreduce_exposed_ms_per_step'] is not None and d['allreduce_exposed_ms_per_step'] >= 0
+  assert 'cpu_baseline' not in d      # rank 0 at N = 1 only
