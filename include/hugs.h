@@ -100,6 +100,14 @@ int hugs_mlp256_tail_max_layers(void);      /* the nl cap of hugs_mlp256_tail_fw
 int hugs_mlp256_tail_fwd(int dtype, int M, int nl, const void* Y0, const void* const* Wt, const float* const* bias,
                          void* const* Y, uint32_t* const* bits, const float* wd, const float* bd, float density_bias, float* raw,
                          float* density, void* stream);
+/* Backward twin of hugs_mlp256_tail_fwd for nl == 3 (the reference's PropMLP, models.py:451-456,467 with disable_rgb; what
+ * jax.value_and_grad derives, train_utils.py:454): G3 = (d_raw (x) wd) * (Y3 > 0), G_{l-1} = (G_l W_l^T) * (Y_{l-1} > 0) for l = 3, 2, 1 in
+ * ONE launch with the three operand copies Wn[l-1] ([256 (fan_in)][256 (fan_out)] bf16) resident in registers.  bits[0..3]: the 1-bit
+ * relu masks of Y0 .. Y3 as hugs_gemm_nt_bits / hugs_mlp256_tail_fwd wrote them; G[0..3]: the outputs G0 .. G3 [M,256] bf16 (the G
+ * operands of the weight-gradient GEMMs).  Wn / bits / G are HOST arrays of device pointers; M a multiple of 256, dtype 1 (bf16).
+ * Replaces hugs_rank1_mask + three masked hugs_gemm_nt_bits launches. */
+int hugs_mlp256_tail_bwd(int dtype, int M, int nl, const float* d_raw, const float* wd, const void* const* Wn,
+                         const uint32_t* const* bits, void* const* G, void* stream);
 /* models.py:456 raw_density = Dense(1)(x)[...,0]; :467 density = softplus(raw + density_bias) */
 int hugs_density_fwd(int dtype, int M, int K, const void* Y, int ldy, const float* w, const float* b,
                      float density_bias, float* raw, float* density, void* stream);

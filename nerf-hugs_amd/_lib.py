@@ -21,6 +21,7 @@ _PROTOS = {
     'hugs_gemm_tn_batch_nsplit': 'ip',
     'hugs_density_fwd': 'iiipippfpps',
     'hugs_mlp256_tail_fwd': 'iiipppppppfpps',
+    'hugs_mlp256_tail_bwd': 'iiippppps',
     'hugs_density_bwd': 'iiipippfpppps',
     'hugs_rank1_mask': 'iiipppipis',
     'hugs_glo_gather': 'iippips',

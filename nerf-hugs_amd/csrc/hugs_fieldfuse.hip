@@ -44,11 +44,12 @@ __device__ __forceinline__ uint32_t ff_relu_pk(uint32_t u) {
   return __builtin_bit_cast(uint32_t, r);
 }
 // 1 in each 16-bit half that is not zero (relu outputs: positive or +0): v_pk_min_u16 with 1 -- bits 0 and 16, the mask layout's pair
+// (as inline asm -- round 5: from __builtin_elementwise_min the compiler made two 16-bit compares, two selects and a v_perm per
+//  pair, ~300 vector instructions per tile of the forward kernel; the inline constant 1 feeds both halves through op_sel_hi 0)
 __device__ __forceinline__ uint32_t ff_nz_pk(uint32_t u) {
-  typedef unsigned short __attribute__((ext_vector_type(2))) us2;
-  const us2 one = {1, 1};
-  const us2 r = __builtin_elementwise_min(__builtin_bit_cast(us2, u), one);
-  return __builtin_bit_cast(uint32_t, r);
+  uint32_t r;
+  asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(r) : "v"(u));
+  return r;
 }
 template <int F16> __device__ __forceinline__ uint32_t ff_cvt_pk(float a, float b) {       // one v_cvt_pk_{bf16,f16}_f32 (RNE)
   const ff_f32x2_t f = {a, b};

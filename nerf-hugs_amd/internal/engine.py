@@ -20,6 +20,7 @@ _TN_BATCH = int(__import__('os').environ.get('HUGS_TN_BATCH', '1'))
 _DW_AFTER_PROP = __import__('os').environ.get('HUGS_DW_AFTER_PROP', '1') == '1'
 # G_last through the folded matrix P = W_bottleneck W_view[:Bw] (one K = 128 GEMM on the critical chain instead of two; A/B switch)
 _MLP_FUSE_ROWS = int(__import__('os').environ.get('HUGS_MLP_FUSE_ROWS', '32768'))      # 0: never fuse the 256-wide trunk tail
+_MLP_CHAIN3 = __import__('os').environ.get('HUGS_MLPFUSE_CHAIN3', '1') != '0'      # (the library reads the same switch)
 _HEAD_FOLD = __import__('os').environ.get('HUGS_HEAD_FOLD', '1') == '1'
 _SIDE_LATE = __import__('os').environ.get('HUGS_SIDE_LATE', '0') == '1'      # A/B: side-stream work released behind the G_last GEMM
 _TN_ITEM = np.dtype([('X', np.uint64), ('G', np.uint64), ('dW', np.uint64), ('db', np.uint64), ('ldx', np.int32), ('ldg', np.int32),
@@ -403,8 +404,12 @@ class Engine:
     # (hugs_mlp256_tail_fwd), where it is faster than the per-layer GEMMs: up to _MLP_FUSE_ROWS rows (stand-alone, 3 layers + head:
     # 24 vs 45 us at 16 384 rows -- the launch-bound regime of small per-GPU batches --, 81 vs 67 us at 65 536, 1.05 vs 0.85 ms at
     # 1 M rows, where the per-layer launches already run at the HBM rate and the fused kernel's phases do not overlap well enough)
+    # Round 5: exactly three fused layers with their mask bits (the reference's PropMLP, depth 4) run the register-resident kernel
+    # (k_mlp256_chain3_fwd: the 384 KB of weights loaded once per CU) at every size -- no row cap
+    chain3 = _MLP_CHAIN3 and _MLP_FUSE_ROWS > 0 and spec.net_depth == 4 and all(b is not None for b in bits[1:])
     fuse_tail = (dt == 1 and nchunk == 1 and W == 256 and spec.net_width == 256 and spec.net_depth >= 2 and M % 256 == 0 and
-                 spec.net_depth - 1 <= int(_lib.lib().cdll.hugs_mlp256_tail_max_layers()) and M <= _MLP_FUSE_ROWS and not any(l['concat'] for l in spec.layers[1:spec.net_depth]))
+                 spec.net_depth - 1 <= int(_lib.lib().cdll.hugs_mlp256_tail_max_layers()) and (M <= _MLP_FUSE_ROWS or chain3) and
+                 not any(l['concat'] for l in spec.layers[1:spec.net_depth]))
     for c in range(nchunk):
       rows = slice(c * mc, (c + 1) * mc)
       x = X0[rows]
@@ -722,7 +727,15 @@ class Engine:
     wd = lay.view(theta, (spec.name, ld['name'], 'kernel'), padded=True).reshape(-1)
     Ga = ws.get(tag + '/Ga', (M, W), self.tdt)
     Gb = ws.get(tag + '/Gb', (M, W), self.tdt)
-    if spec.disable_rgb:
+    # Round 5: the proposal MLP's dX chain (rank-1 head gradient + three masked dX GEMMs) as ONE launch with register-resident
+    # weights (hugs_mlp256_tail_bwd) when the forward wrote all four layers' mask bits
+    bits_all = lv.get('bits') or []
+    fused_bwd = (_MLP_CHAIN3 and _MLP_FUSE_ROWS > 0 and dt == 1 and spec.disable_rgb and W == 256 and spec.net_width == 256 and
+                 spec.net_depth == 4 and M % 256 == 0 and len(bits_all) == 4 and all(b is not None for b in bits_all) and
+                 not any(l['concat'] for l in spec.layers[:4]) and _TN_BATCH > 0 and spec.Fp % 256 == 0 and M >= 2048)
+    if fused_bwd:
+      pass          # (G3 .. G0 are written by the fused launch in the trunk section below)
+    elif spec.disable_rgb:
       _lib.call('hugs_rank1_mask', dt, M, W, d_raw, wd, Ylast, W, Ga, W)
     elif not spec.use_viewdirs:
       # G_last = (d_rgb W_rgb^T + d_raw (x) w_d) * (Ylast > 0): the rgb head's own backward (its G is already masked) + the
@@ -848,9 +861,17 @@ class Engine:
       # (two launches -- the upper half under the lower half's dX GEMMs -- measured: 6.80 ms against 6.61 for one launch and
       # 6.83 for the per-layer form, same box: what is lost is the concurrency itself.  The data-parallel step therefore keeps
       # ONE launch as well and releases the whole trunk's gradient range to its all-reduce behind it.)
-      two = _TN_BATCH == 2
+      two = _TN_BATCH == 2 and not fused_bwd
       cuts = [depth // 2, 0] if (two and depth >= 2) else [0]
       Gs = [Ga, Gb] + [ws.get(f'{tag}/G{k}', (M, W), self.tdt) for k in range(2, depth)]
+      if fused_bwd:
+        key = ('mlp_tail_bwd', tag, theta.data_ptr(), M)
+        tab = ws.bufs.get(key)
+        if tab is None:      # host arrays of device pointers (a function of buffer addresses only)
+          ptr = lambda ts: np.ascontiguousarray([t.data_ptr() for t in ts], np.uint64)
+          tab = ws.bufs[key] = (ptr([self.wn[(spec.name, trunk[i]['name'], 'kernel')] for i in (1, 2, 3)]), ptr(bits_all),
+                                ptr([Gs[3], Gs[2], Gs[1], Gs[0]]))      # G_l of layer l lives in Gs[depth - 1 - l]
+        _lib.call('hugs_mlp256_tail_bwd', dt, M, 3, d_raw, wd, tab[0].ctypes.data, tab[1].ctypes.data, tab[2].ctypes.data)
       g_of, hi = {}, depth - 1
       done = []
       for i in range(depth - 1, -1, -1):
@@ -886,7 +907,7 @@ class Engine:
               lb_ = lay.by_path[(spec.name, trunk[hi]['name'], 'bias')]
               leaf_done(lk['off'], lb_['off'] + int(np.prod(lb_['pshape'])))
           hi = i - 1
-        if i > 0:
+        if i > 0 and not fused_bwd:
           bprev = lv['bits'][i - 1] if lv.get('bits') else None
           Wn_ = self.wn[path][:W] if l['concat'] else self.wn[path]
           if bprev is not None:

@@ -287,7 +287,7 @@ def test_allreduce_leftover_ranges_cover_every_leaf():
   # a bucket that cuts a leaf in half does not count as covering it -- and reducing the whole leaf on top of the half bucket
   # would double-count: that is refused loudly
   k0 = kernels[0]
-  with pytest.raises(AssertionError):
+  with pytest.raises(RuntimeError):
     check([(k0[0], (k0[0] + k0[1]) // 2)] + kernels[1:])
   configs.clear_config()
 

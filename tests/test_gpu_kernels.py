@@ -500,3 +500,55 @@ def test_mlp256_tail_fused_forward_vs_layer_by_layer(M, nl):
   r = Y[-1].double() @ wd.double() + bd.double()
   np.testing.assert_allclose(raw.cpu().numpy(), r.cpu().numpy(), rtol=2e-5, atol=2e-5)
   np.testing.assert_allclose(dens.cpu().numpy(), torch.nn.functional.softplus(r - 1.0).cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize('M', [256, 1280, 66560])
+def test_mlp256_tail_fused_backward_vs_layer_by_layer(M):
+  """hugs_mlp256_tail_bwd (round 5: the PropMLP's dX chain -- rank-1 head gradient + three masked dX products -- in one launch with
+  register-resident weights) against (i) the float64 chain on the same bf16 operands with every G_l re-rounded to bf16 as the
+  stored gradient is and (ii) the launches it replaces (hugs_rank1_mask + hugs_gemm_nt_bits x 3), with the masks the fused FORWARD
+  kernel wrote."""
+  L = _L()
+  g = torch.Generator(device=dev).manual_seed(M + 7)
+  rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+  Y0f = rn(M, 256)
+  Y0 = Y0f.clamp(min=0).bfloat16()
+  bits0 = torch.zeros(M * 256 // 32, dtype=torch.int32, device=dev)
+  # Y0 and its mask bits the way the step makes them: a relu GEMM that writes bits (identity-like product of a random input)
+  X = rn(M, 256).bfloat16()
+  W0 = (rn(256, 256) * (2.0 / 256)**0.5).bfloat16()
+  L.call('hugs_gemm_nt_bits', 1, M, 256, 256, 0, X, 256, None, 0, W0, 256, torch.zeros(256, device=dev), 1, None, None, Y0, 256, bits0, None)
+  Wt = [(rn(256, 256) * (2.0 / 256)**0.5).bfloat16() for _ in range(3)]      # [out, in]
+  Wn = [w.t().contiguous() for w in Wt]                                       # [in, out]: the dX operand copies
+  bias = [rn(256) * 0.1 for _ in range(3)]
+  wd, bd = rn(256) * 0.1, rn(1)
+  Y = [torch.empty(M, 256, device=dev, dtype=torch.bfloat16) for _ in range(3)]
+  bits = [torch.zeros(M * 256 // 32, dtype=torch.int32, device=dev) for _ in range(3)]
+  raw, dens = torch.empty(M, device=dev), torch.empty(M, device=dev)
+  ptrs = lambda ts: np.ascontiguousarray([t.data_ptr() for t in ts], np.uint64)
+  a_w, a_b, a_y, a_bits = ptrs(Wt), ptrs(bias), ptrs(Y), ptrs(bits)
+  L.call('hugs_mlp256_tail_fwd', 1, M, 3, Y0, a_w.ctypes.data, a_b.ctypes.data, a_y.ctypes.data, a_bits.ctypes.data, wd, bd, -1.0, raw, dens)
+  d_raw = rn(M) * 0.3
+  G = [torch.empty(M, 256, device=dev, dtype=torch.bfloat16) for _ in range(4)]
+  a_wn, a_allbits, a_g = ptrs(Wn), ptrs([bits0] + bits), ptrs(G)
+  L.call('hugs_mlp256_tail_bwd', 1, M, 3, d_raw, wd, a_wn.ctypes.data, a_allbits.ctypes.data, a_g.ctypes.data)
+  torch.cuda.synchronize()
+  acts = [Y0] + Y
+  # (i) float64 chain
+  ref = (d_raw.double()[:, None] * wd.double()[None]).float().bfloat16().double() * (acts[3].double() > 0)
+  assert float((G[3].double() - ref).abs().max()) <= 1e-2 * max(1e-6, float(ref.abs().max()))
+  for l in (3, 2, 1):
+    x = G[l].double()      # the next product reads the bf16-rounded gradient
+    ref = (x @ Wt[l - 1].double()) * (acts[l - 1].double() > 0)
+    assert float((G[l - 1].double() - ref).abs().max()) <= 1e-2 * max(1e-6, float(ref.abs().max())), l
+  # (ii) the launches it replaces
+  Gu = [torch.empty(M, 256, device=dev, dtype=torch.bfloat16) for _ in range(4)]
+  L.call('hugs_rank1_mask', 1, M, 256, d_raw, wd, acts[3], 256, Gu[3], 256)
+  allbits = [bits0] + bits
+  for l in (3, 2, 1):
+    L.call('hugs_gemm_nt_bits', 1, M, 256, 256, 0, Gu[l], 256, None, 0, Wn[l - 1], 256, None, 0, None, None, Gu[l - 1], 256, None, allbits[l - 1])
+  torch.cuda.synchronize()
+  assert torch.equal(G[3], Gu[3])
+  for l in (2, 1, 0):      # (different accumulation order: equal to a bf16 ulp of the largest entry)
+    assert float((G[l].double() - Gu[l].double()).abs().max()) <= 8e-3 * float(Gu[l].double().abs().max()), l
+  assert float(G[0].double().abs().max()) > 0
