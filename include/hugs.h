@@ -203,6 +203,11 @@ int hugs_opt_adam_dyn(int nchunks, int nleaf, const void* chunks, const void* le
                       float* m, float* v, const float* mod_scale, const int* trainable, float gscale, float max_val,
                       const float* dyn, float b1, float b2, float eps, float* part2_ws, float* leaf_upd, void* stream);
 int hugs_set_floats(float* dst, int n, float a, float b, float c, float d, void* stream);
+/* One launch in front of a replayed (captured) train step (train_utils.py:386-477's inputs: rays, batch.rgb, rng; train_frac through
+ * the scalars): item i copies words[i] 4-byte words src[i] -> dst[i] (n <= 16; HOST arrays of device pointers), dst_f[0..nf) =
+ * {a, b, c, d}[0..nf) as hugs_set_floats. */
+int hugs_stage_step(int n, const void* const* src, void* const* dst, const int* words, float* dst_f, int nf, float a, float b, float c,
+                    float d, void* stream);
 /* fp32 master [K,N] -> compute-dtype copies Wn [K,N] and Wt [N,K] (either may be NULL) */
 int hugs_cast_weights(int dtype, int K, int N, const float* W, void* Wn, void* Wt, void* stream);
 /* The same cast for a device table of matrices in one launch.  items: nitems records of 40 bytes

@@ -45,6 +45,7 @@ _PROTOS = {
     'hugs_opt_adam': 'iippppppppffffffffpps',
     'hugs_opt_adam_dyn': 'iippppppppffpfffpps',
     'hugs_set_floats': 'piffffs',
+    'hugs_stage_step': 'ippppiffffs',
     'hugs_level_sample_fwd_dyn': 'ippiifffpfppiiiipppps',
     'hugs_cast_weights': 'iiippps',
     'hugs_cast_weights_batch': 'iipis',

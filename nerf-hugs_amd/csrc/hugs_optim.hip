@@ -253,6 +253,42 @@ extern "C" int hugs_set_floats(float* dst, int n, float a, float b, float c, flo
   return 0;
 }
 
+// One launch in front of a replayed (captured) step: the step's inputs -- up to 16 flat buffers of 4-byte words (ray fields, target
+// colours, the jax key) -- are copied into the buffers the graph was captured on, and the per-step scalars go into dst_f[0..nf).
+// The source ADDRESSES change from step to step (whatever batch the caller hands over), so they travel as kernel arguments.
+struct StageItems { const uint32_t* src[16]; uint32_t* dst[16]; int words[16]; int n; };
+__global__ __launch_bounds__(256) void k_stage_step(StageItems S, float* dst_f, int nf, float a, float b, float c, float d) {
+  const int it = blockIdx.y;
+  if (it == S.n) {      // (the extra row of blocks: the scalars)
+    const float v[4] = {a, b, c, d};
+    if (blockIdx.x == 0 && (int)threadIdx.x < nf) dst_f[threadIdx.x] = v[threadIdx.x];
+    return;
+  }
+  const uint32_t* __restrict__ s_ = S.src[it];
+  uint32_t* __restrict__ d_ = S.dst[it];
+  const int n = S.words[it];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) d_[i] = s_[i];
+}
+// include/hugs.h hugs_stage_step: src / dst are HOST arrays of n device pointers, words[i] = 4-byte words of item i
+extern "C" int hugs_stage_step(int n, const void* const* src, void* const* dst, const int* words, float* dst_f, int nf, float a, float b,
+                               float c, float d, void* stream) {
+  HUGS_REQUIRE(n >= 0 && n <= 16 && nf >= 0 && nf <= 4 && (n == 0 || (src && dst && words)) && (nf == 0 || dst_f), -2,
+               "hugs_stage_step: %d items (<= 16), %d scalars (<= 4)", n, nf);
+  StageItems S;
+  S.n = n;
+  int mx = 1;
+  for (int i = 0; i < 16; ++i) {
+    S.src[i] = i < n ? (const uint32_t*)src[i] : nullptr; S.dst[i] = i < n ? (uint32_t*)dst[i] : nullptr; S.words[i] = i < n ? words[i] : 0;
+    HUGS_REQUIRE(i >= n || (S.src[i] && S.dst[i] && S.words[i] >= 0), -2, "hugs_stage_step: item %d", i);
+    if (S.words[i] > mx) mx = S.words[i];
+  }
+  int gx = (mx + 1023) / 1024;
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(k_stage_step, dim3(gx, n + 1), dim3(256), 0, (hipStream_t)stream, S, dst_f, nf, a, b, c, d);
+  HUGS_CHECK_LAUNCH("hugs_stage_step");
+  return 0;
+}
+
 extern "C" int hugs_cast_weights_batch(int dtype, int nitems, const void* items, int total_blocks, void* stream) {
   if (nitems <= 0 || total_blocks <= 0) return 0;
   if (dtype == 2) hipLaunchKernelGGL(k_cast_weights_batch<2>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, nitems, (const CastItem*)items);

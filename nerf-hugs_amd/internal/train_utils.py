@@ -293,13 +293,20 @@ def create_train_step(model, config, is_finetune=False):
     names = list(rays)      # (the engine adds derived entries -- 'dir_enc' -- to the dict it is handed: they are not inputs)
     srcs = [rays[k] for k in names if rays[k].data_ptr() != ent['rays'][k].data_ptr()] + ([gt] if gt.data_ptr() != ent['gt'].data_ptr() else [])
     dsts = [ent['rays'][k] for k in names if rays[k].data_ptr() != ent['rays'][k].data_ptr()] + ([ent['gt']] if gt.data_ptr() != ent['gt'].data_ptr() else [])
-    for dt_ in (torch.float32, torch.int32):
-      d_ = [d for d in dsts if d.dtype == dt_]
-      if d_:
-        torch._foreach_copy_(d_, [s_ for s_ in srcs if s_.dtype == dt_])
     if ent['key'] is not None and rng.data_ptr() != ent['key'].data_ptr():
-      ent['key'].copy_(rng)
-    _lib.call('hugs_set_floats', ent['dyn'], 4, *step_scalars(state, train_frac))
+      srcs.append(rng.contiguous()); dsts.append(ent['key'])
+    # ONE launch: every input copy (all of them 4-byte element types) + the step's four scalars (round 5; it was two
+    # _foreach_copy_ launches, a key copy and hugs_set_floats: ~40 us of launch latency in front of a 1.3 ms step at 128 rays)
+    if len(srcs) <= 16 and all(s_.element_size() == 4 and s_.is_contiguous() and s_.numel() == d_.numel() for s_, d_ in zip(srcs, dsts)):
+      tb = ent.setdefault('stage_tab', (np.zeros(16, np.uint64), np.zeros(16, np.uint64), np.zeros(16, np.int32)))
+      for i_, (s_, d_) in enumerate(zip(srcs, dsts)):
+        tb[0][i_], tb[1][i_], tb[2][i_] = s_.data_ptr(), d_.data_ptr(), s_.numel()
+      _lib.call('hugs_stage_step', len(srcs), tb[0].ctypes.data, tb[1].ctypes.data, tb[2].ctypes.data, ent['dyn'], 4,
+                *step_scalars(state, train_frac))
+    else:
+      for s_, d_ in zip(srcs, dsts):
+        d_.copy_(s_)
+      _lib.call('hugs_set_floats', ent['dyn'], 4, *step_scalars(state, train_frac))
     if 'graph' not in ent:
       world = _world()
       g, g2 = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if world > 1 else None)
@@ -397,7 +404,11 @@ def create_train_step(model, config, is_finetune=False):
 
     grad = ws.get('grad', (layout.size + STAT_TAIL,))
     tail = grad[layout.size:]
-    tail.zero_()
+    # the stat tail is zeroed ONCE per step function: every slot a step uses is overwritten (=, never +=) by its loss kernels on
+    # every step, the slots it does not use stay zero (their all-reduce sums zeros) -- one launch less per step
+    if cache.get('tail_zeroed') != tail.data_ptr():
+      tail.zero_()
+      cache['tail_zeroed'] = tail.data_ptr()
     # ---- losses -------------------------------------------------------------------------------------
     if 'coef' not in cache:
       cache['coef'] = torch.tensor([config.data_coarse_loss_mult] * (L - 1) + [config.data_loss_mult],
