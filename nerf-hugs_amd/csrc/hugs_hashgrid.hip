@@ -214,37 +214,44 @@ k_hashgrid_bwd(int n, int L, HgLevels lv, const float* __restrict__ x, const voi
   }
 }
 
-// Level 0 in LDS.  The coarsest level (16^3 cells: 4913 entries) receives every sample's gradient in a few thousand
+// Coarse levels in LDS.  The coarsest level (16^3 cells: 4913 entries) receives every sample's gradient in a few thousand
 // addresses: the most contended -- and, per level, the most expensive -- part of the global scatter.  Here a persistent
-// workgroup accumulates it in a private LDS copy of the level (ds_add_f32; runs of lanes in one cell are summed first, as in
+// workgroup accumulates the level in a private LDS copy (ds_add_f32; runs of lanes in one cell are summed first, as in
 // the global kernel) and adds the copy to the table once at the end: neighbouring lanes, neighbouring floats, so 16 floats per
-// atomic transaction.  Used when the level is dense and fits HG_L0_MAX_FLOATS.
+// atomic transaction.  Round 5: any dense level that fits -- CAP = 12288 floats (48 KiB, 256 threads, three workgroups per CU: level
+// 0) or CAP = 39936 floats (156 KiB, 1024 threads, one workgroup per CU: level 1 of the yml's field grid, 23^3 x 2 floats = 95 KiB,
+// and of its second proposal grid, 26^3 x 2 = 137 KiB); `l` = the level, its gradient columns are l*F .. l*F + F - 1 of d_out.
 #define HG_L0_MAX_FLOATS 12288      // 48 KiB
-template <int F, int BF16>
-__global__ void __launch_bounds__(256)
-k_hashgrid_bwd_l0(int n, HgLevels lv, const float* __restrict__ x, const void* __restrict__ d_out, int row_pitch,
-                  float* __restrict__ d_table) {
-  __shared__ float acc[HG_L0_MAX_FLOATS];
-  const uint32_t res = lv.res[0], entries = lv.off[1] - lv.off[0];
+#define HG_L1_MAX_FLOATS 39936      // 156 KiB
+template <int F, int BF16, int CAP, int NT>
+__global__ void __launch_bounds__(NT)
+k_hashgrid_bwd_lds(int n, int l, HgLevels lv, const float* __restrict__ x, const void* __restrict__ d_out, int row_pitch,
+                   float* __restrict__ d_table) {
+  __shared__ float acc[CAP];
+  const uint32_t res = lv.res[l], entries = lv.off[l + 1] - lv.off[l];
   const int nfl = (int)entries * F;
-  for (int e = threadIdx.x; e < nfl; e += 256) acc[e] = 0.f;
+  for (int e = threadIdx.x; e < nfl; e += NT) acc[e] = 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  const float sc = lv.scale[0];
-  const int ntile = (n + 255) / 256;
+  const float sc = lv.scale[l];
+  const int ntile = (n + NT - 1) / NT;
   for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
-    const int i = t * 256 + threadIdx.x;
+    const int i = t * NT + threadIdx.x;
     const bool live = i < n;
     const int ii = live ? i : n - 1;
+    float g[F];
+    bool gnz = false;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      g[f] = !live ? 0.f : BF16 ? op16_to_f(((const uint16_t*)d_out)[(size_t)ii * row_pitch + l * F + f], BF16)
+                                : ((const float*)d_out)[(size_t)ii * row_pitch + l * F + f];
+      gnz |= g[f] != 0.f;
+    }
+    if (__ballot(gnz) == 0ull) continue;      // (a wave without gradient at this level: see k_hashgrid_bwd)
     const float fx = fmaf(x[3 * ii], sc, .5f), fy = fmaf(x[3 * ii + 1], sc, .5f), fz = fmaf(x[3 * ii + 2], sc, .5f);
     const float gx = floorf(fx), gy = floorf(fy), gz = floorf(fz);
     const float wx = fx - gx, wy = fy - gy, wz = fz - gz;
     const uint32_t cx = (uint32_t)(int)gx, cy = (uint32_t)(int)gy, cz = (uint32_t)(int)gz;
-    float g[F];
-#pragma unroll
-    for (int f = 0; f < F; ++f)
-      g[f] = !live ? 0.f : BF16 ? op16_to_f(((const uint16_t*)d_out)[(size_t)ii * row_pitch + f], BF16)
-                                : ((const float*)d_out)[(size_t)ii * row_pitch + f];
     float v[8][F];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -286,8 +293,8 @@ k_hashgrid_bwd_l0(int n, HgLevels lv, const float* __restrict__ x, const void* _
     }
   }
   __syncthreads();
-  float* tb = d_table + (size_t)lv.off[0] * F;
-  for (int e = threadIdx.x; e < nfl; e += 256) {
+  float* tb = d_table + (size_t)lv.off[l] * F;
+  for (int e = threadIdx.x; e < nfl; e += NT) {
     const float a = acc[e];
     if (a != 0.f) atomicAdd(tb + e, a);
   }
@@ -465,20 +472,38 @@ extern "C" int hugs_hashgrid_bwd(int n, int n_levels, int features, const long l
   if (n <= 0) return 0;
   const dim3 g((n + 255) / 256), b(256);
   hipStream_t st = (hipStream_t)stream;
-  // level 0 through LDS when it is dense and small (see k_hashgrid_bwd_l0); the global kernel then starts at level 1
-  const unsigned long long r0 = (unsigned long long)lv.res[0];
-  const unsigned e0 = lv.off[1] - lv.off[0];
+  // the coarse levels through LDS while they are dense and fit (see k_hashgrid_bwd_lds); the global kernel starts behind them.
+  // HUGS_HG_LDS_LEVELS = 0 / 1 / 2 (default 2): none / level 0 only (round 3) / every level that fits 156 KiB (round 5)
+  static const int lds_levels = []() { const char* e = getenv("HUGS_HG_LDS_LEVELS"); return e ? atoi(e) : 2; }();
+  int dev = 0, ncu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) ncu = 256;
   int l_begin = 0;
-  if (r0 * r0 * r0 <= e0 && (long long)e0 * features <= HG_L0_MAX_FLOATS && n >= 65536) {
-    const int g0 = (int)(((n + 255) / 256) < 768 ? ((n + 255) / 256) : 768);
-    if (features == 2) {
-      HG_BY_DTYPE(d_out_bf16, k_hashgrid_bwd_l0, 2, <<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum));
+  while (l_begin < n_levels && n >= 65536) {
+    const unsigned long long r = (unsigned long long)lv.res[l_begin];
+    const unsigned e = lv.off[l_begin + 1] - lv.off[l_begin];
+    const long long fl = (long long)e * features;
+    if (r * r * r > e) break;                                  // hashed: not a private copy's job
+    if (fl <= HG_L0_MAX_FLOATS && lds_levels >= 1) {
+      const int g0 = (int)(((n + 255) / 256) < 3 * ncu ? ((n + 255) / 256) : 3 * ncu);
+#define HG_LDS_SMALL(F_) do { if (d_out_bf16 == 2) k_hashgrid_bwd_lds<F_, 2, HG_L0_MAX_FLOATS, 256><<<g0, 256, 0, st>>>(n, l_begin, lv, x01, d_out, row_pitch, d_table_accum); \
+        else if (d_out_bf16) k_hashgrid_bwd_lds<F_, 1, HG_L0_MAX_FLOATS, 256><<<g0, 256, 0, st>>>(n, l_begin, lv, x01, d_out, row_pitch, d_table_accum); \
+        else k_hashgrid_bwd_lds<F_, 0, HG_L0_MAX_FLOATS, 256><<<g0, 256, 0, st>>>(n, l_begin, lv, x01, d_out, row_pitch, d_table_accum); } while (0)
+      if (features == 2) HG_LDS_SMALL(2); else HG_LDS_SMALL(4);
+#undef HG_LDS_SMALL
+    } else if (fl <= HG_L1_MAX_FLOATS && lds_levels >= 2) {
+      const int g1 = (int)(((n + 1023) / 1024) < ncu ? ((n + 1023) / 1024) : ncu);
+#define HG_LDS_BIG(F_) do { if (d_out_bf16 == 2) k_hashgrid_bwd_lds<F_, 2, HG_L1_MAX_FLOATS, 1024><<<g1, 1024, 0, st>>>(n, l_begin, lv, x01, d_out, row_pitch, d_table_accum); \
+        else if (d_out_bf16) k_hashgrid_bwd_lds<F_, 1, HG_L1_MAX_FLOATS, 1024><<<g1, 1024, 0, st>>>(n, l_begin, lv, x01, d_out, row_pitch, d_table_accum); \
+        else k_hashgrid_bwd_lds<F_, 0, HG_L1_MAX_FLOATS, 1024><<<g1, 1024, 0, st>>>(n, l_begin, lv, x01, d_out, row_pitch, d_table_accum); } while (0)
+      if (features == 2) HG_LDS_BIG(2); else HG_LDS_BIG(4);
+#undef HG_LDS_BIG
     } else {
-      HG_BY_DTYPE(d_out_bf16, k_hashgrid_bwd_l0, 4, <<<g0, b, 0, st>>>(n, lv, x01, d_out, row_pitch, d_table_accum));
+      break;
     }
-    l_begin = 1;
-    if (n_levels == 1) { HUGS_CHECK_LAUNCH("k_hashgrid_bwd_l0"); return 0; }
+    HUGS_CHECK_LAUNCH("k_hashgrid_bwd_lds");
+    ++l_begin;
   }
+  if (l_begin >= n_levels) return 0;
   if (features == 2) {
     HG_BY_DTYPE(d_out_bf16, k_hashgrid_bwd, 2, <<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin));
   } else {

@@ -71,6 +71,7 @@ class MLPSpec:
     self.bottleneck_width = 256
     self.net_depth_viewdirs = 1
     self.net_width_viewdirs = 128
+    self.skip_layer_dir = 4
     self.min_deg_point = 0
     self.max_deg_point = 12
     self.skip_layer = 4
@@ -122,6 +123,8 @@ class MLPSpec:
       L.append(dict(fan_in=k, kpad=kp, fan_out=self.bottleneck_width, kind='bottleneck'))
       kv = self.bottleneck_width + self.nd + self.num_glo
       L.append(dict(fan_in=kv, kpad=kv, fan_out=self.net_width_viewdirs, kind='view'))
+      for _ in range(1, self.net_depth_viewdirs):      # models.py:508-512: further Dense(net_width_viewdirs) + relu layers (round 5)
+        L.append(dict(fan_in=self.net_width_viewdirs, kpad=self.net_width_viewdirs, fan_out=self.net_width_viewdirs, kind='vtrunk'))
       L.append(dict(fan_in=self.net_width_viewdirs, kpad=self.net_width_viewdirs, fan_out=self.num_rgb_channels, kind='rgb'))
     self.t0 = len(L)          # index of the first transient layer (flax creates them after the rgb head, models.py:521-539)
     if self.num_tra > 0:
@@ -136,6 +139,11 @@ class MLPSpec:
       l['name'] = f'Dense_{i}'
     self.layers = L
 
+  def head_layers(self):
+    """(bottleneck, view, [further view layers], rgb) of an MLP with the view branch."""
+    nd, dv = self.net_depth, self.net_depth_viewdirs
+    return self.layers[nd + 1], self.layers[nd + 2], self.layers[nd + 3:nd + 2 + dv], self.layers[nd + 2 + dv]
+
   def _check(self):
     d = self.net_depth
     if (d - 1) > 0 and (d - 1) % self.skip_layer == 0:
@@ -146,8 +154,13 @@ class MLPSpec:
       raise NotImplementedError('bottleneck_width must be a multiple of 128 and net_width_viewdirs == 128 (MFMA tiles)')
     if self.net_width % 128 and self.net_depth > self.skip_layer + 1:
       raise NotImplementedError('a trunk width that is not a multiple of 128 together with a skip concat is not built')
-    if self.net_depth_viewdirs != 1 or self.num_rgb_channels != 3:
-      raise NotImplementedError('net_depth_viewdirs != 1 / num_rgb_channels != 3 are not built')
+    if self.num_rgb_channels != 3:
+      raise NotImplementedError('num_rgb_channels != 3 is not built')
+    if self.net_depth_viewdirs < 1 or self.net_depth_viewdirs > self.skip_layer_dir:
+      # models.py:511: x = concat(x, inputs) after view layer i when i % skip_layer_dir == 0 and i > 0, i.e. from depth skip_layer_dir + 1
+      raise NotImplementedError('1 <= net_depth_viewdirs <= skip_layer_dir (the view MLP\'s skip concat is not built)')
+    if self.net_depth_viewdirs > 1 and (not self.use_viewdirs or self.disable_rgb):
+      pass      # (no view MLP is created: models.py:486)
     if not 0 <= self.min_deg_point < self.max_deg_point:
       raise ValueError(f'min_deg_point {self.min_deg_point} / max_deg_point {self.max_deg_point}')
     if self.num_tra > 0 and (self.disable_rgb or self.net_width_transient != 128 or self.net_depth_transient < 2 or
@@ -314,7 +327,7 @@ class Engine:
       # steps in front of a capture build the table of the state's buffer, so no H2D copy happens inside the capture.
       rec, blk = [], 0
       for lf in self.layout.leaves:
-        if lf['path'][-1] != 'kernel' or lf['layer']['kind'] not in ('trunk', 'bottleneck', 'view', 'tview', 'ttrunk'):
+        if lf['path'][-1] != 'kernel' or lf['layer']['kind'] not in ('trunk', 'bottleneck', 'view', 'vtrunk', 'tview', 'ttrunk'):
           continue
         l = lf['layer']
         W = self.layout.view(theta, lf['path'], padded=True)
@@ -468,7 +481,7 @@ class Engine:
       _lib.call('hugs_rgb_fwd', dt, M, W, x, W, Wr, br, spec.rgb_padding, rgb)
       out.update(bott=None, hview=None, rgb=rgb)
     elif not spec.disable_rgb:
-      lb, lv, lr = spec.layers[spec.net_depth + 1:spec.net_depth + 4]
+      lb, lv, lvx, lr = spec.head_layers()
       Bw, H = spec.bottleneck_width, spec.net_width_viewdirs
       bott = ws.get(tag + '/bott', (M, Bw), self.tdt)
       _lib.call('hugs_gemm_nt', dt, M, Bw, W, 0, x, W, None, 0, self.wt[(spec.name, lb['name'], 'kernel')], W,
@@ -484,10 +497,17 @@ class Engine:
       hact = ws.get(tag + '/hview', (M, H), self.tdt)
       _lib.call('hugs_gemm_nt', dt, M, H, Bw, 0, bott, Bw, None, 0, self.wt[(spec.name, lv['name'], 'kernel')], Bw, None, rb,
                 S, H, 1, None, 0, None, None, hact, H)
+      hviews = [hact]
+      for k_, lx in enumerate(lvx):      # net_depth_viewdirs > 1 (models.py:508-512): Dense(H) + relu on the view branch
+        hn = ws.get(f'{tag}/hview{k_ + 1}', (M, H), self.tdt)
+        _lib.call('hugs_gemm_nt', dt, M, H, H, 0, hviews[-1], H, None, 0, self.wt[(spec.name, lx['name'], 'kernel')], H,
+                  lay.view(theta, (spec.name, lx['name'], 'bias')), None, 1, 0, 1, None, 0, None, None, hn, H)
+        hviews.append(hn)
+      hact = hviews[-1]
       rgb = ws.get(tag + '/rgb', (M, 3))
       Wr, br = self._rgb_head(theta, spec, lr, tag + '/rgbhead')
       _lib.call('hugs_rgb_fwd', dt, M, H, hact, H, Wr, br, spec.rgb_padding, rgb)
-      out.update(bott=bott, hview=hact, rgb=rgb)
+      out.update(bott=bott, hview=hact, hviews=hviews, rgb=rgb)
       if spec.num_tra > 0 and tra is not None:
         # models.py:521-539: x = [bottleneck | tra_vec] -> (Dense+relu) x depth_t -> density_t, rgb_t, uncertainty.
         # The tra_vec part of the first layer is constant along a ray: a per-ray bias, like the view layer's.
@@ -751,7 +771,7 @@ class Engine:
       _lib.call('hugs_rank1_mask', dt, M, W, d_raw, wd, Ylast, W, Gb, W)
       Ga.add_(Gb)
     else:
-      lb, lvw, lr = spec.layers[spec.net_depth + 1:spec.net_depth + 4]
+      lb, lvw, lvx, lr = spec.head_layers()
       Bw, H = spec.bottleneck_width, spec.net_width_viewdirs
       Gv = ws.get(tag + '/Gview', (M, H), self.tdt)
       rws = ws.get(tag + '/rgb_ws', (max(_lib.lib().cdll.hugs_rgb_bwd_ws_bytes() // 4, 1),))
@@ -762,6 +782,16 @@ class Engine:
       if spec.rgb_premultiplier != 1.:
         gview((spec.name, lr['name'], 'kernel')).mul_(float(spec.rgb_premultiplier))
         gview((spec.name, lr['name'], 'bias')).mul_(float(spec.rgb_premultiplier))
+      # net_depth_viewdirs > 1: back through the further view layers, last to first -- dW_i = h_{i-1}^T G_i, db_i = colsum G_i,
+      # G_{i-1} = (G_i W_i^T) * (h_{i-1} > 0); Gv ends up as the gradient at the FIRST view layer's pre-activation, as below expects
+      hvs = lv.get('hviews') or [lv['hview']]
+      for k_ in range(len(lvx) - 1, -1, -1):
+        lx = lvx[k_]
+        px = (spec.name, lx['name'], 'kernel')
+        self._tn(M, H, H, hvs[k_], H, Gv, H, gview(px), gview((spec.name, lx['name'], 'bias')))
+        Gp = ws.get(f'{tag}/Gview_{k_ & 1}', (M, H), self.tdt)
+        _lib.call('hugs_gemm_nt', dt, M, H, H, 0, Gv, H, None, 0, self.wn[px], H, None, None, 1, 0, 0, hvs[k_], H, None, None, Gp, H)
+        Gv = Gp
       gWv = gview((spec.name, lvw['name'], 'kernel'))
       Wv = lay.view(theta, (spec.name, lvw['name'], 'kernel'))
       d_rb = ws.get(tag + '/d_rb', (int(_lib.lib().cdll.hugs_raybias_bwd_ws_rows(N, spec.nd, spec.num_glo)), H))

@@ -338,6 +338,7 @@ class ModelCfg:
     self.prop_disable_rgb = False
     self.bottleneck_width = 256
     self.width_viewdirs = 128
+    self.depth_viewdirs = 1                                  # models.py:365 net_depth_viewdirs (skip_layer_dir = 4 never triggers for <= 4)
     self.skip_layer = 4
     self.max_deg_point = 12
     self.basis_shape = 'icosahedron'
@@ -404,6 +405,8 @@ def mlp_layer_dims(cfg, which):
     dims.append((k, cfg.bottleneck_width))              # bottleneck
     kv = cfg.bottleneck_width + 3 + 3 * 2 * cfg.deg_view + (cfg.num_glo_features if which == 'nerf' else 0)
     dims.append((kv, cfg.width_viewdirs))
+    for _ in range(getattr(cfg, 'depth_viewdirs', 1) - 1):       # models.py:508-512: further Dense(net_width_viewdirs) + relu layers
+      dims.append((cfg.width_viewdirs, cfg.width_viewdirs))
     dims.append((cfg.width_viewdirs, 3))
     if which == 'nerf' and cfg.transient_type == 'nerfw':        # models.py:521-539, created after the rgb head
       k = cfg.bottleneck_width + cfg.num_transient_features
@@ -524,14 +527,22 @@ def mlp_forward(cfg, mod, which, feats, viewdirs, glo_vec, taps=None, tra_vec=No
   if taps is not None:
     taps.append(pre.detach())
   x = q(_relu(pre, masks))
-  L = mod[f'Dense_{depth + 3}']
+  Dv = getattr(cfg, 'depth_viewdirs', 1)
+  assert 1 <= Dv <= 4, 'models.py:511: the skip concat of the view MLP (i % skip_layer_dir == 0 and i > 0) starts at depth 5'
+  for i in range(1, Dv):                                           # models.py:508-512, i >= 1
+    L = mod[f'Dense_{depth + 2 + i}']
+    pre = x @ q(L['kernel']) + L['bias']
+    if taps is not None:
+      taps.append(pre.detach())
+    x = q(_relu(pre, masks))
+  L = mod[f'Dense_{depth + 2 + Dv}']
   rgb = torch.sigmoid(cfg.rgb_premultiplier * (x @ L['kernel'] + L['bias']) + cfg.rgb_bias)      # models.py:514-516
   rgb = rgb * (1 + 2 * cfg.rgb_padding) - cfg.rgb_padding
   if tra_vec is None or which != 'nerf' or cfg.transient_type != 'nerfw':
     return density, rgb
   # models.py:521-539 (skip_layer_transient = 4 never triggers for depth 4)
   x = torch.cat([bott, tra_vec[..., None, :].expand(bott.shape[:-1] + (-1,))], -1)
-  j = depth + 4
+  j = depth + 3 + Dv
   for i in range(cfg.transient_depth):
     pre = x @ mod[f'Dense_{j + i}']['kernel'] + mod[f'Dense_{j + i}']['bias']
     if taps is not None:

@@ -62,6 +62,7 @@ def make_pair(gin_lines, seed=3, compute_dtype='fp32'):
   cfg.weight_decay_mults = dict(config.weight_decay_mults or {})
   cfg.disable_integration = bool(model.disable_integration)
   cfg.use_viewdirs = bool(model.use_viewdirs)
+  cfg.depth_viewdirs = int(model.nerf_spec.net_depth_viewdirs)
   cfg.min_deg_point = int(model.nerf_spec.min_deg_point)
   cfg.rgb_premultiplier, cfg.rgb_bias = float(model.nerf_spec.rgb_premultiplier), float(model.nerf_spec.rgb_bias)
   if model.mask_spec is not None:

@@ -24,8 +24,9 @@ def _hip_masks_samples_feats(model, levels, N):
     spec, S = lv['spec'], lv['S']
     W, F = spec.net_width, spec.F
     m = [(lv['acts'][i + 1][:, :W].float() > 0).cpu().reshape(N, S, W) for i in range(spec.net_depth)]
-    if lv.get('hview') is not None:
-      m.append((lv['hview'].float() > 0).cpu().reshape(N, S, -1))
+    if lv.get('hview') is not None:      # the view layer, then the further view layers of net_depth_viewdirs > 1
+      for h in (lv.get('hviews') or [lv['hview']]):
+        m.append((h.float() > 0).cpu().reshape(N, S, -1))
     masks.append(m)
     ov.append((lv['sdist'].cpu().clone(), lv['tdist'].cpu().clone()))
     ofe.append(lv['X0'][:, :F].float().cpu().reshape(N, S, F))
@@ -63,7 +64,7 @@ def _step_and_replay(gin, compute_dtype, n_patch=1, P=8, near=0.1, far=1.2, quan
   return out, stats, ostats
 
 
-@pytest.mark.parametrize('variant', ['base2', 'default3_charb_contract_glo', 'withmask_glo48', 'robustnerf'])
+@pytest.mark.parametrize('variant', ['base2', 'default3_charb_contract_glo', 'withmask_glo48', 'robustnerf', 'view_depth3_glo'])
 def test_whole_step_gradient_every_leaf_with_replayed_relu_masks(variant):
   gin, kw = list(SMALL), {}
   if variant == 'default3_charb_contract_glo':
@@ -75,6 +76,8 @@ def test_whole_step_gradient_every_leaf_with_replayed_relu_masks(variant):
   elif variant == 'withmask_glo48':
     gin = [g for g in SMALL if 'data_loss_type' not in g] + ["Config.transient_type = 'withmask'", "Model.num_glo_features = 48"]
     kw = dict(n_patch=2)
+  elif variant == 'view_depth3_glo':      # round 5: NerfMLP.net_depth_viewdirs > 1 (models.py:508-512)
+    gin = list(SMALL) + ["NerfMLP.net_depth_viewdirs = 3", "Model.num_glo_features = 4"]
   elif variant == 'robustnerf':
     gin = [g.replace('patch_size = 8', 'patch_size = 16') for g in SMALL] + [
         "Config.transient_type = 'robustnerf'", "Config.robustnerf_inlier_quantile = 0.8"]
