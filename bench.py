@@ -298,7 +298,7 @@ def bench_nerfacto(args, device, world, rank):
 
   def step():
     nonlocal res
-    res = model.train_step(batch, u01=draws(), world=world)
+    res = model.train_step(batch, u01=draws(), world=world)      # (`model` is rebound for the second measurement below)
   for _ in range(args.warmup):
     step()
 
@@ -325,6 +325,19 @@ def bench_nerfacto(args, device, world, rank):
     wins.append(window())
   dt = float(np.median(wins))
   kernels = nerfacto_roofline(model, step, N) if world == 1 else None
+  # the same step with the grid-input gradients stored in 16 bits (what rounds 3-4 timed: in the half mode scaled gradients below
+  # 6e-8 flush to zero there and skip their table atomics) -- a second model, a quarter of the timed budget
+  half_grad = None
+  if world == 1 and model.dt and model.grid_grad_f32:
+    m_main = model
+    model = NerfactoModel(NerfactoConfig(**CFG5), device=device, compute_dtype=args.dtype, seed=20200823, grid_grad_f32=False)
+    for _ in range(args.warmup):
+      step()
+    w2 = [window() for _ in range(max(2, len(wins) // 4))]
+    half_grad = {"ms_per_step": round(float(np.median(w2)) / args.steps * 1e3, 3), "value": round(N * args.steps / float(np.median(w2)), 1),
+                 "note": "HUGS_NF_GRID_GRAD_F32=0: the fused kernels' feature gradients rounded to the 16-bit operand type before the table scatter"}
+    model = m_main
+    step(); torch.cuda.synchronize()      # (`res` below is the main model's again)
   if rank == 0:
     st = res['stats'].cpu().numpy()
     extra = {"loss_scale_last": model.loss_scale()} if model.amp else {}
@@ -335,6 +348,9 @@ def bench_nerfacto(args, device, world, rank):
             "config": {"workload": "configs[4] restatement: nerfacto hash-grid fields (phototourism_nerfacto_base.yml sizes), "
                                    "16384 rays/GPU, full train step", "params": int(model.flat.numel()), "parallelism": f"dp{world}"},
             "loss_rgb_last": round(float(st[1]), 6), **extra}
+    line["grid_input_gradient"] = "fp32" if (model.dt and model.grid_grad_f32) else ("16-bit" if model.dt else "fp32 (parity mode)")
+    if half_grad is not None:
+      line["with_16bit_grid_input_gradient"] = half_grad
     if kernels:
       line["roofline"] = kernels[0]
       line["instep_kernels"] = kernels[1:12]

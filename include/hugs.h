@@ -175,7 +175,7 @@ int hugs_nf_prop_fwd(long long M, int in_dim, int hidden, int dtype, const void*
 int hugs_nf_prop_bwd(long long M, int in_dim, int hidden, int dtype, const void* X, int ldx, const float* W0, int ldw0,
                      const float* b0, const float* w1, int ldw1, const float* raw, const float* sel,
                      const float* d_density, void* dX, float* gW0, float* gb0, float* gw1, float* gb1, void* ws,
-                     void* stream);
+                     int dx_f32 /* dX is a float [M, ldx] buffer (16-bit rows of <= 16 features only: the matrix-core form) */, void* stream);
 /* train_utils.py:228-239 interlevel_loss -> stepfun.py:30-86 (per-ray loss + d/d w_env) */
 int hugs_interlevel(int nrays, int S, int Sp, const float* t, const float* w, const float* t_env, const float* w_env,
                     float scale, float* loss_ray, float* d_w_env, void* stream);
@@ -407,7 +407,7 @@ int hugs_nf_field_fwd(int dtype, long long M, int S, const void* X0, int ldx0, c
 int hugs_nf_field_bwd(int dtype, long long M, int S, const void* G1, const void* C1n, const void* C0n, const void* W1xn,
                       const void* W0n, const uint32_t* bH0, const uint32_t* bY0, const float* d_density, const float* sel,
                       const void* raw, int ngeo, int napp, const int* embed_idx, void* G0, void* Gb, void* Gy0, void* dX0, int ldx0,
-                      float* d_embedding, void* stream);
+                      float* d_embedding, int dx_f32 /* dX0 is a float [M, ldx0] buffer instead of a 16-bit one */, void* stream);
 /* per-ray head-input template of the kernel above: out[ray, 0..127] = [SH16 | 0 x ngeo | appearance | 0 ..] (16-bit) */
 int hugs_nf_head_template(int dtype, int nrays, const float* sh, const float* app, int ngeo, int napp, void* out, void* stream);
 int hugs_nf_adam(long long n, float* theta, const float* grad, float* m, float* v, float lr, float b1, float b2, float eps,

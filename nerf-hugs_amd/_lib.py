@@ -35,7 +35,7 @@ _PROTOS = {
     'hugs_robust_mask': 'iipppfififpppps',
     'hugs_nf_robust_mask': 'iipppfififpppps',
     'hugs_nf_prop_fwd': 'qiii' 'pipi' 'ppi' 'pppp' 's',
-    'hugs_nf_prop_bwd': 'qiii' 'pipi' 'ppi' 'ppp' 'p' 'pppp' 'p' 's',
+    'hugs_nf_prop_bwd': 'qiii' 'pipi' 'ppi' 'ppp' 'p' 'pppp' 'p' 'i' 's',
     'hugs_interlevel': 'iiippppfpps',
     'hugs_distortion': 'iippfpps',
     'hugs_sum': 'ipfps',
@@ -84,7 +84,7 @@ _PROTOS = {
     'hugs_nf_head_input': 'qiippiipipis',
     'hugs_nf_field_fwd': 'iqipipippppppppppipppppppppps',
     'hugs_nf_head_template': 'iippiips',
-    'hugs_nf_field_bwd': 'iqippppppppppiipppppips',
+    'hugs_nf_field_bwd': 'iqippppppppppiipppppipis',
     'hugs_nf_app_bwd': 'iiipiiipps',
     'hugs_nf_rgb_act': 'qipifps',
     'hugs_nf_rgb_grad': 'qipppis',

@@ -426,6 +426,7 @@ __global__ __launch_bounds__(256, 1) void k_field_fwd(const FieldFwd P) {
 // ------------------------------------------------------------------------------------------------
 struct FieldBwd {
   int M, S, ldx0, ngeo, napp;
+  int dx_f32;                               // dX0 is a float [M, ldx0] buffer (round 5: the grid-input gradient without a 16-bit rounding)
   const uint16_t* G1;                       // [M,256]
   const uint16_t *C1n, *C0n, *W1xn, *W0n;   // [256][256], [128][256], [256][128], [>=32][256]   ([k_out][n], 16-bit)
   const uint32_t *bH0, *bY0;                // relu masks of H0 / Y0 (forward layout)
@@ -594,13 +595,21 @@ __global__ __launch_bounds__(256, 1) void k_field_bwd(const FieldBwd P) {
       ff_f32x4_t acc[4][4];
       ff_acc_zero<1>(acc);
       ff_mma_r<F16, 8, 1, 8>(act[1], frag_off, w0r, acc, act[1], (char*)(P.Gy0 + (size_t)m0 * 256), tid);
-      char* dst = (char*)(P.dX0 + (size_t)m0 * P.ldx0);
-      const unsigned xo = ff_fresh((unsigned)(r16 * P.ldx0 + wn * 16 + kb * 4) * 2u);
+      if (P.dx_f32) {      // fp32 feature gradients: in the half mode a scaled gradient below 6e-8 would flush to zero here
+        char* dst = (char*)((float*)P.dX0 + (size_t)m0 * P.ldx0);
+        const unsigned xo = ff_fresh((unsigned)(r16 * P.ldx0 + wn * 16 + kb * 4) * 4u);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        uint2 u;
-        u.x = ff_cvt_pk<F16>(acc[i][0][0], acc[i][0][1]); u.y = ff_cvt_pk<F16>(acc[i][0][2], acc[i][0][3]);
-        *(uint2*)(dst + (xo + (unsigned)(i * 16 * P.ldx0) * 2u)) = u;
+        for (int i = 0; i < 4; ++i)
+          *(float4*)(dst + (xo + (unsigned)(i * 16 * P.ldx0) * 4u)) = make_float4(acc[i][0][0], acc[i][0][1], acc[i][0][2], acc[i][0][3]);
+      } else {
+        char* dst = (char*)(P.dX0 + (size_t)m0 * P.ldx0);
+        const unsigned xo = ff_fresh((unsigned)(r16 * P.ldx0 + wn * 16 + kb * 4) * 2u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          uint2 u;
+          u.x = ff_cvt_pk<F16>(acc[i][0][0], acc[i][0][1]); u.y = ff_cvt_pk<F16>(acc[i][0][2], acc[i][0][3]);
+          *(uint2*)(dst + (xo + (unsigned)(i * 16 * P.ldx0) * 2u)) = u;
+        }
       }
     } else {
       ff_copy_out<8>(act[1], (char*)(P.Gy0 + (size_t)m0 * 256), tid);
@@ -672,7 +681,7 @@ extern "C" int hugs_nf_field_fwd(int dtype, long long M, int S, const void* X0, 
 extern "C" int hugs_nf_field_bwd(int dtype, long long M, int S, const void* G1, const void* C1n, const void* C0n, const void* W1xn,
                                  const void* W0n, const uint32_t* bH0, const uint32_t* bY0, const float* d_density, const float* sel,
                                  const void* raw, int ngeo, int napp, const int* embed_idx, void* G0, void* Gb, void* Gy0, void* dX0,
-                                 int ldx0, float* d_embedding, void* stream) {
+                                 int ldx0, float* d_embedding, int dx_f32, void* stream) {
   HUGS_REQUIRE(dtype == 1 || dtype == 2, -2, "hugs_nf_field_bwd: 16-bit operands only (dtype 1 = bf16, 2 = half), got %d", dtype);
   HUGS_REQUIRE(M > 0 && M % 256 == 0 && M < (1ll << 31) && S > 0 && S % FF_ROWS == 0 && M % S == 0, -3,
                "hugs_nf_field_bwd: %lld rows (a positive multiple of 256), rays of %d samples (a multiple of 64)", M, S);
@@ -681,7 +690,7 @@ extern "C" int hugs_nf_field_bwd(int dtype, long long M, int S, const void* G1, 
   HUGS_REQUIRE(G1 && C1n && C0n && W1xn && W0n && bH0 && bY0 && d_density && sel && raw && G0 && Gb && Gy0 && dX0 && (!d_embedding || napp == 0 || embed_idx), -2,
                "hugs_nf_field_bwd: null pointer");
   FieldBwd P;
-  P.M = (int)M; P.S = S; P.ldx0 = ldx0; P.ngeo = ngeo; P.napp = napp;
+  P.M = (int)M; P.S = S; P.ldx0 = ldx0; P.ngeo = ngeo; P.napp = napp; P.dx_f32 = dx_f32 ? 1 : 0;
   P.G1 = (const uint16_t*)G1; P.C1n = (const uint16_t*)C1n; P.C0n = (const uint16_t*)C0n; P.W1xn = (const uint16_t*)W1xn; P.W0n = (const uint16_t*)W0n;
   P.bH0 = bH0; P.bY0 = bY0; P.d_density = d_density; P.sel = sel; P.raw = (const uint16_t*)raw; P.embed_idx = embed_idx;
   P.G0 = (uint16_t*)G0; P.Gb = (uint16_t*)Gb; P.Gy0 = (uint16_t*)Gy0; P.dX0 = (uint16_t*)dX0; P.d_embedding = napp ? d_embedding : nullptr;

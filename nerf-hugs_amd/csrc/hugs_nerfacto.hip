@@ -898,7 +898,7 @@ __global__ __launch_bounds__(256) void k_nf_prop_bwd_mfma(long long M, int in_di
                                                           const float* __restrict__ W0, int ldw0, const float* __restrict__ b0,
                                                           const float* __restrict__ w1, int ldw1, const float* __restrict__ raw,
                                                           const float* __restrict__ sel, const float* __restrict__ d_density,
-                                                          uint16_t* __restrict__ dX, float* __restrict__ slab) {
+                                                          uint16_t* __restrict__ dX, float* __restrict__ slab, int dx_f32) {
   constexpr int KP = 16;
   __shared__ __attribute__((aligned(16))) uint16_t sXT[4][64 * 16];     // per wave: the tile's feature rows [sample][k]
   __shared__ float sR[4][64];
@@ -940,7 +940,10 @@ __global__ __launch_bounds__(256) void k_nf_prop_bwd_mfma(long long M, int in_di
 #pragma unroll
       for (int sb = 0; sb < 4; ++sb) {
         const long long s = s0 + 16 * sb + lr;
-        if (s < M) *(uint2*)(dX + (size_t)s * ldx + 4 * lq) = make_uint2(0u, 0u);
+        if (s < M) {
+          if (dx_f32) *(float4*)((float*)dX + (size_t)s * ldx + 4 * lq) = make_float4(0.f, 0.f, 0.f, 0.f);
+          else *(uint2*)(dX + (size_t)s * ldx + 4 * lq) = make_uint2(0u, 0u);
+        }
       }
       continue;
     }
@@ -962,7 +965,10 @@ __global__ __launch_bounds__(256) void k_nf_prop_bwd_mfma(long long M, int in_di
         dxacc = pm_mfma<DT>(C.wX[nb], dh, dxacc);
       }
       const long long s = s0 + 16 * sb + lr;
-      if (s < M) *(uint2*)(dX + (size_t)s * ldx + 4 * lq) = pm_pack4<DT>(dxacc[0], dxacc[1], dxacc[2], dxacc[3]);
+      if (s < M) {      // (dx_f32, round 5: the grid-input gradient leaves in fp32 -- a 16-bit store flushes scaled gradients below 6e-8 in the half mode)
+        if (dx_f32) *(float4*)((float*)dX + (size_t)s * ldx + 4 * lq) = make_float4(dxacc[0], dxacc[1], dxacc[2], dxacc[3]);
+        else *(uint2*)(dX + (size_t)s * ldx + 4 * lq) = pm_pack4<DT>(dxacc[0], dxacc[1], dxacc[2], dxacc[3]);
+      }
       // ---- (3) + (4): this block's 16 samples into the weight gradients ----
       const float4 r4 = *(const float4*)(rs + 16 * sb + 4 * lq);
       const float rr[4] = {r4.x, r4.y, r4.z, r4.w};
@@ -1064,7 +1070,7 @@ extern "C" int hugs_nf_prop_fwd(long long M, int in_dim, int hidden, int dtype, 
 extern "C" int hugs_nf_prop_bwd(long long M, int in_dim, int hidden, int dtype, const void* X, int ldx, const float* W0, int ldw0,
                                 const float* b0, const float* w1, int ldw1, const float* raw, const float* sel,
                                 const float* d_density, void* dX, float* gW0, float* gb0, float* gw1, float* gb1, void* ws,
-                                void* stream) {
+                                int dx_f32, void* stream) {
   HUGS_REQUIRE(in_dim >= 1 && in_dim <= 32 && hidden >= 1 && hidden <= PM_H, -3, "hugs_nf_prop_bwd: %d -> %d -> 1 unsupported (<= 32, <= 64)", in_dim, hidden);
   const int KP = in_dim <= 16 ? 16 : 32;
   HUGS_REQUIRE(ldx >= KP && ldx % 8 == 0, -3, "hugs_nf_prop_bwd: feature pitch %d (needs >= %d, multiple of 8)", ldx, KP);
@@ -1076,13 +1082,14 @@ extern "C" int hugs_nf_prop_bwd(long long M, int in_dim, int hidden, int dtype, 
   if (dtype && KP == 16 && ldx % 4 == 0) {        // 16-bit rows of <= 16 features: the matrix-core form (same slab layout)
     const long long nt64 = (M + 63) / 64;
     const int gm = (int)((nt64 + 3) / 4 < 1024 ? (nt64 + 3) / 4 : 1024);
-    if (dtype == 2) hipLaunchKernelGGL(k_nf_prop_bwd_mfma<2>, dim3(gm), dim3(256), 0, st, M, in_dim, hidden, (const uint16_t*)X, ldx, W0, ldw0, b0, w1, ldw1, raw, sel, d_density, (uint16_t*)dX, slab);
-    else hipLaunchKernelGGL(k_nf_prop_bwd_mfma<1>, dim3(gm), dim3(256), 0, st, M, in_dim, hidden, (const uint16_t*)X, ldx, W0, ldw0, b0, w1, ldw1, raw, sel, d_density, (uint16_t*)dX, slab);
+    if (dtype == 2) hipLaunchKernelGGL(k_nf_prop_bwd_mfma<2>, dim3(gm), dim3(256), 0, st, M, in_dim, hidden, (const uint16_t*)X, ldx, W0, ldw0, b0, w1, ldw1, raw, sel, d_density, (uint16_t*)dX, slab, dx_f32);
+    else hipLaunchKernelGGL(k_nf_prop_bwd_mfma<1>, dim3(gm), dim3(256), 0, st, M, in_dim, hidden, (const uint16_t*)X, ldx, W0, ldw0, b0, w1, ldw1, raw, sel, d_density, (uint16_t*)dX, slab, dx_f32);
     hipLaunchKernelGGL(k_nf_prop_reduce, dim3((pm_slab_width(KP) + 63) / 64), dim3(1024), 0, st, slab, gm, KP, in_dim, hidden, gW0, ldw0,
                        gb0, gw1, ldw1, gb1);
     HUGS_CHECK_LAUNCH("hugs_nf_prop_bwd(mfma)");
     return 0;
   }
+  HUGS_REQUIRE(!dx_f32 || dtype == 0, -3, "hugs_nf_prop_bwd: fp32 feature gradients with 16-bit rows need the matrix-core form (<= 16 features, pitch %% 4 == 0)");
 #define PM_BWD(B, K) hipLaunchKernelGGL((k_nf_prop_bwd<B, K>), dim3(grid), dim3(256), 0, st, M, in_dim, hidden, X, ldx, W0, ldw0, b0, w1, ldw1, raw, sel, d_density, dX, slab)
   if (dtype == 2) { if (KP == 16) PM_BWD(2, 16); else PM_BWD(2, 32); }
   else if (dtype) { if (KP == 16) PM_BWD(1, 16); else PM_BWD(1, 32); }

@@ -40,6 +40,13 @@ def _rup(x, m=PAD):
   return (x + m - 1) // m * m
 
 
+# Round 5 (ADVICE r3 / VERDICT r4 item 7): the gradient that enters the hash grids -- the fused kernels' last product -- leaves in
+# fp32.  As a 16-bit store the half mode flushed every scaled gradient below 6e-8 to zero there (71 / 79 / 33 % of the prop0 /
+# prop1 / field grid-input gradients at initialisation, profiles/r03_cfg5_fp16_gradient_underflow.txt), and all-zero runs issue no
+# table atomics: part of the fp16 mode's speed was gradient information it dropped.  HUGS_NF_GRID_GRAD_F32=0 restores the 16-bit
+# store (what tiny-cuda-nn's half pipeline does; bench.py --config cfg5 reports both).
+_GRID_GRAD_F32 = os.environ.get('HUGS_NF_GRID_GRAD_F32', '1') != '0'
+
 class NerfactoConfig:
   """models/nerfacto.py:18-114 ModelConfig + Model.__init__'s bound / enable_scene_contraction (dataclass defaults)."""
 
@@ -121,7 +128,7 @@ class _Layout:
 
 class NerfactoModel:
 
-  def __init__(self, cfg, device='cuda', compute_dtype='bf16', seed=0):
+  def __init__(self, cfg, device='cuda', compute_dtype='bf16', seed=0, grid_grad_f32=None):
     if not torch.cuda.is_available():
       raise L.HugsError('no GPU visible: the hugs path has no CPU fallback')
     L.lib()
@@ -134,6 +141,7 @@ class NerfactoModel:
     # half copies of the hash tables for the forward gathers (tiny-cuda-nn's parameter precision), fp32 master parameters and
     # accumulation, and torch.cuda.amp.GradScaler's dynamic loss scale (train.py:168,210-213) kept on the device
     self.amp = self.dt == 2
+    self.grid_grad_f32 = _GRID_GRAD_F32 if grid_grad_f32 is None else bool(grid_grad_f32)      # (see _GRID_GRAD_F32 above)
     self.ws = Workspace(self.device)
     self.L = cfg.num_proposal_iterations
     self.lay = _Layout()
@@ -370,8 +378,8 @@ class NerfactoModel:
   def _grid_bwd(self, name, x01, dX0):
     g = self.grids[name]
     o, r, s = g._tables()
-    L.call('hugs_hashgrid_bwd', x01.shape[0], g.n_levels, g.features, o, r, s, x01, dX0, self.dt, dX0.stride(0),
-           self.lay.view(self.grad, f'{name}/table'))
+    L.call('hugs_hashgrid_bwd', x01.shape[0], g.n_levels, g.features, o, r, s, x01, dX0, 0 if dX0.dtype == torch.float32 else self.dt,
+           dX0.stride(0), self.lay.view(self.grad, f'{name}/table'))
 
   def forward(self, rays, curr_step, u01=None, training=True):
     """Model.forward_rays (nerfacto.py:286-414), training mode.  rays: dict of device tensors origin / direction / viewdir
@@ -825,10 +833,11 @@ class NerfactoModel:
     Kh, H = self.lay.items['field/c0'][1]
     N1, g = self.lay.items['field/w1'][1][1], c.geo_feat_dim
     G0, Gb, Gy0 = ws.get('G0', (M, H), self.tdt), ws.get('Gb_field', (M, N1), self.tdt), ws.get('Gy0_field', (M, N0), self.tdt)
-    dX0 = ws.get('dX0_field', (M, K0), self.tdt)
+    dx32 = int(self.grid_grad_f32)
+    dX0 = ws.get('dX0_field', (M, K0), torch.float32 if dx32 else self.tdt)
     L.call('hugs_nf_field_bwd', dt, M, S, G1, self.wn['field/c1'], self.wn['field/c0'], self.w1xn, self.wn['field/w0'], st['bH0'], st['bY0'],
            d_dens, st['sel'], st['Y1'], g, self.napp, rays['embed_idx'] if self.napp else None, G0, Gb, Gy0, dX0, K0,
-           self.lay.view(self.grad, 'appearance') if self.napp else None)
+           self.lay.view(self.grad, 'appearance') if self.napp else None, dx32)
     # the field grid's table gradient (atomic-bound, 1.8 ms) needs only dX0: on its own stream next to the four weight-gradient
     # GEMMs (HBM-bound) instead of behind them
     side = None
@@ -868,12 +877,13 @@ class NerfactoModel:
       N0 = self.lay.items[f'{name}/w0'][1][1]
       N1 = self.lay.items[f'{name}/w1'][1][1]
       KP = st['X0'].shape[1]
-      dX0 = ws.get(f'dX0f_{name}', (M, KP), self.tdt)
+      dx32 = int(bool(self.dt) and self.grid_grad_f32 and KP == 16)      # (the matrix-core kernel writes either form)
+      dX0 = ws.get(f'dX0f_{name}', (M, KP), torch.float32 if dx32 else self.tdt)
       slab = ws.get(f'prop_slab_{name}', (L.lib().cdll.hugs_nf_prop_ws_bytes(in_dim) // 4,))      # (per level: the levels run concurrently)
       L.call('hugs_nf_prop_bwd', M, in_dim, hid, dt, st['X0'], KP, self.lay.view(self.flat, f'{name}/w0'), N0,
              self.lay.view(self.flat, f'{name}/b0'), self.lay.view(self.flat, f'{name}/w1'), N1, st['raw'], st['sel'], d_dens,
              dX0, self.lay.view(self.grad, f'{name}/w0'), self.lay.view(self.grad, f'{name}/b0'),
-             self.lay.view(self.grad, f'{name}/w1'), self.lay.view(self.grad, f'{name}/b1'), slab)
+             self.lay.view(self.grad, f'{name}/w1'), self.lay.view(self.grad, f'{name}/b1'), slab, dx32)
       self._grid_bwd(name, st['x01'], dX0)
       return
     N1 = self.lay.items[f'{name}/w1'][1][1]

@@ -5,7 +5,12 @@ import numpy as np, torch
 from nerf_hugs_amd import _lib
 dev = 'cuda'
 M, N, K = int(os.environ.get('M', 131072)), 1024, int(os.environ.get('K', 1024))
-A = torch.randn(M, K, device=dev).bfloat16(); Bt = (torch.randn(N, K, device=dev) / 32).bfloat16()
+DATA = os.environ.get('DATA', 'randn')      # randn | zeros | relu (post-relu activations: half zeros)
+if DATA == 'zeros':
+  A = torch.zeros(M, K, device=dev).bfloat16(); Bt = torch.zeros(N, K, device=dev).bfloat16()
+else:
+  A = torch.randn(M, K, device=dev); A = (A.clamp(min=0) if DATA == 'relu' else A).bfloat16(); Bt = (torch.randn(N, K, device=dev) / 32).bfloat16()
+print('operands:', DATA)
 bias = torch.zeros(N, device=dev); out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
 call = lambda: _lib.call('hugs_gemm_nt', 1, M, N, K, 0, A, K, None, 0, Bt, K, bias, None, 1, 0, 1, None, 0, None, None, out, N)
 cd = _lib.lib().cdll

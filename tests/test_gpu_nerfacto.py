@@ -318,7 +318,7 @@ def test_fused_proposal_net_kernels_vs_autograd(shape, bf16):
   dX = torch.full((M, ldx), 3.0, device=dev, dtype=tdt)
   gW0, gb0, gw1, gb1 = (torch.full(s_, 5.0, device=dev) for s_ in ((128, ldw0), (128,), (128, ldw1), (1,)))
   ws = torch.empty(L.lib().cdll.hugs_nf_prop_ws_bytes(in_dim) // 4, device=dev)
-  L.call('hugs_nf_prop_bwd', M, in_dim, H, bf16, G(Xd), ldx, G(W0), ldw0, G(b0), G(w1), ldw1, raw, G(sel), G(dd), dX, gW0, gb0, gw1, gb1, ws)
+  L.call('hugs_nf_prop_bwd', M, in_dim, H, bf16, G(Xd), ldx, G(W0), ldw0, G(b0), G(w1), ldw1, raw, G(sel), G(dd), dX, gW0, gb0, gw1, gb1, ws, 0)
   tol = lambda ref, rel: rel * max(1e-6, float(ref.abs().max()))
   assert float((gW0[:in_dim, :H].cpu().double() - P[0].grad).abs().max()) < tol(P[0].grad, 2e-4 + (2 * eps16 if mfma else 0))
   assert float((gb0[:H].cpu().double() - P[1].grad).abs().max()) < tol(P[1].grad, 2e-4)
@@ -568,7 +568,7 @@ def test_fused_field_kernels_vs_torch(dt):
   G0, Gb, Gy0 = torch.empty(M, 256, dtype=tdt, device=dev), torch.empty(M, 128, dtype=tdt, device=dev), torch.empty(M, 256, dtype=tdt, device=dev)
   dX0 = torch.zeros(M, 128, dtype=tdt, device=dev)
   demb = torch.zeros(5, napp, device=dev)
-  L.call('hugs_nf_field_bwd', dt, M, S, G1, C1n, C0n, W1xn, W0n, bH0, bY0, d_dens, sel, raw, ngeo, napp, eidx, G0, Gb, Gy0, dX0, 128, demb)
+  L.call('hugs_nf_field_bwd', dt, M, S, G1, C1n, C0n, W1xn, W0n, bH0, bY0, d_dens, sel, raw, ngeo, napp, eidx, G0, Gb, Gy0, dX0, 128, demb, 0)
   torch.cuda.synchronize()
   rG0 = q((G1.float() @ C1t.float()) * (H0.float() > 0))
   dXh = q(G0.float() @ C0t.float())                                     # (from the kernel's own rounded G0, as it computes it)
@@ -580,3 +580,12 @@ def test_fused_field_kernels_vs_torch(dt):
   rde = torch.zeros(5, napp, device=dev)
   rde.index_add_(0, eidx.long(), dXh[:, 16 + ngeo:16 + ngeo + napp].reshape(N, S, napp).sum(1))
   assert float((demb - rde).abs().max()) <= 2e-3 * float(rde.abs().max())
+  # round 5: the same launch with the feature gradient in fp32 (no 16-bit rounding of the product Gy0 w0^T: tiny values survive)
+  dX0f = torch.zeros(M, 128, dtype=torch.float32, device=dev)
+  demb2 = torch.zeros(5, napp, device=dev)
+  G1s = (G1.float() * 1e-6).to(tdt)      # gradients small enough that the 16-bit store of the half mode would flush most of them
+  L.call('hugs_nf_field_bwd', dt, M, S, G1s, C1n, C0n, W1xn, W0n, bH0, bY0, d_dens * 1e-6, sel, raw, ngeo, napp, eidx, G0, Gb, Gy0, dX0f, 128, demb2, 1)
+  torch.cuda.synchronize()
+  ref32 = (Gy0.float() @ W0t.float())[:, :32]
+  assert float((dX0f[:, :32] - ref32).abs().max()) <= 1e-5 * float(ref32.abs().max()) and float(ref32.abs().max()) > 0
+  assert float((dX0f[:, :32] != 0).float().mean()) >= float((q(ref32) != 0).float().mean())

@@ -127,11 +127,11 @@ def test_bf16_full_width_gradients_encoder_inside_the_comparison():
   comparison.  A feature the two sides round to neighbouring bf16 values (2^-8 relative) moves the first layer's
   pre-activations; the ReLU decisions stay the product's.  Bounds from profiles/r05_parity_margins.txt."""
   errs, stats, ostats = _step_and_replay(list(FULL_WIDTH), 'bf16', quant=True, replay_feats=False)
-  assert abs(float(stats['loss']) / float(ostats['loss']) - 1) < 5e-3
+  assert abs(float(stats["loss"]) / float(ostats["loss"]) - 1) < 2e-3      # (measured 2.7e-4)
   big = [(k, v) for k, v in errs.items() if v[2] >= 1024]
   assert len(big) >= 12
   for name, (emax, el2, n) in big:
-    assert el2 < 3e-2, f'{name}: relative L2 error {el2:.3e} (max {emax:.2e})'
+    assert el2 < 1.5e-2, f"{name}: relative L2 error {el2:.3e} (max {emax:.2e})"      # (measured 8.4e-3 at worst)
 
 
 def test_train_step_config1_shape_full_width_1024_rays():
