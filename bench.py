@@ -141,11 +141,18 @@ def cpu_baseline(seed):
 
   # thread counts tried: HUGS_CPU_THREADS, or 16 and every core of the box (a 64-ray step does not always scale past 16
   # threads); the best one is the baseline, `cores` = the threads it used, `host_cpu_count` = what the box has
-  tries = [int(os.environ['HUGS_CPU_THREADS'])] if 'HUGS_CPU_THREADS' in os.environ else sorted({min(host, 16), host})
+  # (a first run with all 256 hardware threads of the GPU box took 60 s per step -- 1 ray/s against 89 at 16 threads --: the second
+  #  candidate is capped at 64 and dropped after its warm-up step when that step is already 3x slower than the best one)
+  tries = [int(os.environ['HUGS_CPU_THREADS'])] if 'HUGS_CPU_THREADS' in os.environ else sorted({min(host, 16), min(host, 64)})
   best, tried, kk = None, {}, 0
   for ncores in tries:
     torch.set_num_threads(ncores)
+    t_w = time.time()
     step(kk); kk += 1
+    t_w = time.time() - t_w
+    if best is not None and t_w > 3.0 * n / best[0]:
+      tried[str(ncores)] = f'dropped after a {t_w:.1f} s warm-up step'
+      continue
     t0 = time.time()
     k = 0
     while time.time() - t0 < 12.0 / len(tries) or k < 2:
