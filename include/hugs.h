@@ -171,11 +171,12 @@ int hugs_nf_robust_mask(int npatch, int P, const float* pred, const float* gt, c
 long long hugs_nf_prop_ws_bytes(int in_dim);
 int hugs_nf_prop_fwd(long long M, int in_dim, int hidden, int dtype, const void* X, int ldx, const float* W0, int ldw0,
                      const float* b0, const float* w1, int ldw1, const float* b1, const float* sel, float* raw,
-                     float* density, void* stream);
+                     float* density, int density_act, float density_bias, void* stream);
 int hugs_nf_prop_bwd(long long M, int in_dim, int hidden, int dtype, const void* X, int ldx, const float* W0, int ldw0,
                      const float* b0, const float* w1, int ldw1, const float* raw, const float* sel,
                      const float* d_density, void* dX, float* gW0, float* gb0, float* gw1, float* gb1, void* ws,
-                     int dx_f32 /* dX is a float [M, ldx] buffer (16-bit rows of <= 16 features only: the matrix-core form) */, void* stream);
+                     int dx_f32 /* dX is a float [M, ldx] buffer (16-bit rows of <= 16 features only: the matrix-core form) */,
+                     int density_act, float density_bias, void* stream);
 /* train_utils.py:228-239 interlevel_loss -> stepfun.py:30-86 (per-ray loss + d/d w_env) */
 int hugs_interlevel(int nrays, int S, int Sp, const float* t, const float* w, const float* t_env, const float* w_env,
                     float scale, float* loss_ray, float* d_w_env, void* stream);
@@ -376,9 +377,13 @@ int hugs_nf_weights_bwd(int nrays, int S, const float* density, const float* ebi
                         const float* d_w_extra, float* d_density, float* d_rgb_s, void* stream);
 int hugs_nf_interlevel(int nrays, int S, int Sp, const float* t, const float* w, const float* t_env, const float* w_env,
                        float scale, float* loss_ray, float* d_w_env, void* stream);
-int hugs_nf_density_act(long long M, int dtype, const void* Y, int ldy, int col, const float* sel, float* density, void* stream);
+/* density_act / density_bias (here and in hugs_nf_prop_*, hugs_nf_field_*): models/nerfacto.py:36,702-710,910-918 density_activation --
+ * 0 = trunc_exp (custom_functions.py:38-52), 1 = softplus(raw + density_bias), density_bias = -1 by the fields' constructors. */
+int hugs_nf_density_act(long long M, int dtype, const void* Y, int ldy, int col, const float* sel, float* density, int density_act,
+                        float density_bias, void* stream);
 int hugs_nf_base_grad(long long M, int dtype, const void* Y, int ldy, const float* sel, const float* d_density,
-                      const void* dXh, int ldx, int geo_col0, int ngeo, void* G, int ldg, void* stream);
+                      const void* dXh, int ldx, int geo_col0, int ngeo, void* G, int ldg, int density_act, float density_bias,
+                      void* stream);
 int hugs_nf_head_input(long long M, int S, int dtype, const float* sh, const void* Yb, int ldy, int ngeo, const float* app,
                        int napp, void* X, int ldx, void* stream);
 int hugs_nf_app_bwd(int nrays, int S, int dtype, const void* dX, int ldx, int col0, int napp, const int* embed_idx,
@@ -396,7 +401,8 @@ int hugs_nf_rgb_grad(long long M, int dtype, const float* rgb, const float* d_rg
 int hugs_nf_field_fwd(int dtype, long long M, int S, const void* X0, int ldx0, const void* W0t, int ldw0, const void* W1x,
                       const void* C0t, const void* C1t, const float* b0, const float* b1x, const float* cb0, const float* cb1,
                       const float* c2, const float* cb2, const void* tmpl, int ngeo, const float* sel, void* Y0, void* raw, void* Xh,
-                      void* H0, void* H1, uint32_t* bY0, uint32_t* bH0, float* density, float* rgb, void* stream);
+                      void* H0, void* H1, uint32_t* bY0, uint32_t* bH0, float* density, float* rgb, int density_act,
+                      float density_bias, void* stream);
 /* Backward of the two networks above from colour layer 1's pre-activation gradient G1 [M,256] (hugs_rgb_bwd writes it) down to the
  * hash-feature gradient, one launch: G0 = (G1 c1^T) relu'(H0), dXh = G0 c0^T, appearance columns summed per ray into d_embedding
  * (+=, float atomics; null: skipped), Gb = [d_raw | 0 | d geo | 0] in HEAD-INPUT column order (d_raw = d_density exp(clamp(raw,
@@ -407,7 +413,8 @@ int hugs_nf_field_fwd(int dtype, long long M, int S, const void* X0, int ldx0, c
 int hugs_nf_field_bwd(int dtype, long long M, int S, const void* G1, const void* C1n, const void* C0n, const void* W1xn,
                       const void* W0n, const uint32_t* bH0, const uint32_t* bY0, const float* d_density, const float* sel,
                       const void* raw, int ngeo, int napp, const int* embed_idx, void* G0, void* Gb, void* Gy0, void* dX0, int ldx0,
-                      float* d_embedding, int dx_f32 /* dX0 is a float [M, ldx0] buffer instead of a 16-bit one */, void* stream);
+                      float* d_embedding, int dx_f32 /* dX0 is a float [M, ldx0] buffer instead of a 16-bit one */, int density_act,
+                      float density_bias, void* stream);
 /* per-ray head-input template of the kernel above: out[ray, 0..127] = [SH16 | 0 x ngeo | appearance | 0 ..] (16-bit) */
 int hugs_nf_head_template(int dtype, int nrays, const float* sh, const float* app, int ngeo, int napp, void* out, void* stream);
 int hugs_nf_adam(long long n, float* theta, const float* grad, float* m, float* v, float lr, float b1, float b2, float eps,

@@ -34,8 +34,8 @@ _PROTOS = {
     'hugs_data_loss': 'iipppififppps',
     'hugs_robust_mask': 'iipppfififpppps',
     'hugs_nf_robust_mask': 'iipppfififpppps',
-    'hugs_nf_prop_fwd': 'qiii' 'pipi' 'ppi' 'pppp' 's',
-    'hugs_nf_prop_bwd': 'qiii' 'pipi' 'ppi' 'ppp' 'p' 'pppp' 'p' 'i' 's',
+    'hugs_nf_prop_fwd': 'qiii' 'pipi' 'ppi' 'pppp' 'if' 's',
+    'hugs_nf_prop_bwd': 'qiii' 'pipi' 'ppi' 'ppp' 'p' 'pppp' 'p' 'i' 'if' 's',
     'hugs_interlevel': 'iiippppfpps',
     'hugs_distortion': 'iippfpps',
     'hugs_sum': 'ipfps',
@@ -79,12 +79,12 @@ _PROTOS = {
     'hugs_nf_weights_fwd': 'iipppipppppps',
     'hugs_nf_weights_bwd': 'iipppippppppps',
     'hugs_nf_interlevel': 'iiippppfpps',
-    'hugs_nf_density_act': 'qipiipps',
-    'hugs_nf_base_grad': 'qipipppiiipis',
+    'hugs_nf_density_act': 'qipiippifs',
+    'hugs_nf_base_grad': 'qipipppiiipiifs',
     'hugs_nf_head_input': 'qiippiipipis',
-    'hugs_nf_field_fwd': 'iqipipippppppppppipppppppppps',
+    'hugs_nf_field_fwd': 'iqipipippppppppppippppppppppifs',
     'hugs_nf_head_template': 'iippiips',
-    'hugs_nf_field_bwd': 'iqippppppppppiipppppipis',
+    'hugs_nf_field_bwd': 'iqippppppppppiipppppipiifs',
     'hugs_nf_app_bwd': 'iiipiiipps',
     'hugs_nf_rgb_act': 'qipifps',
     'hugs_nf_rgb_grad': 'qipppis',

@@ -74,3 +74,16 @@ __device__ __forceinline__ uint16_t f_to_h16(float f) { return __builtin_bit_cas
 __device__ __forceinline__ float op16_to_f(uint16_t h, int dt) { return dt == 2 ? h16_to_f(h) : bf16_to_f(h); }
 __device__ __forceinline__ uint16_t f_to_op16(float f, int dt) { return dt == 2 ? f_to_h16(f) : f_to_bf16(f); }
 __device__ __forceinline__ uint32_t f2_to_op16(float a, float b, int dt) { return (uint32_t)f_to_op16(a, dt) | ((uint32_t)f_to_op16(b, dt) << 16); }
+
+// nerfacto density activation (models/nerfacto.py:702-710, 910-918): act 0 = trunc_exp (custom_functions.py:38-52: exp forward, exp of the
+// input clamped to [-15, 15] in the backward), act 1 = softplus(raw + density_bias) (F.softplus: linear above threshold 20).
+__device__ __forceinline__ float nf_density_value(float raw, int act, float bias) {
+  if (!act) return expf(raw);
+  const float x = raw + bias;
+  return x > 20.f ? x : log1pf(expf(x));
+}
+__device__ __forceinline__ float nf_density_slope(float raw, int act, float bias) {
+  if (!act) return expf(fminf(fmaxf(raw, -15.f), 15.f));
+  const float x = raw + bias;
+  return x > 20.f ? 1.f : 1.f / (1.f + expf(-x));
+}

@@ -112,6 +112,7 @@ __device__ long long ff_trace_buf[2 * 8 * 16];
 
 struct FieldFwd {
   int M, S, ldx0, ldw0, ngeo;
+  int dact; float dbias;                    // density activation (hugs_common.h nf_density_value)
   const uint16_t* X0;                       // [M, ldx0] hash features, columns 0..31 real
   const uint16_t *W0t, *W1t, *C0t, *C1t;    // [256][ldw0], [128][256], [256][128], [256][256]  ([n][k], 16-bit)
   const float *b0, *b1, *cb0, *cb1;         // [256], [128], [256], [256]
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(256, 1) void k_field_fwd(const FieldFwd P) {
           if (geo) *(uint2*)(act[0] + ((n >> 5) * FF_STAGE + row * 64 + ((((n & 31) >> 3) ^ swz) << 4) + (n & 4) * 2)) = u;
           if (n == 0) {
             *(uint16_t*)((char*)(P.raw + m0) + ff_fresh((unsigned)row * 2u)) = (uint16_t)u.x;
-            *(float*)((char*)(P.density + m0) + ff_fresh((unsigned)row * 4u)) = expf(FfOps<F16>::lo(u.x)) * sel_s[row];
+            *(float*)((char*)(P.density + m0) + ff_fresh((unsigned)row * 4u)) = nf_density_value(FfOps<F16>::lo(u.x), P.dact, P.dbias) * sel_s[row];
           }
         }
       }
@@ -426,6 +427,7 @@ __global__ __launch_bounds__(256, 1) void k_field_fwd(const FieldFwd P) {
 // ------------------------------------------------------------------------------------------------
 struct FieldBwd {
   int M, S, ldx0, ngeo, napp;
+  int dact; float dbias;                    // density activation (hugs_common.h nf_density_slope)
   int dx_f32;                               // dX0 is a float [M, ldx0] buffer (round 5: the grid-input gradient without a 16-bit rounding)
   const uint16_t* G1;                       // [M,256]
   const uint16_t *C1n, *C0n, *W1xn, *W0n;   // [256][256], [128][256], [256][128], [>=32][256]   ([k_out][n], 16-bit)
@@ -569,7 +571,7 @@ __global__ __launch_bounds__(256, 1) void k_field_bwd(const FieldBwd P) {
         if (part == 0) {
           const float raw = FfOps<F16>::lo((uint32_t)*(const uint16_t*)((const char*)(P.raw + m0) + ff_fresh((unsigned)row * 2u)));
           const unsigned ro = ff_fresh((unsigned)row * 4u);
-          const float dr = *(const float*)((const char*)(P.d_density + m0) + ro) * expf(fminf(fmaxf(raw, -15.f), 15.f)) *
+          const float dr = *(const float*)((const char*)(P.d_density + m0) + ro) * nf_density_slope(raw, P.dact, P.dbias) *
                            *(const float*)((const char*)(P.sel + m0) + ro);
           *(uint4*)(rb + ((0 ^ sw) << 4)) = make_uint4(ff_cvt_pk<F16>(dr, 0.f), 0u, 0u, 0u);
           *(uint4*)(rb + ((1 ^ sw) << 4)) = z;
@@ -650,7 +652,7 @@ extern "C" int hugs_nf_field_fwd(int dtype, long long M, int S, const void* X0, 
                                  const void* C0t, const void* C1t, const float* b0, const float* b1, const float* cb0,
                                  const float* cb1, const float* c2, const float* cb2, const void* tmpl, int ngeo, const float* sel,
                                  void* Y0, void* raw, void* Xh, void* H0, void* H1, uint32_t* bY0, uint32_t* bH0, float* density,
-                                 float* rgb, void* stream) {
+                                 float* rgb, int density_act, float density_bias, void* stream) {
   HUGS_REQUIRE(dtype == 1 || dtype == 2, -2, "hugs_nf_field_fwd: 16-bit operands only (dtype 1 = bf16, 2 = half), got %d", dtype);
   HUGS_REQUIRE(M > 0 && M % 256 == 0 && M < (1ll << 31) && S > 0 && M % S == 0, -3,
                "hugs_nf_field_fwd: %lld rows (a positive multiple of 256, whole rays of %d samples)", M, S);
@@ -661,7 +663,7 @@ extern "C" int hugs_nf_field_fwd(int dtype, long long M, int S, const void* X0, 
   HUGS_REQUIRE(X0 && W0t && W1x && C0t && C1t && b0 && b1 && cb0 && cb1 && c2 && cb2 && tmpl && sel && Y0 && raw && Xh && H0 && H1 && density && rgb,
                -2, "hugs_nf_field_fwd: null pointer");
   FieldFwd P;
-  P.M = (int)M; P.S = S; P.ldx0 = ldx0; P.ldw0 = ldw0; P.ngeo = ngeo;
+  P.M = (int)M; P.S = S; P.ldx0 = ldx0; P.ldw0 = ldw0; P.ngeo = ngeo; P.dact = density_act; P.dbias = density_bias;
   P.X0 = (const uint16_t*)X0;
   P.W0t = (const uint16_t*)W0t; P.W1t = (const uint16_t*)W1x; P.C0t = (const uint16_t*)C0t; P.C1t = (const uint16_t*)C1t;
   P.b0 = b0; P.b1 = b1; P.cb0 = cb0; P.cb1 = cb1; P.c2 = c2; P.cb2 = cb2; P.tmpl = (const uint16_t*)tmpl; P.sel = sel;
@@ -681,7 +683,7 @@ extern "C" int hugs_nf_field_fwd(int dtype, long long M, int S, const void* X0, 
 extern "C" int hugs_nf_field_bwd(int dtype, long long M, int S, const void* G1, const void* C1n, const void* C0n, const void* W1xn,
                                  const void* W0n, const uint32_t* bH0, const uint32_t* bY0, const float* d_density, const float* sel,
                                  const void* raw, int ngeo, int napp, const int* embed_idx, void* G0, void* Gb, void* Gy0, void* dX0,
-                                 int ldx0, float* d_embedding, int dx_f32, void* stream) {
+                                 int ldx0, float* d_embedding, int dx_f32, int density_act, float density_bias, void* stream) {
   HUGS_REQUIRE(dtype == 1 || dtype == 2, -2, "hugs_nf_field_bwd: 16-bit operands only (dtype 1 = bf16, 2 = half), got %d", dtype);
   HUGS_REQUIRE(M > 0 && M % 256 == 0 && M < (1ll << 31) && S > 0 && S % FF_ROWS == 0 && M % S == 0, -3,
                "hugs_nf_field_bwd: %lld rows (a positive multiple of 256), rays of %d samples (a multiple of 64)", M, S);
@@ -690,7 +692,7 @@ extern "C" int hugs_nf_field_bwd(int dtype, long long M, int S, const void* G1, 
   HUGS_REQUIRE(G1 && C1n && C0n && W1xn && W0n && bH0 && bY0 && d_density && sel && raw && G0 && Gb && Gy0 && dX0 && (!d_embedding || napp == 0 || embed_idx), -2,
                "hugs_nf_field_bwd: null pointer");
   FieldBwd P;
-  P.M = (int)M; P.S = S; P.ldx0 = ldx0; P.ngeo = ngeo; P.napp = napp; P.dx_f32 = dx_f32 ? 1 : 0;
+  P.M = (int)M; P.S = S; P.ldx0 = ldx0; P.ngeo = ngeo; P.napp = napp; P.dx_f32 = dx_f32 ? 1 : 0; P.dact = density_act; P.dbias = density_bias;
   P.G1 = (const uint16_t*)G1; P.C1n = (const uint16_t*)C1n; P.C0n = (const uint16_t*)C0n; P.W1xn = (const uint16_t*)W1xn; P.W0n = (const uint16_t*)W0n;
   P.bH0 = bH0; P.bY0 = bY0; P.d_density = d_density; P.sel = sel; P.raw = (const uint16_t*)raw; P.embed_idx = embed_idx;
   P.G0 = (uint16_t*)G0; P.Gb = (uint16_t*)Gb; P.Gy0 = (uint16_t*)Gy0; P.dX0 = (uint16_t*)dX0; P.d_embedding = napp ? d_embedding : nullptr;

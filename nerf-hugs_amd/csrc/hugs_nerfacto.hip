@@ -351,10 +351,10 @@ extern "C" int hugs_nf_interlevel(int nrays, int S, int Sp, const float* t, cons
 // ------------------------------------------------------------------------------------------------
 // density = trunc_exp(Y[:, col]) * selector  (nerfacto.py:833-836 / 984-987)
 __global__ void k_nf_density_act(long long M, int bf16, const void* __restrict__ Y, int ldy, int col, const float* __restrict__ sel,
-                                 float* __restrict__ density) {
+                                 float* __restrict__ density, int act, float dbias) {
   const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
-  density[m] = expf(nf_load(Y, (size_t)m * ldy + col, bf16)) * sel[m];
+  density[m] = nf_density_value(nf_load(Y, (size_t)m * ldy + col, bf16), act, dbias) * sel[m];
 }
 
 // eight consecutive columns per thread (one 16-byte store in bf16): the per-element form of these glue kernels spent its time
@@ -383,14 +383,14 @@ __device__ __forceinline__ void nf_row_chunk(unsigned e, unsigned cpr, unsigned&
 // (custom_functions.py:46-50), columns 1 .. ngeo = dXhead[:, geo_col0 ...] (the head's input gradient), the rest 0.
 __global__ void k_nf_base_grad(long long M, int bf16, const void* __restrict__ Y, int ldy, const float* __restrict__ sel,
                                const float* __restrict__ d_density, const void* __restrict__ dXh, int ldx, int geo_col0, int ngeo,
-                               void* __restrict__ G, int ldg) {
+                               void* __restrict__ G, int ldg, int act, float dbias) {
   if (ldg & 7) {                                  // narrow / odd pitches (the fused proposal path uses ldg = 1): one element per thread
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long m = e / ldg;
     const int c = (int)(e % ldg);
     if (m >= M) return;
     float v = 0.f;
-    if (c == 0) v = d_density[m] * expf(fminf(fmaxf(nf_load(Y, (size_t)m * ldy, bf16), -15.f), 15.f)) * sel[m];
+    if (c == 0) v = d_density[m] * nf_density_slope(nf_load(Y, (size_t)m * ldy, bf16), act, dbias) * sel[m];
     else if (c <= ngeo && dXh) v = nf_load(dXh, (size_t)m * ldx + geo_col0 + c - 1, bf16);
     nf_store(G, (size_t)m * ldg + c, bf16, v);
     return;
@@ -410,14 +410,14 @@ __global__ void k_nf_base_grad(long long M, int bf16, const void* __restrict__ Y
       for (int q = 0; q < 8; ++q) {
         const int c = (int)c0 + q, j = q + 7;                      // element geo_col0 + c0 - 8 + j = geo_col0 + c - 1
         const uint16_t h = (uint16_t)((j & 1) ? (w[j >> 1] >> 16) : w[j >> 1]);
-        if (c == 0) v[q] = d_density[m] * expf(fminf(fmaxf(nf_load(Y, (size_t)m * ldy, bf16), -15.f), 15.f)) * sel[m];
+        if (c == 0) v[q] = d_density[m] * nf_density_slope(nf_load(Y, (size_t)m * ldy, bf16), act, dbias) * sel[m];
         else if (c <= ngeo) v[q] = op16_to_f(h, bf16);
       }
     } else {
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int c = (int)c0 + q;
-        if (c == 0) v[q] = d_density[m] * expf(fminf(fmaxf(nf_load(Y, (size_t)m * ldy, bf16), -15.f), 15.f)) * sel[m];
+        if (c == 0) v[q] = d_density[m] * nf_density_slope(nf_load(Y, (size_t)m * ldy, bf16), act, dbias) * sel[m];
         else if (c <= ngeo && dXh) v[q] = nf_load(dXh, (size_t)m * ldx + geo_col0 + c - 1, bf16);
       }
     }
@@ -520,15 +520,18 @@ __global__ void k_nf_rgb_grad(long long M, int bf16, const float* __restrict__ r
     if (tot_ > 0) hipLaunchKernelGGL(kern, dim3((unsigned)((tot_ + 255) / 256)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
   } while (0)
 
-extern "C" int hugs_nf_density_act(long long M, int dtype, const void* Y, int ldy, int col, const float* sel, float* density, void* stream) {
-  NF_LAUNCH1D(k_nf_density_act, M, M, dtype, Y, ldy, col, sel, density);
+extern "C" int hugs_nf_density_act(long long M, int dtype, const void* Y, int ldy, int col, const float* sel, float* density,
+                                   int density_act, float density_bias, void* stream) {
+  HUGS_REQUIRE(density_act == 0 || density_act == 1, -2, "hugs_nf_density_act: density_act %d (0 trunc_exp, 1 softplus)", density_act);
+  NF_LAUNCH1D(k_nf_density_act, M, M, dtype, Y, ldy, col, sel, density, density_act, density_bias);
   HUGS_CHECK_LAUNCH("hugs_nf_density_act");
   return 0;
 }
 extern "C" int hugs_nf_base_grad(long long M, int dtype, const void* Y, int ldy, const float* sel, const float* d_density,
-                                 const void* dXh, int ldx, int geo_col0, int ngeo, void* G, int ldg, void* stream) {
+                                 const void* dXh, int ldx, int geo_col0, int ngeo, void* G, int ldg, int density_act, float density_bias,
+                                 void* stream) {
   HUGS_REQUIRE(M * (long long)((ldg & 7) ? ldg : (ldg >> 3)) < (1ll << 32), -3, "hugs_nf_base_grad: %lld x %d elements exceed the 32-bit index", M, ldg);
-  NF_LAUNCH1D(k_nf_base_grad, (ldg & 7) ? M * ldg : M * (ldg >> 3), M, dtype, Y, ldy, sel, d_density, dXh, ldx, geo_col0, ngeo, G, ldg);
+  NF_LAUNCH1D(k_nf_base_grad, (ldg & 7) ? M * ldg : M * (ldg >> 3), M, dtype, Y, ldy, sel, d_density, dXh, ldx, geo_col0, ngeo, G, ldg, density_act, density_bias);
   HUGS_CHECK_LAUNCH("hugs_nf_base_grad");
   return 0;
 }
@@ -626,7 +629,7 @@ template <int BF16, int KP>
 __global__ __launch_bounds__(256) void k_nf_prop_fwd(long long M, int in_dim, int H, const void* __restrict__ X, int ldx,
                                                      const float* __restrict__ W0, int ldw0, const float* __restrict__ b0,
                                                      const float* __restrict__ w1, int ldw1, const float* __restrict__ b1,
-                                                     const float* __restrict__ sel, float* __restrict__ raw, float* __restrict__ density) {
+                                                     const float* __restrict__ sel, float* __restrict__ raw, float* __restrict__ density, int act, float dbias) {
   __shared__ __attribute__((aligned(16))) float sW0[KP * PM_H];
   __shared__ __attribute__((aligned(16))) float sb0[PM_H];
   __shared__ __attribute__((aligned(16))) float sw1[PM_H];
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(256) void k_nf_prop_fwd(long long M, int in_dim, in
       o = fmaf(fmaxf(h[n + 2], 0.f), w.z, o); o = fmaf(fmaxf(h[n + 3], 0.f), w.w, o);
     }
     raw[m] = o;
-    density[m] = expf(o) * sel[m];               // custom_functions.py:38-44 trunc_exp forward, nerfacto.py:984-988 selector
+    density[m] = nf_density_value(o, act, dbias) * sel[m];      // custom_functions.py:38-44 trunc_exp forward (or softplus), nerfacto.py:984-988 selector
   }
 }
 
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(256, KP == 32 ? 1 : 2) void k_nf_prop_bwd(long long
                                                         const float* __restrict__ W0, int ldw0, const float* __restrict__ b0,
                                                         const float* __restrict__ w1, int ldw1, const float* __restrict__ raw,
                                                         const float* __restrict__ sel, const float* __restrict__ d_density,
-                                                        void* __restrict__ dX, float* __restrict__ slab) {
+                                                        void* __restrict__ dX, float* __restrict__ slab, int act, float dbias) {
   // The hidden layer is walked in two halves of 32 units, the per-sample values of a half parked in LDS (T[unit][sample],
   // pitch 65: conflict-free by sample and by unit); only x, dx and the weight-gradient accumulators live in registers (the
   // fully unrolled 64-register form of the forward kernel spilled here; a whole-layer T left one workgroup per CU).
@@ -687,7 +690,7 @@ __global__ __launch_bounds__(256, KP == 32 ? 1 : 2) void k_nf_prop_bwd(long long
     float x[KP], dx[KP];
     pm_load_x<BF16, KP>(X, mm, ldx, x);
     // d raw = d density * exp(clamp(raw, -15, 15)) * selector (custom_functions.py:46-50)
-    const float r = valid ? d_density[mm] * expf(fminf(fmaxf(raw[mm], -15.f), 15.f)) * sel[mm] : 0.f;
+    const float r = valid ? d_density[mm] * nf_density_slope(raw[mm], act, dbias) * sel[mm] : 0.f;
     ab1 += r;
 #pragma unroll
     for (int k = 0; k < KP; ++k) dx[k] = 0.f;
@@ -851,7 +854,7 @@ template <int DT>
 __global__ __launch_bounds__(256) void k_nf_prop_fwd_mfma(long long M, int in_dim, int H, const uint16_t* __restrict__ X, int ldx,
                                                           const float* __restrict__ W0, int ldw0, const float* __restrict__ b0,
                                                           const float* __restrict__ w1, int ldw1, const float* __restrict__ b1,
-                                                          const float* __restrict__ sel, float* __restrict__ raw, float* __restrict__ density) {
+                                                          const float* __restrict__ sel, float* __restrict__ raw, float* __restrict__ density, int act, float dbias) {
   const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
   PmConst<DT> C;
   C.load(lane, in_dim, H, W0, ldw0, b0, w1, ldw1);
@@ -887,7 +890,7 @@ __global__ __launch_bounds__(256) void k_nf_prop_fwd_mfma(long long M, int in_di
       if (lq == 0 && s < M) {
         o += b1v;
         raw[s] = o;
-        density[s] = expf(o) * sel[s];             // custom_functions.py:38-44 trunc_exp forward, nerfacto.py:984-988 selector
+        density[s] = nf_density_value(o, act, dbias) * sel[s];      // custom_functions.py:38-44 trunc_exp forward (or softplus), nerfacto.py:984-988 selector
       }
     }
   }
@@ -898,7 +901,7 @@ __global__ __launch_bounds__(256) void k_nf_prop_bwd_mfma(long long M, int in_di
                                                           const float* __restrict__ W0, int ldw0, const float* __restrict__ b0,
                                                           const float* __restrict__ w1, int ldw1, const float* __restrict__ raw,
                                                           const float* __restrict__ sel, const float* __restrict__ d_density,
-                                                          uint16_t* __restrict__ dX, float* __restrict__ slab, int dx_f32) {
+                                                          uint16_t* __restrict__ dX, float* __restrict__ slab, int dx_f32, int act, float dbias) {
   constexpr int KP = 16;
   __shared__ __attribute__((aligned(16))) uint16_t sXT[4][64 * 16];     // per wave: the tile's feature rows [sample][k]
   __shared__ float sR[4][64];
@@ -932,7 +935,7 @@ __global__ __launch_bounds__(256) void k_nf_prop_bwd_mfma(long long M, int in_di
   for (long long t = wave; t < ntile; t += nwave) {
     const long long s0 = t << 6;
     // d raw = d density * exp(clamp(raw, -15, 15)) * selector (custom_functions.py:46-50), sample s0 + lane
-    const float r = dn * expf(fminf(fmaxf(rn, -15.f), 15.f)) * sn;
+    const float r = dn * nf_density_slope(rn, act, dbias) * sn;
     uint2 xf[4] = {xn[0], xn[1], xn[2], xn[3]};
     load_tile(t + nwave, xn, dn, rn, sn);
     ab1 += r;
@@ -1044,7 +1047,7 @@ extern "C" long long hugs_nf_prop_ws_bytes(int in_dim) {
 }
 extern "C" int hugs_nf_prop_fwd(long long M, int in_dim, int hidden, int dtype, const void* X, int ldx, const float* W0, int ldw0,
                                 const float* b0, const float* w1, int ldw1, const float* b1, const float* sel, float* raw,
-                                float* density, void* stream) {
+                                float* density, int density_act, float density_bias, void* stream) {
   HUGS_REQUIRE(in_dim >= 1 && in_dim <= 32 && hidden >= 1 && hidden <= PM_H, -3, "hugs_nf_prop_fwd: %d -> %d -> 1 unsupported (<= 32, <= 64)", in_dim, hidden);
   const int KP = in_dim <= 16 ? 16 : 32;
   HUGS_REQUIRE(ldx >= KP && ldx % 8 == 0, -3, "hugs_nf_prop_fwd: feature pitch %d (needs >= %d, multiple of 8)", ldx, KP);
@@ -1054,12 +1057,12 @@ extern "C" int hugs_nf_prop_fwd(long long M, int in_dim, int hidden, int dtype, 
   if (dtype && KP == 16 && ldx % 4 == 0) {        // 16-bit rows of <= 16 features: the matrix-core form
     const long long ntile = (M + 63) / 64;
     const int gm = (int)((ntile + 3) / 4 < 4096 ? (ntile + 3) / 4 : 4096);
-    if (dtype == 2) hipLaunchKernelGGL(k_nf_prop_fwd_mfma<2>, dim3(gm), dim3(256), 0, st, M, in_dim, hidden, (const uint16_t*)X, ldx, W0, ldw0, b0, w1, ldw1, b1, sel, raw, density);
-    else hipLaunchKernelGGL(k_nf_prop_fwd_mfma<1>, dim3(gm), dim3(256), 0, st, M, in_dim, hidden, (const uint16_t*)X, ldx, W0, ldw0, b0, w1, ldw1, b1, sel, raw, density);
+    if (dtype == 2) hipLaunchKernelGGL(k_nf_prop_fwd_mfma<2>, dim3(gm), dim3(256), 0, st, M, in_dim, hidden, (const uint16_t*)X, ldx, W0, ldw0, b0, w1, ldw1, b1, sel, raw, density, density_act, density_bias);
+    else hipLaunchKernelGGL(k_nf_prop_fwd_mfma<1>, dim3(gm), dim3(256), 0, st, M, in_dim, hidden, (const uint16_t*)X, ldx, W0, ldw0, b0, w1, ldw1, b1, sel, raw, density, density_act, density_bias);
     HUGS_CHECK_LAUNCH("hugs_nf_prop_fwd(mfma)");
     return 0;
   }
-#define PM_FWD(B, K) hipLaunchKernelGGL((k_nf_prop_fwd<B, K>), dim3(grid), dim3(256), 0, st, M, in_dim, hidden, X, ldx, W0, ldw0, b0, w1, ldw1, b1, sel, raw, density)
+#define PM_FWD(B, K) hipLaunchKernelGGL((k_nf_prop_fwd<B, K>), dim3(grid), dim3(256), 0, st, M, in_dim, hidden, X, ldx, W0, ldw0, b0, w1, ldw1, b1, sel, raw, density, density_act, density_bias)
   if (dtype == 2) { if (KP == 16) PM_FWD(2, 16); else PM_FWD(2, 32); }
   else if (dtype) { if (KP == 16) PM_FWD(1, 16); else PM_FWD(1, 32); }
   else { if (KP == 16) PM_FWD(0, 16); else PM_FWD(0, 32); }
@@ -1070,7 +1073,7 @@ extern "C" int hugs_nf_prop_fwd(long long M, int in_dim, int hidden, int dtype, 
 extern "C" int hugs_nf_prop_bwd(long long M, int in_dim, int hidden, int dtype, const void* X, int ldx, const float* W0, int ldw0,
                                 const float* b0, const float* w1, int ldw1, const float* raw, const float* sel,
                                 const float* d_density, void* dX, float* gW0, float* gb0, float* gw1, float* gb1, void* ws,
-                                int dx_f32, void* stream) {
+                                int dx_f32, int density_act, float density_bias, void* stream) {
   HUGS_REQUIRE(in_dim >= 1 && in_dim <= 32 && hidden >= 1 && hidden <= PM_H, -3, "hugs_nf_prop_bwd: %d -> %d -> 1 unsupported (<= 32, <= 64)", in_dim, hidden);
   const int KP = in_dim <= 16 ? 16 : 32;
   HUGS_REQUIRE(ldx >= KP && ldx % 8 == 0, -3, "hugs_nf_prop_bwd: feature pitch %d (needs >= %d, multiple of 8)", ldx, KP);
@@ -1082,15 +1085,15 @@ extern "C" int hugs_nf_prop_bwd(long long M, int in_dim, int hidden, int dtype, 
   if (dtype && KP == 16 && ldx % 4 == 0) {        // 16-bit rows of <= 16 features: the matrix-core form (same slab layout)
     const long long nt64 = (M + 63) / 64;
     const int gm = (int)((nt64 + 3) / 4 < 1024 ? (nt64 + 3) / 4 : 1024);
-    if (dtype == 2) hipLaunchKernelGGL(k_nf_prop_bwd_mfma<2>, dim3(gm), dim3(256), 0, st, M, in_dim, hidden, (const uint16_t*)X, ldx, W0, ldw0, b0, w1, ldw1, raw, sel, d_density, (uint16_t*)dX, slab, dx_f32);
-    else hipLaunchKernelGGL(k_nf_prop_bwd_mfma<1>, dim3(gm), dim3(256), 0, st, M, in_dim, hidden, (const uint16_t*)X, ldx, W0, ldw0, b0, w1, ldw1, raw, sel, d_density, (uint16_t*)dX, slab, dx_f32);
+    if (dtype == 2) hipLaunchKernelGGL(k_nf_prop_bwd_mfma<2>, dim3(gm), dim3(256), 0, st, M, in_dim, hidden, (const uint16_t*)X, ldx, W0, ldw0, b0, w1, ldw1, raw, sel, d_density, (uint16_t*)dX, slab, dx_f32, density_act, density_bias);
+    else hipLaunchKernelGGL(k_nf_prop_bwd_mfma<1>, dim3(gm), dim3(256), 0, st, M, in_dim, hidden, (const uint16_t*)X, ldx, W0, ldw0, b0, w1, ldw1, raw, sel, d_density, (uint16_t*)dX, slab, dx_f32, density_act, density_bias);
     hipLaunchKernelGGL(k_nf_prop_reduce, dim3((pm_slab_width(KP) + 63) / 64), dim3(1024), 0, st, slab, gm, KP, in_dim, hidden, gW0, ldw0,
                        gb0, gw1, ldw1, gb1);
     HUGS_CHECK_LAUNCH("hugs_nf_prop_bwd(mfma)");
     return 0;
   }
   HUGS_REQUIRE(!dx_f32 || dtype == 0, -3, "hugs_nf_prop_bwd: fp32 feature gradients with 16-bit rows need the matrix-core form (<= 16 features, pitch %% 4 == 0)");
-#define PM_BWD(B, K) hipLaunchKernelGGL((k_nf_prop_bwd<B, K>), dim3(grid), dim3(256), 0, st, M, in_dim, hidden, X, ldx, W0, ldw0, b0, w1, ldw1, raw, sel, d_density, dX, slab)
+#define PM_BWD(B, K) hipLaunchKernelGGL((k_nf_prop_bwd<B, K>), dim3(grid), dim3(256), 0, st, M, in_dim, hidden, X, ldx, W0, ldw0, b0, w1, ldw1, raw, sel, d_density, dX, slab, density_act, density_bias)
   if (dtype == 2) { if (KP == 16) PM_BWD(2, 16); else PM_BWD(2, 32); }
   else if (dtype) { if (KP == 16) PM_BWD(1, 16); else PM_BWD(1, 32); }
   else { if (KP == 16) PM_BWD(0, 16); else PM_BWD(0, 32); }

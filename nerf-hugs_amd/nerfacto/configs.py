@@ -18,7 +18,7 @@ PHOTOTOURISM_NERFACTO_BASE = dict(
 
 _BASE_KEYS = ('bound', 'enable_scene_contraction', 'patch_size', 'lr_init', 'lr_final', 'lr_decay_mult', 'warmup_steps', 'num_steps',
               'opt_betas', 'opt_eps')
-_IGNORED_MODEL_KEYS = ('enable_tcnn_mlp', 'use_same_proposal_network', 'density_activation')
+_IGNORED_MODEL_KEYS = ('enable_tcnn_mlp',)
 
 
 def yml_to_kwargs(doc):
@@ -28,10 +28,7 @@ def yml_to_kwargs(doc):
     raise ValueError(f"model_type {base.get('model_type')!r}: this path builds the nerfacto model")
   if model.get('enable_tcnn_mlp', False):
     raise NotImplementedError('enable_tcnn_mlp: True (tiny-cuda-nn fused MLPs): the shipped ymls select the nn.Linear form')
-  if model.get('use_same_proposal_network', False):
-    raise NotImplementedError('use_same_proposal_network')
-  if model.get('density_activation', 'trunc_exp') != 'trunc_exp':
-    raise NotImplementedError("density_activation: only 'trunc_exp' (the default every yml uses) is built")
+  # (round 5: use_same_proposal_network and density_activation = 'softplus' are built -- NerfactoConfig checks their values)
   kw = {k: v for k, v in model.items() if k not in _IGNORED_MODEL_KEYS}
   for k in ('num_proposal_samples_per_ray',):
     if k in kw:

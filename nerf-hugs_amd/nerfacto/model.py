@@ -71,6 +71,9 @@ class NerfactoConfig:
     self.robustnerf_smoothed_inlier_quantile, self.robustnerf_inner_patch_size = 0.5, 8
     self.robustnerf_inner_patch_inlier_quantile, self.patch_size = 0.4, 16      # patch_size: train.py's config.patch_size
     self.rgb_bias = 0.
+    # round 5: nerfacto.py:36 density_activation ('trunc_exp' | 'softplus': F.softplus(raw + density_bias), density_bias = -1 is the
+    # fields' constructor default, nerfacto.py:660,890) and :66 use_same_proposal_network (ONE proposal network for every level)
+    self.density_activation, self.density_bias, self.use_same_proposal_network = 'trunc_exp', -1., False
     # HA-NeRF (nerfacto.py:42-53, 94-102): transient embedding + ImplicitMask
     self.use_transient_embedding, self.transient_embedding_dim = False, 16
     self.num_levels_implicit, self.base_res_implicit, self.max_res_implicit = 8, 16, 1024
@@ -88,6 +91,10 @@ class NerfactoConfig:
       # a name that is never bound anywhere in the file
       raise NameError("name 'output_type' is not defined (the reference's nerfacto NeRF-W branch, models/nerfacto.py:394, "
                       "cannot execute; nothing to reproduce)")
+    if self.density_activation not in ('trunc_exp', 'softplus'):
+      raise NotImplementedError()                                                             # nerfacto.py:709-710
+    if self.use_same_proposal_network:
+      assert len(self.proposal_net_args_list) == 1, 'Only one proposal network is allowed.'     # nerfacto.py:192
     if self.transient_type not in (None, 'withmask', 'robustnerf', 'hanerf'):
       raise NotImplementedError(f"nerfacto transient_type {self.transient_type!r}")
     if self.transient_type == 'hanerf':       # nerfacto.py:139-143
@@ -146,7 +153,10 @@ class NerfactoModel:
     self.L = cfg.num_proposal_iterations
     self.lay = _Layout()
     self.grids, self.nets, self.fused = {}, {}, {}
-    for i in range(self.L):
+    self.dact, self.dbias = int(cfg.density_activation == 'softplus'), float(cfg.density_bias)
+    # level -> the proposal network it evaluates (nerfacto.py:334: network 0 for every level with use_same_proposal_network)
+    self.net_of = (lambda lvl: 'prop0') if cfg.use_same_proposal_network else (lambda lvl: f'prop{lvl}')
+    for i in range(1 if cfg.use_same_proposal_network else self.L):
       a = cfg.prop_args(i)
       g = HashGrid(a['num_levels'], a['features_per_level'], a['log2_hashmap_size'], a['base_res'], None, a['max_res'], device='cpu')
       self.grids[f'prop{i}'] = g
@@ -400,7 +410,7 @@ class NerfactoModel:
       M = N * S
       if M % 128:
         raise ValueError(f'{N} rays x {S} samples is not a multiple of the 128-row GEMM tile')
-      name = f'prop{lvl}' if is_prop else 'field'
+      name = self.net_of(lvl) if is_prop else 'field'
       ub, mj = self._u_base(S, u01 is not None)
       jit = None
       if u01 is not None:
@@ -424,8 +434,8 @@ class NerfactoModel:
         raw = ws.get(f'raw{lvl}', (M,))
         L.call('hugs_nf_prop_fwd', M, in_dim, hid, dt, X0, KP, self.lay.view(self.flat, f'{name}/w0'), N0,
                self.lay.view(self.flat, f'{name}/b0'), self.lay.view(self.flat, f'{name}/w1'), N1,
-               self.lay.view(self.flat, f'{name}/b1'), sel, raw, dens)
-        st = dict(S=S, M=M, name=name, sbins=sb, ebins=eb, x01=x01, sel=sel, X0=X0, Y0=None, Y1=None, raw=raw, density=dens, rgb=None)
+               self.lay.view(self.flat, f'{name}/b1'), sel, raw, dens, self.dact, self.dbias)
+        st = dict(S=S, M=M, name=name, tag=f'L{lvl}', sbins=sb, ebins=eb, x01=x01, sel=sel, X0=X0, Y0=None, Y1=None, raw=raw, density=dens, rgb=None)
       elif not is_prop and M % 256 == 0 and self._field_fuse_ok():
         st = self._field_forward_fused(lvl, rays, N, S, M, x01, sel, dens, training)
         st.update(sbins=sb, ebins=eb)
@@ -439,7 +449,7 @@ class NerfactoModel:
         bY0 = ws.get(f'bitsY0_{lvl}', (M * N0 // 32,), torch.int32) if training and self._bits_ok(M, N0, K0) and self._bits_ok(M, N0, N1) else None
         self._nt(M, f'{name}/w0', X0, self.lay.view(self.flat, f'{name}/b0'), True, Y0, bits=bY0)
         self._nt(M, f'{name}/w1', Y0, self.lay.view(self.flat, f'{name}/b1'), False, Y1)
-        L.call('hugs_nf_density_act', M, dt, Y1, N1, 0, sel, dens)
+        L.call('hugs_nf_density_act', M, dt, Y1, N1, 0, sel, dens, self.dact, self.dbias)
         st = dict(S=S, M=M, name=name, sbins=sb, ebins=eb, x01=x01, sel=sel, X0=X0, Y0=Y0, Y1=Y1, density=dens, rgb=None, bY0=bY0)
       rgb_out = None
       if st.get('fused_field'):
@@ -524,7 +534,7 @@ class NerfactoModel:
     V = lambda n: self.lay.view(self.flat, n)
     L.call('hugs_nf_field_fwd', dt, M, S, X0, K0, self.wt['field/w0'], K0, self.wt['field/w1x'], self.wt['field/c0'], self.wt['field/c1'],
            V('field/b0'), self.b1x, V('field/cb0'), V('field/cb1'), V('field/c2'), beff, tmpl, c.geo_feat_dim, sel,
-           Y0, raw16, Xh, H0, H1, bY0, bH0, dens, rgb)
+           Y0, raw16, Xh, H0, H1, bY0, bH0, dens, rgb, self.dact, self.dbias)
     return dict(S=S, M=M, name='field', x01=x01, sel=sel, X0=X0, Y0=Y0, Y1=raw16, density=dens, rgb=rgb, bY0=bY0, bH0=bH0,
                 Xh=Xh, H0=H0, H1=H1, Yc=None, app=app, fused_field=True)
 
@@ -704,6 +714,8 @@ class NerfactoModel:
     ev0 = torch.cuda.Event(); ev0.record(cur)
     done = []
     self._bwd_done = []
+    self._prop_grad_written = set()
+    same_net = bool(self.cfg.use_same_proposal_network)
     for l in range(self.L, -1, -1):
       st = levels[l]
       is_prop = l < self.L
@@ -712,7 +724,7 @@ class NerfactoModel:
       if not is_prop and not (want('field') or want('appearance_embedding')):
         continue
       if multi and is_prop:
-        side = self._bwd_streams[l % 2]
+        side = self._bwd_streams[0 if same_net else l % 2]      # (levels of one shared network: one stream, in order)
         with torch.cuda.stream(side):
           side.wait_event(ev0)
           self._backward_level(st, batch, N, None, d_w[l])
@@ -837,7 +849,7 @@ class NerfactoModel:
     dX0 = ws.get('dX0_field', (M, K0), torch.float32 if dx32 else self.tdt)
     L.call('hugs_nf_field_bwd', dt, M, S, G1, self.wn['field/c1'], self.wn['field/c0'], self.w1xn, self.wn['field/w0'], st['bH0'], st['bY0'],
            d_dens, st['sel'], st['Y1'], g, self.napp, rays['embed_idx'] if self.napp else None, G0, Gb, Gy0, dX0, K0,
-           self.lay.view(self.grad, 'appearance') if self.napp else None, dx32)
+           self.lay.view(self.grad, 'appearance') if self.napp else None, dx32, self.dact, self.dbias)
     # the field grid's table gradient (atomic-bound, 1.8 ms) needs only dX0: on its own stream next to the four weight-gradient
     # GEMMs (HBM-bound) instead of behind them
     side = None
@@ -868,7 +880,7 @@ class NerfactoModel:
   def _backward_level(self, st, rays, N, d_rgb_out, d_w_extra):
     c, ws, dt = self.cfg, self.ws, self.dt
     S, M, name = st['S'], st['M'], st['name']
-    d_dens = ws.get(f'd_dens_{name}', (M,))
+    d_dens = ws.get(f"d_dens_{st.get('tag', name)}", (M,))
     d_rgb_s = ws.get('d_rgb_s', (M, 3)) if st['rgb'] is not None else None
     L.call('hugs_nf_weights_bwd', N, S, st['density'], st['ebins'], rays['direction'], int(c.opaque_background), st['rgb'],
            rays.get('bg_rgb') if st['rgb'] is not None else None, st['weights'], d_rgb_out, d_w_extra, d_dens, d_rgb_s)
@@ -877,15 +889,27 @@ class NerfactoModel:
       N0 = self.lay.items[f'{name}/w0'][1][1]
       N1 = self.lay.items[f'{name}/w1'][1][1]
       KP = st['X0'].shape[1]
+      tag = st.get('tag', name)
       dx32 = int(bool(self.dt) and self.grid_grad_f32 and KP == 16)      # (the matrix-core kernel writes either form)
-      dX0 = ws.get(f'dX0f_{name}', (M, KP), torch.float32 if dx32 else self.tdt)
-      slab = ws.get(f'prop_slab_{name}', (L.lib().cdll.hugs_nf_prop_ws_bytes(in_dim) // 4,))      # (per level: the levels run concurrently)
+      dX0 = ws.get(f'dX0f_{tag}', (M, KP), torch.float32 if dx32 else self.tdt)
+      slab = ws.get(f'prop_slab_{tag}', (L.lib().cdll.hugs_nf_prop_ws_bytes(in_dim) // 4,))      # (per level: the levels run concurrently)
+      gv = lambda leaf: self.lay.view(self.grad, f'{name}/{leaf}')
+      # use_same_proposal_network: the second level that reaches a shared network ADDS its weight gradients (the kernel writes =):
+      # through a scratch copy of the four leaves (the table gradient is scatter-added either way)
+      accumulate = name in getattr(self, '_prop_grad_written', ())
+      tgt = {leaf: (ws.get(f'prop_gtmp_{leaf}', tuple(gv(leaf).shape)) if accumulate else gv(leaf)) for leaf in ('w0', 'b0', 'w1', 'b1')}
       L.call('hugs_nf_prop_bwd', M, in_dim, hid, dt, st['X0'], KP, self.lay.view(self.flat, f'{name}/w0'), N0,
              self.lay.view(self.flat, f'{name}/b0'), self.lay.view(self.flat, f'{name}/w1'), N1, st['raw'], st['sel'], d_dens,
-             dX0, self.lay.view(self.grad, f'{name}/w0'), self.lay.view(self.grad, f'{name}/b0'),
-             self.lay.view(self.grad, f'{name}/w1'), self.lay.view(self.grad, f'{name}/b1'), slab, dx32)
+             dX0, tgt['w0'], tgt['b0'], tgt['w1'], tgt['b1'], slab, dx32, self.dact, self.dbias)
+      if accumulate:
+        for leaf in ('w0', 'b0', 'w1', 'b1'):
+          L.call('hugs_add_inplace', gv(leaf).numel(), tgt[leaf], gv(leaf))
+      elif hasattr(self, '_prop_grad_written'):
+        self._prop_grad_written.add(name)
       self._grid_bwd(name, st['x01'], dX0)
       return
+    if self.cfg.use_same_proposal_network and name != 'field':
+      raise NotImplementedError('use_same_proposal_network with proposal networks wider than the fused kernels (in <= 32, hidden <= 64)')
     N1 = self.lay.items[f'{name}/w1'][1][1]
     dXh = None
     if st['rgb'] is not None:
@@ -917,7 +941,7 @@ class NerfactoModel:
                self.lay.view(self.grad, 'appearance'))
     Gb = ws.get(f'Gb_{name}', (M, N1), self.tdt)
     L.call('hugs_nf_base_grad', M, dt, st['Y1'], st['Y1'].shape[1], st['sel'], d_dens, dXh, 0 if dXh is None else dXh.shape[1], 16,
-           c.geo_feat_dim if dXh is not None else 0, Gb, N1)
+           c.geo_feat_dim if dXh is not None else 0, Gb, N1, self.dact, self.dbias)
     self._tn(M, f'{name}/w1', st['Y0'], Gb, f'{name}/b1')
     N0 = st['Y0'].shape[1]
     Gy0 = ws.get(f'Gy0_{name}', (M, N0), self.tdt)

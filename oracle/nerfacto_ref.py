@@ -50,6 +50,9 @@ class Cfg:
     self.robustnerf_smoothed_inlier_quantile, self.robustnerf_inner_patch_size = 0.5, 8
     self.robustnerf_inner_patch_inlier_quantile, self.patch_size = 0.4, 16
     self.rgb_bias = 0.
+    # nerfacto.py:36 density_activation ('trunc_exp' | 'softplus' = F.softplus(raw + density_bias), density_bias = -1: :660,890) and
+    # :66 use_same_proposal_network (network 0 evaluates every proposal level, :334)
+    self.density_activation, self.density_bias, self.use_same_proposal_network = 'trunc_exp', -1., False
     self.use_transient_embedding, self.transient_embedding_dim = False, 16
     self.num_levels_implicit, self.base_res_implicit, self.max_res_implicit = 8, 16, 1024
     self.log2_hashmap_size_implicit, self.features_per_level_implicit, self.hidden_dim_implicit = 17, 2, 128
@@ -88,6 +91,15 @@ class _TruncExp(torch.autograd.Function):
 
 
 trunc_exp = _TruncExp.apply
+
+
+def density_activation(cfg, raw):
+  """nerfacto.py:702-710 / 910-918."""
+  if cfg.density_activation == 'trunc_exp':
+    return trunc_exp(raw)
+  if cfg.density_activation == 'softplus':
+    return torch.nn.functional.softplus(raw + cfg.density_bias)
+  raise NotImplementedError()
 
 
 # ---- ray_utils.py -----------------------------------------------------------------------------------------------------
@@ -258,7 +270,7 @@ def prop_density(cfg, P, i, positions):
   x = _HashGridFn.apply(P['table'], p, spec)
   x = torch.relu(x @ P['w0'] + P['b0'])
   raw = x @ P['w1'] + P['b1']
-  return trunc_exp(raw) * sel[..., None]
+  return density_activation(cfg, raw) * sel[..., None]
 
 
 def field_forward(cfg, P, positions, viewdirs, app):
@@ -268,7 +280,7 @@ def field_forward(cfg, P, positions, viewdirs, app):
   x = _HashGridFn.apply(P['table'], p, spec)
   x = torch.relu(x @ P['w0'] + P['b0']) @ P['w1'] + P['b1']
   raw, geo = x[..., :1], x[..., 1:]
-  density = trunc_exp(raw) * sel[..., None]
+  density = density_activation(cfg, raw) * sel[..., None]
   d = torch.from_numpy(HG.sh4(((viewdirs + 1.0) / 2.0).detach().numpy())).to(positions.dtype)
   h = torch.cat([d, geo] + ([app] if app is not None else []), dim=-1)
   h = torch.relu(h @ P['c0'] + P['cb0'])
@@ -290,7 +302,7 @@ def init_params(cfg, seed=0, dtype=torch.float32):
   def table(spec):
     return ((torch.rand(spec['n_entries'], spec['F'], generator=g, dtype=torch.float64) * 2 - 1) * 1e-4).to(dtype)
   P = {}
-  for i in range(cfg.num_proposal_iterations):
+  for i in range(1 if cfg.use_same_proposal_network else cfg.num_proposal_iterations):      # nerfacto.py:191-214
     a = cfg.prop_args(i)
     spec = grid_spec(a['num_levels'], a['base_res'], a['max_res'], a['log2_hashmap_size'], a['features_per_level'])
     w0, b0 = lin(spec['out_dim'], a['hidden_dim']); w1, b1 = lin(a['hidden_dim'], 1)
@@ -342,7 +354,8 @@ def forward_rays(cfg, P, rays, curr_step, u01, training=True):
     pos = rays['origin'][:, None, :] + rays['direction'][:, None, :] * t_mid[..., None]
     N, S = t_mid.shape
     if is_prop:
-      dens = prop_density(cfg, P[f'prop{lvl}'], lvl, pos.reshape(-1, 3)).reshape(N, S)
+      net = 0 if cfg.use_same_proposal_network else lvl                                       # nerfacto.py:334
+      dens = prop_density(cfg, P[f'prop{net}'], net, pos.reshape(-1, 3)).reshape(N, S)
       rgb = None
     else:
       vd = rays['viewdir'][:, None, :].expand_as(pos).reshape(-1, 3)

@@ -17,7 +17,7 @@ eidx = torch.randint(0, 100, (N,), generator=g, device=dev).int()
 G0, Gb, Gy0, dX0 = torch.empty(M, 256, dtype=tdt, device=dev), torch.empty(M, 128, dtype=tdt, device=dev), torch.empty(M, 256, dtype=tdt, device=dev), torch.zeros(M, 128, dtype=tdt, device=dev)
 demb = torch.zeros(100, 48, device=dev)
 def run():
-  L.call('hugs_nf_field_bwd', dt, M, S, G1, C1n, C0n, W1xn, W0n, bH0, bY0, dd, sel, raw, 64, 48, eidx, G0, Gb, Gy0, dX0, 128, demb, 0)
+  L.call('hugs_nf_field_bwd', dt, M, S, G1, C1n, C0n, W1xn, W0n, bH0, bY0, dd, sel, raw, 64, 48, eidx, G0, Gb, Gy0, dX0, 128, demb, 0, 0, -1.0)
 for _ in range(3): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -18,7 +18,7 @@ H0, H1 = torch.empty(M, 256, dtype=tdt, device=dev), torch.empty(M, 256, dtype=t
 bY0, bH0 = torch.empty(M * 8, dtype=torch.int32, device=dev), torch.empty(M * 8, dtype=torch.int32, device=dev)
 dens, rgb = torch.empty(M, device=dev), torch.empty(M, 3, device=dev)
 def run():
-  L.call('hugs_nf_field_fwd', dt, M, S, X0, 128, W0t, 128, W1x, C0t, C1t, b0, b1, cb0, cb1, c2, cb2, tmpl, 64, sel, Y0, raw, Xh, H0, H1, bY0, bH0, dens, rgb)
+  L.call('hugs_nf_field_fwd', dt, M, S, X0, 128, W0t, 128, W1x, C0t, C1t, b0, b1, cb0, cb1, c2, cb2, tmpl, 64, sel, Y0, raw, Xh, H0, H1, bY0, bH0, dens, rgb, 0, -1.0)
 for _ in range(3): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -19,5 +19,5 @@ for M, in_dim in ((8388608, 10), (4194304, 14)):
   dd = torch.randn(M, device=dev) * 1e-3; dX = torch.empty(M, 16, device=dev, dtype=torch.float16)
   g = [torch.empty(128, 128, device=dev), torch.empty(128, device=dev), torch.empty(128, 128, device=dev), torch.empty(1, device=dev)]
   ws = torch.empty(L.lib().cdll.hugs_nf_prop_ws_bytes(in_dim) // 4, device=dev)
-  print(M, in_dim, 'fwd', f"{t(lambda: L.call('hugs_nf_prop_fwd', M, in_dim, H, 2, X, 16, W0, 128, b0, w1, 128, b1, sel, raw, dens)):.1f} us",
-        'bwd', f"{t(lambda: L.call('hugs_nf_prop_bwd', M, in_dim, H, 2, X, 16, W0, 128, b0, w1, 128, raw, sel, dd, dX, g[0], g[1], g[2], g[3], ws, 0)):.1f} us", flush=True)
+  print(M, in_dim, 'fwd', f"{t(lambda: L.call('hugs_nf_prop_fwd', M, in_dim, H, 2, X, 16, W0, 128, b0, w1, 128, b1, sel, raw, dens, 0, -1.0)):.1f} us",
+        'bwd', f"{t(lambda: L.call('hugs_nf_prop_bwd', M, in_dim, H, 2, X, 16, W0, 128, b0, w1, 128, raw, sel, dd, dX, g[0], g[1], g[2], g[3], ws, 0, 0, -1.0)):.1f} us", flush=True)

@@ -100,7 +100,8 @@ def _rays(N, seed):
               bg_rgb=torch.ones(N, 3), rgb=torch.rand(N, 3, generator=g)), g
 
 
-@pytest.mark.parametrize('variant', ['base', 'contract_piecewise_charb', 'withmask', 'robustnerf', 'wide_prop', 'prop_gemm'])
+@pytest.mark.parametrize('variant', ['base', 'contract_piecewise_charb', 'withmask', 'robustnerf', 'wide_prop', 'prop_gemm', 'softplus',
+                                     'same_proposal_network', 'softplus_same_net_gemm_field'])
 def test_model_forward_loss_and_gradients_vs_oracle(variant, monkeypatch):
   from nerf_hugs_amd.nerfacto.model import NerfactoConfig, NerfactoModel
   from oracle import nerfacto_ref as NF
@@ -115,6 +116,12 @@ def test_model_forward_loss_and_gradients_vs_oracle(variant, monkeypatch):
     kw.update(proposal_net_args_list=[dict(hidden_dim=24, log2_hashmap_size=9, num_levels=9, max_res=48)])
   if variant == 'prop_gemm':      # the padded-GEMM fallback of the proposal nets (taken for nets wider than 32 -> 64 -> 1)
     monkeypatch.setenv('HUGS_NF_FUSED_PROP', '0')
+  # round 5: nerfacto.py:36 density_activation = 'softplus' (F.softplus(raw - 1) in both field types) and :66 use_same_proposal_network
+  # (ONE proposal network evaluates both proposal levels: its gradients are the sum of the two levels')
+  if variant.startswith('softplus'):
+    kw.update(density_activation='softplus')
+  if 'same' in variant:
+    kw.update(use_same_proposal_network=True)
   ocfg = NF.Cfg(**kw)
   P = NF.init_params(ocfg, 3)
   # tables at U(+-1e-4) make every field output ~bias: scale them up so that the grids matter in the comparison
@@ -303,7 +310,7 @@ def test_fused_proposal_net_kernels_vs_autograd(shape, bf16):
   dd[M // 3: M // 3 + 200] = 0.                     # a stretch of samples without gradient (whole waves at the larger M)
   G = lambda a: a.to(dev).contiguous()
   raw, dens = torch.empty(M, device=dev), torch.empty(M, device=dev)
-  L.call('hugs_nf_prop_fwd', M, in_dim, H, bf16, G(Xd), ldx, G(W0), ldw0, G(b0), G(w1), ldw1, G(b1), G(sel), raw, dens)
+  L.call('hugs_nf_prop_fwd', M, in_dim, H, bf16, G(Xd), ldx, G(W0), ldw0, G(b0), G(w1), ldw1, G(b1), G(sel), raw, dens, 0, -1.0)
   # float64 reference on the values the kernel saw
   x64 = Xd.double()[:, :in_dim].requires_grad_(True)
   W0ref = W0.to(tdt).float() if mfma else W0
@@ -318,7 +325,7 @@ def test_fused_proposal_net_kernels_vs_autograd(shape, bf16):
   dX = torch.full((M, ldx), 3.0, device=dev, dtype=tdt)
   gW0, gb0, gw1, gb1 = (torch.full(s_, 5.0, device=dev) for s_ in ((128, ldw0), (128,), (128, ldw1), (1,)))
   ws = torch.empty(L.lib().cdll.hugs_nf_prop_ws_bytes(in_dim) // 4, device=dev)
-  L.call('hugs_nf_prop_bwd', M, in_dim, H, bf16, G(Xd), ldx, G(W0), ldw0, G(b0), G(w1), ldw1, raw, G(sel), G(dd), dX, gW0, gb0, gw1, gb1, ws, 0)
+  L.call('hugs_nf_prop_bwd', M, in_dim, H, bf16, G(Xd), ldx, G(W0), ldw0, G(b0), G(w1), ldw1, raw, G(sel), G(dd), dX, gW0, gb0, gw1, gb1, ws, 0, 0, -1.0)
   tol = lambda ref, rel: rel * max(1e-6, float(ref.abs().max()))
   assert float((gW0[:in_dim, :H].cpu().double() - P[0].grad).abs().max()) < tol(P[0].grad, 2e-4 + (2 * eps16 if mfma else 0))
   assert float((gb0[:H].cpu().double() - P[1].grad).abs().max()) < tol(P[1].grad, 2e-4)
@@ -411,10 +418,10 @@ def test_cfg5_16384_rays_bf16_properties(cdt):
   np.testing.assert_allclose(runs[0][:, 1], runs[1][:, 1], rtol=3e-2)
 
 
-def _cfg5_model_and_batch(cdt, N, seed=3):
+def _cfg5_model_and_batch(cdt, N, seed=3, **over):
   from nerf_hugs_amd.nerfacto.model import NerfactoConfig, NerfactoModel
   from nerf_hugs_amd.nerfacto.configs import PHOTOTOURISM_NERFACTO_BASE as YML
-  model = NerfactoModel(NerfactoConfig(**YML), compute_dtype=cdt, seed=seed)
+  model = NerfactoModel(NerfactoConfig(**dict(YML, **over)), compute_dtype=cdt, seed=seed)
   g = torch.Generator(device=dev).manual_seed(100)
   # (tables at their U(+-1e-4) init leave the field at its biases: scale them so the hash features matter; biases off zero)
   for name, (off, pshape, shape) in model.lay.items.items():
@@ -475,13 +482,13 @@ def test_fused_field_forward_equals_layer_by_layer(cdt, monkeypatch):
     assert float((a[k] - b[k]).abs().max()) < 2e-3, (k, float((a[k] - b[k]).abs().max()), float((a[k] - b[k]).abs().mean()))
 
 
-@pytest.mark.parametrize('cdt', ['bf16', 'fp16'])
-def test_fused_field_step_gradients_equal_layer_by_layer(cdt, monkeypatch):
+@pytest.mark.parametrize('cdt,act', [('bf16', 'trunc_exp'), ('fp16', 'trunc_exp'), ('bf16', 'softplus')])
+def test_fused_field_step_gradients_equal_layer_by_layer(cdt, act, monkeypatch):
   """One whole train step (no update) with the fused field kernels (forward only; forward + backward: k_field_fwd / k_field_bwd) vs
   the layer-by-layer path: the same loss statistics and the same parameter gradients up to 16-bit rounding of the intermediate
   gradients (the same roundings at the same places, other accumulation orders) and the float-atomic table / embedding scatter."""
   N = 512
-  model, batch, u01 = _cfg5_model_and_batch(cdt, N)
+  model, batch, u01 = _cfg5_model_and_batch(cdt, N, density_activation=act)      # (round 5: + the softplus activation in the fused kernels)
   out = {}
   for mode in (('0', '0'), ('1', '0'), ('1', '1')):
     monkeypatch.setenv('HUGS_NF_FIELD_FUSE', mode[0])
@@ -545,7 +552,7 @@ def test_fused_field_kernels_vs_torch(dt):
   H0, H1 = torch.empty(M, 256, dtype=tdt, device=dev), torch.empty(M, 256, dtype=tdt, device=dev)
   bY0, bH0 = torch.zeros(M * 8, dtype=torch.int32, device=dev), torch.zeros(M * 8, dtype=torch.int32, device=dev)
   dens, rgb = torch.empty(M, device=dev), torch.empty(M, 3, device=dev)
-  L.call('hugs_nf_field_fwd', dt, M, S, X0, 128, W0t, 128, W1x, C0t, C1t, b0, b1x, cb0, cb1, c2, cb2, tmpl, ngeo, sel, Y0, raw, Xh, H0, H1, bY0, bH0, dens, rgb)
+  L.call('hugs_nf_field_fwd', dt, M, S, X0, 128, W0t, 128, W1x, C0t, C1t, b0, b1x, cb0, cb1, c2, cb2, tmpl, ngeo, sel, Y0, raw, Xh, H0, H1, bY0, bH0, dens, rgb, 0, -1.0)
   torch.cuda.synchronize()
   # reference
   rY0 = q(torch.relu(X0.float() @ W0t.float().T + b0))
@@ -568,7 +575,7 @@ def test_fused_field_kernels_vs_torch(dt):
   G0, Gb, Gy0 = torch.empty(M, 256, dtype=tdt, device=dev), torch.empty(M, 128, dtype=tdt, device=dev), torch.empty(M, 256, dtype=tdt, device=dev)
   dX0 = torch.zeros(M, 128, dtype=tdt, device=dev)
   demb = torch.zeros(5, napp, device=dev)
-  L.call('hugs_nf_field_bwd', dt, M, S, G1, C1n, C0n, W1xn, W0n, bH0, bY0, d_dens, sel, raw, ngeo, napp, eidx, G0, Gb, Gy0, dX0, 128, demb, 0)
+  L.call('hugs_nf_field_bwd', dt, M, S, G1, C1n, C0n, W1xn, W0n, bH0, bY0, d_dens, sel, raw, ngeo, napp, eidx, G0, Gb, Gy0, dX0, 128, demb, 0, 0, -1.0)
   torch.cuda.synchronize()
   rG0 = q((G1.float() @ C1t.float()) * (H0.float() > 0))
   dXh = q(G0.float() @ C0t.float())                                     # (from the kernel's own rounded G0, as it computes it)
@@ -584,7 +591,7 @@ def test_fused_field_kernels_vs_torch(dt):
   dX0f = torch.zeros(M, 128, dtype=torch.float32, device=dev)
   demb2 = torch.zeros(5, napp, device=dev)
   G1s = (G1.float() * 1e-6).to(tdt)      # gradients small enough that the 16-bit store of the half mode would flush most of them
-  L.call('hugs_nf_field_bwd', dt, M, S, G1s, C1n, C0n, W1xn, W0n, bH0, bY0, d_dens * 1e-6, sel, raw, ngeo, napp, eidx, G0, Gb, Gy0, dX0f, 128, demb2, 1)
+  L.call('hugs_nf_field_bwd', dt, M, S, G1s, C1n, C0n, W1xn, W0n, bH0, bY0, d_dens * 1e-6, sel, raw, ngeo, napp, eidx, G0, Gb, Gy0, dX0f, 128, demb2, 1, 0, -1.0)
   torch.cuda.synchronize()
   ref32 = (Gy0.float() @ W0t.float())[:, :32]
   assert float((dX0f[:, :32] - ref32).abs().max()) <= 1e-5 * float(ref32.abs().max()) and float(ref32.abs().max()) > 0
