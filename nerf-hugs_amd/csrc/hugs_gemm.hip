@@ -775,6 +775,55 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
     asm volatile("" ::: "memory");                                                        \
     GP_Q(cur, nxt, 0) GP_Q(cur, nxt, 1) GP_Q(cur, nxt, 2) GP_Q(cur, nxt, 3)               \
   }
+  // Round 5 experiment (HUGS_NT_HALF=1): the wait + barrier of an iteration sits in the MIDDLE of the stage's MFMAs.  Quarters 0, 1
+  // (fragments already in registers) are issued BEFORE it, so the matrix pipe has 16 MFMAs per wave queued while the eight waves
+  // straggle into the barrier; the LDS-DMA of stage g+4 and the reads of stage g+1's first fragments (wb[0..3], xa[0..3]) follow it
+  // next to quarters 2, 3; the other four fragments (xa[4..7], needed from quarter 2 on) are read at the top of the NEXT iteration,
+  // ahead of its barrier -- their ring slot stays valid until that barrier releases the slot's refill.
+  auto frags_late = [&](Frags& f) {
+    const unsigned char* la = lds + ((c_slot + 3) & 3) * STAGE + wm * 128 * 64 + frag_off;
+#pragma unroll
+    for (int i = 4; i < 8; ++i) f.xa[i] = *(const bf16x8_t*)(la + i * 16 * 64);
+  };
+  auto frags_early = [&](Frags& f, int h) {
+    const unsigned char* la = lds + c_slot * STAGE + wm * 128 * 64 + frag_off;
+    const unsigned char* lb = lds + c_slot * STAGE + A_BYTES + wn * 64 * 64 + frag_off;
+    if (h == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f.wb[j] = *(const bf16x8_t*)(lb + j * 16 * 64);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f.xa[i] = *(const bf16x8_t*)(la + i * 16 * 64);
+      c_slot = (c_slot + 1) & 3;
+    }
+  };
+  auto frags_early2 = [&](Frags& f, int e) {      // e = 0, 1: wb[2e], wb[2e+1]; e = 2, 3: xa[2(e-2)], xa[2(e-2)+1]; e == 3 advances the slot
+    const unsigned char* la = lds + c_slot * STAGE + wm * 128 * 64 + frag_off;
+    const unsigned char* lb = lds + c_slot * STAGE + A_BYTES + wn * 64 * 64 + frag_off;
+    if (e < 2) { f.wb[2 * e] = *(const bf16x8_t*)(lb + (2 * e) * 16 * 64); f.wb[2 * e + 1] = *(const bf16x8_t*)(lb + (2 * e + 1) * 16 * 64); }
+    else { f.xa[2 * (e - 2)] = *(const bf16x8_t*)(la + (2 * (e - 2)) * 16 * 64); f.xa[2 * (e - 2) + 1] = *(const bf16x8_t*)(la + (2 * (e - 2) + 1) * 16 * 64); }
+    if (e == 3) c_slot = (c_slot + 1) & 3;
+  };
+  auto mfma_row = [&](const Frags& f, int i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = HUGS_MFMA_16X16X32(f.wb[j], f.xa[i], acc[i][j], 0, 0, 0);
+  };
+#define GP_ITERH(cur, nxt, VM)                                                           \
+  {                                                                                       \
+    frags_late(cur);                                                                      \
+    mfma_piece(cur, 0); __builtin_amdgcn_sched_barrier(0);                                \
+    mfma_piece(cur, 1); __builtin_amdgcn_sched_barrier(0);                                \
+    asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");                     \
+    __builtin_amdgcn_s_barrier();                                                         \
+    asm volatile("" ::: "memory");                                                        \
+    issue_piece(0); frags_early2(nxt, 0); mfma_row(cur, 4); __builtin_amdgcn_sched_barrier(0); \
+    issue_piece(1); frags_early2(nxt, 1); mfma_row(cur, 5); __builtin_amdgcn_sched_barrier(0); \
+    issue_piece(2); frags_early2(nxt, 2); mfma_row(cur, 6); __builtin_amdgcn_sched_barrier(0); \
+    issue_piece(3); frags_early2(nxt, 3); mfma_row(cur, 7); __builtin_amdgcn_sched_barrier(0); \
+  }
+#ifndef HUGS_NT_HALF
+#define HUGS_NT_HALF 0
+#endif
 #define GP_ITER(cur, nxt, VM)                                                            \
   {                                                                                       \
     asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" ::: "memory");                     \
@@ -831,12 +880,21 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
     // What remains of the tile-boundary cost is NOT mainly a store-acknowledgement stall: a five-slot ring that requests
     // stage 4 ahead of the stores (bias from VGPRs, all 160 KiB of LDS) took only ~0.5k off these iterations and lost 1.9k in
     // its epilogue -- measured, removed; DESIGN.md section 4.
+#if HUGS_NT_HALF
+    if (EPI >= 0 && (EPI & EPI_BOUT)) { GP_ITERH(f0, f1, 28) GP_ITERH(f1, f0, 28) GP_ITERH(f0, f1, 28) }
+    else { GP_ITERH(f0, f1, 24) GP_ITERH(f1, f0, 24) GP_ITERH(f0, f1, 24) }
+    GP_ITERH(f1, f0, 8)
+    HUGS_TRP(i, 1)
+#pragma unroll 1
+    for (int st = 4; st < ns; st += 2) { GP_ITERH(f0, f1, 8) GP_ITERH(f1, f0, 8) }
+#else
     if (EPI >= 0 && (EPI & EPI_BOUT)) { GP_ITER(f0, f1, 28) GP_ITERQ(f1, f0, 28) GP_ITERQ(f0, f1, 28) }
     else { GP_ITER(f0, f1, 24) GP_ITERQ(f1, f0, 24) GP_ITERQ(f0, f1, 24) }
     GP_ITERQ(f1, f0, 8)
     HUGS_TRP(i, 1)
 #pragma unroll 1
     for (int st = 4; st < ns; st += 2) { GP_ITERQ(f0, f1, 8) GP_ITERQ(f1, f0, 8) }
+#endif
     HUGS_TRP(i, 2)
 #ifdef HUGS_MFMA32_STANDIN
 #pragma unroll
@@ -851,6 +909,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
   }
 #undef GP_ITER
 #undef GP_ITERQ
+#undef GP_ITERH
 #undef GP_Q
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dead stages past the last tile must land before the LDS is released
 }
