@@ -187,6 +187,21 @@ int hugs_sum(int n, const float* x, float scale, float* out, void* stream);
 int hugs_add_inplace(long long n, const float* src, float* dst, void* stream);
 /* dst += alpha * src: the gradient of the weight-decay term m * ||theta_group||^2 (train_utils.py:444-447) */
 int hugs_axpy(long long n, float alpha, const float* src, float* dst, void* stream);
+/* Element-wise steps of the option branches (round 5: they were torch ops).
+ *   hugs_noise_softplus: models.py:458-460,467 raw[0..n_noise) += noise_scale * noise (noise null: nothing added); density = softplus(raw + bias)
+ *   hugs_axpy_op:        models.py:478-481 y (compute dtype 0 fp32 / 1 bf16 / 2 half) += a * x (fp32) -- bottleneck noise
+ *   hugs_add_op:         dst (compute dtype) += src (compute dtype)
+ *   hugs_affine:         dst = a * src + b (fp32; src may be dst) -- rgb_premultiplier / rgb_bias folded into the rgb head (models.py:514-516)
+ *   hugs_bg_blend_fwd:   render.py:219-221 with a per-ray, per-channel background (models.py:256-261): bgw = max(0, 1 - sum_s w), rgb_out += bgw * bg
+ *   hugs_bg_blend_bwd:   d_w_total[ray, s] = (d_w_extra or 0) - (bg . d_rgb_out)[ray] where bgw > 0 */
+int hugs_noise_softplus(long long n, long long n_noise, float* raw, const float* noise, float noise_scale, float density_bias,
+                        float* density, void* stream);
+int hugs_axpy_op(int dtype, long long n, float a, const float* x, void* y, void* stream);
+int hugs_add_op(int dtype, long long n, const void* src, void* dst, void* stream);
+int hugs_affine(long long n, const float* src, float a, float b, float* dst, void* stream);
+int hugs_bg_blend_fwd(int N, int S, const float* w, const float* bg_rgb, float* rgb_out, float* bgw, void* stream);
+int hugs_bg_blend_bwd(int N, int S, const float* d_rgb_out, const float* bg_rgb, const float* bgw, const float* d_w_extra,
+                      float* d_w_total, void* stream);
 
 /* train_utils.py:442 weight_l2s, :461-462 grad norms/maxes, :351-369 clip_gradients, :466 nan_to_num, :468
  * optax.adam (:487-512), :470-473 update norms/maxes on the flat fp32 parameter buffer.

@@ -41,6 +41,12 @@ _PROTOS = {
     'hugs_sum': 'ipfps',
     'hugs_add_inplace': 'qpps',
     'hugs_axpy': 'qfpps',
+    'hugs_noise_softplus': 'qqppffps',
+    'hugs_axpy_op': 'iqfpps',
+    'hugs_add_op': 'iqpps',
+    'hugs_affine': 'qpffps',
+    'hugs_bg_blend_fwd': 'iipppps',
+    'hugs_bg_blend_bwd': 'iippppps',
     'hugs_opt_stats': 'iiippppfffppps',
     'hugs_opt_adam': 'iippppppppffffffffpps',
     'hugs_opt_adam_dyn': 'iippppppppffpfffpps',

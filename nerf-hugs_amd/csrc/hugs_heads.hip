@@ -542,3 +542,100 @@ extern "C" int hugs_rgb_bwd(int dtype, int M, int H, const void* Hact, int ldh, 
   HUGS_CHECK_LAUNCH("hugs_rgb_bwd");
   return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Round 5: the option branches' element-wise steps as kernels (they were torch ops in engine.py -- per-sample arithmetic outside the
+// library and outside a captured step).
+// ------------------------------------------------------------------------------------------------
+// models.py:458-460,467: raw += noise_scale * noise (noise null: nothing added) ; density = softplus(raw + density_bias)
+__global__ void k_noise_softplus(long long n, long long n_noise, float* __restrict__ raw, const float* __restrict__ noise, float scale,
+                                 float density_bias, float* __restrict__ density) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float r = raw[i];
+  if (noise && i < n_noise) { r = fmaf(scale, noise[i], r); raw[i] = r; }
+  density[i] = softplusf(r + density_bias);
+}
+// y (compute dtype) += a * x (fp32)            (models.py:478-481 bottleneck noise)
+template <int DT>
+__global__ void k_axpy_op(long long n, float a, const float* __restrict__ x, void* __restrict__ y) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (DT) { uint16_t* p = (uint16_t*)y + i; *p = f_to_op16(fmaf(a, x[i], op16_to_f(*p, DT)), DT); }
+  else ((float*)y)[i] = fmaf(a, x[i], ((float*)y)[i]);
+}
+// dst (compute dtype) += src (compute dtype)
+template <int DT>
+__global__ void k_add_op(long long n, const void* __restrict__ src, void* __restrict__ dst) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (DT) { uint16_t* p = (uint16_t*)dst + i; *p = f_to_op16(op16_to_f(*p, DT) + op16_to_f(((const uint16_t*)src)[i], DT), DT); }
+  else ((float*)dst)[i] += ((const float*)src)[i];
+}
+// dst = a * src + b (fp32; src may be dst)      (rgb_premultiplier / rgb_bias folded into the rgb head's weights, models.py:514-516)
+__global__ void k_affine(long long n, const float* __restrict__ src, float a, float b, float* __restrict__ dst) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = fmaf(a, src[i], b);
+}
+// render.py:219-221 with a per-ray, per-channel background (models.py:256-261): bgw = max(0, 1 - sum_s w), rgb_out += bgw * bg
+__global__ void k_bg_blend_fwd(int N, int S, const float* __restrict__ w, const float* __restrict__ bg, float* __restrict__ rgb_out,
+                               float* __restrict__ bgw) {
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (ray >= N) return;
+  float a = 0.f;
+  for (int s_ = lane; s_ < S; s_ += 64) a += w[(size_t)ray * S + s_];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d);
+  const float b = fmaxf(0.f, 1.f - a);
+  if (lane == 0) bgw[ray] = b;
+  if (lane < 3) rgb_out[ray * 3 + lane] += b * bg[ray * 3 + lane];
+}
+// its backward: d/dw_s of bgw * bg = -(bg . d_rgb_out) where 1 - sum w > 0, the same for every sample of the ray, added to d_w_extra
+__global__ void k_bg_blend_bwd(int N, int S, const float* __restrict__ d_rgb_out, const float* __restrict__ bg, const float* __restrict__ bgw,
+                               const float* __restrict__ d_w_extra, float* __restrict__ d_w_total) {
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (ray >= N) return;
+  const float dacc = bgw[ray] > 0.f ? -(d_rgb_out[ray * 3] * bg[ray * 3] + d_rgb_out[ray * 3 + 1] * bg[ray * 3 + 1] + d_rgb_out[ray * 3 + 2] * bg[ray * 3 + 2]) : 0.f;
+  for (int s_ = lane; s_ < S; s_ += 64) d_w_total[(size_t)ray * S + s_] = (d_w_extra ? d_w_extra[(size_t)ray * S + s_] : 0.f) + dacc;
+}
+
+#define HH_1D(kern, n_, ...) do { const long long nn_ = (n_); if (nn_ > 0) hipLaunchKernelGGL(kern, dim3((unsigned)((nn_ + 255) / 256)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); } while (0)
+extern "C" int hugs_noise_softplus(long long n, long long n_noise, float* raw, const float* noise, float noise_scale, float density_bias,
+                                   float* density, void* stream) {
+  HUGS_REQUIRE(raw && density && n_noise <= n, -2, "hugs_noise_softplus: null pointer / more noise values than rows");
+  HH_1D(k_noise_softplus, n, n, n_noise, raw, noise, noise_scale, density_bias, density);
+  HUGS_CHECK_LAUNCH("hugs_noise_softplus");
+  return 0;
+}
+extern "C" int hugs_axpy_op(int dtype, long long n, float a, const float* x, void* y, void* stream) {
+  HUGS_REQUIRE(dtype >= 0 && dtype <= 2 && (n == 0 || (x && y)), -2, "hugs_axpy_op: dtype %d / null pointer", dtype);
+  if (dtype == 2) HH_1D(k_axpy_op<2>, n, n, a, x, y); else if (dtype) HH_1D(k_axpy_op<1>, n, n, a, x, y); else HH_1D(k_axpy_op<0>, n, n, a, x, y);
+  HUGS_CHECK_LAUNCH("hugs_axpy_op");
+  return 0;
+}
+extern "C" int hugs_add_op(int dtype, long long n, const void* src, void* dst, void* stream) {
+  HUGS_REQUIRE(dtype >= 0 && dtype <= 2 && (n == 0 || (src && dst)), -2, "hugs_add_op: dtype %d / null pointer", dtype);
+  if (dtype == 2) HH_1D(k_add_op<2>, n, n, src, dst); else if (dtype) HH_1D(k_add_op<1>, n, n, src, dst); else HH_1D(k_add_op<0>, n, n, src, dst);
+  HUGS_CHECK_LAUNCH("hugs_add_op");
+  return 0;
+}
+extern "C" int hugs_affine(long long n, const float* src, float a, float b, float* dst, void* stream) {
+  HUGS_REQUIRE(n == 0 || (src && dst), -2, "hugs_affine: null pointer");
+  HH_1D(k_affine, n, n, src, a, b, dst);
+  HUGS_CHECK_LAUNCH("hugs_affine");
+  return 0;
+}
+extern "C" int hugs_bg_blend_fwd(int N, int S, const float* w, const float* bg_rgb, float* rgb_out, float* bgw, void* stream) {
+  HUGS_REQUIRE(N >= 0 && S > 0 && w && bg_rgb && rgb_out && bgw, -2, "hugs_bg_blend_fwd: null pointer");
+  if (N > 0) hipLaunchKernelGGL(k_bg_blend_fwd, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, N, S, w, bg_rgb, rgb_out, bgw);
+  HUGS_CHECK_LAUNCH("hugs_bg_blend_fwd");
+  return 0;
+}
+extern "C" int hugs_bg_blend_bwd(int N, int S, const float* d_rgb_out, const float* bg_rgb, const float* bgw, const float* d_w_extra,
+                                 float* d_w_total, void* stream) {
+  HUGS_REQUIRE(N >= 0 && S > 0 && d_rgb_out && bg_rgb && bgw && d_w_total, -2, "hugs_bg_blend_bwd: null pointer");
+  if (N > 0) hipLaunchKernelGGL(k_bg_blend_bwd, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, N, S, d_rgb_out, bg_rgb, bgw, d_w_extra, d_w_total);
+  HUGS_CHECK_LAUNCH("hugs_bg_blend_bwd");
+  return 0;
+}

@@ -471,8 +471,8 @@ class Engine:
       density_key, noise_key = hrandom.split(mlp_key)          # models.py:435 density_key, rng = random_split(rng)
       if spec.density_noise > 0:                                  # models.py:458-460: raw_density += noise * normal(key, [N, S])
         # the reference draws [n_real, S] values: a padded batch must not draw for its padding (another size = another stream)
-        raw[:Mr].add_(hrandom.normal(density_key, (Mr,)), alpha=float(spec.density_noise))
-        density.copy_(torch.logaddexp(raw + float(spec.density_bias), torch.zeros_like(raw)))   # softplus, as hugs_density_fwd
+        _lib.call('hugs_noise_softplus', M, Mr, raw, hrandom.normal(density_key, (Mr,)), float(spec.density_noise),
+                  float(spec.density_bias), density)      # raw += noise * normal ; density = softplus(raw + bias), as hugs_density_fwd
     out = dict(X0=X0, acts=acts, raw=raw, density=density, rgb=None, bits=bits if nchunk == 1 else [None] * len(bits))
     if not spec.disable_rgb and not spec.use_viewdirs:
       lr = spec.layers[spec.net_depth + 1]
@@ -489,7 +489,7 @@ class Engine:
       if noise_key is not None and spec.bottleneck_noise > 0:   # models.py:478-481: bottleneck += noise * normal(key, [N, S, Bw])
         from . import random as hrandom
         kb, _ = hrandom.split(noise_key)
-        bott[:Mr].add_(hrandom.normal(kb, (Mr, Bw)).to(bott.dtype), alpha=float(spec.bottleneck_noise))
+        _lib.call('hugs_axpy_op', dt, Mr * Bw, float(spec.bottleneck_noise), hrandom.normal(kb, (Mr, Bw)), bott)
       Wv = lay.view(theta, (spec.name, lv['name'], 'kernel'))
       rb = ws.get(tag + '/raybias', (N, H))
       _lib.call('hugs_raybias_fwd', N, H, spec.nd, spec.num_glo, rays['dir_enc'], glo, Wv[Bw:],
@@ -618,8 +618,8 @@ class Engine:
         if out.get('dens_t') is not None:
           raise NotImplementedError('a random background together with the NeRF-W transient branch')
         bgw = ws.get(f'L{lvl}/bgw', (N,))
-        torch.sum(w, dim=-1, out=bgw); bgw.neg_().add_(1.0).clamp_(min=0.0)
-        rgb_out.addcmul_(bgw[:, None], bg_rgb)      # (proposal levels too: their colours are zero, the background term is not)
+        # (proposal levels too: their colours are zero, the background term is not)
+        _lib.call('hugs_bg_blend_fwd', N, S, w, bg_rgb.contiguous(), rgb_out, bgw)
         out.update(bg_rgb=bg_rgb, bgw=bgw)
       if out.get('dens_t') is not None:     # models.py:285-307
         nw = {k: ws.get(f'L{lvl}/{k}', (N, 3)) for k in ('rgb_combined', 'rgb_static', 'rgb_transient')}
@@ -690,9 +690,8 @@ class Engine:
     if p_ == 1. and r_ == 0.:
       return W, b
     We, be = self.ws.get(tag + '/W_eff', tuple(W.shape)), self.ws.get(tag + '/b_eff', (4,))
-    torch.mul(W, p_, out=We)
-    torch.mul(b, p_, out=be[:3])
-    be[:3].add_(r_)
+    _lib.call('hugs_affine', W.numel(), W, p_, 0.0, We)
+    _lib.call('hugs_affine', 3, b, p_, r_, be)
     return We, be
 
   def backward_level(self, theta, grad, lv, rays, N, d_rgb_out, d_w_extra, nerfw=None, leaf_done=None, lane=0, after_heads=None,
@@ -715,14 +714,8 @@ class Engine:
       bg_int = 0.0
       if d_rgb_out is not None:
         # d/dw_s of bg_w * bg = -(bg . d_rgb_out) where 1 - sum w > 0, the same for every sample of the ray
-        dacc = ws.get(tag + '/d_bgw', (N,))
-        torch.sum(d_rgb_out * lv['bg_rgb'], dim=-1, out=dacc)
-        dacc.mul_((lv['bgw'] > 0).to(dacc.dtype)).neg_()
         dwt = ws.get(tag + '/d_w_total', (N, S))
-        if d_w_extra is not None:
-          torch.add(d_w_extra, dacc[:, None], out=dwt)
-        else:
-          dwt.copy_(dacc[:, None].expand(N, S))
+        _lib.call('hugs_bg_blend_bwd', N, S, d_rgb_out, lv['bg_rgb'].contiguous(), lv['bgw'], d_w_extra, dwt)
         d_w_extra = dwt
     _lib.call('hugs_composite_bwd', N, S, lv['density'], lv['rgb'], lv['tdist'], rays['directions'],
               int(self.model.opaque_background), bg_int, d_rgb_out, d_w_extra, d_density, d_rgb_s)
@@ -766,10 +759,10 @@ class Engine:
       _lib.call('hugs_rgb_bwd', dt, M, W, Ylast, W, Wr, lv['rgb'], d_rgb_s, spec.rgb_padding, Ga, W,
                 gview((spec.name, lr['name'], 'kernel'), True), gview((spec.name, lr['name'], 'bias')), rws)
       if spec.rgb_premultiplier != 1.:
-        gview((spec.name, lr['name'], 'kernel'), True).mul_(float(spec.rgb_premultiplier))
-        gview((spec.name, lr['name'], 'bias')).mul_(float(spec.rgb_premultiplier))
+        for g_ in (gview((spec.name, lr['name'], 'kernel'), True), gview((spec.name, lr['name'], 'bias'))):
+          _lib.call('hugs_affine', g_.numel(), g_, float(spec.rgb_premultiplier), 0.0, g_)
       _lib.call('hugs_rank1_mask', dt, M, W, d_raw, wd, Ylast, W, Gb, W)
-      Ga.add_(Gb)
+      _lib.call('hugs_add_op', dt, M * W, Gb, Ga)
     else:
       lb, lvw, lvx, lr = spec.head_layers()
       Bw, H = spec.bottleneck_width, spec.net_width_viewdirs
@@ -780,8 +773,8 @@ class Engine:
                 d_rgb_s, spec.rgb_padding, Gv, H, gview((spec.name, lr['name'], 'kernel')),
                 gview((spec.name, lr['name'], 'bias')), rws)
       if spec.rgb_premultiplier != 1.:
-        gview((spec.name, lr['name'], 'kernel')).mul_(float(spec.rgb_premultiplier))
-        gview((spec.name, lr['name'], 'bias')).mul_(float(spec.rgb_premultiplier))
+        for g_ in (gview((spec.name, lr['name'], 'kernel')), gview((spec.name, lr['name'], 'bias'))):
+          _lib.call('hugs_affine', g_.numel(), g_, float(spec.rgb_premultiplier), 0.0, g_)
       # net_depth_viewdirs > 1: back through the further view layers, last to first -- dW_i = h_{i-1}^T G_i, db_i = colsum G_i,
       # G_{i-1} = (G_i W_i^T) * (h_{i-1} > 0); Gv ends up as the gradient at the FIRST view layer's pre-activation, as below expects
       hvs = lv.get('hviews') or [lv['hview']]
@@ -1013,8 +1006,8 @@ class Engine:
     _lib.call('hugs_rgb_bwd', dt, M, Ht, x3, Ht, Wrt, lv['rgb_t'], d_ct,
               spec.rgb_padding, G, Ht, gview((spec.name, lr_['name'], 'kernel')), gview((spec.name, lr_['name'], 'bias')), rws)
     if spec.rgb_premultiplier != 1.:
-      gview((spec.name, lr_['name'], 'kernel')).mul_(float(spec.rgb_premultiplier))
-      gview((spec.name, lr_['name'], 'bias')).mul_(float(spec.rgb_premultiplier))
+      for g_ in (gview((spec.name, lr_['name'], 'kernel')), gview((spec.name, lr_['name'], 'bias'))):
+        _lib.call('hugs_affine', g_.numel(), g_, float(spec.rgb_premultiplier), 0.0, g_)
     dws = ws.get('dens_ws_t', (max(_lib.lib().cdll.hugs_density_bwd_ws_bytes(Ht) // 4, 1),))
     d_raw_t, d_raw_u = ws.get('tbwd/d_raw_t', (M,)), ws.get('tbwd/d_raw_u', (M,))
     _lib.call('hugs_density_bwd', dt, M, Ht, x3, Ht, d_dt, lv['raw_t'], spec.density_bias, d_raw_t,

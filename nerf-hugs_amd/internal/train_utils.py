@@ -598,7 +598,7 @@ def create_train_step(model, config, is_finetune=False):
     packed = ws.get('stats_packed', (STAT_TAIL + nleaf * 6 + 16,))
     packed[:STAT_TAIL].copy_(tail)
     if world > 1:
-      packed[:STAT_TAIL].mul_(gscale)
+      _lib.call('hugs_affine', STAT_TAIL, packed, gscale, 0.0, packed)
     assert leaf_stats.data_ptr() == packed[STAT_TAIL:].data_ptr()
     if tt == 'robustnerf':
       if 'thr_dev' not in cache:
