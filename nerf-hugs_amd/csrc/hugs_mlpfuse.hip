@@ -409,6 +409,210 @@ __global__ __launch_bounds__(256, 1) void k_mlp256_chain3_fwd(const MlpTail P) {
 
 
 // ------------------------------------------------------------------------------------------------
+// The same forward chain on EIGHT waves (two per SIMD): wave wq owns output columns [32 wq, 32 wq + 32) of all 64 rows, i.e. 64
+// registers of every weight matrix (192 of its 256).  One wave per SIMD (the kernel above) leaves every LDS latency, barrier and the
+// whole epilogue exposed -- ~20 k cycles per tile for 6 k cycles of MFMAs; with two waves per SIMD one wave's epilogue and waits sit
+// under the other's MFMAs.  Costs: every wave reads the whole activation tile as its B operand (LDS fragment traffic 128 -> 256 KB per
+// layer and tile, 1 k cycles at 256 B/clk: under the 2 k cycles of MFMAs per SIMD and layer), and two waves share each 32-bit word of
+// the mask-bit layout (their halves are OR-ed through LDS behind the layer's barrier).  The density head is an fp32 dot product on the
+// lane's 8 rounded outputs (no operand fragments in LDS: the 24 KiB they took do not fit next to four tiles here).
+// ------------------------------------------------------------------------------------------------
+#ifdef MC_TRACE      // (timing builds: s_memtime at the phase edges of workgroup 0's first tiles, waves 0 and 7; scratch/mc_trace.py)
+__device__ long long mc_trace_buf[2 * 8 * 16];
+#define MC_TP(k_) do { if (blockIdx.x == 0 && ti < 8 && (tid == 0 || tid == 448)) mc_trace_buf[((tid != 0) * 8 + ti) * 16 + (k_)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define MC_TP(k_) do { } while (0)
+#endif
+#ifndef MC_DMA_LAYER
+#define MC_DMA_LAYER 2      // the layer whose loop carries the next tile's LDS-DMA requests (2: behind layer 2's copy-out; 3: behind layer 3's)
+#endif
+template <bool HEAD, class Mid>
+__device__ __forceinline__ void mc8_layer(const unsigned char* A, int frag_off, const mf_bf16x8_t (&w)[8][2], const float* bias /* LDS, + wq*32 + kb*4 */,
+                                          int wq, int r16, int kb, int lane, unsigned char* An, uint32_t* bpart /* LDS [2][64] of this wave */,
+                                          bool do_cp, const unsigned char* cp_src, char* cp_dst, int tid, const float* wd_lds /* + wq*32 + kb*4 */,
+                                          float (*red)[8][4], Mid&& mid /* runs behind the copy-out's stores (row block 1) */) {
+  const int swz = 3 * ((r16 >> 2) & 1);
+  // (ONE accumulator set: with two waves per SIMD the other wave's MFMAs cover this wave's epilogue; the double-buffered form of
+  //  the four-wave kernel spilled 7 registers here, reloaded inside the tile loop)
+  mf_f32x4_t acc[1][2];
+  auto acc_init = [&](mf_f32x4_t (&a)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const float4 bb = *(const float4*)(bias + j * 16); a[j] = mf_f32x4_t{bb.x, bb.y, bb.z, bb.w}; }
+  };
+  auto mma_half = [&](int i, int h, mf_f32x4_t (&a)[2]) {
+    mf_bf16x8_t xa[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) xa[s] = *(const mf_bf16x8_t*)(A + (h * 4 + s) * MC_STAGE + frag_off + i * 16 * 64);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) a[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[h * 4 + s][j], xa[s], a[j], 0, 0, 0);
+  };
+  const int jj0 = (wq & 1) * 2;      // this wave's fragments are j = jj0, jj0 + 1 of its NT wave's 64-column block
+  uint32_t bw = 0u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    acc_init(acc[0]); mma_half(i, 0, acc[0]); mma_half(i, 1, acc[0]);
+    if (i == 0 && do_cp) {
+      // this thread's share of a finished tile: 2048 16-byte chunks over 512 threads (chunk id = q * 512 + tid: row q * 16 + (tid >> 5))
+      typedef unsigned __attribute__((ext_vector_type(4))) u4;
+      const int t_ = (int)mc_fresh((unsigned)tid), r0 = t_ >> 5, cc = t_ & 31;
+      const unsigned lo = (unsigned)((cc >> 2) * MC_STAGE + r0 * 64 + (((cc & 3) ^ (3 * ((r0 >> 2) & 1))) << 4));
+      const unsigned go = (unsigned)(r0 * 512 + cc * 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const u4 v = *(const u4*)(cp_src + lo + q * 1024);
+        __builtin_nontemporal_store(v, (u4*)(cp_dst + (size_t)q * 8192 + go));
+      }
+    }
+    if (i == 1) mid();
+    float dsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const mf_f32x4_t v = acc[0][j];
+      uint2 u;
+      u.x = mc_relu_pk(mf_cvt_pk(v[0], v[1])); u.y = mc_relu_pk(mf_cvt_pk(v[2], v[3]));
+      const int ch = j * 2 + (kb >> 1);
+      *(uint2*)(An + wq * MC_STAGE + (i * 16 + r16) * 64 + ((ch ^ swz) << 4) + (kb & 1) * 8) = u;
+      const int k = (i & 1) * 8 + (jj0 + j) * 2;
+      bw |= mc_nz_pk(u.x) << k;
+      bw |= mc_nz_pk(u.y) << (k + 1);
+      if (HEAD) {      // (w_d from LDS at use: eight more resident registers spilled)
+        const float4 wv = *(const float4*)(wd_lds + j * 16);
+        dsum = fmaf(__uint_as_float(u.x << 16), wv.x, dsum); dsum = fmaf(__uint_as_float(u.x & 0xffff0000u), wv.y, dsum);
+        dsum = fmaf(__uint_as_float(u.y << 16), wv.z, dsum); dsum = fmaf(__uint_as_float(u.y & 0xffff0000u), wv.w, dsum);
+      }
+    }
+    if (i & 1) { bpart[(i >> 1) * 64 + lane] = bw; bw = 0u; }
+    if (HEAD) red[i * 16 + r16][wq][kb] = dsum;
+    __builtin_amdgcn_sched_barrier(0);      // (nothing of the next row block -- its 8 fragment reads -- is hoisted above this epilogue)
+  }
+}
+
+__global__ __launch_bounds__(512, 1) void k_mlp256_chain3_fwd8(const MlpTail P) {
+  __shared__ __attribute__((aligned(16))) unsigned char act[4][MC_ACT];      // X (DMA target), P, Q, R
+  __shared__ __attribute__((aligned(16))) float bs[3 * 256];
+  __shared__ __attribute__((aligned(16))) float wds[256];
+  __shared__ uint32_t bparts[2][8][2][64];                                   // [layer parity][wave][word][lane]: mask-bit halves
+  __shared__ __attribute__((aligned(16))) float red[MC_ROWS][8][4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kb = lane >> 4;
+  const int swz = 3 * ((r16 >> 2) & 1);
+  const int frag_off = r16 * 64 + ((kb ^ swz) << 4);
+  const int ntile = P.M / MC_ROWS, G = (int)gridDim.x;
+  for (int e = tid; e < 768; e += 512) bs[e] = P.bias[e >> 8][e & 255];
+  if (tid < 256) wds[tid] = P.wd ? P.wd[tid] : 0.f;
+  const float* wdv = wds + wq * 32 + kb * 4;
+  mf_bf16x8_t w1[8][2], w2[8][2], w3[8][2];
+  {
+    const unsigned wo = (unsigned)((wq * 32 + r16) * 256 + kb * 8) * 2u;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        w1[s][j] = *(const mf_bf16x8_t*)((const char*)P.Wt[0] + (wo + (unsigned)(j * 16 * 256 + s * 32) * 2u));
+        w2[s][j] = *(const mf_bf16x8_t*)((const char*)P.Wt[1] + (wo + (unsigned)(j * 16 * 256 + s * 32) * 2u));
+        w3[s][j] = *(const mf_bf16x8_t*)((const char*)P.Wt[2] + (wo + (unsigned)(j * 16 * 256 + s * 32) * 2u));
+      }
+  }
+  // Loads and stores of a CU go through one in-order vector-memory path: a store issued while the next tile's LDS-DMA requests are in
+  // flight -- an 8 MB read burst when all CUs do it -- waits for them (phase trace, scratch/mc_trace.py: with the requests issued behind
+  // the first barrier, layer 2 took 7.0 k cycles against layer 1's 3.1 k; giving loads and stores to different WAVES did not help:
+  // 5.3 / 6.6 k, the path is shared).  So the requests are issued as late as the tile allows: in layer 3, behind its copy-out stores.
+  // LDS-DMA of a tile's Y0 rows: 32 units of (stage, 16-row block), four per wave
+  const unsigned dma_voff = (unsigned)((lane >> 2) * 256 + (((lane & 3) ^ (3 * (((lane >> 2) >> 2) & 1))) << 3)) * 2u;
+  const unsigned lds_x = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)act[0];
+  auto issue_dma = [&](int t_) {
+    const char* base = (const char*)P.Y0 + (size_t)t_ * MC_ROWS * 512;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int u = wq * 4 + q, s_ = u >> 2, rb = u & 3;
+      const char* sb = base + (size_t)rb * 16 * 512 + s_ * 64;
+      const unsigned la = lds_x + (unsigned)(s_ * MC_STAGE + rb * 1024);
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sb), "v"(dma_voff), "s"(la) : "memory", "m0");
+    }
+  };
+  // the two waves of a pair each hold half of the pair's mask words: wave 2p stores word 0, wave 2p + 1 word 1 (ONE store per wave and layer)
+  auto bits_out = [&](int par, uint32_t* bits, int m0) {
+    const int p2 = wq & ~1, wd_ = wq & 1;
+    const uint32_t v = bparts[par][p2][wd_][lane] | bparts[par][p2 + 1][wd_][lane];
+    uint32_t* btile = bits + ((size_t)(m0 >> 8) * 8 + (size_t)(((m0 >> 7) & 1) * 4 + (wq >> 1))) * 256;
+    const int i_nt0 = ((m0 >> 6) & 1) * 4;
+    *(uint32_t*)((char*)btile + (mc_fresh((unsigned)lane * 4u) + (unsigned)(((i_nt0 >> 1) + wd_) * 64) * 4u)) = v;
+  };
+  if ((int)blockIdx.x < ntile) issue_dma((int)blockIdx.x);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int prev_m0 = -1, ti = -1;
+  for (int t = blockIdx.x; t < ntile; t += G) {
+    const int m0 = t * MC_ROWS;
+    const bool has_next = t + G < ntile;
+    ++ti;
+    MC_TP(0);
+    auto nothing = [] {};
+    mc8_layer<false>(act[0], frag_off, w1, bs + wq * 32 + kb * 4, wq, r16, kb, lane, act[1], &bparts[0][wq][0][0], prev_m0 >= 0, act[3],
+                     (char*)(P.Y[2] + (size_t)(prev_m0 < 0 ? 0 : prev_m0) * 256), tid, wdv, red, nothing);
+    MC_TP(1);
+    __syncthreads();
+    MC_TP(2);
+    bits_out(0, P.bits[0], m0);
+    MC_TP(3);
+    auto dma_next = [&] { if (has_next) issue_dma(t + G); };      // (X is free since the first barrier)
+    mc8_layer<false>(act[1], frag_off, w2, bs + 256 + wq * 32 + kb * 4, wq, r16, kb, lane, act[2], &bparts[1][wq][0][0], true, act[1],
+#if MC_DMA_LAYER == 2
+                     (char*)(P.Y[0] + (size_t)m0 * 256), tid, wdv, red, dma_next);
+#else
+                     (char*)(P.Y[0] + (size_t)m0 * 256), tid, wdv, red, nothing);
+#endif
+    MC_TP(4);
+    __syncthreads();
+    MC_TP(5);
+    bits_out(1, P.bits[1], m0);
+    mc8_layer<true>(act[2], frag_off, w3, bs + 512 + wq * 32 + kb * 4, wq, r16, kb, lane, act[3], &bparts[0][wq][0][0], true, act[2],
+#if MC_DMA_LAYER == 2
+                    (char*)(P.Y[1] + (size_t)m0 * 256), tid, wdv, red, nothing);
+    // the next tile's rows: requested before 1 + 4 stores of this thread (layer 2's mask word, layer 3's copy-out), which may stay in flight
+    MC_TP(6);
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+#else
+                    (char*)(P.Y[1] + (size_t)m0 * 256), tid, wdv, red, dma_next);
+    // the next tile's rows: requested behind every store of the tile
+    MC_TP(6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    MC_TP(7);
+    __syncthreads();
+    MC_TP(8);
+    bits_out(0, P.bits[2], m0);
+    if (P.wd && wq < 4) {
+      // raw density of the tile's 64 rows: four threads per row, each sums two waves' four partial sums, a quad reduction (DPP) adds them
+      // (as ONE wave's job -- 32 scalar LDS reads, exp, log per lane -- it made that wave 1.4 k cycles late for the next tile)
+      const int row = tid >> 2, p4 = tid & 3;
+      const float4 a = *(const float4*)&red[row][p4][0], b = *(const float4*)&red[row][p4 + 4][0];
+      float r = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
+      r += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(r), 0xB1, 0xf, 0xf, true));      // quad_perm [1,0,3,2]
+      r += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(r), 0x4E, 0xf, 0xf, true));      // quad_perm [2,3,0,1]
+      if (p4 == 0) {
+        r += P.bd[0];
+        *(float*)((char*)(P.raw + m0) + mc_fresh((unsigned)row * 4u)) = r;
+        *(float*)((char*)(P.density + m0) + mc_fresh((unsigned)row * 4u)) = mf_softplus(r + P.density_bias);
+      }
+    }
+    MC_TP(9);
+    prev_m0 = m0;
+  }
+  if (prev_m0 >= 0) {
+    typedef unsigned __attribute__((ext_vector_type(4))) u4;
+    const int r0 = tid >> 5, cc = tid & 31;
+    const unsigned lo = (unsigned)((cc >> 2) * MC_STAGE + r0 * 64 + (((cc & 3) ^ (3 * ((r0 >> 2) & 1))) << 4));
+    char* dst = (char*)(P.Y[2] + (size_t)prev_m0 * 256);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(u4*)(dst + (size_t)q * 8192 + (unsigned)(r0 * 512 + cc * 16)) = *(const u4*)(act[3] + lo + q * 1024);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Round 5: the backward twin -- the dX chain of the same three layers from the density head's gradient down to the gradient at
 // layer 0's pre-activation (what jax.value_and_grad derives for models.py:451-456,467 with disable_rgb), one launch:
 //   G3 = (d_raw (x) w_d) * (Y3 > 0)          G2 = (G3 W3^T) * (Y2 > 0)       G1 = (G2 W2^T) * (Y1 > 0)       G0 = (G1 W1^T) * (Y0 > 0)
@@ -610,7 +814,10 @@ extern "C" int hugs_mlp256_tail_fwd(int dtype, int M, int nl, const void* Y0, co
   static const bool chain3 = []() { const char* e = getenv("HUGS_MLPFUSE_CHAIN3"); return !(e && e[0] == '0'); }();
   if (chain3 && nl == 3 && P.bits[0] && P.bits[1] && P.bits[2]) {
     const int ntile = M / 64;
-    hipLaunchKernelGGL(k_mlp256_chain3_fwd, dim3(ntile < ncu ? ntile : ncu), dim3(256), 0, (hipStream_t)stream, P);
+    // HUGS_MLPFUSE_WAVES=4: the one-wave-per-SIMD form; default 8 (two waves per SIMD)
+    static const bool waves8 = []() { const char* e = getenv("HUGS_MLPFUSE_WAVES"); return !(e && e[0] == '4'); }();
+    if (waves8) hipLaunchKernelGGL(k_mlp256_chain3_fwd8, dim3(ntile < ncu ? ntile : ncu), dim3(512), 0, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL(k_mlp256_chain3_fwd, dim3(ntile < ncu ? ntile : ncu), dim3(256), 0, (hipStream_t)stream, P);
     HUGS_CHECK_LAUNCH("hugs_mlp256_tail_fwd(chain3)");
     return 0;
   }
@@ -646,3 +853,7 @@ extern "C" int hugs_mlp256_tail_bwd(int dtype, int M, int nl, const float* d_raw
   HUGS_CHECK_LAUNCH("hugs_mlp256_tail_bwd");
   return 0;
 }
+
+#ifdef MC_TRACE
+extern "C" int hugs_mc_trace_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mc_trace_buf), sizeof(long long) * 256); }
+#endif
