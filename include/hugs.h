@@ -219,11 +219,25 @@ int hugs_opt_adam_dyn(int nchunks, int nleaf, const void* chunks, const void* le
                       float* m, float* v, const float* mod_scale, const int* trainable, float gscale, float max_val,
                       const float* dyn, float b1, float b2, float eps, float* part2_ws, float* leaf_upd, void* stream);
 int hugs_set_floats(float* dst, int n, float a, float b, float c, float d, void* stream);
+/* hugs_opt_adam_dyn whose last launch also publishes what the captured step hands back (train_utils.py:475-477 returns new_state,
+ * stats, rng): packed[0..ntail) = tail * tscale (the pmean'ed stat tail), thr_dst[l] = packed[thr_off + l * thr_stride] (train.py:145-148's
+ * inlier-threshold feedback, on the device), the packed stats to the pinned host slot ptrs[0] and the advanced key to key_dst and to the
+ * device buffer ptrs[1] -- ptrs is a DEVICE table of two addresses that the step's staging launch (hugs_stage_step_pub) fills, since a
+ * captured launch's own arguments cannot change.  pub: 12 host words {tail, packed, ntail, npacked, tscale (float bits), thr_dst (or 0),
+ * thr_off, thr_stride, thr_n, key_src (or 0), key_dst (or 0), ptrs (or 0)}. */
+int hugs_opt_adam_pub(int nchunks, int nleaf, const void* chunks, const void* leaf_info, float* theta, const float* grad,
+                      float* m, float* v, const float* mod_scale, const int* trainable, float gscale, float max_val,
+                      const float* dyn, float b1, float b2, float eps, float* part2_ws, float* leaf_upd,
+                      const unsigned long long* pub, void* stream);
 /* One launch in front of a replayed (captured) train step (train_utils.py:386-477's inputs: rays, batch.rgb, rng; train_frac through
  * the scalars): item i copies words[i] 4-byte words src[i] -> dst[i] (n <= 16; HOST arrays of device pointers), dst_f[0..nf) =
  * {a, b, c, d}[0..nf) as hugs_set_floats. */
 int hugs_stage_step(int n, const void* const* src, void* const* dst, const int* words, float* dst_f, int nf, float a, float b, float c,
                     float d, void* stream);
+/* The same launch, which also writes dst_p[0..1] = {p0, p1} (device table of two addresses read back by hugs_opt_adam_pub's last launch;
+ * 0 = nothing to publish there). */
+int hugs_stage_step_pub(int n, const void* const* src, void* const* dst, const int* words, float* dst_f, int nf, float a, float b,
+                        float c, float d, void* dst_p, void* p0, void* p1, void* stream);
 /* fp32 master [K,N] -> compute-dtype copies Wn [K,N] and Wt [N,K] (either may be NULL) */
 int hugs_cast_weights(int dtype, int K, int N, const float* W, void* Wn, void* Wt, void* stream);
 /* The same cast for a device table of matrices in one launch.  items: nitems records of 40 bytes

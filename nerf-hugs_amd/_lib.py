@@ -52,6 +52,8 @@ _PROTOS = {
     'hugs_opt_adam_dyn': 'iippppppppffpfffpps',
     'hugs_set_floats': 'piffffs',
     'hugs_stage_step': 'ippppiffffs',
+    'hugs_stage_step_pub': 'ippppiffffppps',
+    'hugs_opt_adam_pub': 'iippppppppffpfffppps',
     'hugs_level_sample_fwd_dyn': 'ippiifffpfppiiiipppps',
     'hugs_cast_weights': 'iiippps',
     'hugs_cast_weights_batch': 'iipis',

@@ -9,8 +9,17 @@
 // integrated_pos_enc with math.py:26-38 safe_sin; coord.py:136-147 pos_enc (view directions).
 #include "hugs_common.h"
 
-#define ENC_SAMPLES 32   // samples per workgroup
+#define ENC_SAMPLES_F32 32    // samples per workgroup, fp32 parity build (unchanged since round 1: its instruction stream is pinned)
+#define ENC_SAMPLES_BF16 64   // bf16 (round 5): the per-sample Gaussian step fills one whole wave
 #define ENC_NB 21        // max basis directions (icosahedron, 2 subdivisions)
+
+typedef float enc_f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 enc_bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t enc_pk_bf16(float a, float b) {      // one v_cvt_pk_bf16_f32 (RNE)
+  const enc_f32x2_t f = {a, b};
+  const enc_bf16x2_t h = __builtin_convertvector(f, enc_bf16x2_t);
+  return *(const uint32_t*)&h;
+}
 
 __device__ __forceinline__ float safe_sinf(float x) {
   // math.py:26-38: sin(where(|x| < 100pi, x, x mod 100pi)), python-style mod
@@ -24,6 +33,7 @@ __global__ __launch_bounds__(256) void k_cast_ipe(int nrays, int S, const float*
                                                   const float* __restrict__ origins, const float* __restrict__ dirs,
                                                   const float* __restrict__ radii, const float* __restrict__ basis, int nb,
                                                   int ray_shape, int warp, int max_deg, int kp, void* __restrict__ out) {
+  constexpr int ENC_SAMPLES = BF16 ? ENC_SAMPLES_BF16 : ENC_SAMPLES_F32;
   __shared__ float s_mean[ENC_SAMPLES][3];
   __shared__ float s_cov[ENC_SAMPLES][6];
   __shared__ float s_lm[ENC_SAMPLES][ENC_NB + 1];
@@ -101,12 +111,62 @@ __global__ __launch_bounds__(256) void k_cast_ipe(int nrays, int S, const float*
     const float r1 = c[1] * b0 + c[3] * b1 + c[4] * b2;
     const float r2 = c[2] * b0 + c[4] * b1 + c[5] * b2;
     s_lv[s][j] = b0 * r0 + b1 * r1 + b2 * r2;
+    if (BF16) {      // the bf16 feature loop's operands: revolutions and the base-2 exponent (powers of two scale both exactly)
+      s_lm[s][j] *= 0.15915494309189533577f;
+      s_lv[s][j] *= -0.72134752044448170368f;      // -0.5 log2(e)
+    }
   }
   __syncthreads();
-  // one wave writes one whole row: lane owns 8 consecutive features.  Which (half, degree k, basis j) a feature column
-  // is does not depend on the sample: decoded once per lane (no integer division in the per-sample loop).
   const int lane = tid & 63, wv = tid >> 6;
   const int nfeat_half = nb * max_deg;
+  if constexpr (BF16) {
+    if ((nfeat_half & 3) == 0) {
+      // Round 5 (the loop below spent ~30 vector instructions per feature and ran at 2.9 TB/s of output at 1 M samples): a lane owns
+      // FOUR (degree k, basis j) columns and produces both halves of each -- sin(x) and sin(x + pi/2) share the attenuation
+      // exp(-var/2), the argument is kept in revolutions (a power-of-two scale is exact: fract, v_sin_f32) and the exponent in base 2
+      // (v_exp_f32), pairs leave through v_cvt_pk_bf16_f32.  8 bytes per lane into the sin half, 8 into the cos half of the row.
+      for (int c0 = lane * 4; c0 < nfeat_half; c0 += 256) {
+        int jq[4];
+        float scs[4], sc2[4];
+        {
+          int k = c0 / nb, j = c0 - k * nb;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            jq[q] = j;
+            scs[q] = __int_as_float((127 + ((ray_shape >> 8) & 0xff) + k) << 23);      // 2^(min_deg + k)
+            sc2[q] = scs[q] * scs[q];
+            if (++j == nb) { j = 0; ++k; }
+          }
+        }
+        for (int s = wv; s < ENC_SAMPLES; s += 4) {
+          const long long m = base + s;
+          if (m >= total) break;
+          float vs[4], vc[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float rev = s_lm[s][jq[q]] * scs[q];
+            const float att = __builtin_amdgcn_exp2f(s_lv[s][jq[q]] * sc2[q]);
+            const float rc = rev + 0.25f;          // sin(x + pi/2), as the reference does
+            vs[q] = att * __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(rev));
+            vc[q] = att * __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(rc));
+          }
+          uint16_t* row = (uint16_t*)out + (size_t)m * kp;
+          *(uint2*)(row + c0) = make_uint2(enc_pk_bf16(vs[0], vs[1]), enc_pk_bf16(vs[2], vs[3]));
+          *(uint2*)(row + nfeat_half + c0) = make_uint2(enc_pk_bf16(vc[0], vc[1]), enc_pk_bf16(vc[2], vc[3]));
+        }
+      }
+      // padding columns [2 nfeat_half, kp): zeros (kp and 2 nfeat_half are multiples of 8 and 4: 8-byte pieces)
+      const int npad4 = (kp - 2 * nfeat_half) >> 2;
+      for (int e = tid; e < ENC_SAMPLES * npad4; e += 256) {
+        const int s = e / npad4, c = e - s * npad4;
+        const long long m = base + s;
+        if (m < total) *(uint2*)((uint16_t*)out + (size_t)m * kp + 2 * nfeat_half + 4 * c) = make_uint2(0u, 0u);
+      }
+      return;
+    }
+  }
+  // one wave writes one whole row: lane owns 8 consecutive features.  Which (half, degree k, basis j) a feature column
+  // is does not depend on the sample: decoded once per lane (no integer division in the per-sample loop).
   for (int f0 = lane * 8; f0 < kp; f0 += 512) {
     int jj[8];         // j | k << 8 | half << 16; half == 2: padding column
     float scs[8];
@@ -132,13 +192,11 @@ __global__ __launch_bounds__(256) void k_cast_ipe(int nrays, int S, const float*
         if (half < 2) {
           const float sc = scs[q];
           float x = s_lm[s][j] * sc;
-          if (half) x = x + 1.57079632679489661923f;   // sin(x + pi/2), as the reference does
+          if (half) x = x + (BF16 ? 0.25f : 1.57079632679489661923f);   // sin(x + pi/2), as the reference does
           const float var = s_lv[s][j] * (sc * sc);
           if (BF16) {
-            // bf16 features carry 8 bits: hardware v_sin_f32 (argument in revolutions, after an exact fract) and
-            // v_exp_f32 are well inside that; the fp32 parity mode keeps the accurate library path.
-            const float rev = x * 0.15915494309189533577f;
-            val = __expf(-0.5f * var) * __builtin_amdgcn_sinf(rev - floorf(rev));
+            // (general basis sizes: x / var are already in revolutions / base-2 exponents, see the lift step above)
+            val = __builtin_amdgcn_exp2f(var) * __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x));
           } else {
             val = expf(-0.5f * var) * safe_sinf(x);
           }
@@ -147,10 +205,7 @@ __global__ __launch_bounds__(256) void k_cast_ipe(int nrays, int S, const float*
       }
       if (BF16) {
         uint4 pk;
-        pk.x = f_to_bf16(v[0]) | ((uint32_t)f_to_bf16(v[1]) << 16);
-        pk.y = f_to_bf16(v[2]) | ((uint32_t)f_to_bf16(v[3]) << 16);
-        pk.z = f_to_bf16(v[4]) | ((uint32_t)f_to_bf16(v[5]) << 16);
-        pk.w = f_to_bf16(v[6]) | ((uint32_t)f_to_bf16(v[7]) << 16);
+        pk.x = enc_pk_bf16(v[0], v[1]); pk.y = enc_pk_bf16(v[2], v[3]); pk.z = enc_pk_bf16(v[4], v[5]); pk.w = enc_pk_bf16(v[6], v[7]);
         *(uint4*)((uint16_t*)out + (size_t)m * kp + f0) = pk;
       } else {
         float4* o = (float4*)((float*)out + (size_t)m * kp + f0);
@@ -192,9 +247,9 @@ extern "C" int hugs_cast_ipe_fwd(int nrays, int num_samples, const float* tdist,
                "hugs_cast_ipe_fwd: row pitch %d too small / not a multiple of 8", row_pitch);
   const long long total = (long long)nrays * num_samples;
   if (total <= 0) return 0;
-  const int grid = (int)((total + ENC_SAMPLES - 1) / ENC_SAMPLES);
+  const int grid = (int)((total + ENC_SAMPLES_F32 - 1) / ENC_SAMPLES_F32), grid_b = (int)((total + ENC_SAMPLES_BF16 - 1) / ENC_SAMPLES_BF16);
   if (out_bf16)
-    hipLaunchKernelGGL(k_cast_ipe<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, nrays, num_samples, tdist,
+    hipLaunchKernelGGL(k_cast_ipe<true>, dim3(grid_b), dim3(256), 0, (hipStream_t)stream, nrays, num_samples, tdist,
                        origins, directions, radii, basis, num_basis, ray_shape, warp_contract, max_deg, row_pitch, out);
   else
     hipLaunchKernelGGL(k_cast_ipe<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, nrays, num_samples, tdist,

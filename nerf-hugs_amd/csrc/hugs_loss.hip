@@ -29,7 +29,9 @@ __global__ __launch_bounds__(1024) void k_data_loss(int N, int L, const float* _
                                                     const float* __restrict__ coef /*[L]*/, float* __restrict__ d_pred,
                                                     float* __restrict__ out_stats) {
   __shared__ float red[16];
-  for (int l = 0; l < L; ++l) {
+  // one workgroup per level (round 5: one workgroup walked the levels one after the other -- 89 us at 16 384 rays x 3 levels); the
+  // sums of a level keep their order
+  for (int l = blockIdx.x; l < L; l += gridDim.x) {
     float s_lm = 0.f;
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
       float lm;
@@ -283,7 +285,7 @@ extern "C" int hugs_data_loss(int N, int L, const float* pred, const float* gt, 
   HUGS_REQUIRE(mode >= 0 && mode <= 2, -3, "hugs_data_loss: bad mode %d", mode);
   HUGS_REQUIRE(mode == 0 || lm_src, -3, "hugs_data_loss: mode %d needs a mask", mode);
   if (N <= 0) return 0;
-  hipLaunchKernelGGL(k_data_loss, dim3(1), dim3(1024), 0, (hipStream_t)stream, N, L, pred, gt, lm_src, mode,
+  hipLaunchKernelGGL(k_data_loss, dim3(L), dim3(1024), 0, (hipStream_t)stream, N, L, pred, gt, lm_src, mode,
                      transient_weight, charb, charb_pad, coef, d_pred, out_stats);
   HUGS_CHECK_LAUNCH("hugs_data_loss");
   return 0;

@@ -131,8 +131,19 @@ __global__ __launch_bounds__(256) void k_opt_adam(const OptChunk* __restrict__ c
   if (threadIdx.x == 0) { part2[(size_t)blockIdx.x * 2] = sd; part2[(size_t)blockIdx.x * 2 + 1] = md; }
 }
 
+// What a captured step hands back, written by the step's LAST launch (round 5: it was three blit copies of ~13 us each behind the
+// graph -- stat tail -> packed, packed -> pinned host memory, the advanced key -> a fresh tensor): packed[0..ntail) = tail * tscale,
+// thr_dst[l] = packed[thr_off + l * thr_stride] (RobustNeRF's device-side threshold feedback), the whole packed buffer to the host
+// slot and the key to the device buffer whose ADDRESSES this step's staging launch wrote to ptrs[0..1] (hugs_stage_step_pub: a
+// captured launch's arguments are fixed, the table's content is not).  A null pointer in the table skips that copy.
+struct StepPublish {
+  const float* tail; float* packed; int ntail, npacked; float tscale;
+  float* thr_dst; int thr_off, thr_stride, thr_n;
+  const int* key_src; int* key_dst;
+  const unsigned long long* ptrs;
+};
 __global__ void k_opt_finalize2(int nleaf, const int4* __restrict__ leaf_info, const float* __restrict__ part2,
-                                float* __restrict__ leaf_upd) {
+                                float* __restrict__ leaf_upd, const StepPublish P) {
   const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;      // a wave per leaf, as k_opt_finalize1
   for (int leaf = threadIdx.x >> 6; leaf < nleaf; leaf += nw) {
     const int4 li = leaf_info[leaf];
@@ -140,6 +151,21 @@ __global__ void k_opt_finalize2(int nleaf, const int4* __restrict__ leaf_info, c
     for (int c = li.x + lane; c < li.y; c += 64) { const float2 p = *(const float2*)(part2 + (size_t)c * 2); sd += p.x; md = fmaxf(md, p.y); }
     sd = wave_sum_f(sd); md = wave_max_f(md);
     if (lane == 0) { leaf_upd[leaf * 2] = sd; leaf_upd[leaf * 2 + 1] = md; }
+  }
+  if (!P.packed) return;
+  for (int i = threadIdx.x; i < P.ntail; i += blockDim.x) P.packed[i] = P.tail[i] * P.tscale;
+  __syncthreads();      // (one workgroup: the per-leaf sums above and the scaled tail are visible to all of it)
+  if (P.thr_dst && (int)threadIdx.x < P.thr_n) P.thr_dst[threadIdx.x] = P.packed[P.thr_off + threadIdx.x * P.thr_stride];
+  float* host = P.ptrs ? (float*)P.ptrs[0] : nullptr;
+  int* key2 = P.ptrs ? (int*)P.ptrs[1] : nullptr;
+  if (host) {
+    for (int i = threadIdx.x; i < P.npacked; i += blockDim.x) host[i] = P.packed[i];
+    __threadfence_system();
+  }
+  if (P.key_src && threadIdx.x < 2) {
+    const int k = P.key_src[threadIdx.x];
+    if (P.key_dst) P.key_dst[threadIdx.x] = k;
+    if (key2) key2[threadIdx.x] = k;
   }
 }
 
@@ -217,11 +243,11 @@ extern "C" int hugs_opt_stats(int nchunks, int nleaf, int nmod, const void* chun
 static int opt_adam_impl(int nchunks, int nleaf, const void* chunks, const void* leaf_info, float* theta, const float* grad, float* m, float* v,
                          const float* mod_scale, const int* trainable, float gscale, float max_val, float lr, float b1,
                          float b2, float eps, float bias_corr1, float bias_corr2, float* part2_ws, float* leaf_upd,
-                         const float* dyn, void* stream) {
+                         const float* dyn, const StepPublish& P, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_opt_adam, dim3(nchunks), dim3(256), 0, st, (const OptChunk*)chunks, theta, grad, m, v, mod_scale,
                      trainable, gscale, max_val, lr, b1, b2, eps, bias_corr1, bias_corr2, part2_ws, dyn);
-  hipLaunchKernelGGL(k_opt_finalize2, dim3(1), dim3(1024), 0, st, nleaf, (const int4*)leaf_info, part2_ws, leaf_upd);
+  hipLaunchKernelGGL(k_opt_finalize2, dim3(1), dim3(1024), 0, st, nleaf, (const int4*)leaf_info, part2_ws, leaf_upd, P);
   HUGS_CHECK_LAUNCH("hugs_opt_adam");
   return 0;
 }
@@ -230,7 +256,7 @@ extern "C" int hugs_opt_adam(int nchunks, int nleaf, const void* chunks, const v
                              float b2, float eps, float bias_corr1, float bias_corr2, float* part2_ws, float* leaf_upd,
                              void* stream) {
   return opt_adam_impl(nchunks, nleaf, chunks, leaf_info, theta, grad, m, v, mod_scale, trainable, gscale, max_val, lr, b1, b2, eps,
-                       bias_corr1, bias_corr2, part2_ws, leaf_upd, nullptr, stream);
+                       bias_corr1, bias_corr2, part2_ws, leaf_upd, nullptr, StepPublish{}, stream);
 }
 // dyn: 3 device floats {lr, bias_corr1, bias_corr2}: the per-step scalars of a captured (hipGraph) train step
 extern "C" int hugs_opt_adam_dyn(int nchunks, int nleaf, const void* chunks, const void* leaf_info, float* theta, const float* grad, float* m,
@@ -238,7 +264,23 @@ extern "C" int hugs_opt_adam_dyn(int nchunks, int nleaf, const void* chunks, con
                                  float b1, float b2, float eps, float* part2_ws, float* leaf_upd, void* stream) {
   HUGS_REQUIRE(dyn, -2, "hugs_opt_adam_dyn: dyn is null");
   return opt_adam_impl(nchunks, nleaf, chunks, leaf_info, theta, grad, m, v, mod_scale, trainable, gscale, max_val, 0.f, b1, b2, eps, 1.f,
-                       1.f, part2_ws, leaf_upd, dyn, stream);
+                       1.f, part2_ws, leaf_upd, dyn, StepPublish{}, stream);
+}
+// hugs_opt_adam_dyn whose last launch also publishes the step's results (include/hugs.h): pub = 12 host words
+//   {tail, packed, ntail, npacked, tscale (float bits), thr_dst, thr_off, thr_stride, thr_n, key_src, key_dst, ptrs}
+extern "C" int hugs_opt_adam_pub(int nchunks, int nleaf, const void* chunks, const void* leaf_info, float* theta, const float* grad, float* m,
+                                 float* v, const float* mod_scale, const int* trainable, float gscale, float max_val, const float* dyn,
+                                 float b1, float b2, float eps, float* part2_ws, float* leaf_upd, const unsigned long long* pub, void* stream) {
+  HUGS_REQUIRE(dyn && pub, -2, "hugs_opt_adam_pub: dyn / pub is null");
+  StepPublish P;
+  P.tail = (const float*)pub[0]; P.packed = (float*)pub[1]; P.ntail = (int)pub[2]; P.npacked = (int)pub[3];
+  { const unsigned u = (unsigned)pub[4]; __builtin_memcpy(&P.tscale, &u, 4); }
+  P.thr_dst = (float*)pub[5]; P.thr_off = (int)pub[6]; P.thr_stride = (int)pub[7]; P.thr_n = (int)pub[8];
+  P.key_src = (const int*)pub[9]; P.key_dst = (int*)pub[10]; P.ptrs = (const unsigned long long*)pub[11];
+  HUGS_REQUIRE(P.packed && P.tail && P.ntail >= 0 && P.ntail <= P.npacked && P.thr_n >= 0 && P.thr_n <= 1024, -2,
+               "hugs_opt_adam_pub: descriptor (ntail %d, npacked %d, thr_n %d)", P.ntail, P.npacked, P.thr_n);
+  return opt_adam_impl(nchunks, nleaf, chunks, leaf_info, theta, grad, m, v, mod_scale, trainable, gscale, max_val, 0.f, b1, b2, eps, 1.f,
+                       1.f, part2_ws, leaf_upd, dyn, P, stream);
 }
 __global__ void k_set_floats(float* dst, int n, float a, float b, float c, float d) {
   const float v[4] = {a, b, c, d};
@@ -257,11 +299,13 @@ extern "C" int hugs_set_floats(float* dst, int n, float a, float b, float c, flo
 // colours, the jax key) -- are copied into the buffers the graph was captured on, and the per-step scalars go into dst_f[0..nf).
 // The source ADDRESSES change from step to step (whatever batch the caller hands over), so they travel as kernel arguments.
 struct StageItems { const uint32_t* src[16]; uint32_t* dst[16]; int words[16]; int n; };
-__global__ __launch_bounds__(256) void k_stage_step(StageItems S, float* dst_f, int nf, float a, float b, float c, float d) {
+__global__ __launch_bounds__(256) void k_stage_step(StageItems S, float* dst_f, int nf, float a, float b, float c, float d,
+                                                    unsigned long long* dst_p, unsigned long long p0, unsigned long long p1) {
   const int it = blockIdx.y;
-  if (it == S.n) {      // (the extra row of blocks: the scalars)
+  if (it == S.n) {      // (the extra row of blocks: the scalars, and the two addresses the step's last launch publishes to)
     const float v[4] = {a, b, c, d};
     if (blockIdx.x == 0 && (int)threadIdx.x < nf) dst_f[threadIdx.x] = v[threadIdx.x];
+    if (dst_p && blockIdx.x == 0 && threadIdx.x == 64) { dst_p[0] = p0; dst_p[1] = p1; }
     return;
   }
   const uint32_t* __restrict__ s_ = S.src[it];
@@ -270,8 +314,8 @@ __global__ __launch_bounds__(256) void k_stage_step(StageItems S, float* dst_f, 
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) d_[i] = s_[i];
 }
 // include/hugs.h hugs_stage_step: src / dst are HOST arrays of n device pointers, words[i] = 4-byte words of item i
-extern "C" int hugs_stage_step(int n, const void* const* src, void* const* dst, const int* words, float* dst_f, int nf, float a, float b,
-                               float c, float d, void* stream) {
+static int stage_step_impl(int n, const void* const* src, void* const* dst, const int* words, float* dst_f, int nf, float a, float b,
+                           float c, float d, unsigned long long* dst_p, unsigned long long p0, unsigned long long p1, void* stream) {
   HUGS_REQUIRE(n >= 0 && n <= 16 && nf >= 0 && nf <= 4 && (n == 0 || (src && dst && words)) && (nf == 0 || dst_f), -2,
                "hugs_stage_step: %d items (<= 16), %d scalars (<= 4)", n, nf);
   StageItems S;
@@ -284,9 +328,20 @@ extern "C" int hugs_stage_step(int n, const void* const* src, void* const* dst, 
   }
   int gx = (mx + 1023) / 1024;
   if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(k_stage_step, dim3(gx, n + 1), dim3(256), 0, (hipStream_t)stream, S, dst_f, nf, a, b, c, d);
+  hipLaunchKernelGGL(k_stage_step, dim3(gx, n + 1), dim3(256), 0, (hipStream_t)stream, S, dst_f, nf, a, b, c, d, dst_p, p0, p1);
   HUGS_CHECK_LAUNCH("hugs_stage_step");
   return 0;
+}
+extern "C" int hugs_stage_step(int n, const void* const* src, void* const* dst, const int* words, float* dst_f, int nf, float a, float b,
+                               float c, float d, void* stream) {
+  return stage_step_impl(n, src, dst, words, dst_f, nf, a, b, c, d, nullptr, 0, 0, stream);
+}
+// + dst_p[0..1] = {p0, p1}: the addresses (a pinned host slot for the packed stats, a device buffer for the advanced key; 0 = none)
+// that hugs_opt_adam_pub's last launch reads back from dst_p
+extern "C" int hugs_stage_step_pub(int n, const void* const* src, void* const* dst, const int* words, float* dst_f, int nf, float a, float b,
+                                   float c, float d, void* dst_p, void* p0, void* p1, void* stream) {
+  HUGS_REQUIRE(dst_p, -2, "hugs_stage_step_pub: dst_p is null");
+  return stage_step_impl(n, src, dst, words, dst_f, nf, a, b, c, d, (unsigned long long*)dst_p, (unsigned long long)p0, (unsigned long long)p1, stream);
 }
 
 extern "C" int hugs_cast_weights_batch(int dtype, int nitems, const void* items, int total_blocks, void* stream) {

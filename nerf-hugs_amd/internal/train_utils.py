@@ -6,6 +6,7 @@ One process drives one GPU; data parallelism = one process per GPU with a single
 gradient buffer (+ the step's scalar stats in its tail) per step, replacing jax.lax.pmean
 (train_utils.py:457-459).  Loss normalisers stay per device, as in the reference (they run before pmean)."""
 import math
+import weakref
 
 import numpy as np
 import torch
@@ -58,14 +59,25 @@ class LazyStats(dict):
   """stats dict whose values materialise from one packed device->host copy on first access, so the step
   stays asynchronous (the reference returns device arrays that the host reads every print_every)."""
 
-  def __init__(self, packed_dev, build):
+  def __init__(self, packed_dev, build, host=None, pool=None):
     super().__init__()
-    self._host = torch.empty(packed_dev.shape, dtype=packed_dev.dtype, pin_memory=True)
-    self._host.copy_(packed_dev, non_blocking=True)
+    if host is None:
+      self._host = torch.empty(packed_dev.shape, dtype=packed_dev.dtype, pin_memory=True)
+      self._host.copy_(packed_dev, non_blocking=True)
+    else:
+      # a captured step's last launch has been told to write the packed stats straight into this pinned slot (no copy on the
+      # stream); the slot goes back to the step function's pool when this dict dies
+      self._host = host
+    self._pool = pool
     self._ev = torch.cuda.Event()
     self._ev.record()
     self._build = build
     self._done = False
+
+  def __del__(self):
+    pool, self._pool = getattr(self, '_pool', None), None
+    if pool is not None:
+      pool.append(self._host)
 
   def _mat(self):
     if not self._done:
@@ -198,7 +210,7 @@ def create_train_step(model, config, is_finetune=False):
           decay.append((lf['off'], int(np.prod(lf['pshape'])), float(mult)))
   cache = {}
 
-  def optimizer_step(state, grad, gscale=1.0, dyn=None):
+  def optimizer_step(state, grad, gscale=1.0, dyn=None, pub=None):
     """The second half of the reference's train_step on a gradient buffer in the flat layout
     (train_utils.py:461-473): grad_norms / grad_maxes, clip_gradients per module (value clip, then norm clip with
     `eps + norm`), nan_to_num, Adam (optax.adam: bias-corrected moments, eps outside the sqrt, schedule at the
@@ -220,7 +232,10 @@ def create_train_step(model, config, is_finetune=False):
     lr = h['lr_fn'](count)
     t = count + 1
     part2 = ws.get('opt_part2', (nch * 2,))
-    if dyn is not None:     # a step being captured: {lr, 1 - b1^t, 1 - b2^t} are read from dyn[1:4] (step_scalars below writes them)
+    if dyn is not None and pub is not None:      # + its last launch publishes the step's results (step_finish)
+      _lib.call('hugs_opt_adam_pub', nch, nleaf, eng.chunks, eng.leaf_info, state.flat, grad, state.m, state.v, mod_scale, h['trainable'],
+                gscale, config.grad_max_val, dyn[1:4], h['b1'], h['b2'], h['eps'], part2, leaf_stats[nleaf * 4:nleaf * 6], pub.ctypes.data)
+    elif dyn is not None:     # a step being captured: {lr, 1 - b1^t, 1 - b2^t} are read from dyn[1:4] (step_scalars below writes them)
       _lib.call('hugs_opt_adam_dyn', nch, nleaf, eng.chunks, eng.leaf_info, state.flat, grad, state.m, state.v, mod_scale, h['trainable'],
                 gscale, config.grad_max_val, dyn[1:4], h['b1'], h['b2'], h['eps'], part2, leaf_stats[nleaf * 4:nleaf * 6])
     else:
@@ -263,6 +278,11 @@ def create_train_step(model, config, is_finetune=False):
 
   graphs = {}
 
+  def _handed(ent, rng):
+    """rng IS the key tensor the previous replay handed back, untouched: its value already sits in ent['key']."""
+    h = ent.get('key_handed')
+    return h is not None and h[0]() is rng and rng._version == h[1]
+
   def train_step(rng, state, batch, train_frac, inlier_thresholds):
     eng = model.engine(state.flat.device)
     dev = state.flat.device
@@ -290,23 +310,32 @@ def create_train_step(model, config, is_finetune=False):
       ent['gt'] = torch.empty_like(gt)
       ent['dyn'] = torch.zeros(4, dtype=torch.float32, device=dev)
       ent['key'] = torch.zeros(2, dtype=torch.int32, device=dev) if sig[0] == 'key' else None
+      ent['ptrs'] = torch.zeros(2, dtype=torch.int64, device=dev)     # {pinned stats slot, fresh key buffer} of the step in flight
+      ent['host_pool'] = []
     names = list(rays)      # (the engine adds derived entries -- 'dir_enc' -- to the dict it is handed: they are not inputs)
     srcs = [rays[k] for k in names if rays[k].data_ptr() != ent['rays'][k].data_ptr()] + ([gt] if gt.data_ptr() != ent['gt'].data_ptr() else [])
     dsts = [ent['rays'][k] for k in names if rays[k].data_ptr() != ent['rays'][k].data_ptr()] + ([ent['gt']] if gt.data_ptr() != ent['gt'].data_ptr() else [])
-    if ent['key'] is not None and rng.data_ptr() != ent['key'].data_ptr():
+    # the advanced key is handed back in a FRESH tensor, as the eager path does (ent['key'] is overwritten by every replay, and a
+    # caller that keeps an earlier key -- a checkpoint of the rng, an eval stream -- must not see it change): the step's last launch
+    # writes it there.  A caller that hands the previous step's key straight back (the train loop) finds it in ent['key'] already.
+    key_new = torch.empty_like(ent['key']) if ent['key'] is not None else None
+    if ent['key'] is not None and rng.data_ptr() != ent['key'].data_ptr() and not _handed(ent, rng):
       srcs.append(rng.contiguous()); dsts.append(ent['key'])
-    # ONE launch: every input copy (all of them 4-byte element types) + the step's four scalars (round 5; it was two
-    # _foreach_copy_ launches, a key copy and hugs_set_floats: ~40 us of launch latency in front of a 1.3 ms step at 128 rays)
-    if len(srcs) <= 16 and all(s_.element_size() == 4 and s_.is_contiguous() and s_.numel() == d_.numel() for s_, d_ in zip(srcs, dsts)):
-      tb = ent.setdefault('stage_tab', (np.zeros(16, np.uint64), np.zeros(16, np.uint64), np.zeros(16, np.int32)))
-      for i_, (s_, d_) in enumerate(zip(srcs, dsts)):
-        tb[0][i_], tb[1][i_], tb[2][i_] = s_.data_ptr(), d_.data_ptr(), s_.numel()
-      _lib.call('hugs_stage_step', len(srcs), tb[0].ctypes.data, tb[1].ctypes.data, tb[2].ctypes.data, ent['dyn'], 4,
-                *step_scalars(state, train_frac))
-    else:
+    # ONE launch: every input copy (all of them 4-byte element types) + the step's four scalars + the two addresses the step's
+    # last launch publishes to (round 5; it was two _foreach_copy_ launches, a key copy and hugs_set_floats: ~40 us of launch
+    # latency in front of a 1.3 ms step at 128 rays)
+    npk = STAT_TAIL + len(layout.leaves) * 6 + 16
+    host = ent['host_pool'].pop() if ent['host_pool'] else torch.empty((npk,), dtype=torch.float32, pin_memory=True)
+    one = len(srcs) <= 16 and all(s_.element_size() == 4 and s_.is_contiguous() and s_.numel() == d_.numel() for s_, d_ in zip(srcs, dsts))
+    if not one:
       for s_, d_ in zip(srcs, dsts):
         d_.copy_(s_)
-      _lib.call('hugs_set_floats', ent['dyn'], 4, *step_scalars(state, train_frac))
+      srcs, dsts = [], []
+    tb = ent.setdefault('stage_tab', (np.zeros(16, np.uint64), np.zeros(16, np.uint64), np.zeros(16, np.int32)))
+    for i_, (s_, d_) in enumerate(zip(srcs, dsts)):
+      tb[0][i_], tb[1][i_], tb[2][i_] = s_.data_ptr(), d_.data_ptr(), s_.numel()
+    _lib.call('hugs_stage_step_pub', len(srcs), tb[0].ctypes.data, tb[1].ctypes.data, tb[2].ctypes.data, ent['dyn'], 4,
+              *step_scalars(state, train_frac), ent['ptrs'], host.data_ptr(), key_new)
     if 'graph' not in ent:
       world = _world()
       g, g2 = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if world > 1 else None)
@@ -318,14 +347,14 @@ def create_train_step(model, config, is_finetune=False):
       ok = False
       try:
         with torch.cuda.graph(g, stream=cap, capture_error_mode='thread_local'):
-          key_out = step_core(state, ent['rays'], ent['gt'], N, ent['key'], train_frac, None, ent['dyn'], False)
-          if ent['key'] is not None:
-            ent['key'].copy_(key_out)
+          ent['key_out'] = step_core(state, ent['rays'], ent['gt'], N, ent['key'], train_frac, None, ent['dyn'], False)
+          if ent['key'] is None:
+            ent['key_out'] = None
           if world == 1:
-            packed = step_finish(state, ent['dyn'])
+            packed = step_finish(state, ent['dyn'], ent)
         if world > 1:
           with torch.cuda.graph(g2, stream=cap, capture_error_mode='thread_local'):
-            packed = step_finish(state, ent['dyn'])
+            packed = step_finish(state, ent['dyn'], ent)
         ok = True
       finally:
         eng.capture_lanes = None
@@ -347,9 +376,9 @@ def create_train_step(model, config, is_finetune=False):
     state.step += 1
     eng._cast_src = None          # (the replayed Adam update has moved the masters; the next step re-casts first thing)
     eng.weights_stale = True
-    # the advanced key is handed back as a fresh tensor, as the eager path does: ent['key'] is overwritten by every replay, and a
-    # caller that keeps an earlier key (a checkpoint of the rng, an eval stream) must not see it change
-    return state, LazyStats(ent['packed'], stats_builder(state)), (ent['key'].clone() if ent['key'] is not None else rng)
+    if key_new is not None:
+      ent['key_handed'] = (weakref.ref(key_new), key_new._version)
+    return state, LazyStats(None, stats_builder(state), host=host, pool=ent['host_pool']), (key_new if key_new is not None else rng)
 
   def step_core(state, rays, gt, N, rng, train_frac, inlier_thresholds, dyn, reduce):
     """The first part of the step: forward, losses, backward and -- when `reduce` -- the all-reduces of the gradient buffer
@@ -582,8 +611,11 @@ def create_train_step(model, config, is_finetune=False):
         AR_PROFILE.append((e0_, e1_))
     return rng
 
-  def step_finish(state, dyn):
-    """The second part: weight decay, stats / clip / Adam / re-cast, stat packing.  Returns the packed stats buffer."""
+  def step_finish(state, dyn, ent=None):
+    """The second part: weight decay, stats / clip / Adam / re-cast, stat packing.  Returns the packed stats buffer.
+    ent: the graph entry of a step being captured -- the optimizer's last launch then also publishes the results (packed stat
+    tail, RobustNeRF threshold feedback, the stats to a pinned host slot, the advanced key: hugs_opt_adam_pub) instead of three
+    copies behind the graph."""
     eng = model.engine(state.flat.device)
     ws = eng.ws
     world = _world()
@@ -593,16 +625,28 @@ def create_train_step(model, config, is_finetune=False):
     for off, n_, mult in decay:        # after pmean; the kernels below scale the buffer by gscale, hence the 1/gscale
       _lib.call('hugs_axpy', n_, 2.0 * mult / gscale, state.flat[off:off + n_], grad[off:off + n_])
     nleaf = len(layout.leaves)
+    packed = ws.get('stats_packed', (STAT_TAIL + nleaf * 6 + 16,))
+    if tt == 'robustnerf' and 'thr_dev' not in cache:
+      cache['thr_dev'] = torch.ones((L, 1), dtype=torch.float32, device=packed.device)
+    if ent is not None and dyn is not None:
+      pub = ent['pub'] = np.zeros(12, np.uint64)
+      pub[0], pub[1], pub[2], pub[3] = tail.data_ptr(), packed.data_ptr(), STAT_TAIL, packed.numel()
+      pub[4] = int(np.float32(gscale).view(np.uint32))
+      if tt == 'robustnerf':
+        pub[5], pub[6], pub[7], pub[8] = cache['thr_dev'].data_ptr(), o_rob, 5, L
+      if ent.get('key_out') is not None:
+        pub[9], pub[10] = ent['key_out'].data_ptr(), ent['key'].data_ptr()
+      pub[11] = ent['ptrs'].data_ptr()
+      leaf_stats = optimizer_step(state, grad, gscale, dyn, pub)
+      assert leaf_stats.data_ptr() == packed[STAT_TAIL:].data_ptr()
+      return packed
     leaf_stats = optimizer_step(state, grad, gscale, dyn)
     # ---- stats (lazy) -------------------------------------------------------------------------------
-    packed = ws.get('stats_packed', (STAT_TAIL + nleaf * 6 + 16,))
     packed[:STAT_TAIL].copy_(tail)
     if world > 1:
       _lib.call('hugs_affine', STAT_TAIL, packed, gscale, 0.0, packed)
     assert leaf_stats.data_ptr() == packed[STAT_TAIL:].data_ptr()
     if tt == 'robustnerf':
-      if 'thr_dev' not in cache:
-        cache['thr_dev'] = torch.ones((L, 1), dtype=torch.float32, device=packed.device)
       cache['thr_dev'].copy_(packed[o_rob:o_rob + 5 * L].reshape(L, 5)[:, :1])
     return packed
 
