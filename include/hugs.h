@@ -234,10 +234,10 @@ int hugs_opt_adam_pub(int nchunks, int nleaf, const void* chunks, const void* le
  * {a, b, c, d}[0..nf) as hugs_set_floats. */
 int hugs_stage_step(int n, const void* const* src, void* const* dst, const int* words, float* dst_f, int nf, float a, float b, float c,
                     float d, void* stream);
-/* The same launch, which also writes dst_p[0..1] = {p0, p1} (device table of two addresses read back by hugs_opt_adam_pub's last launch;
- * 0 = nothing to publish there). */
-int hugs_stage_step_pub(int n, const void* const* src, void* const* dst, const int* words, float* dst_f, int nf, float a, float b,
-                        float c, float d, void* dst_p, void* p0, void* p1, void* stream);
+/* The same launch with up to 8 scalars (scalars: HOST array of nf floats), which also writes dst_p[0..1] = {p0, p1} (device table of two
+ * addresses read back by hugs_opt_adam_pub's last launch; 0 = nothing to publish there). */
+int hugs_stage_step_pub(int n, const void* const* src, void* const* dst, const int* words, float* dst_f, int nf, const float* scalars,
+                        void* dst_p, void* p0, void* p1, void* stream);
 /* fp32 master [K,N] -> compute-dtype copies Wn [K,N] and Wt [N,K] (either may be NULL) */
 int hugs_cast_weights(int dtype, int K, int N, const float* W, void* Wn, void* Wt, void* stream);
 /* The same cast for a device table of matrices in one launch.  items: nitems records of 40 bytes
@@ -314,6 +314,9 @@ int hugs_embed_scatter_add(int dtype, int N, int T, const void* dX, int ldx, int
                            float* d_embedding, void* stream);
 int hugs_hanerf_loss(int N, int L, const float* pred, const float* gt, const float* mask, int charb, float charb_pad,
                      const float* coef, float mask_size_mult, float* d_pred, float* d_mask, float* out_stats, void* stream);
+/* mask_size_mult (train_utils.py:190-193) read from one device float: the form a captured (hipGraph) train step uses */
+int hugs_hanerf_loss_dyn(int N, int L, const float* pred, const float* gt, const float* mask, int charb, float charb_pad,
+                         const float* coef, const float* mask_size_mult_dev, float* d_pred, float* d_mask, float* out_stats, void* stream);
 
 /* ---- NeRF-W branch.  render.py:154-182 compute_dual_alpha_weights + :246-273
  * volumetric_rendering_combined_color + models.py:299-307 uncertainty (beta = sum_i w^t_i u_i + beta_min, w^t from

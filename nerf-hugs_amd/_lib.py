@@ -52,7 +52,7 @@ _PROTOS = {
     'hugs_opt_adam_dyn': 'iippppppppffpfffpps',
     'hugs_set_floats': 'piffffs',
     'hugs_stage_step': 'ippppiffffs',
-    'hugs_stage_step_pub': 'ippppiffffppps',
+    'hugs_stage_step_pub': 'ippppipppps',
     'hugs_opt_adam_pub': 'iippppppppffpfffppps',
     'hugs_level_sample_fwd_dyn': 'ippiifffpfppiiiipppps',
     'hugs_cast_weights': 'iiippps',
@@ -72,6 +72,7 @@ _PROTOS = {
     'hugs_mask_head_bwd': 'iiiipippppps',
     'hugs_embed_scatter_add': 'iiipiipps',
     'hugs_hanerf_loss': 'iipppifpfppps',
+    'hugs_hanerf_loss_dyn': 'iipppifppppps',
     'hugs_dual_composite_fwd': 'iipppppppiffpppps',
     'hugs_dual_composite_bwd': 'iipppppppifppfppppps',
     'hugs_rank1_add2_mask': 'iiipppppipis',

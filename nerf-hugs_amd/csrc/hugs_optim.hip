@@ -298,13 +298,12 @@ extern "C" int hugs_set_floats(float* dst, int n, float a, float b, float c, flo
 // One launch in front of a replayed (captured) step: the step's inputs -- up to 16 flat buffers of 4-byte words (ray fields, target
 // colours, the jax key) -- are copied into the buffers the graph was captured on, and the per-step scalars go into dst_f[0..nf).
 // The source ADDRESSES change from step to step (whatever batch the caller hands over), so they travel as kernel arguments.
-struct StageItems { const uint32_t* src[16]; uint32_t* dst[16]; int words[16]; int n; };
-__global__ __launch_bounds__(256) void k_stage_step(StageItems S, float* dst_f, int nf, float a, float b, float c, float d,
+struct StageItems { const uint32_t* src[16]; uint32_t* dst[16]; int words[16]; int n; float f[8]; };
+__global__ __launch_bounds__(256) void k_stage_step(StageItems S, float* dst_f, int nf,
                                                     unsigned long long* dst_p, unsigned long long p0, unsigned long long p1) {
   const int it = blockIdx.y;
   if (it == S.n) {      // (the extra row of blocks: the scalars, and the two addresses the step's last launch publishes to)
-    const float v[4] = {a, b, c, d};
-    if (blockIdx.x == 0 && (int)threadIdx.x < nf) dst_f[threadIdx.x] = v[threadIdx.x];
+    if (blockIdx.x == 0 && (int)threadIdx.x < nf) dst_f[threadIdx.x] = S.f[threadIdx.x];
     if (dst_p && blockIdx.x == 0 && threadIdx.x == 64) { dst_p[0] = p0; dst_p[1] = p1; }
     return;
   }
@@ -314,12 +313,13 @@ __global__ __launch_bounds__(256) void k_stage_step(StageItems S, float* dst_f, 
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) d_[i] = s_[i];
 }
 // include/hugs.h hugs_stage_step: src / dst are HOST arrays of n device pointers, words[i] = 4-byte words of item i
-static int stage_step_impl(int n, const void* const* src, void* const* dst, const int* words, float* dst_f, int nf, float a, float b,
-                           float c, float d, unsigned long long* dst_p, unsigned long long p0, unsigned long long p1, void* stream) {
-  HUGS_REQUIRE(n >= 0 && n <= 16 && nf >= 0 && nf <= 4 && (n == 0 || (src && dst && words)) && (nf == 0 || dst_f), -2,
-               "hugs_stage_step: %d items (<= 16), %d scalars (<= 4)", n, nf);
+static int stage_step_impl(int n, const void* const* src, void* const* dst, const int* words, float* dst_f, int nf, const float* scal,
+                           unsigned long long* dst_p, unsigned long long p0, unsigned long long p1, void* stream) {
+  HUGS_REQUIRE(n >= 0 && n <= 16 && nf >= 0 && nf <= 8 && (n == 0 || (src && dst && words)) && (nf == 0 || (dst_f && scal)), -2,
+               "hugs_stage_step: %d items (<= 16), %d scalars (<= 8)", n, nf);
   StageItems S;
   S.n = n;
+  for (int i = 0; i < 8; ++i) S.f[i] = i < nf ? scal[i] : 0.f;
   int mx = 1;
   for (int i = 0; i < 16; ++i) {
     S.src[i] = i < n ? (const uint32_t*)src[i] : nullptr; S.dst[i] = i < n ? (uint32_t*)dst[i] : nullptr; S.words[i] = i < n ? words[i] : 0;
@@ -328,20 +328,23 @@ static int stage_step_impl(int n, const void* const* src, void* const* dst, cons
   }
   int gx = (mx + 1023) / 1024;
   if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(k_stage_step, dim3(gx, n + 1), dim3(256), 0, (hipStream_t)stream, S, dst_f, nf, a, b, c, d, dst_p, p0, p1);
+  hipLaunchKernelGGL(k_stage_step, dim3(gx, n + 1), dim3(256), 0, (hipStream_t)stream, S, dst_f, nf, dst_p, p0, p1);
   HUGS_CHECK_LAUNCH("hugs_stage_step");
   return 0;
 }
 extern "C" int hugs_stage_step(int n, const void* const* src, void* const* dst, const int* words, float* dst_f, int nf, float a, float b,
                                float c, float d, void* stream) {
-  return stage_step_impl(n, src, dst, words, dst_f, nf, a, b, c, d, nullptr, 0, 0, stream);
+  HUGS_REQUIRE(nf >= 0 && nf <= 4, -2, "hugs_stage_step: %d scalars (<= 4)", nf);
+  const float v[4] = {a, b, c, d};
+  return stage_step_impl(n, src, dst, words, dst_f, nf, v, nullptr, 0, 0, stream);
 }
 // + dst_p[0..1] = {p0, p1}: the addresses (a pinned host slot for the packed stats, a device buffer for the advanced key; 0 = none)
 // that hugs_opt_adam_pub's last launch reads back from dst_p
-extern "C" int hugs_stage_step_pub(int n, const void* const* src, void* const* dst, const int* words, float* dst_f, int nf, float a, float b,
-                                   float c, float d, void* dst_p, void* p0, void* p1, void* stream) {
+// (scalars: HOST array of nf <= 8 floats)
+extern "C" int hugs_stage_step_pub(int n, const void* const* src, void* const* dst, const int* words, float* dst_f, int nf,
+                                   const float* scalars, void* dst_p, void* p0, void* p1, void* stream) {
   HUGS_REQUIRE(dst_p, -2, "hugs_stage_step_pub: dst_p is null");
-  return stage_step_impl(n, src, dst, words, dst_f, nf, a, b, c, d, (unsigned long long*)dst_p, (unsigned long long)p0, (unsigned long long)p1, stream);
+  return stage_step_impl(n, src, dst, words, dst_f, nf, scalars, (unsigned long long*)dst_p, (unsigned long long)p0, (unsigned long long)p1, stream);
 }
 
 extern "C" int hugs_cast_weights_batch(int dtype, int nitems, const void* items, int total_blocks, void* stream) {

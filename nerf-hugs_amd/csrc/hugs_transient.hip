@@ -103,8 +103,9 @@ __device__ __forceinline__ float block_sum1024(float v, float* red) {
 __global__ void __launch_bounds__(1024)
 k_hanerf_loss(int N, int L, const float* __restrict__ pred, const float* __restrict__ gt, const float* __restrict__ mask,
               int charb, float pad, const float* __restrict__ coef, float mask_mult, float* __restrict__ d_pred,
-              float* __restrict__ d_mask, float* __restrict__ stats) {
+              float* __restrict__ d_mask, float* __restrict__ stats, const float* __restrict__ mask_mult_dev) {
   __shared__ float red[16];
+  if (mask_mult_dev) mask_mult = *mask_mult_dev;      // hugs_hanerf_loss_dyn: the step's value lives in device memory (captured step)
   const float inv = 1.f / (3.f * (float)N);
   for (int l = 0; l < L; ++l) {
     const float cf = coef[l];
@@ -192,7 +193,17 @@ extern "C" int hugs_hanerf_loss(int N, int L, const float* pred, const float* gt
                                 float* out_stats, void* stream) {
   HUGS_REQUIRE(N > 0 && L >= 1 && L <= 8, -2, "hugs_hanerf_loss: N=%d L=%d", N, L);
   k_hanerf_loss<<<1, 1024, 0, (hipStream_t)stream>>>(N, L, pred, gt, mask, charb, charb_pad, coef, mask_size_mult, d_pred,
-                                                     d_mask, out_stats);
+                                                     d_mask, out_stats, nullptr);
+  HUGS_CHECK_LAUNCH("k_hanerf_loss");
+  return 0;
+}
+// mask_size_mult (train_utils.py:190-193: it decays with the step) read from one device float: a captured step's arguments are fixed
+extern "C" int hugs_hanerf_loss_dyn(int N, int L, const float* pred, const float* gt, const float* mask, int charb,
+                                    float charb_pad, const float* coef, const float* mask_size_mult_dev, float* d_pred, float* d_mask,
+                                    float* out_stats, void* stream) {
+  HUGS_REQUIRE(N > 0 && L >= 1 && L <= 8 && mask_size_mult_dev, -2, "hugs_hanerf_loss_dyn: N=%d L=%d", N, L);
+  k_hanerf_loss<<<1, 1024, 0, (hipStream_t)stream>>>(N, L, pred, gt, mask, charb, charb_pad, coef, 0.f, d_pred, d_mask, out_stats,
+                                                     mask_size_mult_dev);
   HUGS_CHECK_LAUNCH("k_hanerf_loss");
   return 0;
 }

@@ -151,6 +151,9 @@ _STEP_GRAPH = __import__('os').environ.get('HUGS_STEP_GRAPH', 'auto')
 # lanes (Engine._side_stream) that keep a stream of their own inside the captured step; the others run on the stream they are
 # called from.  Lane 2 (the proposal level's weight-gradient stream) forks from lane 1, a forked stream: see engine.wait_event
 _GRAPH_LANES = tuple(int(x) for x in __import__('os').environ.get('HUGS_STEP_GRAPH_LANES', '1,3,4').split(',') if x != '')
+# HUGS_STEP_GRAPH_TRANSIENT=0: the HA-NeRF / NeRF-W steps stay eager (round 5: their per-step scalar is device-resident and they capture)
+_GRAPH_TRANSIENT = __import__('os').environ.get('HUGS_STEP_GRAPH_TRANSIENT', '1') != '0'
+_GRAPH_TYPES = (None, 'withmask', 'robustnerf') + (('hanerf', 'nerfw') if _GRAPH_TRANSIENT else ())
 _STEP_GRAPH_ROWS = int(__import__('os').environ.get('HUGS_STEP_GRAPH_ROWS', '100000'))
 
 
@@ -249,20 +252,28 @@ def create_train_step(model, config, is_finetune=False):
     state.step += 1
     return leaf_stats
 
+  def mask_size_mult(train_frac):
+    """train_utils.py:190-193: HA-NeRF's mask-size weight decays from _max to _min with the step."""
+    return max(config.hanerf_mask_size_loss_mult_min, config.hanerf_mask_size_loss_mult_max *
+               math.exp(-float(train_frac) * config.max_steps * config.hanerf_mask_size_loss_mult_k))
+
   def step_scalars(state, train_frac):
-    """The per-step scalars a captured step reads from device memory: (anneal, lr, 1 - b1^t, 1 - b2^t)."""
+    """The per-step scalars a captured step reads from device memory: (anneal, lr, 1 - b1^t, 1 - b2^t, HA-NeRF mask-size weight)."""
     h = state.hyper
     t = state.step + 1
-    return (model.engine(state.flat.device).anneal_factor(float(train_frac)), h['lr_fn'](state.step), 1.0 - h['b1']**t, 1.0 - h['b2']**t)
+    return (model.engine(state.flat.device).anneal_factor(float(train_frac)), h['lr_fn'](state.step), 1.0 - h['b1']**t, 1.0 - h['b2']**t,
+            mask_size_mult(train_frac) if tt == 'hanerf' else 0.0)
 
   def graph_signature(rng, state, N, train_frac, inlier_thresholds):
     """None when this step cannot be replayed from captured hipGraphs, else the key of its graphs.  Capturable: the plain /
     static-mask / RobustNeRF losses, jitter from a jax key through the fused chain kernel (or none), no near-plane annealing (its histogram
     is rewritten from the host).  Data parallel: TWO graphs (forward + backward | clip + Adam) around ONE eager all-reduce of
     the gradient buffer -- the collective is not captured."""
-    if _STEP_GRAPH == '0' or _lib.PROFILE is not None or tt not in (None, 'withmask', 'robustnerf') or inlier_thresholds is not None:
+    if _STEP_GRAPH == '0' or _lib.PROFILE is not None or tt not in _GRAPH_TYPES or inlier_thresholds is not None:
       return None      # (RobustNeRF: with the thresholds fed back on the device -- inlier_thresholds=None -- not handed over by the host)
-    if model.near_anneal_rate is not None or model.has_noise() or model.nerf_spec.num_tra > 0 or model.mask_spec is not None:
+    if model.near_anneal_rate is not None or model.has_noise():
+      return None
+    if (model.nerf_spec.num_tra > 0 or model.mask_spec is not None) and not _GRAPH_TRANSIENT:
       return None
     if hrandom.is_key(rng):
       if not (config.randomized and L <= hrandom.step_jitter_max_levels()):
@@ -308,7 +319,7 @@ def create_train_step(model, config, is_finetune=False):
     if 'graph' not in ent:
       ent['rays'] = {k: torch.empty_like(v) for k, v in rays.items()}
       ent['gt'] = torch.empty_like(gt)
-      ent['dyn'] = torch.zeros(4, dtype=torch.float32, device=dev)
+      ent['dyn'] = torch.zeros(8, dtype=torch.float32, device=dev)
       ent['key'] = torch.zeros(2, dtype=torch.int32, device=dev) if sig[0] == 'key' else None
       ent['ptrs'] = torch.zeros(2, dtype=torch.int64, device=dev)     # {pinned stats slot, fresh key buffer} of the step in flight
       ent['host_pool'] = []
@@ -334,8 +345,13 @@ def create_train_step(model, config, is_finetune=False):
     tb = ent.setdefault('stage_tab', (np.zeros(16, np.uint64), np.zeros(16, np.uint64), np.zeros(16, np.int32)))
     for i_, (s_, d_) in enumerate(zip(srcs, dsts)):
       tb[0][i_], tb[1][i_], tb[2][i_] = s_.data_ptr(), d_.data_ptr(), s_.numel()
-    _lib.call('hugs_stage_step_pub', len(srcs), tb[0].ctypes.data, tb[1].ctypes.data, tb[2].ctypes.data, ent['dyn'], 4,
-              *step_scalars(state, train_frac), ent['ptrs'], host.data_ptr(), key_new)
+    sc_ = ent.setdefault('scal', np.zeros(8, np.float32))
+    scal_ = step_scalars(state, train_frac)
+    sc_[:5] = scal_
+    if tt == 'hanerf':
+      cache['mask_size_mult'] = scal_[4]      # (the stats builder reports it: step_core only runs at capture time)
+    _lib.call('hugs_stage_step_pub', len(srcs), tb[0].ctypes.data, tb[1].ctypes.data, tb[2].ctypes.data, ent['dyn'], 5, sc_.ctypes.data,
+              ent['ptrs'], host.data_ptr(), key_new)
     if 'graph' not in ent:
       world = _world()
       g, g2 = torch.cuda.CUDAGraph(), (torch.cuda.CUDAGraph() if world > 1 else None)
@@ -471,14 +487,16 @@ def create_train_step(model, config, is_finetune=False):
       mode, lm = 2, mask
     d_mask = None
     if tt == 'hanerf':
-      # train_utils.py:190-193: the mask-size weight decays from _max to _min with the step
-      msm = max(config.hanerf_mask_size_loss_mult_min, config.hanerf_mask_size_loss_mult_max *
-                math.exp(-float(train_frac) * config.max_steps * config.hanerf_mask_size_loss_mult_k))
+      msm = mask_size_mult(train_frac)
       cache['mask_size_mult'] = msm
       d_mask = ws.get('d_mask', (N,))
       hst = ws.get('hanerf_stats', (2 * L + 2,))
-      _lib.call('hugs_hanerf_loss', N, L, pred, gt, mask_st['mask'], int(config.data_loss_type == 'charb'),
-                config.charb_padding, cache['coef'], msm, d_pred, d_mask, hst)
+      if dyn is not None:      # a step being captured: the weight is read from dyn[4] (step_scalars)
+        _lib.call('hugs_hanerf_loss_dyn', N, L, pred, gt, mask_st['mask'], int(config.data_loss_type == 'charb'),
+                  config.charb_padding, cache['coef'], dyn[4:5], d_pred, d_mask, hst)
+      else:
+        _lib.call('hugs_hanerf_loss', N, L, pred, gt, mask_st['mask'], int(config.data_loss_type == 'charb'),
+                  config.charb_padding, cache['coef'], msm, d_pred, d_mask, hst)
       tail[0:2 * L].copy_(hst[:2 * L])
       tail[o_han:o_han + 2].copy_(hst[2 * L:])
     elif tt == 'nerfw':

@@ -8,7 +8,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from tests.test_gpu_train_step import SMALL
+from tests.test_gpu_train_step import SMALL, HANERF, NERFW
 
 
 def _run(mode, gin, nsteps, rng_kind, n_patch=2, P=8):
@@ -59,6 +59,23 @@ def test_graph_replay_is_bit_identical_to_the_eager_step(rng_kind, variant):
     assert e[4] == g[4], (e[4], g[4])
   else:
     np.testing.assert_allclose(np.array(e[4]), np.array(g[4]), rtol=2e-3)
+
+
+@pytest.mark.parametrize('variant', ['hanerf', 'nerfw'])
+def test_graph_replay_of_the_transient_variants(variant):
+  """HA-NeRF (its mask-size weight decays with the step: a device-resident scalar of the captured step) and NeRF-W replayed from the
+  graph against the eager steps.  Their embedding rows are float-atomic scatter-adds (hugs_embed_scatter_add, k_glo_bwd), so two
+  runs agree to rounding, not bit for bit -- the bound is the one the GLO variant above uses."""
+  gin = list(HANERF if variant == 'hanerf' else NERFW)
+  e = _run('0', gin, 6, 'key')
+  g = _run('1', gin, 6, 'key')
+  assert not e[6] and g[6], 'the graph path did not engage'
+  assert e[5] == g[5] == 6
+  for a, b, name in zip(e[:3], g[:3], ('params', 'adam m', 'adam v')):
+    sc = float(a.abs().max())
+    assert float((a - b).abs().max()) <= 2e-3 * sc, (name, float((a - b).abs().max()), sc)
+  assert torch.equal(e[3], g[3]), 'jax key after 6 steps'
+  np.testing.assert_allclose(np.array(e[4]), np.array(g[4]), rtol=2e-3)
 
 
 def test_graph_is_not_used_where_the_step_cannot_be_captured():
