@@ -59,21 +59,31 @@ k_mask_head_draw(int N, int Npad, const float* __restrict__ mask, const float* _
   d_raw[n] = n < N ? d_mask[n] * m * (1.f - m) : 0.f;
 }
 
-// dW[k] = sum_n d_raw[n] X[n,k]; db = sum_n d_raw[n].  One thread per column, fixed order (deterministic).
+// dW[k] = sum_n d_raw[n] X[n,k]; db = sum_n d_raw[n] (column W).  256 threads = 16 columns x 16 row groups, the groups' partial sums
+// added in LDS in group order: deterministic.  (Round 5: one thread per column walked all N rows -- 1024 dependent loads, 386 us
+// of the HA-NeRF step.)
 template <int BF16>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 k_mask_head_dw(int N, int W, const void* __restrict__ X, int ldxv, const float* __restrict__ d_raw,
                float* __restrict__ dW, float* __restrict__ db) {
-  const int k = blockIdx.x * 64 + threadIdx.x;
+  __shared__ float red[16][17];
+  const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int k = blockIdx.x * 16 + c;
+  float a = 0.f;
   if (k < W) {
-    float a = 0.f;
-    for (int n = 0; n < N; ++n) a += d_raw[n] * ldx<BF16>(X, (size_t)n * ldxv + k);
-    dW[k] = a;
+#pragma unroll 4
+    for (int n = rg; n < N; n += 16) a += d_raw[n] * ldx<BF16>(X, (size_t)n * ldxv + k);
+  } else if (k == W) {
+#pragma unroll 4
+    for (int n = rg; n < N; n += 16) a += d_raw[n];
   }
-  if (k == W) {
-    float a = 0.f;
-    for (int n = 0; n < N; ++n) a += d_raw[n];
-    db[0] = a;
+  red[rg][c] = a;
+  __syncthreads();
+  if (rg == 0 && k <= W) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][c];
+    if (k < W) dW[k] = t; else db[0] = t;
   }
 }
 
@@ -170,9 +180,9 @@ extern "C" int hugs_mask_head_bwd(int dtype, int N, int Npad, int W, const void*
   if (Npad == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   k_mask_head_draw<<<(Npad + 255) / 256, 256, 0, st>>>(N, Npad, mask, d_mask, d_raw);
-  if (dtype == 2) k_mask_head_dw<2><<<W / 64 + 1, 64, 0, st>>>(N, W, X, ldx, d_raw, dW, db);
-  else if (dtype) k_mask_head_dw<1><<<W / 64 + 1, 64, 0, st>>>(N, W, X, ldx, d_raw, dW, db);
-  else k_mask_head_dw<0><<<W / 64 + 1, 64, 0, st>>>(N, W, X, ldx, d_raw, dW, db);
+  if (dtype == 2) k_mask_head_dw<2><<<W / 16 + 1, 256, 0, st>>>(N, W, X, ldx, d_raw, dW, db);
+  else if (dtype) k_mask_head_dw<1><<<W / 16 + 1, 256, 0, st>>>(N, W, X, ldx, d_raw, dW, db);
+  else k_mask_head_dw<0><<<W / 16 + 1, 256, 0, st>>>(N, W, X, ldx, d_raw, dW, db);
   HUGS_CHECK_LAUNCH("k_mask_head_bwd");
   return 0;
 }

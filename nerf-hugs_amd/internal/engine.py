@@ -816,7 +816,7 @@ class Engine:
       if fold:
         pass            # (computed on the head stream, in front of the bottleneck's weight gradient: head_dw_2)
       elif nerfw is not None:
-        G0t = self._transient_backward(theta, grad, lv, rays, N, d_dt, d_ct, d_u)
+        G0t = self._transient_backward(theta, grad, lv, rays, N, d_dt, d_ct, d_u, side=hl)
         Ht = spec.net_width_transient
         # dBott = Gv Wv[:Bw]^T + G0t Wt0[:Bw]^T: one GEMM over the two K segments
         _lib.call('hugs_gemm_nt', dt, M, Bw, H, Ht, Gv, H, G0t, Ht, self.wcat, H + Ht, None, None, 1, 0, 0, None, 0, None,
@@ -989,7 +989,7 @@ class Engine:
     if not spec.disable_rgb and spec.use_viewdirs:
       wait_event(main, heads_done)
 
-  def _transient_backward(self, theta, grad, lv, rays, N, d_dt, d_ct, d_u):
+  def _transient_backward(self, theta, grad, lv, rays, N, d_dt, d_ct, d_u, side=None):
     """Backward of the NeRF-W transient branch (heads -> trunk -> per-ray tra_vec part).  Returns G at the first
     transient layer's pre-activation [M, Ht]; writes the branch's weight gradients (=) and scatter-adds into
     TransientEmbed_0."""
@@ -1000,7 +1000,6 @@ class Engine:
     x3 = tacts[-1]
     ld_, lr_, lu_ = spec.layers[t0 + dtn:t0 + dtn + 3]
     G = ws.get('tbwd/Ga', (M, Ht), self.tdt)
-    other = ws.get('tbwd/Gb', (M, Ht), self.tdt)
     rws = ws.get('rgb_ws', (max(_lib.lib().cdll.hugs_rgb_bwd_ws_bytes() // 4, 1),))
     Wrt, _ = self._rgb_head(theta, spec, lr_, 'tbwd/rgbhead_t')
     _lib.call('hugs_rgb_bwd', dt, M, Ht, x3, Ht, Wrt, lv['rgb_t'], d_ct,
@@ -1010,26 +1009,45 @@ class Engine:
         _lib.call('hugs_affine', g_.numel(), g_, float(spec.rgb_premultiplier), 0.0, g_)
     dws = ws.get('dens_ws_t', (max(_lib.lib().cdll.hugs_density_bwd_ws_bytes(Ht) // 4, 1),))
     d_raw_t, d_raw_u = ws.get('tbwd/d_raw_t', (M,)), ws.get('tbwd/d_raw_u', (M,))
-    _lib.call('hugs_density_bwd', dt, M, Ht, x3, Ht, d_dt, lv['raw_t'], spec.density_bias, d_raw_t,
-              gview((spec.name, ld_['name'], 'kernel')).reshape(-1), gview((spec.name, ld_['name'], 'bias')), dws)
-    _lib.call('hugs_density_bwd', dt, M, Ht, x3, Ht, d_u, lv['raw_u'], 0.0, d_raw_u,
-              gview((spec.name, lu_['name'], 'kernel')).reshape(-1), gview((spec.name, lu_['name'], 'bias')), dws)
+    # Round 5: only rgb_t -> d_raw -> G_3 -> ... -> G_0 is on the way to dBott and the trunk backward.  The branch's weight gradients
+    # (two head column sums, three 128 x 128 products + reductions, the per-ray tra_vec part with its embedding scatter, the first
+    # layer's product: ~0.4 ms of small launches that sat BETWEEN the dX GEMMs) go to the head weight-gradient stream; every G_i
+    # keeps its own buffer until they have read it.
+    cur = torch.cuda.current_stream()
+    side = side if side is not None else cur
+    def on_side(fn):
+      ev = new_event(); ev.record(cur)
+      with torch.cuda.stream(side):
+        wait_event(side, ev)
+        fn()
+    _lib.call('hugs_density_bwd', dt, M, Ht, x3, Ht, d_dt, lv['raw_t'], spec.density_bias, d_raw_t, None, None, None)
+    _lib.call('hugs_density_bwd', dt, M, Ht, x3, Ht, d_u, lv['raw_u'], 0.0, d_raw_u, None, None, None)
+    def head_dw():
+      _lib.call('hugs_density_bwd', dt, M, Ht, x3, Ht, None, lv['raw_t'], spec.density_bias, d_raw_t,
+                gview((spec.name, ld_['name'], 'kernel')).reshape(-1), gview((spec.name, ld_['name'], 'bias')), dws)
+      _lib.call('hugs_density_bwd', dt, M, Ht, x3, Ht, None, lv['raw_u'], 0.0, d_raw_u,
+                gview((spec.name, lu_['name'], 'kernel')).reshape(-1), gview((spec.name, lu_['name'], 'bias')), dws)
+    on_side(head_dw)
     _lib.call('hugs_rank1_add2_mask', dt, M, Ht, d_raw_t, lay.view(theta, (spec.name, ld_['name'], 'kernel')).reshape(-1),
               d_raw_u, lay.view(theta, (spec.name, lu_['name'], 'kernel')).reshape(-1), x3, Ht, G, Ht)
     for i in range(dtn - 1, 0, -1):
       l = spec.layers[t0 + i]
       path = (spec.name, l['name'], 'kernel')
-      self._tn(M, Ht, Ht, tacts[i - 1], Ht, G, Ht, gview(path), gview((spec.name, l['name'], 'bias')))
+      Gi, xin = G, tacts[i - 1]
+      on_side(lambda Gi=Gi, xin=xin, path=path, l=l: self._tn(M, Ht, Ht, xin, Ht, Gi, Ht, gview(path), gview((spec.name, l['name'], 'bias'))))
+      Gn = ws.get(f'tbwd/G{i - 1}', (M, Ht), self.tdt)
       _lib.call('hugs_gemm_nt', dt, M, Ht, Ht, 0, G, Ht, None, 0, self.wn[path], Ht, None, None, 1, 0, 0, tacts[i - 1], Ht,
-                None, None, other, Ht)
-      G, other = other, G
+                None, None, Gn, Ht)
+      G = Gn
     lt = spec.layers[t0]
     gWt0 = gview((spec.name, lt['name'], 'kernel'))
     Wt0 = lay.view(theta, (spec.name, lt['name'], 'kernel'))
     d_rb = ws.get('tbwd/d_rb', (int(_lib.lib().cdll.hugs_raybias_bwd_ws_rows(N, 0, spec.num_tra)), Ht))
-    _lib.call('hugs_raybias_bwd', dt, N, S, Ht, 0, spec.num_tra, G, Ht, None, lv['tra'], Wt0[Bw:], rays.get('embed_idx'), d_rb,
-              gWt0[Bw:], gview(('TransientEmbed_0', 'embedding')))
-    self._tn(M, Bw, Ht, lv['bott'], Bw, G, Ht, gWt0[:Bw], gview((spec.name, lt['name'], 'bias')))
+    def first_dw(G0=G):
+      _lib.call('hugs_raybias_bwd', dt, N, S, Ht, 0, spec.num_tra, G0, Ht, None, lv['tra'], Wt0[Bw:], rays.get('embed_idx'), d_rb,
+                gWt0[Bw:], gview(('TransientEmbed_0', 'embedding')))
+      self._tn(M, Bw, Ht, lv['bott'], Bw, G0, Ht, gWt0[:Bw], gview((spec.name, lt['name'], 'bias')))
+    on_side(first_dw)
     return G
 
   # ---- HA-NeRF ImplicitMask (per ray) --------------------------------------------------------------

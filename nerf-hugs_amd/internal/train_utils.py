@@ -396,6 +396,18 @@ def create_train_step(model, config, is_finetune=False):
       ent['key_handed'] = (weakref.ref(key_new), key_new._version)
     return state, LazyStats(None, stats_builder(state), host=host, pool=ent['host_pool']), (key_new if key_new is not None else rng)
 
+  def copy_many(pairs):
+    """dst.copy_(src) for a few small fp32 buffers in ONE launch (hugs_stage_step without scalars) instead of one blit each."""
+    pairs = [(s_, d_) for s_, d_ in pairs if s_.numel() > 0]
+    if not all(s_.is_contiguous() and d_.is_contiguous() and s_.element_size() == 4 and s_.numel() == d_.numel() for s_, d_ in pairs):
+      for s_, d_ in pairs:
+        d_.copy_(s_)
+      return
+    a = np.array([s_.data_ptr() for s_, _ in pairs], np.uint64)
+    b = np.array([d_.data_ptr() for _, d_ in pairs], np.uint64)
+    w = np.array([s_.numel() for s_, _ in pairs], np.int32)
+    _lib.call('hugs_stage_step', len(pairs), a.ctypes.data, b.ctypes.data, w.ctypes.data, None, 0, 0.0, 0.0, 0.0, 0.0)
+
   def step_core(state, rays, gt, N, rng, train_frac, inlier_thresholds, dyn, reduce):
     """The first part of the step: forward, losses, backward and -- when `reduce` -- the all-reduces of the gradient buffer
     (buckets issued underneath the backward pass + the rest).  dyn: None, or the device scalars of a captured step.  Returns
@@ -497,21 +509,19 @@ def create_train_step(model, config, is_finetune=False):
       else:
         _lib.call('hugs_hanerf_loss', N, L, pred, gt, mask_st['mask'], int(config.data_loss_type == 'charb'),
                   config.charb_padding, cache['coef'], msm, d_pred, d_mask, hst)
-      tail[0:2 * L].copy_(hst[:2 * L])
-      tail[o_han:o_han + 2].copy_(hst[2 * L:])
+      copy_many([(hst[:2 * L], tail[0:2 * L]), (hst[2 * L:], tail[o_han:o_han + 2])])
     elif tt == 'nerfw':
       fin_ = levels[-1]
       Mf = N * fin_['S']
       pred_nw = ws.get('pred_nerfw', (L, N, 3))
-      pred_nw.copy_(pred)
-      pred_nw[L - 1].copy_(fin_['rgb_combined'])       # the final level is scored on rgb_combined (train_utils.py:158-159)
+      # the final level is scored on rgb_combined (train_utils.py:158-159)
+      copy_many(([(pred[:L - 1], pred_nw[:L - 1])] if L > 1 else []) + [(fin_['rgb_combined'], pred_nw[L - 1])])
       nw = dict(d_rgb_combined=d_pred[L - 1], d_beta=ws.get('d_beta', (N,)),
                 dens_t_const=config.nerfw_density_loss_mult / Mf)
       nst = ws.get('nerfw_stats', (2 * L + 1,))
       _lib.call('hugs_nerfw_loss', N, L, pred_nw, gt, fin_['uncertainty'], int(config.data_loss_type == 'charb'),
                 config.charb_padding, cache['coef'], config.nerfw_beta_loss_mult, d_pred, nw['d_beta'], nst)
-      tail[0:2 * L].copy_(nst[:2 * L])
-      tail[o_nw:o_nw + 1].copy_(nst[2 * L:])
+      copy_many([(nst[:2 * L], tail[0:2 * L]), (nst[2 * L:], tail[o_nw:o_nw + 1])])
       _lib.call('hugs_sum', Mf, fin_['dens_t'], 1.0 / Mf, tail[o_nw + 1:o_nw + 2])
     else:
       _lib.call('hugs_data_loss', N, L, pred, gt, lm, mode, config.withmask_transient_weight,
