@@ -14,6 +14,8 @@
 // (hugs_gemm.hip's convention: the K-stage LDS layout, its XOR swizzle and the mask-bit layout are that file's).  A layer's
 // weights stream from L2 straight into registers, three K-stages ahead; the first three stages of the NEXT layer are requested
 // before the current layer's epilogue.  Compiled for both 16-bit operand formats (dtype 1 = bf16, 2 = IEEE half).
+#include <type_traits>
+#include <stdlib.h>
 #include "hugs_common.h"
 
 namespace {
@@ -412,6 +414,248 @@ __global__ __launch_bounds__(256, 1) void k_field_fwd(const FieldFwd P) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Round 5: the same forward on EIGHT waves (two per SIMD), as k_mlp256_chain3_fwd8 (hugs_mlpfuse.hip): wave wq owns output columns
+// [32 wq, 32 wq + 32) of the 256-wide layers (16 of layer 1's 128) for all 64 rows -- 136 registers of weights instead of 272, so two
+// waves fit a SIMD and one wave's epilogue / LDS waits sit under the other's MFMAs (one wave per SIMD: ~0.5 of the byte bound).  Costs:
+// every wave reads the whole activation tile as its B operand (twice the LDS fragment traffic), the two waves of a pair each hold half
+// of the pair's mask words (OR-ed through LDS behind the layer's barrier), the rgb head's partial sums come from 8 waves.
+// Same arithmetic per output element as k_field_fwd (same K order, same rounding points): bit-identical activations, densities,
+// mask bits; rgb sums its 8 partial dot products in a different order than the 4-wave kernel's 4.
+// ------------------------------------------------------------------------------------------------
+// a tile's inputs over 512 threads: thread (row = tid >> 3, cc = tid & 7) requests 8 bytes of the row's hash features and the 32 bytes
+// [32 cc, 32 cc + 32) of its ray's head-input template (half of k_field_fwd's per-thread share: 10 registers in flight instead of 20)
+struct Ff8In { uint2 x; uint4 t0, t1; };
+__device__ __forceinline__ Ff8In ff8_load_inputs(const FieldFwd& P, int m0, int tid) {
+  const int row = tid >> 3, cc = tid & 7;
+  Ff8In r;
+  r.x = *(const uint2*)((const char*)(P.X0 + (size_t)m0 * P.ldx0) + ff_fresh((unsigned)(row * P.ldx0 + cc * 4) * 2u));
+  const unsigned ray = (unsigned)(m0 + row) / (unsigned)P.S;
+  const char* tp = (const char*)P.tmpl + ff_fresh(ray * 256u + (unsigned)cc * 32u);
+  r.t0 = *(const uint4*)tp; r.t1 = *(const uint4*)(tp + 16);
+  return r;
+}
+__device__ __forceinline__ void ff8_put_inputs(unsigned char* A, float* sel_s, const Ff8In& nx, float nsel, int tid) {
+  const int row = tid >> 3, cc = tid & 7, sw = 3 * ((row >> 2) & 1);
+  *(uint2*)(A + 7 * FF_STAGE + row * 64 + (((cc >> 1) ^ sw) << 4) + (cc & 1) * 8) = nx.x;
+  unsigned char* tb = A + (cc >> 1) * FF_STAGE + row * 64;
+  const int k0 = (cc & 1) * 2;
+  *(uint4*)(tb + ((k0 ^ sw) << 4)) = nx.t0; *(uint4*)(tb + (((k0 + 1) ^ sw) << 4)) = nx.t1;
+  if (tid < FF_ROWS) sel_s[tid] = nsel;
+}
+
+template <int NST>
+__device__ __forceinline__ void ff8_copy_out(const unsigned char* src, char* dst_tile, int tid) {
+  // a finished tile (NST K-stages of all 64 rows) LDS -> HBM rows of 64 NST bytes, 16 bytes per thread and step, 512 threads
+#pragma unroll
+  for (int q = 0; q < NST / 2; ++q) {
+    const int id = q * 512 + tid, row = id / (NST * 4), cc = id % (NST * 4);
+    const uint4 v = *(const uint4*)(src + (cc >> 2) * FF_STAGE + row * 64 + (((cc & 3) ^ (3 * ((row >> 2) & 1))) << 4));
+    *(uint4*)(dst_tile + ff_fresh((unsigned)(row * (NST * 64) + cc * 16))) = v;
+  }
+}
+
+template <int F16, int KST, int CP, bool LAST>
+__device__ __forceinline__ void ff8_layer256(const unsigned char* A, int frag_off, const typename FfOps<F16>::x8_t (&w)[KST][2],
+                                             const float* bias /* + wq*32 + kb*4 */, int m0, int wq, int r16, int kb, int lane,
+                                             unsigned char* An, uint32_t* bpart /* LDS [2][64] of this wave */, uint16_t* Y,
+                                             const unsigned char* cp_src, char* cp_dst, int tid,
+                                             const typename FfOps<F16>::x8_t (&c2f)[3], float (*red)[8][3]) {
+  typedef typename FfOps<F16>::x8_t x8_t;
+  const int swz = 3 * ((r16 >> 2) & 1);
+  float4 bb[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bb[j] = *(const float4*)(bias + j * 16);
+  const int jj0 = (wq & 1) * 2;      // this wave's fragments are j = jj0, jj0 + 1 of its NT wave's 64-column block
+  uint32_t bw = 0u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ff_f32x4_t acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[j] = ff_f32x4_t{bb[j].x, bb[j].y, bb[j].z, bb[j].w};
+    {
+      x8_t xa[KST];
+#pragma unroll
+      for (int s = 0; s < KST; ++s) xa[s] = *(const x8_t*)(A + s * FF_STAGE + frag_off + i * 16 * 64);
+#pragma unroll
+      for (int s = 0; s < KST; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = FfOps<F16>::mfma(w[s][j], xa[s], acc[j]);
+    }
+    if constexpr (CP > 0) { if (i == 0) ff8_copy_out<CP>(cp_src, cp_dst, tid); }
+    uint32_t uk[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const ff_f32x4_t v = acc[j];
+      uint2 u;
+      u.x = ff_relu_pk(ff_cvt_pk<F16>(v[0], v[1])); u.y = ff_relu_pk(ff_cvt_pk<F16>(v[2], v[3]));
+      uk[j][0] = u.x; uk[j][1] = u.y;
+      // (LAST: H1 goes through LDS too -- as 8-byte stores from the accumulator layout a row block's 16 rows x 32 bytes cost the
+      //  vector-memory path ~100 cycles per instruction; the tile leaves as whole 512-byte rows from inside the NEXT tile's first layers)
+      const int ch = j * 2 + (kb >> 1);
+      *(uint2*)(An + wq * FF_STAGE + (i * 16 + r16) * 64 + ((ch ^ swz) << 4) + (kb & 1) * 8) = u;
+      if constexpr (!LAST) {
+        const int k = (i & 1) * 8 + (jj0 + j) * 2;
+        bw |= ff_nz_pk(u.x) << k;
+        bw |= ff_nz_pk(u.y) << (k + 1);
+      }
+    }
+    if (!LAST && (i & 1)) { bpart[(i >> 1) * 64 + lane] = bw; bw = 0u; }
+    if (LAST) {
+      // rgb head on the rounded activations (k_field_fwd's scheme): this wave's two fragments are ONE B operand
+      typedef unsigned __attribute__((ext_vector_type(4))) u4;
+      const u4 bw4 = {uk[0][0], uk[0][1], uk[1][0], uk[1][1]};
+      const x8_t bf = __builtin_bit_cast(x8_t, bw4);
+      ff_f32x4_t pr = {0.f, 0.f, 0.f, 0.f};
+      pr = FfOps<F16>::mfma(c2f[0], bf, pr);
+      pr = FfOps<F16>::mfma(c2f[1], bf, pr);
+      if (!F16) pr = FfOps<F16>::mfma(c2f[2], bf, pr);
+      if (kb == 0) { red[i * 16 + r16][wq][0] = pr[0]; red[i * 16 + r16][wq][1] = pr[1]; red[i * 16 + r16][wq][2] = pr[2]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);      // (nothing of the next row block is hoisted above this epilogue: the other wave fills the pipe)
+  }
+}
+
+template <int F16>
+__global__ __launch_bounds__(512, 1) void k_field_fwd8(const FieldFwd P) {
+  typedef typename FfOps<F16>::x8_t x8_t;
+  __shared__ __attribute__((aligned(16))) unsigned char act[3][FF_ACT];      // [2]: the finished H1 tile on its way out
+  __shared__ float red[FF_ROWS][8][3];
+  __shared__ float sel_s[FF_ROWS];
+  __shared__ float cb2s[4];
+  __shared__ __attribute__((aligned(16))) float bs[256 + 128 + 256 + 256];      // b0 | b1x | cb0 | cb1
+  __shared__ uint32_t bparts[2][8][2][64];                                       // [layer parity][wave][word][lane]: mask-bit halves
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kb = lane >> 4;
+  const int swz = 3 * ((r16 >> 2) & 1);
+  const int frag_off = r16 * 64 + ((kb ^ swz) << 4);
+  const int ntile = P.M / FF_ROWS, G = (int)gridDim.x;
+  if (tid < 3) cb2s[tid] = P.cb2[tid];
+  // the rgb layer's weights for this wave's 32 columns as an MFMA A operand in the slot order of the packed outputs: lane (n = r16, kb),
+  // slot e -> column wq*32 + (e >> 2)*16 + kb*4 + (e & 3); hi + lo (+ third) 16-bit slices of the fp32 value
+  x8_t c2f[3];
+  {
+    typedef unsigned __attribute__((ext_vector_type(4))) u4;
+    u4 hw, lw, tw;
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      const int c0 = wq * 32 + (e2 >> 1) * 16 + kb * 4 + (e2 & 1) * 2;
+      const float v0 = r16 < 3 ? P.c2[c0 * 3 + r16] : 0.f, v1 = r16 < 3 ? P.c2[(c0 + 1) * 3 + r16] : 0.f;
+      const uint32_t h = ff_cvt_pk<F16>(v0, v1);
+      const float r0 = v0 - FfOps<F16>::lo(h), r1 = v1 - FfOps<F16>::hi(h);
+      const uint32_t l = ff_cvt_pk<F16>(r0, r1);
+      hw[e2] = h; lw[e2] = l;
+      tw[e2] = ff_cvt_pk<F16>(r0 - FfOps<F16>::lo(l), r1 - FfOps<F16>::hi(l));
+    }
+    c2f[0] = __builtin_bit_cast(x8_t, hw); c2f[1] = __builtin_bit_cast(x8_t, lw); c2f[2] = __builtin_bit_cast(x8_t, tw);
+  }
+  for (int e = tid; e < 256; e += 512) { bs[e] = P.b0[e]; bs[384 + e] = P.cb0[e]; bs[640 + e] = P.cb1[e]; }
+  if (tid < 128) bs[256 + tid] = P.b1[tid];
+  const bool l1_live = wq * 16 < 16 + P.ngeo;      // (wave-uniform) this wave's 16 columns of layer 1 hold real outputs
+  x8_t w0r[1][2], w1r[8][1], c0r[4][2], c1r[8][2];
+  {
+    auto load_w = [&](auto& w, const uint16_t* W, unsigned wo, int ldw, auto kst, auto nj) {
+#pragma unroll
+      for (int s = 0; s < decltype(kst)::value; ++s)
+#pragma unroll
+        for (int j = 0; j < decltype(nj)::value; ++j) w[s][j] = *(const x8_t*)((const char*)W + (wo + (unsigned)(j * 16 * ldw + s * 32) * 2u));
+    };
+    load_w(w0r, P.W0t, (unsigned)((wq * 32 + r16) * P.ldw0 + kb * 8) * 2u, P.ldw0, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+    load_w(w1r, P.W1t, (unsigned)((wq * 16 + r16) * 256 + kb * 8) * 2u, 256, std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{});
+    load_w(c0r, P.C0t, (unsigned)((wq * 32 + r16) * 128 + kb * 8) * 2u, 128, std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
+    load_w(c1r, P.C1t, (unsigned)((wq * 32 + r16) * 256 + kb * 8) * 2u, 256, std::integral_constant<int, 8>{}, std::integral_constant<int, 2>{});
+  }
+  // the two waves of a pair each hold half of the pair's mask words: wave 2p stores word 0, wave 2p + 1 word 1 (hugs_gemm.hip's layout)
+  auto bits_out = [&](int par, uint32_t* bits, int m0) {
+    if (!bits) return;
+    const int p2 = wq & ~1, wd_ = wq & 1;
+    const uint32_t v = bparts[par][p2][wd_][lane] | bparts[par][p2 + 1][wd_][lane];
+    uint32_t* btile = bits + ((size_t)(m0 >> 8) * 8 + (size_t)(((m0 >> 7) & 1) * 4 + (wq >> 1))) * 256;
+    const int i_nt0 = ((m0 >> 6) & 1) * 4;
+    *(uint32_t*)((char*)btile + (ff_fresh((unsigned)lane * 4u) + (unsigned)(((i_nt0 >> 1) + wd_) * 64) * 4u)) = v;
+  };
+  Ff8In nx;
+  float nsel = 0.f;
+  if ((int)blockIdx.x < ntile) {
+    nx = ff8_load_inputs(P, (int)blockIdx.x * FF_ROWS, tid);
+    if (tid < FF_ROWS) nsel = P.sel[(size_t)blockIdx.x * FF_ROWS + tid];
+    ff8_put_inputs(act[0], sel_s, nx, nsel, tid);
+  }
+  __syncthreads();
+  int prev_m0 = -1, ti = -1;
+  for (int t = blockIdx.x; t < ntile; t += G) {
+    const int m0 = t * FF_ROWS;
+    const bool has_next = t + G < ntile;
+    if (prev_m0 >= 0) ff8_copy_out<8>(act[2], (char*)(P.H1 + (size_t)prev_m0 * 256), tid);      // (act[2] is rewritten three barriers from here)
+    prev_m0 = m0;
+    ++ti;
+    FF_TP(0);
+    // ---- base layer 0: 32 -> 256, relu ------------------------------------------------------------------------------
+    ff8_layer256<F16, 1, 0, false>(act[0] + 7 * FF_STAGE, frag_off, w0r, bs + wq * 32 + kb * 4, m0, wq, r16, kb, lane, act[1], &bparts[0][wq][0][0],
+                                   nullptr, nullptr, nullptr, tid, c2f, red);      // (Y0 -> HBM: in layer 1's loop)
+    FF_TP(1);
+    __syncthreads();
+    FF_TP(2);
+    bits_out(0, P.bY0, m0);
+    // ---- base layer 1: 256 -> 1 + ngeo (no activation) in HEAD-INPUT column order: this wave's 16 columns ----------------
+    ff8_copy_out<8>(act[1], (char*)(P.Y0 + (size_t)m0 * 256), tid);
+    FF_TP(3);
+    if (l1_live) {
+      const float4 b1v = *(const float4*)(bs + 256 + wq * 16 + kb * 4);
+      const int n = wq * 16 + kb * 4;
+      const bool geo = n >= 16 && n < 16 + P.ngeo;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ff_f32x4_t a = {b1v.x, b1v.y, b1v.z, b1v.w};
+        x8_t xa[8];
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) xa[s_] = *(const x8_t*)(act[1] + s_ * FF_STAGE + frag_off + i * 16 * 64);
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) a = FfOps<F16>::mfma(w1r[s_][0], xa[s_], a);
+        const int row = i * 16 + r16;
+        uint2 u;
+        u.x = ff_cvt_pk<F16>(a[0], a[1]); u.y = ff_cvt_pk<F16>(a[2], a[3]);
+        if (geo) *(uint2*)(act[0] + ((n >> 5) * FF_STAGE + row * 64 + ((((n & 31) >> 3) ^ swz) << 4) + (n & 4) * 2)) = u;
+        if (n == 0) {
+          *(uint16_t*)((char*)(P.raw + m0) + ff_fresh((unsigned)row * 2u)) = (uint16_t)u.x;
+          *(float*)((char*)(P.density + m0) + ff_fresh((unsigned)row * 4u)) = nf_density_value(FfOps<F16>::lo(u.x), P.dact, P.dbias) * sel_s[row];
+        }
+      }
+    }
+    FF_TP(4);
+    __syncthreads();
+    FF_TP(5);
+    // ---- colour layer 0: 128 -> 256, relu (the head input goes to HBM in its loop); the next tile's inputs are requested here ----
+    if (has_next) {
+      nx = ff8_load_inputs(P, m0 + G * FF_ROWS, tid);
+      if (tid < FF_ROWS) nsel = *(const float*)((const char*)(P.sel + (size_t)m0 + (size_t)G * FF_ROWS) + ff_fresh((unsigned)tid * 4u));
+    }
+    ff8_layer256<F16, 4, 4, false>(act[0], frag_off, c0r, bs + 384 + wq * 32 + kb * 4, m0, wq, r16, kb, lane, act[1], &bparts[1][wq][0][0], nullptr,
+                                   act[0], (char*)(P.Xh + (size_t)m0 * 128), tid, c2f, red);      // (H0 -> HBM: in the next loop)
+    FF_TP(6);
+    __syncthreads();
+    FF_TP(7);
+    bits_out(1, P.bH0, m0);
+    // ---- colour layer 1: 256 -> 256, relu; rgb = sigmoid(H1 c2 + cb2) on the rounded activations ---------------------------
+    if (has_next) ff8_put_inputs(act[0], sel_s, nx, nsel, tid);      // (act[0] is free since the barrier above)
+    FF_TP(8);
+    ff8_layer256<F16, 8, 8, true>(act[1], frag_off, c1r, bs + 640 + wq * 32 + kb * 4, m0, wq, r16, kb, lane, act[2], nullptr, nullptr,
+                                  act[1], (char*)(P.H0 + (size_t)m0 * 256), tid, c2f, red);
+    FF_TP(9);
+    __syncthreads();
+    FF_TP(10);
+    if (tid < FF_ROWS * 3) {
+      const int row = tid / 3, c = tid - row * 3;
+      const float a = (((red[row][0][c] + red[row][1][c]) + (red[row][2][c] + red[row][3][c])) +
+                       ((red[row][4][c] + red[row][5][c]) + (red[row][6][c] + red[row][7][c]))) + cb2s[c];
+      *(float*)((char*)(P.rgb + (size_t)m0 * 3) + ff_fresh((unsigned)tid * 4u)) = 1.f / (1.f + expf(-a));
+    }
+    FF_TP(11);
+  }
+  if (prev_m0 >= 0) ff8_copy_out<8>(act[2], (char*)(P.H1 + (size_t)prev_m0 * 256), tid);      // (behind the last tile's final barrier)
+}
+
+// ------------------------------------------------------------------------------------------------
 // Backward of the same two networks from the colour layer 1 gradient down to the hash-feature gradient (models/nerfacto.py's
 // autograd through :693-759), one launch:
 //   G0  = (G1 c1^T) * relu'(H0)            [M,256]   (G1 = the gradient at colour layer 1's pre-activation: hugs_rgb_bwd writes it)
@@ -673,7 +917,13 @@ extern "C" int hugs_nf_field_fwd(int dtype, long long M, int S, const void* X0, 
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) ncu = 256;
   const int ntile = (int)(M / FF_ROWS);
   const dim3 grid(ntile < ncu ? ntile : ncu), block(256);
-  if (dtype == 2) hipLaunchKernelGGL(k_field_fwd<1>, grid, block, 0, (hipStream_t)stream, P);
+  static int waves8 = -1;      // HUGS_FF_WAVES=4: the one-wave-per-SIMD kernel of round 4
+  if (waves8 < 0) { const char* e = getenv("HUGS_FF_WAVES"); waves8 = !(e && e[0] == '4'); }
+  if (waves8) {
+    if (dtype == 2) hipLaunchKernelGGL(k_field_fwd8<1>, grid, dim3(512), 0, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL(k_field_fwd8<0>, grid, dim3(512), 0, (hipStream_t)stream, P);
+  }
+  else if (dtype == 2) hipLaunchKernelGGL(k_field_fwd<1>, grid, block, 0, (hipStream_t)stream, P);
   else hipLaunchKernelGGL(k_field_fwd<0>, grid, block, 0, (hipStream_t)stream, P);
   HUGS_CHECK_LAUNCH("hugs_nf_field_fwd");
   return 0;

@@ -36,8 +36,16 @@ if hasattr(cd, 'hugs_ff_trace_read'):
   cd.hugs_ff_trace_read(buf.ctypes.data_as(ctypes.c_void_p))
   tr = buf.reshape(2, 8, 16)
   names = ['L0', '-', 'sync', 'L1 mma+copyY0', 'L1 epi', 'sync', 'C0(+loads,copyXh)', '-', 'sync', 'put inputs', 'C1(+copyH0,rgb)', '-', 'sync', 'final']
+  if os.environ.get('HUGS_FF_WAVES', '8') != '4':
+    names = ['copyH1+L0', 'sync', 'bits+copyY0', 'L1', 'sync', 'C0(+loads,copyXh)', 'sync', 'bits+put', 'C1(+copyH0,rgb)', 'sync', 'final']
   for w in range(2):
     print('wave', 0 if w == 0 else 3, 'phase cycles per tile:')
     for ti in range(1, 6):
-      d = np.diff(tr[w, ti][:15]); nxt = tr[w, ti + 1, 0] - tr[w, ti, 14]
+      last = 14 if os.environ.get('HUGS_FF_WAVES', '8') == '4' else 11
+      d = np.diff(tr[w, ti][:last + 1]); nxt = tr[w, ti + 1, 0] - tr[w, ti, last]
       print('   tile', ti, ' '.join(f'{n}={int(v)}' for n, v in zip(names, d)), 'loop=', int(nxt), 'total', int(tr[w, ti + 1, 0] - tr[w, ti, 0]))
+# checksums of every output (A/B of kernel forms: HUGS_FF_WAVES=4 vs default must agree bit for bit except rgb's summation order)
+import hashlib
+for name, t in (('Y0', Y0), ('raw', raw), ('Xh', Xh), ('H0', H0), ('H1', H1), ('bY0', bY0), ('bH0', bH0), ('dens', dens)):
+  print('  ', name, hashlib.md5(t.cpu().numpy().tobytes()).hexdigest()[:12])
+print('   rgb sum', float(rgb.double().sum()))
