@@ -173,6 +173,43 @@ def test_cast_ipe_vs_oracle_and_golden(golden, warp):
     np.testing.assert_allclose(got[..., :63], golden[f'{tag}/l1_ipe_sub'][..., :63], atol=2e-5)
 
 
+def test_cast_ipe_general_basis_shapes_bf16_and_fp32():
+  """Basis / degree combinations off the bf16 fast path (it takes feature counts per half that are multiples of 4: 21 x 12): an
+  octahedron basis (3 directions) with 5 degrees = 15 features per half, 32-column rows -- both builds against the oracle, padding zero."""
+  from oracle import torch_ref as R
+  L = _L()
+  N, S, nb, deg = 32, 64, 3, 5
+  g = torch.Generator().manual_seed(2)
+  basis = torch.tensor(R.generate_basis('octahedron', 1).T.copy(), dtype=torch.float32)
+  assert basis.shape == (3, nb)
+  o = torch.randn(N, 3, generator=g) * 0.5
+  d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
+  radii = 5e-4 + 1.5e-3 * torch.rand(N, 1, generator=g)
+  td = torch.sort(torch.rand(N, S + 1, generator=g) * 3 + 0.1, -1).values
+  means, covs = R.cast_rays(td, o, d, radii)
+  lm, lv = R.lift_and_diagonalize(means, covs, basis)
+  ref = R.integrated_pos_enc(lm, lv, 0, deg).reshape(N * S, 2 * nb * deg)
+  args = (N, S, td.to(dev), o.to(dev), d.to(dev), radii.reshape(-1).to(dev), basis.to(dev), nb, 0, 0, deg)
+  out = torch.full((N * S, 32), 7.0, device=dev)
+  L.call('hugs_cast_ipe_fwd', *args, 0, 32, out)
+  assert float((out.cpu()[:, :30] - ref).abs().max()) < 2e-5 and float(out[:, 30:].abs().max()) == 0
+  outb = torch.full((N * S, 32), 7.0, device=dev, dtype=torch.bfloat16)
+  L.call('hugs_cast_ipe_fwd', *args, 1, 32, outb)
+  assert float((outb.float().cpu()[:, :30] - ref).abs().max()) < 5e-3 and float(outb[:, 30:].float().abs().max()) == 0
+  # ... and one ON the fast path with a ragged last workgroup (64 samples per workgroup; 33 rays x 3 samples = 99)
+  N2, S2 = 33, 3
+  td2 = torch.sort(torch.rand(N2, S2 + 1, generator=g) * 3 + 0.1, -1).values
+  o2, d2, r2 = torch.randn(N2, 3, generator=g) * 0.5, torch.nn.functional.normalize(torch.randn(N2, 3, generator=g), dim=-1), torch.full((N2, 1), 1e-3)
+  b21 = torch.tensor(R.generate_basis('icosahedron', 2).T.copy(), dtype=torch.float32)
+  m2, c2 = R.cast_rays(td2, o2, d2, r2)
+  lm2, lv2 = R.lift_and_diagonalize(m2, c2, b21)
+  ref2 = R.integrated_pos_enc(lm2, lv2, 0, 12).reshape(N2 * S2, 504)
+  ob = torch.full((N2 * S2 + 5, 512), 7.0, device=dev, dtype=torch.bfloat16)      # (+5 guard rows)
+  L.call('hugs_cast_ipe_fwd', N2, S2, td2.to(dev), o2.to(dev), d2.to(dev), r2.reshape(-1).to(dev), b21.to(dev), 21, 0, 0, 12, 1, 512, ob)
+  assert float((ob[:N2 * S2].float().cpu()[:, :504] - ref2).abs().max()) < 6e-3
+  assert float(ob[:N2 * S2, 504:].float().abs().max()) == 0 and float((ob[N2 * S2:].float() - 7.0).abs().max()) == 0
+
+
 def test_dir_enc_vs_golden(golden):
   L = _L()
   v = G(golden['cfg2_det/viewdirs'])

@@ -93,3 +93,41 @@ def test_graph_is_not_used_where_the_step_cannot_be_captured():
     assert not train_step.graph_active() and np.isfinite(float(stats['loss']))
   finally:
     train_utils._STEP_GRAPH = old
+
+
+def test_stage_step_pub_and_hanerf_loss_dyn_through_the_c_abi():
+  """hugs_stage_step_pub: <= 16 copies + <= 8 scalars + the two publish addresses in one launch; hugs_hanerf_loss_dyn == hugs_hanerf_loss
+  with the mask-size weight read from device memory."""
+  import ctypes
+  from nerf_hugs_amd import _lib as L
+  dev = 'cuda'
+  g = torch.Generator(device=dev).manual_seed(0)
+  srcs = [torch.randn(n, generator=g, device=dev) for n in (3, 1024, 70001)] + [torch.randint(0, 1 << 30, (2,), generator=g, device=dev, dtype=torch.int32)]
+  dsts = [torch.zeros_like(t) for t in srcs]
+  a = np.array([t.data_ptr() for t in srcs], np.uint64); b = np.array([t.data_ptr() for t in dsts], np.uint64)
+  w = np.array([t.numel() for t in srcs], np.int32)
+  dyn = torch.zeros(8, device=dev)
+  ptrs = torch.zeros(2, dtype=torch.int64, device=dev)
+  sc = np.array([0.5, 1e-3, 0.25, 0.125, 7.0, 0, 0, 0], np.float32)
+  L.call('hugs_stage_step_pub', len(srcs), a.ctypes.data, b.ctypes.data, w.ctypes.data, dyn, 5, sc.ctypes.data, ptrs, 0x1234560, dsts[0])
+  torch.cuda.synchronize()
+  for s_, d_ in zip(srcs, dsts):
+    assert torch.equal(s_, d_)
+  assert dyn.cpu().tolist() == [0.5, float(np.float32(1e-3)), 0.25, 0.125, 7.0, 0.0, 0.0, 0.0]
+  assert ptrs.cpu().tolist() == [0x1234560, dsts[0].data_ptr()]
+  with pytest.raises(ValueError):      # (argument errors surface as ValueError, as the reference's do)
+    L.call('hugs_stage_step_pub', 0, None, None, None, dyn, 9, sc.ctypes.data, ptrs, 0, None)      # > 8 scalars
+  # HA-NeRF loss, by-value vs device-resident weight
+  N, Lv = 256, 2
+  pred, gt, mask = torch.rand(Lv, N, 3, generator=g, device=dev), torch.rand(N, 3, generator=g, device=dev), torch.rand(N, generator=g, device=dev)
+  coef = torch.tensor([0.1, 1.0], device=dev)
+  outs = []
+  for form in (0, 1):
+    dp, dm, st = torch.zeros(Lv, N, 3, device=dev), torch.zeros(N, device=dev), torch.zeros(2 * Lv + 2, device=dev)
+    if form == 0:
+      L.call('hugs_hanerf_loss', N, Lv, pred, gt, mask, 1, 1e-3, coef, 0.0371, dp, dm, st)
+    else:
+      L.call('hugs_hanerf_loss_dyn', N, Lv, pred, gt, mask, 1, 1e-3, coef, torch.tensor([0.0371], device=dev), dp, dm, st)
+    outs.append((dp, dm, st))
+  for x, y in zip(*outs):
+    assert torch.equal(x, y)
