@@ -139,6 +139,9 @@ int hugs_rgb_fwd(int dtype, int M, int H, const void* Hact, int ldh, const float
 long long hugs_rgb_bwd_ws_bytes(void);
 int hugs_rgb_bwd(int dtype, int M, int H, const void* Hact, int ldh, const float* W, const float* rgb,
                  const float* d_rgb, float pad, void* G, int ldg, float* dW, float* db, void* ws, void* stream);
+/* hugs_rgb_bwd with dW == NULL (H <= 256) leaves the weight gradient as per-workgroup partial sums in ws; this is its second half
+ * (dW [H,3], db [3]), for a stream that is not the one the G consumer waits on. */
+int hugs_rgb_bwd_reduce(int M, int H, float* dW, float* db, const void* ws, void* stream);
 
 /* render.py:130-151 compute_alpha_weights + :185-244 volumetric_rendering.  extras (optional, [nrays,5]) =
  * {acc, distance_mean, distance_median, distance_percentile_5, distance_percentile_95}. */

@@ -29,6 +29,7 @@ _PROTOS = {
     'hugs_raybias_bwd': 'iiiiii' 'p' 'i' 'ppppppp' 's',
     'hugs_rgb_fwd': 'iiipippfps',
     'hugs_rgb_bwd': 'iiipipppfpippps',
+    'hugs_rgb_bwd_reduce': 'iippps',
     'hugs_composite_fwd': 'iippppifpppps',
     'hugs_composite_bwd': 'iippppifpppps',
     'hugs_data_loss': 'iipppififppps',

@@ -517,6 +517,7 @@ extern "C" long long hugs_rgb_bwd_ws_bytes(void) { return (long long)RGB_BLOCKS 
 extern "C" int hugs_rgb_bwd(int dtype, int M, int H, const void* Hact, int ldh, const float* W, const float* rgb,
                             const float* d_rgb, float pad, void* G, int ldg, float* dW, float* db, void* ws, void* stream) {
   HUGS_REQUIRE(H > 0 && H % 128 == 0, -3, "hugs_rgb_bwd: head width %d unsupported (a multiple of 128)", H);
+  HUGS_REQUIRE(dW || H <= 256, -3, "hugs_rgb_bwd: dW == NULL (reduction deferred to hugs_rgb_bwd_reduce) needs a single column slab, H = %d", H);
   if (M <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   int rpb = (M + RGB_BLOCKS - 1) / RGB_BLOCKS;
@@ -536,10 +537,27 @@ extern "C" int hugs_rgb_bwd(int dtype, int M, int H, const void* Hact, int ldh, 
     else { if (dtype == 2) RGB_BWD(2, 2); else if (dtype) RGB_BWD(1, 2); else RGB_BWD(0, 2); }
 #undef RGB_BWD
     // (the bias gradient is the same in every slab: written by the first)
-    hipLaunchKernelGGL(k_slab_reduce_small, dim3((step * 3 + 3 + SRS_COLS - 1) / SRS_COLS), dim3(1024), 0, st, slab, nblk, step * 3, step * 3 + 4,
-                       dW + (size_t)c0 * 3, c0 == 0 ? 3 : 0, c0 == 0 ? db : nullptr);
+    if (dW)
+      hipLaunchKernelGGL(k_slab_reduce_small, dim3((step * 3 + 3 + SRS_COLS - 1) / SRS_COLS), dim3(1024), 0, st, slab, nblk, step * 3, step * 3 + 4,
+                         dW + (size_t)c0 * 3, c0 == 0 ? 3 : 0, c0 == 0 ? db : nullptr);
   }
   HUGS_CHECK_LAUNCH("hugs_rgb_bwd");
+  return 0;
+}
+
+// The second half of hugs_rgb_bwd called with dW == NULL (H <= 256: one column slab, its partial sums stay in ws): dW [H,3], db [3] from
+// the workspace.  Round 5: the 387-column reduction of the view head sat between rgb_bwd and the G_last product on the step's critical
+// chain -- 5 us alone, 54 us next to the proposal level's persistent backward kernel, whose workgroups it waited for; nothing before the
+// gradient exchange reads dW, so the step launches it on the head weight-gradient stream.
+extern "C" int hugs_rgb_bwd_reduce(int M, int H, float* dW, float* db, const void* ws, void* stream) {
+  HUGS_REQUIRE(H > 0 && H % 128 == 0 && H <= 256 && dW && db && ws, -3, "hugs_rgb_bwd_reduce: head width %d (128 or 256), non-null dW / db / ws", H);
+  if (M <= 0) return 0;
+  int rpb = (M + RGB_BLOCKS - 1) / RGB_BLOCKS;
+  rpb = (rpb + 15) / 16 * 16;
+  const int nblk = (M + rpb - 1) / rpb;
+  hipLaunchKernelGGL(k_slab_reduce_small, dim3((H * 3 + 3 + SRS_COLS - 1) / SRS_COLS), dim3(1024), 0, (hipStream_t)stream, (const float*)ws, nblk, H * 3,
+                     H * 3 + 4, dW, 3, db);
+  HUGS_CHECK_LAUNCH("hugs_rgb_bwd_reduce");
   return 0;
 }
 

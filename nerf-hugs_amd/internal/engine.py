@@ -22,6 +22,7 @@ _DW_AFTER_PROP = __import__('os').environ.get('HUGS_DW_AFTER_PROP', '1') == '1'
 _MLP_FUSE_ROWS = int(__import__('os').environ.get('HUGS_MLP_FUSE_ROWS', '32768'))      # 0: never fuse the 256-wide trunk tail
 _MLP_CHAIN3 = __import__('os').environ.get('HUGS_MLPFUSE_CHAIN3', '1') != '0'      # (the library reads the same switch)
 _HEAD_FOLD = __import__('os').environ.get('HUGS_HEAD_FOLD', '1') == '1'
+_RGB_REDUCE_SIDE = __import__('os').environ.get('HUGS_RGB_REDUCE_SIDE', '1') == '1'      # A/B: the view head's dW reduction on the head stream
 _SIDE_LATE = __import__('os').environ.get('HUGS_SIDE_LATE', '0') == '1'      # A/B: side-stream work released behind the G_last GEMM
 _TN_ITEM = np.dtype([('X', np.uint64), ('G', np.uint64), ('dW', np.uint64), ('db', np.uint64), ('ldx', np.int32), ('ldg', np.int32),
                      ('Mrows', np.int32), ('Kc', np.int32), ('N', np.int32), ('reserved', np.int32)])      # include/hugs.h HugsTnItem
@@ -769,12 +770,22 @@ class Engine:
       Gv = ws.get(tag + '/Gview', (M, H), self.tdt)
       rws = ws.get(tag + '/rgb_ws', (max(_lib.lib().cdll.hugs_rgb_bwd_ws_bytes() // 4, 1),))
       Wr, _ = self._rgb_head(theta, spec, lr, tag + '/rgbhead')
+      # (round 5: only G is on the way to the trunk; the head's 387-column weight-gradient reduction -- 5 us alone, 50+ next to the
+      #  proposal level's persistent backward kernel -- goes to the head weight-gradient stream with the other head gradients)
+      # (the final level only: the proposal levels share one workspace per MLP, and their next level's rgb_bwd would overwrite the
+      #  partial sums before a reduce on another stream has read them)
+      defer_rgb = _RGB_REDUCE_SIDE and H <= 256 and not spec.is_prop
+      def rgb_dw():
+        if defer_rgb:
+          _lib.call('hugs_rgb_bwd_reduce', M, H, gview((spec.name, lr['name'], 'kernel')), gview((spec.name, lr['name'], 'bias')), rws)
+        if spec.rgb_premultiplier != 1.:
+          for g_ in (gview((spec.name, lr['name'], 'kernel')), gview((spec.name, lr['name'], 'bias'))):
+            _lib.call('hugs_affine', g_.numel(), g_, float(spec.rgb_premultiplier), 0.0, g_)
       _lib.call('hugs_rgb_bwd', dt, M, H, lv['hview'], H, Wr, lv['rgb'],
-                d_rgb_s, spec.rgb_padding, Gv, H, gview((spec.name, lr['name'], 'kernel')),
+                d_rgb_s, spec.rgb_padding, Gv, H, None if defer_rgb else gview((spec.name, lr['name'], 'kernel')),
                 gview((spec.name, lr['name'], 'bias')), rws)
-      if spec.rgb_premultiplier != 1.:
-        for g_ in (gview((spec.name, lr['name'], 'kernel')), gview((spec.name, lr['name'], 'bias'))):
-          _lib.call('hugs_affine', g_.numel(), g_, float(spec.rgb_premultiplier), 0.0, g_)
+      if not defer_rgb:
+        rgb_dw()
       # net_depth_viewdirs > 1: back through the further view layers, last to first -- dW_i = h_{i-1}^T G_i, db_i = colsum G_i,
       # G_{i-1} = (G_i W_i^T) * (h_{i-1} > 0); Gv ends up as the gradient at the FIRST view layer's pre-activation, as below expects
       hvs = lv.get('hviews') or [lv['hview']]
@@ -796,6 +807,8 @@ class Engine:
       hl = self._side_stream(lane + 3)
 
       def head_dw_1():
+        if defer_rgb:
+          rgb_dw()
         _lib.call('hugs_density_bwd', dt, M, W, Ylast, W, None, lv['raw'], spec.density_bias, d_raw,
                   gview((spec.name, ld['name'], 'kernel'), True).reshape(-1), gview((spec.name, ld['name'], 'bias')), dws)
         _lib.call('hugs_raybias_bwd', dt, N, S, H, spec.nd, spec.num_glo, Gv, H, rays['dir_enc'], lv['glo'], Wv[Bw:],
