@@ -44,3 +44,5 @@ timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $ROOT/gpurun_out/r5e3/tra
 cd $ROOT
 STEP=9 python scratch/timeline.py gpurun_out/r5e3/trace_ref360 seq > gpurun_out/r5e3/ref360_timeline.txt 2>&1
 rm -rf gpurun_out/r5e3/trace_ref360
+timeout 900 python scratch/parity_margins.py > gpurun_out/r5e3/parity_margins.txt 2>&1
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r5e3/pytest_full.txt 2>&1; tail -3 gpurun_out/r5e3/pytest_full.txt
