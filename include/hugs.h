@@ -151,6 +151,11 @@ int hugs_composite_fwd(int nrays, int S, const float* density, const float* rgb_
 int hugs_composite_bwd(int nrays, int S, const float* density, const float* rgb_s, const float* tdist,
                        const float* dirs, int opaque_background, float bg, const float* d_rgb_out,
                        const float* d_w_extra, float* d_density, float* d_rgb_s, void* stream);
+/* hugs_composite_bwd that also writes the softplus density head's pre-activation gradient d_raw = d_density * sigmoid(raw + density_bias)
+ * (models.py:461 density = softplus(raw + bias): what hugs_density_bwd computes first when handed d_density) */
+int hugs_composite_bwd_raw(int nrays, int S, const float* density, const float* rgb_s, const float* tdist, const float* dirs,
+                           int opaque_background, float bg, const float* d_rgb_out, const float* d_w_extra, float* d_density,
+                           float* d_rgb_s, const float* raw, float density_bias, float* d_raw, void* stream);
 
 /* train_utils.py:72-111 compute_data_loss (mode 0 lossmult, 1 static mask, 2 robust mask) value + gradient */
 int hugs_data_loss(int N, int L, const float* pred, const float* gt, const float* lm_src, int mode,

@@ -32,6 +32,7 @@ _PROTOS = {
     'hugs_rgb_bwd_reduce': 'iippps',
     'hugs_composite_fwd': 'iippppifpppps',
     'hugs_composite_bwd': 'iippppifpppps',
+    'hugs_composite_bwd_raw': 'iippppifpppppfps',
     'hugs_data_loss': 'iipppififppps',
     'hugs_robust_mask': 'iipppfififpppps',
     'hugs_nf_robust_mask': 'iipppfififpppps',

@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int nrays, int S, const f
                                                        const float* __restrict__ dirs, int opaque, float bg,
                                                        const float* __restrict__ d_rgb_out,
                                                        const float* __restrict__ d_w_extra, float* __restrict__ d_density,
-                                                       float* __restrict__ d_rgb_s) {
+                                                       float* __restrict__ d_rgb_s, const float* __restrict__ raw,
+                                                       float density_bias, float* __restrict__ d_raw) {
   const int lane = threadIdx.x & 63, ray = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ray >= nrays) return;
   const int C = (S + 63) >> 6;
@@ -202,7 +203,10 @@ __global__ __launch_bounds__(256) void k_composite_bwd(int nrays, int S, const f
       // d w_i / d sd_i = T_i e^{-sd_i};  d w_j / d sd_i = -w_j for j > i
       float dsd = gw[k] * expf(-(R.pre[k] + R.sd[k])) - suf;
       if (opaque && i == S - 1) dsd = 0.f;   // the last interval was replaced by +inf: no gradient
-      d_density[(size_t)ray * S + i] = dsd * ((td[i + 1] - td[i]) * dnorm);
+      const float dd = dsd * ((td[i + 1] - td[i]) * dnorm);
+      d_density[(size_t)ray * S + i] = dd;
+      // (hugs_composite_bwd_raw: the softplus head's pre-activation gradient in the same pass -- k_density_bwd_raw's arithmetic)
+      if (d_raw) d_raw[(size_t)ray * S + i] = dd / (1.f + expf(-(raw[(size_t)ray * S + i] + density_bias)));
       suf += gw[k] * R.w[k];
     }
   }
@@ -222,15 +226,32 @@ extern "C" int hugs_composite_fwd(int nrays, int S, const float* density, const 
   return 0;
 }
 
-extern "C" int hugs_composite_bwd(int nrays, int S, const float* density, const float* rgb_s, const float* tdist,
-                                  const float* dirs, int opaque_background, float bg, const float* d_rgb_out,
-                                  const float* d_w_extra, float* d_density, float* d_rgb_s, void* stream) {
+static int composite_bwd_impl(int nrays, int S, const float* density, const float* rgb_s, const float* tdist,
+                              const float* dirs, int opaque_background, float bg, const float* d_rgb_out,
+                              const float* d_w_extra, float* d_density, float* d_rgb_s, const float* raw, float density_bias,
+                              float* d_raw, void* stream) {
   HUGS_REQUIRE(S >= 1 && S <= 1024, -3, "hugs_composite_bwd: %d samples per ray unsupported (<= 1024)", S);
   if (nrays <= 0) return 0;
 #define HUGS_CB_LAUNCH(C_) hipLaunchKernelGGL(k_composite_bwd<C_>, dim3((nrays + 3) / 4), dim3(256), 0, (hipStream_t)stream, nrays, S, \
-    density, rgb_s, tdist, dirs, opaque_background, bg, d_rgb_out, d_w_extra, d_density, d_rgb_s)
+    density, rgb_s, tdist, dirs, opaque_background, bg, d_rgb_out, d_w_extra, d_density, d_rgb_s, raw, density_bias, d_raw)
   if (S <= 256) HUGS_CB_LAUNCH(4); else if (S <= 512) HUGS_CB_LAUNCH(8); else HUGS_CB_LAUNCH(16);
 #undef HUGS_CB_LAUNCH
   HUGS_CHECK_LAUNCH("hugs_composite_bwd");
   return 0;
+}
+extern "C" int hugs_composite_bwd(int nrays, int S, const float* density, const float* rgb_s, const float* tdist,
+                                  const float* dirs, int opaque_background, float bg, const float* d_rgb_out,
+                                  const float* d_w_extra, float* d_density, float* d_rgb_s, void* stream) {
+  return composite_bwd_impl(nrays, S, density, rgb_s, tdist, dirs, opaque_background, bg, d_rgb_out, d_w_extra, d_density, d_rgb_s, nullptr, 0.f,
+                            nullptr, stream);
+}
+// + d_raw[m] = d_density[m] * sigmoid(raw[m] + density_bias): the density head's pre-activation gradient (hugs_density_bwd's first half)
+// in the same pass -- one launch less on the way from the loss to the trunk's output gradient
+extern "C" int hugs_composite_bwd_raw(int nrays, int S, const float* density, const float* rgb_s, const float* tdist,
+                                      const float* dirs, int opaque_background, float bg, const float* d_rgb_out,
+                                      const float* d_w_extra, float* d_density, float* d_rgb_s, const float* raw, float density_bias,
+                                      float* d_raw, void* stream) {
+  HUGS_REQUIRE(raw && d_raw, -2, "hugs_composite_bwd_raw: raw / d_raw is null");
+  return composite_bwd_impl(nrays, S, density, rgb_s, tdist, dirs, opaque_background, bg, d_rgb_out, d_w_extra, d_density, d_rgb_s, raw,
+                            density_bias, d_raw, stream);
 }

@@ -22,6 +22,7 @@ _DW_AFTER_PROP = __import__('os').environ.get('HUGS_DW_AFTER_PROP', '1') == '1'
 _MLP_FUSE_ROWS = int(__import__('os').environ.get('HUGS_MLP_FUSE_ROWS', '32768'))      # 0: never fuse the 256-wide trunk tail
 _MLP_CHAIN3 = __import__('os').environ.get('HUGS_MLPFUSE_CHAIN3', '1') != '0'      # (the library reads the same switch)
 _HEAD_FOLD = __import__('os').environ.get('HUGS_HEAD_FOLD', '1') == '1'
+_COMPOSITE_RAW = __import__('os').environ.get('HUGS_COMPOSITE_RAW', '1') == '1'      # A/B: d_raw out of the compositing backward
 _RGB_REDUCE_SIDE = __import__('os').environ.get('HUGS_RGB_REDUCE_SIDE', '1') == '1'      # A/B: the view head's dW reduction on the head stream
 _SIDE_LATE = __import__('os').environ.get('HUGS_SIDE_LATE', '0') == '1'      # A/B: side-stream work released behind the G_last GEMM
 _TN_ITEM = np.dtype([('X', np.uint64), ('G', np.uint64), ('dW', np.uint64), ('db', np.uint64), ('ldx', np.int32), ('ldg', np.int32),
@@ -543,6 +544,15 @@ class Engine:
         out.update(tacts=tacts, raw_t=raw_t, dens_t=dens_t, rgb_t=rgb_t, raw_u=raw_u, unc=unc, tra=tra)
     return out
 
+  def encode_viewdirs(self, rays, N):
+    """rays['dir_enc'] = pos_enc(viewdirs) (coord.py:136-147; models.py:494-497), once per ray batch.  The train step calls it on the
+    weight-cast lane (nothing needs it before the view layer's per-ray bias, which runs behind the first MLP product's wait on that
+    lane): 6 us less in front of the first sampler launch."""
+    if 'dir_enc' not in rays:
+      mdl = self.model
+      rays['dir_enc'] = self.ws.get('dir_enc', (N, mdl.nerf_spec.nd))
+      _lib.call('hugs_dir_enc_fwd', N, mdl.nerf_spec.deg_view, rays['viewdirs'], rays['dir_enc'])
+
   def forward(self, theta, rays, train_frac, u01, compute_extras, zero_glo=False, zero_tra=False, n_real=None, anneal_dev=None,
               weights_ready=None):
     """Model.__call__ (models.py:74-330).  rays: dict of contiguous [N,c] cuda tensors (+ 'dir_enc').
@@ -565,10 +575,7 @@ class Engine:
       tra = ws.get('tra_vec', (N, mdl.nerf_spec.num_tra))
       _lib.call('hugs_glo_gather', N, mdl.nerf_spec.num_tra, self.layout.view(theta, ('TransientEmbed_0', 'embedding')),
                 rays['embed_idx'], int(zero_tra), tra)
-    if 'dir_enc' not in rays:
-      nd = mdl.nerf_spec.nd
-      rays['dir_enc'] = ws.get('dir_enc', (N, nd))
-      _lib.call('hugs_dir_enc_fwd', N, mdl.nerf_spec.deg_view, rays['viewdirs'], rays['dir_enc'])
+    self.encode_viewdirs(rays, N)
     if mdl.near_anneal_rate is None:
       init_s_near = 0.
     else:
@@ -718,8 +725,16 @@ class Engine:
         dwt = ws.get(tag + '/d_w_total', (N, S))
         _lib.call('hugs_bg_blend_bwd', N, S, d_rgb_out, lv['bg_rgb'].contiguous(), lv['bgw'], d_w_extra, dwt)
         d_w_extra = dwt
-    _lib.call('hugs_composite_bwd', N, S, lv['density'], lv['rgb'], lv['tdist'], rays['directions'],
-              int(self.model.opaque_background), bg_int, d_rgb_out, d_w_extra, d_density, d_rgb_s)
+    d_raw = ws.get(tag + '/d_raw', (M,))
+    # (round 5: without the NeRF-W branch -- whose compositing backward ADDS into d_density afterwards -- the density head's
+    #  pre-activation gradient d_raw leaves in the same pass: one launch less between the losses and G_last)
+    raw_fused = nerfw is None and _COMPOSITE_RAW
+    if raw_fused:
+      _lib.call('hugs_composite_bwd_raw', N, S, lv['density'], lv['rgb'], lv['tdist'], rays['directions'],
+                int(self.model.opaque_background), bg_int, d_rgb_out, d_w_extra, d_density, d_rgb_s, lv['raw'], spec.density_bias, d_raw)
+    else:
+      _lib.call('hugs_composite_bwd', N, S, lv['density'], lv['rgb'], lv['tdist'], rays['directions'],
+                int(self.model.opaque_background), bg_int, d_rgb_out, d_w_extra, d_density, d_rgb_s)
     if nerfw is not None:
       # the loss saw rgb_combined and beta: their gradients reach sigma_s (added), c_s, sigma_t, c_t, u
       d_dt, d_ct, d_u = ws.get(tag + '/d_dens_t', (M,)), ws.get(tag + '/d_rgb_t', (M, 3)), ws.get(tag + '/d_unc', (M,))
@@ -729,12 +744,11 @@ class Engine:
     acts = lv['acts']
     Ylast = acts[-1]
     ld = spec.layers[spec.net_depth]
-    d_raw = ws.get(tag + '/d_raw', (M,))
     dws = ws.get(tag + '/dens_ws', (max(_lib.lib().cdll.hugs_density_bwd_ws_bytes(W) // 4, 1),))
     if spec.disable_rgb or not spec.use_viewdirs:
-      _lib.call('hugs_density_bwd', dt, M, W, Ylast, W, d_density, lv['raw'], spec.density_bias, d_raw,
+      _lib.call('hugs_density_bwd', dt, M, W, Ylast, W, None if raw_fused else d_density, lv['raw'], spec.density_bias, d_raw,
                 gview((spec.name, ld['name'], 'kernel'), True).reshape(-1), gview((spec.name, ld['name'], 'bias')), dws)
-    else:
+    elif not raw_fused:
       # only d_raw here: the density head's weight gradient (a pass over the whole [M, W] activation) goes to the head
       # weight-gradient stream below instead of sitting in front of rgb_bwd -> dBott -> G_last
       _lib.call('hugs_density_bwd', dt, M, W, Ylast, W, d_density, lv['raw'], spec.density_bias, d_raw, None, None, None)

@@ -154,6 +154,11 @@ _GRAPH_LANES = tuple(int(x) for x in __import__('os').environ.get('HUGS_STEP_GRA
 # HUGS_STEP_GRAPH_TRANSIENT=0: the HA-NeRF / NeRF-W steps stay eager (round 5: their per-step scalar is device-resident and they capture)
 _GRAPH_TRANSIENT = __import__('os').environ.get('HUGS_STEP_GRAPH_TRANSIENT', '1') != '0'
 _GRAPH_TYPES = (None, 'withmask', 'robustnerf') + (('hanerf', 'nerfw') if _GRAPH_TRANSIENT else ())
+# HUGS_INTERLEVEL_ON_PROP=0|1|auto: the interlevel loss kernels on the proposal stream in front of the proposal levels' backward (1) or on
+# the main stream in front of the whole backward pass (0, rounds 1-4).  auto: on the proposal stream for small steps (<= HUGS_STEP_GRAPH_ROWS
+# rows, the launch-bound regime: 128 rays 1.209 -> 1.195 ms), on the main stream for large ones (there it delays the proposal levels'
+# backward into the trunk's first dX GEMMs: cfg2 +0.3-0.9 % in two same-box A/Bs)
+_IL_ON_PROP = __import__('os').environ.get('HUGS_INTERLEVEL_ON_PROP', 'auto')
 _STEP_GRAPH_ROWS = int(__import__('os').environ.get('HUGS_STEP_GRAPH_ROWS', '100000'))
 
 
@@ -424,6 +429,7 @@ def create_train_step(model, config, is_finetune=False):
       with torch.cuda.stream(lane_w):
         _engine.wait_event(lane_w, e0)
         eng.refresh_weights(state.flat, owner=state)
+        eng.encode_viewdirs(rays, N)      # (first used behind the first MLP product, which waits for this lane)
         ev_w = _engine.new_event(); ev_w.record(lane_w)
     u01 = None
     if isinstance(rng, (list, tuple)):             # explicit U[0,1) draws, one [N] (or [N,S]) tensor per level: the
@@ -530,12 +536,20 @@ def create_train_step(model, config, is_finetune=False):
     Sf = fin['S']
     d_w = [None] * L
     loss_ray = ws.get('loss_ray', (N,))
-    if not is_finetune and config.interlevel_loss_mult > 0:
-      for l in range(L - 1):
-        d_w[l] = ws.get(f'd_w{l}', (N, levels[l]['S']))
-        _lib.call('hugs_interlevel', N, Sf, levels[l]['S'], fin['sdist'], fin['weights'], levels[l]['sdist'],
-                  levels[l]['weights'], config.interlevel_loss_mult / (N * Sf), loss_ray, d_w[l])
-        _lib.call('hugs_sum', N, loss_ray, 1.0 / (N * Sf), tail[o_il + l:o_il + l + 1])
+
+    def interlevel_losses():
+      # (round 5: launched on the proposal stream in front of the proposal levels' backward -- their d_w and one stat each are all
+      #  these kernels produce; on the main stream they sat between the data loss and the final level's compositing backward)
+      if not is_finetune and config.interlevel_loss_mult > 0:
+        lr_ = ws.get('loss_ray_il', (N,))
+        for l in range(L - 1):
+          d_w[l] = ws.get(f'd_w{l}', (N, levels[l]['S']))
+          _lib.call('hugs_interlevel', N, Sf, levels[l]['S'], fin['sdist'], fin['weights'], levels[l]['sdist'],
+                    levels[l]['weights'], config.interlevel_loss_mult / (N * Sf), lr_, d_w[l])
+          _lib.call('hugs_sum', N, lr_, 1.0 / (N * Sf), tail[o_il + l:o_il + l + 1])
+    il_on_prop = _IL_ON_PROP == '1' or (_IL_ON_PROP == 'auto' and N * (model.num_prop_samples * (L - 1) + model.num_nerf_samples) <= _STEP_GRAPH_ROWS)
+    if not il_on_prop:
+      interlevel_losses()
     if not is_finetune and config.distortion_loss_mult > 0:
       d_w[L - 1] = ws.get(f'd_w{L-1}', (N, Sf))
       _lib.call('hugs_distortion', N, Sf, fin['sdist'], fin['weights'], config.distortion_loss_mult / N, loss_ray, d_w[L - 1])
@@ -611,6 +625,8 @@ def create_train_step(model, config, is_finetune=False):
       ev_loss = _engine.new_event(); ev_loss.record(bwd_main)
       with torch.cuda.stream(prop_stream):
         _engine.wait_event(prop_stream, ev_loss)
+        if il_on_prop:
+          interlevel_losses()
         for l in range(L - 2, -1, -1):
           level_backward(l, 2)
         if not prop_done:
