@@ -493,9 +493,13 @@ class Engine:
         kb, _ = hrandom.split(noise_key)
         _lib.call('hugs_axpy_op', dt, Mr * Bw, float(spec.bottleneck_noise), hrandom.normal(kb, (Mr, Bw)), bott)
       Wv = lay.view(theta, (spec.name, lv['name'], 'kernel'))
-      rb = ws.get(tag + '/raybias', (N, H))
-      _lib.call('hugs_raybias_fwd', N, H, spec.nd, spec.num_glo, rays['dir_enc'], glo, Wv[Bw:],
-                lay.view(theta, (spec.name, lv['name'], 'bias')), rb)
+      pre = rays.get('_raybias')
+      if pre is not None and pre[0] == spec.name and pre[1] == lvl and glo is rays.get('_glo'):
+        rb = pre[2]      # (encode_rays: computed on the train step's weight-cast lane)
+      else:
+        rb = ws.get(tag + '/raybias', (N, H))
+        _lib.call('hugs_raybias_fwd', N, H, spec.nd, spec.num_glo, rays['dir_enc'], glo, Wv[Bw:],
+                  lay.view(theta, (spec.name, lv['name'], 'bias')), rb)
       hact = ws.get(tag + '/hview', (M, H), self.tdt)
       _lib.call('hugs_gemm_nt', dt, M, H, Bw, 0, bott, Bw, None, 0, self.wt[(spec.name, lv['name'], 'kernel')], Bw, None, rb,
                 S, H, 1, None, 0, None, None, hact, H)
@@ -545,13 +549,35 @@ class Engine:
     return out
 
   def encode_viewdirs(self, rays, N):
-    """rays['dir_enc'] = pos_enc(viewdirs) (coord.py:136-147; models.py:494-497), once per ray batch.  The train step calls it on the
-    weight-cast lane (nothing needs it before the view layer's per-ray bias, which runs behind the first MLP product's wait on that
-    lane): 6 us less in front of the first sampler launch."""
+    """rays['dir_enc'] = pos_enc(viewdirs) (coord.py:136-147; models.py:494-497), once per ray batch."""
     if 'dir_enc' not in rays:
       mdl = self.model
       rays['dir_enc'] = self.ws.get('dir_enc', (N, mdl.nerf_spec.nd))
       _lib.call('hugs_dir_enc_fwd', N, mdl.nerf_spec.deg_view, rays['viewdirs'], rays['dir_enc'])
+
+  def encode_rays(self, theta, rays, N):
+    """Everything of a TRAIN step's forward pass that depends on the rays and the fp32 masters only, not on a sampling level: the
+    view-direction encoding, the GLO / transient embedding rows of the rays' cameras and the NerfMLP view layer's per-ray bias
+    (models.py:120-129, 494-505).  The train step runs it on the weight-cast lane -- the first MLP product waits for that lane, and
+    nothing here is needed before it -- instead of in front of the first sampler launch (dir_enc, gathers) and between the bottleneck
+    and view products (ray bias: 11 us of a 1.2 ms step at 128 rays).  forward() / _mlp_forward() use what they find in `rays`."""
+    mdl, ws, lay = self.model, self.ws, self.layout
+    self.encode_viewdirs(rays, N)
+    if mdl.num_glo_features > 0:
+      rays['_glo'] = ws.get('glo', (N, mdl.num_glo_features))
+      _lib.call('hugs_glo_gather', N, mdl.num_glo_features, lay.view(theta, ('GloEmbed_0', 'embedding')), rays['embed_idx'], 0, rays['_glo'])
+    spec = mdl.nerf_spec
+    if spec.num_tra > 0:
+      rays['_tra'] = ws.get('tra_vec', (N, spec.num_tra))
+      _lib.call('hugs_glo_gather', N, spec.num_tra, lay.view(theta, ('TransientEmbed_0', 'embedding')), rays['embed_idx'], 0, rays['_tra'])
+    if not spec.disable_rgb and spec.use_viewdirs:
+      lb, lv, lvx, lr = spec.head_layers()
+      Bw, H = spec.bottleneck_width, spec.net_width_viewdirs
+      Wv = lay.view(theta, (spec.name, lv['name'], 'kernel'))
+      rb = ws.get(f'{spec.name}/L{mdl.num_levels - 1}/raybias', (N, H))
+      _lib.call('hugs_raybias_fwd', N, H, spec.nd, spec.num_glo, rays['dir_enc'], rays.get('_glo'), Wv[Bw:],
+                lay.view(theta, (spec.name, lv['name'], 'bias')), rb)
+      rays['_raybias'] = (spec.name, mdl.num_levels - 1, rb)
 
   def forward(self, theta, rays, train_frac, u01, compute_extras, zero_glo=False, zero_tra=False, n_real=None, anneal_dev=None,
               weights_ready=None):
@@ -567,14 +593,18 @@ class Engine:
       self.refresh_weights(theta)
     glo = None
     if mdl.num_glo_features > 0:
-      glo = ws.get('glo', (N, mdl.num_glo_features))
-      emb = self.layout.view(theta, ('GloEmbed_0', 'embedding'))
-      _lib.call('hugs_glo_gather', N, mdl.num_glo_features, emb, rays['embed_idx'], int(zero_glo), glo)
+      glo = rays.get('_glo') if not zero_glo else None       # (encode_rays: gathered on the train step's weight-cast lane)
+      if glo is None:
+        glo = ws.get('glo', (N, mdl.num_glo_features))
+        emb = self.layout.view(theta, ('GloEmbed_0', 'embedding'))
+        _lib.call('hugs_glo_gather', N, mdl.num_glo_features, emb, rays['embed_idx'], int(zero_glo), glo)
     tra = None
     if mdl.nerf_spec.num_tra > 0:          # NeRF-W: TransientEmbed rows of the rays' cameras (models.py:120-129)
-      tra = ws.get('tra_vec', (N, mdl.nerf_spec.num_tra))
-      _lib.call('hugs_glo_gather', N, mdl.nerf_spec.num_tra, self.layout.view(theta, ('TransientEmbed_0', 'embedding')),
-                rays['embed_idx'], int(zero_tra), tra)
+      tra = rays.get('_tra') if not zero_tra else None
+      if tra is None:
+        tra = ws.get('tra_vec', (N, mdl.nerf_spec.num_tra))
+        _lib.call('hugs_glo_gather', N, mdl.nerf_spec.num_tra, self.layout.view(theta, ('TransientEmbed_0', 'embedding')),
+                  rays['embed_idx'], int(zero_tra), tra)
     self.encode_viewdirs(rays, N)
     if mdl.near_anneal_rate is None:
       init_s_near = 0.
