@@ -494,6 +494,8 @@ class Engine:
         _lib.call('hugs_axpy_op', dt, Mr * Bw, float(spec.bottleneck_noise), hrandom.normal(kb, (Mr, Bw)), bott)
       Wv = lay.view(theta, (spec.name, lv['name'], 'kernel'))
       pre = rays.get('_raybias')
+      if rays.get('_ev_rays') is not None:      # (dir_enc / the embedding rows / the precomputed bias come from the weight-cast lane)
+        wait_event(torch.cuda.current_stream(), rays['_ev_rays'])
       if pre is not None and pre[0] == spec.name and pre[1] == lvl and glo is rays.get('_glo'):
         rb = pre[2]      # (encode_rays: computed on the train step's weight-cast lane)
       else:

@@ -429,8 +429,11 @@ def create_train_step(model, config, is_finetune=False):
       with torch.cuda.stream(lane_w):
         _engine.wait_event(lane_w, e0)
         eng.refresh_weights(state.flat, owner=state)
-        eng.encode_rays(state.flat, rays, N)      # (first used behind the first MLP product, which waits for this lane)
         ev_w = _engine.new_event(); ev_w.record(lane_w)
+        # behind the casts on the same lane: whatever depends on the rays and the fp32 masters only (first used by the final level's view
+        # layer, which waits for rays['_ev_rays'])
+        eng.encode_rays(state.flat, rays, N)
+        rays['_ev_rays'] = _engine.new_event(); rays['_ev_rays'].record(lane_w)
     u01 = None
     if isinstance(rng, (list, tuple)):             # explicit U[0,1) draws, one [N] (or [N,S]) tensor per level: the
       if len(rng) != L:                            # numbers jax.random.uniform handed the reference (fixtures, tests)
