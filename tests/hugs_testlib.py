@@ -65,6 +65,13 @@ def make_pair(gin_lines, seed=3, compute_dtype='fp32'):
   cfg.depth_viewdirs = int(model.nerf_spec.net_depth_viewdirs)
   cfg.min_deg_point = int(model.nerf_spec.min_deg_point)
   cfg.rgb_premultiplier, cfg.rgb_bias = float(model.nerf_spec.rgb_premultiplier), float(model.nerf_spec.rgb_bias)
+  # the remaining gin-visible knobs the oracle knows (scratch/config_fuzz2.py walks them): sampler, heads, background
+  cfg.anneal_slope, cfg.single_jitter = float(model.anneal_slope), bool(model.single_jitter)
+  cfg.dilation_multiplier, cfg.dilation_bias, cfg.resample_padding = float(model.dilation_multiplier), float(model.dilation_bias), float(model.resample_padding)
+  cfg.bg_intensity = float(model.bg_intensity)
+  cfg.skip_layer, cfg.deg_view = int(model.nerf_spec.skip_layer), int(model.nerf_spec.deg_view)
+  cfg.density_bias, cfg.rgb_padding = float(model.nerf_spec.density_bias), float(model.nerf_spec.rgb_padding)
+  cfg.bottleneck_width, cfg.width_viewdirs = int(model.nerf_spec.bottleneck_width), int(model.nerf_spec.net_width_viewdirs)
   if model.mask_spec is not None:
     cfg.mask_depth, cfg.mask_width, cfg.mask_deg_coord = (model.mask_spec.net_depth, model.mask_spec.net_width,
                                                            model.mask_spec.deg_coord)
