@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64) void k_nf_interlevel(int nrays, int S, int Sp, 
 
 extern "C" int hugs_nf_interlevel(int nrays, int S, int Sp, const float* t, const float* w, const float* t_env, const float* w_env,
                                   float scale, float* loss_ray, float* d_w_env, void* stream) {
-  HUGS_REQUIRE(S >= 1 && Sp >= 1 && S < NF_CAP && Sp < NF_CAP - 1, -3, "hugs_nf_interlevel: S=%d Sp=%d exceed the capacity", S, Sp);
+  HUGS_REQUIRE(S >= 1 && Sp >= 1 && S < NF_CAP && Sp < NF_CAP, -3, "hugs_nf_interlevel: S=%d Sp=%d exceed the capacity (%d per level)", S, Sp, NF_CAP - 1);      // (s_te / s_cy / s_diff hold Sp + 1 entries)
   if (nrays <= 0) return 0;
   hipLaunchKernelGGL(k_nf_interlevel, dim3(nrays), dim3(64), 0, (hipStream_t)stream, nrays, S, Sp, t, w, t_env, w_env, scale, loss_ray, d_w_env);
   HUGS_CHECK_LAUNCH("hugs_nf_interlevel");

@@ -86,6 +86,28 @@ def test_interlevel_and_distortion_vs_reference(z):
   np.testing.assert_allclose(dw.cpu().numpy(), z['loss/d_w_distortion'], rtol=2e-5, atol=1e-9)
 
 
+def test_interlevel_at_the_sample_capacity_vs_oracle():
+  """1024 envelope bins per ray (the kernels' capacity: round 5 -- the launcher refused 1024 by an off-by-one) against the oracle's
+  lossfun_outer and its autograd gradient."""
+  from nerf_hugs_amd import _lib as L
+  from oracle import nerfacto_ref as R
+  g = torch.Generator().manual_seed(4)
+  N, S, Sp = 16, 256, 1024
+  t = torch.sort(torch.rand(N, S + 1, generator=g), -1).values
+  te = torch.sort(torch.rand(N, Sp + 1, generator=g), -1).values
+  te[:, 0], te[:, -1] = 0., 1.
+  w = torch.rand(N, S, generator=g); w = w / w.sum(-1, keepdim=True)
+  we = (torch.rand(N, Sp, generator=g) * 0.5 / Sp).requires_grad_(True)
+  loss_ray = R.lossfun_outer(t, w, te, we).sum(-1)
+  (loss_ray.sum() / (N * S)).backward()
+  lr, dw = torch.empty(N, device=dev), torch.empty(N, Sp, device=dev)
+  L.call('hugs_nf_interlevel', N, S, Sp, t.to(dev), w.to(dev), te.to(dev), we.detach().to(dev), 1.0 / (N * S), lr, dw)
+  np.testing.assert_allclose(lr.cpu().numpy(), loss_ray.detach().numpy(), rtol=5e-5, atol=1e-9)
+  np.testing.assert_allclose(dw.cpu().numpy(), we.grad.numpy(), rtol=5e-5, atol=5e-5 * float(we.grad.abs().max()))
+  with pytest.raises(L.HugsError):
+    L.call('hugs_nf_interlevel', N, S, 1025, t.to(dev), w.to(dev), te.to(dev), we.detach().to(dev), 1.0, lr, dw)
+
+
 SMALL = dict(num_levels=4, max_res=64, log2_hashmap_size=10, hidden_dim=16, geo_feat_dim=7, hidden_dim_color=16,
              num_proposal_samples_per_ray=(32, 16), num_nerf_samples_per_ray=8, opaque_background=True,
              use_appearance_embedding=True, appearance_embedding_dim=5, num_embedding=4, distortion_loss_mult=0.01,
