@@ -465,6 +465,10 @@ def create_train_step(model, config, is_finetune=False):
         ev_mask = _engine.new_event(); ev_mask.record(side_s)
     levels = eng.forward(state.flat, rays, float(train_frac), u01, False, False, anneal_dev=None if dyn is None else dyn[0:1],
                          weights_ready=ev_w)
+    if rays.get('_ev_rays') is not None:
+      # (a model without a view layer -- use_viewdirs = False, rgb disabled -- never waited for the ray encodings of the weight-cast lane:
+      #  inside a capture that is a stream left unjoined, outside it a dangling dependency for the backward's reads of dir_enc / glo)
+      _engine.wait_event(torch.cuda.current_stream(), rays['_ev_rays'])
     if mask_st is not None:
       _engine.wait_event(main_s, ev_mask)
 

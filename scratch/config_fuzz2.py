@@ -20,6 +20,17 @@ VARIANTS.update({
   'prop with rgb + viewdirs': ["PropMLP.disable_rgb = False", "PropMLP.bottleneck_width = 128", "Config.data_coarse_loss_mult = 0.2"],
   'no opaque bg + bg 0.5': ["Model.opaque_background = False", "Model.bg_intensity_range = (0.5, 0.5)"],
   'withmask + glo': ["Config.transient_type = 'withmask'", "Model.num_glo_features = 4"],
+  'samples 1024/1024': ["Model.num_prop_samples = 1024", "Model.num_nerf_samples = 1024"],
+  'samples 256/512': ["Model.num_prop_samples = 256", "Model.num_nerf_samples = 512"],
+  'samples 4/4': ["Model.num_prop_samples = 4", "Model.num_nerf_samples = 4"],
+  'levels 7': ["Model.num_levels = 7", "Model.num_prop_samples = 16", "Model.num_nerf_samples = 16"],
+  'no viewdirs + glo 4': ["Model.use_viewdirs = False", "Model.num_glo_features = 4"],
+  'view depth 4': ["NerfMLP.net_depth_viewdirs = 4"],
+  'hanerf': ["Config.transient_type = 'hanerf'", "Model.num_transient_features = 16", "Model.num_glo_features = 4", "NerfMLP.bottleneck_width = 128"],
+  'nerfw': ["Config.transient_type = 'nerfw'", "Model.num_transient_features = 16", "Model.num_glo_features = 4", "NerfMLP.bottleneck_width = 128"],
+  'robustnerf patch 16': ["Config.transient_type = 'robustnerf'", "Config.patch_size = 16"],
+  'log raydist': ["Model.raydist_fn = @jnp.log"],
+  'sqrt raydist + contract': ["Model.raydist_fn = @jnp.sqrt", "NerfMLP.warp_fn = @coord.contract", "PropMLP.warp_fn = @coord.contract"],
 })
 only = sys.argv[1:] 
 for name, extra in VARIANTS.items():
@@ -27,7 +38,7 @@ for name, extra in VARIANTS.items():
     continue
   keys = {e.split('=')[0].strip() for e in extra}
   gin = [g for g in SMALL if g.split('=')[0].strip() not in keys] + extra
-  P = 4 if 'patch 4' in name else 8
+  P = 4 if 'patch 4' in name else 16 if 'patch 16' in name else 8
   res = []
   try:
     _run_case(gin, n_patch=max(1, 64 // (P * P)), P=P)

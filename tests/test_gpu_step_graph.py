@@ -32,10 +32,12 @@ def _run(mode, gin, nsteps, rng_kind, n_patch=2, P=8):
 
 
 @pytest.mark.parametrize('rng_kind', ['key', 'none'])
-@pytest.mark.parametrize('variant', ['base', 'withmask_glo', 'robustnerf'])
+@pytest.mark.parametrize('variant', ['base', 'withmask_glo', 'robustnerf', 'no_viewdirs_glo'])
 def test_graph_replay_is_bit_identical_to_the_eager_step(rng_kind, variant):
   gin = list(SMALL)
   kw = {}
+  if variant == 'no_viewdirs_glo':      # no view layer: nothing in the forward pass waits for the ray encodings of the weight-cast lane
+    gin += ["Model.use_viewdirs = False", "Model.num_glo_features = 4"]
   if variant == 'withmask_glo':
     gin += ["Config.transient_type = 'withmask'", "Model.num_glo_features = 4", "Config.data_loss_type = 'charb'"]
   if variant == 'robustnerf':      # thresholds fed back on the device from step to step (train.py:145-148 through the host)
@@ -55,7 +57,7 @@ def test_graph_replay_is_bit_identical_to_the_eager_step(rng_kind, variant):
       assert torch.equal(a, b), name
   if rng_kind == 'key':
     assert torch.equal(e[3], g[3]), 'jax key after 7 steps'
-  if variant in ('base', 'robustnerf'):
+  if variant in ('base', 'robustnerf', 'no_viewdirs_glo'):
     assert e[4] == g[4], (e[4], g[4])
   else:
     np.testing.assert_allclose(np.array(e[4]), np.array(g[4]), rtol=2e-3)
