@@ -133,3 +133,53 @@ def test_stage_step_pub_and_hanerf_loss_dyn_through_the_c_abi():
     outs.append((dp, dm, st))
   for x, y in zip(*outs):
     assert torch.equal(x, y)
+
+
+def _mixed_sequence(mode):
+  """Steps at two batch sizes, renderings between them (Model.apply re-casts weights from whatever buffer it is handed), a parameter
+  restore in the middle (load into the SAME flat buffer: its version count moves) and a cloned-parameter rendering."""
+  from tests import hugs_testlib as H
+  from nerf_hugs_amd.internal import train_utils, random as hr
+  old = train_utils._STEP_GRAPH
+  train_utils._STEP_GRAPH = mode
+  try:
+    gin = list(SMALL) + ["Model.num_glo_features = 4"]
+    config, model, state, render_fn, train_step, cfg, oparams = H.make_pair(gin, compute_dtype='bf16')
+    key = hr.PRNGKey(7)
+    big = [H.synth_rays(2, 8, 20 + i) for i in range(4)]
+    small = [H.synth_rays(1, 8, 40 + i) for i in range(4)]
+    probe = H.synth_rays(1, 8, 99)
+    snap = None
+    outs = []
+    for i in range(10):
+      b = (big if i % 3 else small)[i % 4]
+      state, stats, key = train_step(key, state, b, 0.05 * i, None)
+      if i == 3:
+        snap = (state.flat.clone(), state.m.clone(), state.v.clone(), state.step)
+      if i in (2, 5, 8):
+        rend, _ = model.apply(state.flat, None, probe.rays, 1.0, False)
+        outs.append(rend[-1]['rgb'].clone())
+      if i == 5:
+        rend, _ = model.apply(state.flat.clone(), None, probe.rays, 1.0, False)      # another buffer: another cast table
+        outs.append(rend[-1]['rgb'].clone())
+      if i == 6:      # restore the step-3 snapshot in place
+        state.flat.copy_(snap[0]); state.m.copy_(snap[1]); state.v.copy_(snap[2]); state.step = snap[3]
+      outs.append(torch.tensor(float(stats['loss'])))
+    torch.cuda.synchronize()
+    return state.flat.clone(), state.m.clone(), key.clone(), outs, train_step.graph_active()
+  finally:
+    train_utils._STEP_GRAPH = old
+
+
+def test_mixed_sequence_graph_vs_eager():
+  e = _mixed_sequence('0')
+  g = _mixed_sequence('1')
+  assert not e[4] and g[4]
+  # (GLO rows: float-atomic scatter-adds -- agreement to rounding, as in the GLO variant above)
+  for a, b, name in ((e[0], g[0], 'params'), (e[1], g[1], 'adam m')):
+    sc = float(a.abs().max())
+    assert float((a - b).abs().max()) <= 2e-3 * sc, (name, float((a - b).abs().max()), sc)
+  assert torch.equal(e[2], g[2]), 'jax key'
+  assert len(e[3]) == len(g[3])
+  for i, (a, b) in enumerate(zip(e[3], g[3])):
+    assert float((a.float() - b.float()).abs().max()) <= 2e-3 * max(1.0, float(a.float().abs().max())), i
