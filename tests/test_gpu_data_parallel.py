@@ -84,7 +84,12 @@ def _compare(tmp_path, gin, backend, nsteps=1, graph='0', dtype='fp32'):
 GIN256 = [g for g in GIN if 'net_width' not in g] + ["PropMLP.net_width = 256", "NerfMLP.net_width = 256"]
 
 
-@pytest.mark.parametrize('gin', [GIN, HANERF], ids=['base', 'hanerf'])
+NERFW = GIN + ["Config.transient_type = 'nerfw'", "Model.num_transient_features = 16", "Model.num_glo_features = 4",
+               "NerfMLP.bottleneck_width = 128"]
+NOVIEW = GIN + ["Model.use_viewdirs = False", "Model.num_glo_features = 4"]
+
+
+@pytest.mark.parametrize('gin', [GIN, HANERF, NERFW, NOVIEW], ids=['base', 'hanerf', 'nerfw', 'no_viewdirs'])
 def test_two_rank_step_equals_single_process(tmp_path, gin):
   _compare(tmp_path, gin, 'gloo')
 
@@ -93,6 +98,12 @@ def test_two_rank_step_equals_single_process_bf16_batched_dw(tmp_path):
   """bf16, 256-wide nets: the batched weight-gradient launch and its single trunk bucket.  Per-ray arithmetic does not depend
   on the sharding (same kernels row by row); only the fp32 reduction order of the weight gradients does."""
   _compare(tmp_path, GIN256, 'gloo', dtype='bf16')
+
+
+def test_two_rank_graph_steps_bf16_batched_dw(tmp_path):
+  """The captured data-parallel form in the shipped precision with the batched weight-gradient launch (round 5: the step's last launch
+  publishes stats / key from the SECOND graph)."""
+  _compare(tmp_path, GIN256, 'gloo', nsteps=4, graph='1', dtype='bf16')
 
 
 def test_two_rank_graph_steps_equal_single_process(tmp_path):
