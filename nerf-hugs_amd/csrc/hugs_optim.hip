@@ -58,6 +58,8 @@ __global__ void k_opt_finalize1(int nleaf, int nmod, const int4* __restrict__ le
                                 float* __restrict__ mod_scale) {
   // a WAVE per leaf (round 4: a thread per leaf walked up to 96 chunk records one after the other: 24 us of pure latency at the
   // end of every step): lane l sums the chunks l, l + 64, ..., the lanes combine in a fixed xor butterfly -- deterministic
+  __shared__ float s_sc[1024];
+  __shared__ int s_mod[1024];
   const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
   for (int leaf = threadIdx.x >> 6; leaf < nleaf; leaf += nw) {
     const int4 li = leaf_info[leaf];
@@ -67,13 +69,16 @@ __global__ void k_opt_finalize1(int nleaf, int nmod, const int4* __restrict__ le
       sg += p.x; mg = fmaxf(mg, p.y); st += p.z; sc += p.w;
     }
     sg = wave_sum_f(sg); mg = wave_max_f(mg); st = wave_sum_f(st); sc = wave_sum_f(sc);
-    if (lane == 0) { leaf_stats[leaf * 4] = sg; leaf_stats[leaf * 4 + 1] = mg; leaf_stats[leaf * 4 + 2] = st; leaf_stats[leaf * 4 + 3] = sc; }
+    if (lane == 0) {
+      leaf_stats[leaf * 4] = sg; leaf_stats[leaf * 4 + 1] = mg; leaf_stats[leaf * 4 + 2] = st; leaf_stats[leaf * 4 + 3] = sc;
+      s_sc[leaf] = sc; s_mod[leaf] = li.z;      // (round 5: the module pass below walked the leaves through ~2 dependent global loads each)
+    }
   }
   __syncthreads();
   if ((int)threadIdx.x < nmod) {   // fixed leaf order per module
     float sq = 0.f;
     for (int leaf = 0; leaf < nleaf; ++leaf)
-      if (leaf_info[leaf].z == (int)threadIdx.x) sq += leaf_stats[leaf * 4 + 3];
+      if (s_mod[leaf] == (int)threadIdx.x) sq += s_sc[leaf];
     float mult = 1.f;
     if (max_norm > 0.f) {
       const float x = max_norm / (HUGS_EPS + sqrtf(sq));
@@ -115,10 +120,17 @@ __global__ __launch_bounds__(256) void k_opt_adam(const OptChunk* __restrict__ c
     const int nv = (c.off & 3) ? 0 : (c.len >> 2);       // 16-byte accesses (chunk offsets are multiples of 4 floats), scalar tail
     for (int i = threadIdx.x; i < nv; i += 256) {
       const int ix = c.off + 4 * i;
-      const float4 g = *(const float4*)(grad + ix);
-      float4 mi = *(const float4*)(m + ix), vi = *(const float4*)(v + ix), th = *(const float4*)(theta + ix);
+      // (round 5: the gradient and both moments are touched once per step -- streaming loads / stores, so that they do not push the
+      //  masters, which the next step's operand casts read, out of the 256 MB memory-side cache)
+      typedef float __attribute__((ext_vector_type(4))) f4;
+      const f4 gq = __builtin_nontemporal_load((const f4*)(grad + ix));
+      const f4 mq = __builtin_nontemporal_load((const f4*)(m + ix)), vq = __builtin_nontemporal_load((const f4*)(v + ix));
+      const float4 g = make_float4(gq.x, gq.y, gq.z, gq.w);
+      float4 mi = make_float4(mq.x, mq.y, mq.z, mq.w), vi = make_float4(vq.x, vq.y, vq.z, vq.w), th = *(const float4*)(theta + ix);
       one(g.x, mi.x, vi.x, th.x); one(g.y, mi.y, vi.y, th.y); one(g.z, mi.z, vi.z, th.z); one(g.w, mi.w, vi.w, th.w);
-      *(float4*)(m + ix) = mi; *(float4*)(v + ix) = vi; *(float4*)(theta + ix) = th;
+      __builtin_nontemporal_store(f4{mi.x, mi.y, mi.z, mi.w}, (f4*)(m + ix));
+      __builtin_nontemporal_store(f4{vi.x, vi.y, vi.z, vi.w}, (f4*)(v + ix));
+      *(float4*)(theta + ix) = th;
     }
     for (int i = 4 * nv + threadIdx.x; i < c.len; i += 256) {
       const int ix = c.off + i;
