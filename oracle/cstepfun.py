@@ -105,6 +105,15 @@ def level_sample(t_prev, w_prev, do_dilate, dilation, lo, hi, anneal, pad, u_bas
   ns = u_base.shape[0]
   sd = np.empty((N, ns + 1), np.float32); td = np.empty((N, ns + 1), np.float32)
   idx = np.empty((N, ns), np.int32)
+  if jitter is not None and np.asarray(jitter).ndim == 2 and np.asarray(jitter).shape[1] == ns and ns > 1:
+    # one draw per sample (Model.single_jitter = False, stepfun.py:203-209)
+    jit = _c(jitter)
+    rc = lib().orc_level_sample_batch_pj(
+        N, _p(t_prev), _p(w_prev), n_prev, int(do_dilate), ctypes.c_float(dilation),
+        ctypes.c_float(lo), ctypes.c_float(hi), ctypes.c_float(anneal), ctypes.c_float(pad),
+        _p(u_base), _p(jit), ns, int(raydist), _p(near), _p(far), _p(sd), _p(td), idx.ctypes.data_as(i32p))
+    if rc: raise ValueError(f'orc_level_sample rc={rc}')
+    return sd, td, idx
   jit = None if jitter is None else _c(jitter).reshape(-1)
   rc = lib().orc_level_sample_batch(
       N, _p(t_prev), _p(w_prev), n_prev, int(do_dilate), ctypes.c_float(dilation),

@@ -316,6 +316,36 @@ int orc_level_sample(const float* t_prev, const float* w_prev, int n_prev, int d
   return 0;
 }
 
+/* The same level with one jitter draw PER SAMPLE (stepfun.py:203-209 with single_jitter = False: uniform(rng, t.shape[:-1] + (num_samples,))):
+ * u[j] = u_base[j] + jitter[j].  Implemented by folding the per-sample draws into the u grid it hands on (one float add per sample, as
+ * the reference's `linspace + uniform`). */
+int orc_level_sample_pj(const float* t_prev, const float* w_prev, int n_prev, int do_dilate,
+                        float dilation, float lo, float hi, float anneal, float resample_padding,
+                        const float* u_base, const float* jitter_ps, int ns, int raydist, float near,
+                        float far, float* sdist, float* tdist, int32_t* idx) {
+  float u[ORC_CAP];
+  if (ns > ORC_CAP) return -1;
+  for (int j = 0; j < ns; ++j) u[j] = u_base[j] + jitter_ps[j];
+  return orc_level_sample(t_prev, w_prev, n_prev, do_dilate, dilation, lo, hi, anneal, resample_padding, u, 0.0f, ns, raydist, near, far,
+                          sdist, tdist, idx, 0, 0, 0);
+}
+
+/* batched wrapper with per-sample jitter [nrays, ns] */
+int orc_level_sample_batch_pj(int nrays, const float* t_prev, const float* w_prev, int n_prev,
+                              int do_dilate, float dilation, float lo, float hi, float anneal,
+                              float resample_padding, const float* u_base, const float* jitter,
+                              int ns, int raydist, const float* near, const float* far,
+                              float* sdist, float* tdist, int32_t* idx) {
+  for (int r = 0; r < nrays; ++r) {
+    int rc = orc_level_sample_pj(t_prev + (size_t)r * (n_prev + 1), w_prev + (size_t)r * n_prev, n_prev,
+                                 do_dilate, dilation, lo, hi, anneal, resample_padding, u_base,
+                                 jitter + (size_t)r * ns, ns, raydist, near[r], far[r],
+                                 sdist + (size_t)r * (ns + 1), tdist + (size_t)r * (ns + 1), idx + (size_t)r * ns);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 /* batched wrapper: rays are rows. jitter may be NULL (deterministic). */
 int orc_level_sample_batch(int nrays, const float* t_prev, const float* w_prev, int n_prev,
                            int do_dilate, float dilation, float lo, float hi, float anneal,

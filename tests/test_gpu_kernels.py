@@ -173,6 +173,28 @@ def test_cast_ipe_vs_oracle_and_golden(golden, warp):
     np.testing.assert_allclose(got[..., :63], golden[f'{tag}/l1_ipe_sub'][..., :63], atol=2e-5)
 
 
+def test_level_sample_per_sample_jitter_vs_reference_and_oracle():
+  """One jitter draw per sample (Model.single_jitter = False, stepfun.py:203-209): the HIP sampler with jitter_stride = S against the
+  reference-executed fixture (tests/golden/ref_persample_jitter.npz) and, bit for bit, against the C oracle's per-sample entry."""
+  import os
+  from oracle import cstepfun as C, torch_ref as R
+  L = _L()
+  z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_persample_jitter.npz'))
+  n, S0, S1, dilation, anneal = z['meta']
+  n, S0, S1 = int(n), int(S0), int(S1)
+  near, far = torch.zeros(n, device=dev), torch.ones(n, device=dev)
+  ub, mj = R.sample_u_base(S1, True)
+  jit = (z['l1_u01'] * np.float32(mj)).astype(np.float32)
+  sd, td = torch.empty(n, S1 + 1, device=dev), torch.empty(n, S1 + 1, device=dev)
+  idx = torch.empty(n, S1, device=dev, dtype=torch.int32)
+  L.call('hugs_level_sample_fwd', n, G(z['l0_sdist']), G(z['l0_weights']), S0, 1, float(dilation), 0.0, 1.0, float(anneal), 0.0, G(ub), G(jit), S1,
+         S1, 0, 1, near, far, sd, td, idx, None, None)
+  np.testing.assert_allclose(sd.cpu().numpy(), z['l1_sdist'], rtol=0, atol=2e-5)
+  osd, otd, oidx = C.level_sample(z['l0_sdist'], z['l0_weights'], True, float(dilation), 0., 1., float(anneal), 0.0, ub, jit, 0,
+                                  np.zeros(n, np.float32), np.ones(n, np.float32), sum_order=1)
+  assert np.array_equal(sd.cpu().numpy(), osd) and np.array_equal(idx.cpu().numpy(), oidx)
+
+
 def test_cast_ipe_general_basis_shapes_bf16_and_fp32():
   """Basis / degree combinations off the bf16 fast path (it takes feature counts per half that are multiples of 4: 21 x 12): an
   octahedron basis (3 directions) with 5 degrees = 15 features per half, 32-column rows -- both builds against the oracle, padding zero."""

@@ -25,7 +25,9 @@ def _run_case(gin, n_patch=1, P=8, near=0.1, far=1.2, seed=5, inlier=None, tol_g
   gen = torch.Generator(device='cuda').manual_seed(11)
   gen_state = gen.get_state()
   L = model.num_levels
-  u01 = [torch.rand(N, generator=gen, device='cuda') for _ in range(L)]
+  # (the draws the step itself takes from the generator: one per ray, or one per sample with Model.single_jitter = False)
+  Ss = [model.num_prop_samples] * (L - 1) + [model.num_nerf_samples]
+  u01 = [torch.rand((N,) if model.single_jitter else (N, Ss[l]), generator=gen, device='cuda') for l in range(L)]
   gen.set_state(gen_state)
   thr = None if inlier is None else np.full((L, 1), inlier, np.float32)
   # oracle

@@ -239,3 +239,26 @@ def test_inner_outer_match_interval_loops():
     np.testing.assert_allclose(inner.numpy(), ref_in, rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(outer.numpy(), ref_out, rtol=1e-5, atol=1e-5)
     assert float(R.lossfun_outer(torch.tensor(t0), torch.tensor(w0), torch.tensor(t0), torch.tensor(w0)).max()) < 1e-10
+
+
+def test_level_sample_per_sample_jitter_vs_reference():
+  """Model.single_jitter = False (stepfun.py:203-209, one uniform draw per sample): the reference's sample_intervals executed on two
+  chained levels (tests/golden/gen_persample_jitter_fixture.py) against the C oracle's per-sample entry (orc_level_sample_batch_pj)."""
+  import os
+  z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_persample_jitter.npz'))
+  n, S0, S1, dilation, anneal = z['meta']
+  n, S0, S1 = int(n), int(S0), int(S1)
+  near, far = np.zeros(n, np.float32), np.ones(n, np.float32)
+  ub, mj = R.sample_u_base(S0, True)
+  sd0, _, _ = C.level_sample(np.tile(np.array([[0., 1.]], np.float32), (n, 1)), np.ones((n, 1), np.float32), False, 0., 0., 1., 1.0, 0.0, ub,
+                             (z['l0_u01'] * np.float32(mj)).astype(np.float32), 0, near, far)
+  np.testing.assert_allclose(sd0, z['l0_sdist'], rtol=0, atol=5e-7)
+  ub, mj = R.sample_u_base(S1, True)
+  sd1, _, _ = C.level_sample(z['l0_sdist'], z['l0_weights'], True, float(dilation), 0., 1., float(anneal), 0.0, ub,
+                             (z['l1_u01'] * np.float32(mj)).astype(np.float32), 0, near, far)
+  np.testing.assert_allclose(sd1, z['l1_sdist'], rtol=0, atol=2e-5)
+  assert np.all(np.diff(sd1, axis=-1) >= 0)
+  # the per-sample draws matter: with the first column only (the single-jitter form) the result differs
+  sdx, _, _ = C.level_sample(z['l0_sdist'], z['l0_weights'], True, float(dilation), 0., 1., float(anneal), 0.0, ub,
+                             (z['l1_u01'][:, 0] * np.float32(mj)).astype(np.float32), 0, near, far)
+  assert float(np.abs(sdx - z['l1_sdist']).max()) > 1e-3
