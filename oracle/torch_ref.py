@@ -586,21 +586,25 @@ def model_forward(cfg, variables, rays, train_frac, u01, compute_extras, zero_gl
     glo = (torch.zeros(N, cfg.num_glo_features, dtype=dt) if zero_glo else
            P['GloEmbed_0']['embedding'][rays['embed_idx'][:, 0].long()])
   near, far = rays['near'], rays['far']
-  sdist = torch.cat([torch.zeros_like(near), torch.ones_like(far)], -1)
+  # models.py:138-149: `near_anneal_rate` anneals the near bound in over the first part of training
+  rate = getattr(cfg, 'near_anneal_rate', None)
+  init_s_near = 0. if rate is None else float(np.clip(1 - train_frac / rate, 0, getattr(cfg, 'near_anneal_init', 0.95)))
+  init_s_far = 1.
+  sdist = torch.cat([torch.full_like(near, init_s_near), torch.full_like(far, init_s_far)], -1)
   weights = torch.ones_like(near)
   prod = 1
   renderings, history = [], []
   for lvl in range(cfg.num_levels):
     is_prop = lvl < cfg.num_levels - 1
     S = cfg.num_prop_samples if is_prop else cfg.num_nerf_samples
-    dilation = cfg.dilation_bias + cfg.dilation_multiplier * (1. - 0.) / prod
+    dilation = cfg.dilation_bias + cfg.dilation_multiplier * (init_s_far - init_s_near) / prod      # models.py:161-162
     prod *= S
     anneal = (cfg.anneal_slope * train_frac) / ((cfg.anneal_slope - 1) * train_frac + 1) \
         if cfg.anneal_slope > 0 else 1.
     ub, mj = sample_u_base(S, u01 is not None)
     jit = None if u01 is None else (u01[lvl].detach().numpy().astype(np.float32) * np.float32(mj))
     sd, td, _ = cstepfun.level_sample(
-        sdist.detach().numpy(), weights.detach().numpy(), lvl > 0, dilation, 0., 1., anneal,
+        sdist.detach().numpy(), weights.detach().numpy(), lvl > 0, dilation, init_s_near, init_s_far, anneal,      # domain: models.py:176,203
         cfg.resample_padding, ub, jit, RAYDIST[cfg.raydist_fn],
         near.numpy(), far.numpy())
     sdist = torch.from_numpy(sd).to(dt)          # stop_gradient (models.py:208-209)

@@ -69,6 +69,7 @@ def make_pair(gin_lines, seed=3, compute_dtype='fp32'):
   cfg.anneal_slope, cfg.single_jitter = float(model.anneal_slope), bool(model.single_jitter)
   cfg.dilation_multiplier, cfg.dilation_bias, cfg.resample_padding = float(model.dilation_multiplier), float(model.dilation_bias), float(model.resample_padding)
   cfg.bg_intensity = float(model.bg_intensity)
+  cfg.near_anneal_rate, cfg.near_anneal_init = model.near_anneal_rate, float(model.near_anneal_init)
   cfg.skip_layer, cfg.deg_view = int(model.nerf_spec.skip_layer), int(model.nerf_spec.deg_view)
   cfg.density_bias, cfg.rgb_padding = float(model.nerf_spec.density_bias), float(model.nerf_spec.rgb_padding)
   cfg.bottleneck_width, cfg.width_viewdirs = int(model.nerf_spec.bottleneck_width), int(model.nerf_spec.net_width_viewdirs)

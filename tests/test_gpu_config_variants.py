@@ -28,6 +28,7 @@ VARIANTS = {
     'samples_256_512': ["Model.num_prop_samples = 256", "Model.num_nerf_samples = 512"],
     'cylinder': ["Model.ray_shape = 'cylinder'"],
     'single_jitter_off': ["Model.single_jitter = False"],
+    'near_anneal': ["Model.near_anneal_rate = 0.5"],      # (_run_case steps at train_frac 0.37: init_s_near = 0.26)
     'no_anneal_no_dilation': ["Model.anneal_slope = 0.", "Model.dilation_multiplier = 0.", "Model.dilation_bias = 0."],
     'resample_padding': ["Model.resample_padding = 0.01"],
     'density_bias_0': BOTH('density_bias = 0.'),
