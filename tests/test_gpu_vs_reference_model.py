@@ -233,3 +233,34 @@ def test_data_loss_kernel_vs_reference_unit_vectors():
     np.testing.assert_allclose(o[0::2], z[f'unit/data/{tag}/mses'], rtol=2e-5, err_msg=tag)
     data = coarse * o[1:2 * L - 2:2].sum() + o[2 * L - 1]
     assert abs(data - float(z[f'unit/data/{tag}/data'])) <= 2e-5 * abs(data), tag
+
+
+from tests import ref_model_variants as FV
+
+
+@pytest.mark.parametrize('case', FV.CASES)
+def test_forward_vs_reference_option_variants(case):
+  """HIP forward of every level against the reference's own Model.__call__ executed for option variants
+  (tests/golden/gen_model_variant_fixtures.py): near-plane annealing, one jitter draw per sample, cylinder rays, four levels, sampler /
+  head / encoding knobs, a model without a view layer, a deeper view MLP, a grey non-opaque background, log ray distance + contraction."""
+  from nerf_hugs_amd.internal import configs, train_utils, utils, models as M
+  from tests.test_oracle_vs_reference_model import _check_variant_levels
+  configs.clear_config()
+  configs.parse_config_files_and_bindings(None, FV.gin_lines(case))
+  config = configs.make_config()
+  model, state, render_fn, train_step, lr_fn = train_utils.setup_model(config, 0, compute_dtype='fp32')
+  model.load_variables(state.flat, FV.param_tree(case))
+  T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+  rays = utils.Rays(**{f: T(FV.get(case, f'rays/{f}')) for f in FV.RAY_FIELDS})
+  L = model.num_levels
+  eng = model.engine(dev)
+  eng.refresh_weights(state.flat)
+  r = M.rays_to_dict(rays, dev)
+  N = r['origins'].shape[0]
+  levels = eng.forward(state.flat, r, float(FV.npz()['train_frac']), [u.to(dev) for u in FV.u01(case, L)], False)
+
+  def mine(l, k):
+    if k == 'rend_rgb':
+      return levels[l]['rgb_out'].cpu().numpy()
+    return levels[l][k].reshape(N, -1).float().cpu().numpy()
+  _check_variant_levels(case, L, mine)
