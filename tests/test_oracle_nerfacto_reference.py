@@ -17,8 +17,23 @@ import torch
 
 from oracle import nerfacto_ref as R
 
-Z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ref_nerfacto_model.npz'))
+class _Fixtures:
+  """One key space over ref_nerfacto_model.npz and ref_nerfacto_variants.npz (round 5: option variants executed by the reference,
+  tests/golden/gen_nerfacto_variant_fixtures.py); case names are distinct."""
+
+  def __init__(self, *names):
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    self._z = [np.load(os.path.join(here, n)) for n in names]
+    self.files = [k for z in self._z for k in z.files]
+    self._of = {k: z for z in self._z for k in z.files}
+
+  def __getitem__(self, k):
+    return self._of[k][k]
+
+
+Z = _Fixtures('ref_nerfacto_model.npz', 'ref_nerfacto_variants.npz')
 CASES = ['base', 'base_noprop', 'withmask', 'robustnerf', 'hanerf']
+VARIANTS = ['softplus', 'same_proposal_network', 'features_per_level_4', 'not_opaque_charb', 'reciprocal_contraction', 'one_proposal_iteration']
 
 
 def spec_of(case):
@@ -65,7 +80,7 @@ def leaves(t, prefix=''):
       yield prefix + k, v
 
 
-@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('case', CASES + VARIANTS)
 def test_forward_loss_and_gradients_vs_reference(case):
   cfg, sp = cfg_of(case)
   P = tree(case, 'params', torch.float32, requires_grad=True)     # float32 like the reference run: same sampler arithmetic, same cells
