@@ -7,9 +7,23 @@ import os
 import numpy as np
 import torch
 
-_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_model.npz')
+_HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+_PATH = os.path.join(_HERE, 'ref_model.npz')
 _NPZ = None
 CASES = ('base', 'withmask', 'robust', 'nerfw', 'hanerf')
+# round 5: loss / optimizer option variants of the reference's train_step (tests/golden/gen_model_train_variant_fixtures.py ->
+# ref_model_train_variants.npz: same key layout, no finite differences); one key space with the main file
+TRAIN_VARIANTS = ('coarse_charb', 'decay_clips_schedule')
+
+
+class _Merged:
+  def __init__(self, paths):
+    zs = [np.load(p) for p in paths]
+    self._of = {k: z for z in zs for k in z.files}
+    self.files = list(self._of)
+
+  def __getitem__(self, k):
+    return self._of[k][k]
 RAY_FIELDS = ('pix_coords', 'origins', 'directions', 'viewdirs', 'radii', 'lossmult', 'static_mask', 'near', 'far',
               'embed_idx', 'cam_idx')
 
@@ -17,7 +31,7 @@ RAY_FIELDS = ('pix_coords', 'origins', 'directions', 'viewdirs', 'radii', 'lossm
 def npz():
   global _NPZ
   if _NPZ is None:
-    _NPZ = np.load(_PATH)
+    _NPZ = _Merged([_PATH, os.path.join(_HERE, 'ref_model_train_variants.npz')])
   return _NPZ
 
 
@@ -94,10 +108,16 @@ def oracle_cfg(case):
       width_viewdirs=n.get('net_width_viewdirs', 128), prop_depth=p['net_depth'], prop_width=p['net_width'],
       prop_disable_rgb=p['disable_rgb'])
   for k in ('data_loss_type', 'distortion_loss_mult', 'transient_type', 'patch_size', 'withmask_transient_weight',
-            'grad_max_norm', 'grad_max_val', 'robustnerf_inlier_quantile', 'max_steps'):
+            'grad_max_norm', 'grad_max_val', 'robustnerf_inlier_quantile', 'max_steps', 'charb_padding', 'data_coarse_loss_mult',
+            'interlevel_loss_mult', 'disable_multiscale_loss', 'lr_init', 'lr_final', 'lr_delay_steps', 'lr_delay_mult', 'adam_eps'):
     if k in c:
       kw[k] = c[k]
   cfg = R.ModelCfg(**kw)
+  if 'weight_decay_mults' in c:
+    cfg.weight_decay_mults = dict(c['weight_decay_mults'])
+  for k in ('adam_beta1', 'adam_beta2'):
+    if k in c:
+      setattr(cfg, k, c[k])
   if 'net_width_transient' in n:
     cfg.transient_width = n['net_width_transient']
   cfg.rgb_premultiplier, cfg.rgb_bias = n.get('rgb_premultiplier', 1.), n.get('rgb_bias', 0.)

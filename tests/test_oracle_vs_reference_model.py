@@ -24,7 +24,7 @@ def _forward(case, dtype=torch.float32, override=None):
   return cfg, P, rays, tf, rend, hist
 
 
-@pytest.mark.parametrize('case', FX.CASES)
+@pytest.mark.parametrize('case', FX.CASES + FX.TRAIN_VARIANTS)
 def test_model_forward_vs_reference(case):
   """Model.__call__ + MLP.__call__ (models.py:74-330, 406-550): every level's sample positions, densities,
   colours, weights and rendered colours (+ NeRF-W / HA-NeRF outputs)."""
@@ -83,7 +83,7 @@ def test_sampler_interval_index_vs_reference(case):
     assert not mism.any(), f'{case} level {l}: {int(mism.sum())}/{idx.size} interval indices differ'
 
 
-@pytest.mark.parametrize('case', FX.CASES)
+@pytest.mark.parametrize('case', FX.CASES + FX.TRAIN_VARIANTS)
 def test_losses_and_stats_vs_reference(case):
   """compute_data_loss / compute_robustnerf_loss / compute_nerfw_loss / compute_hanerf_loss + interlevel +
   distortion as assembled by train_step.loss_fn (train_utils.py:72-248, 404-455)."""
@@ -152,7 +152,7 @@ def test_directional_derivatives_vs_reference(case):
     assert abs(mine - fd) <= 2e-5 * scale + 4 * abs(fd - fd2) + 1e-9, (case, i, mine, fd, fd2)
 
 
-@pytest.mark.parametrize('case', FX.CASES)
+@pytest.mark.parametrize('case', FX.CASES + FX.TRAIN_VARIANTS)
 def test_clip_gradients_vs_reference(case):
   """clip_gradients (train_utils.py:351-369) on the seeded synthetic gradient tree the reference's train_step was
   run with; withmask's bindings make both the value clip and the norm clip bite."""
@@ -172,10 +172,11 @@ def test_clip_gradients_vs_reference(case):
     assert abs(mx - float(FX.get(case, f'stats/grad_maxes/{k}'))) <= 1e-6 * mx
 
 
-def test_adam_restated_consistent_with_standin():
+@pytest.mark.parametrize('case', ['base', 'decay_clips_schedule'])
+def test_adam_restated_consistent_with_standin(case):
   """NOT a pin of optax (un-vendored, restated on both sides): only guards that the oracle's restatement and the
-  stand-in's agree, incl. the schedule being evaluated at the pre-increment count."""
-  case = 'base'
+  stand-in's agree, incl. the schedule being evaluated at the pre-increment count (round 5: also with a warm-up schedule, betas and
+  eps off their defaults, both clips biting)."""
   cfg = FX.oracle_cfg(case)
   flat = {k: torch.from_numpy(v.copy()) for k, v in FX.flat_params(case).items()}
   g = {k: torch.from_numpy(v.astype(np.float32)) for k, v in FX.seeded_tree(case, 4242, 3e-3).items()}
