@@ -807,9 +807,11 @@ def _natkey(s):
   return [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', s)]
 
 
-def loss_and_grad(cfg, variables, rays, gt_rgb, train_frac, u01, inlier_thresholds=None, bg_rgbs=None, **forward_kw):
+def loss_and_grad(cfg, variables, rays, gt_rgb, train_frac, u01, inlier_thresholds=None, bg_rgbs=None, is_finetune=False,
+                  **forward_kw):
   """The value_and_grad half of train_step (train_utils.py:404-455).  rays/gt flat [N,c];
-  robustnerf reshapes to [n,P,P,c] patches."""
+  robustnerf reshapes to [n,P,P,c] patches.  is_finetune (create_train_step's third argument): the plain data loss whatever
+  transient_type is (:422-423), no interlevel / distortion / weight-decay term (:435-447); the model itself is unchanged."""
   leaves = flat_leaves(variables['params'])
   req = [v.clone().requires_grad_(True) for _, v in leaves]
   P = {}
@@ -821,7 +823,7 @@ def loss_and_grad(cfg, variables, rays, gt_rgb, train_frac, u01, inlier_threshol
     d[ks[-1]] = v
   renderings, history = model_forward(cfg, {'params': P}, rays, train_frac, u01, False, bg_rgbs=bg_rgbs, **forward_kw)
   losses, stats = {}, {}
-  if cfg.transient_type is None:
+  if is_finetune or cfg.transient_type is None:
     losses['data'], st = compute_data_loss(cfg, gt_rgb, rays, renderings, False)
   elif cfg.transient_type == 'withmask':
     losses['data'], st = compute_data_loss(cfg, gt_rgb, rays, renderings, True)
@@ -838,11 +840,11 @@ def loss_and_grad(cfg, variables, rays, gt_rgb, train_frac, u01, inlier_threshol
   else:
     raise ValueError()
   stats.update(st)
-  if cfg.interlevel_loss_mult > 0:
+  if not is_finetune and cfg.interlevel_loss_mult > 0:
     losses['interlevel'] = interlevel_loss(cfg, history)
-  if cfg.distortion_loss_mult > 0:
+  if not is_finetune and cfg.distortion_loss_mult > 0:
     losses['distortion'] = distortion_loss(cfg, history)
-  if cfg.weight_decay_mults:        # train_utils.py:442-447: m * ||theta_group||^2 over summarize_tree groups
+  if not is_finetune and cfg.weight_decay_mults:        # train_utils.py:442-447: m * ||theta_group||^2 over summarize_tree groups
     losses['weight'] = sum(m * sum((v**2).sum() for (name, _), v in zip(leaves, req)
                                    if name == k or name.startswith(k + '/'))
                            for k, m in cfg.weight_decay_mults.items())
@@ -869,6 +871,12 @@ def clip_gradients(cfg, grads):
       gs = {n: mult * g for n, g in gs.items()}
     out.update(gs)
   return out
+
+
+def finetune_trainable(name):
+  """create_finetune_optimizer's partition (train_utils.py:539-543): Adam on the leaves that have 'embedding' as one of their path
+  keys, a zero update on every other leaf."""
+  return 'embedding' in name.split('/')
 
 
 def adam_update(cfg, params, grads, m, v, count):

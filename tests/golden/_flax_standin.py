@@ -368,9 +368,35 @@ def _build_optax():
                      mu, nu)
       return upd, {'count': c, 'mu': mu, 'nu': nu}
 
+  class _Zero:
+    # optax.set_to_zero: stateless, every update is zero
+    def init(self, params):
+      return {}
+
+    def update(self, grads, state, params=None):
+      return tree_map(lambda g: np.zeros_like(g), grads), state
+
+  class _Multi:
+    # optax.multi_transform(transforms, param_labels): each leaf is updated by the transform its label names.  Both
+    # transforms in use here (adam, set_to_zero) act leaf by leaf, so running each on the whole tree and picking per
+    # leaf equals running each on its own partition.
+    def __init__(self, transforms, labels):
+      self.tx, self.labels = dict(transforms), labels
+
+    def init(self, params):
+      return {name: t.init(params) for name, t in self.tx.items()}
+
+    def update(self, grads, state, params=None):
+      upd, new = {}, {}
+      for name, t in self.tx.items():
+        upd[name], new[name] = t.update(grads, state[name], params)
+      names = list(self.tx)
+      pick = lambda label, *us: us[names.index(label)]
+      return tree_map(pick, self.labels, *[upd[n] for n in names]), new
+
   optax.adam = _Adam
-  optax.set_to_zero = lambda: None
-  optax.multi_transform = lambda *a, **k: None
+  optax.set_to_zero = _Zero
+  optax.multi_transform = _Multi
   return optax
 
 

@@ -80,6 +80,7 @@ CASES = {
 TRAIN_FRAC = 0.37
 N_DIRS = 10
 SYN_GRAD_SEED = 4242
+FINETUNE = False     # gen_model_finetune_fixtures.py sets it: the finetune stage's optimizer + train_step instead
 
 
 def flatten(tree, prefix=''):
@@ -195,8 +196,9 @@ def main():
     out[f'{case}/train_frac'] = np.float64(TRAIN_FRAC)
 
     # ---- the reference's train_step, executed (pmap stand-in: one device, no leading axis) ----
-    state, lr_fn = train_utils.create_optimizer(config, variables)
-    train_step = train_utils.create_train_step(model, config, False)
+    make_optimizer = train_utils.create_finetune_optimizer if FINETUNE else train_utils.create_optimizer
+    state, lr_fn = make_optimizer(config, variables)
+    train_step = train_utils.create_train_step(model, config, FINETUNE)
     gsyn = seeded_tree(flat, SYN_GRAD_SEED, scale=3e-3)
     F.HOOK['grad'] = lambda params: {'params': unflatten({k: g.astype(f32) for k, g in gsyn.items()})}
     key0 = jax.random.PRNGKey(1234)
@@ -259,7 +261,7 @@ def main():
       to64 = lambda x: x.astype(np.float64) if x.dtype == np.float32 else x
       batch64 = jax.tree_util.tree_map(to64, batch)
       vars64 = jax.tree_util.tree_map(to64, variables)
-      state64, _ = train_utils.create_optimizer(config, vars64)
+      state64, _ = make_optimizer(config, vars64)
       # Model.__call__ runs first inside loss_fn, so the first L tape entries are the levels' sample positions:
       # keep the float32 run's (they are the fixture's `train/l*_sdist`), and rebuild every later constant
       # (interlevel c / w, robust errors / masks, HA-NeRF mask) in float64 on top of them.

@@ -14,6 +14,9 @@ CASES = ('base', 'withmask', 'robust', 'nerfw', 'hanerf')
 # round 5: loss / optimizer option variants of the reference's train_step (tests/golden/gen_model_train_variant_fixtures.py ->
 # ref_model_train_variants.npz: same key layout, no finite differences); one key space with the main file
 TRAIN_VARIANTS = ('coarse_charb', 'decay_clips_schedule')
+# the finetune stage executed (tests/golden/gen_model_finetune_fixtures.py -> ref_model_finetune.npz: create_finetune_optimizer +
+# create_train_step(model, config, True) on a NeRF-W and a HA-NeRF model); same key layout, no finite differences
+FINETUNE_CASES = ('ft_nerfw', 'ft_hanerf')
 
 
 class _Merged:
@@ -31,7 +34,7 @@ RAY_FIELDS = ('pix_coords', 'origins', 'directions', 'viewdirs', 'radii', 'lossm
 def npz():
   global _NPZ
   if _NPZ is None:
-    _NPZ = _Merged([_PATH, os.path.join(_HERE, 'ref_model_train_variants.npz')])
+    _NPZ = _Merged([_PATH, os.path.join(_HERE, 'ref_model_train_variants.npz'), os.path.join(_HERE, 'ref_model_finetune.npz')])
   return _NPZ
 
 
@@ -93,8 +96,13 @@ def u01(case, L):
   return [torch.from_numpy(get(case, f'l{l}_u01').copy()) for l in range(L)]
 
 
-def oracle_cfg(case):
-  """spec -> oracle.torch_ref.ModelCfg (same knob names the reference's gin bindings use)."""
+def is_finetune(case):
+  return bool(spec(case)['Config'].get('finetune_enable', False))
+
+
+def oracle_cfg(case, finetune_optimizer=False):
+  """spec -> oracle.torch_ref.ModelCfg (same knob names the reference's gin bindings use).  finetune_optimizer: the schedule /
+  Adam fields carry the spec's finetune_* values (create_finetune_optimizer, train_utils.py:518-537)."""
   from oracle import torch_ref as R
   s = spec(case)
   c, m, n, p = s['Config'], s['Model'], s['NerfMLP'], s['PropMLP']
@@ -121,6 +129,11 @@ def oracle_cfg(case):
   if 'net_width_transient' in n:
     cfg.transient_width = n['net_width_transient']
   cfg.rgb_premultiplier, cfg.rgb_bias = n.get('rgb_premultiplier', 1.), n.get('rgb_bias', 0.)
+  if finetune_optimizer:
+    for dst, src in (('lr_init', 'finetune_lr_init'), ('lr_final', 'finetune_lr_final'), ('max_steps', 'finetune_max_steps'),
+                     ('lr_delay_steps', 'finetune_lr_delay_steps'), ('lr_delay_mult', 'finetune_lr_delay_mult'),
+                     ('adam_beta1', 'finetune_adam_beta1'), ('adam_beta2', 'finetune_adam_beta2'), ('adam_eps', 'finetune_adam_eps')):
+      setattr(cfg, dst, c[src])
   return cfg
 
 

@@ -80,6 +80,50 @@ def test_graph_replay_of_the_transient_variants(variant):
   np.testing.assert_allclose(np.array(e[4]), np.array(g[4]), rtol=2e-3)
 
 
+def _run_finetune(mode, gin, nsteps):
+  from tests import hugs_testlib as H
+  from nerf_hugs_amd.internal import train_utils, random as hr
+  old = train_utils._STEP_GRAPH
+  train_utils._STEP_GRAPH = mode
+  try:
+    config, model, state, render_fn, train_step, cfg, oparams = H.make_pair(gin + ["Config.finetune_enable = True"], compute_dtype='bf16')
+    key = hr.PRNGKey(7)
+    for i in range(2):                     # the training stage first: every gradient slot and both Adam moments are non-trivial
+      state, _, key = train_step(key, state, H.synth_rays(2, 8, 11 + i), 0.5, None)
+    fstate, ftrain, _ = train_utils.setup_finetune_model(config, model, state)
+    theta0 = fstate.flat.clone()
+    out = []
+    for i in range(nsteps):
+      fstate, stats, key = ftrain(key, fstate, H.synth_rays(2, 8, 5 + (i % 3)), 1.0, None)
+      out.append((float(stats['loss']), float(stats['psnr']), float(stats['grad_norms']['NerfMLP_0']), float(stats['opt_update_maxes']['GloEmbed_0'])))
+    torch.cuda.synchronize()
+    return fstate.flat.clone(), fstate.m.clone(), fstate.v.clone(), key.clone(), out, fstate.step, ftrain.graph_active(), model.layout, theta0
+  finally:
+    train_utils._STEP_GRAPH = old
+
+
+@pytest.mark.parametrize('variant', ['glo', 'nerfw'])
+def test_graph_replay_of_the_finetune_stage(variant):
+  """train.py:97-109: after training, create_train_step(model, config, True) + the embedding-only optimizer.  The finetune step is
+  captured like the training step; against the eager enqueue it agrees to the rounding of the GLO scatter-add, and in both only the
+  GLO table moves."""
+  gin = list(NERFW) if variant == 'nerfw' else list(SMALL) + ["Model.num_glo_features = 4"]
+  e = _run_finetune('0', gin, 6)
+  g = _run_finetune('1', gin, 6)
+  assert not e[6] and g[6], 'the graph path did not engage'
+  assert e[5] == g[5] == 6
+  for a, b, name in zip(e[:3], g[:3], ('params', 'adam m', 'adam v')):
+    sc = float(a.abs().max())
+    assert float((a - b).abs().max()) <= 2e-3 * sc, (name, float((a - b).abs().max()), sc)
+  assert torch.equal(e[3], g[3])
+  np.testing.assert_allclose(np.array(e[4]), np.array(g[4]), rtol=2e-3)
+  for r in (e, g):
+    lay = r[7]
+    for lf in lay.leaves:
+      d = float((lay.view(r[0], lf['path']) - lay.view(r[8], lf['path'])).abs().max())
+      assert (d > 0) == ('/'.join(lf['path']) == 'GloEmbed_0/embedding'), lf['path']
+
+
 def test_graph_is_not_used_where_the_step_cannot_be_captured():
   """RobustNeRF thresholds fed from the host, explicit jitter draws, a torch.Generator: eager enqueue, same results as ever."""
   from tests import hugs_testlib as H

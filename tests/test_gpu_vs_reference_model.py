@@ -24,6 +24,8 @@ def _build(case, compute_dtype='fp32'):
   config = configs.make_config()
   model, state, render_fn, train_step, lr_fn = train_utils.setup_model(config, 0, compute_dtype=compute_dtype)
   model.load_variables(state.flat, FX.param_tree(case))
+  if FX.is_finetune(case):        # train.py:97-109: the stage after training, on the same model / parameters
+    state, train_step, lr_fn = train_utils.setup_finetune_model(config, model, state)
   shp = FX.get(case, 'rays/origins').shape[:-1]
   T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
   rays = utils.Rays(**{f: T(FX.get(case, f'rays/{f}')) for f in FX.RAY_FIELDS})
@@ -31,7 +33,7 @@ def _build(case, compute_dtype='fp32'):
   return config, model, state, train_step, batch, lr_fn
 
 
-@pytest.mark.parametrize('case', FX.CASES + FX.TRAIN_VARIANTS)
+@pytest.mark.parametrize('case', FX.CASES + FX.TRAIN_VARIANTS + FX.FINETUNE_CASES)
 def test_forward_vs_reference(case):
   from nerf_hugs_amd.internal import models as M
   config, model, state, train_step, batch, _ = _build(case)
@@ -103,7 +105,7 @@ def test_sampler_bins_and_indices_vs_reference(case):
     assert np.array_equal(idx, ref_idx), f'{case} l{l}: {int((idx != ref_idx).sum())}/{idx.size} interval indices differ'
 
 
-@pytest.mark.parametrize('case', FX.CASES + FX.TRAIN_VARIANTS)
+@pytest.mark.parametrize('case', FX.CASES + FX.TRAIN_VARIANTS + FX.FINETUNE_CASES)
 def test_train_step_stats_and_derivatives_vs_reference(case):
   """One train_step on the reference's batch / weights / uniform draws: loss terms, mses, psnrs, robust stats,
   weight_l2s, and <grad, v> against the reference's float64 central differences along seeded directions."""
@@ -123,8 +125,9 @@ def test_train_step_stats_and_derivatives_vs_reference(case):
   np.testing.assert_allclose(np.asarray(stats['psnrs']), FX.get(case, 'stats/psnrs'), rtol=0, atol=1e-3)
   for k in [k for k in FX.keys(case, 'stats/') if k.startswith('robust_')]:
     np.testing.assert_allclose(np.asarray(stats[k]), FX.get(case, f'stats/{k}'), rtol=1e-4, atol=1e-6, err_msg=k)
-  if config.transient_type == 'hanerf':
+  if config.transient_type == 'hanerf' and not FX.is_finetune(case):
     np.testing.assert_allclose(np.asarray(stats['implicit_mask']), FX.get(case, 'stats/implicit_mask'), rtol=1e-4)
+  assert ('implicit_mask' in stats) == ('implicit_mask' in FX.keys(case, 'stats/'))
   # summarize_tree key sets (train_utils.py:61-69) and weight_l2s values
   for group in ('weight_l2s', 'grad_norms', 'grad_maxes', 'opt_update_norms', 'opt_update_maxes'):
     assert set(stats[group].keys()) == set(FX.keys(case, f'stats/{group}/')), group
@@ -144,8 +147,18 @@ def test_train_step_stats_and_derivatives_vs_reference(case):
   othr = None if thr is None else [torch.from_numpy(t.copy()) for t in thr]
   _, og, _, _ = R.loss_and_grad(cfg, FX.param_tree(case), FX.rays_flat(case),
                                 torch.from_numpy(FX.get(case, 'rgb').reshape(-1, 3).copy()),
-                                float(FX.get(case, 'train_frac')), FX.u01(case, L), othr)
-  if case in FX.TRAIN_VARIANTS:
+                                float(FX.get(case, 'train_frac')), FX.u01(case, L), othr, is_finetune=FX.is_finetune(case))
+  if FX.is_finetune(case):
+    # the parts of the tree the finetune loss does not reach: exactly zero, as in the reference's value_and_grad
+    dead = {k for k in og if float(og[k].abs().max()) == 0.0}
+    assert {k.split('/')[0] for k in dead} >= {'PropMLP_0', 'TransientEmbed_0'} and 'GloEmbed_0/embedding' not in dead
+    for k in dead:
+      assert float(np.abs(g[k]).max()) == 0.0, k
+    # and only the reference's 'trainable' partition moved
+    for lf in model.layout.leaves:
+      d = float((model.layout.view(state.flat, lf['path']) - model.layout.view(theta0, lf['path'])).abs().max())
+      assert (d > 0) == ('/'.join(lf['path']) == 'GloEmbed_0/embedding'), lf['path']
+  if case in FX.TRAIN_VARIANTS + FX.FINETUNE_CASES:
     # (no finite differences recorded for the option variants: the gradient against the float32 oracle, whose losses the CPU suite
     #  holds to the reference for the same case, along the same seeded directions)
     ndir = 4
@@ -166,7 +179,7 @@ def test_train_step_stats_and_derivatives_vs_reference(case):
     assert abs(mine - fd) <= 1e-2 * scale, (case, i, mine, fd)
 
 
-@pytest.mark.parametrize('case', ['base', 'withmask', 'robust', 'decay_clips_schedule'])
+@pytest.mark.parametrize('case', ['base', 'withmask', 'robust', 'decay_clips_schedule', 'ft_nerfw', 'ft_hanerf'])
 def test_clip_and_update_on_reference_gradient(case):
   """The reference's train_step was run with a seeded synthetic gradient tree through its own stats /
   clip_gradients / nan_to_num / apply_gradients code; the same tree through hugs_opt_stats + hugs_opt_adam.

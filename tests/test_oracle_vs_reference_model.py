@@ -24,7 +24,7 @@ def _forward(case, dtype=torch.float32, override=None):
   return cfg, P, rays, tf, rend, hist
 
 
-@pytest.mark.parametrize('case', FX.CASES + FX.TRAIN_VARIANTS)
+@pytest.mark.parametrize('case', FX.CASES + FX.TRAIN_VARIANTS + FX.FINETUNE_CASES)
 def test_model_forward_vs_reference(case):
   """Model.__call__ + MLP.__call__ (models.py:74-330, 406-550): every level's sample positions, densities,
   colours, weights and rendered colours (+ NeRF-W / HA-NeRF outputs)."""
@@ -83,7 +83,7 @@ def test_sampler_interval_index_vs_reference(case):
     assert not mism.any(), f'{case} level {l}: {int(mism.sum())}/{idx.size} interval indices differ'
 
 
-@pytest.mark.parametrize('case', FX.CASES + FX.TRAIN_VARIANTS)
+@pytest.mark.parametrize('case', FX.CASES + FX.TRAIN_VARIANTS + FX.FINETUNE_CASES)
 def test_losses_and_stats_vs_reference(case):
   """compute_data_loss / compute_robustnerf_loss / compute_nerfw_loss / compute_hanerf_loss + interlevel +
   distortion as assembled by train_step.loss_fn (train_utils.py:72-248, 404-455)."""
@@ -94,7 +94,7 @@ def test_losses_and_stats_vs_reference(case):
   if cfg.transient_type == 'robustnerf':
     thr = [torch.from_numpy(t.copy()) for t in FX.get(case, 'inlier_thresholds')]
   stats, grads, _, _ = R.loss_and_grad(cfg, P, rays, gt, float(FX.get(case, 'train_frac')),
-                                       FX.u01(case, cfg.num_levels), thr)
+                                       FX.u01(case, cfg.num_levels), thr, is_finetune=FX.is_finetune(case))
   ref_loss = float(FX.get(case, 'stats/loss'))
   assert abs(float(stats['loss']) - ref_loss) <= 2e-5 * abs(ref_loss)
   for k in FX.keys(case, 'stats/losses/'):
@@ -108,7 +108,15 @@ def test_losses_and_stats_vs_reference(case):
   for k in [k for k in FX.keys(case, 'stats/') if k.startswith('robust_')]:
     np.testing.assert_allclose(torch.stack(list(stats[k])).numpy() if isinstance(stats[k], list) else stats[k].numpy(),
                                FX.get(case, f'stats/{k}'), rtol=1e-5, atol=1e-7, err_msg=k)
-  if cfg.transient_type == 'hanerf':
+  if FX.is_finetune(case):
+    # train_utils.py:422-447 with is_finetune: the data loss alone, nothing of the transient machinery in the statistics, and (the
+    # loss does not see them) exactly zero gradient on the proposal MLP, the transient embedding and the mask / transient branches
+    assert set(stats['losses']) == {'data'} and 'stats/implicit_mask' not in [f'stats/{k}' for k in FX.keys(case, 'stats/')]
+    for k, g in grads.items():
+      if k.split('/')[0] in ('PropMLP_0', 'TransientEmbed_0', 'ImplicitMask_0'):
+        assert float(g.abs().max()) == 0.0, k
+    assert float(grads['GloEmbed_0/embedding'].abs().max()) > 0
+  elif cfg.transient_type == 'hanerf':
     np.testing.assert_allclose(stats['implicit_mask'].numpy(), FX.get(case, 'stats/implicit_mask'), rtol=1e-5)
   # weight_l2s (train_utils.py:442): summarize_tree keys and values
   flat = FX.flat_params(case)
@@ -152,7 +160,7 @@ def test_directional_derivatives_vs_reference(case):
     assert abs(mine - fd) <= 2e-5 * scale + 4 * abs(fd - fd2) + 1e-9, (case, i, mine, fd, fd2)
 
 
-@pytest.mark.parametrize('case', FX.CASES + FX.TRAIN_VARIANTS)
+@pytest.mark.parametrize('case', FX.CASES + FX.TRAIN_VARIANTS + FX.FINETUNE_CASES)
 def test_clip_gradients_vs_reference(case):
   """clip_gradients (train_utils.py:351-369) on the seeded synthetic gradient tree the reference's train_step was
   run with; withmask's bindings make both the value clip and the norm clip bite."""
@@ -186,6 +194,31 @@ def test_adam_restated_consistent_with_standin(case):
   for k in flat:
     ref = FX.get(case, f'update_head/{k}')
     np.testing.assert_allclose((newp[k] - flat[k]).reshape(-1)[:32].numpy(), ref, rtol=2e-3, atol=1e-9)
+
+
+@pytest.mark.parametrize('case', FX.FINETUNE_CASES)
+def test_finetune_optimizer_vs_reference(case):
+  """create_finetune_optimizer (train_utils.py:515-552) as the reference ran it on the seeded synthetic gradient tree: which
+  leaves move (the reference's own path_aware_map partition), the finetune_* schedule at step 0, and the update itself with the
+  finetune_* Adam knobs (optax restated on both sides -- the partition, the clip before it and the knob routing are the pins)."""
+  cfg = FX.oracle_cfg(case, finetune_optimizer=True)
+  lr0 = R.learning_rate_decay(0, cfg.lr_init, cfg.lr_final, cfg.max_steps, cfg.lr_delay_steps, cfg.lr_delay_mult)
+  assert abs(float(lr0) - float(FX.get(case, 'lr0'))) <= 1e-6 * float(lr0)
+  flat = {k: torch.from_numpy(v.copy()) for k, v in FX.flat_params(case).items()}
+  g = {k: torch.from_numpy(v.astype(np.float32)) for k, v in FX.seeded_tree(case, 4242, 3e-3).items()}
+  g = R.clip_gradients(cfg, g)                    # (the clip sees the whole tree, frozen leaves included: :464 before :468)
+  z = {k: torch.zeros_like(v) for k, v in flat.items()}
+  newp, _, _ = R.adam_update(cfg, flat, g, z, dict(z), 0)
+  moved = set()
+  for k in flat:
+    ref = FX.get(case, f'update_head/{k}')
+    if R.finetune_trainable(k):
+      moved.add(k)
+      assert float(np.abs(ref).max()) > 0, k
+      np.testing.assert_allclose((newp[k] - flat[k]).reshape(-1)[:32].numpy(), ref, rtol=2e-3, atol=1e-9)
+    else:
+      assert float(np.abs(ref).max()) == 0.0, k
+  assert moved == {'GloEmbed_0/embedding', 'TransientEmbed_0/embedding'}
 
 
 def test_robustnerf_mask_unit_vs_reference():
