@@ -602,10 +602,8 @@ def create_train_step(model, config, is_finetune=False):
       nonlocal prop_done
       coef = config.data_loss_mult if l == L - 1 else config.data_coarse_loss_mult
       is_prop = l < L - 1
-      if is_finetune and is_prop:
-        return                         # proposal MLP gets no gradient in the finetune stage
       if is_prop and d_w[l] is None and coef == 0:
-        return
+        return          # (always so in the finetune stage -- no interlevel term -- unless a coarse data loss reaches a proposal MLP that renders colour)
       tgt = grad
       if is_prop and prop_done:
         tgt = ws.get('grad_tmp', (layout.size + STAT_TAIL,))

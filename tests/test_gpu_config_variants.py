@@ -56,6 +56,37 @@ def test_variant_forward_and_gradients_vs_oracle(name):
   _run_case(gin, n_patch=max(1, 64 // (P * P)), P=P)
 
 
+FT = ["Config.finetune_enable = True", "Config.finetune_lr_init = 0.02", "Config.finetune_lr_delay_steps = 20", "Config.finetune_adam_beta1 = 0.8",
+      "Config.finetune_adam_eps = 1e-7", "Model.num_glo_features = 4"]
+FINETUNE_VARIANTS = {
+    'glo': [],
+    'withmask_charb_levels3_contract': ["Config.transient_type = 'withmask'", "Config.data_loss_type = 'charb'", "Model.num_levels = 3",
+                                        "Model.num_prop_samples = 64", "Model.num_nerf_samples = 32", "NerfMLP.warp_fn = @coord.contract",
+                                        "PropMLP.warp_fn = @coord.contract", "Model.raydist_fn = @jnp.reciprocal"],
+    'robustnerf': ["Config.transient_type = 'robustnerf'", "Config.patch_size = 16"],
+    'hanerf': ["Config.transient_type = 'hanerf'", "Model.num_transient_features = 16", "NerfMLP.bottleneck_width = 128"],
+    'nerfw_glo48': ["Config.transient_type = 'nerfw'", "Model.num_transient_features = 16", "NerfMLP.bottleneck_width = 128",
+                    "Model.num_glo_features = 48"],
+    'no_viewdirs_weight_decay': ["Model.use_viewdirs = False", "Config.weight_decay_mults = {'NerfMLP_0': 0.1}"],
+    'coarse_loss_prop_rgb': ["PropMLP.disable_rgb = False", "PropMLP.bottleneck_width = 128", "Config.data_coarse_loss_mult = 0.2"],
+}
+
+
+@pytest.mark.parametrize('name', sorted(FINETUNE_VARIANTS))
+def test_finetune_step_forward_and_gradients_vs_oracle(name):
+  """The finetune stage's step (train.py:97-109; create_train_step(model, config, True) + create_finetune_optimizer) of each model
+  family against the oracle, whose finetune form tests/test_oracle_vs_reference_model.py holds to the reference executed: the plain
+  data loss whatever transient_type is (robustnerf thresholds ignored, no mask / uncertainty terms), every leaf's gradient, and an
+  update that moves the embedding tables only, by the finetune_* schedule and Adam knobs."""
+  extra = FT + FINETUNE_VARIANTS[name]
+  keys = {e.split('=')[0].strip() for e in extra}
+  gin = [g for g in SMALL if g.split('=')[0].strip() not in keys]
+  for e in extra:         # (a later binding of the same key wins, as in gin)
+    gin = [g for g in gin if g.split('=')[0].strip() != e.split('=')[0].strip()] + [e]
+  P = 16 if name == 'robustnerf' else 8
+  _run_case(gin, n_patch=max(1, 64 // (P * P)), P=P, inlier=0.3 if name == 'robustnerf' else None, finetune=True)
+
+
 @pytest.mark.parametrize('name,err', [('nerf_depth_5', NotImplementedError), ('rawnerf', AssertionError)])
 def test_refusals(name, err):
   """A skip concat after the LAST trunk layer is not built (models.py:451-456 would create it for net_depth = 5, 9); a data loss other

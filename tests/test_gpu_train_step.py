@@ -16,10 +16,20 @@ SMALL = ["Config.patch_size = 8", "Config.data_loss_type = 'mse'", "Config.disto
          "NerfMLP.net_depth = 8", "NerfMLP.net_width = 128", "Config.randomized = True"]
 
 
-def _run_case(gin, n_patch=1, P=8, near=0.1, far=1.2, seed=5, inlier=None, tol_grad=1e-1):
+def _run_case(gin, n_patch=1, P=8, near=0.1, far=1.2, seed=5, inlier=None, tol_grad=1e-1, finetune=False):
+  """finetune: the step is the finetune stage's (setup_finetune_model; train_utils.py:599-605) on the same model / parameters."""
   from tests import hugs_testlib as H
   from oracle import torch_ref as R
   config, model, state, render_fn, train_step, cfg, oparams = H.make_pair(gin)
+  if finetune:
+    import copy
+    from nerf_hugs_amd.internal import train_utils
+    state, train_step, _ = train_utils.setup_finetune_model(config, model, state)
+    cfg_opt = copy.copy(cfg)
+    for k in ('lr_init', 'lr_final', 'max_steps', 'lr_delay_steps', 'lr_delay_mult', 'adam_beta1', 'adam_beta2', 'adam_eps'):
+      setattr(cfg_opt, k, getattr(config, 'finetune_' + k))
+  else:
+    cfg_opt = cfg
   batch = H.synth_rays(n_patch, P, seed, near=near, far=far)
   N = n_patch * P * P
   gen = torch.Generator(device='cuda').manual_seed(11)
@@ -33,7 +43,7 @@ def _run_case(gin, n_patch=1, P=8, near=0.1, far=1.2, seed=5, inlier=None, tol_g
   # oracle
   othr = None if inlier is None else [torch.tensor([inlier]) for _ in range(L)]
   ostats, ograds, orend, ohist = R.loss_and_grad(cfg, oparams, H.oracle_rays(batch), batch.rgb.reshape(-1, 3),
-                                                 0.37, [u.cpu() for u in u01], othr)
+                                                 0.37, [u.cpu() for u in u01], othr, is_finetune=finetune)
   # product forward (same jitter)
   theta0 = state.flat.clone()
   eng = model.engine('cuda')
@@ -66,6 +76,7 @@ def _run_case(gin, n_patch=1, P=8, near=0.1, far=1.2, seed=5, inlier=None, tol_g
         f'grad {name}: rel err median {float(e.median()):.2e} max {float(e.max()):.2e} (max |g| {float(sc):.2e})'
   assert abs(float(stats['loss']) / float(ostats['loss']) - 1) < 1e-4
   np.testing.assert_allclose(stats['mses'].numpy(), ostats['mses'].detach().numpy(), rtol=2e-4)
+  assert set(stats['losses'].keys()) == set(ostats['losses'].keys())
   for k, v in ostats['losses'].items():
     # (absolute floor 1e-7: the interlevel term of some cases is ~5e-5, a sum of squared hinge excesses that one sample
     # crossing a proposal bin edge between the two float32 evaluations moves by 1e-3 of itself)
@@ -73,16 +84,19 @@ def _run_case(gin, n_patch=1, P=8, near=0.1, far=1.2, seed=5, inlier=None, tol_g
   # optimizer: oracle clip + adam on the ORACLE gradients
   names = [n for n, _ in R.flat_leaves(oparams['params'])]
   p0 = {n: t for n, t in R.flat_leaves(oparams['params'])}
-  clipped = R.clip_gradients(cfg, gprod)
+  clipped = R.clip_gradients(cfg_opt, gprod)
   z = {n: torch.zeros_like(p0[n]) for n in names}
-  newp, _, _ = R.adam_update(cfg, p0, clipped, z, z, 0)
+  newp, _, _ = R.adam_update(cfg_opt, p0, clipped, z, z, 0)
   for lf in model.layout.leaves:
     name = '/'.join(lf['path'])
     d_prod = (model.layout.view(state.flat, lf['path']) - model.layout.view(theta0, lf['path'])).cpu().double()
     d_orc = (newp[name] - p0[name]).double()
+    if finetune and not R.finetune_trainable(name):
+      assert float(d_prod.abs().max()) == 0.0, f'frozen leaf moved: {name}'
+      continue
     # new - old is quantised to ulp(theta) (theta ~ 0.1 -> 7.5e-9) on both sides
     assert float((d_prod - d_orc).abs().max()) <= 1e-4 * float(d_orc.abs().max()) + 3e-8, f'update {name}'
-  if inlier is not None:
+  if inlier is not None and not finetune:
     for k in ['inlier_threshold', 'is_inlier_loss', 'has_inlier_neighbors', 'is_inlier_patch', 'mask']:
       np.testing.assert_allclose(stats['robust_' + k].numpy(), ostats['robust_' + k].detach().numpy(), rtol=2e-4, atol=1e-6, err_msg=k)
   return worst
