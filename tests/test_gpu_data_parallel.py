@@ -21,7 +21,7 @@ HANERF = GIN + ["Config.transient_type = 'hanerf'", "Model.num_transient_feature
                 "NerfMLP.bottleneck_width = 128"]
 
 
-def _step(rank, world, port, out_dir, gin, backend='gloo', nsteps=1, graph='0', dtype='fp32'):
+def _step(rank, world, port, out_dir, gin, backend='gloo', nsteps=1, graph='0', dtype='fp32', finetune=0):
   import sys
   sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
   from tests import hugs_testlib as H
@@ -46,16 +46,21 @@ def _step(rank, world, port, out_dir, gin, backend='gloo', nsteps=1, graph='0', 
     state, stats, _ = train_step(None, state, batch, 0.4 + 0.01 * i, None)
   torch.cuda.synchronize()
   assert train_step.graph_active() == (graph == '1' and nsteps > 2)
+  if finetune:          # train.py:97-109: the embedding-only stage behind the training steps, same sharding
+    state, ftrain, _ = train_utils.setup_finetune_model(config, model, state)
+    for i in range(finetune):
+      state, stats, _ = ftrain(None, state, batch, 1.0, None)
+    torch.cuda.synchronize()
   if rank == 0:
     torch.save({'flat': state.flat.cpu(), 'loss': float(stats['loss']), 'mses': stats['mses']}, os.path.join(out_dir, f'w{world}.pt'))
   if world > 1:
     dist.destroy_process_group()
 
 
-def _compare(tmp_path, gin, backend, nsteps=1, graph='0', dtype='fp32'):
+def _compare(tmp_path, gin, backend, nsteps=1, graph='0', dtype='fp32', finetune=0):
   s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-  mp.spawn(_step, args=(1, port, str(tmp_path), gin, backend, nsteps, graph, dtype), nprocs=1, join=True)
-  mp.spawn(_step, args=(2, port, str(tmp_path), gin, backend, nsteps, graph, dtype), nprocs=2, join=True)
+  mp.spawn(_step, args=(1, port, str(tmp_path), gin, backend, nsteps, graph, dtype, finetune), nprocs=1, join=True)
+  mp.spawn(_step, args=(2, port, str(tmp_path), gin, backend, nsteps, graph, dtype, finetune), nprocs=2, join=True)
   a = torch.load(tmp_path / 'w1.pt'); b = torch.load(tmp_path / 'w2.pt')
   from tests import hugs_testlib as H
   from nerf_hugs_amd.internal import configs, models
@@ -69,7 +74,7 @@ def _compare(tmp_path, gin, backend, nsteps=1, graph='0', dtype='fp32'):
     ua, ub = m.layout.view(da, lf['path']), m.layout.view(db, lf['path'])
     # (several steps: Adam turns a gradient that differs in its last bits into an update that differs by ~lr * relative error,
     # and the reassociated gradient sums of the two shardings drift apart step by step: 5e-3 of the largest update per leaf)
-    if nsteps == 1:
+    if nsteps == 1 and not finetune:
       assert float((ua - ub).abs().max()) <= 2e-3 * float(ua.abs().max()) + 3e-8, lf['path']
     else:      # a population statement: one ReLU decision that flips in step 2 moves single entries by a sample's contribution
       sc = float(ua.abs().max())
@@ -92,6 +97,13 @@ NOVIEW = GIN + ["Model.use_viewdirs = False", "Model.num_glo_features = 4"]
 @pytest.mark.parametrize('gin', [GIN, HANERF, NERFW, NOVIEW], ids=['base', 'hanerf', 'nerfw', 'no_viewdirs'])
 def test_two_rank_step_equals_single_process(tmp_path, gin):
   _compare(tmp_path, gin, 'gloo')
+
+
+def test_two_rank_finetune_stage_equals_single_process(tmp_path):
+  """One training step, then two steps of the finetune stage (every gradient range goes through the un-bucketed all-reduce there; the
+  coarse data loss keeps the proposal MLP in the backward pass), two ranks against one process."""
+  gin = NERFW + ["Config.finetune_enable = True", "PropMLP.disable_rgb = False", "PropMLP.bottleneck_width = 128", "Config.data_coarse_loss_mult = 0.2"]
+  _compare(tmp_path, gin, 'gloo', finetune=2)
 
 
 def test_two_rank_step_equals_single_process_bf16_batched_dw(tmp_path):
