@@ -1,0 +1,86 @@
+"""Random COMBINATIONS of the gin options the reference accepts (scratch/config_fuzz2.py walks them one at a time): each draw goes through
+tests/test_gpu_train_step._run_case -- forward of every level, every loss term, every leaf's gradient, clip + Adam against the fp32 oracle --
+as a training step or (every third draw that has an embedding table) as the finetune stage's step.   python scratch/config_fuzz3.py [seed] [n]"""
+import sys, os, random
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tests.test_gpu_train_step import SMALL, _run_case
+
+BOTH = lambda *names: [f'{m}.{n}' for m in ('NerfMLP', 'PropMLP') for n in names]
+CONTRACT = ["NerfMLP.warp_fn = @coord.contract", "PropMLP.warp_fn = @coord.contract"]
+GROUPS = {
+    'transient': [None, ["Config.transient_type = 'withmask'"], ["Config.transient_type = 'robustnerf'", "Config.patch_size = 16"],
+                  ["Config.transient_type = 'hanerf'", "Model.num_transient_features = 16", "NerfMLP.bottleneck_width = 128"],
+                  ["Config.transient_type = 'nerfw'", "Model.num_transient_features = 16", "NerfMLP.bottleneck_width = 128"]],
+    'glo': [None, ["Model.num_glo_features = 1"], ["Model.num_glo_features = 4"], ["Model.num_glo_features = 48"]],
+    'levels': [None, ["Model.num_levels = 3"], ["Model.num_levels = 4"]],
+    'samples': [["Model.num_prop_samples = 32", "Model.num_nerf_samples = 32"], ["Model.num_prop_samples = 48", "Model.num_nerf_samples = 24"],
+                ["Model.num_prop_samples = 64", "Model.num_nerf_samples = 64"]],
+    'raydist': [None, ["Model.raydist_fn = @jnp.reciprocal"], ["Model.raydist_fn = @jnp.log"], ["Model.raydist_fn = @jnp.sqrt"], ["Model.raydist_fn = 'piecewise'"]],
+    'contract': [None, CONTRACT],
+    'shape': [None, None, ["Model.ray_shape = 'cylinder'"]],
+    'view': [None, None, ["Model.use_viewdirs = False"], BOTH('net_depth_viewdirs = 2'), BOTH('deg_view = 2'), BOTH('deg_view = 6')],
+    'prop_rgb': [None, None, ["PropMLP.disable_rgb = False", "PropMLP.bottleneck_width = 128", "Config.data_coarse_loss_mult = 0.2"]],
+    'bg': [None, ["Model.opaque_background = False"], ["Model.opaque_background = False", "Model.bg_intensity_range = (0.5, 0.5)"]],
+    'loss': [None, ["Config.data_loss_type = 'charb'"], ["Config.disable_multiscale_loss = True"], ["Config.data_loss_type = 'charb'", "Config.charb_padding = 0.01"]],
+    'jitter': [None, None, ["Model.single_jitter = False"]],
+    'anneal': [None, None, ["Model.near_anneal_rate = 0.5"], ["Model.anneal_slope = 0."], ["Model.dilation_multiplier = 0.", "Model.dilation_bias = 0."],
+               ["Model.resample_padding = 0.01"]],
+    'trunk': [None, None, BOTH('skip_layer = 2'), ["NerfMLP.net_depth = 2"], ["NerfMLP.net_width = 192"], ["NerfMLP.net_width = 384", "NerfMLP.net_depth = 4"],
+              ["PropMLP.net_width = 64"], ["PropMLP.net_depth = 1"]],
+    'heads': [None, None, BOTH('density_bias = 0.'), BOTH('rgb_padding = 0.'), ["NerfMLP.max_deg_point = 16", "PropMLP.max_deg_point = 16"],
+              ["NerfMLP.max_deg_point = 3", "PropMLP.max_deg_point = 3"]],
+    'reg': [None, None, ["Config.weight_decay_mults = {'NerfMLP_0': 0.05}"], ["Config.grad_max_val = 0.0005"], ["Config.grad_max_norm = 0.01"],
+            ["Config.interlevel_loss_mult = 0.3", "Config.distortion_loss_mult = 0."]],
+}
+FT = ["Config.finetune_enable = True", "Config.finetune_lr_init = 0.02", "Config.finetune_lr_delay_steps = 20", "Config.finetune_adam_beta1 = 0.8"]
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+rnd = random.Random(seed)
+tally = {}
+ONLY = [int(x) for x in os.environ.get('FUZZ_ONLY', '').split(',') if x]
+for i in range(count):
+  picks = {g: rnd.choice(opts) for g, opts in GROUPS.items()}
+  if ONLY and i not in ONLY:
+    continue
+  extra = [e for v in picks.values() if v for e in v]
+  rd = picks['raydist']
+  if picks['shape'] and rd and ('reciprocal' in rd[0] or 'piecewise' in rd[0]):
+    # cylinder rays belong to the llff gins (NDC, near / far of order one); with far = 1e6 / 50 and no contraction in front of the
+    # covariance lift, b^T cov b cancels 1e10-sized terms in float32 and comes out negative (-> exp(+x) = inf) in the reference's own arithmetic
+    extra = [e for e in extra if 'ray_shape' not in e]
+  has_table = any('num_glo_features' in e or 'num_transient_features' in e for e in extra)
+  finetune = has_table and i % 3 == 2
+  if finetune:
+    extra += FT
+  gin = list(SMALL)
+  for e in extra:
+    gin = [g for g in gin if g.split('=')[0].strip() != e.split('=')[0].strip()] + [e]
+  P = 16 if any('robustnerf' in e for e in extra) else 8
+  kw = dict(n_patch=max(1, 64 // (P * P)), P=P, finetune=finetune, fwd_population=True)
+  if any('robustnerf' in e for e in extra):
+    kw['inlier'] = 0.3
+  rd = picks['raydist']
+  if rd and 'reciprocal' in rd[0]:
+    kw.update(near=(0.05, 0.3), far=1e6)
+  if rd and 'piecewise' in rd[0]:
+    kw.update(near=(0.0, 0.2), far=50.0)
+  if ONLY:
+    import diag_case
+    diag_case.diag(gin, **kw)
+    continue
+  try:
+    worst = _run_case(gin, **kw)
+    res = f'ok (worst leaf rel {worst:.1e})'
+  except NotImplementedError as e:
+    res = f'refused: {str(e)[:100]}'
+  except AssertionError as e:
+    res = f'MISMATCH: {str(e)[:200]}'
+  except Exception as e:
+    res = f'{type(e).__name__}: {str(e)[:160]}'
+  tally[res.split(':')[0].split(' ')[0]] = tally.get(res.split(':')[0].split(' ')[0], 0) + 1
+  tag = ('FT ' if finetune else '   ') + '; '.join(e.split('.', 1)[1].replace(' = ', '=') if e.startswith(('Model.', 'Config.')) else e.replace(' = ', '=') for e in extra if e not in FT)
+  print(f'{i:3d} {res:60s} {tag}', flush=True)
+  torch.cuda.empty_cache()
+print('tally', tally)
