@@ -79,8 +79,23 @@ for i in range(count):
     res = f'MISMATCH: {str(e)[:200]}'
   except Exception as e:
     res = f'{type(e).__name__}: {str(e)[:160]}'
+  if res.startswith('ok') and os.environ.get('FUZZ_GRAPH'):
+    # the same option set in the shipped precision, replayed from the captured hipGraph against the eager enqueue (jax key, 5 steps)
+    from tests.test_gpu_step_graph import _run as graph_run, _run_finetune as graph_run_ft
+    try:
+      if finetune:
+        e_, g_ = graph_run_ft('0', gin, 5), graph_run_ft('1', gin, 5)
+      else:
+        gk = dict(n_patch=max(2, 128 // (P * P)), P=P)
+        e_, g_ = graph_run('0', gin, 5, 'key', **gk), graph_run('1', gin, 5, 'key', **gk)
+      sc = float(e_[0].abs().max()); d = float((e_[0] - g_[0]).abs().max())
+      keys_equal = bool(torch.equal(e_[3], g_[3]))
+      res += ' | graph ' + ('NOT ENGAGED' if not g_[6] else ('== eager' if d == 0 else f'vs eager {d / sc:.1e}') + ('' if keys_equal else ' KEY DIFFERS')
+                            + ('' if d <= 2e-3 * sc else ' GRAPH MISMATCH'))
+    except Exception as e:
+      res += f' | graph {type(e).__name__}: {str(e)[:120]}'
   tally[res.split(':')[0].split(' ')[0]] = tally.get(res.split(':')[0].split(' ')[0], 0) + 1
   tag = ('FT ' if finetune else '   ') + '; '.join(e.split('.', 1)[1].replace(' = ', '=') if e.startswith(('Model.', 'Config.')) else e.replace(' = ', '=') for e in extra if e not in FT)
-  print(f'{i:3d} {res:60s} {tag}', flush=True)
+  print(f'{i:3d} {res:85s} {tag}', flush=True)
   torch.cuda.empty_cache()
 print('tally', tally)
