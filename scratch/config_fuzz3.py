@@ -94,8 +94,32 @@ for i in range(count):
                             + ('' if d <= 2e-3 * sc else ' GRAPH MISMATCH'))
     except Exception as e:
       res += f' | graph {type(e).__name__}: {str(e)[:120]}'
+  if not res.startswith('refused') and os.environ.get('FUZZ_EVAL'):
+    # test-mode rendering (compute_extras, deterministic samples, a ragged ray count, zero_glo on odd draws) against the oracle's
+    try:
+      from tests import hugs_testlib as H
+      from oracle import torch_ref as R
+      config, model, state, render_fn, train_step, cfg, oparams = H.make_pair(gin)
+      near_far = {k: kw[k] for k in ('near', 'far') if k in kw}
+      batch = H.synth_rays(1, 8, 9, **near_far)
+      n_rays = 37
+      rays = batch.rays.map(lambda x: x.reshape(64, -1)[:n_rays])
+      zg = bool(i % 2) and model.num_glo_features > 0
+      rend, _ = model.apply(state.flat, None, rays, 1.0, True, zero_glo=zg)
+      ob = {k: v[:n_rays] for k, v in H.oracle_rays(batch).items()}
+      orend, _ = R.model_forward(cfg, oparams, ob, 1.0, None, True, zero_glo=zg)
+      per_ray = torch.zeros(n_rays, dtype=torch.float64)
+      for k in ['rgb', 'acc', 'distance_mean', 'distance_median', 'distance_percentile_5', 'distance_percentile_95']:
+        a = rend[-1][k].cpu().reshape(n_rays, -1).double(); b = orend[-1][k].detach().reshape(n_rays, -1).double()
+        per_ray = torch.maximum(per_ray, (a - b).abs().max(-1).values / max(1.0, float(b.abs().max())))
+      off = int((per_ray > 2e-4).sum())
+      res += f' | eval worst {float(per_ray.max()):.1e}, {off}/{n_rays} rays > 2e-4' + (' EVAL MISMATCH' if off > 3 else '')
+    except NotImplementedError as e:
+      res += f' | eval refused'
+    except Exception as e:
+      res += f' | eval {type(e).__name__}: {str(e)[:120]}'
   tally[res.split(':')[0].split(' ')[0]] = tally.get(res.split(':')[0].split(' ')[0], 0) + 1
   tag = ('FT ' if finetune else '   ') + '; '.join(e.split('.', 1)[1].replace(' = ', '=') if e.startswith(('Model.', 'Config.')) else e.replace(' = ', '=') for e in extra if e not in FT)
-  print(f'{i:3d} {res:85s} {tag}', flush=True)
+  print(f'{i:3d} {res:110s} {tag}', flush=True)
   torch.cuda.empty_cache()
 print('tally', tally)
