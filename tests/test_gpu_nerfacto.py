@@ -138,29 +138,13 @@ _NF_EXTRA = {
 }
 
 
-@pytest.mark.parametrize('variant', ['base', 'contract_piecewise_charb', 'withmask', 'robustnerf', 'wide_prop', 'prop_gemm', 'softplus',
-                                     'same_proposal_network', 'softplus_same_net_gemm_field'] + sorted(_NF_EXTRA))
-def test_model_forward_loss_and_gradients_vs_oracle(variant, monkeypatch):
+def _check_nerfacto_vs_oracle(kw, variant=''):
+  """One train_step of NerfactoModel (fp32) against oracle.nerfacto_ref on the same rays / draws / parameters: every level's bins and
+  weights, the colour, every loss term and statistic, every parameter's gradient.  kw: NerfactoConfig / NF.Cfg fields.  (Also driven by
+  scratch/nerfacto_fuzz2.py with random combinations of the options.)"""
   from nerf_hugs_amd.nerfacto.model import NerfactoConfig, NerfactoModel
   from oracle import nerfacto_ref as NF
-  kw = dict(SMALL)
-  if variant == 'contract_piecewise_charb':
-    kw.update(enable_scene_contraction=True, proposal_initial_sampler='piecewise', rgb_loss_type='charb', opaque_background=False)
-  if variant == 'withmask':
-    kw.update(transient_type='withmask', withmask_transient_weight=0.25)
-  if variant == 'robustnerf':
-    kw.update(transient_type='robustnerf', robustnerf_inlier_quantile=0.7, rgb_loss_type='charb')
-  if variant == 'wide_prop':      # 18 input features, 24 hidden units: the fused proposal kernels' 32-wide instantiation
-    kw.update(proposal_net_args_list=[dict(hidden_dim=24, log2_hashmap_size=9, num_levels=9, max_res=48)])
-  if variant == 'prop_gemm':      # the padded-GEMM fallback of the proposal nets (taken for nets wider than 32 -> 64 -> 1)
-    monkeypatch.setenv('HUGS_NF_FUSED_PROP', '0')
-  # round 5: nerfacto.py:36 density_activation = 'softplus' (F.softplus(raw - 1) in both field types) and :66 use_same_proposal_network
-  # (ONE proposal network evaluates both proposal levels: its gradients are the sum of the two levels')
-  if variant.startswith('softplus'):
-    kw.update(density_activation='softplus')
-  if 'same' in variant:
-    kw.update(use_same_proposal_network=True)
-  kw.update(_NF_EXTRA.get(variant, {}))
+  robust, withmask = kw.get('transient_type') == 'robustnerf', kw.get('transient_type') == 'withmask'
   nlev = kw.get('num_proposal_iterations', 2) + 1
   ocfg = NF.Cfg(**kw)
   P = NF.init_params(ocfg, 3)
@@ -170,10 +154,10 @@ def test_model_forward_loss_and_gradients_vs_oracle(variant, monkeypatch):
       P[k]['table'] = P[k]['table'] * 3e3
   model = NerfactoModel(NerfactoConfig(**kw), compute_dtype='fp32')
   model.load_params(P)
-  N = 256 if variant == 'robustnerf' else 128       # robustnerf: one whole 16x16 patch
+  N = 256 if robust else 128       # robustnerf: one whole 16x16 patch
   b, g = _rays(N, 5)
   thr0 = 0.05                                        # current inlier threshold (extra_infos of the previous step)
-  if variant == 'withmask':
+  if withmask:
     b['static_mask'] = (torch.rand(N, generator=g) < 0.7).float() * torch.rand(N, generator=g)
   u01 = [torch.rand(N, generator=g) for _ in range(nlev)]
   leaves = []
@@ -197,7 +181,7 @@ def test_model_forward_loss_and_gradients_vs_oracle(variant, monkeypatch):
   assert abs(st[0] - float(info['mse'])) <= 2e-4 * float(info['mse'])
   assert abs(float(st[2:2 + nlev - 1].sum()) - float(info['interlevel_loss'])) <= 1e-3 * float(info['interlevel_loss']) + 1e-9
   assert abs(st[8] - float(info['distortion_loss'])) <= 1e-3 * float(info['distortion_loss'])
-  if variant == 'robustnerf':
+  if robust:
     want = [float(info[k]) for k in ('inlier_threshold', 'is_inlier_loss', 'has_inlier_neighbors', 'is_inlier_patch', 'robust_mask')]
     assert 0.05 < want[4] < 0.999, want            # the mask must actually select
     np.testing.assert_allclose(st[10:15], want, rtol=2e-4, atol=1e-6)
@@ -211,6 +195,32 @@ def test_model_forward_loss_and_gradients_vs_oracle(variant, monkeypatch):
       assert sc > 0, (name, k)
       err = float((mine - ref).abs().max()) / sc
       assert err < 5e-3, f'{variant} grad {name}/{k}: rel err {err:.2e} (max |g| {sc:.2e})'
+
+
+@pytest.mark.parametrize('variant', ['base', 'contract_piecewise_charb', 'withmask', 'robustnerf', 'wide_prop', 'prop_gemm', 'softplus',
+                                     'same_proposal_network', 'softplus_same_net_gemm_field'] + sorted(_NF_EXTRA))
+def test_model_forward_loss_and_gradients_vs_oracle(variant, monkeypatch):
+  from nerf_hugs_amd.nerfacto.model import NerfactoConfig, NerfactoModel
+  from oracle import nerfacto_ref as NF
+  kw = dict(SMALL)
+  if variant == 'contract_piecewise_charb':
+    kw.update(enable_scene_contraction=True, proposal_initial_sampler='piecewise', rgb_loss_type='charb', opaque_background=False)
+  if variant == 'withmask':
+    kw.update(transient_type='withmask', withmask_transient_weight=0.25)
+  if variant == 'robustnerf':
+    kw.update(transient_type='robustnerf', robustnerf_inlier_quantile=0.7, rgb_loss_type='charb')
+  if variant == 'wide_prop':      # 18 input features, 24 hidden units: the fused proposal kernels' 32-wide instantiation
+    kw.update(proposal_net_args_list=[dict(hidden_dim=24, log2_hashmap_size=9, num_levels=9, max_res=48)])
+  if variant == 'prop_gemm':      # the padded-GEMM fallback of the proposal nets (taken for nets wider than 32 -> 64 -> 1)
+    monkeypatch.setenv('HUGS_NF_FUSED_PROP', '0')
+  # round 5: nerfacto.py:36 density_activation = 'softplus' (F.softplus(raw - 1) in both field types) and :66 use_same_proposal_network
+  # (ONE proposal network evaluates both proposal levels: its gradients are the sum of the two levels')
+  if variant.startswith('softplus'):
+    kw.update(density_activation='softplus')
+  if 'same' in variant:
+    kw.update(use_same_proposal_network=True)
+  kw.update(_NF_EXTRA.get(variant, {}))
+  _check_nerfacto_vs_oracle(kw, variant)
 
 
 @pytest.mark.parametrize('tag', ['a', 'b', 'c', 'd'])
