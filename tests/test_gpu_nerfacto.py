@@ -194,7 +194,8 @@ def _check_nerfacto_vs_oracle(kw, variant=''):
       sc = float(ref.abs().max())
       assert sc > 0, (name, k)
       err = float((mine - ref).abs().max()) / sc
-      assert err < 5e-3, f'{variant} grad {name}/{k}: rel err {err:.2e} (max |g| {sc:.2e})'
+      n_off = int(((mine - ref).abs() > 5e-3 * sc).sum())
+      assert err < 5e-3, f'{variant} grad {name}/{k}: rel err {err:.2e} (max |g| {sc:.2e}; {n_off} of {ref.numel()} entries off, sum of the differences {float((mine - ref).sum()) / sc:.1e} of it)'
 
 
 @pytest.mark.parametrize('variant', ['base', 'contract_piecewise_charb', 'withmask', 'robustnerf', 'wide_prop', 'prop_gemm', 'softplus',
