@@ -386,6 +386,13 @@ long long hugs_gemm_nt_bits_bytes(int M, int N);
 int hugs_gemm_nt_bits(int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,
                       const void* Bt, int ldb, const float* bias, int relu, const float* r1_row, const float* r1_col,
                       void* out, int ldc, uint32_t* bits_out, const uint32_t* bits_in, void* stream);
+/* The trunk of an MLP (models.py:432-461: for i < net_depth: x = relu(Dense(x)); skip concat at i % skip_layer == 0) as ONE launch:
+ * nl layers  out_l[M, N] = relu([A1_l | A2_l] Bt_l^T + bias_l)  with their 1-bit relu masks, layer l + 1 reading layer l's output
+ * (the caller names it as that layer's A1).  tab: 12 HOST words per layer {A1, A2, Bt, bias, out, bits (device pointers), lda1, lda2,
+ * ldb, K1, K2, 0}; flags: nl * M / 256 device words of scratch (zeroed by the call, on the stream).  Results are bit-identical to nl
+ * hugs_gemm_nt_bits calls.  bf16 (dtype 1); M, N multiples of 256; nl * N <= 8192; every K a multiple of 64 and >= 128; every
+ * leading dimension a multiple of 512; a whole number >= 4 of 256 x 256 tiles per CU.  Returns -3 when the shape does not qualify. */
+int hugs_gemm_nt_chain(int dtype, int M, int N, int nl, const unsigned long long* tab, unsigned* flags, void* stream);
 
 /* ---- nerfacto path (reference /root/reference/nerfacto).  One wavefront per ray in the per-ray
  * kernels (<= 1024 bins / samples).  Matrices [M, ld] row-major in `dtype` (0 fp32, 1 bf16).

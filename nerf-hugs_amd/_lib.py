@@ -16,6 +16,7 @@ _PROTOS = {
     'hugs_dir_enc_fwd': 'iipps',
     'hugs_gemm_nt': 'iiiii' 'pipipi' 'pp' 'iii' 'pi' 'pp' 'pi' 's',
     'hugs_gemm_nt_bits': 'iiiii' 'pipipi' 'p' 'i' 'pp' 'pi' 'pp' 's',
+    'hugs_gemm_nt_chain': 'iiiipps',
     'hugs_gemm_tn': 'iiiiipipippps',
     'hugs_gemm_tn_batch': 'iipips',
     'hugs_gemm_tn_batch_nsplit': 'ip',
@@ -131,6 +132,8 @@ def _raw_stream():
 PROFILE = None
 _PROFILED = {'hugs_gemm_nt': lambda a: ('nt', a[1], a[2], a[3] + a[4], 'mask' if a[16] is not None else ('relu' if a[15] else 'plain')),
              'hugs_gemm_nt_bits': lambda a: ('nt', a[1], a[2], a[3] + a[4], 'mask' if a[18] is not None else ('relu' if a[12] else 'plain')),
+             # all trunk layers of an MLP in ONE launch: (kind, rows, width, layers, 'relu')
+             'hugs_gemm_nt_chain': lambda a: ('ntc', a[1], a[2], a[3], 'relu'),
              'hugs_gemm_tn': lambda a: ('tn', a[1], a[2], a[3], f'split{a[4]}'),
              # nerfacto (bench.py --config cfg5): (kind, samples, levels, features) / (kind, samples, in_dim, hidden)
              'hugs_hashgrid_fwd': lambda a: ('hg_fwd', a[0], a[1], a[2]),

@@ -263,7 +263,7 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {      // one 
   const bf16x2_t h = __builtin_convertvector(f, bf16x2_t);
   return *(const uint32_t*)&h;
 }
-template <int EPI, bool BIAS_IN_ACC = false, bool FRESH_LANE = false, int MASK_AHEAD = 2>
+template <int EPI, bool BIAS_IN_ACC = false, int FRESH_LANE = 0, int MASK_AHEAD = 2>
 __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const GemmEpi& E, int m0, int n0, int wm, int wn,
                                                    int r16, int kb, const float* lds_bias, const float* lds_r1col) {
     // ---- epilogue straight from registers: bias / rank-1 / relu, v_cvt_pk_bf16_f32, one v_permlane16_swap pair
@@ -281,7 +281,9 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
     // (FRESH_LANE: the five-slot kernel has no register left to carry a per-lane 64-bit address across its main loop -- the lane
     // index is re-derived from an opaque copy of the thread index here, so that nothing of it is live before the epilogue)
     int lane_ = threadIdx.x & 63;
-    if (FRESH_LANE) { int t_ = threadIdx.x; asm volatile("" : "+v"(t_)); lane_ = t_ & 63; }
+    if (FRESH_LANE == 1) { int t_ = threadIdx.x; asm volatile("" : "+v"(t_)); lane_ = t_ & 63; }
+    // (2, the layer-chained kernel: the lane index from mbcnt inside a volatile asm -- not even threadIdx's register stays live)
+    if (FRESH_LANE == 2) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_));
     // (the bf16-mask specialisations' load / store geometry -- ccol, srow below -- is loop invariant in the persistent kernel and was
     //  hoisted out of its tile loop into scratch: derive it from the opaque lane index there)
     if (FRESH_LANE && EPI >= 0 && (EPI & EPI_MASK)) { r16 = lane_ & 15; kb = lane_ >> 4; }
@@ -913,6 +915,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
 #undef GP_Q
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dead stages past the last tile must land before the LDS is released
 }
+
+#include "hugs_gemm_chain.inc"
 
 // ------------------------------------------------------------------------------------------------
 // bf16 TN: slab[split][Kc, N] (fp32) = sum over this split's rows of X[m,Kc]^T G[m,N]
@@ -1585,6 +1589,42 @@ extern "C" int hugs_gemm_nt_bits(int dtype, int M, int N, int K1, int K2, const 
   HUGS_REQUIRE(!bits_out || relu, -3, "hugs_gemm_nt_bits: bits_out needs a relu epilogue");
   return gemm_nt_impl(0, dtype, M, N, K1, K2, A1, lda1, A2, lda2, Bt, ldb, bias, nullptr, 1, 0, relu, bits_in ? (const void*)1 : nullptr, 0,
                       r1_row, r1_col, out, ldc, bits_out, bits_in, stream);
+}
+
+// One launch for all trunk layers of an MLP (k_gemm_nt_bf16_chain, hugs_gemm_chain.inc): nl layers of [M, N] = relu(A_l W_l^T + b_l) with
+// the 1-bit relu masks, layer l+1 reading layer l's output.  tab: 12 host words per layer {A1, A2, Bt, bias, out, bits, lda1, lda2, ldb,
+// K1, K2, 0}; flags: nl * M / 256 device words (zeroed here, on the stream).  bf16 only; M, N multiples of 256, N <= 1024 * 8 / nl,
+// every K a multiple of 64 and >= 128, every leading dimension a multiple of 512, at least four tiles per CU.  Returns -3 when the shape does not qualify (the caller then
+// launches layer by layer).
+extern "C" int hugs_gemm_nt_chain(int dtype, int M, int N, int nl, const unsigned long long* tab, unsigned* flags, void* stream) {
+  HUGS_REQUIRE(dtype == 1 && nl >= 2 && nl <= HUGS_NT_CHAIN_MAX && M % 256 == 0 && N % 256 == 0 && (long long)nl * N * 4 <= 32768, -3,
+               "hugs_gemm_nt_chain: bf16, 2..%d layers, M=%d N=%d multiples of 256, nl * N <= 8192", HUGS_NT_CHAIN_MAX, M, N);
+  int dev = 0, ncu = 0;
+  HUGS_REQUIRE(hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess,
+               -100, "hugs_gemm_nt_chain: device query");
+  ncu &= ~7;
+  const int ntiles = (M / 256) * (N / 256);
+  HUGS_REQUIRE(ncu >= 8 && ntiles % ncu == 0 && ntiles / ncu >= 4 && (ntiles / 8) % (N / 256) == 0 && (ncu / 8) % (N / 256) == 0, -3,
+               "hugs_gemm_nt_chain: %d tiles on %d CUs (needs a whole number >= 4 of tiles per CU, whole row bands per XCD and round)", ntiles, ncu);
+  NtChainTab T;
+  T.nl = nl; T.pad_ = 0; T.flags = flags;
+  for (int l = 0; l < nl; ++l) {
+    const unsigned long long* w = tab + 12 * l;
+    NtChainLayer& L = T.L[l];
+    L.A1 = (const uint16_t*)w[0]; L.A2 = (const uint16_t*)w[1]; L.Bt = (const uint16_t*)w[2]; L.bias = (const float*)w[3];
+    L.out = (void*)w[4]; L.bits = (uint32_t*)w[5];
+    L.lda1 = (int)w[6]; L.lda2 = (int)w[7]; L.ldb = (int)w[8]; L.K1 = (int)w[9]; L.K2 = (int)w[10]; L.pad_ = 0;
+    HUGS_REQUIRE(L.A1 && L.Bt && L.bias && L.out && L.bits && L.K1 > 0 && L.K1 % 32 == 0 && L.K2 % 32 == 0 && (L.K1 + L.K2) % 64 == 0 &&
+                 L.K1 + L.K2 >= 128 && (L.K2 == 0 || L.A2) && L.lda1 % 512 == 0 && L.lda2 % 512 == 0 && L.ldb % 512 == 0 && L.lda1 > 0 && L.lda2 > 0 &&
+                 (long long)127 * 1024 * (L.ldb >> 9) + 64 < (1ll << 24) * 1 && L.lda1 <= 8192 && L.lda2 <= 8192 && L.ldb <= 8192, -3,
+                 "hugs_gemm_nt_chain: layer %d operands / K = %d + %d / leading dimensions %d %d %d (multiples of 512, <= 8192)", l, L.K1, L.K2,
+                 L.lda1, L.lda2, L.ldb);
+  }
+  HUGS_REQUIRE(hipMemsetAsync(flags, 0, (size_t)nl * (M / 256) * sizeof(unsigned), (hipStream_t)stream) == hipSuccess, -100,
+               "hugs_gemm_nt_chain: hipMemsetAsync");
+  hipLaunchKernelGGL(k_gemm_nt_bf16_chain, dim3(ncu), dim3(512), 0, (hipStream_t)stream, M, N, T, ntiles);
+  HUGS_CHECK_LAUNCH("hugs_gemm_nt_chain");
+  return 0;
 }
 #endif  // !HUGS_GEMM_F16
 

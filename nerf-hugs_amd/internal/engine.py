@@ -27,6 +27,9 @@ _RGB_REDUCE_SIDE = __import__('os').environ.get('HUGS_RGB_REDUCE_SIDE', '1') == 
 _SIDE_LATE = __import__('os').environ.get('HUGS_SIDE_LATE', '0') == '1'      # A/B: side-stream work released behind the G_last GEMM
 _TN_ITEM = np.dtype([('X', np.uint64), ('G', np.uint64), ('dW', np.uint64), ('db', np.uint64), ('ldx', np.int32), ('ldg', np.int32),
                      ('Mrows', np.int32), ('Kc', np.int32), ('N', np.int32), ('reserved', np.int32)])      # include/hugs.h HugsTnItem
+# HUGS_NT_CHAIN=0|1: the trunk layers of a wide MLP (bf16, 1-bit relu masks, whole 256-row bands per CU round) as ONE persistent launch that
+# walks layer -> tile (hugs_gemm_nt_chain) instead of one launch per layer; outputs bit-identical to the per-layer launches
+_NT_CHAIN = __import__('os').environ.get('HUGS_NT_CHAIN', '0') != '0'
 _CHUNK_BYTES = int(float(__import__('os').environ.get('HUGS_FWD_CHUNK_MB', '1e9')) * 1e6)   # forward row-chunk size (A/B knob)
 
 
@@ -425,7 +428,10 @@ class Engine:
     fuse_tail = (dt == 1 and nchunk == 1 and W == 256 and spec.net_width == 256 and spec.net_depth >= 2 and M % 256 == 0 and
                  spec.net_depth - 1 <= int(_lib.lib().cdll.hugs_mlp256_tail_max_layers()) and (M <= _MLP_FUSE_ROWS or chain3) and
                  not any(l['concat'] for l in spec.layers[1:spec.net_depth]))
-    for c in range(nchunk):
+    chained = False
+    if _NT_CHAIN and dt == 1 and nchunk == 1 and not fuse_tail and spec.net_depth >= 2 and all(b is not None for b in bits):
+      chained = self._trunk_chain(spec, theta, tag, M, W, X0, Ys, bits)
+    for c in range(0 if chained else nchunk):
       rows = slice(c * mc, (c + 1) * mc)
       x = X0[rows]
       for i in range(1 if fuse_tail else spec.net_depth):
@@ -672,6 +678,33 @@ class Engine:
       levels.append(out)
       sdist, weights = sd, w
     return levels
+
+  def _trunk_chain(self, spec, theta, tag, M, W, X0, Ys, bits):
+    """All trunk layers of `spec` in one launch (hugs_gemm_nt_chain; csrc/hugs_gemm_chain.inc).  False when the shape does not
+    qualify (the caller then launches layer by layer): whole 256 x 256 tiles, a whole number >= 4 of tiles per CU, whole row bands
+    per XCD round, leading dimensions in multiples of 512, the layers' biases within 32 KiB of LDS."""
+    depth = spec.net_depth
+    ncu = torch.cuda.get_device_properties(self.device).multi_processor_count & ~7
+    ntiles = (M // 256) * (W // 256)
+    lds_ = [spec.Fp, W] + [spec.layers[i]['kpad'] for i in range(depth)]
+    if (M % 256 or W % 256 or depth > 8 or depth * W * 4 > 32768 or ncu < 8 or ntiles % ncu or ntiles // ncu < 4 or
+        (ntiles // 8) % (W // 256) or (ncu // 8) % (W // 256) or any(v % 512 for v in lds_)):
+      return False
+    key = ('nt_chain', tag, theta.data_ptr(), M)
+    ent = self.ws.bufs.get(key)
+    if ent is None:
+      tab = np.zeros((depth, 12), np.uint64)
+      for i in range(depth):
+        l = spec.layers[i]
+        a1 = X0 if i == 0 else Ys[i - 1]
+        k1 = spec.Fp if i == 0 else W
+        tab[i] = [a1.data_ptr(), X0.data_ptr(), self.wt[(spec.name, l['name'], 'kernel')].data_ptr(),
+                  self.layout.view(theta, (spec.name, l['name'], 'bias'), padded=True).data_ptr(), Ys[i].data_ptr(), bits[i].data_ptr(),
+                  k1, spec.Fp, l['kpad'], k1, spec.Fp if l['concat'] else 0, 0]
+        assert l['kpad'] == k1 + (spec.Fp if l['concat'] else 0)
+      ent = self.ws.bufs[key] = (tab, self.ws.get(tag + '/chain_flags', (depth * (M // 256),), torch.int32))
+    _lib.call('hugs_gemm_nt_chain', self.dt, M, W, depth, ent[0].ctypes.data, ent[1])
+    return True
 
   def anneal_factor(self, train_frac):
     """models.py:185-190: the annealing exponent of the resampling logits at this point of training."""
