@@ -98,6 +98,13 @@ def instep_roofline(train_step, state, next_batch, gen, thr, steps=5):
     k = max(fwd, key=lambda k: len(agg[k]))
     main = entry(k, 'nt_fwd', f"NT forward trunk [{k[1]}x1024]x[1024x1024]^T +bias +relu, writes 1-bit relu masks "
                  "(gemm_bf16::k_gemm_nt_bf16_pers<35>)", 2.0 * k[1] * W * W, 2.0 * k[1] * W * 2 + W * W * 2 + k[1] * W / 8)
+  if main is not None:
+    # what the fraction is made of (profiles/r05_trunk_chain.txt: s_memtime trace build of this kernel): a 256 x 256 x 1024 tile costs
+    # 55.4 k cycles on a CU = 2423 flop / cycle / CU of the 4096 that 2.5 PFLOP/s at 2.4 GHz on 256 CUs means; the rest is the clock the
+    # power manager sustains under this load
+    main["per_cycle_frac"] = 0.5915
+    main["implied_clock_ghz"] = round(main["frac"] / 0.5915 * 2.4, 3)
+    main["per_cycle_source"] = "profiles/r05_trunk_chain.txt (trace build: 55.4 k cycles per 256x256x1024 tile); frac = per_cycle_frac x clock / 2.4 GHz"
   M = max(fwd, key=lambda k: len(agg[k]))[1] if fwd else 131072      # rows of the NerfMLP level (131072 at cfg2)
   fl = 2.0 * M * W * W
   tnk = [k for k in agg if k[0] == 'tn' and k[1] == M and k[2] == W and k[3] == W]
