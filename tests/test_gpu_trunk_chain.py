@@ -9,20 +9,25 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_chained_trunk_is_bit_identical_to_the_per_layer_launches():
+@pytest.mark.parametrize('shape', ['cfg2', 'ref360'])
+def test_chained_trunk_is_bit_identical_to_the_per_layer_launches(shape):
+  """cfg2: 1024 rays x 128 samples (8 tiles per CU and layer); ref360: the reference-default shape, 16 384 rays x 32 samples at the third
+  level (32 tiles per CU and layer), contraction + reciprocal ray distance."""
   import bench
   from nerf_hugs_amd.internal import configs, train_utils, engine as E, models as M
   from tests import hugs_testlib as H
-  configs.clear_config(); configs.parse_config_files_and_bindings(None, bench.GIN)
+  configs.clear_config(); configs.parse_config_files_and_bindings(None, bench.GIN if shape == 'cfg2' else bench.GIN_REF360)
   config = configs.make_config()
   model, state, _, _, _ = train_utils.setup_model(config, 0, compute_dtype='bf16')
-  batch = H.synth_rays(4, 16, 7)
+  n_rays = 1024 if shape == 'cfg2' else 16384
+  batch = H.synth_rays(n_rays // 256, 16, 7) if shape == 'cfg2' else H.synth_rays(n_rays // 256, 16, 7, near=0.2, far=1e6)
   eng = model.engine('cuda')
   rays = M.rays_to_dict(batch.rays, 'cuda')
   gen = torch.Generator(device='cuda').manual_seed(1)
-  u01 = [torch.rand(1024, generator=gen, device='cuda') for _ in range(2)]
+  u01 = [torch.rand(n_rays, generator=gen, device='cuda') for _ in range(model.num_levels)]
+  tag = f'NerfMLP_0/L{model.num_levels - 1}/'
   pick = lambda: {k[0]: t for k, t in eng.ws.bufs.items()
-                  if torch.is_tensor(t) and isinstance(k[0], str) and k[0].startswith('NerfMLP_0/L1/') and ('/Y' in k[0] or 'bits' in k[0])}
+                  if torch.is_tensor(t) and isinstance(k[0], str) and k[0].startswith(tag) and ('/Y' in k[0] or 'bits' in k[0])}
   out = {}
   old = E._NT_CHAIN
   try:
