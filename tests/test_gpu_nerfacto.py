@@ -138,7 +138,7 @@ _NF_EXTRA = {
 }
 
 
-def _check_nerfacto_vs_oracle(kw, variant=''):
+def _check_nerfacto_vs_oracle(kw, variant='', ray_seed=5):
   """One train_step of NerfactoModel (fp32) against oracle.nerfacto_ref on the same rays / draws / parameters: every level's bins and
   weights, the colour, every loss term and statistic, every parameter's gradient.  kw: NerfactoConfig / NF.Cfg fields.  (Also driven by
   scratch/nerfacto_fuzz2.py with random combinations of the options.)"""
@@ -155,7 +155,7 @@ def _check_nerfacto_vs_oracle(kw, variant=''):
   model = NerfactoModel(NerfactoConfig(**kw), compute_dtype='fp32')
   model.load_params(P)
   N = 256 if robust else 128       # robustnerf: one whole 16x16 patch
-  b, g = _rays(N, 5)
+  b, g = _rays(N, ray_seed)
   thr0 = 0.05                                        # current inlier threshold (extra_infos of the previous step)
   if withmask:
     b['static_mask'] = (torch.rand(N, generator=g) < 0.7).float() * torch.rand(N, generator=g)
