@@ -174,17 +174,18 @@ def cpu_baseline(seed):
           "sample": f"{best[2]} full train steps of 64 rays x (64+128) samples, oracle/torch_ref.py fp32, {best[1]} threads"}
 
 
-def eval_psnr_vs_oracle(model, state, batch, dtype):
+def eval_psnr_vs_oracle(model, state, batch, dtype, flat=None):
   """'eval PSNR' leg of the metric (no dataset ships): PSNR of the HIP render (deterministic eval forward, the
   benchmarked compute dtype, trained weights of this run) against the oracle's fp32 CPU render of the same 256
   rays with the same weights."""
   from oracle import torch_ref as R
   from nerf_hugs_amd.internal import models
+  flat = state.flat if flat is None else flat                 # (flat: another parameter buffer of the same model, e.g. the initial weights)
   rays = batch.rays.map(lambda x: x[:1])                      # one 16 x 16 patch
-  rend, _ = model.apply(state.flat, None, rays, 1.0, False)
+  rend, _ = model.apply(flat, None, rays, 1.0, False)
   hip = rend[-1]['rgb'].reshape(-1, 3).float().cpu()
   cfg = R.kubric_cfg(num_levels=2, num_prop_samples=64, num_nerf_samples=128)
-  tree = model.variables(state.flat)['params']
+  tree = model.variables(flat)['params']
   P = {m: {k: {kk: vv.detach().float().cpu() for kk, vv in v.items()} for k, v in sub.items()} for m, sub in tree.items()}
   r = rays.flat()
   orays = dict(origins=r.origins.cpu(), directions=r.directions.cpu(), viewdirs=r.viewdirs.cpu(), radii=r.radii.cpu(),
@@ -460,6 +461,7 @@ def main():
     P = 8
   config = configs.make_config(batch_size=rays_per_gpu * world)
   model, state, _, train_step, _ = train_utils.setup_model(config, 20200823, compute_dtype=args.dtype, device=device)
+  theta_init = state.flat.clone()      # (for the eval-PSNR leg: the render of a network that has structure, see below)
   def make_batch(i):
     batch = synth_batch(rays_per_gpu // (P * P), P, 1000 + rank + 7919 * i, device)
     if args.config == 'ref360':     # 360.gin: near 0.2, far 1e6 (contracted space)
@@ -551,9 +553,13 @@ def main():
     # after the timed region: a few more steps with the GEMM launches bracketed by HIP events (every rank runs them:
     # the steps contain the gradient all-reduce; rank 0 reports)
     roof, roof_others, roof_shapes, state, gen = instep_roofline(train_step, state, next_batch, gen, thr)
-  eval_psnr = None
+  eval_psnr = eval_psnr_init = None
   if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 'cfg2' and args.rays_per_gpu is None:
     eval_psnr = eval_psnr_vs_oracle(model, state, batch, args.dtype)
+    # On a pool of fresh random-colour batches the trained network converges to the mean colour (loss -> 1/12): its render is a constant
+    # that both precisions produce exactly, and the number above says nothing about bf16.  The same comparison at the INITIAL weights
+    # (he_uniform trunk: densities and colours with structure) is the informative one.
+    eval_psnr_init = eval_psnr_vs_oracle(model, state, batch, args.dtype, flat=theta_init)
   if rank == 0:
     rps = rays_per_gpu * world * args.steps / dt
     line = {
@@ -577,7 +583,7 @@ def main():
                    "rays_per_gpu": rays_per_gpu, "global_batch": rays_per_gpu * world,
                    "parallelism": f"dp{world}", "params": model.layout.num_params()},
         "train_psnr_last": round(psnr, 3), "loss_last": round(loss, 6),
-        "eval_psnr_vs_cpu_fp32_db": eval_psnr,
+        "eval_psnr_vs_cpu_fp32_db": eval_psnr, "eval_psnr_vs_cpu_fp32_init_weights_db": eval_psnr_init,
         "step_mfma_frac": (round(rps / world * (FLOP_TRAIN_PER_RAY_REF360 if args.config == 'ref360' else FLOP_TRAIN_PER_RAY) /
                                  (PEAK_BF16 if args.dtype == 'bf16' else 157.3e12), 4) if args.config in ('cfg2', 'ref360') else None),
     }
