@@ -217,7 +217,9 @@ class _Lib:
       msg = self.cdll.hugs_last_error().decode()
       if rc == -2:
         raise ValueError(msg)       # the reference raises ValueError for these argument errors
-      raise HugsError(f'{name} failed (rc={rc}): {msg}')
+      err = HugsError(f'{name} failed (rc={rc}): {msg}')
+      err.rc = rc
+      raise err
 
 
 _LIB = None

@@ -703,7 +703,12 @@ class Engine:
                   k1, spec.Fp, l['kpad'], k1, spec.Fp if l['concat'] else 0, 0]
         assert l['kpad'] == k1 + (spec.Fp if l['concat'] else 0)
       ent = self.ws.bufs[key] = (tab, self.ws.get(tag + '/chain_flags', (depth * (M // 256),), torch.int32))
-    _lib.call('hugs_gemm_nt_chain', self.dt, M, W, depth, ent[0].ctypes.data, ent[1])
+    try:
+      _lib.call('hugs_gemm_nt_chain', self.dt, M, W, depth, ent[0].ctypes.data, ent[1])
+    except _lib.HugsError as e:      # rc -3: the library's own qualification rules refused a shape the check above let through
+      if getattr(e, 'rc', 0) != -3:  # (nothing was launched: the caller falls back to the per-layer launches)
+        raise
+      return False
     return True
 
   def anneal_factor(self, train_frac):
@@ -980,7 +985,9 @@ class Engine:
       cuts = [depth // 2, 0] if (two and depth >= 2) else [0]
       Gs = [Ga, Gb] + [ws.get(f'{tag}/G{k}', (M, W), self.tdt) for k in range(2, depth)]
       if fused_bwd:
-        key = ('mlp_tail_bwd', tag, theta.data_ptr(), M)
+        # (the backward's `tag` carries no level, the mask buffers do: two proposal levels of equal M must not share a table --
+        #  level 0 was masked with level 1's relu bits.  Keyed on the addresses the table is made of.)
+        key = ('mlp_tail_bwd', tag, theta.data_ptr(), M, d_raw.data_ptr()) + tuple(b.data_ptr() for b in bits_all)
         tab = ws.bufs.get(key)
         if tab is None:      # host arrays of device pointers (a function of buffer addresses only)
           ptr = lambda ts: np.ascontiguousarray([t.data_ptr() for t in ts], np.uint64)

@@ -336,13 +336,15 @@ def create_train_step(model, config, is_finetune=False):
     # writes it there.  A caller that hands the previous step's key straight back (the train loop) finds it in ent['key'] already.
     key_new = torch.empty_like(ent['key']) if ent['key'] is not None else None
     if ent['key'] is not None and rng.data_ptr() != ent['key'].data_ptr() and not _handed(ent, rng):
-      srcs.append(rng.contiguous()); dsts.append(ent['key'])
+      # (the staging launch dereferences raw addresses: a key restored on the CPU or living on another device goes through torch first)
+      srcs.append((rng if rng.device == ent['key'].device else rng.to(ent['key'].device)).contiguous()); dsts.append(ent['key'])
     # ONE launch: every input copy (all of them 4-byte element types) + the step's four scalars + the two addresses the step's
     # last launch publishes to (round 5; it was two _foreach_copy_ launches, a key copy and hugs_set_floats: ~40 us of launch
     # latency in front of a 1.3 ms step at 128 rays)
     npk = STAT_TAIL + len(layout.leaves) * 6 + 16
     host = ent['host_pool'].pop() if ent['host_pool'] else torch.empty((npk,), dtype=torch.float32, pin_memory=True)
-    one = len(srcs) <= 16 and all(s_.element_size() == 4 and s_.is_contiguous() and s_.numel() == d_.numel() for s_, d_ in zip(srcs, dsts))
+    one = len(srcs) <= 16 and all(s_.element_size() == 4 and s_.is_contiguous() and s_.numel() == d_.numel() and s_.device == d_.device
+                                  for s_, d_ in zip(srcs, dsts))
     if not one:
       for s_, d_ in zip(srcs, dsts):
         d_.copy_(s_)
@@ -476,9 +478,12 @@ def create_train_step(model, config, is_finetune=False):
     tail = grad[layout.size:]
     # the stat tail is zeroed ONCE per step function: every slot a step uses is overwritten (=, never +=) by its loss kernels on
     # every step, the slots it does not use stay zero (their all-reduce sums zeros) -- one launch less per step
-    if cache.get('tail_zeroed') != tail.data_ptr():
+    # (the owner token lives on the shared workspace, not in this function's cache: two step functions used alternately on one engine
+    #  -- train / finetune, two loss types -- must not leave each other's slots standing, which a SUM all-reduce would multiply by the
+    #  world size on every step)
+    if ws.bufs.get('tail_owner') != (id(cache), tail.data_ptr()):
       tail.zero_()
-      cache['tail_zeroed'] = tail.data_ptr()
+      ws.bufs['tail_owner'] = (id(cache), tail.data_ptr())
     # ---- losses -------------------------------------------------------------------------------------
     if 'coef' not in cache:
       cache['coef'] = torch.tensor([config.data_coarse_loss_mult] * (L - 1) + [config.data_loss_mult],

@@ -33,6 +33,9 @@ def _hip_masks_samples_feats(model, levels, N):
   return masks, ov, ofe
 
 
+_LAST = {}
+
+
 def _step_and_replay(gin, compute_dtype, n_patch=1, P=8, near=0.1, far=1.2, quant=False, inlier=None, replay_feats=True):
   from tests import hugs_testlib as H
   from oracle import torch_ref as R
@@ -43,6 +46,7 @@ def _step_and_replay(gin, compute_dtype, n_patch=1, P=8, near=0.1, far=1.2, quan
   gen = torch.Generator(device='cuda').manual_seed(11)
   u01 = [torch.rand(N, generator=gen, device='cuda') for _ in range(L)]
   eng = model.engine('cuda')
+  _LAST['engine'] = eng
   eng.refresh_weights(state.flat)
   levels = eng.forward(state.flat, M.rays_to_dict(batch.rays, 'cuda'), 0.37, u01, False)
   thr = None if inlier is None else np.full((L, 1), inlier, np.float32)
@@ -193,3 +197,31 @@ def test_three_step_training_trajectory_vs_oracle():
     frac_bad = float(((d_hip - d_orc).abs() > 2e-2 * sc).double().mean())
     assert frac_bad < 1e-3 or d_orc.numel() <= 8, (name, frac_bad)
     worst = max(worst, frac_bad)
+
+
+def test_bf16_three_levels_two_fused_propmlp_backwards_keep_their_own_relu_masks():
+  """with the reference-default three levels both proposal levels run the fused PropMLP backward
+  (hugs_mlp256_tail_bwd: bf16, 4 x 256, M >= 2048, equal M).  Its device-pointer table was cached under a key without the level,
+  so level 0 ran with level 1's mask-bit buffers.  Here: 3 levels, PropMLP 4 x 256, 64 rays x 64 samples = 4096 rows per proposal
+  level; (a) every PropMLP leaf against the bf16-rounded oracle replaying the HIP step's own masks, (b) against the per-layer
+  backward (HUGS_MLPFUSE_CHAIN3 off), which never used the table."""
+  from nerf_hugs_amd.internal import engine as E
+  gin = [g for g in SMALL if 'net_width' not in g and not g.startswith('Model.num_')] + [
+      "PropMLP.net_width = 256", "NerfMLP.net_width = 256", "Model.num_levels = 3", "Model.num_prop_samples = 64",
+      "Model.num_nerf_samples = 32"]
+  errs, stats, ostats = _step_and_replay(list(gin), 'bf16', quant=True)
+  assert abs(float(stats['loss']) / float(ostats['loss']) - 1) < 2e-3
+  tabs = [k for k in _LAST['engine'].ws.bufs if k[0] == 'mlp_tail_bwd']
+  assert len(tabs) == 2, tabs                                   # both proposal levels took the fused backward, each with its own table
+  prop = {k: v for k, v in errs.items() if k.startswith('PropMLP') and v[2] >= 1024}
+  assert len(prop) >= 4
+  for name, (emax, el2, n) in prop.items():
+    assert el2 < 2e-2, f'{name}: relative L2 error {el2:.3e} (max {emax:.2e})'
+  old = E._MLP_CHAIN3
+  try:
+    E._MLP_CHAIN3 = False
+    errs0, _, _ = _step_and_replay(list(gin), 'bf16', quant=True)
+  finally:
+    E._MLP_CHAIN3 = old
+  for name in prop:
+    assert abs(errs[name][1] - errs0[name][1]) < 1e-2, (name, errs[name], errs0[name])
