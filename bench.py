@@ -65,10 +65,19 @@ def instep_roofline(train_step, state, next_batch, gen, thr, steps=5):
   MI355X_MICROARCH.md HBM section; `traffic_source` names the file and the kernel's duration under the profiler next to
   the in-step one), null when that file is absent."""
   from nerf_hugs_amd import _lib
-  _lib.PROFILE = []
-  for _ in range(steps):
-    state, stats, gen = train_step(gen, state, next_batch(), 0.5, thr)
+  # the persistent NT kernel's own cycle account (csrc/hugs_gemm.hip g_nt_cycles; include/hugs.h hugs_debug_set_nt_cycles): s_memtime
+  # cycles and tiles per (epilogue specialisation, K class), summed over every workgroup of every launch of these steps
+  cyc = torch.zeros(64 * 4 * 2, dtype=torch.int64, device='cuda')
   torch.cuda.synchronize()
+  _lib.call('hugs_debug_set_nt_cycles', cyc.data_ptr())
+  _lib.PROFILE = []
+  try:
+    for _ in range(steps):
+      state, stats, gen = train_step(gen, state, next_batch(), 0.5, thr)
+    torch.cuda.synchronize()
+  finally:
+    _lib.call('hugs_debug_set_nt_cycles', 0)
+  cyc = cyc.cpu().numpy().reshape(64, 4, 2)
   recs, _lib.PROFILE = _lib.PROFILE, None
   agg = {}
   for name, key, e0, e1 in recs:
@@ -98,13 +107,20 @@ def instep_roofline(train_step, state, next_batch, gen, thr, steps=5):
     k = max(fwd, key=lambda k: len(agg[k]))
     main = entry(k, 'nt_fwd', f"NT forward trunk [{k[1]}x1024]x[1024x1024]^T +bias +relu, writes 1-bit relu masks "
                  "(gemm_bf16::k_gemm_nt_bf16_pers<35>)", 2.0 * k[1] * W * W, 2.0 * k[1] * W * 2 + W * W * 2 + k[1] * W / 8)
-  if main is not None:
-    # what the fraction is made of (profiles/r05_trunk_chain.txt: s_memtime trace build of this kernel): a 256 x 256 x 1024 tile costs
-    # 55.4 k cycles on a CU = 2423 flop / cycle / CU of the 4096 that 2.5 PFLOP/s at 2.4 GHz on 256 CUs means; the rest is the clock the
-    # power manager sustains under this load
-    main["per_cycle_frac"] = 0.5915
-    main["implied_clock_ghz"] = round(main["frac"] / 0.5915 * 2.4, 3)
-    main["per_cycle_source"] = "profiles/r05_trunk_chain.txt (trace build: 55.4 k cycles per 256x256x1024 tile); frac = per_cycle_frac x clock / 2.4 GHz"
+  def per_cycle(ent, epi, K):
+    # what the fraction is made of, MEASURED by these very launches: cycles per 256 x 256 x K tile on a CU against the 4096 flop / cycle / CU
+    # that 2.5 PFLOP/s at 2.4 GHz on 256 CUs means (workgroup start to its last stage's retirement, prologue included); the rest is the
+    # clock the power manager sustains under this load: frac = per_cycle_frac x clock / 2.4 GHz
+    c, t = cyc[epi, {512: 1, 1024: 2}.get(K, 3)]
+    if ent is None or t <= 0:
+      return
+    cpt = float(c) / float(t)
+    ent["cycles_per_tile"] = round(cpt, 0)
+    ent["per_cycle_frac"] = round(2.0 * 256 * 256 * K / cpt / 4096.0, 4)
+    ent["implied_clock_ghz"] = round(ent["frac"] / ent["per_cycle_frac"] * 2.4, 3)
+    ent["per_cycle_source"] = (f"measured in these {steps} steps: s_memtime account of k_gemm_nt_bf16_pers<{epi}> (hugs_debug_set_nt_cycles), "
+                               f"{int(t)} tiles of 256x256x{K}")
+  per_cycle(main, 35, W)
   M = max(fwd, key=lambda k: len(agg[k]))[1] if fwd else 131072      # rows of the NerfMLP level (131072 at cfg2)
   fl = 2.0 * M * W * W
   tnk = [k for k in agg if k[0] == 'tn' and k[1] == M and k[2] == W and k[3] == W]
@@ -114,64 +130,75 @@ def instep_roofline(train_step, state, next_batch, gen, thr, steps=5):
             entry(k, 'tn_dw', f"TN dW [1024x{M}]x[{M}x1024] {k[4]} (gemm_bf16::k_gemm_tn_bf16_big)", fl, 2.0 * M * W * 2 + W * W * 4) for k in tnk] + [
             entry(k, 'tn_dw_batch', f"TN dW of {k[2]} trunk items in one launch, {k[3]} reduction pieces per tile + the reduce "
                                     f"(gemm_bf16::k_gemm_tn_bf16_batch)", k[1], None) for k in tnb]
+  per_cycle(others[0], 16, W)
   shapes = {(f"{k[0]} M={k[1]} {k[2]}x{k[3]} {k[4]}" if k[0] != 'tnb' else f"tnb {k[4]} GFLOP={k[1] / 1e9:.1f}"): [len(v), round(float(np.mean(v)), 1)]
             for k, v in sorted(agg.items(), key=str)}
   return main, [o for o in others if o], shapes, state, gen
 
 
 def cpu_baseline(seed):
-  """Oracle (CPU restatement of the reference) full training step on a bounded sample: 64 rays of the same
-  workload (same nets, 64+128 samples), all host cores."""
+  """Oracle (CPU restatement of the reference) FULL training steps at the stated workload -- 1024 rays x (64 + 128) samples, the same
+  nets -- on the box's host cores (the reference's convention: train.py:162-165 times whole steps), >= 2 timed steps per thread
+  count tried; `small_sample` keeps rounds 1-5's 64-ray figure.  Budget ~40 s."""
   from oracle import torch_ref as R
   host = os.cpu_count()
   model_name = next((l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name')), 'unknown') \
       if os.path.exists('/proc/cpuinfo') else 'unknown'
+  try:      # physical cores: one thread per core is what a dense fp32 GEMM wants
+    smt = open('/sys/devices/system/cpu/smt/active').read().strip() == '1'
+  except OSError:
+    smt = False
+  phys = max(1, host // 2 if smt else host)
   cfg = R.kubric_cfg(num_levels=2, num_prop_samples=64, num_nerf_samples=128)
   params = R.init_params(cfg, seed)
-  n = 64
-  rng = np.random.default_rng(seed)
-  d = rng.normal(size=(n, 3)); d = d / np.linalg.norm(d, axis=-1, keepdims=True) * rng.uniform(0.8, 1.2, (n, 1))
   T = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.float32)))
-  rays = dict(origins=T(rng.normal(size=(n, 3)) * 0.5), directions=T(d), viewdirs=T(d / np.linalg.norm(d, axis=-1, keepdims=True)),
-              radii=T(rng.uniform(5e-4, 2e-3, (n, 1))), lossmult=T(np.ones((n, 1))), static_mask=T(np.ones((n, 1))),
-              near=T(np.full((n, 1), 0.1)), far=T(np.full((n, 1), 1.2)), embed_idx=torch.zeros(n, 1, dtype=torch.int32))
-  gt = T(rng.uniform(size=(n, 3)))
   leaves = {nme: v for nme, v in R.flat_leaves(params['params'])}
   m = {k: torch.zeros_like(v) for k, v in leaves.items()}
   v_ = {k: torch.zeros_like(v) for k, v in leaves.items()}
 
-  def step(i):
+  def make(n):
+    rng = np.random.default_rng(seed)
+    d = rng.normal(size=(n, 3)); d = d / np.linalg.norm(d, axis=-1, keepdims=True) * rng.uniform(0.8, 1.2, (n, 1))
+    rays = dict(origins=T(rng.normal(size=(n, 3)) * 0.5), directions=T(d), viewdirs=T(d / np.linalg.norm(d, axis=-1, keepdims=True)),
+                radii=T(rng.uniform(5e-4, 2e-3, (n, 1))), lossmult=T(np.ones((n, 1))), static_mask=T(np.ones((n, 1))),
+                near=T(np.full((n, 1), 0.1)), far=T(np.full((n, 1), 1.2)), embed_idx=torch.zeros(n, 1, dtype=torch.int32))
+    return rays, T(rng.uniform(size=(n, 3)))
+
+  kk = 0
+
+  def step(n, rays, gt):
+    nonlocal kk
     u01 = [torch.rand(n) for _ in range(2)]
     stats, grads, _, _ = R.loss_and_grad(cfg, params, rays, gt, 0.5, u01)
     g = R.clip_gradients(cfg, grads)
-    R.adam_update(cfg, leaves, g, m, v_, i)
+    R.adam_update(cfg, leaves, g, m, v_, kk)
+    kk += 1
 
-  # thread counts tried: HUGS_CPU_THREADS, or 16 and every core of the box (a 64-ray step does not always scale past 16
-  # threads); the best one is the baseline, `cores` = the threads it used, `host_cpu_count` = what the box has
-  # (a first run with all 256 hardware threads of the GPU box took 60 s per step -- 1 ray/s against 89 at 16 threads --: the second
-  #  candidate is capped at 64 and dropped after its warm-up step when that step is already 3x slower than the best one)
-  tries = [int(os.environ['HUGS_CPU_THREADS'])] if 'HUGS_CPU_THREADS' in os.environ else sorted({min(host, 16), min(host, 64)})
-  best, tried, kk = None, {}, 0
-  for ncores in tries:
+  def timed(n, ncores, budget, drop_after=None):
+    rays, gt = make(n)
     torch.set_num_threads(ncores)
-    t_w = time.time()
-    step(kk); kk += 1
-    t_w = time.time() - t_w
-    if best is not None and t_w > 3.0 * n / best[0]:
-      tried[str(ncores)] = f'dropped after a {t_w:.1f} s warm-up step'
-      continue
-    t0 = time.time()
-    k = 0
-    while time.time() - t0 < 12.0 / len(tries) or k < 2:
-      step(kk); kk += 1
-      k += 1
-    dt = (time.time() - t0) / k
-    tried[str(ncores)] = round(n / dt, 2)
-    if best is None or n / dt > best[0]:
-      best = (n / dt, ncores, k)
-  return {"value": round(best[0], 2), "unit": "rays/s", "cores": best[1], "host_cpu_count": host, "cpu_model": model_name, "kind": "port",
-          "rays_per_s_by_threads": tried,
-          "sample": f"{best[2]} full train steps of 64 rays x (64+128) samples, oracle/torch_ref.py fp32, {best[1]} threads"}
+    t_w = time.time(); step(n, rays, gt); t_w = time.time() - t_w      # warm-up (allocator, thread pool)
+    if drop_after is not None and t_w > drop_after:
+      return None, f'dropped after a {t_w:.1f} s warm-up step'
+    t0, k = time.time(), 0
+    while k < 2 or time.time() - t0 < budget:
+      step(n, rays, gt); k += 1
+    return n * k / (time.time() - t0), k
+
+  # rounds 1-5's sample: 64 rays, 16 threads (8192-row GEMMs: too small to occupy the box -- kept for continuity)
+  small, ks = timed(64, min(host, 16), 3.0)
+  # the stated workload: 1024 rays; thread counts tried: HUGS_CPU_THREADS, or 64 and the physical core count
+  tries = [int(os.environ['HUGS_CPU_THREADS'])] if 'HUGS_CPU_THREADS' in os.environ else sorted({min(phys, 64), min(phys, 128)})
+  best, tried = None, {}
+  for ncores in tries:
+    r, k = timed(1024, ncores, 10.0 / len(tries), drop_after=None if best is None else 3.0 * 1024 / best[0])
+    tried[str(ncores)] = k if r is None else round(r, 2)
+    if r is not None and (best is None or r > best[0]):
+      best = (r, ncores, k)
+  return {"value": round(best[0], 2), "unit": "rays/s", "cores": best[1], "host_cpu_count": host, "host_physical_cores": phys,
+          "cpu_model": model_name, "kind": "port", "rays_per_s_by_threads": tried,
+          "sample": f"{best[2]} full train steps of 1024 rays x (64+128) samples (the stated workload), oracle/torch_ref.py fp32, {best[1]} threads",
+          "small_sample": {"value": round(small, 2), "cores": min(host, 16), "sample": f"{ks} full train steps of 64 rays (the rounds 1-5 sample)"}}
 
 
 def eval_psnr_vs_oracle(model, state, batch, dtype, flat=None):
@@ -402,6 +429,10 @@ def main():
                   help='number of pre-generated synthetic batches (resident in HBM) cycled one per step, so that no batch is seen\n'
                        'twice inside a timed window of <= this many steps (VERDICT r4 item 1a: the old bench trained ~1300 steps on ONE\n'
                        'memorised batch; GEMM time depends on operand values).  The fixed-batch rate is reported beside it.')
+  ap.add_argument('--targets', default='scene', choices=['scene', 'random'],
+                  help='scene (default): the batch pool is drawn from an analytic scene (nerf_hugs_amd/internal/synthetic.py), so the network\n'
+                       'learns and train PSNR rises; random: independent random colours (the rounds 1-5 pool).  The other one is timed\n'
+                       'beside the headline as `random_targets` / `scene_targets`.')
   ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3', 'cfg4', 'cfg5', 'ref360'],
                   help='cfg2 = the headline workload; cfg3 (static masks, 4096 rays, GLO 48, charb) and cfg4 (RobustNeRF 0.8,\n'
                        'contract + reciprocal, GLO 4, 1024 rays/GPU) and cfg5 (nerfacto hash-grid path, 16384 rays/GPU,\n'
@@ -462,8 +493,16 @@ def main():
   config = configs.make_config(batch_size=rays_per_gpu * world)
   model, state, _, train_step, _ = train_utils.setup_model(config, 20200823, compute_dtype=args.dtype, device=device)
   theta_init = state.flat.clone()      # (for the eval-PSNR leg: the render of a network that has structure, see below)
-  def make_batch(i):
-    batch = synth_batch(rays_per_gpu // (P * P), P, 1000 + rank + 7919 * i, device)
+  from nerf_hugs_amd.internal import synthetic
+
+  def make_batch(i, targets=None):
+    # targets 'scene' (default): rays of pinhole cameras around an analytic textured sphere, colours a function of the ray -- the
+    # network LEARNS, so the GEMM operands (post-relu activations, gradients) are those of a network fitting a scene;
+    # 'random': directions / origins / colours drawn independently (rounds 1-5: the network collapses to the mean colour)
+    if (targets or args.targets) == 'scene':
+      batch = synthetic.scene_batch(np.random.default_rng(1000 + rank + 7919 * i), rays_per_gpu // (P * P), P, device)
+    else:
+      batch = synth_batch(rays_per_gpu // (P * P), P, 1000 + rank + 7919 * i, device)
     if args.config == 'ref360':     # 360.gin: near 0.2, far 1e6 (contracted space)
       batch.rays.near.fill_(0.2)
       batch.rays.far.fill_(1e6)
@@ -523,6 +562,26 @@ def main():
   dt = float(np.median(wins))
   loss = float(stats['loss'])
   psnr = float(stats['psnr'])
+  # the trunk's post-relu active fraction at this point of training: popcount of the 1-bit relu masks the forward NT GEMMs wrote
+  # (they are in HBM for the backward pass): the operand statistics the GEMM times below belong to
+  active = None
+  if rank == 0 and args.dtype == 'bf16':
+    try:
+      eng = model.engine(device)
+      lut = torch.tensor([bin(i).count('1') for i in range(256)], dtype=torch.int64, device=device)
+      fr = {}
+      for k_, t_ in eng.ws.bufs.items():
+        if torch.is_tensor(t_) and isinstance(k_, tuple) and isinstance(k_[0], str) and k_[0].startswith(f'NerfMLP_0/L{model.num_levels - 1}/bits'):
+          fr[k_[0].rsplit('/', 1)[1]] = round(float(lut[t_.view(torch.uint8).long()].sum()) / (t_.numel() * 32), 4)
+      if fr:
+        active = {"mean": round(float(np.mean(list(fr.values()))), 4), "per_layer": dict(sorted(fr.items()))}
+    except Exception as e:      # (a measurement beside the headline: never fails the bench)
+      active = {"error": repr(e)}
+  eval_psnr = eval_psnr_init = None
+  if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 'cfg2' and args.rays_per_gpu is None:
+    eval_psnr = eval_psnr_vs_oracle(model, state, batch, args.dtype)
+    # the same comparison at the INITIAL weights (he_uniform trunk), kept from round 5 for continuity
+    eval_psnr_init = eval_psnr_vs_oracle(model, state, batch, args.dtype, flat=theta_init)
   # the same windows on ONE fixed batch (what rounds 1-4 reported): a quarter of the timed budget
   fwins = [window(batch) for _ in range(max(3, nwin // 4))] if len(pool) > 1 else list(wins)
   dt_fixed = float(np.median(fwins))
@@ -553,13 +612,20 @@ def main():
     # after the timed region: a few more steps with the GEMM launches bracketed by HIP events (every rank runs them:
     # the steps contain the gradient all-reduce; rank 0 reports)
     roof, roof_others, roof_shapes, state, gen = instep_roofline(train_step, state, next_batch, gen, thr)
-  eval_psnr = eval_psnr_init = None
-  if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 'cfg2' and args.rays_per_gpu is None:
-    eval_psnr = eval_psnr_vs_oracle(model, state, batch, args.dtype)
-    # On a pool of fresh random-colour batches the trained network converges to the mean colour (loss -> 1/12): its render is a constant
-    # that both precisions produce exactly, and the number above says nothing about bf16.  The same comparison at the INITIAL weights
-    # (he_uniform trunk: densities and colours with structure) is the informative one.
-    eval_psnr_init = eval_psnr_vs_oracle(model, state, batch, args.dtype, flat=theta_init)
+  # LAST (it un-trains the network): the same windows on the OTHER target kind -- random colours when the headline pool is the scene
+  other = 'random' if args.targets == 'scene' else 'scene'
+  other_line = None
+  if len(pool) > 1:
+    pool_main, pool = pool, [make_batch(i, other) for i in range(min(len(pool), 32))]
+    for _ in range(args.warmup):
+      state, stats, gen = train_step(gen, state, next_batch(), 0.5, thr)
+    owins = [window() for _ in range(max(3, nwin // 4))]
+    dt_o = float(np.median(owins))
+    other_line = {"value": round(rays_per_gpu * world * args.steps / dt_o, 1), "ms_per_step": round(dt_o / args.steps * 1e3, 3),
+                  "windows": len(owins), "over_headline": round(dt_o / dt, 4), "train_psnr_last": round(float(stats['psnr']), 3),
+                  "loss_last": round(float(stats['loss']), 6),
+                  "note": f"{other} targets, {len(pool)} batches, timed after everything else on the same (already trained) network"}
+    pool = pool_main
   if rank == 0:
     rps = rays_per_gpu * world * args.steps / dt
     line = {
@@ -569,7 +635,11 @@ def main():
         "host_enqueue_ms_per_step": round(host_ms, 3), "step_graph": bool(getattr(train_step, 'graph_active', lambda: False)()),
         "value_min": round(rays_per_gpu * world * args.steps / max(wins), 1), "value_max": round(rays_per_gpu * world * args.steps / min(wins), 1),
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype,
-        "data": f"synthetic: {len(pool)} distinct pre-generated batches resident in HBM, one per step (no batch twice inside a window)",
+        "data": (f"synthetic: {len(pool)} distinct pre-generated batches resident in HBM, one per step (no batch twice inside a window); "
+                 + ("rays + colours of an analytic scene (textured sphere, cameras on a ring): the network learns" if args.targets == 'scene'
+                    else "independent random rays and colours")),
+        ("random_targets" if other == 'random' else "scene_targets"): other_line,
+        "trunk_relu_active_fraction": active,
         "fixed_batch": {"value": round(rays_per_gpu * world * args.steps / dt_fixed, 1), "ms_per_step": round(dt_fixed / args.steps * 1e3, 3),
                         "windows": len(fwins), "fresh_over_fixed": round(dt_fixed / dt, 4),
                         "note": "every step on pool[0] (the rounds 1-4 protocol), timed after the headline windows"},

@@ -489,6 +489,13 @@ int hugs_gemm_nt_tiles(int tile_mode, int dtype, int M, int N, int K1, int K2, c
                        const void* mask, int ld_mask, const float* r1_row, const float* r1_col, void* out, int ldc, void* stream);
 int hugs_gemm_tn_tiles(int tile_mode, int dtype, int Mrows, int Kc, int N, int nsplit, const void* X, int ldx, const void* G, int ldg,
                        float* dW, float* dbias, void* ws, void* stream);
+/* measurement hook of the persistent NT kernel (bench.py's measured roofline.per_cycle_frac; no reference counterpart: the reference's
+ * Dense layers, models.py:451-456, are XLA's): buf = 64 x 4 x 2 device uint64 words, zeroed by the caller, or NULL (default: off).
+ * While set, every persistent hugs_gemm_nt / hugs_gemm_nt_bits launch adds, per workgroup, {shader cycles from its first instruction
+ * to the retirement of its last K stage, tiles walked} to record (epilogue specialisation * 4 + K class) -- K class 0: K <= 256,
+ * 1: 512, 2: 1024, 3: other; specialisation = bit set {1 bias, 2 relu, 4 bf16 mask, 8 rank-1, 16 mask bits in, 32 mask bits out}.
+ * Process-global (a __device__ pointer of the bf16 instantiation); not stream-ordered: set it while the device is idle. */
+int hugs_debug_set_nt_cycles(void* buf);
 /* test hooks: the portable exp/log of the sampler and raw IEEE ops as the device executes them */
 int hugs_test_explog(const float* x, int n, float* y_exp, float* y_log, void* stream);
 int hugs_test_arith(const float* a, const float* b, int n, float* out4n, void* stream);

@@ -105,6 +105,7 @@ _PROTOS = {
     'hugs_amp_prepare': 'ipffps',
     'hugs_nf_adam_amp': 'qppppffffpps',
     'hugs_amp_update': 'ppifffs',
+    'hugs_debug_set_nt_cycles': 'p',
     'hugs_gemm_nt_tiles': 'i' 'iiiii' 'pipipi' 'pp' 'iii' 'pi' 'pp' 'pi' 's',
     'hugs_gemm_tn_tiles': 'i' 'iiiiipipippps',
 }

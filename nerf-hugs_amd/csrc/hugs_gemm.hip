@@ -607,6 +607,13 @@ __global__ __launch_bounds__(128 * WN, 2) void k_gemm_nt_bf16_big(
 //   * past the last tile the loader re-issues the final stages (valid addresses, dead ring slots) so that every
 //     iteration issues exactly one stage and the counted waits stay uniform.
 // ------------------------------------------------------------------------------------------------
+// In-launch cycle account (bench.py's measured `roofline.per_cycle_frac`, round 6): when hugs_debug_set_nt_cycles() has handed the
+// library a device buffer, thread 0 of every workgroup adds the shader cycles (s_memtime) between its first instruction and the
+// retirement of its last K stage, and the number of tiles it walked, to the record of its (epilogue specialisation, K class):
+// buf[(EPI * 4 + kclass) * 2 + {0, 1}], kclass = 0: K <= 256, 1: K = 512, 2: K = 1024, 3: anything else.  Two 64-bit atomics per
+// workgroup and launch; a null pointer (the default) costs one scalar load at the end of the kernel.
+__device__ unsigned long long* g_nt_cycles;
+
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
     int M, int N, int K1, int K2, const uint16_t* __restrict__ A1, int lda1, const uint16_t* __restrict__ A2, int lda2,
@@ -621,6 +628,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
   const int ns = (K1 + K2) >> 5;
   const int G = gridDim.x;
   const int nmine = (ntiles - (int)blockIdx.x + G - 1) / G;
+  const unsigned long long cyc_begin = __builtin_readcyclecounter();
 
   float* lds_bias = (float*)(lds + VEC_OFF);
   float* lds_r1 = (float*)(lds + VEC_OFF + 16384);
@@ -914,8 +922,18 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
 #undef GP_ITERH
 #undef GP_Q
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dead stages past the last tile must land before the LDS is released
+  if (tid == 0) {
+    unsigned long long* const cy = g_nt_cycles;
+    if (cy) {
+      const int kc = ns <= 8 ? 0 : ns == 16 ? 1 : ns == 32 ? 2 : 3;
+      unsigned long long* const rec = cy + ((EPI < 0 ? 63 : EPI) * 4 + kc) * 2;
+      atomicAdd(rec, __builtin_readcyclecounter() - cyc_begin);
+      atomicAdd(rec + 1, (unsigned long long)nmine);
+    }
+  }
 }
 
+#include "hugs_gemm_p64.inc"
 #include "hugs_gemm_chain.inc"
 
 // ------------------------------------------------------------------------------------------------
@@ -1561,6 +1579,12 @@ static int gemm_tn_impl(HUGS_TN_ARGS) {
                     : hugs_gemm_tn_impl_bf16(tile_mode, dtype, Mrows, Kc, N, nsplit, X, ldx, G, ldg, dW, dbias, ws, stream);
 }
 
+// measurement hook (include/hugs.h): buf = 64 x 4 x 2 device uint64 (4 KiB, zeroed by the caller) or NULL to switch the account off
+extern "C" int hugs_debug_set_nt_cycles(void* buf) {
+  HUGS_REQUIRE(hipMemcpyToSymbol(HIP_SYMBOL(gemm_bf16::g_nt_cycles), &buf, sizeof(buf)) == hipSuccess, -100, "hugs_debug_set_nt_cycles: hipMemcpyToSymbol");
+  return 0;
+}
+
 extern "C" int hugs_gemm_nt(int dtype, int M, int N, int K1, int K2, const void* A1, int lda1, const void* A2, int lda2,
                             const void* Bt, int ldb, const float* bias, const float* row_bias, int row_div, int ld_rb,
                             int relu, const void* mask, int ld_mask, const float* r1_row, const float* r1_col,
@@ -1669,6 +1693,28 @@ int HUGS_NT_IMPL(HUGS_NT_ARGS) {
     //  trunk's output gradient is a K = 128 product, 8192 tiles at the reference-default shape)
     if (ntiles > ncu && nstage % 2 == 0 && nstage >= 4 && N <= 4096 && tile_mode != 5 && pers_epi) {
       const dim3 gp(ncu), bp(512);
+      // round 6: K in 64-wide super-stages of whole cache lines (hugs_gemm_p64.inc) where the K split allows it and the K rotation of
+      // the two kernels coincides (K a multiple of 512): bit-identical results.  HUGS_NT_K64=0 keeps the 32-wide stages (A/B switch,
+      // read per call).
+      const char* k64_env = getenv("HUGS_NT_K64");
+      const bool k64 = !(k64_env && k64_env[0] == '0') && K1 % 64 == 0 && K2 % 64 == 0 && (K1 + K2) % 512 == 0;
+      if (k64) {
+#define HUGS_NTP_LAUNCH(EPI_) hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI_>), gp, bp, 0, (hipStream_t)stream, M, N, K1, K2, \
+                       (const uint16_t*)A1, lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E, ntiles)
+        switch (epi) {
+          case EPI_BIAS | EPI_RELU: HUGS_NTP_LAUNCH(EPI_BIAS | EPI_RELU); break;
+          case EPI_BIAS | EPI_RELU | EPI_BOUT: HUGS_NTP_LAUNCH(EPI_BIAS | EPI_RELU | EPI_BOUT); break;
+          case EPI_BIN: HUGS_NTP_LAUNCH(EPI_BIN); break;
+          case EPI_BIN | EPI_R1: HUGS_NTP_LAUNCH(EPI_BIN | EPI_R1); break;
+          case EPI_BIAS: HUGS_NTP_LAUNCH(EPI_BIAS); break;
+          case EPI_MASK: HUGS_NTP_LAUNCH(EPI_MASK); break;
+          case EPI_MASK | EPI_R1: HUGS_NTP_LAUNCH(EPI_MASK | EPI_R1); break;
+          default: HUGS_NTP_LAUNCH(0); break;      // epi == 0
+        }
+#undef HUGS_NTP_LAUNCH
+        HUGS_CHECK_LAUNCH("hugs_gemm_nt(persistent, K64)");
+        return 0;
+      }
 #define HUGS_NTP_LAUNCH(EPI_) hipLaunchKernelGGL((k_gemm_nt_bf16_pers<EPI_>), gp, bp, 0, (hipStream_t)stream, M, N, K1, K2, \
                        (const uint16_t*)A1, lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E, ntiles)
       switch (epi) {

@@ -1,0 +1,183 @@
+"""SURVEY 8(e) "semantics to preserve", under test without multi-GPU hardware: the reference normalises every
+loss PER DEVICE SHARD and only then pmeans gradients and stats (train_utils.py:457-459: per-shard value_and_grad -> pmean grads /
+stats -> clip -> Adam).  For the losses whose normaliser depends on the shard this is NOT the globally normalised loss:
+
+  * withmask  -- the denominator is the shard's own  sum(static_mask * lossmult)  (train_utils.py:88-112): with unequal mask counts
+    per shard the mean of per-shard-normalised losses differs from the full-batch loss;
+  * robustnerf -- every device takes the quantile of ITS patches' residuals (train_utils.py:251-319), the threshold that enters
+    the next step is the device MEAN of those quantiles (train.py:145-148 reads the pmean'ed stats), and the inlier masks of the next
+    step are made from it.
+
+Here: W ranks (gloo, all on cuda:0) run the product's data-parallel step; the expectation is the ORACLE evaluated shard by shard
+and averaged in the reference's order (per-shard loss_and_grad -> mean of gradients and stats -> clip -> Adam; for RobustNeRF two
+steps, the second with the mean of the first step's per-shard quantiles).  Also checked: the same batch through ONE process gives
+a different loss (the test would not notice a globally normalised implementation otherwise)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+BASE = ["Config.data_loss_type = 'mse'", "Config.distortion_loss_mult = 0.01", "Config.randomized = False",
+        "Model.opaque_background = True", "Model.num_levels = 2", "Model.num_prop_samples = 32", "Model.num_nerf_samples = 32",
+        "PropMLP.net_depth = 4", "PropMLP.net_width = 128", "PropMLP.disable_rgb = True", "NerfMLP.net_depth = 8",
+        "NerfMLP.net_width = 128"]
+WITHMASK = BASE + ["Config.patch_size = 8", "Config.transient_type = 'withmask'", "Model.num_glo_features = 4"]
+ROBUST = BASE + ["Config.patch_size = 16", "Config.transient_type = 'robustnerf'", "Config.robustnerf_inlier_quantile = 0.8",
+                 "Config.data_coarse_loss_mult = 0.1"]
+# BASELINE configs[3]'s gin (bench.GIN_CFG4: RobustNeRF 0.8, contract + reciprocal, GLO 4) at 4 ranks x 256 rays, narrow nets
+CFG4 = ["Config.patch_size = 16", "Config.data_loss_type = 'mse'", "Config.distortion_loss_mult = 0.001",
+        "Config.transient_type = 'robustnerf'", "Config.robustnerf_inlier_quantile = 0.8", "Model.raydist_fn = @jnp.reciprocal",
+        "Model.num_glo_features = 4", "NerfMLP.warp_fn = @coord.contract", "PropMLP.warp_fn = @coord.contract",
+        "Config.randomized = False", "Model.opaque_background = True", "Model.num_levels = 2", "Model.num_prop_samples = 64",
+        "Model.num_nerf_samples = 128", "PropMLP.net_depth = 4", "PropMLP.net_width = 128", "PropMLP.disable_rgb = True",
+        "NerfMLP.net_depth = 8", "NerfMLP.net_width = 128"]
+
+
+def _batch(n_patch, P, kind):
+  """The global batch: static masks whose density differs strongly between the shards (withmask), residual scales that differ
+  between the shards (robustnerf: the per-device quantiles then differ by construction)."""
+  from tests import hugs_testlib as H
+  far = 1e6 if kind == 'cfg4' else 1.2
+  near = (0.05, 0.3) if kind == 'cfg4' else 0.1
+  b = H.synth_rays(n_patch, P, 5, near=near, far=far, num_embed=16)
+  rng = np.random.default_rng(17)
+  if kind == 'withmask':
+    dens = np.linspace(0.95, 0.15, n_patch)[:, None, None, None]          # mask density falls from the first to the last patch
+    b.rays.static_mask.copy_(torch.from_numpy((rng.uniform(size=(n_patch, P, P, 1)) < dens).astype(np.float32)))
+  else:
+    # ground truth = a per-patch scale of random colours: the residual quantile of a shard follows its patches' scale
+    sc = torch.from_numpy(np.linspace(1.0, 0.2, n_patch).astype(np.float32))[:, None, None, None]
+    b.rgb.mul_(sc)
+  return b
+
+
+def _worker(rank, world, port, out_dir, gin, kind, n_patch, P, nsteps):
+  import sys
+  sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+  from nerf_hugs_amd.internal import configs, train_utils, parallel
+  torch.cuda.set_device(0)
+  if world > 1:
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+  train_utils._STEP_GRAPH = '0'
+  configs.clear_config()
+  configs.parse_config_files_and_bindings(None, gin)
+  config = configs.make_config()
+  model, state, _, train_step, _ = train_utils.setup_model(config, 3, compute_dtype='fp32', device=torch.device('cuda', 0))
+  batch = _batch(n_patch, P, kind)
+  if world > 1:
+    batch = parallel.shard_batch(batch, rank, world)
+  hist = []
+  eng = model.engine('cuda')
+  for i in range(nsteps):
+    before = state.flat.detach().cpu().clone()
+    state, stats, _ = train_step(None, state, batch, 0.4 + 0.01 * i, None)     # (thresholds: ones, then fed back on the device)
+    torch.cuda.synchronize()
+    # the gradient buffer after the step: the SUM over ranks (the 1 / world is folded into the clip / Adam kernels)
+    grad = eng.ws.get('grad', (model.layout.size + 64,))[:model.layout.size].detach().cpu() / world
+    rec = {'loss': float(stats['loss']), 'mses': np.asarray(stats['mses']).copy(), 'flat': state.flat.detach().cpu().clone(),
+           'before': before, 'grad': grad}
+    if 'robust_inlier_threshold' in stats:
+      rec['thr'] = np.asarray(stats['robust_inlier_threshold']).copy()
+      rec['mask'] = np.asarray(stats['robust_mask']).copy()
+    hist.append(rec)
+  torch.cuda.synchronize()
+  if rank == 0:
+    torch.save(hist, os.path.join(out_dir, f'w{world}.pt'))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+def _leaves_of(model, flat):
+  """oracle leaf dict {name: tensor} of a product parameter buffer"""
+  from oracle import torch_ref as R
+  tree = model.variables(flat)['params']
+  P = {m: ({k: {kk: vv.detach().cpu().clone() for kk, vv in v.items()} for k, v in sub.items()} if 'Embed' not in m
+           else {'embedding': sub['embedding'].detach().cpu().clone()}) for m, sub in tree.items()}
+  return P, {n: t for n, t in R.flat_leaves(P)}
+
+
+def _run(tmp_path, gin, kind, n_patch, P, world, nsteps):
+  """Step by step, from the PRODUCT's parameters before the step (Adam turns a last-bit gradient difference into lr x relative error of
+  the update where |g| ~ eps: a free-running oracle trajectory would be compared through that amplifier): the oracle evaluated shard
+  by shard, gradients and stats averaged in the reference's order; then clip + Adam on the product's own averaged gradient."""
+  from tests import hugs_testlib as H
+  from oracle import torch_ref as R
+  from nerf_hugs_amd.internal import parallel
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  mp.spawn(_worker, args=(world, port, str(tmp_path), gin, kind, n_patch, P, nsteps), nprocs=world, join=True)
+  mp.spawn(_worker, args=(1, port, str(tmp_path), gin, kind, n_patch, P, nsteps), nprocs=1, join=True)
+  got, one = torch.load(tmp_path / f'w{world}.pt', weights_only=False), torch.load(tmp_path / 'w1.pt', weights_only=False)
+  config, model, state, _, _, cfg, oparams = H.make_pair(gin)
+  batch = _batch(n_patch, P, kind)
+  L = model.num_levels
+  robust = cfg.transient_type == 'robustnerf'
+  thr = [torch.ones(1) for _ in range(L)]
+  m = v = None
+  for i in range(nsteps):
+    g = got[i]
+    tree, p = _leaves_of(model, g['before'])
+    names = list(p)
+    if m is None:
+      m, v = {n: torch.zeros_like(p[n]) for n in names}, {n: torch.zeros_like(p[n]) for n in names}
+    gsum, loss, mses, thr_new, msk = None, 0., 0., 0., 0.
+    for r in range(world):      # train_utils.py:404-459: value_and_grad on the device's shard, THEN pmean
+      sh = parallel.shard_batch(batch, r, world)
+      st, gr, _, _ = R.loss_and_grad(cfg, {'params': tree}, H.oracle_rays(sh), sh.rgb.reshape(-1, 3), 0.4 + 0.01 * i, None,
+                                     thr if robust else None)
+      gsum = gr if gsum is None else {n: gsum[n] + gr[n] for n in names}
+      loss += float(st['loss']) / world
+      mses = mses + st['mses'].detach().numpy() / world
+      if robust:
+        thr_new = thr_new + st['robust_inlier_threshold'].detach().numpy() / world
+        msk = msk + st['robust_mask'].detach().numpy() / world
+    assert abs(g['loss'] / loss - 1) < 1e-4, (i, g['loss'], loss)
+    np.testing.assert_allclose(g['mses'], mses, rtol=3e-4)
+    if robust:
+      np.testing.assert_allclose(g['thr'].reshape(-1), np.asarray(thr_new).reshape(-1), rtol=2e-4, atol=1e-6)   # device MEAN of the quantiles
+      np.testing.assert_allclose(g['mask'].reshape(-1), np.asarray(msk).reshape(-1), rtol=2e-4, atol=1e-6)
+      thr = [torch.tensor([float(np.asarray(thr_new).reshape(-1)[l])]) for l in range(L)]      # train.py:145-148: feeds the next step
+    gprod = {}
+    for lf in model.layout.leaves:
+      name = '/'.join(lf['path'])
+      gp = model.layout.view(g['grad'], lf['path'])
+      gprod[name] = gp.clone()
+      og = gsum[name] / world
+      sc = og.double().abs().max().clamp(min=1e-20)
+      e = ((gp.double() - og.double()).abs() / sc).flatten()
+      assert (e.numel() <= 8 or float(e.median()) < 3e-3) and float(e.max()) < 1e-1, \
+          f'step {i} grad {name}: rel err median {float(e.median()):.2e} max {float(e.max()):.2e} (max |g| {float(sc):.2e})'
+    # optimizer: the reference's clip + Adam on the averaged gradient (here: the product's) against the product's update
+    newp, m, v = R.adam_update(cfg, p, R.clip_gradients(cfg, gprod), m, v, i)
+    for lf in model.layout.leaves:
+      name = '/'.join(lf['path'])
+      d_prod = (model.layout.view(g['flat'], lf['path']) - model.layout.view(g['before'], lf['path'])).double()
+      d_orc = (newp[name] - p[name]).double()
+      assert float((d_prod - d_orc).abs().max()) <= 1e-4 * float(d_orc.abs().max()) + 3e-8, f'step {i} update {name}'
+  # and the sharded semantics are visible: ONE process on the whole batch normalises globally and reports a different loss
+  assert abs(one[0]['loss'] / got[0]['loss'] - 1) > 1e-3, (one[0]['loss'], got[0]['loss'])
+  if robust:
+    assert float(np.abs(one[0]['thr'] - got[0]['thr']).max()) > 1e-4      # quantile of the whole batch != mean of the shard quantiles
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_withmask_per_shard_normalisers(tmp_path, world):
+  """Unequal static-mask counts per shard: pmean of per-shard-normalised losses / gradients, not the global normalisation."""
+  _run(tmp_path, WITHMASK, 'withmask', 8, 8, world, 1)
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_robustnerf_per_device_quantile_and_threshold_feedback(tmp_path, world):
+  """Two steps: per-device quantiles, their device mean fed back as the next step's threshold, masks of step 2 made from it."""
+  _run(tmp_path, ROBUST, 'robust', 4, 16, world, 2)
+
+
+def test_cfg4_gin_four_ranks_256_rays_each(tmp_path):
+  """BASELINE configs[3]'s bindings (RobustNeRF 0.8, contract + reciprocal, GLO 4, 64 + 128 samples) as 4 ranks x 256 rays, two steps."""
+  _run(tmp_path, CFG4, 'cfg4', 4, 16, 4, 2)
