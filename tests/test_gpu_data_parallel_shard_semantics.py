@@ -161,9 +161,13 @@ def _run(tmp_path, gin, kind, n_patch, P, world, nsteps):
       d_orc = (newp[name] - p[name]).double()
       assert float((d_prod - d_orc).abs().max()) <= 1e-4 * float(d_orc.abs().max()) + 3e-8, f'step {i} update {name}'
   # and the sharded semantics are visible: ONE process on the whole batch normalises globally and reports a different loss
-  assert abs(one[0]['loss'] / got[0]['loss'] - 1) > 1e-3, (one[0]['loss'], got[0]['loss'])
   if robust:
+    # (step 0 runs with thresholds of one: every pixel an inlier, equal-size means -- the shard semantics show in the threshold
+    #  statistic of step 0 and, through it, in the masks and the loss of step 1)
     assert float(np.abs(one[0]['thr'] - got[0]['thr']).max()) > 1e-4      # quantile of the whole batch != mean of the shard quantiles
+    assert abs(one[-1]['loss'] / got[-1]['loss'] - 1) > 1e-4, (one[-1]['loss'], got[-1]['loss'])
+  else:
+    assert abs(one[0]['loss'] / got[0]['loss'] - 1) > 1e-3, (one[0]['loss'], got[0]['loss'])
 
 
 @pytest.mark.parametrize('world', [2, 4])
