@@ -67,6 +67,9 @@ struct GemmEpi {
 #else
 #define HUGS_TR(i)
 #define HUGS_TRP(i, k)
+#define HUGS_TRH(i, h)
+#define HUGS_TRH_DECL
+#define HUGS_TRH_END()
 #define HUGS_TR_ID()
 #define HUGS_STAGGER()
 #endif
@@ -934,6 +937,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
 }
 
 #include "hugs_gemm_p64.inc"
+#include "hugs_gemm_w4.inc"
 #include "hugs_gemm_chain.inc"
 
 // ------------------------------------------------------------------------------------------------
@@ -1698,6 +1702,26 @@ int HUGS_NT_IMPL(HUGS_NT_ARGS) {
       // read per call).
       const char* k64_env = getenv("HUGS_NT_K64");
       const bool k64 = !(k64_env && k64_env[0] == '0') && K1 % 64 == 0 && K2 % 64 == 0 && (K1 + K2) % 512 == 0;
+      // HUGS_NT_W4=1: the four-wave form of the same loop (one wave per SIMD, 128 x 128 per wave, hugs_gemm_w4.inc)
+      const char* w4_env = getenv("HUGS_NT_W4");
+      if (k64 && w4_env && w4_env[0] == '1') {
+        const dim3 bp4(256);
+#define HUGS_NTP_LAUNCH(EPI_) hipLaunchKernelGGL((k_gemm_nt_bf16_w4<EPI_>), gp, bp4, 0, (hipStream_t)stream, M, N, K1, K2, \
+                       (const uint16_t*)A1, lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E, ntiles)
+        switch (epi) {
+          case EPI_BIAS | EPI_RELU: HUGS_NTP_LAUNCH(EPI_BIAS | EPI_RELU); break;
+          case EPI_BIAS | EPI_RELU | EPI_BOUT: HUGS_NTP_LAUNCH(EPI_BIAS | EPI_RELU | EPI_BOUT); break;
+          case EPI_BIN: HUGS_NTP_LAUNCH(EPI_BIN); break;
+          case EPI_BIN | EPI_R1: HUGS_NTP_LAUNCH(EPI_BIN | EPI_R1); break;
+          case EPI_BIAS: HUGS_NTP_LAUNCH(EPI_BIAS); break;
+          case EPI_MASK: HUGS_NTP_LAUNCH(EPI_MASK); break;
+          case EPI_MASK | EPI_R1: HUGS_NTP_LAUNCH(EPI_MASK | EPI_R1); break;
+          default: HUGS_NTP_LAUNCH(0); break;      // epi == 0
+        }
+#undef HUGS_NTP_LAUNCH
+        HUGS_CHECK_LAUNCH("hugs_gemm_nt(persistent, K64, four waves)");
+        return 0;
+      }
       if (k64) {
 #define HUGS_NTP_LAUNCH(EPI_) hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI_>), gp, bp, 0, (hipStream_t)stream, M, N, K1, K2, \
                        (const uint16_t*)A1, lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E, ntiles)

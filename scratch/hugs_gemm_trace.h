@@ -20,3 +20,9 @@ extern "C" int hugs_debug_set_stagger(int groups, int iters) {
 #define HUGS_TRP(i, k) { if (g_nt_trace && threadIdx.x == 0 && (i) < 16) g_nt_trace[((size_t)blockIdx.x * 16 + (i)) * 4 + (k)] = __builtin_readcyclecounter(); }
 #define HUGS_TR_ID() { if (g_nt_trace && threadIdx.x == 0) { g_nt_trace[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg(63492); \
                                                              g_nt_trace[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg(63508); } }
+// per-half-iteration cycle sums of every tile (k_gemm_nt_bf16_p64), kept in registers (a stamp STORED per half sits in the vmcnt queue the
+// next barrier's vmcnt(0) waits for: it measured its own acknowledgement).  Stamp h marks the start of half h; sum[0] = H0 halves
+// (no barrier), sum[1] = H1 halves, both over super-stages 1 .. ns2-1 of all tiles; written once at the end of the kernel.
+#define HUGS_TRH_DECL unsigned long long trh_prev = 0, trh_sum0 = 0, trh_sum1 = 0;
+#define HUGS_TRH(i, h) { const unsigned long long n_ = __builtin_readcyclecounter(); if ((h) >= 3) { if ((h) & 1) trh_sum0 += n_ - trh_prev; else trh_sum1 += n_ - trh_prev; } trh_prev = n_; }
+#define HUGS_TRH_END() { if (g_nt_trace && threadIdx.x == 0) { g_nt_trace[256 * 16 * 4 + (size_t)blockIdx.x * 2] = trh_sum0; g_nt_trace[256 * 16 * 4 + (size_t)blockIdx.x * 2 + 1] = trh_sum1; } }

@@ -20,8 +20,9 @@ fwd = lambda: L.call('hugs_gemm_nt_bits', 1, M, N, K, 0, A, K, None, 0, Bt, K, b
 dx = lambda: L.call('hugs_gemm_nt_bits', 1, M, N, K, 0, G, K, None, 0, Bt, K, None, 0, None, None, o, N, None, bits)
 res = {}
 for rnd in range(6):
-  for mode in ('0', '1'):
-    os.environ['HUGS_NT_K64'] = mode
+  for mode in ('0', '1', 'w4'):
+    os.environ['HUGS_NT_K64'] = '0' if mode == '0' else '1'
+    os.environ['HUGS_NT_W4'] = '1' if mode == 'w4' else '0'
     for name, fn, epi in (('fwd', fwd, 35), ('dx', dx, 16)):
       for _ in range(3): fn()
       cyc.zero_(); torch.cuda.synchronize()

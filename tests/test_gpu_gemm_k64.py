@@ -17,19 +17,21 @@ def _L():
 
 
 def _both(fn):
-  """fn() under HUGS_NT_K64=0 and =1 (the library reads the switch per call); returns the two result lists."""
-  old = os.environ.get('HUGS_NT_K64')
+  """fn() under HUGS_NT_K64=0, =1 and =1 with HUGS_NT_W4=1 (the four-wave form; the library reads the switches per call); returns the
+  three result lists."""
+  old = {k: os.environ.get(k) for k in ('HUGS_NT_K64', 'HUGS_NT_W4')}
   out = []
   try:
-    for v in ('0', '1'):
-      os.environ['HUGS_NT_K64'] = v
+    for v, w in (('0', '0'), ('1', '0'), ('1', '1')):
+      os.environ['HUGS_NT_K64'], os.environ['HUGS_NT_W4'] = v, w
       out.append(fn())
       torch.cuda.synchronize()
   finally:
-    if old is None:
-      os.environ.pop('HUGS_NT_K64', None)
-    else:
-      os.environ['HUGS_NT_K64'] = old
+    for k, v in old.items():
+      if v is None:
+        os.environ.pop(k, None)
+      else:
+        os.environ[k] = v
   return out
 
 
@@ -64,10 +66,11 @@ def test_k64_kernel_bit_identical_to_k32_all_epilogues(shape):
       res.append(o)
     return res
 
-  a, b = _both(run)
-  for i, (x, y) in enumerate(zip(a, b)):
+  a, b, c = _both(run)
+  for i, (x, y, z) in enumerate(zip(a, b, c)):
     assert int((y != 0).sum()) > 0, i
     assert torch.equal(x, y), f'output {i} differs between the 32-wide and the 64-wide staging'
+    assert torch.equal(x, z), f'output {i} differs between the eight-wave and the four-wave kernel'
   A = torch.cat([A1, A2], 1) if K2 else A1
   rows = slice(0, 4096)
   ref = (A[rows].double() @ Bt.double().T + bias.double()).clamp(min=0)
