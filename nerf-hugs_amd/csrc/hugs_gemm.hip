@@ -1701,7 +1701,7 @@ int HUGS_NT_IMPL(HUGS_NT_ARGS) {
       // the two kernels coincides (K a multiple of 512): bit-identical results.  HUGS_NT_K64=0 keeps the 32-wide stages (A/B switch,
       // read per call).
       const char* k64_env = getenv("HUGS_NT_K64");
-      const bool k64 = !(k64_env && k64_env[0] == '0') && K1 % 64 == 0 && K2 % 64 == 0 && (K1 + K2) % 512 == 0;
+      const bool k64 = !(k64_env && k64_env[0] == '0') && K1 % 64 == 0 && K2 % 64 == 0 && (K1 + K2) % 512 == 0 && N <= 2048;      // (N: its arrival counter sits in the rank-1 vector's upper half)
       // HUGS_NT_W4=1: the four-wave form of the same loop (one wave per SIMD, 128 x 128 per wave, hugs_gemm_w4.inc)
       const char* w4_env = getenv("HUGS_NT_W4");
       if (k64 && w4_env && w4_env[0] == '1') {

@@ -131,10 +131,14 @@ def test_two_rank_step_equals_single_process_rccl(tmp_path):
   _compare(tmp_path, GIN, 'nccl')
 
 
-def test_bench_two_ranks_on_one_gpu_prints_the_contract_line():
+@pytest.mark.parametrize('form', ['captured', 'eager_bucketed'])
+def test_bench_two_ranks_on_one_gpu_prints_the_contract_line(form):
   """bench.py's N > 1 path end to end as the driver launches it (torch.distributed.run, one rank per process), two ranks on ONE
   GPU over gloo (HUGS_FORCE_DEVICE / HUGS_DIST_BACKEND test hooks): exactly one JSON line from rank 0 with the contract's keys,
-  whole-job rays/s, and -- round 5 -- the exposed all-reduce time next to it."""
+  whole-job rays/s, and the exposed all-reduce time next to it -- for BOTH forms of the data-parallel step (round 6): the captured
+  one (two hipGraphs around one all-reduce of the whole gradient buffer: the all-reduce never shares the chip with the persistent
+  one-workgroup-per-CU GEMMs) and the eager one (buckets issued under the backward pass), so that the first real SCALE run can be
+  read against either."""
   import json
   import os
   import socket
@@ -145,7 +149,8 @@ def test_bench_two_ranks_on_one_gpu_prints_the_contract_line():
   env = dict(os.environ, HUGS_FORCE_DEVICE='0', HUGS_DIST_BACKEND='gloo')
   out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
                         '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '3',
-                        '--min-time', '0', '--batch-pool', '4'], capture_output=True, text=True, env=env, timeout=600, cwd=root)
+                        '--min-time', '0', '--batch-pool', '4', '--step-graph', '1' if form == 'captured' else '0'],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=root)
   assert out.returncode == 0, out.stderr[-3000:]
   lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
   assert len(lines) == 1, out.stdout[-2000:]
@@ -156,4 +161,7 @@ def test_bench_two_ranks_on_one_gpu_prints_the_contract_line():
   assert d['n_gpus'] == 2 and d['steps'] == 4 and d['scaling'] == 'weak' and d['config']['global_batch'] == 2048
   assert abs(d['value'] - 2048 * 4 / (d['ms_per_step'] * 4 * 1e-3)) < 1e-3 * d['value']      # whole-job rays/s
   assert d['allreduce_exposed_ms_per_step'] is not None and d['allreduce_exposed_ms_per_step'] >= 0
+  assert d['step_graph'] == (form == 'captured')
+  assert ('two hipGraphs' in d['allreduce_form']) == (form == 'captured')
+  print(f"two ranks on one GPU over gloo, {form}: {d['ms_per_step']} ms/step, allreduce_exposed_ms_per_step {d['allreduce_exposed_ms_per_step']}")
   assert 'cpu_baseline' not in d      # rank 0 at N = 1 only
