@@ -937,7 +937,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
 }
 
 #include "hugs_gemm_p64.inc"
+// the four-wave form (one wave per SIMD, 128 x 128 per wave, accumulators in AGPRs): built, bit-identical, measured SLOWER (259 vs 241 us,
+// profiles/r06_nt_w4_ab.txt) and it spills 12-24 bytes per lane -- compiled only with -DHUGS_BUILD_W4 (scratch/build_variant.sh), then
+// selected by HUGS_NT_W4=1
+#ifdef HUGS_BUILD_W4
 #include "hugs_gemm_w4.inc"
+#endif
 #include "hugs_gemm_chain.inc"
 
 // ------------------------------------------------------------------------------------------------
@@ -1702,6 +1707,7 @@ int HUGS_NT_IMPL(HUGS_NT_ARGS) {
       // read per call).
       const char* k64_env = getenv("HUGS_NT_K64");
       const bool k64 = !(k64_env && k64_env[0] == '0') && K1 % 64 == 0 && K2 % 64 == 0 && (K1 + K2) % 512 == 0 && N <= 2048;      // (N: its arrival counter sits in the rank-1 vector's upper half)
+#ifdef HUGS_BUILD_W4
       // HUGS_NT_W4=1: the four-wave form of the same loop (one wave per SIMD, 128 x 128 per wave, hugs_gemm_w4.inc)
       const char* w4_env = getenv("HUGS_NT_W4");
       if (k64 && w4_env && w4_env[0] == '1') {
@@ -1722,6 +1728,7 @@ int HUGS_NT_IMPL(HUGS_NT_ARGS) {
         HUGS_CHECK_LAUNCH("hugs_gemm_nt(persistent, K64, four waves)");
         return 0;
       }
+#endif
       if (k64) {
 #define HUGS_NTP_LAUNCH(EPI_) hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI_>), gp, bp, 0, (hipStream_t)stream, M, N, K1, K2, \
                        (const uint16_t*)A1, lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E, ntiles)

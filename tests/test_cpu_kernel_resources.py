@@ -17,6 +17,7 @@ ALLOWED = {'k_dual_composite_bwd<16>'}
 
 # kernels the cfg2 (Mip-NeRF 360, bf16) and cfg5 (nerfacto, fp16) train steps launch, which must exist AND be spill-free
 STEP_KERNELS = [
+    'gemm_bf16::k_gemm_nt_bf16_p64<35>', 'gemm_bf16::k_gemm_nt_bf16_p64<16>', 'gemm_bf16::k_gemm_nt_bf16_p64<24>', 'gemm_bf16::k_gemm_nt_bf16_p64<1>',
     'gemm_bf16::k_gemm_nt_bf16_pers<35>', 'gemm_bf16::k_gemm_nt_bf16_pers<16>', 'gemm_bf16::k_gemm_nt_bf16_pers<24>',
     'gemm_bf16::k_gemm_nt_bf16_pers<1>', 'gemm_bf16::k_gemm_nt_bf16_pers<0>', 'gemm_bf16::k_gemm_nt_bf16_big<4, 35>',
     'gemm_bf16::k_gemm_nt_bf16_big<4, 16>', 'gemm_bf16::k_gemm_nt_bf16_big<4, 1>', 'gemm_bf16::k_gemm_nt_bf16_big<2, -1>',

@@ -17,8 +17,9 @@ def _L():
 
 
 def _both(fn):
-  """fn() under HUGS_NT_K64=0, =1 and =1 with HUGS_NT_W4=1 (the four-wave form; the library reads the switches per call); returns the
-  three result lists."""
+  """fn() under HUGS_NT_K64=0, =1 and =1 with HUGS_NT_W4=1 (the four-wave form: present only in a library built with -DHUGS_BUILD_W4 --
+  measured slower, profiles/r06_nt_w4_ab.txt; in the shipped library the third run repeats the second; the library reads the switches
+  per call); returns the three result lists."""
   old = {k: os.environ.get(k) for k in ('HUGS_NT_K64', 'HUGS_NT_W4')}
   out = []
   try:
