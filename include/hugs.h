@@ -360,6 +360,16 @@ int hugs_hashgrid_fwd(int n, int n_levels, int features, const long long* level_
 int hugs_hashgrid_bwd(int n, int n_levels, int features, const long long* level_offsets, const int* level_resolutions,
                       const float* level_scales, const float* x01, const void* d_out, int d_out_bf16, int row_pitch,
                       float* d_table_accum, void* stream);
+/* hugs_hashgrid_bwd with a caller-owned device workspace of hugs_hashgrid_bwd_ws_bytes(n, n_levels, features) bytes (0 when the form
+ * does not apply: features != 2): the levels behind the LDS-resident coarse ones are binned by table slot and summed per bin in LDS
+ * (count -> scan -> scatter into per-bin record runs -> one workgroup per bin), then added to the table with plain coalesced
+ * read-modify-writes, instead of one L2 float atomic per corner and feature -- the scatter sits at the chip's atomic-transaction rate
+ * (nerfacto.py:693-733 gets the same gradient from tiny-cuda-nn's atomics).  Same result up to fp32 summation order.  Falls back to the
+ * scatter when ws is NULL / too small, n < 65536, or a level has more than 2^20 entries. */
+long long hugs_hashgrid_bwd_ws_bytes(int n, int n_levels, int features);
+int hugs_hashgrid_bwd_ws(int n, int n_levels, int features, const long long* level_offsets, const int* level_resolutions,
+                         const float* level_scales, const float* x01, const void* d_out, int d_out_dtype, int row_pitch,
+                         float* d_table_accum, void* ws, long long ws_bytes, void* stream);
 int hugs_sh4_fwd(int n, const float* dirs01, int out_bf16, int row_pitch, int col0, void* out, void* stream);
 /* hugs_hashgrid_fwd with the table given as an IEEE-half copy (table_dtype 2; 0 = fp32): the fp16 mode, the reference's
  * `enable_amp: True` (nerfacto/configs/phototourism_nerfacto_base.yml:3; tiny-cuda-nn evaluates the grid on half

@@ -82,6 +82,7 @@ _PROTOS = {
     'hugs_nerfw_loss': 'iipppifpfppps',
     'hugs_hashgrid_fwd': 'iiippppp' 'iips',
     'hugs_hashgrid_bwd': 'iiippppp' 'iips',
+    'hugs_hashgrid_bwd_ws': 'iiippppp' 'iip' 'pq' 's',
     'hugs_hashgrid_fwd_t': 'iiippppp' 'iiips',
     'hugs_sh4_fwd': 'ipiiips',
     'hugs_hashgrid2d_fwd': 'iiippppp' 'piiips',
@@ -140,6 +141,7 @@ _PROFILED = {'hugs_gemm_nt': lambda a: ('nt', a[1], a[2], a[3] + a[4], 'mask' if
              'hugs_hashgrid_fwd': lambda a: ('hg_fwd', a[0], a[1], a[2]),
              'hugs_hashgrid_fwd_t': lambda a: ('hg_fwd', a[0], a[1], a[2]),
              'hugs_hashgrid_bwd': lambda a: ('hg_bwd', a[0], a[1], a[2]),
+             'hugs_hashgrid_bwd_ws': lambda a: ('hg_bwd', a[0], a[1], a[2]),
              'hugs_nf_prop_fwd': lambda a: ('prop_fwd', a[0], a[1], a[2]),
              'hugs_nf_prop_bwd': lambda a: ('prop_bwd', a[0], a[1], a[2]),
              # fused field networks: (kind, samples, geo features, appearance columns)
@@ -156,7 +158,7 @@ class _Lib:
           'There is no CPU fallback.')
     self.cdll = ctypes.CDLL(LIB_PATH)
     self.cdll.hugs_last_error.restype = ctypes.c_char_p
-    for n_ in ('hugs_raybias_bwd_ws_rows', 'hugs_gemm_tn_batch_ws_bytes', 'hugs_gemm_tn_ws_bytes', 'hugs_density_bwd_ws_bytes', 'hugs_rgb_bwd_ws_bytes', 'hugs_ssim_ws_bytes', 'hugs_gemm_nt_bits_bytes', 'hugs_nf_prop_ws_bytes'):
+    for n_ in ('hugs_raybias_bwd_ws_rows', 'hugs_gemm_tn_batch_ws_bytes', 'hugs_gemm_tn_ws_bytes', 'hugs_density_bwd_ws_bytes', 'hugs_rgb_bwd_ws_bytes', 'hugs_ssim_ws_bytes', 'hugs_gemm_nt_bits_bytes', 'hugs_nf_prop_ws_bytes', 'hugs_hashgrid_bwd_ws_bytes'):
       getattr(self.cdll, n_).restype = ctypes.c_longlong
     self.cdll.hugs_gemm_tn_batch_ws_bytes.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
     for name, sig in _PROTOS.items():

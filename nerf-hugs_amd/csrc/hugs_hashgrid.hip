@@ -403,6 +403,8 @@ k_hashgrid2d_bwd(int n, int L, HgLevels lv, const float* __restrict__ x, const v
   }
 }
 
+#include "hugs_hashgrid_binned.inc"
+
 int fill_levels(HgLevels& lv, int L, const long long* off, const int* res, const float* scale, const char* who) {
   HUGS_REQUIRE(L >= 1 && L <= HG_MAXL && off && res && scale, -2, "%s: %d levels (1..%d) / null level table", who, L, HG_MAXL);
   for (int l = 0; l <= L; ++l) {
@@ -462,9 +464,32 @@ static int hashgrid_fwd_impl(int n, int n_levels, int features, const long long*
   return 0;
 }
 
+static int hashgrid_bwd_impl(int n, int n_levels, int features, const long long* level_offsets, const int* level_resolutions,
+                             const float* level_scales, const float* x01, const void* d_out, int d_out_bf16, int row_pitch,
+                             float* d_table_accum, void* ws, long long ws_bytes, void* stream);
 extern "C" int hugs_hashgrid_bwd(int n, int n_levels, int features, const long long* level_offsets,
                                  const int* level_resolutions, const float* level_scales, const float* x01,
                                  const void* d_out, int d_out_bf16, int row_pitch, float* d_table_accum, void* stream) {
+  return hashgrid_bwd_impl(n, n_levels, features, level_offsets, level_resolutions, level_scales, x01, d_out, d_out_bf16, row_pitch,
+                           d_table_accum, nullptr, 0, stream);
+}
+/* The same with a caller-owned workspace (include/hugs.h): the levels behind the LDS-resident ones are then reduced by table slot
+ * (hugs_hashgrid_binned.inc) instead of scattered with L2 atomics.  Measured not faster (profiles/r06_cfg5_hashgrid_levels.txt): the
+ * Python layer calls it only under HUGS_HG_BINNED=1. */
+extern "C" long long hugs_hashgrid_bwd_ws_bytes(int n, int n_levels, int features) {
+  if (n <= 0 || n_levels <= 0 || features != 2) return 0;
+  return 3ll * HG_TB_MAX * 4 + 12ll * 8 * (long long)n * n_levels;
+}
+extern "C" int hugs_hashgrid_bwd_ws(int n, int n_levels, int features, const long long* level_offsets,
+                                    const int* level_resolutions, const float* level_scales, const float* x01,
+                                    const void* d_out, int d_out_bf16, int row_pitch, float* d_table_accum, void* ws, long long ws_bytes,
+                                    void* stream) {
+  return hashgrid_bwd_impl(n, n_levels, features, level_offsets, level_resolutions, level_scales, x01, d_out, d_out_bf16, row_pitch,
+                           d_table_accum, ws, ws_bytes, stream);
+}
+static int hashgrid_bwd_impl(int n, int n_levels, int features, const long long* level_offsets, const int* level_resolutions,
+                             const float* level_scales, const float* x01, const void* d_out, int d_out_bf16, int row_pitch,
+                             float* d_table_accum, void* ws, long long ws_bytes, void* stream) {
   HgLevels lv;
   int rc = fill_levels(lv, n_levels, level_offsets, level_resolutions, level_scales, "hugs_hashgrid_bwd");
   if (rc) return rc;
@@ -504,6 +529,41 @@ extern "C" int hugs_hashgrid_bwd(int n, int n_levels, int features, const long l
     ++l_begin;
   }
   if (l_begin >= n_levels) return 0;
+  // the remaining levels as a segmented reduction by table slot when the caller brought a workspace (F = 2, batches worth four launches)
+  if (ws && features == 2 && n >= 65536) {
+    HgBins bn;
+    uint32_t tb = 0;
+    bool fits = true;
+    for (int l = 0; l <= n_levels; ++l) {
+      bn.first[l] = tb;
+      if (l < n_levels && l >= l_begin) {
+        const uint32_t e = lv.off[l + 1] - lv.off[l], nb = (e + HG_BIN - 1) >> HG_BIN_LOG;
+        if (nb > HG_NB_MAX) fits = false;
+        tb += nb;
+      }
+    }
+    const long long nrec = 8ll * n * (n_levels - l_begin);
+    if (fits && tb <= HG_TB_MAX && 3ll * HG_TB_MAX * 4 + 12ll * nrec <= ws_bytes && nrec < (1ll << 32)) {
+      uint32_t* counts = (uint32_t*)ws;
+      uint32_t* base = counts + HG_TB_MAX;
+      uint32_t* cursor = base + HG_TB_MAX;
+      uint32_t* rec_slot = cursor + HG_TB_MAX;
+      float* rec_v0 = (float*)(rec_slot + nrec);
+      float* rec_v1 = rec_v0 + nrec;
+      HUGS_REQUIRE(hipMemsetAsync(counts, 0, HG_TB_MAX * sizeof(uint32_t), st) == hipSuccess, -100, "hugs_hashgrid_bwd_ws: hipMemsetAsync");
+      const dim3 gs((n + HG_SC_THREADS - 1) / HG_SC_THREADS), bs(HG_SC_THREADS);
+      if (d_out_bf16 == 0) k_hg_bin_count<0><<<gs, bs, 0, st>>>(n, n_levels, lv, bn, x01, d_out, row_pitch, l_begin, counts);
+      else if (d_out_bf16 == 1) k_hg_bin_count<1><<<gs, bs, 0, st>>>(n, n_levels, lv, bn, x01, d_out, row_pitch, l_begin, counts);
+      else k_hg_bin_count<2><<<gs, bs, 0, st>>>(n, n_levels, lv, bn, x01, d_out, row_pitch, l_begin, counts);
+      k_hg_bin_scan<<<1, 1024, 0, st>>>((int)tb, counts, base, cursor);
+      if (d_out_bf16 == 0) k_hg_bin_scatter<0><<<gs, bs, 0, st>>>(n, n_levels, lv, bn, x01, d_out, row_pitch, l_begin, cursor, rec_slot, rec_v0, rec_v1);
+      else if (d_out_bf16 == 1) k_hg_bin_scatter<1><<<gs, bs, 0, st>>>(n, n_levels, lv, bn, x01, d_out, row_pitch, l_begin, cursor, rec_slot, rec_v0, rec_v1);
+      else k_hg_bin_scatter<2><<<gs, bs, 0, st>>>(n, n_levels, lv, bn, x01, d_out, row_pitch, l_begin, cursor, rec_slot, rec_v0, rec_v1);
+      k_hg_bin_reduce<<<tb, 1024, 0, st>>>(n_levels, lv, bn, l_begin, counts, base, rec_slot, rec_v0, rec_v1, d_table_accum);
+      HUGS_CHECK_LAUNCH("hugs_hashgrid_bwd_ws(binned)");
+      return 0;
+    }
+  }
   if (features == 2) {
     HG_BY_DTYPE(d_out_bf16, k_hashgrid_bwd, 2, <<<g, b, 0, st>>>(n, n_levels, lv, x01, d_out, row_pitch, d_table_accum, l_begin));
   } else {

@@ -107,3 +107,38 @@ def test_hashgrid_backward_many_ray_ordered_samples(F):
   # level 0 alone (the LDS path) and the rest separately
   n0 = int(offs[1])
   assert np.abs(d_table.cpu().numpy()[:n0] - gw[:n0]).max() < 3e-4 * np.abs(gw[:n0]).max()
+
+
+def test_hashgrid_table_gradient_binned_equals_the_atomic_scatter():
+  """hugs_hashgrid_bwd_ws (round 6, csrc/hugs_hashgrid_binned.inc): the table gradient as a segmented reduction by table slot -- bins
+  of 16384 entries summed in LDS by one workgroup each -- gives the atomic scatter's gradient up to fp32 summation order.  (Measured not
+  faster, so the model calls it only under HUGS_HG_BINNED=1; the entry point, its fall-backs and its arithmetic stay under test.)
+  131 072 samples on a 6-level grid with dense and hashed levels, a third of the rows without gradient, fp32 and 16-bit gradient rows."""
+  from nerf_hugs_amd import _lib as L
+  dev = 'cuda'
+  g = torch.Generator(device=dev).manual_seed(3)
+  n, F = 131072, 2
+  res = [16, 24, 40, 64, 128, 256]
+  ent = [min((r + 1) ** 3, 1 << 17) for r in res]
+  ent = [(e + 7) // 8 * 8 for e in ent]
+  off = np.concatenate([[0], np.cumsum(ent)]).astype(np.int64)
+  resa = np.asarray(res, np.int32); sc = np.asarray([float(r) for r in res], np.float32)
+  x = torch.rand(n, 3, generator=g, device=dev)
+  for dt, tdt in ((0, torch.float32), (1, torch.bfloat16), (2, torch.float16)):
+    dX = torch.randn(n, len(res) * F, generator=g, device=dev)
+    dX[torch.rand(n, generator=g, device=dev) < 0.33] = 0
+    dX = dX.to(tdt).contiguous()
+    ta = torch.zeros(int(off[-1]) * F, device=dev); tb = torch.zeros_like(ta)
+    L.call('hugs_hashgrid_bwd', n, len(res), F, off.ctypes.data, resa.ctypes.data, sc.ctypes.data, x, dX, dt, dX.stride(0), ta)
+    nbytes = int(L.lib().cdll.hugs_hashgrid_bwd_ws_bytes(n, len(res), F))
+    assert nbytes == 3 * 1024 * 4 + 12 * 8 * n * len(res)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    L.call('hugs_hashgrid_bwd_ws', n, len(res), F, off.ctypes.data, resa.ctypes.data, sc.ctypes.data, x, dX, dt, dX.stride(0), tb, ws, nbytes)
+    torch.cuda.synchronize()
+    assert int((ta != 0).sum()) > 100000
+    assert torch.equal(ta != 0, tb != 0)
+    assert float((ta.double() - tb.double()).abs().max()) <= 2e-5 * float(ta.abs().max())
+    # a workspace that is too small falls back to the scatter (same numbers, nothing written out of bounds)
+    tc = torch.zeros_like(ta)
+    L.call('hugs_hashgrid_bwd_ws', n, len(res), F, off.ctypes.data, resa.ctypes.data, sc.ctypes.data, x, dX, dt, dX.stride(0), tc, ws, 4096)
+    assert float((ta.double() - tc.double()).abs().max()) <= 2e-5 * float(ta.abs().max())
