@@ -1700,8 +1700,13 @@ int HUGS_NT_IMPL(HUGS_NT_ARGS) {
     // (nstage >= 4: a tile of four stages is exactly one ring fill -- the next tile's stages are requested during this tile's four
     //  iterations and the first three waits see the same two younger stages + 16 stores as with longer tiles.  Round 4: the
     //  trunk's output gradient is a K = 128 product, 8192 tiles at the reference-default shape)
-    if (ntiles > ncu && nstage % 2 == 0 && nstage >= 4 && N <= 4096 && tile_mode != 5 && pers_epi) {
-      const dim3 gp(ncu), bp(512);
+    // round 6: grids of at most one tile per CU (the 128-ray step of the fixed-global-batch curve: 16 trunk launches of 256 tiles) also
+    // take the whole-line kernel, one tile per workgroup, instead of k_gemm_nt_bf16_big's 32-wide stages: 128 rays 1.166 / 1.170 ->
+    // 1.123 / 1.122 ms same box (HUGS_NT_P64_SMALL=0: the old selection)
+    const char* small_env = getenv("HUGS_NT_P64_SMALL");
+    const bool small_ok = !(small_env && small_env[0] == '0') && K1 % 64 == 0 && K2 % 64 == 0 && (K1 + K2) % 512 == 0 && N <= 2048;
+    if ((ntiles > ncu || small_ok) && nstage % 2 == 0 && nstage >= 4 && N <= 4096 && tile_mode != 5 && pers_epi) {
+      const dim3 gp(ntiles < ncu ? ntiles : ncu), bp(512);
       // round 6: K in 64-wide super-stages of whole cache lines (hugs_gemm_p64.inc) where the K split allows it and the K rotation of
       // the two kernels coincides (K a multiple of 512): bit-identical results.  HUGS_NT_K64=0 keeps the 32-wide stages (A/B switch,
       // read per call).
