@@ -61,7 +61,7 @@ def instep_roofline(train_step, state, next_batch, gen, thr, steps=5):
   events on the stream it is launched on (nerf_hugs_amd/_lib.py PROFILE hook; the side stream for the weight-gradient
   GEMMs).  `roofline` is the forward NerfMLP trunk layer [131072,1024]x[1024,1024]^T + bias + relu; the masked dX and
   the dW GEMM of the same shape are reported next to it.  `traffic` = HBM bytes per launch from the rocprofv3 PMC
-  passes of the shipped kernels, committed as profiles/r05_gemm_traffic.json (r04_... when absent; 2 x FETCH_SIZE + WRITE_SIZE,
+  passes of the shipped kernels, committed as profiles/r06_gemm_traffic.json (r05_... / r04_... when absent; 2 x FETCH_SIZE + WRITE_SIZE,
   MI355X_MICROARCH.md HBM section; `traffic_source` names the file and the kernel's duration under the profiler next to
   the in-step one), null when that file is absent."""
   from nerf_hugs_amd import _lib
@@ -83,7 +83,7 @@ def instep_roofline(train_step, state, next_batch, gen, thr, steps=5):
   for name, key, e0, e1 in recs:
     agg.setdefault(key, []).append(e0.elapsed_time(e1) * 1e3)     # us
   traffic = {}
-  tname = next((n for n in ('r05_gemm_traffic.json', 'r04_gemm_traffic.json') if os.path.exists(os.path.join(ROOT, 'profiles', n))), None)
+  tname = next((n for n in ('r06_gemm_traffic.json', 'r05_gemm_traffic.json', 'r04_gemm_traffic.json') if os.path.exists(os.path.join(ROOT, 'profiles', n))), None)
   if tname is not None:
     traffic = json.load(open(os.path.join(ROOT, 'profiles', tname)))
 
@@ -106,7 +106,7 @@ def instep_roofline(train_step, state, next_batch, gen, thr, steps=5):
   if fwd:
     k = max(fwd, key=lambda k: len(agg[k]))
     main = entry(k, 'nt_fwd', f"NT forward trunk [{k[1]}x1024]x[1024x1024]^T +bias +relu, writes 1-bit relu masks "
-                 "(gemm_bf16::k_gemm_nt_bf16_pers<35>)", 2.0 * k[1] * W * W, 2.0 * k[1] * W * 2 + W * W * 2 + k[1] * W / 8)
+                 "(gemm_bf16::k_gemm_nt_bf16_p64<35>; HUGS_NT_K64=0: k_gemm_nt_bf16_pers<35>)", 2.0 * k[1] * W * W, 2.0 * k[1] * W * 2 + W * W * 2 + k[1] * W / 8)
   def per_cycle(ent, epi, K):
     # what the fraction is made of, MEASURED by these very launches: cycles per 256 x 256 x K tile on a CU against the 4096 flop / cycle / CU
     # that 2.5 PFLOP/s at 2.4 GHz on 256 CUs means (workgroup start to its last stage's retirement, prologue included); the rest is the
@@ -125,7 +125,7 @@ def instep_roofline(train_step, state, next_batch, gen, thr, steps=5):
   fl = 2.0 * M * W * W
   tnk = [k for k in agg if k[0] == 'tn' and k[1] == M and k[2] == W and k[3] == W]
   tnb = [k for k in agg if k[0] == 'tnb' and k[1] > 4 * fl]      # the NerfMLP trunk's batched weight-gradient launches
-  others = [entry(('nt', M, W, W, 'mask'), 'nt_dx', f"NT dX [{M}x1024]x[1024x1024] *relu-mask bits (gemm_bf16::k_gemm_nt_bf16_pers<16>)", fl,
+  others = [entry(('nt', M, W, W, 'mask'), 'nt_dx', f"NT dX [{M}x1024]x[1024x1024] *relu-mask bits (gemm_bf16::k_gemm_nt_bf16_p64<16>)", fl,
                   2.0 * M * W * 2 + W * W * 2 + M * W / 8)] + [
             entry(k, 'tn_dw', f"TN dW [1024x{M}]x[{M}x1024] {k[4]} (gemm_bf16::k_gemm_tn_bf16_big)", fl, 2.0 * M * W * 2 + W * W * 4) for k in tnk] + [
             entry(k, 'tn_dw_batch', f"TN dW of {k[2]} trunk items in one launch, {k[3]} reduction pieces per tile + the reduce "

@@ -4,7 +4,8 @@ import json, sys, shutil
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 d = json.load(open(f'gpurun_out/pmc_{tag}.json'))
 def find(sub):
-  ks = [k for k in d if sub in k]
+  # round 6: the trunk shapes run k_gemm_nt_bf16_p64<EPI> (64-wide whole-line super-stages); 'pers<..>' patterns match it first
+  ks = [k for k in d if sub.replace('pers<', 'p64<') in k] or [k for k in d if sub in k]
   if len(ks) > 1:      # prefer the name that ENDS with the pattern (k_slab_reduce vs k_slab_reduce_batch)
     ks = [k for k in ks if k.rstrip().endswith(sub)] or ks
   assert len(ks) == 1, (sub, ks)
@@ -16,10 +17,10 @@ def hbm(e, extra=()):
           "mfma_busy_frac": round(e['SQ_VALU_MFMA_BUSY_CYCLES'] / (e['GRBM_GUI_ACTIVE'] / 8 * 1024), 4) if 'GRBM_GUI_ACTIVE' in e else None}
 red = dict(find('k_slab_reduce'), per=2)      # a TN call = the GEMM + two slab reductions (weights, bias)
 out = {
-  "nt_fwd": dict(hbm(find('pers<35>')), kernel='k_gemm_nt_bf16_pers<35>'),
-  "nt_dx": dict(hbm(find('pers<16>')), kernel='k_gemm_nt_bf16_pers<16>'),
-  "nt_fwd_nobits": dict(hbm(find('pers<3>')), kernel='k_gemm_nt_bf16_pers<3>'),
-  "nt_dx_bf16mask": dict(hbm(find('pers<4>')), kernel='k_gemm_nt_bf16_pers<4>'),
+  "nt_fwd": dict(hbm(find('pers<35>')), kernel='k_gemm_nt_bf16_p64<35> (pers<35> before round 6)'),
+  "nt_dx": dict(hbm(find('pers<16>')), kernel='k_gemm_nt_bf16_p64<16>'),
+  "nt_fwd_nobits": dict(hbm(find('pers<3>')), kernel='k_gemm_nt_bf16_p64<3>'),
+  "nt_dx_bf16mask": dict(hbm(find('pers<4>')), kernel='k_gemm_nt_bf16_p64<4>'),
   "tn_dw": dict(hbm(find('k_gemm_tn_bf16_big'), [red]), kernel='k_gemm_tn_bf16_big + 2 x k_slab_reduce'),
   **({"tn_dw_batch": dict(hbm(find('k_gemm_tn_bf16_batch'), [dict(find('k_slab_reduce_batch'), per=1)]),
                           kernel='k_gemm_tn_bf16_batch (9 items = 8.5 trunk layer-equivalents, 2 pieces per tile) + k_slab_reduce_batch',
