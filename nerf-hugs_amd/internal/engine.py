@@ -283,6 +283,17 @@ class Workspace:
   def __init__(self, device):
     self.device = device
     self.bufs = {}
+    self._ptr_keys = []
+
+  def put_table(self, key, value, keep=64):
+    """Host-side pointer tables keyed by buffer ADDRESSES (('mlp_tail', tag, theta.data_ptr(), M), ...): a function of addresses only,
+    read by the C entry point at call time and passed to the kernel by value -- safe to drop and rebuild.  Kept for the `keep` most
+    recent keys so that Model.apply on a stream of clones does not grow the dict without bound."""
+    self.bufs[key] = value
+    self._ptr_keys.append(key)
+    while len(self._ptr_keys) > keep:
+      self.bufs.pop(self._ptr_keys.pop(0), None)
+    return value
 
   def get(self, name, shape, dtype=torch.float32, zero=False):
     key = (name, tuple(shape), dtype)
@@ -353,6 +364,18 @@ class Engine:
         raw[i, 3:].view(np.int32)[:4] = (K, N, b0, nbx)
       tab = (theta.data_ptr(), torch.from_numpy(raw).to(self.device), len(rec), blk)
       self._cast_tables[theta.data_ptr()] = tab
+      # bounded: tables of train-state buffers (`owner`: their address may be baked into a captured step) stay for the life
+      # of the engine, those of other buffers (Model.apply on clones / loaded checkpoints) are kept for the 32 most recent addresses
+      if owner is None:
+        self._cast_lru = getattr(self, '_cast_lru', [])
+        self._cast_lru.append(theta.data_ptr())
+        while len(self._cast_lru) > 32:
+          old = self._cast_lru.pop(0)
+          if old not in getattr(self, '_cast_pinned', ()) and old != theta.data_ptr():
+            self._cast_tables.pop(old, None)
+    if owner is not None:
+      self._cast_pinned = getattr(self, '_cast_pinned', set())
+      self._cast_pinned.add(theta.data_ptr())
     _lib.call('hugs_cast_weights_batch', self.dt, tab[2], tab[1], tab[3])
     if _HEAD_FOLD:
       # P [Wp, H] = W_b [Wp, Bw] W_v[:Bw] [Bw, H]: the trunk's output gradient is (G_view W_v[:Bw]^T) W_b^T = G_view P^T, one
@@ -466,9 +489,9 @@ class Engine:
       tab = ws.bufs.get(key)
       if tab is None:      # host arrays of device pointers (a function of buffer addresses only)
         ptr = lambda ts: np.ascontiguousarray([0 if t is None else t.data_ptr() for t in ts], np.uint64)
-        tab = ws.bufs[key] = (ptr([self.wt[(spec.name, spec.layers[i]['name'], 'kernel')] for i in range(1, spec.net_depth)]),
-                              ptr([lay.view(theta, (spec.name, spec.layers[i]['name'], 'bias'), padded=True) for i in range(1, spec.net_depth)]),
-                              ptr(Ys[1:]), ptr(bits[1:]))
+        tab = ws.put_table(key, (ptr([self.wt[(spec.name, spec.layers[i]['name'], 'kernel')] for i in range(1, spec.net_depth)]),
+                                 ptr([lay.view(theta, (spec.name, spec.layers[i]['name'], 'bias'), padded=True) for i in range(1, spec.net_depth)]),
+                                 ptr(Ys[1:]), ptr(bits[1:])))
       _lib.call('hugs_mlp256_tail_fwd', dt, M, nl, Ys[0], tab[0].ctypes.data, tab[1].ctypes.data, tab[2].ctypes.data,
                 tab[3].ctypes.data, wd, bd, spec.density_bias, raw, density)
     else:
@@ -991,8 +1014,8 @@ class Engine:
         tab = ws.bufs.get(key)
         if tab is None:      # host arrays of device pointers (a function of buffer addresses only)
           ptr = lambda ts: np.ascontiguousarray([t.data_ptr() for t in ts], np.uint64)
-          tab = ws.bufs[key] = (ptr([self.wn[(spec.name, trunk[i]['name'], 'kernel')] for i in (1, 2, 3)]), ptr(bits_all),
-                                ptr([Gs[3], Gs[2], Gs[1], Gs[0]]))      # G_l of layer l lives in Gs[depth - 1 - l]
+          tab = ws.put_table(key, (ptr([self.wn[(spec.name, trunk[i]['name'], 'kernel')] for i in (1, 2, 3)]), ptr(bits_all),
+                                   ptr([Gs[3], Gs[2], Gs[1], Gs[0]])))      # G_l of layer l lives in Gs[depth - 1 - l]
         _lib.call('hugs_mlp256_tail_bwd', dt, M, 3, d_raw, wd, tab[0].ctypes.data, tab[1].ctypes.data, tab[2].ctypes.data)
       g_of, hi = {}, depth - 1
       done = []
