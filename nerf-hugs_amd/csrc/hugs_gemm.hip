@@ -266,9 +266,13 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {      // one 
   const bf16x2_t h = __builtin_convertvector(f, bf16x2_t);
   return *(const uint32_t*)&h;
 }
-template <int EPI, bool BIAS_IN_ACC = false, int FRESH_LANE = 0, int MASK_AHEAD = 2>
+// (after_row(i): called once row block i of the accumulators has been converted and its stores issued -- k_gemm_nt_bf16_p64 starts the
+//  NEXT tile's first MFMAs on that row block there, under the rest of the epilogue's vector work)
+struct NtNoRowFn { __device__ __forceinline__ void operator()(f32x4_t (&)[8][4], int) const {} };
+template <int EPI, bool BIAS_IN_ACC = false, int FRESH_LANE = 0, int MASK_AHEAD = 2, class RowFn = NtNoRowFn>
 __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const GemmEpi& E, int m0, int n0, int wm, int wn,
-                                                   int r16, int kb, const float* lds_bias, const float* lds_r1col) {
+                                                   int r16, int kb, const float* lds_bias, const float* lds_r1col,
+                                                   RowFn after_row = RowFn()) {
     // ---- epilogue straight from registers: bias / rank-1 / relu, v_cvt_pk_bf16_f32, one v_permlane16_swap pair
     // per two neighbouring 16-column fragments turns the 8-byte-per-lane MFMA layout into 16 contiguous bytes per
     // lane (64-byte runs per row): no LDS round trip, no barriers.
@@ -408,6 +412,7 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x4_t (&acc)[8][4], const G
           HUGS_EPI_STORE(v_, p_);
         }
       }
+      after_row(acc, i);
     }
 }
 
