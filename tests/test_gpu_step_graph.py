@@ -227,3 +227,30 @@ def test_mixed_sequence_graph_vs_eager():
   assert len(e[3]) == len(g[3])
   for i, (a, b) in enumerate(zip(e[3], g[3])):
     assert float((a.float() - b.float()).abs().max()) <= 2e-3 * max(1.0, float(a.float().abs().max())), i
+
+
+def test_captured_step_takes_a_key_that_lives_on_the_cpu():
+  """the replay path stages its inputs by raw address; a jax key restored on the CPU (a checkpointed rng, PRNGKey(seed,
+  device='cpu')) handed to a step that is already captured must be moved to the device first, not dereferenced as a host pointer.  The
+  step with the CPU copy of a key must give the result of the step with the device key."""
+  from tests import hugs_testlib as H
+  from nerf_hugs_amd.internal import train_utils, random as hr
+  old = train_utils._STEP_GRAPH
+  train_utils._STEP_GRAPH = '1'
+  try:
+    outs = []
+    for on_cpu in (False, True):
+      config, model, state, render_fn, train_step, cfg, oparams = H.make_pair(list(SMALL), compute_dtype='bf16')
+      batch = H.synth_rays(2, 8, 5)
+      key = hr.PRNGKey(7)
+      for i in range(4):      # two eager steps, the capture, one replay
+        state, stats, key = train_step(key, state, batch, 0.2, None)
+      assert train_step.graph_active()
+      fresh = hr.PRNGKey(99)
+      k_in = fresh.cpu() if on_cpu else fresh
+      state, stats, key = train_step(k_in, state, batch, 0.3, None)
+      torch.cuda.synchronize()
+      outs.append((state.flat.clone(), key.clone(), float(stats['loss'])))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1].cpu(), outs[1][1].cpu()) and outs[0][2] == outs[1][2]
+  finally:
+    train_utils._STEP_GRAPH = old
