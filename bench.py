@@ -93,7 +93,9 @@ def instep_roofline(train_step, state, next_batch, gen, thr, steps=5):
     us = float(np.mean(agg[key]))
     tf = flops / (us * 1e-6) / 1e12
     t = traffic.get(tkey, {})
-    return {"bound": "mfma", "kernel": label, "launches": len(agg[key]), "avg_us": round(us, 1), "achieved": round(tf, 1),
+    lo = float(np.min(agg[key]))      # the fastest launch of the profiled steps: the kernel when no side-stream kernel shares the chip with it
+    return {"bound": "mfma", "kernel": label, "launches": len(agg[key]), "avg_us": round(us, 1), "min_us": round(lo, 1),
+            "frac_at_min_us": round(flops / (lo * 1e-6) / PEAK_BF16, 4), "achieved": round(tf, 1),
             "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": round(tf * 1e12 / PEAK_BF16, 4),
             "traffic": t.get("hbm_bytes_per_launch"), "algorithmic_bytes": alg_bytes if alg_bytes is not None else t.get("algorithmic_bytes"),
             "traffic_source": (f"profiles/{tname}[{tkey}]: separate rocprofv3 --pmc passes, {t.get('avg_us_profiled')} us per launch "
