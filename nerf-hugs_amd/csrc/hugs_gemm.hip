@@ -1709,7 +1709,10 @@ int HUGS_NT_IMPL(HUGS_NT_ARGS) {
     // take the whole-line kernel, one tile per workgroup, instead of k_gemm_nt_bf16_big's 32-wide stages: 128 rays 1.166 / 1.170 ->
     // 1.123 / 1.122 ms same box (HUGS_NT_P64_SMALL=0: the old selection)
     const char* small_env = getenv("HUGS_NT_P64_SMALL");
-    const bool small_ok = !(small_env && small_env[0] == '0') && K1 % 64 == 0 && K2 % 64 == 0 && (K1 + K2) % 512 == 0 && N <= 2048;
+    const char* k64_env0 = getenv("HUGS_NT_K64");
+    // (only together with the whole-line kernel: k_gemm_nt_bf16_pers has never run on a grid of less than one tile per CU)
+    const bool small_ok = !(small_env && small_env[0] == '0') && !(k64_env0 && k64_env0[0] == '0') && K1 % 64 == 0 && K2 % 64 == 0 &&
+                          (K1 + K2) % 512 == 0 && N <= 2048;
     if ((ntiles > ncu || small_ok) && nstage % 2 == 0 && nstage >= 4 && N <= 4096 && tile_mode != 5 && pers_epi) {
       const dim3 gp(ntiles < ncu ? ntiles : ncu), bp(512);
       // round 6: K in 64-wide super-stages of whole cache lines (hugs_gemm_p64.inc) where the K split allows it and the K rotation of
