@@ -98,3 +98,42 @@ def test_k64_kernel_is_the_one_that_ran():
   c = cyc.cpu().reshape(64, 4, 2)
   assert int(c[35, 2, 1]) == (M // 256) * (N // 256) and int(c[35, 2, 0]) > 0
   assert int(c.sum()) == int(c[35, 2].sum())
+
+
+@pytest.mark.parametrize('M', [16384, 8192, 4096 + 256])
+def test_k64_kernel_on_grids_of_at_most_one_tile_per_cu(M):
+  """Round 6: grids of at most one 256 x 256 tile per CU (the 128-ray step's trunk layers: 256 tiles) run the whole-line kernel with one
+  tile per workgroup instead of k_gemm_nt_bf16_big (HUGS_NT_P64_SMALL=0).  The two differ in fp32 summation order (K rotation per row
+  band) and in nothing else: forward with mask bits and the dX form against each other and against float64."""
+  L = _L()
+  N, K = 1024, 1024
+  g = torch.Generator(device=dev).manual_seed(M)
+  A = torch.randn(M, K, device=dev, generator=g).clamp(min=0).bfloat16()
+  G = torch.randn(M, K, device=dev, generator=g).bfloat16()
+  Bt = (torch.randn(N, K, device=dev, generator=g) / K**0.5).bfloat16()
+  bias = torch.randn(N, device=dev, generator=g)
+  out = {}
+  old = os.environ.get('HUGS_NT_P64_SMALL')
+  try:
+    for mode in ('0', '1'):
+      os.environ['HUGS_NT_P64_SMALL'] = mode
+      y = torch.zeros(M, N, device=dev, dtype=torch.bfloat16); bits = torch.zeros(M * N // 32, dtype=torch.int32, device=dev)
+      o = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+      L.call('hugs_gemm_nt_bits', 1, M, N, K, 0, A, K, None, 0, Bt, K, bias, 1, None, None, y, N, bits, None)
+      L.call('hugs_gemm_nt_bits', 1, M, N, K, 0, G, K, None, 0, Bt, K, None, 0, None, None, o, N, None, bits)
+      torch.cuda.synchronize()
+      out[mode] = (y, bits, o)
+  finally:
+    if old is None:
+      os.environ.pop('HUGS_NT_P64_SMALL', None)
+    else:
+      os.environ['HUGS_NT_P64_SMALL'] = old
+  ref = (A.double() @ Bt.double().T + bias.double()).clamp(min=0)
+  for mode in ('0', '1'):
+    y, bits, o = out[mode]
+    assert float((y.double() - ref).abs().max()) < 2e-2 * max(1.0, float(ref.abs().max()))
+    refx = (G.double() @ Bt.double().T) * (y.double() > 0)
+    assert float((o.double() - refx).abs().max()) < 2e-2 * max(1.0, float(refx.abs().max()))
+  # one bf16 rounding apart at most, on a handful of entries (a different fp32 summation order in front of the rounding)
+  d = (out['0'][0].float() - out['1'][0].float()).abs()
+  assert float(d.max()) <= 2.0 ** -7 * float(out['0'][0].float().abs().max()) and float((d > 0).float().mean()) < 0.05
