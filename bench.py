@@ -262,6 +262,19 @@ def nerfacto_roofline(model, step_fn, N, steps=3):
   agg = {}
   for name, key, e0, e1 in recs:
     agg.setdefault(key, []).append(e0.elapsed_time(e1) * 1e3)
+  # the fraction of samples that carry a gradient into each grid (rows of d_out with any non-zero): one extra step with the table-gradient
+  # calls watched -- what the atomic scatter's work is proportional to (round 6: profiles/r06_cfg5_hashgrid_levels.txt)
+  live_frac = {}
+  orig_call = _lib.call
+  def spy(name, *a):
+    if name in ('hugs_hashgrid_bwd', 'hugs_hashgrid_bwd_ws'):
+      live_frac[(a[0], a[1], a[2])] = float((a[7].float().abs().sum(-1) != 0).float().mean())
+    return orig_call(name, *a)
+  _lib.call = spy
+  try:
+    step_fn(); torch.cuda.synchronize()
+  finally:
+    _lib.call = orig_call
   grids = {(g.n_levels, g.features): g for g in model.grids.values()}
   HBM = 8e12
 
@@ -297,6 +310,17 @@ def nerfacto_roofline(model, step_fn, N, steps=3):
         two_bounds(ent, us, by, 0.0, PEAK_BF16, "mfma")
         ent.update(atomic_updates=n * L_ * 8 * F, atomic_updates_per_s=round(n * L_ * 8 * F / (us * 1e-6) / 1e9, 1),
                    limiter="L2 float atomics (scratch/atomic_pair.hip: ~21 G distinct-address transactions/s on this chip)")
+        lf = live_frac.get((n, L_, F))
+        if lf is not None and F == 2:
+          # the roof this kernel actually sits under (round 6): an x-adjacent corner pair of 2 features = one 16-byte transaction when the
+          # pair is contiguous (dense levels always; hashed levels for even cx: every other cell), else two: 4 per sample on a dense
+          # level, 6 on average on a hashed one, for the samples that carry a gradient; chip rate 21 G/s for isolated addresses, 42 G/s for
+          # adjacent pairs (scratch/atomic_pair.hip).  Runs of lanes in one cell that the kernel merges in the wave lower the count at
+          # coarse levels; the estimate is an upper bound on the work and the fraction therefore a lower bound.
+          tr = n * lf * (4.0 * dense + 6.0 * (L_ - dense))
+          ent["atomic_roofline"] = {"live_sample_fraction": round(lf, 4), "transactions_est": round(tr), "achieved_G_per_s": round(tr / (us * 1e-6) / 1e9, 1),
+                                    "peak_G_per_s": [21.0, 42.0], "frac_of_42": round(tr / (us * 1e-6) / 42e9, 3),
+                                    "source": "profiles/r06_cfg5_hashgrid_levels.txt"}
     elif key[0] in ('field_fwd', 'field_bwd'):
       # csrc/hugs_fieldfuse.hip, per sample (16-bit operands): forward reads 32 hash features (64 B) and writes Y0, H0, H1 (3 x 512),
       # the head input (256), 2 x 32 B of mask bits, raw (2), density (4), rgb (12); backward reads G1 (512), the masks (64), raw /
