@@ -499,6 +499,16 @@ int hugs_gemm_nt_tiles(int tile_mode, int dtype, int M, int N, int K1, int K2, c
                        const void* mask, int ld_mask, const float* r1_row, const float* r1_col, void* out, int ldc, void* stream);
 int hugs_gemm_tn_tiles(int tile_mode, int dtype, int Mrows, int Kc, int N, int nsplit, const void* X, int ldx, const void* G, int ldg,
                        float* dW, float* dbias, void* ws, void* stream);
+/* Dynamic tile queues of the persistent NT launches (no reference counterpart: the reference's Dense layers, models.py:451-456, are
+ * XLA's).  Between hugs_gemm_nt_queue_begin and hugs_gemm_nt_queue_end every eligible hugs_gemm_nt / hugs_gemm_nt_bits launch (bf16 /
+ * fp16, the 64-wide whole-line kernel's shapes, at least two 256 x 256 tiles per CU) draws its tiles from per-XCD ticket counters in
+ * the next 32-byte slot of `region` instead of the static walk tile = workgroup + i x grid: a workgroup that gets its CU late (a
+ * kernel of another stream held it) computes fewer tiles and the launch ends when the tiles do.  Results are bit-identical.  _begin
+ * zeroes the region on `stream` (every launch that uses it must be ordered behind that point -- the train step calls it first thing, so
+ * a captured step re-zeroes its slots on every replay); `bytes` a multiple of 32, one slot per launch, launches beyond the region
+ * use the static walk.  Process-global sequence state; _end(0) closes the pair. */
+int hugs_gemm_nt_queue_begin(void* region, long long bytes, void* stream);
+int hugs_gemm_nt_queue_end(int reserved);
 /* measurement hook of the persistent NT kernel (bench.py's measured roofline.per_cycle_frac; no reference counterpart: the reference's
  * Dense layers, models.py:451-456, are XLA's): buf = 64 x 4 x 2 device uint64 words, zeroed by the caller, or NULL (default: off).
  * While set, every persistent hugs_gemm_nt / hugs_gemm_nt_bits launch adds, per workgroup, {shader cycles from its first instruction

@@ -107,6 +107,8 @@ _PROTOS = {
     'hugs_nf_adam_amp': 'qppppffffpps',
     'hugs_amp_update': 'ppifffs',
     'hugs_debug_set_nt_cycles': 'p',
+    'hugs_gemm_nt_queue_begin': 'pqs',
+    'hugs_gemm_nt_queue_end': 'i',
     'hugs_gemm_nt_tiles': 'i' 'iiiii' 'pipipi' 'pp' 'iii' 'pi' 'pp' 'pi' 's',
     'hugs_gemm_tn_tiles': 'i' 'iiiiipipippps',
 }

@@ -16,7 +16,7 @@ for f in hugs_*.hip; do
   [ "$f" = "hugs_gemm_f16.hip" ] && dep="hugs_gemm.hip"      # (it is hugs_gemm.hip compiled with half operands)
   o="_obj/${f%.hip}.o"
   inc=""
-  case "$f" in hugs_gemm.hip|hugs_gemm_f16.hip) inc="hugs_gemm_chain.inc hugs_gemm_p64.inc hugs_gemm_w4.inc";; hugs_hashgrid.hip) inc="hugs_hashgrid_binned.inc";; esac      # (textually included)
+  case "$f" in hugs_gemm.hip|hugs_gemm_f16.hip) inc="hugs_gemm_chain.inc hugs_gemm_p64.inc hugs_gemm_w4.inc hugs_gemm_dq.inc";; hugs_hashgrid.hip) inc="hugs_hashgrid_binned.inc";; esac      # (textually included)
   newer=0; for i_ in $inc; do [ "$i_" -nt "$o" ] && newer=1; done
   if [ ! -f "$o" ] || [ ! -f "${o%.o}.res" ] || [ "$f" -nt "$o" ] || [ "$dep" -nt "$o" ] || [ hugs_common.h -nt "$o" ] || [ build.sh -nt "$o" ] || [ $newer -eq 1 ]; then
     ( $HIPCC $FLAGS $extra -c "$f" -o "$o" 2> "${o%.o}.res" || { grep -v "remark:" "${o%.o}.res" >&2; rm -f "$o" "${o%.o}.res"; exit 1; } ) &

@@ -942,6 +942,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_nt_bf16_pers(
 }
 
 #include "hugs_gemm_p64.inc"
+#include "hugs_gemm_dq.inc"
 // the four-wave form (one wave per SIMD, 128 x 128 per wave, accumulators in AGPRs): built, bit-identical, measured SLOWER (259 vs 241 us,
 // profiles/r06_nt_w4_ab.txt) and it spills 12-24 bytes per lane -- compiled only with -DHUGS_BUILD_W4 (scratch/build_variant.sh), then
 // selected by HUGS_NT_W4=1
@@ -1593,6 +1594,27 @@ static int gemm_tn_impl(HUGS_TN_ARGS) {
                     : hugs_gemm_tn_impl_bf16(tile_mode, dtype, Mrows, Kc, N, nsplit, X, ldx, G, ldg, dW, dbias, ws, stream);
 }
 
+// Dynamic tile queues of the persistent NT launches (hugs_gemm_dq.inc): between hugs_gemm_nt_queue_begin and _end every eligible
+// hugs_gemm_nt / hugs_gemm_nt_bits launch takes the next 32-byte slot (8 counters, one per XCD) of the caller's region, which _begin
+// zeroes on the stream.  Process-global, like the launch sequence it numbers; outside a begin / end pair the static tile walk runs.
+static unsigned* g_ntq_base = nullptr;
+static int g_ntq_slots = 0, g_ntq_next = 0;
+unsigned* hugs_gemm_nt_queue_take() {
+  if (!g_ntq_base || g_ntq_next >= g_ntq_slots) return nullptr;
+  return g_ntq_base + 8 * (g_ntq_next++);
+}
+extern "C" int hugs_gemm_nt_queue_begin(void* region, long long bytes, void* stream) {
+  HUGS_REQUIRE(region && bytes >= 32 && bytes % 32 == 0, -2, "hugs_gemm_nt_queue_begin: region of %lld bytes (a multiple of 32)", bytes);
+  HUGS_REQUIRE(hipMemsetAsync(region, 0, (size_t)bytes, (hipStream_t)stream) == hipSuccess, -100, "hugs_gemm_nt_queue_begin: hipMemsetAsync");
+  g_ntq_base = (unsigned*)region; g_ntq_slots = (int)(bytes / 32); g_ntq_next = 0;
+  return 0;
+}
+extern "C" int hugs_gemm_nt_queue_end(int) {
+  const int used = g_ntq_next;
+  g_ntq_base = nullptr; g_ntq_slots = 0; g_ntq_next = 0;
+  return used < 0 ? 0 : 0;
+}
+
 // measurement hook (include/hugs.h): buf = 64 x 4 x 2 device uint64 (4 KiB, zeroed by the caller) or NULL to switch the account off
 extern "C" int hugs_debug_set_nt_cycles(void* buf) {
   HUGS_REQUIRE(hipMemcpyToSymbol(HIP_SYMBOL(gemm_bf16::g_nt_cycles), &buf, sizeof(buf)) == hipSuccess, -100, "hugs_debug_set_nt_cycles: hipMemcpyToSymbol");
@@ -1666,6 +1688,7 @@ extern "C" int hugs_gemm_nt_chain(int dtype, int M, int N, int nl, const unsigne
 }
 #endif  // !HUGS_GEMM_F16
 
+unsigned* hugs_gemm_nt_queue_take();      // (defined once, in the bf16 pass)
 int HUGS_NT_IMPL(HUGS_NT_ARGS) {
   HUGS_REQUIRE(dtype == HUGS_OP_DTYPE || (HUGS_OP_DTYPE == 1 && dtype == 0), -2, "hugs_gemm_nt: dtype must be 0 (fp32), 1 (bf16) or 2 (fp16)");
   const int bk = dtype ? GB_BK : 16 /* GF_BK */;
@@ -1742,6 +1765,29 @@ int HUGS_NT_IMPL(HUGS_NT_ARGS) {
         return 0;
       }
 #endif
+      // dynamic tile queue per XCD (hugs_gemm_dq.inc) inside a hugs_gemm_nt_queue_begin / _end pair: at least two tiles per workgroup,
+      // whole XCD groups, at least eight super-stages per tile (HUGS_NT_DYNQ=0: off)
+      const char* dq_env = getenv("HUGS_NT_DYNQ");
+      if (k64 && !(dq_env && dq_env[0] == '0') && ntiles >= 2 * ncu && ncu % 8 == 0 && (K1 + K2) >= 512) {
+        unsigned* const slot = hugs_gemm_nt_queue_take();
+        if (slot) {
+#define HUGS_NTP_LAUNCH(EPI_) hipLaunchKernelGGL((k_gemm_nt_bf16_dq<EPI_>), gp, bp, 0, (hipStream_t)stream, M, N, K1, K2, \
+                       (const uint16_t*)A1, lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E, ntiles, slot)
+          switch (epi) {
+            case EPI_BIAS | EPI_RELU: HUGS_NTP_LAUNCH(EPI_BIAS | EPI_RELU); break;
+            case EPI_BIAS | EPI_RELU | EPI_BOUT: HUGS_NTP_LAUNCH(EPI_BIAS | EPI_RELU | EPI_BOUT); break;
+            case EPI_BIN: HUGS_NTP_LAUNCH(EPI_BIN); break;
+            case EPI_BIN | EPI_R1: HUGS_NTP_LAUNCH(EPI_BIN | EPI_R1); break;
+            case EPI_BIAS: HUGS_NTP_LAUNCH(EPI_BIAS); break;
+            case EPI_MASK: HUGS_NTP_LAUNCH(EPI_MASK); break;
+            case EPI_MASK | EPI_R1: HUGS_NTP_LAUNCH(EPI_MASK | EPI_R1); break;
+            default: HUGS_NTP_LAUNCH(0); break;      // epi == 0
+          }
+#undef HUGS_NTP_LAUNCH
+          HUGS_CHECK_LAUNCH("hugs_gemm_nt(persistent, K64, tile queue)");
+          return 0;
+        }
+      }
       if (k64) {
 #define HUGS_NTP_LAUNCH(EPI_) hipLaunchKernelGGL((k_gemm_nt_bf16_p64<EPI_>), gp, bp, 0, (hipStream_t)stream, M, N, K1, K2, \
                        (const uint16_t*)A1, lda1, (const uint16_t*)A2, lda2, (const uint16_t*)Bt, ldb, E, ntiles)

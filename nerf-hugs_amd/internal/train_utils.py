@@ -144,6 +144,10 @@ def _summarize(layout, per_leaf, reduce, post=lambda x: x):
 
 
 _AR_BUCKETS = __import__('os').environ.get('HUGS_AR_BUCKETS', '1') != '0'
+# HUGS_NT_DYNQ=1: the step's persistent NT GEMMs draw their tiles from per-XCD ticket counters (csrc/hugs_gemm_dq.inc) instead of the
+# static walk.  Built in round 6 against the launches that share the chip with side-stream kernels; bit-identical; measured SLOWER
+# (5.934 / 5.942 vs 5.846 / 5.829 ms same box, and the dX launches' average-vs-fastest gap unchanged: profiles/r06_tile_queue_ab.txt) -- off
+_NT_DYNQ = __import__('os').environ.get('HUGS_NT_DYNQ', '0') == '1'
 # Replay of the train step as a captured hipGraph: '0' never, '1' whenever the step is capturable, 'auto' (default): one
 # process -- whenever capturable; data parallel -- when the per-GPU step is small enough to be host-bound (rays x samples per
 # step <= HUGS_STEP_GRAPH_ROWS: the graphs give up the overlap of the bucketed all-reduces with the backward pass)
@@ -419,6 +423,19 @@ def create_train_step(model, config, is_finetune=False):
     """The first part of the step: forward, losses, backward and -- when `reduce` -- the all-reduces of the gradient buffer
     (buckets issued underneath the backward pass + the rest).  dyn: None, or the device scalars of a captured step.  Returns
     the advanced rng."""
+    # round 6: the persistent NT GEMMs of the step draw their tiles from per-XCD ticket counters (csrc/hugs_gemm_dq.inc): one 32-byte
+    # slot per launch out of this buffer, zeroed first thing on the step's stream (inside a captured step: a memset node per replay)
+    eng0 = model.engine(state.flat.device)
+    if _NT_DYNQ and eng0.dt:
+      qbuf = eng0.ws.get('nt_tile_queues', (64 * 8,), torch.int32)
+      _lib.call('hugs_gemm_nt_queue_begin', qbuf, qbuf.numel() * 4)
+      try:
+        return _step_core(state, rays, gt, N, rng, train_frac, inlier_thresholds, dyn, reduce)
+      finally:
+        _lib.call('hugs_gemm_nt_queue_end', 0)
+    return _step_core(state, rays, gt, N, rng, train_frac, inlier_thresholds, dyn, reduce)
+
+  def _step_core(state, rays, gt, N, rng, train_frac, inlier_thresholds, dyn, reduce):
     eng = model.engine(state.flat.device)
     dev = state.flat.device
     ws = eng.ws
